@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""ORACLE tooling — generates tests/golden/*.npz.  Runs ONLY in the build container (needs
+/root/reference); nothing here runs on the GPU box.
+
+What it does:
+  * pre-populates sys.modules with inert ``torchvision`` placeholders and with ``norse`` modules
+    that resolve to oracle/norse_restated.py (Norse 0.0.7 is not vendored in the reference and not
+    installed here),
+  * imports the reference's own ``rpn`` and ``faster_rcnn`` modules from /root/reference,
+  * constructs ``RPNHeadSNN`` / ``FastRCNNPredictorSNNFull`` and executes THEIR ``forward`` bodies
+    unmodified (the spike-rate variants live in string literals at rpn.py:126-200 and
+    faster_rcnn.py:520-618 and are exec-ed verbatim from the reference text at run time),
+  * stores inputs, weights and outputs as small fixtures (tensors, not seeds),
+  * cross-checks the oracle restatement (oracle/snn_oracle.py) against those outputs bit-for-bit.
+
+The fixtures are DATA (inputs + expected outputs); no reference source text is stored.
+
+Usage:  python oracle/make_golden.py [--out tests/golden]
+"""
+import argparse
+import contextlib
+import io
+import os
+import sys
+import textwrap
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+
+from oracle import norse_restated as NR          # noqa: E402
+from oracle import snn_oracle as OR              # noqa: E402
+from oracle import fixtures as FX                # noqa: E402
+
+
+def _mod(name, **attrs):
+    m = types.ModuleType(name)
+    m.__file__ = os.path.join(HERE, "_shim_" + name.replace(".", "_") + ".py")
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    sys.modules[name] = m
+    parent, _, child = name.rpartition(".")
+    if parent:
+        setattr(sys.modules[parent], child, m)
+    return m
+
+
+class _Inert:
+    """placeholder for torchvision classes only named at import / class-creation time"""
+    def __init__(self, *a, **k):
+        pass
+
+
+def install_shims():
+    # ---- norse (4 symbols; reference imports at rpn.py:16-19, faster_rcnn.py:24-27) ----
+    _mod("norse")
+    _mod("norse.torch", LIFParameters=NR.LIFParameters, LICell=NR.LICell, LIFCell=NR.LIFCell)
+    _mod("norse.torch.module")
+    _mod("norse.torch.module.lif", LIFCell=NR.LIFCell)
+    _mod("norse.torch.functional")
+    _mod("norse.torch.functional.lif", lif_current_encoder=NR.lif_current_encoder,
+         LIFParameters=NR.LIFParameters)
+    # ---- torchvision placeholders (names touched at import time only) ----
+    _mod("torchvision")
+    _mod("torchvision.ops", MultiScaleRoIAlign=_Inert, roi_align=lambda *a, **k: None)
+    _mod("torchvision.ops.boxes")
+    _mod("torchvision.ops.misc", FrozenBatchNorm2d=_Inert, Conv2dNormActivation=_Inert)
+    _mod("torchvision.models")
+    _mod("torchvision.models.mobilenetv3", mobilenet_v3_large=lambda *a, **k: None)
+    _mod("torchvision.models.resnet", resnet50=lambda *a, **k: None)
+    _mod("torchvision.models.detection")
+    _mod("torchvision.models.detection._utils", BoxCoder=_Inert, Matcher=_Inert,
+         BalancedPositiveNegativeSampler=_Inert, overwrite_eps=lambda *a, **k: None)
+    _mod("torchvision.models.detection.anchor_utils", AnchorGenerator=_Inert)
+    _mod("torchvision.models.detection.image_list", ImageList=_Inert)
+    _mod("torchvision.models.detection.backbone_utils", _resnet_fpn_extractor=None,
+         _validate_trainable_layers=None, _mobilenet_extractor=None, resnet_fpn_backbone=None)
+    _mod("torchvision.models.detection.transform", GeneralizedRCNNTransform=_Inert)
+    _mod("torchvision._internally_replaced_utils", load_state_dict_from_url=None)
+    _mod("torchvision.utils", _log_api_usage_once=lambda *a, **k: None)
+    sys.modules["torchvision.ops"].boxes = sys.modules["torchvision.ops.boxes"]
+    sys.modules["torchvision.ops"].misc = sys.modules["torchvision.ops.misc"]
+
+
+def load_reference():
+    install_shims()
+    sys.path.insert(0, REF)
+    with contextlib.redirect_stdout(io.StringIO()):
+        import rpn as ref_rpn                      # noqa
+        import faster_rcnn as ref_frcnn            # noqa
+    return ref_rpn, ref_frcnn
+
+
+def _exec_literal_forward(path, first, last):
+    """exec the spike-rate ``forward`` kept as a string literal in the reference (text read from
+    /root/reference at run time, never stored)."""
+    with open(path) as f:
+        lines = f.readlines()[first - 1:last]
+    src = textwrap.dedent("".join(lines))
+    from typing import List, Tuple
+    from torch import Tensor
+    ns = {"torch": torch, "List": List, "Tuple": Tuple, "Tensor": Tensor,
+          "lif_current_encoder": NR.lif_current_encoder}
+    exec(src, ns)
+    return ns["forward"]
+
+
+def np_(t):
+    return t.detach().cpu().numpy()
+
+
+def gen_rpn(ref_rpn, name, spec, out):
+    C, A, T = spec["C"], spec["A"], spec["T"]
+    feats, w_shared, w_cls, w_bbox = FX.rpn_inputs(spec)
+    with contextlib.redirect_stdout(io.StringIO()):
+        head = ref_rpn.RPNHeadSNN(C, A, T)
+    sd = head.state_dict()
+    assert sorted(sd.keys()) == ["conv_bbox.weight", "conv_cls.weight", "shared_conv.weight"], sd.keys()
+    with torch.no_grad():
+        head.shared_conv.weight.copy_(w_shared)
+        head.conv_cls.weight.copy_(w_cls)
+        head.conv_bbox.weight.copy_(w_bbox)
+        logits, bbox = head(feats)                       # the reference's own forward, rpn.py:84-121
+        rate_fwd = _exec_literal_forward(os.path.join(REF, "rpn.py"), 126, 200)
+        l2, b2, rates = rate_fwd(head, feats)            # rpn.py:126-200 verbatim
+    # cross-check the oracle restatement bit-for-bit against the reference's own loop
+    o_l, o_b, o_r, o_tr = OR.rpn_head_forward(feats, w_shared, w_cls, w_bbox, T, trace=True,
+                                               spike_rates=True)
+    for a, b in zip(logits + bbox + list(rates), list(o_l) + list(o_b) + list(o_r)):
+        assert a.dtype == b.dtype and torch.equal(a, b), "oracle != reference loop (%s)" % name
+    for a, b in zip(l2 + b2, logits + bbox):
+        assert torch.equal(a, b)
+    d = {}
+    enc_rate, lif_rate = [], []
+    for l in range(len(feats)):
+        d["logits%d" % l] = np_(logits[l])
+        d["bbox%d" % l] = np_(bbox[l])
+        for j in range(3):
+            d["rate%d_%d" % (l, j)] = np_(rates[3 * l + j])
+        # per-step shared-LIF spikes (bit-packed) from the oracle trace == reference loop values
+        d["spk%d" % l] = np.packbits(np_(o_tr[l]["spk"]).astype(np.uint8), axis=None)
+        d["spk%d_shape" % l] = np.array(o_tr[l]["spk"].shape, dtype=np.int64)
+        enc_rate.append(float(o_tr[l]["z"].mean())); lif_rate.append(float(o_tr[l]["spk"].mean()))
+    np.savez_compressed(os.path.join(out, name + ".npz"), **d)
+    print("wrote %-20s enc rate %s  shared-LIF rate %s" % (name, np.round(enc_rate, 3), np.round(lif_rate, 3)))
+
+
+def gen_det(ref_frcnn, name, spec, out):
+    C, Hd, K, T = spec["C"], spec["Hd"], spec["K"], spec["T"]
+    oob = spec.get("only_one_bbox", False)
+    x, w6, w7, w_cls, w_bbox = FX.det_inputs(spec)
+    with contextlib.redirect_stdout(io.StringIO()):
+        head = ref_frcnn.FastRCNNPredictorSNNFull(C * 49, Hd, K, T, only_one_bbox=oob)
+    sd = head.state_dict()
+    assert sorted(sd.keys()) == ["bbox_pred.weight", "cls_score.weight", "fc6.weight", "fc7.weight"]
+    with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+        head.fc6.weight.copy_(w6); head.fc7.weight.copy_(w7)
+        head.cls_score.weight.copy_(w_cls); head.bbox_pred.weight.copy_(w_bbox)
+        cls, bbox = head(x)                              # faster_rcnn.py:470-516
+        rate_fwd = _exec_literal_forward(os.path.join(REF, "faster_rcnn.py"), 520, 618)
+        rates = rate_fwd(head, x)                        # faster_rcnn.py:520-618 verbatim
+    o_c, o_b, o_tr = OR.det_head_forward(x, w6, w7, w_cls, w_bbox, T, trace=True)
+    o_r = OR.det_head_forward(x, w6, w7, w_cls, w_bbox, T, spike_rates=True, only_one_bbox=oob)
+    for a, b in zip([cls, bbox] + list(rates), [o_c, o_b] + list(o_r)):
+        assert a.dtype == b.dtype and torch.equal(a, b), "oracle != reference loop (%s)" % name
+    d = {"cls": np_(cls), "bbox": np_(bbox),
+         "spk6": np.packbits(np_(o_tr["spk6"]).astype(np.uint8), axis=None),
+         "spk6_shape": np.array(o_tr["spk6"].shape, dtype=np.int64),
+         "spk7": np.packbits(np_(o_tr["spk7"]).astype(np.uint8), axis=None),
+         "spk7_shape": np.array(o_tr["spk7"].shape, dtype=np.int64)}
+    for j, r in enumerate(rates):
+        d["rate%d" % j] = np_(r)
+    np.savez_compressed(os.path.join(out, name + ".npz"), **d)
+    print("wrote %-20s enc %.3f spk6 %.3f spk7 %.3f" % (name, float(o_tr["z"].mean()),
+          float(o_tr["spk6"].mean()), float(o_tr["spk7"].mean())))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=FX.GOLDEN_DIR)
+    args = ap.parse_args()
+    os.makedirs(args.out, exist_ok=True)
+    torch.set_num_threads(8)
+    ref_rpn, ref_frcnn = load_reference()
+    for name, spec in FX.RPN_SPECS.items():
+        gen_rpn(ref_rpn, name, spec, args.out)
+    for name, spec in FX.DET_SPECS.items():
+        gen_det(ref_frcnn, name, spec, args.out)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,80 @@
+"""Known-answer tests pinning the oracle's neuron arithmetic.
+
+The reference has no tests and does not ship Norse 0.0.7; these sequences are the pins:
+the LIF membrane sequence is the one of upstream Norse's test_lif_feed_forward_step."""
+import numpy as np
+import torch
+
+from oracle import norse_restated as NR
+
+
+def test_lif_feed_forward_step_upstream_sequence():
+    # v_th = 1 (default), constant input 1.0
+    cell = NR.LIFCell()
+    state = None
+    x = torch.ones(1)
+    vs = []
+    for _ in range(10):
+        z, state = cell(x, state)
+        vs.append(float(state.v))
+    expect = [0.0, 0.1, 0.27, 0.487, 0.7335, 0.9963, 0.0, 0.3951, 0.7717, 0.0]
+    np.testing.assert_allclose(vs, expect, atol=1e-4)
+
+
+def test_lif_theta_0p1_const_input():
+    cell = NR.LIFCell(p=NR.LIFParameters(alpha=100, v_th=torch.tensor(0.1)), dt=0.001)
+    state = None
+    out = []
+    for _ in range(4):
+        z, state = cell(torch.ones(1), state)
+        out.append((float(z), float(state.v), float(state.i)))
+    expect = [(0, 0, 1), (0, 0.1, 1.8), (1, 0, 2.44), (1, 0, 2.952)]
+    np.testing.assert_allclose(np.array(out), np.array(expect, dtype=np.float64), atol=1e-6)
+
+
+def test_encoder_x1_pattern_and_subthreshold():
+    p = NR.LIFParameters(v_th=torch.tensor(0.25))
+    v = torch.zeros(1)
+    zs, vs = [], []
+    for _ in range(9):
+        z, v = NR.lif_current_encoder(torch.ones(1), v, p, 0.001)
+        zs.append(int(z)); vs.append(float(v))
+    assert zs == [0, 0, 1, 0, 0, 1, 0, 0, 1]
+    np.testing.assert_allclose(vs[:3], [0.1, 0.19, 0.0], atol=1e-7)
+    for x in (0.25, 0.26, 0.3):
+        v = torch.zeros(1)
+        for _ in range(16):
+            z, v = NR.lif_current_encoder(torch.full((1,), x), v, p, 0.001)
+            assert float(z) == 0.0
+
+
+def test_encoder_first_spike_thresholds():
+    # closed form between resets: v_t = x (1 - 0.9^t); spike within T steps iff x(1-0.9^T) > 0.25
+    p = NR.LIFParameters(v_th=torch.tensor(0.25))
+    for T, xmin in ((8, 0.25 / (1 - 0.9 ** 8)), (12, 0.25 / (1 - 0.9 ** 12))):
+        for x, should in ((xmin * 1.001, True), (xmin * 0.999, False)):
+            v = torch.zeros(1); fired = False
+            for _ in range(T):
+                z, v = NR.lif_current_encoder(torch.full((1,), x), v, p, 0.001)
+                fired |= bool(z)
+            assert fired == should
+
+
+def test_li_both_orders():
+    for order, expect in (("jump_first", [0.1, 0.27, 0.487, 0.7335, 0.99631]),
+                          ("voltage_first", [0.0, 0.1, 0.27, 0.487, 0.7335])):
+        state = NR.LIState(torch.zeros(1), torch.zeros(1))
+        vs = []
+        for _ in range(5):
+            v, state = NR.li_feed_forward_step(torch.ones(1), state, li_order=order)
+            vs.append(float(v))
+        np.testing.assert_allclose(vs, expect, atol=1e-5)
+
+
+def test_constants_are_fp32_products():
+    # dt * tau_mem_inv and dt * tau_syn_inv as the 0-dim fp32 products the oracle evaluates
+    p = NR.LIFParameters()
+    a = 0.001 * p.tau_mem_inv
+    b = 0.001 * p.tau_syn_inv
+    assert a.dtype == torch.float32 and b.dtype == torch.float32
+    assert float(a) == float(np.float32(0.1)) and float(b) == float(np.float32(0.2))

@@ -1,0 +1,141 @@
+/*
+ * snn_hip.h — C ABI of libsnnhip.so: the spiking RPN head + spiking RoI (detector) head forward
+ * path of aitor-martinez-seras/SNN-Automotive-Object-Detection as hand-written gfx950 (MI355X)
+ * HIP kernels.
+ *
+ * The reference has no FFI of its own (it is pure Python on torch + Norse); the entry points below
+ * are what a binding for this path calls instead of the reference's Python loops:
+ *
+ *   snn_rpn_head_forward   replaces  RPNHeadSNN.forward                    rpn.py:84-121
+ *                          (+ the spike-rate variant kept as a string literal, rpn.py:126-200)
+ *   snn_det_head_forward   replaces  FastRCNNPredictorSNNFull.forward      faster_rcnn.py:470-516
+ *                          (+ the spike-rate variant, faster_rcnn.py:520-618)
+ *   snn_pack_*             one-off re-layout of the reference's state_dict tensors
+ *                          (shared_conv/conv_cls/conv_bbox, rpn.py:64-75; fc6/fc7/cls_score/bbox_pred,
+ *                          faster_rcnn.py:447-467) into the MFMA fragment-major layout the kernels read
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless it says "host"; the caller owns every buffer; the
+ *     library allocates nothing persistent and frees nothing of the caller's;
+ *   - all work is enqueued on the stream passed in; no internal synchronisation, no default-stream
+ *     use, no host<->device copies: every call is hipGraph-capturable;
+ *   - return value 0 = success, negative = error (message via snn_last_error(), thread-local);
+ *     no exceptions cross the ABI and the library never aborts;
+ *   - re-entrant: no global mutable state besides the thread-local error string.
+ *
+ * Spike tensors never exist as fp32.  A spike train is a set of BIT-PLANES
+ *     plane[t][row][w]   (uint32, bit b of word w = spike of channel 32*w+b at time step t)
+ * rows are spatial positions (RPN: level-major, then n, y, x) or RoIs (detector).
+ */
+#ifndef SNN_HIP_H
+#define SNN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* snn_stream_t;   /* == hipStream_t */
+
+#define SNN_MAX_LEVELS 8
+#define SNN_MAX_STEPS 32
+
+/* Neuron constants.  The fp32 products are formed by the caller exactly as Norse forms them
+ * (0-dim fp32 tensor arithmetic: dt * tau_mem_inv, -dt * tau_syn_inv) so that the element-wise
+ * arithmetic is bit-identical to the reference's (norse lif.py / leaky_integrator.py; reference
+ * call sites rpn.py:58,67,101,106,111,115, faster_rcnn.py:444-456,494-510). */
+typedef struct snn_params {
+    float dt_tau_mem;      /* fl32(dt * tau_mem_inv)   = 0.1f for the reference (dt=0.001, 1/1e-2) */
+    float neg_dt_tau_syn;  /* fl32(-dt * tau_syn_inv)  = -0.2f                  (1/5e-3)           */
+    float v_leak;          /* 0 */
+    float v_reset;         /* 0 */
+    float v_th_enc;        /* 0.25  encoder threshold (rpn.py:58, faster_rcnn.py:444) */
+    float v_th_lif;        /* 0.1   hidden LIF threshold (rpn.py:67, faster_rcnn.py:449,452) */
+    int32_t li_order;      /* 0 = jump-first (upstream li_feed_forward_step), 1 = voltage-first */
+    int32_t reserved;
+} snn_params;
+
+typedef struct snn_rpn_level {
+    const float* feat;     /* [N][C][H][W] fp32, NCHW contiguous (what the FPN hands over) */
+    int32_t N, H, W;
+    int32_t reserved;
+} snn_rpn_level;
+
+int snn_version(void);
+const char* snn_last_error(void);
+
+/* ---- weight packing (call when the weights change; results are plain device buffers) ---------- */
+/* number of floats of a packed GEMM operand with K reduction rows and N output columns */
+size_t snn_packed_gemm_elems(int K_chunks32, int N);
+/* shared_conv.weight [C_out][C_in][3][3] -> packed, reduction index k = tap*Cp + ci (Cp = C_in
+ * rounded up to 32) */
+size_t snn_packed_conv3x3_elems(int C_out, int C_in);
+int snn_pack_conv3x3_weight(const float* w_oihw, int C_out, int C_in, float* packed, snn_stream_t s);
+/* nn.Linear weight [N][K] -> packed */
+size_t snn_packed_linear_elems(int N, int K);
+int snn_pack_linear_weight(const float* w_nk, int N, int K, float* packed, snn_stream_t s);
+/* the two leaky-integrator heads (cls then bbox) [NA][K] and [NB][K] -> transposed [Kp][NOp],
+ * NOp = (NA+NB) rounded up to 16, Kp = K rounded up to 32 */
+size_t snn_packed_heads_elems(int NA, int NB, int K);
+int snn_pack_heads_weight(const float* w_a, int NA, const float* w_b, int NB, int K, float* packed,
+                          snn_stream_t s);
+
+/* ---- RPN head ------------------------------------------------------------------------------- */
+/* P = sum over levels of N*H*W.  Outputs are position-major ("NHWC"): out_logits[P][A],
+ * out_bbox[P][4A]; level l starts at row sum_{j<l} N_j*H_j*W_j and is [N][H][W][A] inside.
+ * Optional (nullable) spike-rate outputs of the rpn.py:126-200 variant:
+ *   spike_counts[n_levels][max_N] (uint64)  number of shared-LIF spikes per level and image,
+ *   sum_logits[P][A], sum_bbox[P][4A]        sum over the T steps of the LI membranes.          */
+size_t snn_rpn_head_workspace_bytes(const snn_rpn_level* levels_host, int n_levels, int C, int A, int T);
+int snn_rpn_head_forward(const snn_rpn_level* levels_host, int n_levels, int C, int A, int T,
+                         const snn_params* p_host,
+                         const float* w_shared_packed, const float* w_heads_packed,
+                         float* out_logits, float* out_bbox,
+                         unsigned long long* spike_counts, float* sum_logits, float* sum_bbox,
+                         void* workspace, size_t workspace_bytes, snn_stream_t stream);
+
+/* ---- detector (RoI) head -------------------------------------------------------------------- */
+/* x[R][D] (the flattened [R][C][7][7] RoI features, faster_rcnn.py:473); out_cls[R][K],
+ * out_bbox[R][K4].  Optional spike-rate outputs of the faster_rcnn.py:520-618 variant:
+ *   spk6_count[R], spk7_count[R] (uint32)  spikes per RoI summed over T and the Hd neurons,
+ *   sum_cls[R][K], sum_bbox[R][K4]         sum over T of the LI membranes.                      */
+size_t snn_det_head_workspace_bytes(int R, int D, int Hd, int K, int K4, int T);
+int snn_det_head_forward(const float* x, int R, int D, int Hd, int K, int K4, int T,
+                         const snn_params* p_host,
+                         const float* w6_packed, const float* w7_packed, const float* w_heads_packed,
+                         float* out_cls, float* out_bbox,
+                         uint32_t* spk6_count, uint32_t* spk7_count, float* sum_cls, float* sum_bbox,
+                         void* workspace, size_t workspace_bytes, snn_stream_t stream);
+
+/* ---- stage-level entry points (parity tests drive the layers one by one, teacher-forced) ----- */
+/* constant-current LIF encoder -> bit-planes.  NCHW feature map -> planes[T][N*H*W][Cw]          */
+int snn_encode_nchw(const float* feat, int N, int C, int H, int W, int T, const snn_params* p_host,
+                    uint32_t* planes, size_t plane_stride_words, snn_stream_t stream);
+/* row-major x[R][D] -> planes[T][R][Dw]                                                          */
+int snn_encode_rows(const float* x, int R, int D, int T, const snn_params* p_host,
+                    uint32_t* planes, size_t plane_stride_words, snn_stream_t stream);
+/* fused 3x3 spike convolution + LIF over T for ONE level: enc planes [T][N*H*W][Cw] ->
+ * spk planes [T][N*H*W][Nw]; counts[N] nullable; dbg_cur (nullable, parity tests only) receives the
+ * shared-LIF input currents [T][N*H*W][Nw*32] fp32                                               */
+int snn_conv3x3_lif(const uint32_t* enc, size_t enc_stride_words, int N, int C_in, int C_out, int H, int W,
+                    int T, const snn_params* p_host, const float* w_packed,
+                    uint32_t* spk, size_t spk_stride_words, unsigned long long* counts, float* dbg_cur,
+                    snn_stream_t stream);
+/* time-batched spike GEMM: A planes as [M][Kw] rows -> cur[M][ldo] fp32 (ldo >= Np)              */
+int snn_spike_gemm(const uint32_t* a_rows, int M, int K, int N, const float* w_packed, float* cur,
+                   int ldo, snn_stream_t stream);
+/* LIF scan over T of currents cur[T][R][ldc] -> spk planes [T][R][Nw]; row_counts[R] nullable     */
+int snn_lif_scan(const float* cur, int T, int R, int N, int ldc, const snn_params* p_host,
+                 uint32_t* spk, size_t spk_stride_words, uint32_t* row_counts, snn_stream_t stream);
+/* leaky-integrator heads on spike planes [T][M][Kw]: out_a[M][NA], out_b[M][NB] = LI membranes at
+ * the last step; sum_a / sum_b (nullable) = their sums over the T steps                           */
+int snn_li_heads(const uint32_t* spk, size_t spk_stride_words, int T, int M, int K,
+                 const float* w_heads_packed, int NA, int NB, const snn_params* p_host,
+                 float* out_a, float* out_b, float* sum_a, float* sum_b, snn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SNN_HIP_H */

@@ -1,0 +1,91 @@
+"""ctypes binding of libsnnhip.so (C ABI: include/snn_hip.h).  There is NO fallback: if the HIP
+library is missing or a call fails, the product path raises."""
+import ctypes as C
+import os
+
+from . import build as _build
+
+c_f32p = C.POINTER(C.c_float)
+c_u32p = C.POINTER(C.c_uint32)
+c_u64p = C.POINTER(C.c_ulonglong)
+c_stream = C.c_void_p
+
+SNN_MAX_LEVELS = 8
+SNN_MAX_STEPS = 32
+
+
+class snn_params(C.Structure):
+    _fields_ = [("dt_tau_mem", C.c_float), ("neg_dt_tau_syn", C.c_float), ("v_leak", C.c_float),
+                ("v_reset", C.c_float), ("v_th_enc", C.c_float), ("v_th_lif", C.c_float),
+                ("li_order", C.c_int32), ("reserved", C.c_int32)]
+
+
+class snn_rpn_level(C.Structure):
+    _fields_ = [("feat", C.c_void_p), ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+# every symbol include/snn_hip.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "snn_version": (C.c_int, []),
+    "snn_last_error": (C.c_char_p, []),
+    "snn_packed_gemm_elems": (C.c_size_t, [C.c_int, C.c_int]),
+    "snn_packed_conv3x3_elems": (C.c_size_t, [C.c_int, C.c_int]),
+    "snn_pack_conv3x3_weight": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, c_stream]),
+    "snn_packed_linear_elems": (C.c_size_t, [C.c_int, C.c_int]),
+    "snn_pack_linear_weight": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, c_stream]),
+    "snn_packed_heads_elems": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "snn_pack_heads_weight": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, c_stream]),
+    "snn_rpn_head_workspace_bytes": (C.c_size_t, [C.POINTER(snn_rpn_level), C.c_int, C.c_int, C.c_int, C.c_int]),
+    "snn_rpn_head_forward": (C.c_int, [C.POINTER(snn_rpn_level), C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.POINTER(snn_params), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, c_stream]),
+    "snn_det_head_workspace_bytes": (C.c_size_t, [C.c_int] * 6),
+    "snn_det_head_forward": (C.c_int, [C.c_void_p] + [C.c_int] * 6 + [C.POINTER(snn_params)] +
+                             [C.c_void_p] * 10 + [C.c_size_t, c_stream]),
+    "snn_encode_nchw": (C.c_int, [C.c_void_p] + [C.c_int] * 5 + [C.POINTER(snn_params), C.c_void_p, C.c_size_t, c_stream]),
+    "snn_encode_rows": (C.c_int, [C.c_void_p] + [C.c_int] * 3 + [C.POINTER(snn_params), C.c_void_p, C.c_size_t, c_stream]),
+    "snn_conv3x3_lif": (C.c_int, [C.c_void_p, C.c_size_t] + [C.c_int] * 6 + [C.POINTER(snn_params), C.c_void_p,
+                                  C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, c_stream]),
+    "snn_spike_gemm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, c_stream]),
+    "snn_lif_scan": (C.c_int, [C.c_void_p] + [C.c_int] * 4 + [C.POINTER(snn_params), C.c_void_p, C.c_size_t,
+                               C.c_void_p, c_stream]),
+    "snn_li_heads": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                               C.POINTER(snn_params), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_stream]),
+}
+
+_LIB = None
+
+
+class SnnHipError(RuntimeError):
+    pass
+
+
+def lib_path() -> str:
+    return _build.LIB_PATH
+
+
+def load(build_if_missing: bool = True):
+    """Load libsnnhip.so (building it in-tree if hipcc is available and it is missing/stale)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = _build.LIB_PATH
+    if build_if_missing and _build.needs_build() and os.path.exists(_build.HIPCC):
+        _build.build()
+    if not os.path.exists(path):
+        raise SnnHipError("libsnnhip.so not found at %s (run `python -m snn_automotive_object_detection_amd.build`); "
+                          "there is no CPU fallback" % path)
+    lib = C.CDLL(path)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().snn_last_error()
+        raise SnnHipError("%s failed (rc=%d): %s" % (what, rc, msg.decode() if msg else "?"))

@@ -1,0 +1,73 @@
+// Shared device helpers for the gfx950 spiking-head kernels.
+// Neuron arithmetic follows Norse 0.0.7 op-for-op (see include/snn_hip.h for the reference call
+// sites); every fp32 operation is an explicitly rounded __f*_rn so that hipcc can never contract
+// a multiply-add into an fma (the reference's element-wise torch kernels round twice).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct NeuronP {
+    float ca;       // fl32(dt * tau_mem_inv)
+    float cb;       // fl32(-dt * tau_syn_inv)
+    float v_leak;
+    float v_reset;
+    float v_th;
+};
+
+// lif_current_encoder (norse/torch/functional/lif.py; reference rpn.py:101, faster_rcnn.py:494)
+//   dv = dt*tau_mem_inv * ((v_leak - v) + x);  v = v + dv;  z = (v - v_th > 0);  v = v - z*(v - v_reset)
+__device__ __forceinline__ bool enc_step(const float x, float& v, const NeuronP& p) {
+    const float dv = __fmul_rn(p.ca, __fadd_rn(__fsub_rn(p.v_leak, v), x));
+    v = __fadd_rn(v, dv);
+    const bool z = __fsub_rn(v, p.v_th) > 0.0f;
+    const float d = __fsub_rn(v, p.v_reset);
+    v = z ? __fsub_rn(v, d) : v;
+    return z;
+}
+
+// lif_feed_forward_step (norse lif.py; reference rpn.py:106, faster_rcnn.py:499,501)
+//   v_dec = v + ca*((v_leak - v) + i)   (OLD i);   i_dec = i + cb*i;   z = (v_dec - v_th > 0)
+//   v = (1-z)*v_dec + z*v_reset;   i = i_dec + cur
+__device__ __forceinline__ bool lif_step(const float cur, float& v, float& i, const NeuronP& p) {
+    const float dv = __fmul_rn(p.ca, __fadd_rn(__fsub_rn(p.v_leak, v), i));
+    const float v_dec = __fadd_rn(v, dv);
+    const float i_dec = __fadd_rn(i, __fmul_rn(p.cb, i));
+    const bool z = __fsub_rn(v_dec, p.v_th) > 0.0f;
+    v = z ? p.v_reset : v_dec;
+    i = __fadd_rn(i_dec, cur);
+    return z;
+}
+
+// row of a 32x32 MFMA accumulator held in register r by lane-half h (col = lane & 31)
+__device__ __forceinline__ int acc_row(const int r, const int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// One 32-deep reduction chunk on the fp32 matrix cores.
+//   aw[mt]  : this lane's spike word for row (lane&31) of M-tile mt, already shifted right by
+//             16*(lane>>5): MFMA q consumes reduction index k = q + 16*(lane>>5)  -> bit q
+//   bw      : LDS image of the packed weights for this wave's first N-tile:
+//             [nt][qq][lane] float4, element r of it = W[k = 4*qq + r + 16*(lane>>5)][n = lane&31]
+// v_mfma_f32_32x32x2_f32 is an exact k-ordered fp32 fma chain (one rounding per product).
+template <int MT, int NT>
+__device__ __forceinline__ void mma_chunk(f32x16 (&acc)[MT][NT], const uint32_t (&aw)[MT],
+                                          const f32x4* __restrict__ bw, const int lane) {
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+        f32x4 b[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) b[nt] = bw[(nt * 4 + qq) * 64 + lane];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int q = qq * 4 + r;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const float a = (float)((aw[mt] >> q) & 1u);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[nt][r], acc[mt][nt], 0, 0, 0);
+            }
+        }
+    }
+}

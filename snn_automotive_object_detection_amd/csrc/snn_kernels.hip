@@ -1,0 +1,794 @@
+// gfx950 (MI355X, CDNA4) kernels of the spiking RPN / detector heads + their C ABI (include/snn_hip.h).
+//
+// Data flow (bit-planes everywhere a spike tensor would be; see include/snn_hip.h):
+//   RPN  : k_encode_nchw -> k_conv3x3_lif (fp32-MFMA implicit GEMM, T-loop inside, LIF state in
+//          registers, ballot -> spike planes) -> k_li_heads (both 1x1 LI heads, time-collapsed)
+//   DET  : k_encode_rows -> k_spike_gemm (time-batched fc6) -> k_lif_scan -> k_spike_gemm (fc7)
+//          -> k_lif_scan -> k_li_heads
+// Reference loops replaced: rpn.py:84-121 (+126-200), faster_rcnn.py:470-516 (+520-618).
+#include "snn_common.h"
+#include "snn_hip.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing (thread-local; no exceptions, no abort)
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+static int check_launch(const char* name) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(-3, "launch of %s failed: %s", name, hipGetErrorString(e));
+    return 0;
+}
+#define SNN_CHECK_LAUNCH(name)                 \
+    do {                                       \
+        const int rc_ = check_launch(name);    \
+        if (rc_) return rc_;                   \
+    } while (0)
+
+static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+static NeuronP make_p(const snn_params* p, float v_th) {
+    NeuronP q;
+    q.ca = p->dt_tau_mem; q.cb = p->neg_dt_tau_syn; q.v_leak = p->v_leak; q.v_reset = p->v_reset;
+    q.v_th = v_th;
+    return q;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing: GEMM operand B[k][n] -> fragment-major
+//   packed[((kc*Nw + nt)*4 + qq)*64 + lane][r] = B[k = kc*32 + 4*qq + r + 16*(lane>>5)][n = nt*32 + (lane&31)]
+// so that one ds_read_b128 per lane yields the B operands of 4 consecutive MFMAs and both the
+// global->LDS copy and the LDS read are perfectly linear (no bank conflicts, no swizzle needed).
+// ------------------------------------------------------------------------------------------------
+enum { PACK_CONV3X3 = 0, PACK_LINEAR = 1 };
+
+__global__ void k_pack_gemm_b(const float* __restrict__ src, float* __restrict__ dst, int mode,
+                              int K, int N, int Kc, int Nw, int Cin, int Cp) {
+    const size_t total = (size_t)Kc * Nw * 1024;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int r = idx & 3;
+        const int lane = (idx >> 2) & 63;
+        const int qq = (idx >> 8) & 3;
+        const size_t blk = idx >> 10;
+        const int nt = (int)(blk % Nw);
+        const int kc = (int)(blk / Nw);
+        const int k = kc * 32 + 4 * qq + r + 16 * (lane >> 5);
+        const int n = nt * 32 + (lane & 31);
+        float v = 0.0f;
+        if (n < N) {
+            if (mode == PACK_CONV3X3) {            // k = tap*Cp + ci ; src OIHW [N][Cin][3][3]
+                const int tap = k / Cp, ci = k % Cp;
+                if (ci < Cin) v = src[((size_t)n * Cin + ci) * 9 + tap];
+            } else {                               // src [N][K] (nn.Linear weight)
+                if (k < K) v = src[(size_t)n * K + k];
+            }
+        }
+        dst[idx] = v;
+    }
+}
+
+// both LI heads -> transposed [Kp][NOp] (NOp = NA+NB rounded up to 16)
+__global__ void k_pack_heads(const float* __restrict__ wa, int NA, const float* __restrict__ wb, int NB,
+                             int K, int Kp, int NOp, float* __restrict__ dst) {
+    const int total = Kp * NOp;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int k = idx / NOp, j = idx % NOp;
+        float v = 0.0f;
+        if (k < K) {
+            if (j < NA) v = wa[(size_t)j * K + k];
+            else if (j < NA + NB) v = wb[(size_t)(j - NA) * K + k];
+        }
+        dst[idx] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1a: constant-current LIF encoder, NCHW fp32 -> bit-planes [T][N*HW][Cw]
+// one thread = one position x one group of 32 channels; global reads are coalesced along W.
+// HBM-bound streaming kernel: reads 4 B/element once, writes T/8 B/element... (T bits)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_encode_nchw(const float* __restrict__ feat, int C, int HW, int Cw,
+                                                     int T, NeuronP p, uint32_t* __restrict__ planes,
+                                                     size_t plane_stride) {
+    const int pos = blockIdx.x * 256 + threadIdx.x;
+    const int cg = blockIdx.y;
+    const int n = blockIdx.z;
+    if (pos >= HW) return;
+    float x[32], v[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        const int c = cg * 32 + j;
+        x[j] = (c < C) ? feat[((size_t)n * C + c) * HW + pos] : 0.0f;
+        v[j] = 0.0f;                              // rpn.py:93  v = zeros
+    }
+    uint32_t* out = planes + ((size_t)n * HW + pos) * Cw + cg;
+    for (int t = 0; t < T; ++t) {
+        uint32_t word = 0;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) word |= (uint32_t)enc_step(x[j], v[j], p) << j;
+        out[(size_t)t * plane_stride] = word;
+    }
+}
+
+// K1b: encoder on row-major x[R][D] -> bit-planes [T][R][Dw]; a wave covers 64 consecutive
+// reduction indices, so one ballot per step IS two plane words.
+__global__ __launch_bounds__(256) void k_encode_rows(const float* __restrict__ x, int R, int D, int Dw, int T,
+                                                     NeuronP p, uint32_t* __restrict__ planes,
+                                                     size_t plane_stride) {
+    const size_t Dp = (size_t)Dw * 32;
+    const size_t total = (size_t)R * Dp;
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    float xv = 0.0f;
+    if (e < total) {
+        const size_t r = e / Dp, k = e % Dp;
+        if (k < (size_t)D) xv = x[r * D + k];
+    }
+    float v = 0.0f;                               // faster_rcnn.py:484
+    const int lane = threadIdx.x & 63;
+    for (int t = 0; t < T; ++t) {
+        const bool z = enc_step(xv, v, p);
+        const unsigned long long m = __ballot(z);
+        if ((lane & 31) == 0 && e < total)
+            planes[(size_t)t * plane_stride + (e >> 5)] = (lane < 32) ? (uint32_t)m : (uint32_t)(m >> 32);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: fused 3x3 spike convolution (implicit GEMM on the fp32 matrix cores) + LIF over the T loop.
+//
+// Work-group = 512 threads = 8 waves (2 along M x 4 along N); tile = 64 positions (an 8x8 patch of
+// one image of one level) x 256 output channels; each wave owns 32 positions x 64 channels
+// (1 x 2 MFMA tiles of 32x32).  Per lane: 32 accumulators + 32 membrane voltages + 32 synaptic
+// currents stay in registers for the whole T loop; nothing but spike bits is written to HBM.
+//   A operand: encoder spike bits of the (8+2)x(8+2) halo of the patch, one LDS image per step
+//              ([channel word][halo position]); a lane turns bit q of its word into 0.0f/1.0f.
+//   B operand: packed weights, one 32-deep chunk (32 KB) per barrier, double-buffered in LDS,
+//              next chunk prefetched into registers while the MFMAs of the current one run.
+// Spatial tiles are independent for the whole T loop (the only coupling is the conv halo on the
+// *encoder* spikes), so there is no inter-work-group synchronisation.
+// ------------------------------------------------------------------------------------------------
+struct ConvLevelDev {
+    int pos_base;        // first row (position) of this level in the plane buffers
+    int N, H, W;
+    int tiles_x, tiles_per_img;
+    int tile_begin;      // first blockIdx.x of this level
+    int pad;
+};
+struct ConvArgs {
+    const uint32_t* enc;
+    uint32_t* spk;
+    const float* wpk;
+    unsigned long long* counts;
+    float* dbg_cur;                              // nullable: input currents [T][P][Nw*32] (parity tests)
+    unsigned long long enc_stride, spk_stride;   // words per time plane
+    int Cw, Nw, T, n_levels, max_n, pad;
+    NeuronP p;
+    ConvLevelDev lv[SNN_MAX_LEVELS];
+};
+
+#define CONV_PH 8
+#define CONV_PW 8
+#define CONV_HALO ((CONV_PH + 2) * (CONV_PW + 2))
+
+__global__ __launch_bounds__(512) void k_conv3x3_lif(const ConvArgs args) {
+    constexpr int WN = 4, NT = 2, BNT = WN * NT;          // 8 n-tiles (256 channels) per block
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    f32x4* ldsB = reinterpret_cast<f32x4*>(smem);                       // 2 x BNT*256 float4
+    uint32_t* ldsA = reinterpret_cast<uint32_t*>(smem + 2 * BNT * 4096); // Cw * CONV_HALO words
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    // ---- which tile ----
+    int l = 0;
+    const int b = blockIdx.x;
+    while (l + 1 < args.n_levels && b >= args.lv[l + 1].tile_begin) ++l;
+    const ConvLevelDev L = args.lv[l];
+    const int local = b - L.tile_begin;
+    const int n = local / L.tiles_per_img;
+    const int rem = local % L.tiles_per_img;
+    const int y0 = (rem / L.tiles_x) * CONV_PH, x0 = (rem % L.tiles_x) * CONV_PW;
+    const int H = L.H, W = L.W;
+    const size_t img_base = (size_t)L.pos_base + (size_t)n * H * W;
+    const int nb = blockIdx.y;                       // 256-channel output block
+    const int Cw = args.Cw, Nw = args.Nw;
+    const int nbt = min(BNT, Nw - nb * BNT);         // n-tiles present in this block
+
+    // this lane's A row: position (py, px) of the patch
+    const int py = wm * 4 + (li >> 3), px = li & 7;
+    const int a_off = py * (CONV_PW + 2) + px;
+
+    // which rows (register r) of this lane are inside the image -> spike mask
+    uint32_t valid_bits = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = acc_row(r, lh);
+        const int yy = y0 + wm * 4 + (row >> 3), xx = x0 + (row & 7);
+        valid_bits |= (uint32_t)(yy < H && xx < W) << r;
+    }
+
+    f32x16 acc[1][NT];
+    float v[NT][16], cur_i[NT][16];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { v[nt][r] = args.p.v_leak; cur_i[nt][r] = 0.0f; }   // state fallback
+
+    const int KC = 9 * Cw;
+    const f32x4* wsrc = reinterpret_cast<const f32x4*>(args.wpk) + (size_t)nb * BNT * 256;
+    const size_t wchunk = (size_t)Nw * 256;          // float4 per reduction chunk (all n-tiles)
+    const int nB4 = nbt * 256;                       // float4 of B this block needs per chunk
+
+    // ---- prologue: B chunk 0 -> LDS buffer 0 ----
+    f32x4 pre[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int idx = tid + 512 * s;
+        pre[s] = (idx < nB4) ? wsrc[idx] : f32x4{0.f, 0.f, 0.f, 0.f};
+        ldsB[idx] = pre[s];
+    }
+    int buf = 0;
+    unsigned long long n_spikes = 0;
+
+    for (int t = 0; t < args.T; ++t) {
+        // ---- encoder spike halo of step t -> LDS ([word][halo position]) ----
+        const uint32_t* enc_t = args.enc + (size_t)t * args.enc_stride;
+        for (int idx = tid; idx < CONV_HALO * Cw; idx += 512) {
+            const int cc = idx % Cw, hp = idx / Cw;
+            const int y = y0 - 1 + hp / (CONV_PW + 2), x = x0 - 1 + hp % (CONV_PW + 2);
+            uint32_t w = 0;
+            if (y >= 0 && y < H && x >= 0 && x < W) w = enc_t[(img_base + (size_t)y * W + x) * Cw + cc];
+            ldsA[cc * CONV_HALO + hp] = w;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][nt][r] = 0.0f;
+
+        int kc = 0;
+        for (int tap = 0; tap < 9; ++tap) {
+            const int a_tap = a_off + (tap / 3) * (CONV_PW + 2) + (tap % 3);
+            for (int cc = 0; cc < Cw; ++cc, ++kc) {
+                // prefetch the next reduction chunk (wraps to chunk 0 for the next time step)
+                const int kn = (kc + 1 == KC) ? 0 : kc + 1;
+                const f32x4* wnext = wsrc + (size_t)kn * wchunk;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int idx = tid + 512 * s;
+                    pre[s] = (idx < nB4) ? wnext[idx] : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                uint32_t aw[1];
+                aw[0] = ldsA[cc * CONV_HALO + a_tap] >> (16 * lh);
+                mma_chunk<1, NT>(acc, aw, ldsB + buf * (BNT * 256) + wn * NT * 256, lane);
+                f32x4* dstB = ldsB + (buf ^ 1) * (BNT * 256);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) dstB[tid + 512 * s] = pre[s];
+                __syncthreads();
+                buf ^= 1;
+            }
+        }
+
+        if (args.dbg_cur != nullptr) {     // test hook: dump the step's input currents
+            float* d = args.dbg_cur + (size_t)t * (args.spk_stride * 32);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int ntg = nb * BNT + wn * NT + nt;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = acc_row(r, lh);
+                    const int yy = y0 + wm * 4 + (row >> 3), xx = x0 + (row & 7);
+                    if (yy < H && xx < W && ntg < Nw)
+                        d[(img_base + (size_t)yy * W + xx) * (Nw * 32) + ntg * 32 + li] = acc[0][nt][r];
+                }
+            }
+        }
+        // ---- LIF epilogue in registers; spikes leave as ballots ----
+        uint32_t myword = 0;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                bool z = lif_step(acc[0][nt][r], v[nt][r], cur_i[nt][r], args.p);
+                z = z && ((valid_bits >> r) & 1u);
+                const unsigned long long m = __ballot(z);
+                n_spikes += __popcll(m);
+                const int L0 = nt * 32 + r * 2;
+                myword = (lane == L0) ? (uint32_t)m : myword;
+                myword = (lane == L0 + 1) ? (uint32_t)(m >> 32) : myword;
+            }
+        }
+        {   // lane -> (nt, r, half): one 32-channel word of one position
+            const int nt = lane >> 5, r = (lane >> 1) & 15, hh = lane & 1;
+            const int row = acc_row(r, hh);
+            const int yy = y0 + wm * 4 + (row >> 3), xx = x0 + (row & 7);
+            const int ntg = nb * BNT + wn * NT + nt;
+            if (yy < H && xx < W && ntg < Nw)
+                args.spk[(size_t)t * args.spk_stride + (img_base + (size_t)yy * W + xx) * Nw + ntg] = myword;
+        }
+    }
+    if (args.counts != nullptr && lane == 0 && n_spikes != 0)
+        atomicAdd(&args.counts[l * args.max_n + n], n_spikes);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3: time-batched spike GEMM  cur[M][ldo] = A_bits[M][K] x W[K][N]   (rows m = t*R + r)
+// A words come straight from global/L2 (one word per row per chunk, prefetched one chunk ahead);
+// B chunks stream through a double-buffered LDS image exactly as in K2.
+// ------------------------------------------------------------------------------------------------
+struct GemmArgs {
+    const uint32_t* A;
+    const float* wpk;
+    float* out;
+    int M, Kw, Nw, ldo, n_blocks, pad;
+};
+
+template <int WM, int WN, int MT, int NT>
+__global__ __launch_bounds__(512) void k_spike_gemm(const GemmArgs args) {
+    static_assert(WM * WN == 8, "8 waves");
+    constexpr int BM = WM * MT * 32, BNT = WN * NT, PRE = BNT / 2;      // PRE float4 per thread per chunk
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    f32x4* ldsB = reinterpret_cast<f32x4*>(smem);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+    const int nb = blockIdx.x % args.n_blocks;       // consecutive blocks (one per XCD) take different weight panels
+    const int mb = blockIdx.x / args.n_blocks;
+    const int m0 = mb * BM;
+    const int Kw = args.Kw, Nw = args.Nw, M = args.M;
+    const int nbt = min(BNT, Nw - nb * BNT);
+    const int nB4 = nbt * 256;
+
+    const uint32_t* arow[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = min(m0 + (wm * MT + mt) * 32 + li, M - 1);
+        arow[mt] = args.A + (size_t)m * Kw;
+    }
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
+
+    const f32x4* wsrc = reinterpret_cast<const f32x4*>(args.wpk) + (size_t)nb * BNT * 256;
+    const size_t wchunk = (size_t)Nw * 256;
+    f32x4 pre[PRE];
+#pragma unroll
+    for (int s = 0; s < PRE; ++s) {
+        const int idx = tid + 512 * s;
+        ldsB[idx] = (idx < nB4) ? wsrc[idx] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    uint32_t a_next[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) a_next[mt] = arow[mt][0];
+    __syncthreads();
+    int buf = 0;
+    for (int kc = 0; kc < Kw; ++kc) {
+        const int kn = min(kc + 1, Kw - 1);
+        const f32x4* wnext = wsrc + (size_t)kn * wchunk;
+#pragma unroll
+        for (int s = 0; s < PRE; ++s) {
+            const int idx = tid + 512 * s;
+            pre[s] = (idx < nB4) ? wnext[idx] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        uint32_t aw[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) { aw[mt] = a_next[mt] >> (16 * lh); a_next[mt] = arow[mt][kn]; }
+        mma_chunk<MT, NT>(acc, aw, ldsB + buf * (BNT * 256) + wn * NT * 256, lane);
+        f32x4* dstB = ldsB + (buf ^ 1) * (BNT * 256);
+#pragma unroll
+        for (int s = 0; s < PRE; ++s) dstB[tid + 512 * s] = pre[s];
+        __syncthreads();
+        buf ^= 1;
+    }
+    // ---- store currents (lanes 0-31 / 32-63 write two 128-B row segments per instruction) ----
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int ntg = nb * BNT + wn * NT + nt;
+            if (ntg >= Nw) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wm * MT + mt) * 32 + acc_row(r, lh);
+                if (m < M) args.out[(size_t)m * args.ldo + ntg * 32 + li] = acc[mt][nt][r];
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4: LIF scan over T of currents cur[T][R][ldc] -> spike planes [T][R][Nw]  (+ per-row counts)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_lif_scan(const float* __restrict__ cur, int T, int R, int N, int Nw,
+                                                  int ldc, NeuronP p, uint32_t* __restrict__ spk,
+                                                  size_t spk_stride, uint32_t* __restrict__ row_counts) {
+    const size_t Np = (size_t)Nw * 32;
+    const size_t total = (size_t)R * Np;
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const bool in = e < total;
+    const size_t r = in ? e / Np : 0;
+    const int n = in ? (int)(e % Np) : 0;
+    const bool live = in && n < N;
+    const float* c = cur + r * ldc + n;
+    const size_t tstride = (size_t)R * ldc;
+    float v = p.v_leak, i = 0.0f;
+    const int lane = threadIdx.x & 63;
+    uint32_t cnt = 0;
+    for (int t = 0; t < T; ++t) {
+        const float x = live ? c[(size_t)t * tstride] : 0.0f;
+        const bool z = lif_step(x, v, i, p) && live;
+        const unsigned long long m = __ballot(z);
+        if ((lane & 31) == 0 && in) {
+            const uint32_t w = (lane < 32) ? (uint32_t)m : (uint32_t)(m >> 32);
+            spk[(size_t)t * spk_stride + (e >> 5)] = w;
+            cnt += __popc(w);
+        }
+    }
+    if (row_counts != nullptr && (lane & 31) == 0 && in && cnt != 0) atomicAdd(&row_counts[r], cnt);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5: both leaky-integrator heads, time-collapsed.  The LI cell and the bias-free 1x1 conv / linear
+// in front of it are linear and only the last membrane is used (rpn.py:118-119,
+// faster_rcnn.py:513-514), so  mem_T = W . (sum_t kappa_last[t] * spk_t)  and the spike-rate
+// variant's sum over t of the membranes is  W . (sum_t kappa_sum[t] * spk_t).
+// ------------------------------------------------------------------------------------------------
+struct Kappa { float last[SNN_MAX_STEPS]; float sum[SNN_MAX_STEPS]; };
+
+template <int RB>
+__global__ __launch_bounds__(256) void k_li_heads(const uint32_t* __restrict__ spk, size_t spk_stride, int T,
+                                                  int M, int Kw, const float* __restrict__ wT, int NOp, int NA,
+                                                  int NB, const Kappa kap, float* __restrict__ out_a,
+                                                  float* __restrict__ out_b, float* __restrict__ sum_a,
+                                                  float* __restrict__ sum_b) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int Kp = Kw * 32;
+    float* S_last = reinterpret_cast<float*>(smem);            // [RB][Kp]
+    float* S_sum = S_last + RB * Kp;                           // [RB][Kp] (only if sums requested)
+    const bool want_sum = (sum_a != nullptr);
+    const int m0 = blockIdx.x * RB;
+    for (int idx = threadIdx.x; idx < RB * Kp; idx += 256) {
+        const int row = idx / Kp, k = idx % Kp;
+        const int m = m0 + row;
+        float sl = 0.0f, ss = 0.0f;
+        if (m < M) {
+            const uint32_t* w = spk + (size_t)m * Kw + (k >> 5);
+            for (int t = 0; t < T; ++t) {
+                const uint32_t bit = (w[(size_t)t * spk_stride] >> (k & 31)) & 1u;
+                if (bit) { sl = __fadd_rn(sl, kap.last[t]); ss = __fadd_rn(ss, kap.sum[t]); }
+            }
+        }
+        S_last[idx] = sl;
+        if (want_sum) S_sum[idx] = ss;
+    }
+    __syncthreads();
+    const int NO = NA + NB;
+    for (int o = threadIdx.x; o < RB * NO; o += 256) {
+        const int row = o / NO, j = o % NO;
+        const int m = m0 + row;
+        if (m >= M) continue;
+        const float* sl = S_last + row * Kp;
+        const float* ss = S_sum + row * Kp;
+        float al = 0.0f, as = 0.0f;
+        for (int k = 0; k < Kp; ++k) {
+            const float w = wT[(size_t)k * NOp + j];
+            al = fmaf(sl[k], w, al);
+            if (want_sum) as = fmaf(ss[k], w, as);
+        }
+        if (j < NA) { out_a[(size_t)m * NA + j] = al; if (want_sum) sum_a[(size_t)m * NA + j] = as; }
+        else { out_b[(size_t)m * NB + (j - NA)] = al; if (want_sum) sum_b[(size_t)m * NB + (j - NA)] = as; }
+    }
+}
+
+// impulse responses of the LI cell (norse leaky_integrator.py: li_feed_forward_step; v_leak = 0)
+static void li_kappa(const snn_params* p, int T, Kappa* k) {
+    const double a = (double)p->dt_tau_mem, cb = (double)p->neg_dt_tau_syn;
+    for (int s = 0; s < SNN_MAX_STEPS; ++s) { k->last[s] = 0.f; k->sum[s] = 0.f; }
+    for (int s = 0; s < T; ++s) {
+        double v = 0.0, i = 0.0, acc = 0.0;
+        for (int t = s; t < T; ++t) {
+            const double x = (t == s) ? 1.0 : 0.0;
+            if (p->li_order == 0) {          // jump-first
+                const double in = i + x;
+                v = v + a * (in - v);
+                i = in + cb * in;
+            } else {                         // voltage-first
+                v = v + a * (i - v);
+                i = i + cb * i + x;
+            }
+            acc += v;
+        }
+        k->last[s] = (float)v;
+        k->sum[s] = (float)acc;
+    }
+}
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+int snn_version(void) { return 1; }
+const char* snn_last_error(void) { return g_err; }
+
+size_t snn_packed_gemm_elems(int K_chunks32, int N) { return (size_t)K_chunks32 * cdiv(N, 32) * 1024; }
+size_t snn_packed_conv3x3_elems(int C_out, int C_in) { return snn_packed_gemm_elems(9 * cdiv(C_in, 32), C_out); }
+size_t snn_packed_linear_elems(int N, int K) { return snn_packed_gemm_elems(cdiv(K, 32), N); }
+size_t snn_packed_heads_elems(int NA, int NB, int K) {
+    return (size_t)cdiv(K, 32) * 32 * (size_t)(cdiv(NA + NB, 16) * 16);
+}
+
+int snn_pack_conv3x3_weight(const float* w, int C_out, int C_in, float* packed, snn_stream_t s) {
+    if (!w || !packed || C_out <= 0 || C_in <= 0) return fail(-1, "snn_pack_conv3x3_weight: bad argument");
+    const int Cp = cdiv(C_in, 32) * 32, Kc = 9 * (Cp / 32), Nw = cdiv(C_out, 32);
+    const size_t total = (size_t)Kc * Nw * 1024;
+    hipLaunchKernelGGL(k_pack_gemm_b, dim3((unsigned)min((size_t)4096, (total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)s, w, packed, (int)PACK_CONV3X3, 9 * Cp, C_out, Kc, Nw, C_in, Cp);
+    SNN_CHECK_LAUNCH("k_pack_gemm_b");
+    return 0;
+}
+
+int snn_pack_linear_weight(const float* w, int N, int K, float* packed, snn_stream_t s) {
+    if (!w || !packed || N <= 0 || K <= 0) return fail(-1, "snn_pack_linear_weight: bad argument");
+    const int Kc = cdiv(K, 32), Nw = cdiv(N, 32);
+    const size_t total = (size_t)Kc * Nw * 1024;
+    hipLaunchKernelGGL(k_pack_gemm_b, dim3((unsigned)min((size_t)4096, (total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)s, w, packed, (int)PACK_LINEAR, K, N, Kc, Nw, 0, 32);
+    SNN_CHECK_LAUNCH("k_pack_gemm_b");
+    return 0;
+}
+
+int snn_pack_heads_weight(const float* wa, int NA, const float* wb, int NB, int K, float* packed,
+                          snn_stream_t s) {
+    if (!wa || !wb || !packed || NA <= 0 || NB <= 0 || K <= 0)
+        return fail(-1, "snn_pack_heads_weight: bad argument");
+    const int Kp = cdiv(K, 32) * 32, NOp = cdiv(NA + NB, 16) * 16;
+    hipLaunchKernelGGL(k_pack_heads, dim3(cdiv((long long)Kp * NOp, 256)), dim3(256), 0, (hipStream_t)s, wa, NA,
+                       wb, NB, K, Kp, NOp, packed);
+    SNN_CHECK_LAUNCH("k_pack_heads");
+    return 0;
+}
+
+static int check_T(int T, const char* who) {
+    if (T < 1 || T > SNN_MAX_STEPS) return fail(-1, "%s: num_steps %d outside [1, %d]", who, T, SNN_MAX_STEPS);
+    return 0;
+}
+
+int snn_encode_nchw(const float* feat, int N, int C, int H, int W, int T, const snn_params* p,
+                    uint32_t* planes, size_t plane_stride, snn_stream_t s) {
+    if (!feat || !planes || !p || N <= 0 || C <= 0 || H <= 0 || W <= 0)
+        return fail(-1, "snn_encode_nchw: bad argument");
+    if (check_T(T, "snn_encode_nchw")) return -1;
+    const int Cw = cdiv(C, 32), HW = H * W;
+    hipLaunchKernelGGL(k_encode_nchw, dim3(cdiv(HW, 256), Cw, N), dim3(256), 0, (hipStream_t)s, feat, C, HW, Cw, T,
+                       make_p(p, p->v_th_enc), planes, plane_stride);
+    SNN_CHECK_LAUNCH("k_encode_nchw");
+    return 0;
+}
+
+int snn_encode_rows(const float* x, int R, int D, int T, const snn_params* p, uint32_t* planes,
+                    size_t plane_stride, snn_stream_t s) {
+    if (!x || !planes || !p || R <= 0 || D <= 0) return fail(-1, "snn_encode_rows: bad argument");
+    if (check_T(T, "snn_encode_rows")) return -1;
+    const int Dw = cdiv(D, 32);
+    const size_t total = (size_t)R * Dw * 32;
+    hipLaunchKernelGGL(k_encode_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)s, x, R, D,
+                       Dw, T, make_p(p, p->v_th_enc), planes, plane_stride);
+    SNN_CHECK_LAUNCH("k_encode_rows");
+    return 0;
+}
+
+// shared by snn_conv3x3_lif (one level) and snn_rpn_head_forward (all levels in one launch)
+static int launch_conv(const snn_rpn_level* lv, int n_levels, int C_in, int C_out, int T, const snn_params* p,
+                       const uint32_t* enc, size_t enc_stride, const float* wpk, uint32_t* spk,
+                       size_t spk_stride, unsigned long long* counts, int max_n, float* dbg_cur,
+                       hipStream_t s) {
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.enc = enc; a.spk = spk; a.wpk = wpk; a.counts = counts; a.dbg_cur = dbg_cur;
+    a.enc_stride = enc_stride; a.spk_stride = spk_stride;
+    a.Cw = cdiv(C_in, 32); a.Nw = cdiv(C_out, 32); a.T = T; a.n_levels = n_levels; a.max_n = max_n;
+    a.p = make_p(p, p->v_th_lif);
+    int tiles = 0, pos = 0;
+    for (int l = 0; l < n_levels; ++l) {
+        ConvLevelDev& d = a.lv[l];
+        d.pos_base = pos; d.N = lv[l].N; d.H = lv[l].H; d.W = lv[l].W;
+        d.tiles_x = cdiv(lv[l].W, CONV_PW);
+        d.tiles_per_img = d.tiles_x * cdiv(lv[l].H, CONV_PH);
+        d.tile_begin = tiles;
+        tiles += d.tiles_per_img * lv[l].N;
+        pos += lv[l].N * lv[l].H * lv[l].W;
+    }
+    const size_t lds = 2 * 8 * 4096 + (size_t)a.Cw * CONV_HALO * 4;
+    if (lds > 160 * 1024) return fail(-1, "conv3x3_lif: C_in=%d needs too much LDS", C_in);
+    hipError_t e = hipFuncSetAttribute((const void*)k_conv3x3_lif, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail(-3, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(k_conv3x3_lif, dim3(tiles, cdiv(a.Nw, 8)), dim3(512), lds, s, a);
+    SNN_CHECK_LAUNCH("k_conv3x3_lif");
+    return 0;
+}
+
+int snn_conv3x3_lif(const uint32_t* enc, size_t enc_stride, int N, int C_in, int C_out, int H, int W, int T,
+                    const snn_params* p, const float* w_packed, uint32_t* spk, size_t spk_stride,
+                    unsigned long long* counts, float* dbg_cur, snn_stream_t s) {
+    if (!enc || !spk || !w_packed || !p || N <= 0 || C_in <= 0 || C_out <= 0 || H <= 0 || W <= 0)
+        return fail(-1, "snn_conv3x3_lif: bad argument");
+    if (check_T(T, "snn_conv3x3_lif")) return -1;
+    snn_rpn_level lv; lv.feat = nullptr; lv.N = N; lv.H = H; lv.W = W; lv.reserved = 0;
+    return launch_conv(&lv, 1, C_in, C_out, T, p, enc, enc_stride, w_packed, spk, spk_stride, counts, N, dbg_cur,
+                       (hipStream_t)s);
+}
+
+int snn_spike_gemm(const uint32_t* a_rows, int M, int K, int N, const float* w_packed, float* cur, int ldo,
+                   snn_stream_t s) {
+    if (!a_rows || !w_packed || !cur || M <= 0 || K <= 0 || N <= 0 || ldo < N)
+        return fail(-1, "snn_spike_gemm: bad argument");
+    GemmArgs a;
+    a.A = a_rows; a.wpk = w_packed; a.out = cur; a.M = M; a.Kw = cdiv(K, 32); a.Nw = cdiv(N, 32); a.ldo = ldo; a.pad = 0;
+    // 128 x 128 tile: 8 waves as 2 (M) x 4 (N), each 64 x 32
+    constexpr int WM = 2, WN = 4, MT = 2, NT = 1;
+    a.n_blocks = cdiv(a.Nw, WN * NT);
+    const size_t lds = 2 * (size_t)(WN * NT) * 4096;
+    auto kern = k_spike_gemm<WM, WN, MT, NT>;
+    hipLaunchKernelGGL(kern, dim3(cdiv(M, WM * MT * 32) * a.n_blocks), dim3(512), lds, (hipStream_t)s, a);
+    SNN_CHECK_LAUNCH("k_spike_gemm");
+    return 0;
+}
+
+int snn_lif_scan(const float* cur, int T, int R, int N, int ldc, const snn_params* p, uint32_t* spk,
+                 size_t spk_stride, uint32_t* row_counts, snn_stream_t s) {
+    if (!cur || !spk || !p || R <= 0 || N <= 0 || ldc < N) return fail(-1, "snn_lif_scan: bad argument");
+    if (check_T(T, "snn_lif_scan")) return -1;
+    const int Nw = cdiv(N, 32);
+    const size_t total = (size_t)R * Nw * 32;
+    hipLaunchKernelGGL(k_lif_scan, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)s, cur, T, R, N,
+                       Nw, ldc, make_p(p, p->v_th_lif), spk, spk_stride, row_counts);
+    SNN_CHECK_LAUNCH("k_lif_scan");
+    return 0;
+}
+
+int snn_li_heads(const uint32_t* spk, size_t spk_stride, int T, int M, int K, const float* w_heads_packed,
+                 int NA, int NB, const snn_params* p, float* out_a, float* out_b, float* sum_a, float* sum_b,
+                 snn_stream_t s) {
+    if (!spk || !w_heads_packed || !p || !out_a || !out_b || M <= 0 || K <= 0 || NA <= 0 || NB <= 0)
+        return fail(-1, "snn_li_heads: bad argument");
+    if ((sum_a == nullptr) != (sum_b == nullptr)) return fail(-1, "snn_li_heads: sum_a and sum_b go together");
+    if (check_T(T, "snn_li_heads")) return -1;
+    Kappa kap;
+    li_kappa(p, T, &kap);
+    const int Kw = cdiv(K, 32), NOp = cdiv(NA + NB, 16) * 16;
+    constexpr int RB = 8;
+    const size_t lds = (size_t)(sum_a ? 2 : 1) * RB * Kw * 32 * 4;
+    if (lds > 160 * 1024) return fail(-1, "snn_li_heads: K=%d too large", K);
+    auto kern = k_li_heads<RB>;
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail(-3, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(kern, dim3(cdiv(M, RB)), dim3(256), lds, (hipStream_t)s, spk, spk_stride, T, M, Kw,
+                       w_heads_packed, NOp, NA, NB, kap, out_a, out_b, sum_a, sum_b);
+    SNN_CHECK_LAUNCH("k_li_heads");
+    return 0;
+}
+
+// ---- whole heads ---------------------------------------------------------------------------------
+static long long rpn_positions(const snn_rpn_level* lv, int n_levels, int* max_n) {
+    long long P = 0; int mn = 0;
+    for (int l = 0; l < n_levels; ++l) { P += (long long)lv[l].N * lv[l].H * lv[l].W; mn = lv[l].N > mn ? lv[l].N : mn; }
+    if (max_n) *max_n = mn;
+    return P;
+}
+
+size_t snn_rpn_head_workspace_bytes(const snn_rpn_level* lv, int n_levels, int C, int A, int T) {
+    (void)A;
+    if (!lv || n_levels <= 0 || n_levels > SNN_MAX_LEVELS || C <= 0 || T < 1) return 0;
+    const long long P = rpn_positions(lv, n_levels, nullptr);
+    const size_t plane = align_up((size_t)T * P * cdiv(C, 32) * 4, 256);
+    return 2 * plane;     // encoder planes + shared-LIF spike planes
+}
+
+int snn_rpn_head_forward(const snn_rpn_level* lv, int n_levels, int C, int A, int T, const snn_params* p,
+                         const float* w_shared_packed, const float* w_heads_packed, float* out_logits,
+                         float* out_bbox, unsigned long long* spike_counts, float* sum_logits, float* sum_bbox,
+                         void* ws, size_t ws_bytes, snn_stream_t stream) {
+    if (!lv || !p || !w_shared_packed || !w_heads_packed || !out_logits || !out_bbox || !ws)
+        return fail(-1, "snn_rpn_head_forward: null argument");
+    if (n_levels <= 0 || n_levels > SNN_MAX_LEVELS) return fail(-1, "snn_rpn_head_forward: n_levels=%d", n_levels);
+    if (C <= 0 || A <= 0) return fail(-1, "snn_rpn_head_forward: bad C/A");
+    if (check_T(T, "snn_rpn_head_forward")) return -1;
+    for (int l = 0; l < n_levels; ++l)
+        if (!lv[l].feat || lv[l].N <= 0 || lv[l].H <= 0 || lv[l].W <= 0)
+            return fail(-1, "snn_rpn_head_forward: bad level %d", l);
+    const size_t need = snn_rpn_head_workspace_bytes(lv, n_levels, C, A, T);
+    if (ws_bytes < need) return fail(-2, "snn_rpn_head_forward: workspace %zu < %zu bytes", ws_bytes, need);
+    int max_n = 0;
+    const long long P = rpn_positions(lv, n_levels, &max_n);
+    const int Cw = cdiv(C, 32);
+    const size_t stride = (size_t)P * Cw;            // words per time plane
+    uint32_t* enc = (uint32_t*)ws;
+    uint32_t* spk = (uint32_t*)((char*)ws + need / 2);
+    hipStream_t s = (hipStream_t)stream;
+    long long pos = 0;
+    for (int l = 0; l < n_levels; ++l) {
+        const int rc = snn_encode_nchw(lv[l].feat, lv[l].N, C, lv[l].H, lv[l].W, T, p, enc + (size_t)pos * Cw, stride, stream);
+        if (rc) return rc;
+        pos += (long long)lv[l].N * lv[l].H * lv[l].W;
+    }
+    if (spike_counts) {
+        hipError_t e = hipMemsetAsync(spike_counts, 0, sizeof(unsigned long long) * n_levels * max_n, s);
+        if (e != hipSuccess) return fail(-3, "hipMemsetAsync failed: %s", hipGetErrorString(e));
+    }
+    int rc = launch_conv(lv, n_levels, C, C, T, p, enc, stride, w_shared_packed, spk, stride, spike_counts, max_n, nullptr, s);
+    if (rc) return rc;
+    return snn_li_heads(spk, stride, T, (int)P, C, w_heads_packed, A, 4 * A, p, out_logits, out_bbox, sum_logits,
+                        sum_bbox, stream);
+}
+
+static void det_ws_layout(int R, int D, int Hd, int T, size_t* o_enc, size_t* o_cur, size_t* o_s6, size_t* o_s7,
+                          size_t* total) {
+    const size_t enc = align_up((size_t)T * R * cdiv(D, 32) * 4, 256);
+    const size_t cur = align_up((size_t)T * R * cdiv(Hd, 32) * 32 * 4, 256);
+    const size_t sp = align_up((size_t)T * R * cdiv(Hd, 32) * 4, 256);
+    *o_enc = 0; *o_cur = enc; *o_s6 = enc + cur; *o_s7 = enc + cur + sp; *total = enc + cur + 2 * sp;
+}
+
+size_t snn_det_head_workspace_bytes(int R, int D, int Hd, int K, int K4, int T) {
+    (void)K; (void)K4;
+    if (R <= 0 || D <= 0 || Hd <= 0 || T < 1) return 0;
+    size_t a, b, c, d, tot;
+    det_ws_layout(R, D, Hd, T, &a, &b, &c, &d, &tot);
+    return tot;
+}
+
+int snn_det_head_forward(const float* x, int R, int D, int Hd, int K, int K4, int T, const snn_params* p,
+                         const float* w6_packed, const float* w7_packed, const float* w_heads_packed,
+                         float* out_cls, float* out_bbox, uint32_t* spk6_count, uint32_t* spk7_count,
+                         float* sum_cls, float* sum_bbox, void* ws, size_t ws_bytes, snn_stream_t stream) {
+    if (!x || !p || !w6_packed || !w7_packed || !w_heads_packed || !out_cls || !out_bbox || !ws)
+        return fail(-1, "snn_det_head_forward: null argument");
+    if (R <= 0 || D <= 0 || Hd <= 0 || K <= 0 || K4 <= 0) return fail(-1, "snn_det_head_forward: bad shape");
+    if (check_T(T, "snn_det_head_forward")) return -1;
+    size_t o_enc, o_cur, o_s6, o_s7, need;
+    det_ws_layout(R, D, Hd, T, &o_enc, &o_cur, &o_s6, &o_s7, &need);
+    if (ws_bytes < need) return fail(-2, "snn_det_head_forward: workspace %zu < %zu bytes", ws_bytes, need);
+    hipStream_t s = (hipStream_t)stream;
+    uint32_t* enc = (uint32_t*)((char*)ws + o_enc);
+    float* cur = (float*)((char*)ws + o_cur);
+    uint32_t* s6 = (uint32_t*)((char*)ws + o_s6);
+    uint32_t* s7 = (uint32_t*)((char*)ws + o_s7);
+    const int Dw = cdiv(D, 32), Hw = cdiv(Hd, 32), Hp = Hw * 32;
+    int rc;
+    if (spk6_count) { if (hipMemsetAsync(spk6_count, 0, sizeof(uint32_t) * R, s) != hipSuccess) return fail(-3, "hipMemsetAsync failed"); }
+    if (spk7_count) { if (hipMemsetAsync(spk7_count, 0, sizeof(uint32_t) * R, s) != hipSuccess) return fail(-3, "hipMemsetAsync failed"); }
+    if ((rc = snn_encode_rows(x, R, D, T, p, enc, (size_t)R * Dw, stream))) return rc;
+    // fc6 for all T steps at once: rows m = t*R + r   (faster_rcnn.py:498)
+    if ((rc = snn_spike_gemm(enc, T * R, D, Hd, w6_packed, cur, Hp, stream))) return rc;
+    if ((rc = snn_lif_scan(cur, T, R, Hd, Hp, p, s6, (size_t)R * Hw, spk6_count, stream))) return rc;   // :499
+    if ((rc = snn_spike_gemm(s6, T * R, Hd, Hd, w7_packed, cur, Hp, stream))) return rc;                // :500
+    if ((rc = snn_lif_scan(cur, T, R, Hd, Hp, p, s7, (size_t)R * Hw, spk7_count, stream))) return rc;   // :501
+    return snn_li_heads(s7, (size_t)R * Hw, T, R, Hd, w_heads_packed, K, K4, p, out_cls, out_bbox, sum_cls,
+                        sum_bbox, stream);                                                               // :505-510
+}
+
+}  // extern "C"

@@ -1,0 +1,72 @@
+"""Drop-in for the reference's ``FastRCNNPredictorSNNFull`` (/root/reference/faster_rcnn.py:414-516)
+on the MI355X kernels: same constructor, ``forward`` signature, return values and ``state_dict``
+keys (``fc6.weight``, ``fc7.weight``, ``cls_score.weight``, ``bbox_pred.weight``; default
+``nn.Linear`` init).  ``RoIHeadsSNN.forward`` (roi_heads.py:1230) can call it unchanged.
+``spike_rates = True`` gives the faster_rcnn.py:520-618 variant (returns ONLY the rate list)."""
+import torch
+from torch import nn
+
+from . import ops
+from .rpn import _WeightCache
+
+
+class FastRCNNPredictorSNNFull(nn.Module):
+    """
+    Spiking box head + predictor: ``num_steps`` x { encoder -> fc6 -> LIF -> fc7 -> LIF ->
+    {cls_score -> LI, bbox_pred -> LI} } on the flattened RoI features.
+
+    Args (faster_rcnn.py:427-429):
+        in_channels (int): number of input features (C*7*7)
+        representation_size (int): size of the intermediate representation
+        num_classes (int): number of output classes (including background)
+        num_steps (int): simulation time steps (T_det)
+        only_one_bbox (bool): 4 box outputs instead of 4 per class
+    """
+
+    def __init__(self, in_channels, representation_size, num_classes, num_steps, only_one_bbox=False):
+        super().__init__()
+        self.num_steps = num_steps                                     # faster_rcnn.py:433
+        self.dt = 0.001                                                # :436
+        self.in_channels = in_channels
+        self.representation_size = representation_size
+        self.num_classes = num_classes
+        self.p_enc = ops.LIFParameters(v_th=torch.tensor(0.25))        # :444
+        self.p_lif = ops.LIFParameters(alpha=100, v_th=torch.tensor(0.1))   # :449,452
+        self.li_order = "jump_first"
+        self.spike_rates = False
+        self.fc6 = nn.Linear(in_channels, representation_size, bias=False)          # :448
+        self.fc7 = nn.Linear(representation_size, representation_size, bias=False)  # :451
+        self.cls_score = nn.Linear(representation_size, num_classes, bias=False)    # :455
+        self.only_one_bbox = only_one_bbox                                           # :460-467
+        self.bbox_pred = nn.Linear(representation_size, 4 if only_one_bbox else num_classes * 4, bias=False)
+        self._c6, self._c7, self._ch = _WeightCache(), _WeightCache(), _WeightCache()
+
+    def _params(self):
+        return ops.make_params(self.p_enc, self.p_lif, self.dt, self.li_order)
+
+    @torch.no_grad()
+    def forward(self, x):
+        T = int(self.num_steps)
+        Hd, K = self.representation_size, self.num_classes
+        K4 = self.bbox_pred.weight.shape[0]
+        w6 = self._c6.get((self.fc6.weight,), ops.pack_linear)
+        w7 = self._c7.get((self.fc7.weight,), ops.pack_linear)
+        wh = self._ch.get((self.cls_score.weight, self.bbox_pred.weight), ops.pack_heads)
+        x = x.flatten(start_dim=1)                                     # :473
+        if x.shape[1] != self.in_channels:
+            raise ValueError("expected %d input features, got %d" % (self.in_channels, x.shape[1]))
+        cls, bbox, (c6, c7, s_c, s_b) = ops.det_head_forward(x, Hd, K, K4, T, self._params(), w6, w7, wh,
+                                                            spike_rates=self.spike_rates)
+        if not self.spike_rates:
+            return cls, bbox                                           # :513-516
+        # faster_rcnn.py:568-618: (count / T).mean(dim=1) and literal "FLOPs" per layer
+        R, dev = x.shape[0], x.device
+        r6 = (c6.to(torch.float64) / float(T * Hd)).to(torch.float32).view(R, 1)
+        r7 = (c7.to(torch.float64) / float(T * Hd)).to(torch.float32).view(R, 1)
+        rc = (s_c / T).mean(dim=1, keepdim=True)
+        rb = (s_b / T).mean(dim=1, keepdim=True)
+        fl = lambda v: torch.tensor([v], device=dev).repeat(R, 1)
+        D = self.in_channels
+        return [torch.hstack((r6, fl(D * Hd))), torch.hstack((r7, fl(Hd * Hd))),
+                torch.hstack((rc, fl(Hd * K))),
+                torch.hstack((rb, fl(Hd * K if self.only_one_bbox else Hd * K * 4)))]

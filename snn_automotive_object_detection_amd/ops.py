@@ -1,0 +1,259 @@
+"""Thin torch-tensor wrappers over the C ABI (include/snn_hip.h).  torch is plumbing here: device
+memory, the current HIP stream, nothing else.  Every function raises if the input is not a CUDA/HIP
+tensor — there is no CPU or eager fallback."""
+import ctypes as C
+from typing import List, NamedTuple, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import snn_params, snn_rpn_level
+
+DT = 0.001                                   # rpn.py:55 / faster_rcnn.py:436
+
+
+class LIFParameters(NamedTuple):
+    """Mirror of norse.torch.LIFParameters for the attributes callers read
+    (``.p_enc.v_th``: custom_utils.py:321-329, train.py:477-478).  0-dim fp32 tensors."""
+    tau_syn_inv: torch.Tensor = torch.as_tensor(1.0 / 5e-3)
+    tau_mem_inv: torch.Tensor = torch.as_tensor(1.0 / 1e-2)
+    v_leak: torch.Tensor = torch.as_tensor(0.0)
+    v_th: torch.Tensor = torch.as_tensor(1.0)
+    v_reset: torch.Tensor = torch.as_tensor(0.0)
+    method: str = "super"
+    alpha: float = torch.as_tensor(100.0)
+
+
+def make_params(p_enc: LIFParameters, p_lif: LIFParameters, dt: float = DT,
+                li_order: str = "jump_first") -> snn_params:
+    """Form the fp32 constants exactly as Norse forms them: 0-dim fp32 tensor products
+    ``dt * tau_mem_inv`` and ``-dt * tau_syn_inv`` (norse lif.py / leaky_integrator.py)."""
+    ca = dt * p_lif.tau_mem_inv.to(torch.float32)
+    cb = -dt * p_lif.tau_syn_inv.to(torch.float32)
+    assert ca.dtype == torch.float32 and cb.dtype == torch.float32
+    return snn_params(float(ca), float(cb), float(p_lif.v_leak), float(p_lif.v_reset),
+                      float(p_enc.v_th.to(torch.float32)), float(p_lif.v_th.to(torch.float32)),
+                      {"jump_first": 0, "voltage_first": 1}[li_order], 0)
+
+
+def _need_gpu(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise _lib.SnnHipError("%s must live on the GPU (got %s); this path has no CPU fallback" % (what, t.device))
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    return t.detach().to(torch.float32).contiguous()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def cdiv(a, b):
+    return (a + b - 1) // b
+
+
+# ---------------------------------------------------------------------------------------------
+# weight packing
+# ---------------------------------------------------------------------------------------------
+def pack_conv3x3(w: torch.Tensor) -> torch.Tensor:
+    _need_gpu(w, "conv weight")
+    lib = _lib.load()
+    w = _f32c(w)
+    co, ci = w.shape[0], w.shape[1]
+    assert tuple(w.shape[2:]) == (3, 3)
+    out = torch.empty(lib.snn_packed_conv3x3_elems(co, ci), dtype=torch.float32, device=w.device)
+    _lib.check(lib.snn_pack_conv3x3_weight(_ptr(w), co, ci, _ptr(out), _stream()), "snn_pack_conv3x3_weight")
+    return out
+
+
+def pack_linear(w: torch.Tensor) -> torch.Tensor:
+    _need_gpu(w, "linear weight")
+    lib = _lib.load()
+    w = _f32c(w)
+    n, k = w.shape
+    out = torch.empty(lib.snn_packed_linear_elems(n, k), dtype=torch.float32, device=w.device)
+    _lib.check(lib.snn_pack_linear_weight(_ptr(w), n, k, _ptr(out), _stream()), "snn_pack_linear_weight")
+    return out
+
+
+def pack_heads(wa: torch.Tensor, wb: torch.Tensor) -> torch.Tensor:
+    _need_gpu(wa, "head weight")
+    lib = _lib.load()
+    wa = _f32c(wa).flatten(1)
+    wb = _f32c(wb).flatten(1)
+    na, k = wa.shape
+    nb = wb.shape[0]
+    assert wb.shape[1] == k
+    out = torch.empty(lib.snn_packed_heads_elems(na, nb, k), dtype=torch.float32, device=wa.device)
+    _lib.check(lib.snn_pack_heads_weight(_ptr(wa), na, _ptr(wb), nb, k, _ptr(out), _stream()), "snn_pack_heads_weight")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# stage-level ops (used by the teacher-forced parity tests)
+# ---------------------------------------------------------------------------------------------
+def encode_nchw(feat: torch.Tensor, T: int, p: snn_params) -> torch.Tensor:
+    """[N,C,H,W] fp32 -> spike bit-planes uint32 viewed as int32 [T, N*H*W, Cw]"""
+    _need_gpu(feat, "feature map")
+    lib = _lib.load()
+    feat = _f32c(feat)
+    N, Cc, H, W = feat.shape
+    Cw = cdiv(Cc, 32)
+    planes = torch.empty((T, N * H * W, Cw), dtype=torch.int32, device=feat.device)
+    _lib.check(lib.snn_encode_nchw(_ptr(feat), N, Cc, H, W, T, C.byref(p), _ptr(planes), N * H * W * Cw, _stream()),
+               "snn_encode_nchw")
+    return planes
+
+
+def encode_rows(x: torch.Tensor, T: int, p: snn_params) -> torch.Tensor:
+    _need_gpu(x, "x")
+    lib = _lib.load()
+    x = _f32c(x)
+    R, D = x.shape
+    Dw = cdiv(D, 32)
+    planes = torch.empty((T, R, Dw), dtype=torch.int32, device=x.device)
+    _lib.check(lib.snn_encode_rows(_ptr(x), R, D, T, C.byref(p), _ptr(planes), R * Dw, _stream()), "snn_encode_rows")
+    return planes
+
+
+def conv3x3_lif(enc: torch.Tensor, N: int, C_in: int, C_out: int, H: int, W: int, p: snn_params,
+                w_packed: torch.Tensor, want_counts: bool = False, want_currents: bool = False):
+    """returns spk planes [T, N*H*W, Nw] (+ counts [N]) (+ input currents [T, N*H*W, Nw*32])"""
+    _need_gpu(enc, "enc planes")
+    lib = _lib.load()
+    T = enc.shape[0]
+    Nw = cdiv(C_out, 32)
+    spk = torch.empty((T, N * H * W, Nw), dtype=torch.int32, device=enc.device)
+    counts = torch.zeros((N,), dtype=torch.int64, device=enc.device) if want_counts else None
+    cur = torch.zeros((T, N * H * W, Nw * 32), dtype=torch.float32, device=enc.device) if want_currents else None
+    _lib.check(lib.snn_conv3x3_lif(_ptr(enc), enc.shape[1] * enc.shape[2], N, C_in, C_out, H, W, T, C.byref(p),
+                                   _ptr(w_packed), _ptr(spk), N * H * W * Nw, _ptr(counts), _ptr(cur), _stream()),
+               "snn_conv3x3_lif")
+    out = (spk,) + ((counts,) if want_counts else ()) + ((cur,) if want_currents else ())
+    return out if len(out) > 1 else spk
+
+
+def spike_gemm(a_rows: torch.Tensor, K: int, N: int, w_packed: torch.Tensor) -> torch.Tensor:
+    """a_rows int32 [M, Kw] -> cur fp32 [M, Np]"""
+    _need_gpu(a_rows, "spike rows")
+    lib = _lib.load()
+    M = a_rows.shape[0]
+    Np = cdiv(N, 32) * 32
+    cur = torch.empty((M, Np), dtype=torch.float32, device=a_rows.device)
+    _lib.check(lib.snn_spike_gemm(_ptr(a_rows), M, K, N, _ptr(w_packed), _ptr(cur), Np, _stream()), "snn_spike_gemm")
+    return cur
+
+
+def lif_scan(cur: torch.Tensor, N: int, p: snn_params, want_counts: bool = False):
+    """cur fp32 [T, R, ldc] -> planes int32 [T, R, Nw]"""
+    _need_gpu(cur, "currents")
+    lib = _lib.load()
+    cur = _f32c(cur)
+    T, R, ldc = cur.shape
+    Nw = cdiv(N, 32)
+    spk = torch.empty((T, R, Nw), dtype=torch.int32, device=cur.device)
+    counts = torch.zeros((R,), dtype=torch.int32, device=cur.device) if want_counts else None
+    _lib.check(lib.snn_lif_scan(_ptr(cur), T, R, N, ldc, C.byref(p), _ptr(spk), R * Nw, _ptr(counts), _stream()),
+               "snn_lif_scan")
+    return (spk, counts) if want_counts else spk
+
+
+def li_heads(spk: torch.Tensor, K: int, w_heads_packed: torch.Tensor, NA: int, NB: int, p: snn_params,
+             want_sums: bool = False):
+    _need_gpu(spk, "spike planes")
+    lib = _lib.load()
+    T, M, Kw = spk.shape
+    dev = spk.device
+    out_a = torch.empty((M, NA), dtype=torch.float32, device=dev)
+    out_b = torch.empty((M, NB), dtype=torch.float32, device=dev)
+    sum_a = torch.empty_like(out_a) if want_sums else None
+    sum_b = torch.empty_like(out_b) if want_sums else None
+    _lib.check(lib.snn_li_heads(_ptr(spk), M * Kw, T, M, K, _ptr(w_heads_packed), NA, NB, C.byref(p), _ptr(out_a),
+                                _ptr(out_b), _ptr(sum_a), _ptr(sum_b), _stream()), "snn_li_heads")
+    return (out_a, out_b, sum_a, sum_b) if want_sums else (out_a, out_b)
+
+
+# ---------------------------------------------------------------------------------------------
+# whole heads
+# ---------------------------------------------------------------------------------------------
+class _Workspace:
+    """grow-only per-device scratch buffer (the C ABI never allocates)"""
+    def __init__(self):
+        self.buf = {}
+
+    def get(self, device: torch.device, nbytes: int) -> torch.Tensor:
+        key = (device.type, device.index)
+        b = self.buf.get(key)
+        if b is None or b.numel() < nbytes:
+            b = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+            self.buf[key] = b
+        return b
+
+
+_WS = _Workspace()
+
+
+def rpn_head_forward(feats: Sequence[torch.Tensor], C_: int, A: int, T: int, p: snn_params,
+                     w_shared_packed: torch.Tensor, w_heads_packed: torch.Tensor, spike_rates: bool = False):
+    """Returns (out_logits [P,A], out_bbox [P,4A], level_rows, extras) — position-major outputs."""
+    lib = _lib.load()
+    if len(feats) == 0 or len(feats) > _lib.SNN_MAX_LEVELS:
+        raise _lib.SnnHipError("RPN head takes 1..%d feature levels, got %d" % (_lib.SNN_MAX_LEVELS, len(feats)))
+    feats = [_f32c(f) for f in feats]
+    for f in feats:
+        _need_gpu(f, "feature map")
+        if f.dim() != 4 or f.shape[1] != C_:
+            raise _lib.SnnHipError("feature map must be [N,%d,H,W], got %s" % (C_, tuple(f.shape)))
+    dev = feats[0].device
+    lv = (snn_rpn_level * len(feats))()
+    rows = []
+    for l, f in enumerate(feats):
+        lv[l] = snn_rpn_level(f.data_ptr(), f.shape[0], f.shape[2], f.shape[3], 0)
+        rows.append(f.shape[0] * f.shape[2] * f.shape[3])
+    P = sum(rows)
+    max_n = max(f.shape[0] for f in feats)
+    ws_bytes = lib.snn_rpn_head_workspace_bytes(lv, len(feats), C_, A, T)
+    ws = _WS.get(dev, ws_bytes)
+    out_logits = torch.empty((P, A), dtype=torch.float32, device=dev)
+    out_bbox = torch.empty((P, 4 * A), dtype=torch.float32, device=dev)
+    counts = sum_l = sum_b = None
+    if spike_rates:
+        counts = torch.empty((len(feats), max_n), dtype=torch.int64, device=dev)
+        sum_l = torch.empty_like(out_logits)
+        sum_b = torch.empty_like(out_bbox)
+    _lib.check(lib.snn_rpn_head_forward(lv, len(feats), C_, A, T, C.byref(p), _ptr(w_shared_packed),
+                                        _ptr(w_heads_packed), _ptr(out_logits), _ptr(out_bbox), _ptr(counts),
+                                        _ptr(sum_l), _ptr(sum_b), _ptr(ws), ws.numel(), _stream()),
+               "snn_rpn_head_forward")
+    return out_logits, out_bbox, rows, (counts, sum_l, sum_b)
+
+
+def det_head_forward(x: torch.Tensor, Hd: int, K: int, K4: int, T: int, p: snn_params, w6_packed: torch.Tensor,
+                     w7_packed: torch.Tensor, w_heads_packed: torch.Tensor, spike_rates: bool = False):
+    lib = _lib.load()
+    _need_gpu(x, "box features")
+    x = _f32c(x).flatten(1)
+    R, D = x.shape
+    dev = x.device
+    out_cls = torch.empty((R, K), dtype=torch.float32, device=dev)
+    out_bbox = torch.empty((R, K4), dtype=torch.float32, device=dev)
+    c6 = c7 = s_c = s_b = None
+    if spike_rates:
+        c6 = torch.empty((R,), dtype=torch.int32, device=dev)
+        c7 = torch.empty((R,), dtype=torch.int32, device=dev)
+        s_c = torch.empty_like(out_cls)
+        s_b = torch.empty_like(out_bbox)
+    if R == 0:
+        return out_cls, out_bbox, (c6, c7, s_c, s_b)
+    ws_bytes = lib.snn_det_head_workspace_bytes(R, D, Hd, K, K4, T)
+    ws = _WS.get(dev, ws_bytes)
+    _lib.check(lib.snn_det_head_forward(_ptr(x), R, D, Hd, K, K4, T, C.byref(p), _ptr(w6_packed), _ptr(w7_packed),
+                                        _ptr(w_heads_packed), _ptr(out_cls), _ptr(out_bbox), _ptr(c6), _ptr(c7),
+                                        _ptr(s_c), _ptr(s_b), _ptr(ws), ws.numel(), _stream()),
+               "snn_det_head_forward")
+    return out_cls, out_bbox, (c6, c7, s_c, s_b)

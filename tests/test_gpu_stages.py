@@ -1,0 +1,144 @@
+"""GPU parity, stage by stage and teacher-forced (SURVEY.md §7 risk 1): each HIP kernel is fed the
+ORACLE's tensors of the previous stage and compared with the oracle's next stage.
+
+  encoder kernels      bit-exact (element-wise fp32 arithmetic, same rounding sequence)
+  LIF scan             bit-exact given identical input currents
+  conv / GEMM currents <= 1e-5 abs (fp32 summation order differs from oneDNN's — cannot be bit-exact)
+  conv+LIF spikes      identical except neurons whose oracle margin |v_dec - theta| is below the
+                       current tolerance at their FIRST differing step (flip budget)
+  LI heads             <= 1e-5 abs
+All calls go through the C ABI (ctypes)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import fixtures as FX
+from oracle import snn_oracle as OR
+from tests._util import planes_to_dense, dense_to_planes, nchw_to_rows
+
+pytestmark = pytest.mark.gpu
+
+CUR_TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def S():
+    import snn_automotive_object_detection_amd as pkg
+    from snn_automotive_object_detection_amd import ops
+    return ops
+
+
+def _params(ops, li_order="jump_first"):
+    return ops.make_params(ops.LIFParameters(v_th=torch.tensor(0.25)),
+                           ops.LIFParameters(alpha=100, v_th=torch.tensor(0.1)), 0.001, li_order)
+
+
+@pytest.mark.parametrize("name", sorted(FX.RPN_SPECS))
+def test_encoder_nchw_bit_exact(S, gpu_device, name):
+    spec = FX.RPN_SPECS[name]
+    feats, *_ = FX.rpn_inputs(spec)
+    for f in feats:
+        z = OR.encoder_spikes(f, spec["T"])                       # [T,N,C,H,W]
+        planes = S.encode_nchw(f.to(gpu_device), spec["T"], _params(S))
+        got = planes_to_dense(planes, f.shape[1])
+        assert np.array_equal(got, nchw_to_rows(z))
+        # padding channels (C..Cw*32) must be silent
+        full = planes_to_dense(planes, planes.shape[2] * 32)
+        assert full[:, :, f.shape[1]:].sum() == 0
+
+
+@pytest.mark.parametrize("name", sorted(FX.DET_SPECS))
+def test_encoder_rows_bit_exact(S, gpu_device, name):
+    spec = FX.DET_SPECS[name]
+    x = FX.det_inputs(spec)[0].flatten(1)
+    z = OR.encoder_spikes(x, spec["T"])                           # [T,R,D]
+    planes = S.encode_rows(x.to(gpu_device), spec["T"], _params(S))
+    assert np.array_equal(planes_to_dense(planes, x.shape[1]), z.numpy())
+
+
+def _first_flip_margins(spk_got, spk_exp, vdec_exp, theta=0.1):
+    """for every neuron whose spike train differs: oracle margin at the first differing step"""
+    diff = spk_got != spk_exp                                     # [T, ...]
+    any_diff = diff.any(axis=0)
+    first = diff.argmax(axis=0)
+    idx = np.nonzero(any_diff)
+    margins = np.abs(vdec_exp[(first[idx],) + idx] - theta)
+    return int(any_diff.sum()), margins
+
+
+@pytest.mark.parametrize("name", sorted(FX.RPN_SPECS))
+def test_conv3x3_lif_teacher_forced(S, gpu_device, name):
+    spec = FX.RPN_SPECS[name]
+    T, C = spec["T"], spec["C"]
+    feats, w_s, w_c, w_b = FX.rpn_inputs(spec)
+    wp = S.pack_conv3x3(w_s.to(gpu_device))
+    _, _, traces = OR.rpn_head_forward(feats, w_s, w_c, w_b, T, trace=True)
+    for f, tr in zip(feats, traces):
+        N, _, H, W = f.shape
+        enc = dense_to_planes(nchw_to_rows(tr["z"])).to(gpu_device)          # oracle's encoder spikes
+        spk, counts, cur = S.conv3x3_lif(enc, N, C, C, H, W, _params(S), wp, want_counts=True, want_currents=True)
+        # (i) input currents of every step
+        cur_exp = nchw_to_rows(tr["cur"])
+        cur_got = cur.cpu().numpy()[:, :, :C]
+        assert np.abs(cur_got - cur_exp).max() <= CUR_TOL
+        # (ii) spikes, with the flip budget
+        spk_exp = nchw_to_rows(tr["spk"])
+        spk_got = planes_to_dense(spk, C)
+        _, _, vdec = OR.lif_scan_from_currents(tr["cur"])
+        n_flip, margins = _first_flip_margins(spk_got, spk_exp, nchw_to_rows(vdec))
+        assert n_flip <= 2 + 1e-5 * spk_exp[0].size, "too many flipped neurons: %d" % n_flip
+        assert (margins <= 2 * CUR_TOL).all(), margins
+        # (iii) spike counts == popcount of what was written
+        got_counts = spk_got.reshape(T, N, H * W, C).sum(axis=(0, 2, 3))
+        assert np.array_equal(counts.cpu().numpy(), got_counts.astype(np.int64))
+
+
+@pytest.mark.parametrize("name", sorted(FX.DET_SPECS))
+def test_det_stages_teacher_forced(S, gpu_device, name):
+    spec = FX.DET_SPECS[name]
+    T, Hd, K = spec["T"], spec["Hd"], spec["K"]
+    x, w6, w7, wc, wb = FX.det_inputs(spec)
+    R, D = x.shape[0], x[0].numel()
+    _, _, tr = OR.det_head_forward(x, w6, w7, wc, wb, T, trace=True)
+    p = _params(S)
+    # fc6 currents from the oracle's encoder spikes, all T steps in one GEMM (rows t*R + r)
+    zp = dense_to_planes(tr["z"].numpy()).to(gpu_device)
+    cur6 = S.spike_gemm(zp.view(T * R, -1), D, Hd, S.pack_linear(w6.to(gpu_device)))
+    cur6 = cur6.view(T, R, -1)[:, :, :Hd].cpu()
+    assert (cur6 - tr["cur6"]).abs().max() <= CUR_TOL
+    # LIF scan on the ORACLE's currents is bit-exact (element-wise arithmetic only)
+    spk6, c6 = S.lif_scan(tr["cur6"].to(gpu_device), Hd, p, want_counts=True)
+    assert np.array_equal(planes_to_dense(spk6, Hd), tr["spk6"].numpy())
+    assert np.array_equal(c6.cpu().numpy(), tr["spk6"].sum(dim=(0, 2)).numpy().astype(np.int32))
+    # fc7 from the oracle's spk6
+    s6p = dense_to_planes(tr["spk6"].numpy()).to(gpu_device)
+    cur7 = S.spike_gemm(s6p.view(T * R, -1), Hd, Hd, S.pack_linear(w7.to(gpu_device))).view(T, R, -1)[:, :, :Hd].cpu()
+    assert (cur7 - tr["cur7"]).abs().max() <= CUR_TOL
+    spk7 = S.lif_scan(tr["cur7"].to(gpu_device), Hd, p)
+    assert np.array_equal(planes_to_dense(spk7, Hd), tr["spk7"].numpy())
+    # LI heads from the oracle's spk7: last membranes and their sums over t
+    s7p = dense_to_planes(tr["spk7"].numpy()).to(gpu_device)
+    wh = S.pack_heads(wc.to(gpu_device), wb.to(gpu_device))
+    o_c, o_b, s_c, s_b = S.li_heads(s7p, Hd, wh, wc.shape[0], wb.shape[0], p, want_sums=True)
+    assert (o_c.cpu() - tr["mem_cls"][-1]).abs().max() <= CUR_TOL
+    assert (o_b.cpu() - tr["mem_bbox"][-1]).abs().max() <= CUR_TOL
+    assert (s_c.cpu() - tr["mem_cls"].sum(0)).abs().max() <= T * CUR_TOL
+    assert (s_b.cpu() - tr["mem_bbox"].sum(0)).abs().max() <= T * CUR_TOL
+
+
+@pytest.mark.parametrize("li_order", ["jump_first", "voltage_first"])
+def test_li_heads_both_orders(S, gpu_device, li_order):
+    spec = FX.RPN_SPECS["rpn_c64_A5_T8"]
+    T, C, A = spec["T"], spec["C"], spec["A"]
+    feats, w_s, w_c, w_b = FX.rpn_inputs(spec)
+    _, _, traces = OR.rpn_head_forward(feats, w_s, w_c, w_b, T, trace=True)
+    spk = traces[0]["spk"]
+    exp_o, _ = OR.li_last_from_spikes(spk, w_c, li_order, conv=True)
+    exp_b, _ = OR.li_last_from_spikes(spk, w_b, li_order, conv=True)
+    planes = dense_to_planes(nchw_to_rows(spk)).to(gpu_device)
+    wh = S.pack_heads(w_c.to(gpu_device), w_b.to(gpu_device))
+    o_a, o_b = S.li_heads(planes, C, wh, A, 4 * A, _params(S, li_order))
+    N, _, H, W = exp_o.shape
+    assert (o_a.cpu().view(N, H, W, A).permute(0, 3, 1, 2) - exp_o).abs().max() <= CUR_TOL
+    assert (o_b.cpu().view(N, H, W, 4 * A).permute(0, 3, 1, 2) - exp_b).abs().max() <= CUR_TOL

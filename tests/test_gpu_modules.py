@@ -76,9 +76,11 @@ def test_rpn_head_spike_rates_vs_golden(pkg, gpu_device, name):
             e = exp["rate%d_%d" % (l, j)]
             assert r.dtype == np.float32 and r.shape == e.shape
             assert np.array_equal(r[:, 1], e[:, 1])                          # "FLOPs" column: exact
-            np.testing.assert_allclose(r[:, 0], e[:, 0], rtol=2e-3, atol=2e-6)   # a flipped spike moves a mean by < 1e-5
+            # j=0: spikes/(T*C*H*W); j=1,2: means of signed LI membranes (they cancel, so the bound is
+            # absolute: one flipped hidden spike moves such a mean by ~1e-3/(A*H*W))
+            np.testing.assert_allclose(r[:, 0], e[:, 0], rtol=2e-3 if j == 0 else 1e-4, atol=2e-6 if j == 0 else 2e-5)
         d = np.abs(logits[l].cpu().numpy() - exp["logits%d" % l])
-        assert np.quantile(d, 0.999) <= TOL
+        assert (d > TOL).sum() <= 3 * spec["A"]        # at most a few flipped positions
 
 
 def _det_module(pkg, spec, dev, inp):

@@ -96,6 +96,20 @@ int snn_rpn_head_forward(const snn_rpn_level* levels_host, int n_levels, int C, 
                          unsigned long long* spike_counts, float* sum_logits, float* sum_bbox,
                          void* workspace, size_t workspace_bytes, snn_stream_t stream);
 
+/* Same call restricted to a subset of its three stages (they communicate through the workspace);
+ * lets a profiler bracket the dominant kernel exactly as the full call launches it. */
+#define SNN_STAGE_ENCODE 1
+#define SNN_STAGE_CONV_LIF 2
+#define SNN_STAGE_LI_HEADS 4
+#define SNN_STAGE_ALL 7
+int snn_rpn_head_forward_stages(const snn_rpn_level* levels_host, int n_levels, int C, int A, int T,
+                                const snn_params* p_host,
+                                const float* w_shared_packed, const float* w_heads_packed,
+                                float* out_logits, float* out_bbox,
+                                unsigned long long* spike_counts, float* sum_logits, float* sum_bbox,
+                                void* workspace, size_t workspace_bytes, int stage_mask,
+                                snn_stream_t stream);
+
 /* ---- detector (RoI) head -------------------------------------------------------------------- */
 /* x[R][D] (the flattened [R][C][7][7] RoI features, faster_rcnn.py:473); out_cls[R][K],
  * out_bbox[R][K4].  Optional spike-rate outputs of the faster_rcnn.py:520-618 variant:

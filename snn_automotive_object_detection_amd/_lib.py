@@ -40,6 +40,10 @@ SYMBOLS = {
     "snn_rpn_head_forward": (C.c_int, [C.POINTER(snn_rpn_level), C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.POINTER(snn_params), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, c_stream]),
+    "snn_rpn_head_forward_stages": (C.c_int, [C.POINTER(snn_rpn_level), C.c_int, C.c_int, C.c_int, C.c_int,
+                                              C.POINTER(snn_params), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int,
+                                              c_stream]),
     "snn_det_head_workspace_bytes": (C.c_size_t, [C.c_int] * 6),
     "snn_det_head_forward": (C.c_int, [C.c_void_p] + [C.c_int] * 6 + [C.POINTER(snn_params)] +
                              [C.c_void_p] * 10 + [C.c_size_t, c_stream]),

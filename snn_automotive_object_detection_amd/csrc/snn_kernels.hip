@@ -708,10 +708,10 @@ size_t snn_rpn_head_workspace_bytes(const snn_rpn_level* lv, int n_levels, int C
     return 2 * plane;     // encoder planes + shared-LIF spike planes
 }
 
-int snn_rpn_head_forward(const snn_rpn_level* lv, int n_levels, int C, int A, int T, const snn_params* p,
-                         const float* w_shared_packed, const float* w_heads_packed, float* out_logits,
-                         float* out_bbox, unsigned long long* spike_counts, float* sum_logits, float* sum_bbox,
-                         void* ws, size_t ws_bytes, snn_stream_t stream) {
+int snn_rpn_head_forward_stages(const snn_rpn_level* lv, int n_levels, int C, int A, int T, const snn_params* p,
+                                const float* w_shared_packed, const float* w_heads_packed, float* out_logits,
+                                float* out_bbox, unsigned long long* spike_counts, float* sum_logits,
+                                float* sum_bbox, void* ws, size_t ws_bytes, int stage_mask, snn_stream_t stream) {
     if (!lv || !p || !w_shared_packed || !w_heads_packed || !out_logits || !out_bbox || !ws)
         return fail(-1, "snn_rpn_head_forward: null argument");
     if (n_levels <= 0 || n_levels > SNN_MAX_LEVELS) return fail(-1, "snn_rpn_head_forward: n_levels=%d", n_levels);
@@ -730,19 +730,31 @@ int snn_rpn_head_forward(const snn_rpn_level* lv, int n_levels, int C, int A, in
     uint32_t* spk = (uint32_t*)((char*)ws + need / 2);
     hipStream_t s = (hipStream_t)stream;
     long long pos = 0;
-    for (int l = 0; l < n_levels; ++l) {
+    for (int l = 0; l < n_levels && (stage_mask & SNN_STAGE_ENCODE); ++l) {
         const int rc = snn_encode_nchw(lv[l].feat, lv[l].N, C, lv[l].H, lv[l].W, T, p, enc + (size_t)pos * Cw, stride, stream);
         if (rc) return rc;
         pos += (long long)lv[l].N * lv[l].H * lv[l].W;
     }
-    if (spike_counts) {
-        hipError_t e = hipMemsetAsync(spike_counts, 0, sizeof(unsigned long long) * n_levels * max_n, s);
-        if (e != hipSuccess) return fail(-3, "hipMemsetAsync failed: %s", hipGetErrorString(e));
+    if (stage_mask & SNN_STAGE_CONV_LIF) {
+        if (spike_counts) {
+            hipError_t e = hipMemsetAsync(spike_counts, 0, sizeof(unsigned long long) * n_levels * max_n, s);
+            if (e != hipSuccess) return fail(-3, "hipMemsetAsync failed: %s", hipGetErrorString(e));
+        }
+        int rc = launch_conv(lv, n_levels, C, C, T, p, enc, stride, w_shared_packed, spk, stride, spike_counts, max_n, nullptr, s);
+        if (rc) return rc;
     }
-    int rc = launch_conv(lv, n_levels, C, C, T, p, enc, stride, w_shared_packed, spk, stride, spike_counts, max_n, nullptr, s);
-    if (rc) return rc;
+    if (!(stage_mask & SNN_STAGE_LI_HEADS)) return 0;
     return snn_li_heads(spk, stride, T, (int)P, C, w_heads_packed, A, 4 * A, p, out_logits, out_bbox, sum_logits,
                         sum_bbox, stream);
+}
+
+int snn_rpn_head_forward(const snn_rpn_level* lv, int n_levels, int C, int A, int T, const snn_params* p,
+                         const float* w_shared_packed, const float* w_heads_packed, float* out_logits,
+                         float* out_bbox, unsigned long long* spike_counts, float* sum_logits, float* sum_bbox,
+                         void* ws, size_t ws_bytes, snn_stream_t stream) {
+    return snn_rpn_head_forward_stages(lv, n_levels, C, A, T, p, w_shared_packed, w_heads_packed, out_logits,
+                                       out_bbox, spike_counts, sum_logits, sum_bbox, ws, ws_bytes, SNN_STAGE_ALL,
+                                       stream);
 }
 
 static void det_ws_layout(int R, int D, int Hd, int T, size_t* o_enc, size_t* o_cur, size_t* o_s6, size_t* o_s7,

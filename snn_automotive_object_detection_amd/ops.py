@@ -199,8 +199,10 @@ _WS = _Workspace()
 
 
 def rpn_head_forward(feats: Sequence[torch.Tensor], C_: int, A: int, T: int, p: snn_params,
-                     w_shared_packed: torch.Tensor, w_heads_packed: torch.Tensor, spike_rates: bool = False):
-    """Returns (out_logits [P,A], out_bbox [P,4A], level_rows, extras) — position-major outputs."""
+                     w_shared_packed: torch.Tensor, w_heads_packed: torch.Tensor, spike_rates: bool = False,
+                     stage_mask: int = 7):
+    """Returns (out_logits [P,A], out_bbox [P,4A], level_rows, extras) — position-major outputs.
+    ``stage_mask`` (SNN_STAGE_*: 1 encode, 2 conv+LIF, 4 LI heads) is for profiling only."""
     lib = _lib.load()
     if len(feats) == 0 or len(feats) > _lib.SNN_MAX_LEVELS:
         raise _lib.SnnHipError("RPN head takes 1..%d feature levels, got %d" % (_lib.SNN_MAX_LEVELS, len(feats)))
@@ -226,9 +228,10 @@ def rpn_head_forward(feats: Sequence[torch.Tensor], C_: int, A: int, T: int, p: 
         counts = torch.empty((len(feats), max_n), dtype=torch.int64, device=dev)
         sum_l = torch.empty_like(out_logits)
         sum_b = torch.empty_like(out_bbox)
-    _lib.check(lib.snn_rpn_head_forward(lv, len(feats), C_, A, T, C.byref(p), _ptr(w_shared_packed),
-                                        _ptr(w_heads_packed), _ptr(out_logits), _ptr(out_bbox), _ptr(counts),
-                                        _ptr(sum_l), _ptr(sum_b), _ptr(ws), ws.numel(), _stream()),
+    _lib.check(lib.snn_rpn_head_forward_stages(lv, len(feats), C_, A, T, C.byref(p), _ptr(w_shared_packed),
+                                               _ptr(w_heads_packed), _ptr(out_logits), _ptr(out_bbox),
+                                               _ptr(counts), _ptr(sum_l), _ptr(sum_b), _ptr(ws), ws.numel(),
+                                               int(stage_mask), _stream()),
                "snn_rpn_head_forward")
     return out_logits, out_bbox, rows, (counts, sum_l, sum_b)
 

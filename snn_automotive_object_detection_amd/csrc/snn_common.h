@@ -45,29 +45,45 @@ __device__ __forceinline__ bool lif_step(const float cur, float& v, float& i, co
 __device__ __forceinline__ int acc_row(const int r, const int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
 // One 32-deep reduction chunk on the fp32 matrix cores.
-//   aw[mt]  : this lane's spike word for row (lane&31) of M-tile mt, already shifted right by
-//             16*(lane>>5): MFMA q consumes reduction index k = q + 16*(lane>>5)  -> bit q
-//   bw      : LDS image of the packed weights for this wave's first N-tile:
-//             [nt][qq][lane] float4, element r of it = W[k = 4*qq + r + 16*(lane>>5)][n = lane&31]
+//   a[mt][qq] : 4 consecutive fp32 spike values (0.0f / 1.0f) of row (lane&31) of M-tile mt, read by one
+//               ds_read_b128 from the expanded LDS image: reduction indices k = 4*qq + r + 16*(lane>>5)
+//   b[qq]     : weights W[k = 4*qq + r + 16*(lane>>5)][n = lane&31], one coalesced 1-KiB wave load each
+//               from the fragment-major packed image
+// The loop body is MFMA only.  On gfx950 the fp32 MFMA (64 FLOP/clk/SIMD = the VALU rate) loses ~6.5
+// cycles of matrix-pipe time per VALU instruction issued beside it (tools/mfma_probe*.hip), so spike
+// bits are never converted inside this loop.
 // v_mfma_f32_32x32x2_f32 is an exact k-ordered fp32 fma chain (one rounding per product).
-template <int MT, int NT>
-__device__ __forceinline__ void mma_chunk(f32x16 (&acc)[MT][NT], const uint32_t (&aw)[MT],
-                                          const f32x4* __restrict__ bw, const int lane) {
+template <int MT>
+__device__ __forceinline__ void mma_chunk(f32x16 (&acc)[MT], const f32x4 (&a)[MT][4], const f32x4 (&b)[4]) {
 #pragma unroll
-    for (int qq = 0; qq < 4; ++qq) {
-        f32x4 b[NT];
+    for (int qq = 0; qq < 4; ++qq)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) b[nt] = bw[(nt * 4 + qq) * 64 + lane];
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int q = qq * 4 + r;
+            for (int mt = 0; mt < MT; ++mt)
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][qq][r], b[qq][r], acc[mt], 0, 0, 0);
+}
+
+// half a chunk (qq = 2*HALF, 2*HALF+1): lets the A operands be fetched from LDS half a chunk ahead with
+// only 8*MT live registers per half
+template <int MT, int HALF>
+__device__ __forceinline__ void mma_half(f32x16 (&acc)[MT], const f32x4 (&a)[MT][2], const f32x4 (&b)[4]) {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const float a = (float)((aw[mt] >> q) & 1u);
+    for (int q2 = 0; q2 < 2; ++q2)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[nt][r], acc[mt][nt], 0, 0, 0);
-            }
-        }
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][q2][r], b[2 * HALF + q2][r], acc[mt], 0, 0, 0);
+}
+
+// 32 spike bits -> 32 fp32 values (0.0f / 1.0f) written as 8 x 16 B to dst (LDS)
+__device__ __forceinline__ void expand_word(uint32_t w, float* dst) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        f32x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (float)((w >> (4 * j + r)) & 1u);
+        *reinterpret_cast<f32x4*>(dst + 4 * j) = v;
     }
 }

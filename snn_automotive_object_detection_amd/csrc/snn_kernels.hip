@@ -150,14 +150,17 @@ __global__ __launch_bounds__(256) void k_encode_rows(const float* __restrict__ x
 // ------------------------------------------------------------------------------------------------
 // K2: fused 3x3 spike convolution (implicit GEMM on the fp32 matrix cores) + LIF over the T loop.
 //
-// Work-group = 512 threads = 8 waves (2 along M x 4 along N); tile = 64 positions (an 8x8 patch of
-// one image of one level) x 256 output channels; each wave owns 32 positions x 64 channels
-// (1 x 2 MFMA tiles of 32x32).  Per lane: 32 accumulators + 32 membrane voltages + 32 synaptic
-// currents stay in registers for the whole T loop; nothing but spike bits is written to HBM.
-//   A operand: encoder spike bits of the (8+2)x(8+2) halo of the patch, one LDS image per step
-//              ([channel word][halo position]); a lane turns bit q of its word into 0.0f/1.0f.
-//   B operand: packed weights, one 32-deep chunk (32 KB) per barrier, double-buffered in LDS,
-//              next chunk prefetched into registers while the MFMAs of the current one run.
+// Work-group = 512 threads = 8 waves; tile = 64 positions (an 8x8 patch of one image of one level)
+// x 256 output channels; wave w owns all 64 positions x channels [32w, 32w+32)  (2 x 1 MFMA tiles).
+// Per lane: 32 accumulators + 32 membrane voltages + 32 synaptic currents stay in registers for the
+// whole T loop; nothing but spike bits is written to HBM.
+//   A operand: the encoder spikes of the (8+2)x(8+2) halo of the patch are expanded ONCE per time
+//              step from bit-planes to an fp32 LDS image [halo position][channel] (104 KB at C=256);
+//              every (tap, channel-chunk) operand is then a plain ds_read_b128 - the MFMA loop holds
+//              no VALU instruction (on gfx950 each one costs ~6.5 cycles of fp32 matrix-pipe time).
+//   B operand: every wave streams its own 4-KiB weight fragment per 32-deep chunk straight from the
+//              packed global image (L2-resident: 2.4 MB) into registers, one chunk ahead of the
+//              MFMAs (ping-pong register sets) - no LDS staging, no per-chunk barrier.
 // Spatial tiles are independent for the whole T loop (the only coupling is the conv halo on the
 // *encoder* spikes), so there is no inter-work-group synchronisation.
 // ------------------------------------------------------------------------------------------------
@@ -183,17 +186,20 @@ struct ConvArgs {
 #define CONV_PH 8
 #define CONV_PW 8
 #define CONV_HALO ((CONV_PH + 2) * (CONV_PW + 2))
+#define CONV_BNT 8                                // n-tiles (waves) per block
+#define CONV_APAD 4                               // floats of padding per halo position (bank spread)
+#define CONV_MAX_CW 12                            // 100 x (384+4) x 4 B = 155 KB of LDS
+#define CONV_HW ((CONV_HALO * CONV_MAX_CW + 511) / 512)   // halo words per thread
 
+template <bool DBG>
 __global__ __launch_bounds__(512) void k_conv3x3_lif(const ConvArgs args) {
-    constexpr int WN = 4, NT = 2, BNT = WN * NT;          // 8 n-tiles (256 channels) per block
+    constexpr int MT = 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    f32x4* ldsB = reinterpret_cast<f32x4*>(smem);                       // 2 x BNT*256 float4
-    uint32_t* ldsA = reinterpret_cast<uint32_t*>(smem + 2 * BNT * 4096); // Cw * CONV_HALO words
+    float* ldsA = reinterpret_cast<float*>(smem);                  // [CONV_HALO][CST]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 31, lh = lane >> 5;
 
     // ---- which tile ----
@@ -207,121 +213,164 @@ __global__ __launch_bounds__(512) void k_conv3x3_lif(const ConvArgs args) {
     const int y0 = (rem / L.tiles_x) * CONV_PH, x0 = (rem % L.tiles_x) * CONV_PW;
     const int H = L.H, W = L.W;
     const size_t img_base = (size_t)L.pos_base + (size_t)n * H * W;
-    const int nb = blockIdx.y;                       // 256-channel output block
     const int Cw = args.Cw, Nw = args.Nw;
-    const int nbt = min(BNT, Nw - nb * BNT);         // n-tiles present in this block
+    const int CST = Cw * 32 + CONV_APAD;             // floats per halo position
+    const int ntg = blockIdx.y * CONV_BNT + wave;    // this wave's 32-channel output tile
+    const bool active = ntg < Nw;                    // wave-uniform
 
-    // this lane's A row: position (py, px) of the patch
-    const int py = wm * 4 + (li >> 3), px = li & 7;
-    const int a_off = py * (CONV_PW + 2) + px;
+    // this lane's A rows: float offset of position (py, px) of the patch for the two M-tiles
+    int a_off[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) a_off[mt] = ((mt * 4 + (li >> 3)) * (CONV_PW + 2) + (li & 7)) * CST + 16 * lh;
 
-    // which rows (register r) of this lane are inside the image -> spike mask
+    // which (mt, r) accumulator rows of this lane are inside the image -> spike mask
     uint32_t valid_bits = 0;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = acc_row(r, lh);
-        const int yy = y0 + wm * 4 + (row >> 3), xx = x0 + (row & 7);
-        valid_bits |= (uint32_t)(yy < H && xx < W) << r;
-    }
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = acc_row(r, lh);
+            const int yy = y0 + mt * 4 + (row >> 3), xx = x0 + (row & 7);
+            valid_bits |= (uint32_t)(yy < H && xx < W) << (mt * 16 + r);
+        }
 
-    f32x16 acc[1][NT];
-    float v[NT][16], cur_i[NT][16];
+    f32x16 acc[MT];
+    float v[MT][16], cur_i[MT][16];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { v[nt][r] = args.p.v_leak; cur_i[nt][r] = 0.0f; }   // state fallback
+        for (int r = 0; r < 16; ++r) { v[mt][r] = args.p.v_leak; cur_i[mt][r] = 0.0f; }   // state fallback
 
     const int KC = 9 * Cw;
-    const f32x4* wsrc = reinterpret_cast<const f32x4*>(args.wpk) + (size_t)nb * BNT * 256;
+    // weight fragment of (chunk kc, tile ntg): 256 float4, lane reads [qq*64 + lane]
+    const f32x4* wsrc = reinterpret_cast<const f32x4*>(args.wpk) + (size_t)(active ? ntg : 0) * 256 + lane;
     const size_t wchunk = (size_t)Nw * 256;          // float4 per reduction chunk (all n-tiles)
-    const int nB4 = nbt * 256;                       // float4 of B this block needs per chunk
 
-    // ---- prologue: B chunk 0 -> LDS buffer 0 ----
-    f32x4 pre[4];
+    // ---- halo spike words of one time step: thread owns words idx = tid + 512*j ----
+    uint32_t hw[CONV_HW];
+    auto fetch_halo = [&](int t) {
+        const uint32_t* enc_t = args.enc + (size_t)t * args.enc_stride;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const int idx = tid + 512 * s;
-        pre[s] = (idx < nB4) ? wsrc[idx] : f32x4{0.f, 0.f, 0.f, 0.f};
-        ldsB[idx] = pre[s];
-    }
-    int buf = 0;
+        for (int j = 0; j < CONV_HW; ++j) {
+            const int idx = tid + 512 * j;
+            hw[j] = 0;
+            if (idx < CONV_HALO * Cw) {
+                const int cc = idx % Cw, hp = idx / Cw;
+                const int y = y0 - 1 + hp / (CONV_PW + 2), x = x0 - 1 + hp % (CONV_PW + 2);
+                if (y >= 0 && y < H && x >= 0 && x < W) hw[j] = enc_t[(img_base + (size_t)y * W + x) * Cw + cc];
+            }
+        }
+    };
+    auto expand_halo = [&]() {
+#pragma unroll
+        for (int j = 0; j < CONV_HW; ++j) {
+            const int idx = tid + 512 * j;
+            if (idx < CONV_HALO * Cw) expand_word(hw[j], ldsA + (idx / Cw) * CST + (idx % Cw) * 32);
+        }
+    };
+
+    // ---- software pipeline state: chunk whose operands are fetched NEXT ----
+    const f32x4* wnext = wsrc;       // weights: wraps around at KC (next step re-reads the same image)
+    int kcB = 0;
+    auto load_b = [&](f32x4 (&dst)[4]) {
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) dst[qq] = wnext[qq * 64];
+        if (++kcB == KC) { kcB = 0; wnext = wsrc; } else wnext += wchunk;
+    };
+    int tapA = 0, ccA = 0;           // spike operands: (tap, channel word) of the chunk being fetched
+    const float* a_base = ldsA;
+    auto load_a_lo = [&](f32x4 (&dst)[MT][2]) {      // first half (qq 0,1) of the next chunk
+        a_base = ldsA + ((tapA / 3) * (CONV_PW + 2) + (tapA % 3)) * CST + ccA * 32;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int q2 = 0; q2 < 2; ++q2) dst[mt][q2] = *reinterpret_cast<const f32x4*>(a_base + a_off[mt] + 4 * q2);
+        if (++ccA == Cw) { ccA = 0; ++tapA; }
+    };
+    auto load_a_hi = [&](f32x4 (&dst)[MT][2]) {      // second half (qq 2,3) of the same chunk
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int q2 = 0; q2 < 2; ++q2) dst[mt][q2] = *reinterpret_cast<const f32x4*>(a_base + a_off[mt] + 8 + 4 * q2);
+    };
+
+    f32x4 b0[4], b1[4];
+    f32x4 alo[MT][2], ahi[MT][2];
+    fetch_halo(0);
+    if (active) load_b(b0);
     unsigned long long n_spikes = 0;
 
     for (int t = 0; t < args.T; ++t) {
-        // ---- encoder spike halo of step t -> LDS ([word][halo position]) ----
-        const uint32_t* enc_t = args.enc + (size_t)t * args.enc_stride;
-        for (int idx = tid; idx < CONV_HALO * Cw; idx += 512) {
-            const int cc = idx % Cw, hp = idx / Cw;
-            const int y = y0 - 1 + hp / (CONV_PW + 2), x = x0 - 1 + hp % (CONV_PW + 2);
-            uint32_t w = 0;
-            if (y >= 0 && y < H && x >= 0 && x < W) w = enc_t[(img_base + (size_t)y * W + x) * Cw + cc];
-            ldsA[cc * CONV_HALO + hp] = w;
-        }
-        __syncthreads();
+        __syncthreads();                                   // everyone done reading the previous image
+        expand_halo();
+        if (t + 1 < args.T) fetch_halo(t + 1);             // latency hidden behind this step's MFMAs
+        __syncthreads();                                   // image of step t complete
+        // SIMD partners (waves w and w+4) run the same program; half a chunk of skew keeps one of
+        // them issuing MFMAs while the other refills its operands
+        if (wave >= 4) __builtin_amdgcn_s_sleep(16);
+        if (active) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[0][nt][r] = 0.0f;
-
-        int kc = 0;
-        for (int tap = 0; tap < 9; ++tap) {
-            const int a_tap = a_off + (tap / 3) * (CONV_PW + 2) + (tap % 3);
-            for (int cc = 0; cc < Cw; ++cc, ++kc) {
-                // prefetch the next reduction chunk (wraps to chunk 0 for the next time step)
-                const int kn = (kc + 1 == KC) ? 0 : kc + 1;
-                const f32x4* wnext = wsrc + (size_t)kn * wchunk;
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const int idx = tid + 512 * s;
-                    pre[s] = (idx < nB4) ? wnext[idx] : f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-                uint32_t aw[1];
-                aw[0] = ldsA[cc * CONV_HALO + a_tap] >> (16 * lh);
-                mma_chunk<1, NT>(acc, aw, ldsB + buf * (BNT * 256) + wn * NT * 256, lane);
-                f32x4* dstB = ldsB + (buf ^ 1) * (BNT * 256);
-#pragma unroll
-                for (int s = 0; s < 4; ++s) dstB[tid + 512 * s] = pre[s];
-                __syncthreads();
-                buf ^= 1;
+                for (int r = 0; r < 16; ++r) acc[mt][r] = 0.0f;
+            tapA = 0; ccA = 0;
+            load_a_lo(alo);
+            // A operands run half a chunk ahead of the MFMAs, B operands one chunk ahead
+            auto chunk = [&](int kc, const f32x4 (&bcur)[4], f32x4 (&bnext)[4]) {
+                load_b(bnext);                 // chunk kc+1 (or chunk 0 of the next time step)
+                load_a_hi(ahi);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_half<MT, 0>(acc, alo, bcur);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kc + 1 < KC) load_a_lo(alo);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_half<MT, 1>(acc, ahi, bcur);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            int kc = 0;
+            for (; kc + 1 < KC; kc += 2) {     // two chunks per trip: ping-pong weight registers, no copies
+                chunk(kc, b0, b1);
+                chunk(kc + 1, b1, b0);
             }
-        }
-
-        if (args.dbg_cur != nullptr) {     // test hook: dump the step's input currents
-            float* d = args.dbg_cur + (size_t)t * (args.spk_stride * 32);
+            if (kc < KC) {                     // odd chunk count (C_in = 32 * odd)
+                chunk(kc, b0, b1);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int ntg = nb * BNT + wn * NT + nt;
+                for (int qq = 0; qq < 4; ++qq) b0[qq] = b1[qq];
+            }
+            if (DBG) {                         // test-hook instantiation: dump the step's input currents
+                float* d = args.dbg_cur + (size_t)t * (args.spk_stride * 32);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = acc_row(r, lh);
+                        const int yy = y0 + mt * 4 + (row >> 3), xx = x0 + (row & 7);
+                        if (yy < H && xx < W)
+                            d[(img_base + (size_t)yy * W + xx) * (Nw * 32) + ntg * 32 + li] = acc[mt][r];
+                    }
+            }
+            // ---- LIF epilogue in registers; spikes leave as ballots ----
+            uint32_t myword = 0;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = acc_row(r, lh);
-                    const int yy = y0 + wm * 4 + (row >> 3), xx = x0 + (row & 7);
-                    if (yy < H && xx < W && ntg < Nw)
-                        d[(img_base + (size_t)yy * W + xx) * (Nw * 32) + ntg * 32 + li] = acc[0][nt][r];
+                    bool z = lif_step(acc[mt][r], v[mt][r], cur_i[mt][r], args.p);
+                    z = z && ((valid_bits >> (mt * 16 + r)) & 1u);
+                    const unsigned long long m = __ballot(z);
+                    n_spikes += __popcll(m);
+                    const int L0 = mt * 32 + r * 2;
+                    myword = (lane == L0) ? (uint32_t)m : myword;
+                    myword = (lane == L0 + 1) ? (uint32_t)(m >> 32) : myword;
                 }
             }
-        }
-        // ---- LIF epilogue in registers; spikes leave as ballots ----
-        uint32_t myword = 0;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                bool z = lif_step(acc[0][nt][r], v[nt][r], cur_i[nt][r], args.p);
-                z = z && ((valid_bits >> r) & 1u);
-                const unsigned long long m = __ballot(z);
-                n_spikes += __popcll(m);
-                const int L0 = nt * 32 + r * 2;
-                myword = (lane == L0) ? (uint32_t)m : myword;
-                myword = (lane == L0 + 1) ? (uint32_t)(m >> 32) : myword;
+            {   // lane -> (mt, r, half): one 32-channel word of one position
+                const int mt = lane >> 5, r = (lane >> 1) & 15, hh = lane & 1;
+                const int row = acc_row(r, hh);
+                const int yy = y0 + mt * 4 + (row >> 3), xx = x0 + (row & 7);
+                if (yy < H && xx < W)
+                    args.spk[(size_t)t * args.spk_stride + (img_base + (size_t)yy * W + xx) * Nw + ntg] = myword;
             }
-        }
-        {   // lane -> (nt, r, half): one 32-channel word of one position
-            const int nt = lane >> 5, r = (lane >> 1) & 15, hh = lane & 1;
-            const int row = acc_row(r, hh);
-            const int yy = y0 + wm * 4 + (row >> 3), xx = x0 + (row & 7);
-            const int ntg = nb * BNT + wn * NT + nt;
-            if (yy < H && xx < W && ntg < Nw)
-                args.spk[(size_t)t * args.spk_stride + (img_base + (size_t)yy * W + xx) * Nw + ntg] = myword;
         }
     }
     if (args.counts != nullptr && lane == 0 && n_spikes != 0)
@@ -330,8 +379,14 @@ __global__ __launch_bounds__(512) void k_conv3x3_lif(const ConvArgs args) {
 
 // ------------------------------------------------------------------------------------------------
 // K3: time-batched spike GEMM  cur[M][ldo] = A_bits[M][K] x W[K][N]   (rows m = t*R + r)
-// A words come straight from global/L2 (one word per row per chunk, prefetched one chunk ahead);
-// B chunks stream through a double-buffered LDS image exactly as in K2.
+// Work-group = 8 waves = 128 rows x 256 columns; wave w owns the 128 rows x columns of n-tile w
+// (4 x 1 MFMA tiles).  Per 32-deep chunk the 512 threads expand the 128 spike words of the tile to
+// an fp32 LDS image [row][32 k] (double-buffered, one barrier per chunk; 16 bit->float conversions
+// per thread per 64 MFMAs per wave), A operands are ds_read_b128, B fragments stream from global
+// one chunk ahead exactly as in K2.
+// blockIdx -> (row tile, panel) puts all work-groups of one XCD (blockIdx % 8) on the same weight
+// panel whenever the panel count divides 8, so a panel is fetched from HBM once per XCD and then
+// served from that XCD's L2.
 // ------------------------------------------------------------------------------------------------
 struct GemmArgs {
     const uint32_t* A;
@@ -340,82 +395,92 @@ struct GemmArgs {
     int M, Kw, Nw, ldo, n_blocks, pad;
 };
 
-template <int WM, int WN, int MT, int NT>
-__global__ __launch_bounds__(512) void k_spike_gemm(const GemmArgs args) {
-    static_assert(WM * WN == 8, "8 waves");
-    constexpr int BM = WM * MT * 32, BNT = WN * NT, PRE = BNT / 2;      // PRE float4 per thread per chunk
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    f32x4* ldsB = reinterpret_cast<f32x4*>(smem);
+#define GEMM_AST 36                                 // floats per LDS row: 32 + 4 (conflict-free b128 reads)
 
+template <int MT>
+__global__ __launch_bounds__(512) void k_spike_gemm(const GemmArgs args) {
+    static_assert(MT == 4, "512 threads expand 128 rows x 4 bytes");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* ldsA = reinterpret_cast<float*>(smem);                  // 2 x [128][GEMM_AST]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 31, lh = lane >> 5;
-    const int nb = blockIdx.x % args.n_blocks;       // consecutive blocks (one per XCD) take different weight panels
+    const int nb = blockIdx.x % args.n_blocks;
     const int mb = blockIdx.x / args.n_blocks;
-    const int m0 = mb * BM;
+    const int m0 = mb * (MT * 32);
     const int Kw = args.Kw, Nw = args.Nw, M = args.M;
-    const int nbt = min(BNT, Nw - nb * BNT);
-    const int nB4 = nbt * 256;
+    const int ntg = nb * 8 + wave;
+    const bool active = ntg < Nw;                     // wave-uniform
 
-    const uint32_t* arow[MT];
+    // expansion role: thread -> (row, byte) of the tile's spike words
+    const int xrow = tid >> 2, xbyte = tid & 3;
+    const uint32_t* xsrc = args.A + (size_t)min(m0 + xrow, M - 1) * Kw;
+    float* xdst = ldsA + xrow * GEMM_AST + xbyte * 8;
+    auto expand = [&](uint32_t w, int buf) {
+        const uint32_t byte = (w >> (8 * xbyte)) & 0xffu;
+        f32x4 lo, hi;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int m = min(m0 + (wm * MT + mt) * 32 + li, M - 1);
-        arow[mt] = args.A + (size_t)m * Kw;
-    }
-    f32x16 acc[MT][NT];
+        for (int r = 0; r < 4; ++r) { lo[r] = (float)((byte >> r) & 1u); hi[r] = (float)((byte >> (4 + r)) & 1u); }
+        float* d = xdst + buf * (128 * GEMM_AST);
+        *reinterpret_cast<f32x4*>(d) = lo;
+        *reinterpret_cast<f32x4*>(d + 4) = hi;
+    };
+
+    f32x16 acc[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.0f;
 
-    const f32x4* wsrc = reinterpret_cast<const f32x4*>(args.wpk) + (size_t)nb * BNT * 256;
+    const f32x4* wsrc = reinterpret_cast<const f32x4*>(args.wpk) + (size_t)(active ? ntg : 0) * 256 + lane;
     const size_t wchunk = (size_t)Nw * 256;
-    f32x4 pre[PRE];
+    const float* abase = ldsA + li * GEMM_AST + 16 * lh;
+
+    f32x4 b0[4], b1[4];
+    auto load_b = [&](f32x4 (&dst)[4], int kc) {
+        const f32x4* wn = wsrc + (size_t)min(kc, Kw - 1) * wchunk;
 #pragma unroll
-    for (int s = 0; s < PRE; ++s) {
-        const int idx = tid + 512 * s;
-        ldsB[idx] = (idx < nB4) ? wsrc[idx] : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    uint32_t a_next[MT];
+        for (int qq = 0; qq < 4; ++qq) dst[qq] = wn[qq * 64];
+    };
+    auto chunk = [&](int kc, const f32x4 (&bcur)[4], f32x4 (&bnext)[4], uint32_t& wnext) {
+        // stage chunk kc+1 (spike image + weights) while chunk kc is multiplied
+        if (kc + 1 < Kw) expand(wnext, (kc + 1) & 1);
+        wnext = xsrc[min(kc + 2, Kw - 1)];
+        if (active) {
+            load_b(bnext, kc + 1);
+            f32x4 a[MT][4];
+            const float* ab = abase + (kc & 1) * (128 * GEMM_AST);
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) a_next[mt] = arow[mt][0];
-    __syncthreads();
-    int buf = 0;
-    for (int kc = 0; kc < Kw; ++kc) {
-        const int kn = min(kc + 1, Kw - 1);
-        const f32x4* wnext = wsrc + (size_t)kn * wchunk;
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int s = 0; s < PRE; ++s) {
-            const int idx = tid + 512 * s;
-            pre[s] = (idx < nB4) ? wnext[idx] : f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int qq = 0; qq < 4; ++qq) a[mt][qq] = *reinterpret_cast<const f32x4*>(ab + mt * 32 * GEMM_AST + 4 * qq);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_chunk<MT>(acc, a, bcur);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        uint32_t aw[MT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) { aw[mt] = a_next[mt] >> (16 * lh); a_next[mt] = arow[mt][kn]; }
-        mma_chunk<MT, NT>(acc, aw, ldsB + buf * (BNT * 256) + wn * NT * 256, lane);
-        f32x4* dstB = ldsB + (buf ^ 1) * (BNT * 256);
-#pragma unroll
-        for (int s = 0; s < PRE; ++s) dstB[tid + 512 * s] = pre[s];
         __syncthreads();
-        buf ^= 1;
+    };
+
+    uint32_t wnext = xsrc[0];
+    expand(wnext, 0);
+    wnext = xsrc[min(1, Kw - 1)];
+    if (active) load_b(b0, 0);
+    __syncthreads();
+    int kc = 0;
+    for (; kc + 1 < Kw; kc += 2) {
+        chunk(kc, b0, b1, wnext);
+        chunk(kc + 1, b1, b0, wnext);
     }
+    if (kc < Kw) chunk(kc, b0, b1, wnext);
+    if (!active) return;
     // ---- store currents (lanes 0-31 / 32-63 write two 128-B row segments per instruction) ----
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int ntg = nb * BNT + wn * NT + nt;
-            if (ntg >= Nw) continue;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + (wm * MT + mt) * 32 + acc_row(r, lh);
-                if (m < M) args.out[(size_t)m * args.ldo + ntg * 32 + li] = acc[mt][nt][r];
-            }
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + mt * 32 + acc_row(r, lh);
+            if (m < M) args.out[(size_t)m * args.ldo + ntg * 32 + li] = acc[mt][r];
         }
 }
 
@@ -622,11 +687,12 @@ static int launch_conv(const snn_rpn_level* lv, int n_levels, int C_in, int C_ou
         tiles += d.tiles_per_img * lv[l].N;
         pos += lv[l].N * lv[l].H * lv[l].W;
     }
-    const size_t lds = 2 * 8 * 4096 + (size_t)a.Cw * CONV_HALO * 4;
-    if (lds > 160 * 1024) return fail(-1, "conv3x3_lif: C_in=%d needs too much LDS", C_in);
-    hipError_t e = hipFuncSetAttribute((const void*)k_conv3x3_lif, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (a.Cw > CONV_MAX_CW) return fail(-1, "conv3x3_lif: C_in=%d > %d not supported", C_in, CONV_MAX_CW * 32);
+    const size_t lds = (size_t)CONV_HALO * (a.Cw * 32 + CONV_APAD) * 4;
+    auto kern = dbg_cur ? k_conv3x3_lif<true> : k_conv3x3_lif<false>;
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return fail(-3, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(k_conv3x3_lif, dim3(tiles, cdiv(a.Nw, 8)), dim3(512), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(tiles, cdiv(a.Nw, CONV_BNT)), dim3(512), lds, s, a);
     SNN_CHECK_LAUNCH("k_conv3x3_lif");
     return 0;
 }
@@ -648,12 +714,11 @@ int snn_spike_gemm(const uint32_t* a_rows, int M, int K, int N, const float* w_p
         return fail(-1, "snn_spike_gemm: bad argument");
     GemmArgs a;
     a.A = a_rows; a.wpk = w_packed; a.out = cur; a.M = M; a.Kw = cdiv(K, 32); a.Nw = cdiv(N, 32); a.ldo = ldo; a.pad = 0;
-    // 128 x 128 tile: 8 waves as 2 (M) x 4 (N), each 64 x 32
-    constexpr int WM = 2, WN = 4, MT = 2, NT = 1;
-    a.n_blocks = cdiv(a.Nw, WN * NT);
-    const size_t lds = 2 * (size_t)(WN * NT) * 4096;
-    auto kern = k_spike_gemm<WM, WN, MT, NT>;
-    hipLaunchKernelGGL(kern, dim3(cdiv(M, WM * MT * 32) * a.n_blocks), dim3(512), lds, (hipStream_t)s, a);
+    // 128 rows x 256 columns per work-group: 8 waves, each 128 x 32
+    constexpr int MT = 4;
+    a.n_blocks = cdiv(a.Nw, 8);
+    auto kern = k_spike_gemm<MT>;
+    hipLaunchKernelGGL(kern, dim3(cdiv(M, MT * 32) * a.n_blocks), dim3(512), 2 * 128 * GEMM_AST * 4, (hipStream_t)s, a);
     SNN_CHECK_LAUNCH("k_spike_gemm");
     return 0;
 }

@@ -523,6 +523,11 @@ __global__ __launch_bounds__(256) void k_lif_scan(const float* __restrict__ cur,
 // ------------------------------------------------------------------------------------------------
 struct Kappa { float last[SNN_MAX_STEPS]; float sum[SNN_MAX_STEPS]; };
 
+// Block = 256 threads = RB rows; the reduction runs in slabs of HEADS_KS channels:
+//   phase 1  thread = (row, 32-channel word): S[row][k] = sum_t kappa[t] * bit_t(row, k)  -> LDS (fp32)
+//   phase 2  thread = (row, group of 4 outputs): acc4 += S[row][k] * Wt[k][4jg..4jg+3]   (Wt slab in LDS)
+// NOp (outputs rounded up to 16) * RB / 4 <= 256.
+#define HEADS_KS 128
 template <int RB>
 __global__ __launch_bounds__(256) void k_li_heads(const uint32_t* __restrict__ spk, size_t spk_stride, int T,
                                                   int M, int Kw, const float* __restrict__ wT, int NOp, int NA,
@@ -530,41 +535,89 @@ __global__ __launch_bounds__(256) void k_li_heads(const uint32_t* __restrict__ s
                                                   float* __restrict__ out_b, float* __restrict__ sum_a,
                                                   float* __restrict__ sum_b) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int Kp = Kw * 32;
-    float* S_last = reinterpret_cast<float*>(smem);            // [RB][Kp]
-    float* S_sum = S_last + RB * Kp;                           // [RB][Kp] (only if sums requested)
+    constexpr int SST = HEADS_KS + 4;                          // padded row of S
+    float* S_last = reinterpret_cast<float*>(smem);            // [RB][SST]
     const bool want_sum = (sum_a != nullptr);
+    float* S_sum = S_last + RB * SST;                          // [RB][SST], present only if sums are requested
+    float* Wl = S_last + (want_sum ? 2 : 1) * RB * SST;        // [HEADS_KS][NOp]
+    const int tid = threadIdx.x;
     const int m0 = blockIdx.x * RB;
-    for (int idx = threadIdx.x; idx < RB * Kp; idx += 256) {
-        const int row = idx / Kp, k = idx % Kp;
-        const int m = m0 + row;
-        float sl = 0.0f, ss = 0.0f;
-        if (m < M) {
-            const uint32_t* w = spk + (size_t)m * Kw + (k >> 5);
-            for (int t = 0; t < T; ++t) {
-                const uint32_t bit = (w[(size_t)t * spk_stride] >> (k & 31)) & 1u;
-                if (bit) { sl = __fadd_rn(sl, kap.last[t]); ss = __fadd_rn(ss, kap.sum[t]); }
+    const int JG = NOp / 4;                                    // output groups per row
+    const int prow = tid / JG, pjg = tid % JG;                 // phase-2 role
+    const bool pact = prow < RB;
+    f32x4 acc_l = {0.f, 0.f, 0.f, 0.f}, acc_s = {0.f, 0.f, 0.f, 0.f};
+    const int n_slabs = (Kw * 32 + HEADS_KS - 1) / HEADS_KS;
+    for (int sl = 0; sl < n_slabs; ++sl) {
+        const int w0 = sl * (HEADS_KS / 32);                   // first channel word of the slab
+        const int nw = min(HEADS_KS / 32, Kw - w0);
+        // weights of the slab -> LDS (coalesced float4 copy; rows beyond Kp are never touched)
+        {
+            const f32x4* src = reinterpret_cast<const f32x4*>(wT + (size_t)w0 * 32 * NOp);
+            f32x4* dst = reinterpret_cast<f32x4*>(Wl);
+            for (int i = tid; i < nw * 32 * NOp / 4; i += 256) dst[i] = src[i];
+        }
+        // phase 1
+        for (int item = tid; item < RB * (HEADS_KS / 32); item += 256) {
+            const int row = item / (HEADS_KS / 32), wi = item % (HEADS_KS / 32);
+            const int m = m0 + row;
+            float sl_[32], ss_[32];
+#pragma unroll
+            for (int b = 0; b < 32; ++b) { sl_[b] = 0.f; ss_[b] = 0.f; }
+            if (m < M && wi < nw) {
+                const uint32_t* wp = spk + (size_t)m * Kw + w0 + wi;
+#pragma unroll 4
+                for (int t = 0; t < T; ++t) {
+                    const uint32_t w = wp[(size_t)t * spk_stride];
+                    const float kl = kap.last[t], ks = kap.sum[t];
+#pragma unroll
+                    for (int b = 0; b < 32; ++b) {
+                        const float bit = (float)((w >> b) & 1u);
+                        sl_[b] = fmaf(bit, kl, sl_[b]);            // exact: bit is 0 or 1
+                        if (want_sum) ss_[b] = fmaf(bit, ks, ss_[b]);
+                    }
+                }
+            }
+            f32x4* dl = reinterpret_cast<f32x4*>(S_last + row * SST + wi * 32);
+            f32x4* ds = reinterpret_cast<f32x4*>(S_sum + row * SST + wi * 32);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                dl[j] = f32x4{sl_[4 * j], sl_[4 * j + 1], sl_[4 * j + 2], sl_[4 * j + 3]};
+                if (want_sum) ds[j] = f32x4{ss_[4 * j], ss_[4 * j + 1], ss_[4 * j + 2], ss_[4 * j + 3]};
             }
         }
-        S_last[idx] = sl;
-        if (want_sum) S_sum[idx] = ss;
-    }
-    __syncthreads();
-    const int NO = NA + NB;
-    for (int o = threadIdx.x; o < RB * NO; o += 256) {
-        const int row = o / NO, j = o % NO;
-        const int m = m0 + row;
-        if (m >= M) continue;
-        const float* sl = S_last + row * Kp;
-        const float* ss = S_sum + row * Kp;
-        float al = 0.0f, as = 0.0f;
-        for (int k = 0; k < Kp; ++k) {
-            const float w = wT[(size_t)k * NOp + j];
-            al = fmaf(sl[k], w, al);
-            if (want_sum) as = fmaf(ss[k], w, as);
+        __syncthreads();
+        // phase 2
+        if (pact) {
+            const float* sl_row = S_last + prow * SST;
+            const float* ss_row = S_sum + prow * SST;
+            const float* wcol = Wl + 4 * pjg;
+            const int kn = nw * 32;
+#pragma unroll 4
+            for (int k = 0; k < kn; ++k) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(wcol + (size_t)k * NOp);
+                const float a = sl_row[k];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc_l[r] = fmaf(a, w[r], acc_l[r]);
+                if (want_sum) {
+                    const float c = ss_row[k];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc_s[r] = fmaf(c, w[r], acc_s[r]);
+                }
+            }
         }
-        if (j < NA) { out_a[(size_t)m * NA + j] = al; if (want_sum) sum_a[(size_t)m * NA + j] = as; }
-        else { out_b[(size_t)m * NB + (j - NA)] = al; if (want_sum) sum_b[(size_t)m * NB + (j - NA)] = as; }
+        __syncthreads();
+    }
+    const int m = m0 + prow;
+    if (pact && m < M) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = 4 * pjg + r;
+            if (j < NA) { out_a[(size_t)m * NA + j] = acc_l[r]; if (want_sum) sum_a[(size_t)m * NA + j] = acc_s[r]; }
+            else if (j < NA + NB) {
+                out_b[(size_t)m * NB + (j - NA)] = acc_l[r];
+                if (want_sum) sum_b[(size_t)m * NB + (j - NA)] = acc_s[r];
+            }
+        }
     }
 }
 
@@ -745,13 +798,18 @@ int snn_li_heads(const uint32_t* spk, size_t spk_stride, int T, int M, int K, co
     Kappa kap;
     li_kappa(p, T, &kap);
     const int Kw = cdiv(K, 32), NOp = cdiv(NA + NB, 16) * 16;
-    constexpr int RB = 8;
-    const size_t lds = (size_t)(sum_a ? 2 : 1) * RB * Kw * 32 * 4;
-    if (lds > 160 * 1024) return fail(-1, "snn_li_heads: K=%d too large", K);
-    auto kern = k_li_heads<RB>;
+    if (NOp > 256) return fail(-1, "snn_li_heads: %d outputs per row not supported", NA + NB);
+    // rows per block: as many as 256 threads can own (row, 4-output group) pairs for
+    const int jg = NOp / 4;
+    const int rb = (256 / jg >= 64) ? 64 : (256 / jg >= 32) ? 32 : (256 / jg >= 16) ? 16 : (256 / jg >= 8) ? 8 : 4;
+    const size_t lds = ((size_t)(sum_a ? 2 : 1) * rb * (HEADS_KS + 4) + (size_t)HEADS_KS * NOp) * 4;
+    if (lds > 160 * 1024) return fail(-1, "snn_li_heads: LDS budget exceeded (NOp=%d)", NOp);
+    void (*kern)(const uint32_t*, size_t, int, int, int, const float*, int, int, int, const Kappa, float*, float*,
+                 float*, float*) = rb == 64 ? k_li_heads<64> : rb == 32 ? k_li_heads<32> : rb == 16 ? k_li_heads<16>
+                                             : rb == 8 ? k_li_heads<8> : k_li_heads<4>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return fail(-3, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(kern, dim3(cdiv(M, RB)), dim3(256), lds, (hipStream_t)s, spk, spk_stride, T, M, Kw,
+    hipLaunchKernelGGL(kern, dim3(cdiv(M, rb)), dim3(256), lds, (hipStream_t)s, spk, spk_stride, T, M, Kw,
                        w_heads_packed, NOp, NA, NB, kap, out_a, out_b, sum_a, sum_b);
     SNN_CHECK_LAUNCH("k_li_heads");
     return 0;

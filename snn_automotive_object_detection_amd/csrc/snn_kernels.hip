@@ -243,7 +243,8 @@ __global__ __launch_bounds__(512) void k_conv3x3_lif(const ConvArgs args) {
 
     const int KC = 9 * Cw;
     // weight fragment of (chunk kc, tile ntg): 256 float4, lane reads [qq*64 + lane]
-    const f32x4* wsrc = reinterpret_cast<const f32x4*>(args.wpk) + (size_t)(active ? ntg : 0) * 256 + lane;
+    // (wave-uniform base pointer + lane index: global_load with an SGPR base, no per-chunk VALU address math)
+    const f32x4* wsrc = reinterpret_cast<const f32x4*>(args.wpk) + (size_t)(active ? ntg : 0) * 256;
     const size_t wchunk = (size_t)Nw * 256;          // float4 per reduction chunk (all n-tiles)
 
     // ---- halo spike words of one time step: thread owns words idx = tid + 512*j ----
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_lif(const ConvArgs args) {
     int kcB = 0;
     auto load_b = [&](f32x4 (&dst)[4]) {
 #pragma unroll
-        for (int qq = 0; qq < 4; ++qq) dst[qq] = wnext[qq * 64];
+        for (int qq = 0; qq < 4; ++qq) dst[qq] = wnext[qq * 64 + lane];
         if (++kcB == KC) { kcB = 0; wnext = wsrc; } else wnext += wchunk;
     };
     int tapA = 0, ccA = 0;           // spike operands: (tap, channel word) of the chunk being fetched
@@ -433,7 +434,7 @@ __global__ __launch_bounds__(512) void k_spike_gemm(const GemmArgs args) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mt][r] = 0.0f;
 
-    const f32x4* wsrc = reinterpret_cast<const f32x4*>(args.wpk) + (size_t)(active ? ntg : 0) * 256 + lane;
+    const f32x4* wsrc = reinterpret_cast<const f32x4*>(args.wpk) + (size_t)(active ? ntg : 0) * 256;   // uniform
     const size_t wchunk = (size_t)Nw * 256;
     const float* abase = ldsA + li * GEMM_AST + 16 * lh;
 
@@ -441,7 +442,7 @@ __global__ __launch_bounds__(512) void k_spike_gemm(const GemmArgs args) {
     auto load_b = [&](f32x4 (&dst)[4], int kc) {
         const f32x4* wn = wsrc + (size_t)min(kc, Kw - 1) * wchunk;
 #pragma unroll
-        for (int qq = 0; qq < 4; ++qq) dst[qq] = wn[qq * 64];
+        for (int qq = 0; qq < 4; ++qq) dst[qq] = wn[qq * 64 + lane];
     };
     auto chunk = [&](int kc, const f32x4 (&bcur)[4], f32x4 (&bnext)[4], uint32_t& wnext) {
         // stage chunk kc+1 (spike image + weights) while chunk kc is multiplied

@@ -218,10 +218,13 @@ __global__ __launch_bounds__(512) void k_conv3x3_lif(const ConvArgs args) {
     const int ntg = blockIdx.y * CONV_BNT + wave;    // this wave's 32-channel output tile
     const bool active = ntg < Nw;                    // wave-uniform
 
-    // this lane's A rows: float offset of position (py, px) of the patch for the two M-tiles
-    int a_off[MT];
+    // this lane's A rows: LDS offset (in 16-byte units: CST is a multiple of 4 floats) of position
+    // (py, px) of the patch for the two M-tiles
+    const f32x4* lds16 = reinterpret_cast<const f32x4*>(smem);
+    uint32_t a_q[MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) a_off[mt] = ((mt * 4 + (li >> 3)) * (CONV_PW + 2) + (li & 7)) * CST + 16 * lh;
+    for (int mt = 0; mt < MT; ++mt)
+        a_q[mt] = (uint32_t)(((mt * 4 + (li >> 3)) * (CONV_PW + 2) + (li & 7)) * (CST / 4) + 4 * lh);
 
     // which (mt, r) accumulator rows of this lane are inside the image -> spike mask
     uint32_t valid_bits = 0;
@@ -279,20 +282,22 @@ __global__ __launch_bounds__(512) void k_conv3x3_lif(const ConvArgs args) {
         if (++kcB == KC) { kcB = 0; wnext = wsrc; } else wnext += wchunk;
     };
     int tapA = 0, ccA = 0;           // spike operands: (tap, channel word) of the chunk being fetched
-    const float* a_base = ldsA;
+    uint32_t a_cur[MT];              // lane's LDS index (16-B units) of the chunk in flight: one v_add per M-tile
     auto load_a_lo = [&](f32x4 (&dst)[MT][2]) {      // first half (qq 0,1) of the next chunk
-        a_base = ldsA + ((tapA / 3) * (CONV_PW + 2) + (tapA % 3)) * CST + ccA * 32;
+        const uint32_t cq = (uint32_t)(((tapA / 3) * (CONV_PW + 2) + (tapA % 3)) * (CST / 4) + ccA * 8);   // scalar
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+        for (int mt = 0; mt < MT; ++mt) {
+            a_cur[mt] = a_q[mt] + cq;
 #pragma unroll
-            for (int q2 = 0; q2 < 2; ++q2) dst[mt][q2] = *reinterpret_cast<const f32x4*>(a_base + a_off[mt] + 4 * q2);
+            for (int q2 = 0; q2 < 2; ++q2) dst[mt][q2] = lds16[a_cur[mt] + q2];
+        }
         if (++ccA == Cw) { ccA = 0; ++tapA; }
     };
     auto load_a_hi = [&](f32x4 (&dst)[MT][2]) {      // second half (qq 2,3) of the same chunk
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int q2 = 0; q2 < 2; ++q2) dst[mt][q2] = *reinterpret_cast<const f32x4*>(a_base + a_off[mt] + 8 + 4 * q2);
+            for (int q2 = 0; q2 < 2; ++q2) dst[mt][q2] = lds16[a_cur[mt] + 2 + q2];
     };
 
     f32x4 b0[4], b1[4];
@@ -306,9 +311,6 @@ __global__ __launch_bounds__(512) void k_conv3x3_lif(const ConvArgs args) {
         expand_halo();
         if (t + 1 < args.T) fetch_halo(t + 1);             // latency hidden behind this step's MFMAs
         __syncthreads();                                   // image of step t complete
-        // SIMD partners (waves w and w+4) run the same program; half a chunk of skew keeps one of
-        // them issuing MFMAs while the other refills its operands
-        if (wave >= 4) __builtin_amdgcn_s_sleep(16);
         if (active) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)

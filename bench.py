@@ -158,6 +158,12 @@ def main():
     det_ms = time_ms(lambda: det_head(rois), iters)
     conv_fl, rpn_fl, det_fl = algorithmic_flops()
     achieved = conv_fl / (conv_ms * 1e-3) / 1e12
+    traffic = None                    # HBM bytes per launch of the dominant kernel, from the committed PMC passes
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_traffic.json")) as f:
+            traffic = json.load(f)["hbm_bytes_per_launch"]
+    except Exception:
+        pass
 
     out = {
         "metric": "images/sec (T_rpn=8,T_det=12, 1024x2048 b=2) spiking RPN+RoI heads forward",
@@ -170,7 +176,7 @@ def main():
                    "exchange": "all-gather of per-image detections [100x6] (RCCL)" if world > 1 else "none"},
         "roofline": {"bound": "mfma", "kernel": "k_conv3x3_lif", "achieved": round(achieved, 2),
                      "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                     "traffic": None, "launch_ms": round(conv_ms, 4), "algorithmic_gflop_per_launch": round(conv_fl / 1e9, 1)},
+                     "traffic": traffic, "launch_ms": round(conv_ms, 4), "algorithmic_gflop_per_launch": round(conv_fl / 1e9, 1)},
         "breakdown_ms": {"rpn_head": round(rpn_ms, 3), "rpn_encode": round(enc_ms, 3), "rpn_conv3x3_lif": round(conv_ms, 3),
                          "det_head": round(det_ms, 3)},
         "heads_tflops": round((rpn_fl + det_fl) / ((rpn_ms + det_ms) * 1e-3) / 1e12, 2),

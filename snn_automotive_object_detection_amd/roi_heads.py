@@ -1,0 +1,90 @@
+"""``RoIHeadsSNN`` with the reference's constructor/forward signature (/root/reference/roi_heads.py:
+901-1347, inference side): box_roi_pool -> **spiking head** (the accelerated call, roi_heads.py:1230) ->
+postprocess_detections (1075-1176) that keeps the surviving background boxes and returns
+``all_scores`` / ``all_boxes`` for new-object discovery.  Everything except the head call is stock torch."""
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+from torch import nn, Tensor
+
+from .stock import boxes as box_ops
+
+
+class RoIHeadsSNN(nn.Module):
+    def __init__(self, box_roi_pool, box_head_and_predictor,
+                 fg_iou_thresh, bg_iou_thresh, batch_size_per_image, positive_fraction, bbox_reg_weights,
+                 score_thresh, nms_thresh, detections_per_img,
+                 mask_roi_pool=None, mask_head=None, mask_predictor=None,
+                 keypoint_roi_pool=None, keypoint_head=None, keypoint_predictor=None):
+        super().__init__()
+        if bbox_reg_weights is None:
+            bbox_reg_weights = (10.0, 10.0, 5.0, 5.0)                                # roi_heads.py:938-940
+        self.box_coder = box_ops.BoxCoder(bbox_reg_weights)
+        self.box_roi_pool = box_roi_pool
+        self.box_head_and_predictor = box_head_and_predictor
+        self.score_thresh = score_thresh
+        self.nms_thresh = nms_thresh
+        self.detections_per_img = detections_per_img
+        # training-side hyper-parameters are accepted for signature compatibility only
+        self.fg_iou_thresh, self.bg_iou_thresh = fg_iou_thresh, bg_iou_thresh
+        self.batch_size_per_image, self.positive_fraction = batch_size_per_image, positive_fraction
+        if any(m is not None for m in (mask_roi_pool, mask_head, mask_predictor, keypoint_roi_pool,
+                                       keypoint_head, keypoint_predictor)):
+            raise NotImplementedError("mask/keypoint branches are dead code in the reference (train.py:263-268)")
+
+    def has_mask(self):
+        return False
+
+    def has_keypoint(self):
+        return False
+
+    def postprocess_detections(self, class_logits: Tensor, box_regression: Tensor, proposals: List[Tensor],
+                               image_shapes: List[Tuple[int, int]]):
+        device = class_logits.device
+        num_classes = class_logits.shape[-1]
+        per_image = [p.shape[0] for p in proposals]
+        pred_boxes = self.box_coder.decode(box_regression, proposals)
+        pred_scores = F.softmax(class_logits, -1)
+        out = ([], [], [], [], [])
+        for boxes, scores, shape in zip(pred_boxes.split(per_image, 0), pred_scores.split(per_image, 0), image_shapes):
+            boxes = box_ops.clip_boxes_to_image(boxes, shape)
+            labels = torch.arange(num_classes, device=device).view(1, -1).expand_as(scores)
+            boxes_all, scores_all = boxes.detach().clone(), scores.detach().clone()
+            boxes_bg, scores_bg, labels_bg = boxes[:, 0].reshape(-1, 4), scores[:, 0].reshape(-1), labels[:, 0].reshape(-1)
+            boxes, scores, labels = boxes[:, 1:].reshape(-1, 4), scores[:, 1:].reshape(-1), labels[:, 1:].reshape(-1)
+            inds = torch.where(scores > self.score_thresh)[0]                         # roi_heads.py:1134
+            boxes, scores, labels = boxes[inds], scores[inds], labels[inds]
+            # background boxes survive only for RoIs without any foreground detection (1137-1148;
+            # vectorised form of the reference's per-detection Python loop)
+            is_bg = torch.ones(scores_bg.shape[0], dtype=torch.bool, device=device)
+            is_bg[torch.div(inds, num_classes - 1, rounding_mode="trunc")] = False
+            inds_bg = torch.where(is_bg)[0]
+            boxes_bg, scores_bg, labels_bg = boxes_bg[inds_bg], scores_bg[inds_bg], labels_bg[inds_bg]
+            keep = box_ops.remove_small_boxes(boxes, min_size=1e-2)
+            boxes, scores, labels = boxes[keep], scores[keep], labels[keep]
+            keep_bg = box_ops.remove_small_boxes(boxes_bg, min_size=1e-2)
+            boxes_bg, scores_bg, labels_bg = boxes_bg[keep_bg], scores_bg[keep_bg], labels_bg[keep_bg]
+            keep = box_ops.batched_nms(boxes, scores, labels, self.nms_thresh)[: self.detections_per_img]
+            keep_bg = box_ops.batched_nms(boxes_bg, scores_bg, labels_bg, self.nms_thresh)
+            out[0].append(torch.cat((boxes[keep], boxes_bg[keep_bg]), dim=0))
+            out[1].append(torch.cat((scores[keep], scores_bg[keep_bg]), dim=0))
+            out[2].append(torch.cat((labels[keep], labels_bg[keep_bg]), dim=0))
+            out[3].append(scores_all)
+            out[4].append(boxes_all)
+        return out
+
+    def forward(self, features: Dict[str, Tensor], proposals: List[Tensor], image_shapes: List[Tuple[int, int]],
+                targets: Optional[List[Dict[str, Tensor]]] = None):
+        if self.training:
+            raise NotImplementedError("inference only: training the RoI heads is out of scope (DESIGN.md §7)")
+        box_features = self.box_roi_pool(features, proposals, image_shapes)          # roi_heads.py:1217
+        head_out = self.box_head_and_predictor(box_features)                         # roi_heads.py:1230 (HIP)
+        if getattr(self.box_head_and_predictor, "spike_rates", False):
+            return head_out                                                          # roi_heads.py:1219-1223
+        class_logits, box_regression = head_out
+        boxes, scores, labels, all_scores, all_boxes = self.postprocess_detections(
+            class_logits, box_regression, proposals, image_shapes)
+        result = [{"boxes": boxes[i], "labels": labels[i], "scores": scores[i], "all_scores": all_scores[i],
+                   "all_boxes": all_boxes[i]} for i in range(len(boxes))]
+        return result, {}

@@ -93,3 +93,91 @@ class RPNHeadSNN(nn.Module):
         if self.spike_rates:
             return logits, bbox_reg, rates
         return logits, bbox_reg
+
+
+# ---------------------------------------------------------------------------------------------
+# Stock-torch caller of the head (inference side of /root/reference/rpn.py:299-703).  Not part of
+# the accelerated path; present so that the detector runs end-to-end without torchvision.
+# ---------------------------------------------------------------------------------------------
+def permute_and_flatten(layer: Tensor, N: int, A: int, C: int, H: int, W: int) -> Tensor:
+    return layer.view(N, -1, C, H, W).permute(0, 3, 4, 1, 2).reshape(N, -1, C)       # rpn.py:256-258
+
+
+def concat_box_prediction_layers(box_cls: List[Tensor], box_regression: List[Tensor]) -> Tuple[Tensor, Tensor]:
+    """rpn.py:262-296: order (image, level, y, x, anchor)"""
+    cls_flat, reg_flat = [], []
+    for cls_l, reg_l in zip(box_cls, box_regression):
+        N, AxC, H, W = cls_l.shape
+        A = reg_l.shape[1] // 4
+        C = AxC // A
+        cls_flat.append(permute_and_flatten(cls_l, N, A, C, H, W))
+        reg_flat.append(permute_and_flatten(reg_l, N, A, 4, H, W))
+    return torch.cat(cls_flat, dim=1).flatten(0, -2), torch.cat(reg_flat, dim=1).reshape(-1, 4)
+
+
+class RegionProposalNetwork(nn.Module):
+    """Inference side of the reference's RegionProposalNetwork (rpn.py:330-372 ctor, 563-703 forward):
+    head -> anchors -> decode -> per-level top-k -> sigmoid -> clip -> remove small -> NMS per level ->
+    top post_nms_top_n.  In eval mode the second return value is the list of per-image
+    {'proposals', 'objectness'} dicts (rpn.py:493-499, 692-693)."""
+
+    def __init__(self, anchor_generator, head, fg_iou_thresh, bg_iou_thresh, batch_size_per_image,
+                 positive_fraction, pre_nms_top_n, post_nms_top_n, nms_thresh, score_thresh=0.0):
+        super().__init__()
+        from .stock.boxes import BoxCoder
+        self.anchor_generator = anchor_generator
+        self.head = head
+        self.box_coder = BoxCoder(weights=(1.0, 1.0, 1.0, 1.0))                       # rpn.py:347
+        self._pre_nms_top_n = pre_nms_top_n
+        self._post_nms_top_n = post_nms_top_n
+        self.nms_thresh = nms_thresh
+        self.score_thresh = score_thresh
+        self.min_size = 1e-3                                                          # rpn.py:371
+
+    def pre_nms_top_n(self):
+        return self._pre_nms_top_n["training" if self.training else "testing"]
+
+    def post_nms_top_n(self):
+        return self._post_nms_top_n["training" if self.training else "testing"]
+
+    def filter_proposals(self, proposals, objectness, image_shapes, num_anchors_per_level):
+        from .stock import boxes as box_ops
+        num_images = proposals.shape[0]
+        device = proposals.device
+        objectness = objectness.detach().reshape(num_images, -1)
+        levels = torch.cat([torch.full((n,), i, dtype=torch.int64, device=device)
+                            for i, n in enumerate(num_anchors_per_level)]).reshape(1, -1).expand_as(objectness)
+        idx, offset = [], 0
+        for ob in objectness.split(num_anchors_per_level, 1):                         # rpn.py:434-446
+            k = min(self.pre_nms_top_n(), ob.shape[1])
+            idx.append(ob.topk(k, dim=1)[1] + offset)
+            offset += ob.shape[1]
+        top = torch.cat(idx, dim=1)
+        bi = torch.arange(num_images, device=device)[:, None]
+        objectness, levels, proposals = objectness[bi, top], levels[bi, top], proposals[bi, top]
+        prob = torch.sigmoid(objectness)
+        pre_nms = [{"proposals": p, "objectness": prob[i]} for i, p in enumerate(proposals)]   # rpn.py:493-499
+        final_boxes, final_scores = [], []
+        for boxes, scores, lvl, shape in zip(proposals, prob, levels, image_shapes):
+            boxes = box_ops.clip_boxes_to_image(boxes, shape)
+            keep = box_ops.remove_small_boxes(boxes, self.min_size)
+            boxes, scores, lvl = boxes[keep], scores[keep], lvl[keep]
+            keep = torch.where(scores >= self.score_thresh)[0]
+            boxes, scores, lvl = boxes[keep], scores[keep], lvl[keep]
+            keep = box_ops.batched_nms(boxes, scores, lvl, self.nms_thresh)[: self.post_nms_top_n()]
+            final_boxes.append(boxes[keep])
+            final_scores.append(scores[keep])
+        return final_boxes, final_scores, pre_nms
+
+    def forward(self, images, features, targets=None):
+        if self.training:
+            raise NotImplementedError("inference only: training the RPN is out of scope (DESIGN.md §7)")
+        feats = list(features.values())
+        objectness, pred_bbox_deltas = self.head(feats)[:2]                           # rpn.py:613
+        anchors = self.anchor_generator(images, feats)
+        num_images = len(anchors)
+        num_anchors_per_level = [o.shape[1] * o.shape[2] * o.shape[3] for o in objectness]
+        objectness, pred_bbox_deltas = concat_box_prediction_layers(objectness, pred_bbox_deltas)
+        proposals = self.box_coder.decode(pred_bbox_deltas.detach(), anchors).view(num_images, -1, 4)
+        boxes, scores, pre_nms = self.filter_proposals(proposals, objectness, images.image_sizes, num_anchors_per_level)
+        return boxes, pre_nms

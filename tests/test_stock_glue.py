@@ -1,0 +1,176 @@
+"""CPU tests of the stock-torch glue (torchvision stand-ins) against straightforward loop references,
+and of the whole detector skeleton run end-to-end on CPU with oracle-backed heads."""
+import copy
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from snn_automotive_object_detection_amd.stock import boxes as B
+from snn_automotive_object_detection_amd.stock.anchors import AnchorGenerator, ImageList
+from snn_automotive_object_detection_amd.stock.roi_align import MultiScaleRoIAlign, roi_align
+from snn_automotive_object_detection_amd.stock.transform import GeneralizedRCNNTransform
+
+
+def _rand_boxes(n, g, size=200.0):
+    xy = torch.rand((n, 2), generator=g) * size
+    wh = torch.rand((n, 2), generator=g) * 60 + 1
+    return torch.cat([xy, xy + wh], dim=1)
+
+
+def _greedy_nms(boxes, scores, thr):
+    order = scores.argsort(descending=True, stable=True).tolist()
+    keep = []
+    iou = B.box_iou(boxes, boxes)
+    while order:
+        i = order.pop(0)
+        keep.append(i)
+        order = [j for j in order if iou[i, j] <= thr]
+    return torch.tensor(keep, dtype=torch.int64)
+
+
+@pytest.mark.parametrize("n,thr", [(1, 0.5), (50, 0.5), (400, 0.7), (400, 0.3)])
+def test_nms_equals_greedy(n, thr):
+    g = torch.Generator().manual_seed(n)
+    boxes, scores = _rand_boxes(n, g), torch.rand((n,), generator=g)
+    assert torch.equal(B.nms(boxes, scores, thr), _greedy_nms(boxes, scores, thr))
+
+
+def test_nms_chain_and_empty():
+    # a chain where each box suppresses only its successor: greedy keeps 0, 2, 4, ...
+    boxes = torch.tensor([[float(i) * 4, 0, float(i) * 4 + 10, 10] for i in range(12)])
+    scores = torch.linspace(1, 0.1, 12)
+    assert torch.equal(B.nms(boxes, scores, 0.4), _greedy_nms(boxes, scores, 0.4))
+    assert B.nms(torch.zeros((0, 4)), torch.zeros((0,)), 0.5).numel() == 0
+    assert B.batched_nms(torch.zeros((0, 4)), torch.zeros((0,)), torch.zeros((0,), dtype=torch.int64), 0.5).numel() == 0
+
+
+def test_batched_nms_is_per_category():
+    g = torch.Generator().manual_seed(5)
+    boxes, scores = _rand_boxes(120, g), torch.rand((120,), generator=g)
+    idxs = torch.randint(0, 4, (120,), generator=g)
+    got = set(B.batched_nms(boxes, scores, idxs, 0.5).tolist())
+    exp = set()
+    for c in range(4):
+        sel = torch.where(idxs == c)[0]
+        exp |= set(sel[_greedy_nms(boxes[sel], scores[sel], 0.5)].tolist())
+    assert got == exp
+
+
+def test_box_coder_decode_identity_and_clamp():
+    coder = B.BoxCoder((10.0, 10.0, 5.0, 5.0))
+    boxes = [torch.tensor([[10.0, 20.0, 50.0, 80.0]])]
+    out = coder.decode(torch.zeros((1, 8)), boxes)
+    assert out.shape == (1, 2, 4) and torch.allclose(out[0, 0], boxes[0][0])
+    big = coder.decode(torch.tensor([[0.0, 0.0, 1e4, 1e4]]), boxes)
+    w = big[0, 0, 2] - big[0, 0, 0]
+    assert torch.isclose(w, torch.tensor(40.0 * 1000.0 / 16), rtol=1e-5)          # dw clamped at log(1000/16)
+
+
+def test_anchor_generator_layout():
+    ag = AnchorGenerator(sizes=((32,), (64,)), aspect_ratios=((0.5, 1.0, 2.0),) * 2)
+    assert ag.num_anchors_per_location() == [3, 3]
+    imgs = ImageList(torch.zeros((2, 3, 64, 128)), [(64, 128), (60, 100)])
+    feats = [torch.zeros((2, 8, 16, 32)), torch.zeros((2, 8, 8, 16))]
+    anchors = ag(imgs, feats)
+    assert len(anchors) == 2 and anchors[0].shape == (16 * 32 * 3 + 8 * 16 * 3, 4)
+    a = anchors[0]
+    # order (y, x, anchor): second location is one stride (4 px) to the right
+    assert torch.equal(a[3:6] - a[0:3], torch.tensor([[4.0, 0, 4, 0]] * 3))
+    # ratio 1.0 anchor of level 0 is a 32x32 square centred on the cell origin
+    assert torch.equal(a[1], torch.tensor([-16.0, -16.0, 16.0, 16.0]))
+    ar = (a[0, 3] - a[0, 1]) / (a[0, 2] - a[0, 0])
+    assert abs(float(ar) - 0.5) < 0.05
+
+
+def _roi_align_naive(feat, roi, scale, P=7, S=2):
+    C, H, W = feat.shape[1:]
+    n = int(roi[0])
+    x1, y1, x2, y2 = [float(v) * scale for v in roi[1:]]
+    rw, rh = max(x2 - x1, 1.0), max(y2 - y1, 1.0)
+    out = torch.zeros((C, P, P), dtype=torch.float64)
+    f = feat[n].double()
+    for ph in range(P):
+        for pw in range(P):
+            acc = torch.zeros(C, dtype=torch.float64)
+            for iy in range(S):
+                for ix in range(S):
+                    y = y1 + ph * rh / P + (iy + 0.5) * rh / P / S
+                    x = x1 + pw * rw / P + (ix + 0.5) * rw / P / S
+                    if y < -1.0 or y > H or x < -1.0 or x > W:
+                        continue
+                    y, x = max(y, 0.0), max(x, 0.0)
+                    yl, xl = int(y), int(x)
+                    if yl >= H - 1:
+                        yh = yl = H - 1; y = float(yl)
+                    else:
+                        yh = yl + 1
+                    if xl >= W - 1:
+                        xh = xl = W - 1; x = float(xl)
+                    else:
+                        xh = xl + 1
+                    ly, lx = y - yl, x - xl
+                    acc += (1 - ly) * (1 - lx) * f[:, yl, xl] + (1 - ly) * lx * f[:, yl, xh] + \
+                           ly * (1 - lx) * f[:, yh, xl] + ly * lx * f[:, yh, xh]
+            out[:, ph, pw] = acc / (S * S)
+    return out
+
+
+def test_roi_align_matches_naive():
+    g = torch.Generator().manual_seed(9)
+    feat = torch.randn((2, 5, 13, 17), generator=g)
+    rois = torch.tensor([[0, 2.0, 3.0, 40.0, 30.0], [1, -5.0, -3.0, 20.0, 60.0], [0, 60.0, 40.0, 70.0, 52.5],
+                         [1, 10.0, 10.0, 10.2, 10.1]])
+    got = roi_align(feat, rois, 0.25)
+    for k in range(rois.shape[0]):
+        exp = _roi_align_naive(feat, rois[k], 0.25)
+        assert torch.allclose(got[k].double(), exp, atol=1e-5), k
+
+
+def test_multiscale_level_mapper():
+    pool = MultiScaleRoIAlign(["0", "1", "2", "3"], 7, 2)
+    feats = {"0": torch.randn(1, 4, 64, 64), "1": torch.randn(1, 4, 32, 32), "2": torch.randn(1, 4, 16, 16),
+             "3": torch.randn(1, 4, 8, 8), "pool": torch.randn(1, 4, 4, 4)}
+    boxes = [torch.tensor([[0.0, 0, 50, 50], [0, 0, 112, 112], [0, 0, 224, 224], [0, 0, 250, 250]])]
+    out = pool(feats, boxes, [(256, 256)])
+    assert out.shape == (4, 4, 7, 7)
+    # sqrt(area) 50 -> k=1 clamped to 2 (stride 4); 112 -> k=3 (stride 8); 224, 250 -> k=4 (stride 16)
+    for k, (lv, sc) in enumerate([("0", 0.25), ("1", 0.125), ("2", 1 / 16), ("2", 1 / 16)]):
+        r = torch.cat([torch.zeros(1), boxes[0][k]])[None]
+        assert torch.allclose(out[k], roi_align(feats[lv], r, sc)[0], atol=1e-6)
+
+
+def test_transform_cityscapes_and_bdd_shapes():
+    t = GeneralizedRCNNTransform(768, 1536, [0.2869, 0.3251, 0.2839], [0.1870, 0.1902, 0.1872])
+    il, _ = t([torch.rand(3, 1024, 2048), torch.rand(3, 1024, 2048)])
+    assert tuple(il.tensors.shape) == (2, 3, 768, 1536) and il.image_sizes == [(768, 1536)] * 2
+    il, _ = t([torch.rand(3, 720, 1280)])
+    assert tuple(il.tensors.shape) == (1, 3, 768, 1376) and il.image_sizes == [(768, 1365)]
+    res = t.postprocess([{"boxes": torch.tensor([[0.0, 0.0, 1365.0, 768.0]])}], il.image_sizes, [(720, 1280)])
+    assert torch.allclose(res[0]["boxes"], torch.tensor([[0.0, 0.0, 1280.0, 720.0]]))
+
+
+def test_detector_skeleton_end_to_end_on_cpu_with_oracle_heads():
+    import snn_automotive_object_detection_amd as S
+    from tests._oracle_heads import OracleRPNHead, OracleDetHead
+    torch.manual_seed(0)
+    m = S.create_model("cityscapes", 9, True, True, 0, False, False, num_steps_rpn=4, num_steps_detector=4).eval()
+    assert isinstance(m, S.GeneralizedRCNN) and isinstance(m.roi_heads, S.RoIHeadsSNN)
+    m.transform.min_size, m.transform.max_size = 128, 256                # small canvas: CPU test
+    m.rpn._pre_nms_top_n = dict(training=100, testing=100)
+    m.rpn._post_nms_top_n = dict(training=60, testing=60)
+    m.rpn.head = OracleRPNHead(m.rpn.head)
+    m.roi_heads.box_head_and_predictor = OracleDetHead(m.roi_heads.box_head_and_predictor)
+    out = m([torch.rand(3, 160, 320), torch.rand(3, 128, 300)])
+    assert len(out) == 2
+    for d in out:
+        assert set(d) >= {"boxes", "labels", "scores", "all_scores", "all_boxes", "proposals", "objectness"}
+        n = d["boxes"].shape[0]
+        assert d["boxes"].shape == (n, 4) and d["labels"].shape == (n,) and d["scores"].shape == (n,)
+        assert d["all_scores"].shape[1] == 9 and d["all_boxes"].shape[1:] == (9, 4)
+        assert d["all_scores"].shape[0] == d["all_boxes"].shape[0] <= 60
+        assert d["proposals"].shape[1] == 4 and d["proposals"].shape[0] == d["objectness"].shape[0]
+        assert torch.isfinite(d["boxes"]).all()
+    with pytest.raises(NotImplementedError):
+        m.train()([torch.rand(3, 64, 64)])

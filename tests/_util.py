@@ -26,3 +26,10 @@ def nchw_to_rows(z: torch.Tensor) -> np.ndarray:
     """[T, N, C, H, W] -> [T, N*H*W, C] (row = (n*H + y)*W + x)"""
     T, N, C, H, W = z.shape
     return z.permute(0, 1, 3, 4, 2).reshape(T, N * H * W, C).numpy()
+
+
+def flip_budget(positions: int, channels: int, steps: int) -> float:
+    """How many positions may hold a hidden spike that differs from the oracle's.  Two fp32 summation orders
+    of the same 3x3 convolution disagree on ~7e-8 of the neuron-steps (SURVEY.md §7 risk 1 measured 5 of 7.5e7
+    between two oneDNN layouts); a position has channels*steps of them.  Budget = 3.5x that rate + 2."""
+    return 2 + 2.5e-7 * channels * steps * positions

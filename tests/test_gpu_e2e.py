@@ -6,6 +6,8 @@ import numpy as np
 import pytest
 import torch
 
+from tests._util import flip_budget
+
 pytestmark = pytest.mark.gpu
 
 
@@ -40,7 +42,7 @@ def test_create_model_end_to_end_and_heads_in_situ(gpu_device):
     for l in range(5):
         d = torch.maximum((cap["rpn_out"][0][l] - o_l[l]).abs().amax(1), (cap["rpn_out"][1][l] - o_b[l]).abs().amax(1))
         total += d.numel(); bad += int((d > 1e-4).sum())
-    assert bad <= 2 + 1e-4 * total, (bad, total)
+    assert bad <= flip_budget(total, 256, 8), (bad, total)
     # detector head in situ
     dh = m.roi_heads.box_head_and_predictor
     o_c, o_d = OR.det_head_forward(cap["det_in"], dh.fc6.weight.cpu(), dh.fc7.weight.cpu(), dh.cls_score.weight.cpu(),

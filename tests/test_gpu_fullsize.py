@@ -4,6 +4,8 @@ import numpy as np
 import pytest
 import torch
 
+from tests._util import flip_budget
+
 pytestmark = pytest.mark.gpu
 LEVELS = [(192, 384), (96, 192), (48, 96), (24, 48), (12, 24)]
 
@@ -26,7 +28,7 @@ def test_rpn_head_full_size_vs_oracle(gpu_device):
         bad += int((d > 1e-4).sum())
         assert float(d.max()) < 0.05
     # threshold ties flip ~1e-7 of the spikes between two fp32 summation orders (SURVEY §7 risk 1)
-    assert bad <= 1e-4 * total, "positions off-tolerance: %d of %d" % (bad, total)
+    assert bad <= flip_budget(total, 256, 8), "positions off-tolerance: %d of %d" % (bad, total)
     # shared-LIF rate sanity: counts are exact integers / (T*C*H*W)
     for l, (h, w) in enumerate(LEVELS):
         r = rates[3 * l][:, 0].cpu().numpy() * (8 * 256 * h * w)

@@ -149,6 +149,24 @@ int snn_li_heads(const uint32_t* spk, size_t spk_stride_words, int T, int M, int
                  const float* w_heads_packed, int NA, int NB, const snn_params* p_host,
                  float* out_a, float* out_b, float* sum_a, float* sum_b, snn_stream_t stream);
 
+/* ---- exact bf16x3 contractions (bf16 matrix cores, fp32-exact result) -------------------------------
+ * Spikes are exactly {0,1} and every fp32 weight is exactly the sum of three bf16 values, so
+ * A x W = A x W_hi + A x W_mid + A x W_lo with every product exact and fp32 accumulation; measured as
+ * accurate as the fp32 MFMA chain (tools/bf16x3_numerics.hip).  Packed operand: uint16 [3][K/32][Np][32]. */
+size_t snn_packed_bf16x3_elems(int K_chunks32, int N);
+size_t snn_packed_conv3x3_bf16x3_elems(int C_out, int C_in);
+int snn_pack_conv3x3_weight_bf16x3(const float* w_oihw, int C_out, int C_in, uint16_t* packed, snn_stream_t s);
+size_t snn_packed_linear_bf16x3_elems(int N, int K);
+int snn_pack_linear_weight_bf16x3(const float* w_nk, int N, int K, uint16_t* packed, snn_stream_t s);
+/* cur[M][ldo] = A_bits[M][K] x W[K][N] */
+int snn_spike_gemm_bf16x3(const uint32_t* a_rows, int M, int K, int N, const uint16_t* w_packed, float* cur,
+                          int ldo, snn_stream_t stream);
+/* un-fused time-batched 3x3 spike convolution over all levels: enc planes [T][P][Cw] -> cur[T*P][ldo]
+ * (row = t*P + position; position order as in snn_rpn_head_forward); follow with snn_lif_scan */
+int snn_spike_conv3x3_bf16x3(const uint32_t* enc, size_t enc_stride_words, const snn_rpn_level* levels_host,
+                             int n_levels, int C_in, int C_out, int T, const uint16_t* w_packed, float* cur,
+                             int ldo, snn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

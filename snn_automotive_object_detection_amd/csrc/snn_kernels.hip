@@ -488,6 +488,221 @@ __global__ __launch_bounds__(512) void k_spike_gemm(const GemmArgs args) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// K3b: exact bf16x3 spike GEMM on the bf16 matrix cores (16x the fp32 MFMA rate, 3 MFMAs per product).
+//
+// Spikes are exactly {0,1} and every fp32 weight is exactly hi + mid + lo with three bf16 values, so
+//   A_bits x W  ==  A_bf16 x W_hi + A_bf16 x W_mid + A_bf16 x W_lo     (every product exact)
+// with fp32 accumulation inside v_mfma_f32_32x32x16_bf16.  Measured against fp64 the result is as accurate
+// as the fp32 MFMA chain (tools/bf16x3_numerics.hip: rms error 4.1e-8 vs 4.2e-8 at K=2304).
+//
+// cur[M][ldo] = A_bits[M][K] x W[K][N];   work-group = 8 waves = 256 rows x 128 columns, wave = 64 x 64.
+// Per 32-deep chunk: B = 3 planes x 128 x 32 bf16 (24 KB) copied global->LDS, A = 256 spike words expanded
+// to bf16 in LDS (two 16-bit halves per row, one per thread); both double-buffered, one barrier per chunk.
+// LDS rows are 64 B of data + 16 B pad (80-B stride): conflict-free ds_read_b128 fragment reads.
+// CONV = true: row m = (t, position) and the chunk (tap, channel word) is gathered straight from the
+// encoder bit-planes (9 taps, zero outside the image) - the un-fused time-batched 3x3 convolution.
+// ------------------------------------------------------------------------------------------------
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+#define G3_BM 256
+#define G3_BN 128
+#define G3_ROWB 80                                  // bytes per LDS row (32 bf16 + pad)
+#define G3_A_BYTES (G3_BM * G3_ROWB)                // 20480
+#define G3_B_BYTES (3 * G3_BN * G3_ROWB)            // 30720
+#define G3_LDS (2 * (G3_A_BYTES + G3_B_BYTES))      // 102400
+
+struct Gemm3Args {
+    const uint32_t* A;           // fc: [M][Kw] spike words;  conv: encoder planes [T][P][Cw]
+    const uint16_t* wpk;         // [3][Kc][Np][32] bf16
+    float* out;                  // [M][ldo]
+    unsigned long long plane_elems;     // Kc*Np*32
+    unsigned long long enc_stride;      // conv: words per time plane
+    int M, Kc, Np, ldo, n_blocks;
+    int Cw, P_total, n_levels;          // conv only
+    ConvLevelDev lv[SNN_MAX_LEVELS];
+};
+
+__device__ __forceinline__ uint32_t bf16_pair(uint32_t w, int j) {      // bits 2j, 2j+1 -> two bf16 (0 / 1.0)
+    const uint32_t t = (w >> (2 * j)) & 3u;
+    return ((t | (t << 15)) & 0x10001u) * 0x3F80u;
+}
+
+template <bool CONV>
+__global__ __launch_bounds__(512) void k_gemm_bf16x3(const Gemm3Args args) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nb = blockIdx.x % args.n_blocks;
+    const int mb = blockIdx.x / args.n_blocks;
+    const int m0 = mb * G3_BM;
+    const int Kc = args.Kc, Np = args.Np, M = args.M;
+
+    // ---- A staging role: thread -> (row, 16-bit half) ----
+    const int xrow = tid >> 1, xhalf = tid & 1;
+    const int xm = m0 + xrow;
+    const uint32_t* a_src = args.A;                 // fc: row base; conv: plane base of the row's time step
+    long long a_center = 0;                         // conv: word index of the centre tap, channel word 0
+    int a_W = 0;
+    uint32_t a_valid = 0;                           // conv: 9-bit tap validity
+    if (CONV) {
+        if (xm < M) {
+            const int t = xm / args.P_total, p = xm % args.P_total;
+            int l = 0;
+            while (l + 1 < args.n_levels && p >= args.lv[l + 1].pos_base) ++l;
+            const int H = args.lv[l].H, W = args.lv[l].W;
+            const int local = p - args.lv[l].pos_base;
+            const int rem = local % (H * W);
+            const int y = rem / W, x = rem % W;
+            a_src = args.A + (size_t)t * args.enc_stride;
+            a_center = (long long)p * args.Cw;
+            a_W = W;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+                a_valid |= (uint32_t)(yy >= 0 && yy < H && xx >= 0 && xx < W) << tap;
+            }
+        }
+    } else {
+        a_src = args.A + (size_t)min(xm, M - 1) * Kc;
+    }
+    auto fetch_a = [&](int kc) -> uint32_t {
+        if (CONV) {
+            const int tap = kc / args.Cw, cc = kc % args.Cw;
+            if (!((a_valid >> tap) & 1u)) return 0u;
+            return a_src[a_center + (long long)((tap / 3 - 1) * a_W + (tap % 3 - 1)) * args.Cw + cc];
+        }
+        return a_src[kc];
+    };
+    auto store_a = [&](uint32_t w, int buf) {
+        const uint32_t hbits = (w >> (16 * xhalf)) & 0xffffu;
+        uint4 lo4, hi4;
+        lo4.x = bf16_pair(hbits, 0); lo4.y = bf16_pair(hbits, 1); lo4.z = bf16_pair(hbits, 2); lo4.w = bf16_pair(hbits, 3);
+        hi4.x = bf16_pair(hbits, 4); hi4.y = bf16_pair(hbits, 5); hi4.z = bf16_pair(hbits, 6); hi4.w = bf16_pair(hbits, 7);
+        unsigned char* d = smem + buf * G3_A_BYTES + xrow * G3_ROWB + xhalf * 32;
+        *reinterpret_cast<uint4*>(d) = lo4;
+        *reinterpret_cast<uint4*>(d + 16) = hi4;
+    };
+
+    // ---- B staging role: thread -> (column n, 16-byte unit u) of each of the 3 planes ----
+    const int bn = tid >> 2, bu = tid & 3;
+    const int bcol = nb * G3_BN + bn;
+    const bool bvalid = bcol < Np;
+    const uint16_t* b_src = args.wpk + ((size_t)(bvalid ? bcol : 0) * 32 + bu * 8);
+    uint4 bst[3];
+    auto fetch_b = [&](int kc) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            bst[pl] = make_uint4(0, 0, 0, 0);
+            if (bvalid) bst[pl] = *reinterpret_cast<const uint4*>(b_src + pl * args.plane_elems + (size_t)kc * Np * 32);
+        }
+    };
+    auto store_b = [&](int buf) {
+        unsigned char* d = smem + 2 * G3_A_BYTES + buf * G3_B_BYTES + bn * G3_ROWB + bu * 16;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<uint4*>(d + pl * (G3_BN * G3_ROWB)) = bst[pl];
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
+
+    const int a_rd = (wm * 64 + li) * G3_ROWB + 16 * lh;       // + mt*32*ROWB + 32*s
+    const int b_rd = (wn * 64 + li) * G3_ROWB + 16 * lh;       // + pl*BN*ROWB + nt*32*ROWB + 32*s
+
+    // prologue: chunk 0
+    uint32_t a_w = fetch_a(0);
+    fetch_b(0);
+    store_a(a_w, 0);
+    store_b(0);
+    __syncthreads();
+
+    for (int kc = 0; kc < Kc; ++kc) {
+        const int buf = kc & 1;
+        const bool more = kc + 1 < Kc;
+        if (more) { a_w = fetch_a(kc + 1); fetch_b(kc + 1); }      // global loads in flight during the MFMAs
+        const unsigned char* Ab = smem + buf * G3_A_BYTES + a_rd;
+        const unsigned char* Bb = smem + 2 * G3_A_BYTES + buf * G3_B_BYTES + b_rd;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 a[2], b[2][3];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) a[mt] = *reinterpret_cast<const bf16x8*>(Ab + mt * 32 * G3_ROWB + 32 * s);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    b[nt][pl] = *reinterpret_cast<const bf16x8*>(Bb + pl * (G3_BN * G3_ROWB) + nt * 32 * G3_ROWB + 32 * s);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    // small terms first: lo, mid, hi
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[nt][2], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[nt][1], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[nt][0], acc[mt][nt], 0, 0, 0);
+                }
+        }
+        if (more) { store_a(a_w, buf ^ 1); store_b(buf ^ 1); }
+        __syncthreads();
+    }
+    // ---- store currents ----
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int col = nb * G3_BN + wn * 64 + nt * 32 + li;
+            if (col >= Np) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + mt * 32 + acc_row(r, lh);
+                if (m < M) args.out[(size_t)m * args.ldo + col] = acc[mt][nt][r];
+            }
+        }
+}
+
+// fp32 weights -> three bf16 planes [3][Kc][Np][32]  (hi = rn(w), mid = rn(w - hi), lo = rn(w - hi - mid): exact)
+__device__ __forceinline__ uint16_t f2bf_rn(float f) {
+    uint32_t u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(uint16_t b) { return __uint_as_float((uint32_t)b << 16); }
+
+__global__ void k_pack_bf16x3(const float* __restrict__ src, uint16_t* __restrict__ dst, int mode, int K, int N,
+                              int Kc, int Np, int Cin, int Cp) {
+    const size_t plane = (size_t)Kc * Np * 32;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < plane; idx += (size_t)gridDim.x * blockDim.x) {
+        const int kk = idx & 31;
+        const size_t rest = idx >> 5;
+        const int n = (int)(rest % Np);
+        const int kc = (int)(rest / Np);
+        const int k = kc * 32 + kk;
+        float w = 0.0f;
+        if (n < N) {
+            if (mode == PACK_CONV3X3) {
+                const int tap = k / Cp, ci = k % Cp;
+                if (ci < Cin) w = src[((size_t)n * Cin + ci) * 9 + tap];
+            } else if (k < K) {
+                w = src[(size_t)n * K + k];
+            }
+        }
+        const uint16_t hi = f2bf_rn(w);
+        const float r1 = __fsub_rn(w, bf2f(hi));
+        const uint16_t mid = f2bf_rn(r1);
+        const float r2 = __fsub_rn(r1, bf2f(mid));
+        const uint16_t lo = f2bf_rn(r2);
+        dst[idx] = hi; dst[plane + idx] = mid; dst[2 * plane + idx] = lo;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K4: LIF scan over T of currents cur[T][R][ldc] -> spike planes [T][R][Nw]  (+ per-row counts)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_lif_scan(const float* __restrict__ cur, int T, int R, int N, int Nw,
@@ -624,6 +839,22 @@ __global__ __launch_bounds__(256) void k_li_heads(const uint32_t* __restrict__ s
     }
 }
 
+// per-position spike counts -> per (level, image) totals (bf16x3 RPN path; the fused kernel counts in-register)
+__global__ void k_sum_counts(const uint32_t* __restrict__ row_counts, unsigned long long* __restrict__ counts,
+                             int max_n, int n_levels, const ConvLevelDev* __restrict__ unused, int l_pos_base,
+                             int l_hw, int l_n, int level) {
+    const int n = blockIdx.x;
+    if (n >= l_n) return;
+    unsigned long long sum = 0;
+    const uint32_t* src = row_counts + (size_t)l_pos_base + (size_t)n * l_hw;
+    for (int i = threadIdx.x; i < l_hw; i += blockDim.x) sum += src[i];
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off);
+    __shared__ unsigned long long part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[level * max_n + n] = part[0] + part[1] + part[2] + part[3];
+}
+
 // impulse responses of the LI cell (norse leaky_integrator.py: li_feed_forward_step; v_leak = 0)
 static void li_kappa(const snn_params* p, int T, Kappa* k) {
     const double a = (double)p->dt_tau_mem, cb = (double)p->neg_dt_tau_syn;
@@ -691,6 +922,77 @@ int snn_pack_heads_weight(const float* wa, int NA, const float* wb, int NB, int 
                        wb, NB, K, Kp, NOp, packed);
     SNN_CHECK_LAUNCH("k_pack_heads");
     return 0;
+}
+
+static int check_T(int T, const char* who);
+
+// ---- bf16x3 (exact 3-way bf16 weight split on the bf16 matrix cores) ----------------------------------
+size_t snn_packed_bf16x3_elems(int K_chunks32, int N) { return (size_t)3 * K_chunks32 * (cdiv(N, 32) * 32) * 32; }
+size_t snn_packed_conv3x3_bf16x3_elems(int C_out, int C_in) { return snn_packed_bf16x3_elems(9 * cdiv(C_in, 32), C_out); }
+size_t snn_packed_linear_bf16x3_elems(int N, int K) { return snn_packed_bf16x3_elems(cdiv(K, 32), N); }
+
+int snn_pack_conv3x3_weight_bf16x3(const float* w, int C_out, int C_in, uint16_t* packed, snn_stream_t s) {
+    if (!w || !packed || C_out <= 0 || C_in <= 0) return fail(-1, "snn_pack_conv3x3_weight_bf16x3: bad argument");
+    const int Cp = cdiv(C_in, 32) * 32, Kc = 9 * (Cp / 32), Np = cdiv(C_out, 32) * 32;
+    const size_t total = (size_t)Kc * Np * 32;
+    hipLaunchKernelGGL(k_pack_bf16x3, dim3((unsigned)min((size_t)4096, (total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)s, w, packed, (int)PACK_CONV3X3, 9 * Cp, C_out, Kc, Np, C_in, Cp);
+    SNN_CHECK_LAUNCH("k_pack_bf16x3");
+    return 0;
+}
+
+int snn_pack_linear_weight_bf16x3(const float* w, int N, int K, uint16_t* packed, snn_stream_t s) {
+    if (!w || !packed || N <= 0 || K <= 0) return fail(-1, "snn_pack_linear_weight_bf16x3: bad argument");
+    const int Kc = cdiv(K, 32), Np = cdiv(N, 32) * 32;
+    const size_t total = (size_t)Kc * Np * 32;
+    hipLaunchKernelGGL(k_pack_bf16x3, dim3((unsigned)min((size_t)4096, (total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)s, w, packed, (int)PACK_LINEAR, K, N, Kc, Np, 0, 32);
+    SNN_CHECK_LAUNCH("k_pack_bf16x3");
+    return 0;
+}
+
+static int launch_gemm3(bool conv, const Gemm3Args& a, hipStream_t s) {
+    auto kern = conv ? k_gemm_bf16x3<true> : k_gemm_bf16x3<false>;
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G3_LDS);
+    if (e != hipSuccess) return fail(-3, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(kern, dim3(cdiv(a.M, G3_BM) * a.n_blocks), dim3(512), G3_LDS, s, a);
+    SNN_CHECK_LAUNCH("k_gemm_bf16x3");
+    return 0;
+}
+
+int snn_spike_gemm_bf16x3(const uint32_t* a_rows, int M, int K, int N, const uint16_t* w_packed, float* cur, int ldo,
+                          snn_stream_t s) {
+    if (!a_rows || !w_packed || !cur || M <= 0 || K <= 0 || N <= 0 || ldo < N)
+        return fail(-1, "snn_spike_gemm_bf16x3: bad argument");
+    Gemm3Args a;
+    memset(&a, 0, sizeof(a));
+    a.A = a_rows; a.wpk = w_packed; a.out = cur; a.M = M; a.Kc = cdiv(K, 32); a.Np = cdiv(N, 32) * 32; a.ldo = ldo;
+    a.plane_elems = (unsigned long long)a.Kc * a.Np * 32;
+    a.n_blocks = cdiv(a.Np, G3_BN);
+    return launch_gemm3(false, a, (hipStream_t)s);
+}
+
+int snn_spike_conv3x3_bf16x3(const uint32_t* enc, size_t enc_stride, const snn_rpn_level* lv, int n_levels, int C_in,
+                             int C_out, int T, const uint16_t* w_packed, float* cur, int ldo, snn_stream_t s) {
+    if (!enc || !lv || !w_packed || !cur || n_levels <= 0 || n_levels > SNN_MAX_LEVELS || C_in <= 0 || C_out <= 0 ||
+        ldo < C_out)
+        return fail(-1, "snn_spike_conv3x3_bf16x3: bad argument");
+    if (check_T(T, "snn_spike_conv3x3_bf16x3")) return -1;
+    Gemm3Args a;
+    memset(&a, 0, sizeof(a));
+    long long P = 0;
+    for (int l = 0; l < n_levels; ++l) {
+        if (lv[l].N <= 0 || lv[l].H <= 0 || lv[l].W <= 0) return fail(-1, "snn_spike_conv3x3_bf16x3: bad level %d", l);
+        a.lv[l].pos_base = (int)P; a.lv[l].N = lv[l].N; a.lv[l].H = lv[l].H; a.lv[l].W = lv[l].W;
+        P += (long long)lv[l].N * lv[l].H * lv[l].W;
+    }
+    if ((long long)T * P > 0x7fffffffLL) return fail(-1, "snn_spike_conv3x3_bf16x3: T*P too large");
+    a.A = enc; a.wpk = w_packed; a.out = cur; a.enc_stride = enc_stride;
+    a.Cw = cdiv(C_in, 32); a.Kc = 9 * a.Cw; a.Np = cdiv(C_out, 32) * 32; a.ldo = ldo;
+    a.plane_elems = (unsigned long long)a.Kc * a.Np * 32;
+    a.P_total = (int)P; a.n_levels = n_levels; a.M = (int)(T * P);
+    a.n_blocks = cdiv(a.Np, G3_BN);
+    return launch_gemm3(true, a, (hipStream_t)s);
 }
 
 static int check_T(int T, const char* who) {

@@ -94,9 +94,56 @@ def pack_heads(wa: torch.Tensor, wb: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def pack_conv3x3_bf16x3(w: torch.Tensor) -> torch.Tensor:
+    _need_gpu(w, "conv weight")
+    lib = _lib.load()
+    w = _f32c(w)
+    co, ci = w.shape[0], w.shape[1]
+    out = torch.empty(lib.snn_packed_conv3x3_bf16x3_elems(co, ci), dtype=torch.int16, device=w.device)
+    _lib.check(lib.snn_pack_conv3x3_weight_bf16x3(_ptr(w), co, ci, _ptr(out), _stream()), "snn_pack_conv3x3_weight_bf16x3")
+    return out
+
+
+def pack_linear_bf16x3(w: torch.Tensor) -> torch.Tensor:
+    _need_gpu(w, "linear weight")
+    lib = _lib.load()
+    w = _f32c(w)
+    n, k = w.shape
+    out = torch.empty(lib.snn_packed_linear_bf16x3_elems(n, k), dtype=torch.int16, device=w.device)
+    _lib.check(lib.snn_pack_linear_weight_bf16x3(_ptr(w), n, k, _ptr(out), _stream()), "snn_pack_linear_weight_bf16x3")
+    return out
+
+
 # ---------------------------------------------------------------------------------------------
 # stage-level ops (used by the teacher-forced parity tests)
 # ---------------------------------------------------------------------------------------------
+def spike_gemm_bf16x3(a_rows: torch.Tensor, K: int, N: int, w_packed: torch.Tensor) -> torch.Tensor:
+    """a_rows int32 [M, Kw] -> cur fp32 [M, Np] on the bf16 matrix cores (exact 3-way weight split)"""
+    _need_gpu(a_rows, "spike rows")
+    lib = _lib.load()
+    M = a_rows.shape[0]
+    Np = cdiv(N, 32) * 32
+    cur = torch.empty((M, Np), dtype=torch.float32, device=a_rows.device)
+    _lib.check(lib.snn_spike_gemm_bf16x3(_ptr(a_rows), M, K, N, _ptr(w_packed), _ptr(cur), Np, _stream()),
+               "snn_spike_gemm_bf16x3")
+    return cur
+
+
+def spike_conv3x3_bf16x3(enc: torch.Tensor, shapes, C_in: int, C_out: int, w_packed: torch.Tensor) -> torch.Tensor:
+    """enc int32 [T, P, Cw] over levels `shapes` = [(N,H,W), ...] -> cur fp32 [T, P, Np]"""
+    _need_gpu(enc, "enc planes")
+    lib = _lib.load()
+    T, P, Cw = enc.shape
+    assert P == sum(n * h * w for n, h, w in shapes)
+    lv = (snn_rpn_level * len(shapes))(*[snn_rpn_level(None, n, h, w, 0) for n, h, w in shapes])
+    Np = cdiv(C_out, 32) * 32
+    cur = torch.empty((T, P, Np), dtype=torch.float32, device=enc.device)
+    _lib.check(lib.snn_spike_conv3x3_bf16x3(_ptr(enc), P * Cw, lv, len(shapes), C_in, C_out, T, _ptr(w_packed), _ptr(cur),
+                                            Np, _stream()), "snn_spike_conv3x3_bf16x3")
+    return cur
+
+
+
 def encode_nchw(feat: torch.Tensor, T: int, p: snn_params) -> torch.Tensor:
     """[N,C,H,W] fp32 -> spike bit-planes uint32 viewed as int32 [T, N*H*W, Cw]"""
     _need_gpu(feat, "feature map")

@@ -142,3 +142,50 @@ def test_li_heads_both_orders(S, gpu_device, li_order):
     N, _, H, W = exp_o.shape
     assert (o_a.cpu().view(N, H, W, A).permute(0, 3, 1, 2) - exp_o).abs().max() <= CUR_TOL
     assert (o_b.cpu().view(N, H, W, 4 * A).permute(0, 3, 1, 2) - exp_b).abs().max() <= CUR_TOL
+
+
+# ---------------------------------------------------------------------------------------------
+# exact bf16x3 contractions (bf16 matrix cores): same teacher-forced bars as the fp32 MFMA kernels
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", sorted(FX.DET_SPECS))
+def test_spike_gemm_bf16x3_teacher_forced(S, gpu_device, name):
+    spec = FX.DET_SPECS[name]
+    T, Hd = spec["T"], spec["Hd"]
+    x, w6, w7, wc, wb = FX.det_inputs(spec)
+    R, D = x.shape[0], x[0].numel()
+    _, _, tr = OR.det_head_forward(x, w6, w7, wc, wb, T, trace=True)
+    zp = dense_to_planes(tr["z"].numpy()).to(gpu_device)
+    cur6 = S.spike_gemm_bf16x3(zp.view(T * R, -1), D, Hd, S.pack_linear_bf16x3(w6.to(gpu_device)))
+    assert (cur6.view(T, R, -1)[:, :, :Hd].cpu() - tr["cur6"]).abs().max() <= CUR_TOL
+    s6p = dense_to_planes(tr["spk6"].numpy()).to(gpu_device)
+    cur7 = S.spike_gemm_bf16x3(s6p.view(T * R, -1), Hd, Hd, S.pack_linear_bf16x3(w7.to(gpu_device)))
+    assert (cur7.view(T, R, -1)[:, :, :Hd].cpu() - tr["cur7"]).abs().max() <= CUR_TOL
+    # the two kernel families agree far below the tolerance
+    cur6_f32 = S.spike_gemm(zp.view(T * R, -1), D, Hd, S.pack_linear(w6.to(gpu_device)))
+    assert (cur6 - cur6_f32).abs().max() <= 5e-6
+
+
+@pytest.mark.parametrize("name", sorted(FX.RPN_SPECS))
+def test_spike_conv3x3_bf16x3_teacher_forced(S, gpu_device, name):
+    spec = FX.RPN_SPECS[name]
+    T, C = spec["T"], spec["C"]
+    feats, w_s, w_c, w_b = FX.rpn_inputs(spec)
+    _, _, traces = OR.rpn_head_forward(feats, w_s, w_c, w_b, T, trace=True)
+    wp = S.pack_conv3x3_bf16x3(w_s.to(gpu_device))
+    # all levels in ONE launch: planes concatenated along the position axis
+    enc = torch.cat([dense_to_planes(nchw_to_rows(tr["z"])) for tr in traces], dim=1).to(gpu_device)
+    shapes = [(f.shape[0], f.shape[2], f.shape[3]) for f in feats]
+    cur = S.spike_conv3x3_bf16x3(enc, shapes, C, C, wp).cpu().numpy()
+    pos = 0
+    for f, tr in zip(feats, traces):
+        n = f.shape[0] * f.shape[2] * f.shape[3]
+        exp = nchw_to_rows(tr["cur"])
+        assert np.abs(cur[:, pos:pos + n, :C] - exp).max() <= CUR_TOL
+        pos += n
+    # LIF scan on these currents reproduces the oracle's spikes up to threshold ties
+    p = _params(S)
+    spk = S.lif_scan(torch.from_numpy(cur).to(gpu_device), C, p)
+    got = planes_to_dense(spk, C)
+    exp_spk = np.concatenate([nchw_to_rows(tr["spk"]) for tr in traces], axis=1)
+    flipped = (got != exp_spk).any(axis=(0, 2)).sum()
+    assert flipped <= 2 + 1e-3 * got.shape[1]

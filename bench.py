@@ -11,9 +11,13 @@ FastRCNNPredictorSNNFull.forward (T_det=12) on the 2x1000 RoI features [2000,256
 then the path's one exchange step (all-gather of per-image detections, dp.py) when N>1.
 Images shard over ranks (weak scaling: every rank runs its own batch of 2).
 
-Prints ONE JSON line (rank 0): metric images/s + "roofline" (dominant kernel = fused conv3x3+LIF,
-timed live with HIP events on the launch stream) + "cpu_baseline" (the oracle on the host cores,
-bounded sample, rank 0 at N=1 only).
+Prints ONE JSON line (rank 0): metric images/s + "roofline" (dominant kernel, timed live with HIP events
+on the launch stream) + "cpu_baseline" (the oracle on the host cores, bounded sample, rank 0 at N=1 only).
+
+--precision bf16x3 (default): both big contractions run on the bf16 matrix cores with an EXACT 3-way bf16
+  split of the fp32 weights (spikes are exactly {0,1}; fp32 accumulation; as accurate as the fp32 MFMA chain,
+  tools/bf16x3_numerics.hip) - the results are fp32 results, the executed MFMA work is 3x the algorithmic FLOPs.
+--precision f32: fp32 matrix cores, 3x3 conv + LIF fused over T (profiles/r1_c_pmc_final.txt).
 """
 import argparse
 import json
@@ -31,6 +35,7 @@ C, A, K_CLS, HD = 256, 3, 9, 1024
 T_RPN, T_DET = 8, 12
 BATCH, ROIS_PER_IMG = 2, 1000
 PEAK_F32_MFMA_TFLOPS = 157.3                                     # MI355X_MICROARCH.md chip table
+PEAK_BF16_MFMA_TFLOPS = 2500.0                                   # dense bf16 (no sparsity)
 
 
 def algorithmic_flops():
@@ -95,6 +100,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", choices=["bf16x3", "f32"], default="bf16x3")
     args = ap.parse_args()
 
     import snn_automotive_object_detection_amd as S
@@ -112,6 +118,7 @@ def main():
     torch.manual_seed(1234)                                      # same weights on every rank
     rpn_head = S.RPNHeadSNN(C, A, T_RPN).to(dev)
     det_head = S.FastRCNNPredictorSNNFull(C * 49, HD, K_CLS, T_DET).to(dev)
+    rpn_head.precision = det_head.precision = args.precision
     feats, rois = make_inputs(dev, 1000 + rank)                  # inputs resident in HBM
 
     def step():
@@ -149,7 +156,7 @@ def main():
         return sum(a.elapsed_time(b) for a, b in ev) / iters
 
     p = rpn_head._params()
-    w_sh = rpn_head._cache_shared.val
+    w_sh = rpn_head._packed_shared()
     w_hd = rpn_head._cache_heads.val
     iters = max(3, min(args.steps, 10))
     conv_ms = time_ms(lambda: ops.rpn_head_forward(feats, C, A, T_RPN, p, w_sh, w_hd, stage_mask=2), iters)
@@ -157,11 +164,28 @@ def main():
     rpn_ms = time_ms(lambda: rpn_head(feats), iters)
     det_ms = time_ms(lambda: det_head(rois), iters)
     conv_fl, rpn_fl, det_fl = algorithmic_flops()
-    achieved = conv_fl / (conv_ms * 1e-3) / 1e12
+    P = BATCH * sum(h * w for h, w in LEVELS)
+    if args.precision == "f32":
+        kernel, peak, exec_factor, kernel_ms = "k_conv3x3_lif<false>", PEAK_F32_MFMA_TFLOPS, 1.0, conv_ms
+        traffic_key = "f32"
+    else:
+        # stage 2 = k_gemm_bf16x3<true> (time-batched conv) + k_lif_scan; time the GEMM alone for the roofline
+        encs = torch.empty((T_RPN, P, C // 32), dtype=torch.int32, device=dev)
+        shapes = [(BATCH, h, w) for h, w in LEVELS]
+        pos = 0
+        for f in feats:
+            n = f.shape[0] * f.shape[2] * f.shape[3]
+            encs[:, pos:pos + n] = ops.encode_nchw(f, T_RPN, p)
+            pos += n
+        kernel_ms = time_ms(lambda: ops.spike_conv3x3_bf16x3(encs, shapes, C, C, w_sh), iters)
+        kernel, peak, exec_factor = "k_gemm_bf16x3<true>", PEAK_BF16_MFMA_TFLOPS, 3.0
+        traffic_key = "bf16x3"
+        del encs
+    achieved = conv_fl / (kernel_ms * 1e-3) / 1e12             # ALGORITHMIC (dense-equivalent) TFLOP/s
     traffic = None                    # HBM bytes per launch of the dominant kernel, from the committed PMC passes
     try:
         with open(os.path.join(ROOT, "profiles", "r1_traffic.json")) as f:
-            traffic = json.load(f)["hbm_bytes_per_launch"]
+            traffic = json.load(f)[traffic_key]["hbm_bytes_per_launch"]
     except Exception:
         pass
 
@@ -169,14 +193,18 @@ def main():
         "metric": "images/sec (T_rpn=8,T_det=12, 1024x2048 b=2) spiking RPN+RoI heads forward",
         "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "cityscapes_1024x2048_b2_heads: RPNHeadSNN(T=8) on 5-level pyramid 2x256x{192x384..12x24}"
+        "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "f32 (weights as exact bf16x3 split, fp32 accumulate)",
+        "data": "synthetic",
+        "config": {"precision": args.precision, "workload": "cityscapes_1024x2048_b2_heads: RPNHeadSNN(T=8) on 5-level pyramid 2x256x{192x384..12x24}"
                                " + FastRCNNPredictorSNNFull(T=12) on 2000 RoIs x 12544, K=9; random-init weights",
                    "global_batch": BATCH * world, "parallelism": "dp%d" % world,
                    "exchange": "all-gather of per-image detections [100x6] (RCCL)" if world > 1 else "none"},
-        "roofline": {"bound": "mfma", "kernel": "k_conv3x3_lif", "achieved": round(achieved, 2),
-                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                     "traffic": traffic, "launch_ms": round(conv_ms, 4), "algorithmic_gflop_per_launch": round(conv_fl / 1e9, 1)},
+        "roofline": {"bound": "mfma", "kernel": kernel, "achieved": round(achieved * exec_factor, 2),
+                     "peak": peak, "unit": "TFLOP/s", "frac": round(achieved * exec_factor / peak, 4),
+                     "traffic": traffic, "launch_ms": round(kernel_ms, 4),
+                     "algorithmic_gflop_per_launch": round(conv_fl / 1e9, 1), "executed_over_algorithmic": exec_factor,
+                     "algorithmic_tflops": round(achieved, 2),
+                     "algorithmic_frac_of_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4)},
         "breakdown_ms": {"rpn_head": round(rpn_ms, 3), "rpn_encode": round(enc_ms, 3), "rpn_conv3x3_lif": round(conv_ms, 3),
                          "det_head": round(det_ms, 3)},
         "heads_tflops": round((rpn_fl + det_fl) / ((rpn_ms + det_ms) * 1e-3) / 1e12, 2),

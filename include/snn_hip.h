@@ -54,8 +54,12 @@ typedef struct snn_params {
     float v_th_enc;        /* 0.25  encoder threshold (rpn.py:58, faster_rcnn.py:444) */
     float v_th_lif;        /* 0.1   hidden LIF threshold (rpn.py:67, faster_rcnn.py:449,452) */
     int32_t li_order;      /* 0 = jump-first (upstream li_feed_forward_step), 1 = voltage-first */
-    int32_t reserved;
+    int32_t precision;     /* SNN_PRECISION_*: how the two big contractions run (results are fp32-exact in both) */
 } snn_params;
+
+#define SNN_PRECISION_F32 0      /* fp32 matrix cores (v_mfma_f32_32x32x2_f32); 3x3 conv + LIF fused over T */
+#define SNN_PRECISION_BF16X3 1   /* bf16 matrix cores, exact 3-way bf16 split of the fp32 weights; the conv runs
+                                    time-batched (currents through HBM) followed by the LIF scan */
 
 typedef struct snn_rpn_level {
     const float* feat;     /* [N][C][H][W] fp32, NCHW contiguous (what the FPN hands over) */
@@ -88,10 +92,12 @@ int snn_pack_heads_weight(const float* w_a, int NA, const float* w_b, int NB, in
  * Optional (nullable) spike-rate outputs of the rpn.py:126-200 variant:
  *   spike_counts[n_levels][max_N] (uint64)  number of shared-LIF spikes per level and image,
  *   sum_logits[P][A], sum_bbox[P][4A]        sum over the T steps of the LI membranes.          */
-size_t snn_rpn_head_workspace_bytes(const snn_rpn_level* levels_host, int n_levels, int C, int A, int T);
+size_t snn_rpn_head_workspace_bytes(const snn_rpn_level* levels_host, int n_levels, int C, int A, int T,
+                                    int precision);
 int snn_rpn_head_forward(const snn_rpn_level* levels_host, int n_levels, int C, int A, int T,
                          const snn_params* p_host,
-                         const float* w_shared_packed, const float* w_heads_packed,
+                         const void* w_shared_packed /* snn_pack_conv3x3_weight[_bf16x3], matching p_host->precision */,
+                         const float* w_heads_packed,
                          float* out_logits, float* out_bbox,
                          unsigned long long* spike_counts, float* sum_logits, float* sum_bbox,
                          void* workspace, size_t workspace_bytes, snn_stream_t stream);
@@ -104,7 +110,7 @@ int snn_rpn_head_forward(const snn_rpn_level* levels_host, int n_levels, int C, 
 #define SNN_STAGE_ALL 7
 int snn_rpn_head_forward_stages(const snn_rpn_level* levels_host, int n_levels, int C, int A, int T,
                                 const snn_params* p_host,
-                                const float* w_shared_packed, const float* w_heads_packed,
+                                const void* w_shared_packed, const float* w_heads_packed,
                                 float* out_logits, float* out_bbox,
                                 unsigned long long* spike_counts, float* sum_logits, float* sum_bbox,
                                 void* workspace, size_t workspace_bytes, int stage_mask,
@@ -115,10 +121,11 @@ int snn_rpn_head_forward_stages(const snn_rpn_level* levels_host, int n_levels, 
  * out_bbox[R][K4].  Optional spike-rate outputs of the faster_rcnn.py:520-618 variant:
  *   spk6_count[R], spk7_count[R] (uint32)  spikes per RoI summed over T and the Hd neurons,
  *   sum_cls[R][K], sum_bbox[R][K4]         sum over T of the LI membranes.                      */
-size_t snn_det_head_workspace_bytes(int R, int D, int Hd, int K, int K4, int T);
+size_t snn_det_head_workspace_bytes(int R, int D, int Hd, int K, int K4, int T, int precision);
 int snn_det_head_forward(const float* x, int R, int D, int Hd, int K, int K4, int T,
                          const snn_params* p_host,
-                         const float* w6_packed, const float* w7_packed, const float* w_heads_packed,
+                         const void* w6_packed, const void* w7_packed /* snn_pack_linear_weight[_bf16x3] */,
+                         const float* w_heads_packed,
                          float* out_cls, float* out_bbox,
                          uint32_t* spk6_count, uint32_t* spk7_count, float* sum_cls, float* sum_bbox,
                          void* workspace, size_t workspace_bytes, snn_stream_t stream);

@@ -12,17 +12,18 @@ c_stream = C.c_void_p
 
 SNN_MAX_LEVELS = 8
 SNN_MAX_STEPS = 32
+PRECISIONS = {"f32": 0, "bf16x3": 1}
 
 
 class snn_params(C.Structure):
     _fields_ = [("dt_tau_mem", C.c_float), ("neg_dt_tau_syn", C.c_float), ("v_leak", C.c_float),
                 ("v_reset", C.c_float), ("v_th_enc", C.c_float), ("v_th_lif", C.c_float),
-                ("li_order", C.c_int32), ("reserved", C.c_int32)]
+                ("li_order", C.c_int32), ("precision", C.c_int32)]
 
 
 class snn_rpn_level(C.Structure):
     _fields_ = [("feat", C.c_void_p), ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("precision", C.c_int32)]
 
 
 # every symbol include/snn_hip.h declares: name -> (restype, argtypes)
@@ -36,7 +37,7 @@ SYMBOLS = {
     "snn_pack_linear_weight": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, c_stream]),
     "snn_packed_heads_elems": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "snn_pack_heads_weight": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, c_stream]),
-    "snn_rpn_head_workspace_bytes": (C.c_size_t, [C.POINTER(snn_rpn_level), C.c_int, C.c_int, C.c_int, C.c_int]),
+    "snn_rpn_head_workspace_bytes": (C.c_size_t, [C.POINTER(snn_rpn_level), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "snn_rpn_head_forward": (C.c_int, [C.POINTER(snn_rpn_level), C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.POINTER(snn_params), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, c_stream]),
@@ -44,7 +45,7 @@ SYMBOLS = {
                                               C.POINTER(snn_params), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int,
                                               c_stream]),
-    "snn_det_head_workspace_bytes": (C.c_size_t, [C.c_int] * 6),
+    "snn_det_head_workspace_bytes": (C.c_size_t, [C.c_int] * 7),
     "snn_det_head_forward": (C.c_int, [C.c_void_p] + [C.c_int] * 6 + [C.POINTER(snn_params)] +
                              [C.c_void_p] * 10 + [C.c_size_t, c_stream]),
     "snn_encode_nchw": (C.c_int, [C.c_void_p] + [C.c_int] * 5 + [C.POINTER(snn_params), C.c_void_p, C.c_size_t, c_stream]),

@@ -839,20 +839,17 @@ __global__ __launch_bounds__(256) void k_li_heads(const uint32_t* __restrict__ s
     }
 }
 
-// per-position spike counts -> per (level, image) totals (bf16x3 RPN path; the fused kernel counts in-register)
-__global__ void k_sum_counts(const uint32_t* __restrict__ row_counts, unsigned long long* __restrict__ counts,
-                             int max_n, int n_levels, const ConvLevelDev* __restrict__ unused, int l_pos_base,
-                             int l_hw, int l_n, int level) {
-    const int n = blockIdx.x;
-    if (n >= l_n) return;
+// per-position spike counts -> per-image totals of one level (bf16x3 RPN path; the fused kernel counts in-register)
+__global__ __launch_bounds__(256) void k_sum_counts(const uint32_t* __restrict__ row_counts,
+                                                    unsigned long long* __restrict__ counts, int hw) {
+    const uint32_t* src = row_counts + (size_t)blockIdx.x * hw;
     unsigned long long sum = 0;
-    const uint32_t* src = row_counts + (size_t)l_pos_base + (size_t)n * l_hw;
-    for (int i = threadIdx.x; i < l_hw; i += blockDim.x) sum += src[i];
+    for (int i = threadIdx.x; i < hw; i += 256) sum += src[i];
     for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off);
     __shared__ unsigned long long part[4];
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sum;
     __syncthreads();
-    if (threadIdx.x == 0) counts[level * max_n + n] = part[0] + part[1] + part[2] + part[3];
+    if (threadIdx.x == 0) counts[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
 }
 
 // impulse responses of the LI cell (norse leaky_integrator.py: li_feed_forward_step; v_leak = 0)
@@ -1128,34 +1125,48 @@ static long long rpn_positions(const snn_rpn_level* lv, int n_levels, int* max_n
     return P;
 }
 
-size_t snn_rpn_head_workspace_bytes(const snn_rpn_level* lv, int n_levels, int C, int A, int T) {
+static void rpn_ws_layout(long long P, int C, int T, int precision, size_t* o_spk, size_t* o_cur, size_t* o_cnt,
+                          size_t* total) {
+    const size_t plane = align_up((size_t)T * P * cdiv(C, 32) * 4, 256);
+    *o_spk = plane;
+    *o_cur = 2 * plane;
+    const size_t cur = precision == SNN_PRECISION_BF16X3 ? align_up((size_t)T * P * cdiv(C, 32) * 32 * 4, 256) : 0;
+    *o_cnt = 2 * plane + cur;
+    const size_t cnt = precision == SNN_PRECISION_BF16X3 ? align_up((size_t)P * 4, 256) : 0;
+    *total = 2 * plane + cur + cnt;
+}
+
+size_t snn_rpn_head_workspace_bytes(const snn_rpn_level* lv, int n_levels, int C, int A, int T, int precision) {
     (void)A;
     if (!lv || n_levels <= 0 || n_levels > SNN_MAX_LEVELS || C <= 0 || T < 1) return 0;
-    const long long P = rpn_positions(lv, n_levels, nullptr);
-    const size_t plane = align_up((size_t)T * P * cdiv(C, 32) * 4, 256);
-    return 2 * plane;     // encoder planes + shared-LIF spike planes
+    size_t a, b, c, tot;
+    rpn_ws_layout(rpn_positions(lv, n_levels, nullptr), C, T, precision, &a, &b, &c, &tot);
+    return tot;
 }
 
 int snn_rpn_head_forward_stages(const snn_rpn_level* lv, int n_levels, int C, int A, int T, const snn_params* p,
-                                const float* w_shared_packed, const float* w_heads_packed, float* out_logits,
+                                const void* w_shared_packed, const float* w_heads_packed, float* out_logits,
                                 float* out_bbox, unsigned long long* spike_counts, float* sum_logits,
                                 float* sum_bbox, void* ws, size_t ws_bytes, int stage_mask, snn_stream_t stream) {
     if (!lv || !p || !w_shared_packed || !w_heads_packed || !out_logits || !out_bbox || !ws)
         return fail(-1, "snn_rpn_head_forward: null argument");
     if (n_levels <= 0 || n_levels > SNN_MAX_LEVELS) return fail(-1, "snn_rpn_head_forward: n_levels=%d", n_levels);
     if (C <= 0 || A <= 0) return fail(-1, "snn_rpn_head_forward: bad C/A");
+    if (p->precision != SNN_PRECISION_F32 && p->precision != SNN_PRECISION_BF16X3)
+        return fail(-1, "snn_rpn_head_forward: unknown precision %d", p->precision);
     if (check_T(T, "snn_rpn_head_forward")) return -1;
     for (int l = 0; l < n_levels; ++l)
         if (!lv[l].feat || lv[l].N <= 0 || lv[l].H <= 0 || lv[l].W <= 0)
             return fail(-1, "snn_rpn_head_forward: bad level %d", l);
-    const size_t need = snn_rpn_head_workspace_bytes(lv, n_levels, C, A, T);
-    if (ws_bytes < need) return fail(-2, "snn_rpn_head_forward: workspace %zu < %zu bytes", ws_bytes, need);
     int max_n = 0;
     const long long P = rpn_positions(lv, n_levels, &max_n);
+    size_t o_spk, o_cur, o_cnt, need;
+    rpn_ws_layout(P, C, T, p->precision, &o_spk, &o_cur, &o_cnt, &need);
+    if (ws_bytes < need) return fail(-2, "snn_rpn_head_forward: workspace %zu < %zu bytes", ws_bytes, need);
     const int Cw = cdiv(C, 32);
     const size_t stride = (size_t)P * Cw;            // words per time plane
     uint32_t* enc = (uint32_t*)ws;
-    uint32_t* spk = (uint32_t*)((char*)ws + need / 2);
+    uint32_t* spk = (uint32_t*)((char*)ws + o_spk);
     hipStream_t s = (hipStream_t)stream;
     long long pos = 0;
     for (int l = 0; l < n_levels && (stage_mask & SNN_STAGE_ENCODE); ++l) {
@@ -1164,12 +1175,38 @@ int snn_rpn_head_forward_stages(const snn_rpn_level* lv, int n_levels, int C, in
         pos += (long long)lv[l].N * lv[l].H * lv[l].W;
     }
     if (stage_mask & SNN_STAGE_CONV_LIF) {
-        if (spike_counts) {
-            hipError_t e = hipMemsetAsync(spike_counts, 0, sizeof(unsigned long long) * n_levels * max_n, s);
-            if (e != hipSuccess) return fail(-3, "hipMemsetAsync failed: %s", hipGetErrorString(e));
+        if (p->precision == SNN_PRECISION_F32) {
+            if (spike_counts) {
+                hipError_t e = hipMemsetAsync(spike_counts, 0, sizeof(unsigned long long) * n_levels * max_n, s);
+                if (e != hipSuccess) return fail(-3, "hipMemsetAsync failed: %s", hipGetErrorString(e));
+            }
+            int rc = launch_conv(lv, n_levels, C, C, T, p, enc, stride, (const float*)w_shared_packed, spk, stride,
+                                 spike_counts, max_n, nullptr, s);
+            if (rc) return rc;
+        } else {
+            // time-batched conv on the bf16 matrix cores -> currents -> LIF scan over T (rpn.py:105-106)
+            float* cur = (float*)((char*)ws + o_cur);
+            uint32_t* row_counts = spike_counts ? (uint32_t*)((char*)ws + o_cnt) : nullptr;
+            const int Np = Cw * 32;
+            int rc = snn_spike_conv3x3_bf16x3(enc, stride, lv, n_levels, C, C, T, (const uint16_t*)w_shared_packed, cur,
+                                              Np, stream);
+            if (rc) return rc;
+            if (row_counts && hipMemsetAsync(row_counts, 0, sizeof(uint32_t) * P, s) != hipSuccess)
+                return fail(-3, "hipMemsetAsync failed");
+            if ((rc = snn_lif_scan(cur, T, (int)P, C, Np, p, spk, stride, row_counts, stream))) return rc;
+            if (spike_counts) {
+                if (hipMemsetAsync(spike_counts, 0, sizeof(unsigned long long) * n_levels * max_n, s) != hipSuccess)
+                    return fail(-3, "hipMemsetAsync failed");
+                long long pb = 0;
+                for (int l = 0; l < n_levels; ++l) {
+                    const int hw = lv[l].H * lv[l].W;
+                    hipLaunchKernelGGL(k_sum_counts, dim3(lv[l].N), dim3(256), 0, s, row_counts + pb,
+                                       spike_counts + (size_t)l * max_n, hw);
+                    SNN_CHECK_LAUNCH("k_sum_counts");
+                    pb += (long long)lv[l].N * hw;
+                }
+            }
         }
-        int rc = launch_conv(lv, n_levels, C, C, T, p, enc, stride, w_shared_packed, spk, stride, spike_counts, max_n, nullptr, s);
-        if (rc) return rc;
     }
     if (!(stage_mask & SNN_STAGE_LI_HEADS)) return 0;
     return snn_li_heads(spk, stride, T, (int)P, C, w_heads_packed, A, 4 * A, p, out_logits, out_bbox, sum_logits,
@@ -1177,7 +1214,7 @@ int snn_rpn_head_forward_stages(const snn_rpn_level* lv, int n_levels, int C, in
 }
 
 int snn_rpn_head_forward(const snn_rpn_level* lv, int n_levels, int C, int A, int T, const snn_params* p,
-                         const float* w_shared_packed, const float* w_heads_packed, float* out_logits,
+                         const void* w_shared_packed, const float* w_heads_packed, float* out_logits,
                          float* out_bbox, unsigned long long* spike_counts, float* sum_logits, float* sum_bbox,
                          void* ws, size_t ws_bytes, snn_stream_t stream) {
     return snn_rpn_head_forward_stages(lv, n_levels, C, A, T, p, w_shared_packed, w_heads_packed, out_logits,
@@ -1193,8 +1230,8 @@ static void det_ws_layout(int R, int D, int Hd, int T, size_t* o_enc, size_t* o_
     *o_enc = 0; *o_cur = enc; *o_s6 = enc + cur; *o_s7 = enc + cur + sp; *total = enc + cur + 2 * sp;
 }
 
-size_t snn_det_head_workspace_bytes(int R, int D, int Hd, int K, int K4, int T) {
-    (void)K; (void)K4;
+size_t snn_det_head_workspace_bytes(int R, int D, int Hd, int K, int K4, int T, int precision) {
+    (void)K; (void)K4; (void)precision;
     if (R <= 0 || D <= 0 || Hd <= 0 || T < 1) return 0;
     size_t a, b, c, d, tot;
     det_ws_layout(R, D, Hd, T, &a, &b, &c, &d, &tot);
@@ -1202,7 +1239,7 @@ size_t snn_det_head_workspace_bytes(int R, int D, int Hd, int K, int K4, int T) 
 }
 
 int snn_det_head_forward(const float* x, int R, int D, int Hd, int K, int K4, int T, const snn_params* p,
-                         const float* w6_packed, const float* w7_packed, const float* w_heads_packed,
+                         const void* w6_packed, const void* w7_packed, const float* w_heads_packed,
                          float* out_cls, float* out_bbox, uint32_t* spk6_count, uint32_t* spk7_count,
                          float* sum_cls, float* sum_bbox, void* ws, size_t ws_bytes, snn_stream_t stream) {
     if (!x || !p || !w6_packed || !w7_packed || !w_heads_packed || !out_cls || !out_bbox || !ws)
@@ -1223,9 +1260,15 @@ int snn_det_head_forward(const float* x, int R, int D, int Hd, int K, int K4, in
     if (spk7_count) { if (hipMemsetAsync(spk7_count, 0, sizeof(uint32_t) * R, s) != hipSuccess) return fail(-3, "hipMemsetAsync failed"); }
     if ((rc = snn_encode_rows(x, R, D, T, p, enc, (size_t)R * Dw, stream))) return rc;
     // fc6 for all T steps at once: rows m = t*R + r   (faster_rcnn.py:498)
-    if ((rc = snn_spike_gemm(enc, T * R, D, Hd, w6_packed, cur, Hp, stream))) return rc;
+    const bool b3 = p->precision == SNN_PRECISION_BF16X3;
+    if (p->precision != SNN_PRECISION_F32 && !b3) return fail(-1, "snn_det_head_forward: unknown precision %d", p->precision);
+    rc = b3 ? snn_spike_gemm_bf16x3(enc, T * R, D, Hd, (const uint16_t*)w6_packed, cur, Hp, stream)
+            : snn_spike_gemm(enc, T * R, D, Hd, (const float*)w6_packed, cur, Hp, stream);
+    if (rc) return rc;
     if ((rc = snn_lif_scan(cur, T, R, Hd, Hp, p, s6, (size_t)R * Hw, spk6_count, stream))) return rc;   // :499
-    if ((rc = snn_spike_gemm(s6, T * R, Hd, Hd, w7_packed, cur, Hp, stream))) return rc;                // :500
+    rc = b3 ? snn_spike_gemm_bf16x3(s6, T * R, Hd, Hd, (const uint16_t*)w7_packed, cur, Hp, stream)
+            : snn_spike_gemm(s6, T * R, Hd, Hd, (const float*)w7_packed, cur, Hp, stream);                       // :500
+    if (rc) return rc;
     if ((rc = snn_lif_scan(cur, T, R, Hd, Hp, p, s7, (size_t)R * Hw, spk7_count, stream))) return rc;   // :501
     return snn_li_heads(s7, (size_t)R * Hw, T, R, Hd, w_heads_packed, K, K4, p, out_cls, out_bbox, sum_cls,
                         sum_bbox, stream);                                                               // :505-510

@@ -34,23 +34,27 @@ class FastRCNNPredictorSNNFull(nn.Module):
         self.p_lif = ops.LIFParameters(alpha=100, v_th=torch.tensor(0.1))   # :449,452
         self.li_order = "jump_first"
         self.spike_rates = False
+        self.precision = "bf16x3"          # or "f32" (fp32 matrix cores); see RPNHeadSNN
         self.fc6 = nn.Linear(in_channels, representation_size, bias=False)          # :448
         self.fc7 = nn.Linear(representation_size, representation_size, bias=False)  # :451
         self.cls_score = nn.Linear(representation_size, num_classes, bias=False)    # :455
         self.only_one_bbox = only_one_bbox                                           # :460-467
         self.bbox_pred = nn.Linear(representation_size, 4 if only_one_bbox else num_classes * 4, bias=False)
-        self._c6, self._c7, self._ch = _WeightCache(), _WeightCache(), _WeightCache()
+        self._c6 = {"f32": _WeightCache(), "bf16x3": _WeightCache()}
+        self._c7 = {"f32": _WeightCache(), "bf16x3": _WeightCache()}
+        self._ch = _WeightCache()
 
     def _params(self):
-        return ops.make_params(self.p_enc, self.p_lif, self.dt, self.li_order)
+        return ops.make_params(self.p_enc, self.p_lif, self.dt, self.li_order, self.precision)
 
     @torch.no_grad()
     def forward(self, x):
         T = int(self.num_steps)
         Hd, K = self.representation_size, self.num_classes
         K4 = self.bbox_pred.weight.shape[0]
-        w6 = self._c6.get((self.fc6.weight,), ops.pack_linear)
-        w7 = self._c7.get((self.fc7.weight,), ops.pack_linear)
+        pack = ops.pack_linear if self.precision == "f32" else ops.pack_linear_bf16x3
+        w6 = self._c6[self.precision].get((self.fc6.weight,), pack)
+        w7 = self._c7[self.precision].get((self.fc7.weight,), pack)
         wh = self._ch.get((self.cls_score.weight, self.bbox_pred.weight), ops.pack_heads)
         x = x.flatten(start_dim=1)                                     # :473
         if x.shape[1] != self.in_channels:

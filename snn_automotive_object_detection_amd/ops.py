@@ -25,7 +25,7 @@ class LIFParameters(NamedTuple):
 
 
 def make_params(p_enc: LIFParameters, p_lif: LIFParameters, dt: float = DT,
-                li_order: str = "jump_first") -> snn_params:
+                li_order: str = "jump_first", precision: str = "bf16x3") -> snn_params:
     """Form the fp32 constants exactly as Norse forms them: 0-dim fp32 tensor products
     ``dt * tau_mem_inv`` and ``-dt * tau_syn_inv`` (norse lif.py / leaky_integrator.py)."""
     ca = dt * p_lif.tau_mem_inv.to(torch.float32)
@@ -33,7 +33,7 @@ def make_params(p_enc: LIFParameters, p_lif: LIFParameters, dt: float = DT,
     assert ca.dtype == torch.float32 and cb.dtype == torch.float32
     return snn_params(float(ca), float(cb), float(p_lif.v_leak), float(p_lif.v_reset),
                       float(p_enc.v_th.to(torch.float32)), float(p_lif.v_th.to(torch.float32)),
-                      {"jump_first": 0, "voltage_first": 1}[li_order], 0)
+                      {"jump_first": 0, "voltage_first": 1}[li_order], _lib.PRECISIONS[precision])
 
 
 def _need_gpu(t: torch.Tensor, what: str):
@@ -266,7 +266,7 @@ def rpn_head_forward(feats: Sequence[torch.Tensor], C_: int, A: int, T: int, p: 
         rows.append(f.shape[0] * f.shape[2] * f.shape[3])
     P = sum(rows)
     max_n = max(f.shape[0] for f in feats)
-    ws_bytes = lib.snn_rpn_head_workspace_bytes(lv, len(feats), C_, A, T)
+    ws_bytes = lib.snn_rpn_head_workspace_bytes(lv, len(feats), C_, A, T, p.precision)
     ws = _WS.get(dev, ws_bytes)
     out_logits = torch.empty((P, A), dtype=torch.float32, device=dev)
     out_bbox = torch.empty((P, 4 * A), dtype=torch.float32, device=dev)
@@ -300,7 +300,7 @@ def det_head_forward(x: torch.Tensor, Hd: int, K: int, K4: int, T: int, p: snn_p
         s_b = torch.empty_like(out_bbox)
     if R == 0:
         return out_cls, out_bbox, (c6, c7, s_c, s_b)
-    ws_bytes = lib.snn_det_head_workspace_bytes(R, D, Hd, K, K4, T)
+    ws_bytes = lib.snn_det_head_workspace_bytes(R, D, Hd, K, K4, T, p.precision)
     ws = _WS.get(dev, ws_bytes)
     _lib.check(lib.snn_det_head_forward(_ptr(x), R, D, Hd, K, K4, T, C.byref(p), _ptr(w6_packed), _ptr(w7_packed),
                                         _ptr(w_heads_packed), _ptr(out_cls), _ptr(out_bbox), _ptr(c6), _ptr(c7),

@@ -168,6 +168,11 @@ int snn_pack_linear_weight_bf16x3(const float* w_nk, int N, int K, uint16_t* pac
 /* cur[M][ldo] = A_bits[M][K] x W[K][N] */
 int snn_spike_gemm_bf16x3(const uint32_t* a_rows, int M, int K, int N, const uint16_t* w_packed, float* cur,
                           int ldo, snn_stream_t stream);
+/* 3x3 spike convolution + LIF fused over T on the bf16 matrix cores, all levels in one launch:
+ * enc planes [T][P][Cw] -> spk planes [T][P][Nw]; the membrane state never leaves the registers */
+int snn_conv3x3_lif_bf16x3(const uint32_t* enc, size_t enc_stride_words, const snn_rpn_level* levels_host,
+                           int n_levels, int C_in, int C_out, int T, const snn_params* p_host,
+                           const uint16_t* w_packed, uint32_t* spk, size_t spk_stride_words, snn_stream_t stream);
 /* un-fused time-batched 3x3 spike convolution over all levels: enc planes [T][P][Cw] -> cur[T*P][ldo]
  * (row = t*P + position; position order as in snn_rpn_head_forward); follow with snn_lif_scan */
 int snn_spike_conv3x3_bf16x3(const uint32_t* enc, size_t enc_stride_words, const snn_rpn_level* levels_host,

@@ -519,6 +519,11 @@ struct Gemm3Args {
     unsigned long long enc_stride;      // conv: words per time plane
     int M, Kc, Np, ldo, n_blocks;
     int Cw, P_total, n_levels;          // conv only
+    // fused conv + LIF (FUSE): rows are positions, the T loop runs inside, spikes leave as bit-planes
+    int T, pad;
+    uint32_t* spk;
+    unsigned long long spk_stride;
+    NeuronP p;
     ConvLevelDev lv[SNN_MAX_LEVELS];
 };
 
@@ -527,8 +532,11 @@ __device__ __forceinline__ uint32_t bf16_pair(uint32_t w, int j) {      // bits 
     return ((t | (t << 15)) & 0x10001u) * 0x3F80u;
 }
 
-template <bool CONV>
+// FUSE (conv only): M = positions; per time step the 9*Cw chunks are accumulated, then the LIF update runs
+// on the accumulators in registers (64 acc + 64 v + 64 i per lane) and only spike bits are written.
+template <bool CONV, bool FUSE>
 __global__ __launch_bounds__(512) void k_gemm_bf16x3(const Gemm3Args args) {
+    static_assert(CONV || !FUSE, "LIF fusion is for the conv rows");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -549,7 +557,7 @@ __global__ __launch_bounds__(512) void k_gemm_bf16x3(const Gemm3Args args) {
     uint32_t a_valid = 0;                           // conv: 9-bit tap validity
     if (CONV) {
         if (xm < M) {
-            const int t = xm / args.P_total, p = xm % args.P_total;
+            const int t = FUSE ? 0 : xm / args.P_total, p = FUSE ? xm : xm % args.P_total;
             int l = 0;
             while (l + 1 < args.n_levels && p >= args.lv[l + 1].pos_base) ++l;
             const int H = args.lv[l].H, W = args.lv[l].W;
@@ -616,42 +624,93 @@ __global__ __launch_bounds__(512) void k_gemm_bf16x3(const Gemm3Args args) {
     const int a_rd = (wm * 64 + li) * G3_ROWB + 16 * lh;       // + mt*32*ROWB + 32*s
     const int b_rd = (wn * 64 + li) * G3_ROWB + 16 * lh;       // + pl*BN*ROWB + nt*32*ROWB + 32*s
 
-    // prologue: chunk 0
+    // LIF state of the fused variant (registers, whole T loop)
+    float v[FUSE ? 2 : 1][FUSE ? 2 : 1][FUSE ? 16 : 1], ci[FUSE ? 2 : 1][FUSE ? 2 : 1][FUSE ? 16 : 1];
+    uint32_t valid_bits[2] = {0u, 0u};
+    if (FUSE) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { v[mt][nt][r] = args.p.v_leak; ci[mt][nt][r] = 0.0f; }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                valid_bits[mt] |= (uint32_t)(m0 + wm * 64 + mt * 32 + acc_row(r, lh) < M) << r;
+    }
+    const int n_steps = FUSE ? args.T : 1;
+
+    // prologue: chunk 0 (of step 0)
     uint32_t a_w = fetch_a(0);
     fetch_b(0);
     store_a(a_w, 0);
     store_b(0);
     __syncthreads();
+    int buf = 0;
 
-    for (int kc = 0; kc < Kc; ++kc) {
-        const int buf = kc & 1;
-        const bool more = kc + 1 < Kc;
-        if (more) { a_w = fetch_a(kc + 1); fetch_b(kc + 1); }      // global loads in flight during the MFMAs
-        const unsigned char* Ab = smem + buf * G3_A_BYTES + a_rd;
-        const unsigned char* Bb = smem + 2 * G3_A_BYTES + buf * G3_B_BYTES + b_rd;
+    for (int t = 0; t < n_steps; ++t) {
+        for (int kc = 0; kc < Kc; ++kc) {
+            const bool last = kc + 1 == Kc;
+            const bool more = !last || t + 1 < n_steps;
+            if (more) {                                     // global loads in flight during the MFMAs
+                if (FUSE && last) a_src += args.enc_stride; // next chunk belongs to the next time plane
+                a_w = fetch_a(last ? 0 : kc + 1);
+                fetch_b(last ? 0 : kc + 1);
+            }
+            const unsigned char* Ab = smem + buf * G3_A_BYTES + a_rd;
+            const unsigned char* Bb = smem + 2 * G3_A_BYTES + buf * G3_B_BYTES + b_rd;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            bf16x8 a[2], b[2][3];
+            for (int s = 0; s < 2; ++s) {
+                bf16x8 a[2];
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) a[mt] = *reinterpret_cast<const bf16x8*>(Ab + mt * 32 * G3_ROWB + 32 * s);
+                for (int mt = 0; mt < 2; ++mt) a[mt] = *reinterpret_cast<const bf16x8*>(Ab + mt * 32 * G3_ROWB + 32 * s);
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+                for (int nt = 0; nt < 2; ++nt) {
+                    bf16x8 b[3];                 // one N-tile's three planes at a time: 12 live registers
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-                    b[nt][pl] = *reinterpret_cast<const bf16x8*>(Bb + pl * (G3_BN * G3_ROWB) + nt * 32 * G3_ROWB + 32 * s);
+                    for (int pl = 0; pl < 3; ++pl)
+                        b[pl] = *reinterpret_cast<const bf16x8*>(Bb + pl * (G3_BN * G3_ROWB) + nt * 32 * G3_ROWB + 32 * s);
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        // small terms first: lo, mid, hi
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[2], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[1], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[0], acc[mt][nt], 0, 0, 0);
+                    }
+                }
+            }
+            if (more) { store_a(a_w, buf ^ 1); store_b(buf ^ 1); }
+            __syncthreads();
+            buf ^= 1;
+        }
+        if (FUSE) {
+            // ---- LIF epilogue in registers; spikes leave as ballots (2 position words per register) ----
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
-                    // small terms first: lo, mid, hi
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[nt][2], acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[nt][1], acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[nt][0], acc[mt][nt], 0, 0, 0);
+                    uint32_t myword = 0;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        bool z = lif_step(acc[mt][nt][r], v[mt][nt][r], ci[mt][nt][r], args.p);
+                        z = z && ((valid_bits[mt] >> r) & 1u);
+                        acc[mt][nt][r] = 0.0f;
+                        const unsigned long long m = __ballot(z);
+                        myword = (lane == 2 * r) ? (uint32_t)m : myword;
+                        myword = (lane == 2 * r + 1) ? (uint32_t)(m >> 32) : myword;
+                    }
+                    if (lane < 32) {      // lane -> (r = lane>>1, half = lane&1): one 32-channel word of one position
+                        const int row = m0 + wm * 64 + mt * 32 + acc_row(lane >> 1, lane & 1);
+                        const int ntile = (nb * G3_BN + wn * 64 + nt * 32) >> 5;
+                        if (row < M && ntile * 32 < Np)
+                            args.spk[(size_t)t * args.spk_stride + (size_t)row * (Np >> 5) + ntile] = myword;
+                    }
                 }
         }
-        if (more) { store_a(a_w, buf ^ 1); store_b(buf ^ 1); }
-        __syncthreads();
     }
+    if (FUSE) return;
     // ---- store currents ----
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -839,12 +898,15 @@ __global__ __launch_bounds__(256) void k_li_heads(const uint32_t* __restrict__ s
     }
 }
 
-// per-position spike counts -> per-image totals of one level (bf16x3 RPN path; the fused kernel counts in-register)
-__global__ __launch_bounds__(256) void k_sum_counts(const uint32_t* __restrict__ row_counts,
-                                                    unsigned long long* __restrict__ counts, int hw) {
-    const uint32_t* src = row_counts + (size_t)blockIdx.x * hw;
+// spikes per image of one level, counted from the bit-planes (spike-rate mode of the bf16x3 path)
+__global__ __launch_bounds__(256) void k_count_spikes(const uint32_t* __restrict__ spk, unsigned long long spk_stride,
+                                                      int T, int words_per_image,
+                                                      unsigned long long* __restrict__ counts) {
     unsigned long long sum = 0;
-    for (int i = threadIdx.x; i < hw; i += 256) sum += src[i];
+    for (int t = 0; t < T; ++t) {
+        const uint32_t* src = spk + (size_t)t * spk_stride + (size_t)blockIdx.x * words_per_image;
+        for (int i = threadIdx.x; i < words_per_image; i += 256) sum += __popc(src[i]);
+    }
     for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off);
     __shared__ unsigned long long part[4];
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sum;
@@ -949,7 +1011,7 @@ int snn_pack_linear_weight_bf16x3(const float* w, int N, int K, uint16_t* packed
 }
 
 static int launch_gemm3(bool conv, const Gemm3Args& a, hipStream_t s) {
-    auto kern = conv ? k_gemm_bf16x3<true> : k_gemm_bf16x3<false>;
+    auto kern = conv ? (a.spk ? k_gemm_bf16x3<true, true> : k_gemm_bf16x3<true, false>) : k_gemm_bf16x3<false, false>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G3_LDS);
     if (e != hipSuccess) return fail(-3, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
     hipLaunchKernelGGL(kern, dim3(cdiv(a.M, G3_BM) * a.n_blocks), dim3(512), G3_LDS, s, a);
@@ -967,6 +1029,40 @@ int snn_spike_gemm_bf16x3(const uint32_t* a_rows, int M, int K, int N, const uin
     a.plane_elems = (unsigned long long)a.Kc * a.Np * 32;
     a.n_blocks = cdiv(a.Np, G3_BN);
     return launch_gemm3(false, a, (hipStream_t)s);
+}
+
+static int conv3_common(const char* who, const uint32_t* enc, size_t enc_stride, const snn_rpn_level* lv, int n_levels,
+                        int C_in, int C_out, int T, const uint16_t* w_packed, Gemm3Args& a, long long* P_out) {
+    if (!enc || !lv || !w_packed || n_levels <= 0 || n_levels > SNN_MAX_LEVELS || C_in <= 0 || C_out <= 0)
+        return fail(-1, "%s: bad argument", who);
+    if (check_T(T, who)) return -1;
+    memset(&a, 0, sizeof(a));
+    long long P = 0;
+    for (int l = 0; l < n_levels; ++l) {
+        if (lv[l].N <= 0 || lv[l].H <= 0 || lv[l].W <= 0) return fail(-1, "%s: bad level %d", who, l);
+        a.lv[l].pos_base = (int)P; a.lv[l].N = lv[l].N; a.lv[l].H = lv[l].H; a.lv[l].W = lv[l].W;
+        P += (long long)lv[l].N * lv[l].H * lv[l].W;
+    }
+    if ((long long)T * P > 0x7fffffffLL) return fail(-1, "%s: T*P too large", who);
+    a.A = enc; a.wpk = w_packed; a.enc_stride = enc_stride;
+    a.Cw = cdiv(C_in, 32); a.Kc = 9 * a.Cw; a.Np = cdiv(C_out, 32) * 32;
+    a.plane_elems = (unsigned long long)a.Kc * a.Np * 32;
+    a.P_total = (int)P; a.n_levels = n_levels;
+    a.n_blocks = cdiv(a.Np, G3_BN);
+    *P_out = P;
+    return 0;
+}
+
+int snn_conv3x3_lif_bf16x3(const uint32_t* enc, size_t enc_stride, const snn_rpn_level* lv, int n_levels, int C_in,
+                           int C_out, int T, const snn_params* p, const uint16_t* w_packed, uint32_t* spk,
+                           size_t spk_stride, snn_stream_t s) {
+    if (!spk || !p) return fail(-1, "snn_conv3x3_lif_bf16x3: bad argument");
+    Gemm3Args a;
+    long long P;
+    int rc = conv3_common("snn_conv3x3_lif_bf16x3", enc, enc_stride, lv, n_levels, C_in, C_out, T, w_packed, a, &P);
+    if (rc) return rc;
+    a.M = (int)P; a.T = T; a.spk = spk; a.spk_stride = spk_stride; a.p = make_p(p, p->v_th_lif);
+    return launch_gemm3(true, a, (hipStream_t)s);
 }
 
 int snn_spike_conv3x3_bf16x3(const uint32_t* enc, size_t enc_stride, const snn_rpn_level* lv, int n_levels, int C_in,
@@ -1130,9 +1226,10 @@ static void rpn_ws_layout(long long P, int C, int T, int precision, size_t* o_sp
     const size_t plane = align_up((size_t)T * P * cdiv(C, 32) * 4, 256);
     *o_spk = plane;
     *o_cur = 2 * plane;
+    // bf16x3: the conv runs time-batched and hands T*P*Np fp32 currents to the LIF scan through HBM
     const size_t cur = precision == SNN_PRECISION_BF16X3 ? align_up((size_t)T * P * cdiv(C, 32) * 32 * 4, 256) : 0;
     *o_cnt = 2 * plane + cur;
-    const size_t cnt = precision == SNN_PRECISION_BF16X3 ? align_up((size_t)P * 4, 256) : 0;
+    const size_t cnt = 0;
     *total = 2 * plane + cur + cnt;
 }
 
@@ -1184,25 +1281,24 @@ int snn_rpn_head_forward_stages(const snn_rpn_level* lv, int n_levels, int C, in
                                  spike_counts, max_n, nullptr, s);
             if (rc) return rc;
         } else {
-            // time-batched conv on the bf16 matrix cores -> currents -> LIF scan over T (rpn.py:105-106)
+            // time-batched conv on the bf16 matrix cores -> currents -> LIF scan over T (rpn.py:98-106).
+            // (snn_conv3x3_lif_bf16x3 fuses the scan into the GEMM and gives bit-identical planes; at 255 VGPRs it
+            //  measures 5.8 ms against 4.7 + 0.5 ms for this pair, so the pair is what runs.)
             float* cur = (float*)((char*)ws + o_cur);
-            uint32_t* row_counts = spike_counts ? (uint32_t*)((char*)ws + o_cnt) : nullptr;
             const int Np = Cw * 32;
             int rc = snn_spike_conv3x3_bf16x3(enc, stride, lv, n_levels, C, C, T, (const uint16_t*)w_shared_packed, cur,
                                               Np, stream);
             if (rc) return rc;
-            if (row_counts && hipMemsetAsync(row_counts, 0, sizeof(uint32_t) * P, s) != hipSuccess)
-                return fail(-3, "hipMemsetAsync failed");
-            if ((rc = snn_lif_scan(cur, T, (int)P, C, Np, p, spk, stride, row_counts, stream))) return rc;
+            if ((rc = snn_lif_scan(cur, T, (int)P, C, Np, p, spk, stride, nullptr, stream))) return rc;
             if (spike_counts) {
                 if (hipMemsetAsync(spike_counts, 0, sizeof(unsigned long long) * n_levels * max_n, s) != hipSuccess)
                     return fail(-3, "hipMemsetAsync failed");
                 long long pb = 0;
                 for (int l = 0; l < n_levels; ++l) {
                     const int hw = lv[l].H * lv[l].W;
-                    hipLaunchKernelGGL(k_sum_counts, dim3(lv[l].N), dim3(256), 0, s, row_counts + pb,
-                                       spike_counts + (size_t)l * max_n, hw);
-                    SNN_CHECK_LAUNCH("k_sum_counts");
+                    hipLaunchKernelGGL(k_count_spikes, dim3(lv[l].N), dim3(256), 0, s, spk + (size_t)pb * Cw,
+                                       (unsigned long long)stride, T, hw * Cw, spike_counts + (size_t)l * max_n);
+                    SNN_CHECK_LAUNCH("k_count_spikes");
                     pb += (long long)lv[l].N * hw;
                 }
             }

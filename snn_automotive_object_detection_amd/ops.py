@@ -129,6 +129,20 @@ def spike_gemm_bf16x3(a_rows: torch.Tensor, K: int, N: int, w_packed: torch.Tens
     return cur
 
 
+def conv3x3_lif_bf16x3(enc: torch.Tensor, shapes, C_in: int, C_out: int, p: snn_params, w_packed: torch.Tensor) -> torch.Tensor:
+    """enc int32 [T, P, Cw] over levels `shapes` = [(N,H,W), ...] -> shared-LIF spike planes int32 [T, P, Nw]"""
+    _need_gpu(enc, "enc planes")
+    lib = _lib.load()
+    T, P, Cw = enc.shape
+    assert P == sum(n * h * w for n, h, w in shapes)
+    lv = (snn_rpn_level * len(shapes))(*[snn_rpn_level(None, n, h, w, 0) for n, h, w in shapes])
+    Nw = cdiv(C_out, 32)
+    spk = torch.empty((T, P, Nw), dtype=torch.int32, device=enc.device)
+    _lib.check(lib.snn_conv3x3_lif_bf16x3(_ptr(enc), P * Cw, lv, len(shapes), C_in, C_out, T, C.byref(p), _ptr(w_packed),
+                                          _ptr(spk), P * Nw, _stream()), "snn_conv3x3_lif_bf16x3")
+    return spk
+
+
 def spike_conv3x3_bf16x3(enc: torch.Tensor, shapes, C_in: int, C_out: int, w_packed: torch.Tensor) -> torch.Tensor:
     """enc int32 [T, P, Cw] over levels `shapes` = [(N,H,W), ...] -> cur fp32 [T, P, Np]"""
     _need_gpu(enc, "enc planes")

@@ -55,8 +55,7 @@ def test_rpn_head_vs_golden(pkg, gpu_device, name, precision):
         if precision == "f32":
             spk = ops.conv3x3_lif(enc, N, C, C, H, W, p, ops.pack_conv3x3(m.shared_conv.weight))
         else:
-            cur = ops.spike_conv3x3_bf16x3(enc, [(N, H, W)], C, C, ops.pack_conv3x3_bf16x3(m.shared_conv.weight))
-            spk = ops.lif_scan(cur, C, p)
+            spk = ops.conv3x3_lif_bf16x3(enc, [(N, H, W)], C, C, p, ops.pack_conv3x3_bf16x3(m.shared_conv.weight))
         got = planes_to_dense(spk, C).reshape(spec["T"], N, H, W, C)
         gold = FX.unpack_spikes(exp["spk%d" % l], exp["spk%d_shape" % l]).transpose(0, 1, 3, 4, 2)
         flipped_pos = (got != gold).any(axis=(0, 4))                       # [N,H,W]

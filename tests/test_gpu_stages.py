@@ -189,3 +189,7 @@ def test_spike_conv3x3_bf16x3_teacher_forced(S, gpu_device, name):
     exp_spk = np.concatenate([nchw_to_rows(tr["spk"]) for tr in traces], axis=1)
     flipped = (got != exp_spk).any(axis=(0, 2)).sum()
     assert flipped <= 2 + 1e-3 * got.shape[1]
+    # the fused conv + LIF kernel (state in registers over the T loop) gives the same spike planes as the
+    # un-fused pair bit for bit: same MFMA order, same element-wise arithmetic
+    fused = S.conv3x3_lif_bf16x3(enc, shapes, C, C, p, wp)
+    assert torch.equal(fused, spk)

@@ -498,7 +498,9 @@ __global__ __launch_bounds__(512) void k_spike_gemm(const GemmArgs args) {
 // cur[M][ldo] = A_bits[M][K] x W[K][N];   work-group = 8 waves = 256 rows x 128 columns, wave = 64 x 64.
 // Per 32-deep chunk: B = 3 planes x 128 x 32 bf16 (24 KB) copied global->LDS, A = 256 spike words expanded
 // to bf16 in LDS (two 16-bit halves per row, one per thread); both double-buffered, one barrier per chunk.
-// LDS rows are 64 B of data + 16 B pad (80-B stride): conflict-free ds_read_b128 fragment reads.
+// LDS rows are 64 B (no padding) with an XOR swizzle of the 16-B units: conflict-free ds_read_b128 fragment
+// reads at 80 KB of LDS per work-group, so TWO work-groups share a CU and one's barrier/staging phase hides
+// behind the other's MFMAs.
 // CONV = true: row m = (t, position) and the chunk (tap, channel word) is gathered straight from the
 // encoder bit-planes (9 taps, zero outside the image) - the un-fused time-batched 3x3 convolution.
 // ------------------------------------------------------------------------------------------------
@@ -506,10 +508,13 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
 #define G3_BM 256
 #define G3_BN 128
-#define G3_ROWB 80                                  // bytes per LDS row (32 bf16 + pad)
-#define G3_A_BYTES (G3_BM * G3_ROWB)                // 20480
-#define G3_B_BYTES (3 * G3_BN * G3_ROWB)            // 30720
-#define G3_LDS (2 * (G3_A_BYTES + G3_B_BYTES))      // 102400
+#define G3_ROWB 64                                  // bytes per LDS row: 32 bf16, four 16-B units, XOR-swizzled
+#define G3_A_BYTES (G3_BM * G3_ROWB)                // 16384
+#define G3_B_BYTES (3 * G3_BN * G3_ROWB)            // 24576
+#define G3_LDS (2 * (G3_A_BYTES + G3_B_BYTES))      // 81920: two work-groups per CU
+// unit u of row r lives at physical unit u ^ ((r >> 2) & 3): the 16 lanes of a ds_read_b128 group (rows that
+// differ in r & 3 or in (r >> 2) & 3) then hit 16 distinct 16-B slots of the 256-B bank row - conflict-free
+#define G3_SWZ(r) (((r) >> 2) & 3)
 
 struct Gemm3Args {
     const uint32_t* A;           // fc: [M][Kw] spike words;  conv: encoder planes [T][P][Cw]
@@ -535,7 +540,7 @@ __device__ __forceinline__ uint32_t bf16_pair(uint32_t w, int j) {      // bits 
 // FUSE (conv only): M = positions; per time step the 9*Cw chunks are accumulated, then the LIF update runs
 // on the accumulators in registers (64 acc + 64 v + 64 i per lane) and only spike bits are written.
 template <bool CONV, bool FUSE>
-__global__ __launch_bounds__(512) void k_gemm_bf16x3(const Gemm3Args args) {
+__global__ __launch_bounds__(512, FUSE ? 2 : 4) void k_gemm_bf16x3(const Gemm3Args args) {
     static_assert(CONV || !FUSE, "LIF fusion is for the conv rows");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -589,26 +594,27 @@ __global__ __launch_bounds__(512) void k_gemm_bf16x3(const Gemm3Args args) {
         uint4 lo4, hi4;
         lo4.x = bf16_pair(hbits, 0); lo4.y = bf16_pair(hbits, 1); lo4.z = bf16_pair(hbits, 2); lo4.w = bf16_pair(hbits, 3);
         hi4.x = bf16_pair(hbits, 4); hi4.y = bf16_pair(hbits, 5); hi4.z = bf16_pair(hbits, 6); hi4.w = bf16_pair(hbits, 7);
-        unsigned char* d = smem + buf * G3_A_BYTES + xrow * G3_ROWB + xhalf * 32;
-        *reinterpret_cast<uint4*>(d) = lo4;
-        *reinterpret_cast<uint4*>(d + 16) = hi4;
+        unsigned char* d = smem + buf * G3_A_BYTES + xrow * G3_ROWB;
+        *reinterpret_cast<uint4*>(d + (((2 * xhalf) ^ G3_SWZ(xrow)) << 4)) = lo4;
+        *reinterpret_cast<uint4*>(d + (((2 * xhalf + 1) ^ G3_SWZ(xrow)) << 4)) = hi4;
     };
 
     // ---- B staging role: thread -> (column n, 16-byte unit u) of each of the 3 planes ----
     const int bn = tid >> 2, bu = tid & 3;
     const int bcol = nb * G3_BN + bn;
     const bool bvalid = bcol < Np;
-    const uint16_t* b_src = args.wpk + ((size_t)(bvalid ? bcol : 0) * 32 + bu * 8);
+    const uint32_t b_off = (uint32_t)((bvalid ? bcol : 0) * 32 + bu * 8);       // elements; uniform base + lane offset
     uint4 bst[3];
     auto fetch_b = [&](int kc) {
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
+            const uint16_t* base = args.wpk + pl * args.plane_elems + (size_t)kc * Np * 32;     // wave-uniform
             bst[pl] = make_uint4(0, 0, 0, 0);
-            if (bvalid) bst[pl] = *reinterpret_cast<const uint4*>(b_src + pl * args.plane_elems + (size_t)kc * Np * 32);
+            if (bvalid) bst[pl] = *reinterpret_cast<const uint4*>(base + b_off);
         }
     };
     auto store_b = [&](int buf) {
-        unsigned char* d = smem + 2 * G3_A_BYTES + buf * G3_B_BYTES + bn * G3_ROWB + bu * 16;
+        unsigned char* d = smem + 2 * G3_A_BYTES + buf * G3_B_BYTES + bn * G3_ROWB + ((bu ^ G3_SWZ(bn)) << 4);
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<uint4*>(d + pl * (G3_BN * G3_ROWB)) = bst[pl];
     };
@@ -621,8 +627,10 @@ __global__ __launch_bounds__(512) void k_gemm_bf16x3(const Gemm3Args args) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
 
-    const int a_rd = (wm * 64 + li) * G3_ROWB + 16 * lh;       // + mt*32*ROWB + 32*s
-    const int b_rd = (wn * 64 + li) * G3_ROWB + 16 * lh;       // + pl*BN*ROWB + nt*32*ROWB + 32*s
+    // fragment of k16-step s = logical unit 2s + lh; (row >> 2) & 3 == (li >> 2) & 3 for every tile row of this lane
+    const int u_rd = (lh ^ G3_SWZ(li)) << 4;                   // step 0; step 1 = u_rd ^ 32
+    const int a_rd = (wm * 64 + li) * G3_ROWB;                 // + mt*32*ROWB
+    const int b_rd = (wn * 64 + li) * G3_ROWB;                 // + pl*BN*ROWB + nt*32*ROWB
 
     // LIF state of the fused variant (registers, whole T loop)
     float v[FUSE ? 2 : 1][FUSE ? 2 : 1][FUSE ? 16 : 1], ci[FUSE ? 2 : 1][FUSE ? 2 : 1][FUSE ? 16 : 1];
@@ -665,13 +673,13 @@ __global__ __launch_bounds__(512) void k_gemm_bf16x3(const Gemm3Args args) {
             for (int s = 0; s < 2; ++s) {
                 bf16x8 a[2];
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) a[mt] = *reinterpret_cast<const bf16x8*>(Ab + mt * 32 * G3_ROWB + 32 * s);
+                for (int mt = 0; mt < 2; ++mt) a[mt] = *reinterpret_cast<const bf16x8*>(Ab + mt * 32 * G3_ROWB + (u_rd ^ (32 * s)));
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
                     bf16x8 b[3];                 // one N-tile's three planes at a time: 12 live registers
 #pragma unroll
                     for (int pl = 0; pl < 3; ++pl)
-                        b[pl] = *reinterpret_cast<const bf16x8*>(Bb + pl * (G3_BN * G3_ROWB) + nt * 32 * G3_ROWB + 32 * s);
+                        b[pl] = *reinterpret_cast<const bf16x8*>(Bb + pl * (G3_BN * G3_ROWB) + nt * 32 * G3_ROWB + (u_rd ^ (32 * s)));
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt) {
                         // small terms first: lo, mid, hi

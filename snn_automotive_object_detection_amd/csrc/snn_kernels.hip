@@ -506,6 +506,13 @@ __global__ __launch_bounds__(512) void k_spike_gemm(const GemmArgs args) {
 // ------------------------------------------------------------------------------------------------
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
+// LDS-DMA: 16 B per lane straight from global memory into LDS at (wave-uniform dst) + 16*lane; no VGPR destination,
+// completion is counted on vmcnt (the __syncthreads() that ends a chunk waits for it)
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst_uniform) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_dst_uniform, 16, 0, 0);
+}
+
 #define G3_BM 256
 #define G3_BN 128
 #define G3_ROWB 64                                  // bytes per LDS row: 32 bf16, four 16-B units, XOR-swizzled
@@ -599,24 +606,19 @@ __global__ __launch_bounds__(512, FUSE ? 2 : 4) void k_gemm_bf16x3(const Gemm3Ar
         *reinterpret_cast<uint4*>(d + (((2 * xhalf + 1) ^ G3_SWZ(xrow)) << 4)) = hi4;
     };
 
-    // ---- B staging role: thread -> (column n, 16-byte unit u) of each of the 3 planes ----
-    const int bn = tid >> 2, bu = tid & 3;
-    const int bcol = nb * G3_BN + bn;
-    const bool bvalid = bcol < Np;
-    const uint32_t b_off = (uint32_t)((bvalid ? bcol : 0) * 32 + bu * 8);       // elements; uniform base + lane offset
-    uint4 bst[3];
-    auto fetch_b = [&](int kc) {
+    // ---- B staging: LDS-DMA.  Wave w copies rows [16w, 16w+16) of each of the 3 planes (1 KiB per instruction);
+    // lane L lands in physical unit L&3 of row 16w + (L>>2), so it fetches logical unit (L&3) ^ swz(row): the
+    // swizzle is applied on the SOURCE address, the LDS image stays lane-linear ----
+    const int brow = wave * 16 + (lane >> 2);
+    const int bcol = min(nb * G3_BN + brow, Np - 1);           // columns past Np: any valid row (never stored)
+    const uint32_t b_off = (uint32_t)(bcol * 32 + (((lane & 3) ^ G3_SWZ(brow)) << 3));     // elements
+    auto stage_b = [&](int kc, int buf) {
+        unsigned char* d = smem + 2 * G3_A_BYTES + buf * G3_B_BYTES + wave * 1024;          // wave-uniform
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
-            const uint16_t* base = args.wpk + pl * args.plane_elems + (size_t)kc * Np * 32;     // wave-uniform
-            bst[pl] = make_uint4(0, 0, 0, 0);
-            if (bvalid) bst[pl] = *reinterpret_cast<const uint4*>(base + b_off);
+            const uint16_t* base = args.wpk + pl * args.plane_elems + (size_t)kc * Np * 32; // wave-uniform
+            glds16(base + b_off, d + pl * (G3_BN * G3_ROWB));
         }
-    };
-    auto store_b = [&](int buf) {
-        unsigned char* d = smem + 2 * G3_A_BYTES + buf * G3_B_BYTES + bn * G3_ROWB + ((bu ^ G3_SWZ(bn)) << 4);
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<uint4*>(d + pl * (G3_BN * G3_ROWB)) = bst[pl];
     };
 
     f32x16 acc[2][2];
@@ -652,9 +654,8 @@ __global__ __launch_bounds__(512, FUSE ? 2 : 4) void k_gemm_bf16x3(const Gemm3Ar
 
     // prologue: chunk 0 (of step 0)
     uint32_t a_w = fetch_a(0);
-    fetch_b(0);
+    stage_b(0, 0);
     store_a(a_w, 0);
-    store_b(0);
     __syncthreads();
     int buf = 0;
 
@@ -665,31 +666,45 @@ __global__ __launch_bounds__(512, FUSE ? 2 : 4) void k_gemm_bf16x3(const Gemm3Ar
             if (more) {                                     // global loads in flight during the MFMAs
                 if (FUSE && last) a_src += args.enc_stride; // next chunk belongs to the next time plane
                 a_w = fetch_a(last ? 0 : kc + 1);
-                fetch_b(last ? 0 : kc + 1);
+                stage_b(last ? 0 : kc + 1, buf ^ 1);        // lands in the other buffer while this one is read
             }
             const unsigned char* Ab = smem + buf * G3_A_BYTES + a_rd;
             const unsigned char* Bb = smem + 2 * G3_A_BYTES + buf * G3_B_BYTES + b_rd;
+            // four groups g = (k16-step s, N-tile nt) of 6 MFMAs; the three B planes of group g+1 (and the A
+            // fragments of step 1) are read from LDS while group g multiplies
+            bf16x8 a[2], bq[2][3];
+            auto ld_a = [&](int s_) {
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                bf16x8 a[2];
+                for (int mt = 0; mt < 2; ++mt) a[mt] = *reinterpret_cast<const bf16x8*>(Ab + mt * 32 * G3_ROWB + (u_rd ^ (32 * s_)));
+            };
+            auto ld_b = [&](bf16x8 (&dst)[3], int s_, int nt_) {
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) a[mt] = *reinterpret_cast<const bf16x8*>(Ab + mt * 32 * G3_ROWB + (u_rd ^ (32 * s)));
+                for (int pl = 0; pl < 3; ++pl)
+                    dst[pl] = *reinterpret_cast<const bf16x8*>(Bb + pl * (G3_BN * G3_ROWB) + nt_ * 32 * G3_ROWB + (u_rd ^ (32 * s_)));
+            };
+            auto mm = [&](const bf16x8 (&b)[3], int nt_) {
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    bf16x8 b[3];                 // one N-tile's three planes at a time: 12 live registers
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl)
-                        b[pl] = *reinterpret_cast<const bf16x8*>(Bb + pl * (G3_BN * G3_ROWB) + nt * 32 * G3_ROWB + (u_rd ^ (32 * s)));
-#pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) {
-                        // small terms first: lo, mid, hi
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[2], acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[1], acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[0], acc[mt][nt], 0, 0, 0);
-                    }
+                for (int mt = 0; mt < 2; ++mt) {     // small terms first: lo, mid, hi
+                    acc[mt][nt_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[2], acc[mt][nt_], 0, 0, 0);
+                    acc[mt][nt_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[1], acc[mt][nt_], 0, 0, 0);
+                    acc[mt][nt_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[0], acc[mt][nt_], 0, 0, 0);
                 }
-            }
-            if (more) { store_a(a_w, buf ^ 1); store_b(buf ^ 1); }
+            };
+            ld_a(0); ld_b(bq[0], 0, 0);
+            ld_b(bq[1], 0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(bq[0], 0);
+            __builtin_amdgcn_sched_barrier(0);
+            ld_b(bq[0], 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(bq[1], 1);
+            __builtin_amdgcn_sched_barrier(0);
+            ld_a(1); ld_b(bq[1], 1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(bq[0], 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(bq[1], 1);
+            if (more) store_a(a_w, buf ^ 1);
             __syncthreads();
             buf ^= 1;
         }

@@ -588,11 +588,12 @@ __global__ __launch_bounds__(512, FUSE ? 2 : 4) void k_gemm_bf16x3(const Gemm3Ar
     } else {
         a_src = args.A + (size_t)min(xm, M - 1) * Kc;
     }
-    auto fetch_a = [&](int kc) -> uint32_t {
+    auto fetch_a = [&](int t_rel, int kc) -> uint32_t {     // t_rel: time step of the fused T loop (0 otherwise)
         if (CONV) {
             const int tap = kc / args.Cw, cc = kc % args.Cw;
             if (!((a_valid >> tap) & 1u)) return 0u;
-            return a_src[a_center + (long long)((tap / 3 - 1) * a_W + (tap % 3 - 1)) * args.Cw + cc];
+            const uint32_t* plane = FUSE ? a_src + (size_t)t_rel * args.enc_stride : a_src;
+            return plane[a_center + (long long)((tap / 3 - 1) * a_W + (tap % 3 - 1)) * args.Cw + cc];
         }
         return a_src[kc];
     };
@@ -652,10 +653,24 @@ __global__ __launch_bounds__(512, FUSE ? 2 : 4) void k_gemm_bf16x3(const Gemm3Ar
     }
     const int n_steps = FUSE ? args.T : 1;
 
-    // prologue: chunk 0 (of step 0)
-    uint32_t a_w = fetch_a(0);
-    stage_b(0, 0);
-    store_a(a_w, 0);
+    // Software pipeline over the chunk sequence (t, kc): spike words are fetched from global two chunks ahead,
+    // expanded into the other LDS buffer one chunk ahead (VALU + ds_write in the shadow of the MFMAs); weight
+    // planes arrive one chunk ahead by LDS-DMA.  One barrier per chunk.
+    int f_t = 0, f_kc = 0;                              // next chunk of the fetch stream (wave-uniform)
+    auto fetch_next = [&]() -> uint32_t {
+        uint32_t w = 0u;
+        if (f_t < n_steps) {
+            w = fetch_a(f_t, f_kc);
+            if (++f_kc == Kc) { f_kc = 0; ++f_t; }
+        }
+        return w;
+    };
+    {
+        const uint32_t w0 = fetch_next();
+        stage_b(0, 0);
+        store_a(w0, 0);
+    }
+    uint32_t a_nxt = fetch_next();                      // chunk 1
     __syncthreads();
     int buf = 0;
 
@@ -663,11 +678,8 @@ __global__ __launch_bounds__(512, FUSE ? 2 : 4) void k_gemm_bf16x3(const Gemm3Ar
         for (int kc = 0; kc < Kc; ++kc) {
             const bool last = kc + 1 == Kc;
             const bool more = !last || t + 1 < n_steps;
-            if (more) {                                     // global loads in flight during the MFMAs
-                if (FUSE && last) a_src += args.enc_stride; // next chunk belongs to the next time plane
-                a_w = fetch_a(last ? 0 : kc + 1);
-                stage_b(last ? 0 : kc + 1, buf ^ 1);        // lands in the other buffer while this one is read
-            }
+            const uint32_t a_nn = fetch_next();          // chunk +2: global load in flight across this chunk
+            if (more) stage_b(last ? 0 : kc + 1, buf ^ 1);   // lands in the other buffer while this one is read
             const unsigned char* Ab = smem + buf * G3_A_BYTES + a_rd;
             const unsigned char* Bb = smem + 2 * G3_A_BYTES + buf * G3_B_BYTES + b_rd;
             // four groups g = (k16-step s, N-tile nt) of 6 MFMAs; the three B planes of group g+1 (and the A
@@ -694,9 +706,8 @@ __global__ __launch_bounds__(512, FUSE ? 2 : 4) void k_gemm_bf16x3(const Gemm3Ar
             ld_b(bq[1], 0, 1);
             __builtin_amdgcn_sched_barrier(0);
             mm(bq[0], 0);
-            __builtin_amdgcn_sched_barrier(0);
+            if (more) store_a(a_nxt, buf ^ 1);           // expansion VALU + 2 ds_write_b128 beside the MFMAs
             ld_b(bq[0], 1, 0);
-            __builtin_amdgcn_sched_barrier(0);
             mm(bq[1], 1);
             __builtin_amdgcn_sched_barrier(0);
             ld_a(1); ld_b(bq[1], 1, 1);
@@ -704,9 +715,9 @@ __global__ __launch_bounds__(512, FUSE ? 2 : 4) void k_gemm_bf16x3(const Gemm3Ar
             mm(bq[0], 0);
             __builtin_amdgcn_sched_barrier(0);
             mm(bq[1], 1);
-            if (more) store_a(a_w, buf ^ 1);
             __syncthreads();
             buf ^= 1;
+            a_nxt = a_nn;
         }
         if (FUSE) {
             // ---- LIF epilogue in registers; spikes leave as ballots (2 position words per register) ----

@@ -169,18 +169,9 @@ def main():
         kernel, peak, exec_factor, kernel_ms = "k_conv3x3_lif<false>", PEAK_F32_MFMA_TFLOPS, 1.0, conv_ms
         traffic_key = "f32"
     else:
-        # stage 2 = k_gemm_bf16x3<true> (time-batched conv) + k_lif_scan; time the GEMM alone for the roofline
-        encs = torch.empty((T_RPN, P, C // 32), dtype=torch.int32, device=dev)
-        shapes = [(BATCH, h, w) for h, w in LEVELS]
-        pos = 0
-        for f in feats:
-            n = f.shape[0] * f.shape[2] * f.shape[3]
-            encs[:, pos:pos + n] = ops.encode_nchw(f, T_RPN, p)
-            pos += n
-        kernel_ms = time_ms(lambda: ops.spike_conv3x3_bf16x3(encs, shapes, C, C, w_sh), iters)
-        kernel, peak, exec_factor = "k_gemm_bf16x3<true>", PEAK_BF16_MFMA_TFLOPS, 3.0
+        # stage 2 = k_gemm_bf16x3<true, true>: 3x3 conv + LIF fused over T on the bf16 matrix cores
+        kernel, peak, exec_factor, kernel_ms = "k_gemm_bf16x3<true, true>", PEAK_BF16_MFMA_TFLOPS, 3.0, conv_ms
         traffic_key = "bf16x3"
-        del encs
     achieved = conv_fl / (kernel_ms * 1e-3) / 1e12             # ALGORITHMIC (dense-equivalent) TFLOP/s
     traffic = None                    # HBM bytes per launch of the dominant kernel, from the committed PMC passes
     try:

@@ -1260,8 +1260,8 @@ static void rpn_ws_layout(long long P, int C, int T, int precision, size_t* o_sp
     const size_t plane = align_up((size_t)T * P * cdiv(C, 32) * 4, 256);
     *o_spk = plane;
     *o_cur = 2 * plane;
-    // bf16x3: the conv runs time-batched and hands T*P*Np fp32 currents to the LIF scan through HBM
-    const size_t cur = precision == SNN_PRECISION_BF16X3 ? align_up((size_t)T * P * cdiv(C, 32) * 32 * 4, 256) : 0;
+    const size_t cur = 0;     // (only the un-fused snn_spike_conv3x3_bf16x3 + snn_lif_scan pair needs currents)
+    (void)precision;
     *o_cnt = 2 * plane + cur;
     const size_t cnt = 0;
     *total = 2 * plane + cur + cnt;
@@ -1315,15 +1315,12 @@ int snn_rpn_head_forward_stages(const snn_rpn_level* lv, int n_levels, int C, in
                                  spike_counts, max_n, nullptr, s);
             if (rc) return rc;
         } else {
-            // time-batched conv on the bf16 matrix cores -> currents -> LIF scan over T (rpn.py:98-106).
-            // (snn_conv3x3_lif_bf16x3 fuses the scan into the GEMM and gives bit-identical planes; at 255 VGPRs it
-            //  measures 5.8 ms against 4.7 + 0.5 ms for this pair, so the pair is what runs.)
-            float* cur = (float*)((char*)ws + o_cur);
-            const int Np = Cw * 32;
-            int rc = snn_spike_conv3x3_bf16x3(enc, stride, lv, n_levels, C, C, T, (const uint16_t*)w_shared_packed, cur,
-                                              Np, stream);
+            // conv + LIF fused over T on the bf16 matrix cores (rpn.py:98-106): membrane state in registers, only
+            // spike planes written (4.5 ms against 4.2 + 0.5 ms for snn_spike_conv3x3_bf16x3 + snn_lif_scan, which
+            // give bit-identical planes)
+            int rc = snn_conv3x3_lif_bf16x3(enc, stride, lv, n_levels, C, C, T, p, (const uint16_t*)w_shared_packed,
+                                            spk, stride, stream);
             if (rc) return rc;
-            if ((rc = snn_lif_scan(cur, T, (int)P, C, Np, p, spk, stride, nullptr, stream))) return rc;
             if (spike_counts) {
                 if (hipMemsetAsync(spike_counts, 0, sizeof(unsigned long long) * n_levels * max_n, s) != hipSuccess)
                     return fail(-3, "hipMemsetAsync failed");

@@ -35,3 +35,5 @@ cur = ops.spike_conv3x3_bf16x3(encs, shapes, 256, 256, wb)
 t4 = tm(lambda: ops.lif_scan(cur, 256, p), 3)
 fl = 2.0 * T * P * 9 * 256 * 256
 print('conv bf16x3 gemm %.3f ms (%.1f TF algorithmic, %.1f TF executed)  + lif_scan %.3f ms  [fused f32 kernel: 13.1 ms]' % (t3, fl / t3 / 1e9, 3 * fl / t3 / 1e9, t4))
+t5 = tm(lambda: ops.conv3x3_lif_bf16x3(encs, shapes, 256, 256, p, wb), 3)
+print('conv bf16x3 FUSED conv+LIF %.3f ms   (un-fused pair %.3f ms)' % (t5, t3 + t4))

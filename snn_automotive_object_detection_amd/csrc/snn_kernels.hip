@@ -546,9 +546,12 @@ __device__ __forceinline__ uint32_t bf16_pair(uint32_t w, int j) {      // bits 
 
 // FUSE (conv only): M = positions; per time step the 9*Cw chunks are accumulated, then the LIF update runs
 // on the accumulators in registers (64 acc + 64 v + 64 i per lane) and only spike bits are written.
-template <bool CONV, bool FUSE>
+// SC = 32-deep chunks per barrier: 1 (80 KB of LDS, two work-groups per CU) or 2 (160 KB, for the fused variant
+// that owns its CU anyway: half as many barriers).
+template <bool CONV, bool FUSE, int SC>
 __global__ __launch_bounds__(512, FUSE ? 2 : 4) void k_gemm_bf16x3(const Gemm3Args args) {
     static_assert(CONV || !FUSE, "LIF fusion is for the conv rows");
+    constexpr int A_OFF = 0, B_OFF = 2 * SC * G3_A_BYTES;       // LDS: [2 buffers][SC sub-chunks] of A, then of B
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -597,12 +600,12 @@ __global__ __launch_bounds__(512, FUSE ? 2 : 4) void k_gemm_bf16x3(const Gemm3Ar
         }
         return a_src[kc];
     };
-    auto store_a = [&](uint32_t w, int buf) {
+    auto store_a = [&](uint32_t w, int slot) {
         const uint32_t hbits = (w >> (16 * xhalf)) & 0xffffu;
         uint4 lo4, hi4;
         lo4.x = bf16_pair(hbits, 0); lo4.y = bf16_pair(hbits, 1); lo4.z = bf16_pair(hbits, 2); lo4.w = bf16_pair(hbits, 3);
         hi4.x = bf16_pair(hbits, 4); hi4.y = bf16_pair(hbits, 5); hi4.z = bf16_pair(hbits, 6); hi4.w = bf16_pair(hbits, 7);
-        unsigned char* d = smem + buf * G3_A_BYTES + xrow * G3_ROWB;
+        unsigned char* d = smem + A_OFF + slot * G3_A_BYTES + xrow * G3_ROWB;
         *reinterpret_cast<uint4*>(d + (((2 * xhalf) ^ G3_SWZ(xrow)) << 4)) = lo4;
         *reinterpret_cast<uint4*>(d + (((2 * xhalf + 1) ^ G3_SWZ(xrow)) << 4)) = hi4;
     };
@@ -613,8 +616,8 @@ __global__ __launch_bounds__(512, FUSE ? 2 : 4) void k_gemm_bf16x3(const Gemm3Ar
     const int brow = wave * 16 + (lane >> 2);
     const int bcol = min(nb * G3_BN + brow, Np - 1);           // columns past Np: any valid row (never stored)
     const uint32_t b_off = (uint32_t)(bcol * 32 + (((lane & 3) ^ G3_SWZ(brow)) << 3));     // elements
-    auto stage_b = [&](int kc, int buf) {
-        unsigned char* d = smem + 2 * G3_A_BYTES + buf * G3_B_BYTES + wave * 1024;          // wave-uniform
+    auto stage_b = [&](int kc, int slot) {
+        unsigned char* d = smem + B_OFF + slot * G3_B_BYTES + wave * 1024;                  // wave-uniform
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
             const uint16_t* base = args.wpk + pl * args.plane_elems + (size_t)kc * Np * 32; // wave-uniform
@@ -665,59 +668,70 @@ __global__ __launch_bounds__(512, FUSE ? 2 : 4) void k_gemm_bf16x3(const Gemm3Ar
         }
         return w;
     };
-    {
+    uint32_t a_nxt[SC], a_nn[SC];
+#pragma unroll
+    for (int j = 0; j < SC; ++j) {                      // super-chunk 0 -> buffer 0
         const uint32_t w0 = fetch_next();
-        stage_b(0, 0);
-        store_a(w0, 0);
+        stage_b(j, j);
+        store_a(w0, j);
     }
-    uint32_t a_nxt = fetch_next();                      // chunk 1
+#pragma unroll
+    for (int j = 0; j < SC; ++j) a_nxt[j] = fetch_next();   // super-chunk 1
     __syncthreads();
     int buf = 0;
 
     for (int t = 0; t < n_steps; ++t) {
-        for (int kc = 0; kc < Kc; ++kc) {
-            const bool last = kc + 1 == Kc;
+        for (int kc = 0; kc < Kc; kc += SC) {
+            const bool last = kc + SC == Kc;
             const bool more = !last || t + 1 < n_steps;
-            const uint32_t a_nn = fetch_next();          // chunk +2: global load in flight across this chunk
-            if (more) stage_b(last ? 0 : kc + 1, buf ^ 1);   // lands in the other buffer while this one is read
-            const unsigned char* Ab = smem + buf * G3_A_BYTES + a_rd;
-            const unsigned char* Bb = smem + 2 * G3_A_BYTES + buf * G3_B_BYTES + b_rd;
-            // four groups g = (k16-step s, N-tile nt) of 6 MFMAs; the three B planes of group g+1 (and the A
-            // fragments of step 1) are read from LDS while group g multiplies
-            bf16x8 a[2], bq[2][3];
-            auto ld_a = [&](int s_) {
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) a[mt] = *reinterpret_cast<const bf16x8*>(Ab + mt * 32 * G3_ROWB + (u_rd ^ (32 * s_)));
-            };
-            auto ld_b = [&](bf16x8 (&dst)[3], int s_, int nt_) {
+            for (int j = 0; j < SC; ++j) a_nn[j] = fetch_next();     // super-chunk +2: global loads in flight
+            if (more) {
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-                    dst[pl] = *reinterpret_cast<const bf16x8*>(Bb + pl * (G3_BN * G3_ROWB) + nt_ * 32 * G3_ROWB + (u_rd ^ (32 * s_)));
-            };
-            auto mm = [&](const bf16x8 (&b)[3], int nt_) {
+                for (int j = 0; j < SC; ++j) stage_b((last ? 0 : kc + SC) + j, (buf ^ 1) * SC + j);   // other buffer
+            }
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {     // small terms first: lo, mid, hi
-                    acc[mt][nt_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[2], acc[mt][nt_], 0, 0, 0);
-                    acc[mt][nt_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[1], acc[mt][nt_], 0, 0, 0);
-                    acc[mt][nt_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[0], acc[mt][nt_], 0, 0, 0);
-                }
-            };
-            ld_a(0); ld_b(bq[0], 0, 0);
-            ld_b(bq[1], 0, 1);
-            __builtin_amdgcn_sched_barrier(0);
-            mm(bq[0], 0);
-            if (more) store_a(a_nxt, buf ^ 1);           // expansion VALU + 2 ds_write_b128 beside the MFMAs
-            ld_b(bq[0], 1, 0);
-            mm(bq[1], 1);
-            __builtin_amdgcn_sched_barrier(0);
-            ld_a(1); ld_b(bq[1], 1, 1);
-            __builtin_amdgcn_sched_barrier(0);
-            mm(bq[0], 0);
-            __builtin_amdgcn_sched_barrier(0);
-            mm(bq[1], 1);
+            for (int j = 0; j < SC; ++j) {
+                const unsigned char* Ab = smem + A_OFF + (buf * SC + j) * G3_A_BYTES + a_rd;
+                const unsigned char* Bb = smem + B_OFF + (buf * SC + j) * G3_B_BYTES + b_rd;
+                // four groups g = (k16-step s, N-tile nt) of 6 MFMAs; the three B planes of group g+1 (and the A
+                // fragments of step 1) are read from LDS while group g multiplies
+                bf16x8 a[2], bq[2][3];
+                auto ld_a = [&](int s_) {
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) a[mt] = *reinterpret_cast<const bf16x8*>(Ab + mt * 32 * G3_ROWB + (u_rd ^ (32 * s_)));
+                };
+                auto ld_b = [&](bf16x8 (&dst)[3], int s_, int nt_) {
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        dst[pl] = *reinterpret_cast<const bf16x8*>(Bb + pl * (G3_BN * G3_ROWB) + nt_ * 32 * G3_ROWB + (u_rd ^ (32 * s_)));
+                };
+                auto mm = [&](const bf16x8 (&b)[3], int nt_) {
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {     // small terms first: lo, mid, hi
+                        acc[mt][nt_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[2], acc[mt][nt_], 0, 0, 0);
+                        acc[mt][nt_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[1], acc[mt][nt_], 0, 0, 0);
+                        acc[mt][nt_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[0], acc[mt][nt_], 0, 0, 0);
+                    }
+                };
+                ld_a(0); ld_b(bq[0], 0, 0);
+                ld_b(bq[1], 0, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mm(bq[0], 0);
+                if (more) store_a(a_nxt[j], (buf ^ 1) * SC + j);     // expansion VALU + 2 ds_write_b128 beside the MFMAs
+                ld_b(bq[0], 1, 0);
+                mm(bq[1], 1);
+                __builtin_amdgcn_sched_barrier(0);
+                ld_a(1); ld_b(bq[1], 1, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mm(bq[0], 0);
+                __builtin_amdgcn_sched_barrier(0);
+                mm(bq[1], 1);
+            }
             __syncthreads();
             buf ^= 1;
-            a_nxt = a_nn;
+#pragma unroll
+            for (int j = 0; j < SC; ++j) a_nxt[j] = a_nn[j];
         }
         if (FUSE) {
             // ---- LIF epilogue in registers; spikes leave as ballots (2 position words per register) ----
@@ -1045,10 +1059,14 @@ int snn_pack_linear_weight_bf16x3(const float* w, int N, int K, uint16_t* packed
 }
 
 static int launch_gemm3(bool conv, const Gemm3Args& a, hipStream_t s) {
-    auto kern = conv ? (a.spk ? k_gemm_bf16x3<true, true> : k_gemm_bf16x3<true, false>) : k_gemm_bf16x3<false, false>;
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G3_LDS);
+    const bool fuse = conv && a.spk != nullptr;
+    const int sc = (fuse && a.Kc % 2 == 0) ? 2 : 1;              // the fused variant owns its CU: 160 KB of LDS
+    auto kern = fuse ? (sc == 2 ? k_gemm_bf16x3<true, true, 2> : k_gemm_bf16x3<true, true, 1>)
+                     : (conv ? k_gemm_bf16x3<true, false, 1> : k_gemm_bf16x3<false, false, 1>);
+    const int lds = sc * G3_LDS;
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return fail(-3, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(kern, dim3(cdiv(a.M, G3_BM) * a.n_blocks), dim3(512), G3_LDS, s, a);
+    hipLaunchKernelGGL(kern, dim3(cdiv(a.M, G3_BM) * a.n_blocks), dim3(512), lds, s, a);
     SNN_CHECK_LAUNCH("k_gemm_bf16x3");
     return 0;
 }

@@ -216,3 +216,33 @@ def test_roi_permutation_equivariance_bitwise(pkg, gpu_device):
     c, b = m(x)
     cp, bp = m(x[perm])
     assert torch.equal(c[perm], cp) and torch.equal(b[perm], bp)
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+@pytest.mark.parametrize("C,T,shape", [(320, 3, (1, 9, 14)), (96, 1, (2, 8, 8)), (32, 32, (1, 5, 9)), (384, 2, (1, 8, 8))])
+def test_rpn_head_odd_widths_and_step_limits_vs_oracle(pkg, gpu_device, precision, C, T, shape):
+    """channel counts that are not 256 (odd number of 32-channel words, the f32 kernel's 384 maximum), T = 1 and
+    T = SNN_MAX_STEPS, against the oracle run on the spot"""
+    from oracle import snn_oracle as OR
+    g = torch.Generator().manual_seed(C + T)
+    m = pkg.RPNHeadSNN(C, 3, T)
+    f = torch.randn((shape[0], C, shape[1], shape[2]), generator=g) * 1.5
+    with torch.no_grad():
+        o_l, o_b = OR.rpn_head_forward([f], m.shared_conv.weight, m.conv_cls.weight, m.conv_bbox.weight, T)
+    m = m.to(gpu_device)
+    m.precision = precision
+    l, b = m([f.to(gpu_device)])
+    d = torch.maximum((l[0].cpu() - o_l[0]).abs().amax(1), (b[0].cpu() - o_b[0]).abs().amax(1))
+    assert int((d > TOL).sum()) <= 2 and float(d.max()) < 0.05
+
+
+def test_f32_conv_rejects_too_many_channels_but_bf16x3_takes_them(pkg, gpu_device):
+    from snn_automotive_object_detection_amd._lib import SnnHipError
+    m = pkg.RPNHeadSNN(416, 3, 2).to(gpu_device)
+    f = torch.randn((1, 416, 8, 8), device=gpu_device)
+    m.precision = "f32"
+    with pytest.raises(SnnHipError):
+        m([f])                                   # fp32 LDS spike image: C_in <= 384
+    m.precision = "bf16x3"
+    l, b = m([f])
+    assert tuple(l[0].shape) == (1, 3, 8, 8) and torch.isfinite(l[0]).all()

@@ -85,8 +85,8 @@ def load(build_if_missing: bool = True):
     global _LIB
     if _LIB is not None:
         return _LIB
-    path = _build.LIB_PATH
-    if build_if_missing and _build.needs_build() and os.path.exists(_build.HIPCC):
+    path = os.environ.get("SNN_HIP_LIB", _build.LIB_PATH)      # override: A/B builds of the kernels
+    if path == _build.LIB_PATH and build_if_missing and _build.needs_build() and os.path.exists(_build.HIPCC):
         _build.build()
     if not os.path.exists(path):
         raise SnnHipError("libsnnhip.so not found at %s (run `python -m snn_automotive_object_detection_amd.build`); "

@@ -591,14 +591,22 @@ __global__ __launch_bounds__(512, FUSE ? 2 : 4) void k_gemm_bf16x3(const Gemm3Ar
     } else {
         a_src = args.A + (size_t)min(xm, M - 1) * Kc;
     }
-    auto fetch_a = [&](int t_rel, int kc) -> uint32_t {     // t_rel: time step of the fused T loop (0 otherwise)
+    // Spike-word loads are issued as inline asm: hipcc must not see them, or it drains the LDS-DMA queue
+    // (vmcnt(0)) at their first use while the next chunk's weight planes are still in flight.  Their completion
+    // is counted by hand (vmcnt is in issue order): see the two s_waitcnt in the chunk loop.
+    auto fetch_a = [&](int t_rel, int kc, uint32_t& w) {    // t_rel: time step of the fused T loop (0 otherwise)
+        const uint32_t* ptr;
+        bool ok = true;
         if (CONV) {
             const int tap = kc / args.Cw, cc = kc % args.Cw;
-            if (!((a_valid >> tap) & 1u)) return 0u;
+            ok = (a_valid >> tap) & 1u;
             const uint32_t* plane = FUSE ? a_src + (size_t)t_rel * args.enc_stride : a_src;
-            return plane[a_center + (long long)((tap / 3 - 1) * a_W + (tap % 3 - 1)) * args.Cw + cc];
+            ptr = plane + a_center + (long long)((tap / 3 - 1) * a_W + (tap % 3 - 1)) * args.Cw + cc;
+        } else {
+            ptr = a_src + kc;
         }
-        return a_src[kc];
+        w = 0u;
+        if (ok) asm volatile("global_load_dword %0, %1, off" : "+v"(w) : "v"(ptr) : "memory");
     };
     auto store_a = [&](uint32_t w, int slot) {
         const uint32_t hbits = (w >> (16 * xhalf)) & 0xffffu;
@@ -660,36 +668,41 @@ __global__ __launch_bounds__(512, FUSE ? 2 : 4) void k_gemm_bf16x3(const Gemm3Ar
     // expanded into the other LDS buffer one chunk ahead (VALU + ds_write in the shadow of the MFMAs); weight
     // planes arrive one chunk ahead by LDS-DMA.  One barrier per chunk.
     int f_t = 0, f_kc = 0;                              // next chunk of the fetch stream (wave-uniform)
-    auto fetch_next = [&]() -> uint32_t {
-        uint32_t w = 0u;
+    auto fetch_next = [&](uint32_t& w) {                // always issues exactly one VMEM op per active lane set
         if (f_t < n_steps) {
-            w = fetch_a(f_t, f_kc);
+            fetch_a(f_t, f_kc, w);
             if (++f_kc == Kc) { f_kc = 0; ++f_t; }
+        } else {
+            fetch_a(0, 0, w);                           // past the end: harmless re-read keeps the vmcnt count uniform
         }
-        return w;
     };
-    uint32_t a_nxt[SC], a_nn[SC];
+    uint32_t a_nxt[SC];
 #pragma unroll
     for (int j = 0; j < SC; ++j) {                      // super-chunk 0 -> buffer 0
-        const uint32_t w0 = fetch_next();
+        fetch_next(a_nxt[j]);
         stage_b(j, j);
-        store_a(w0, j);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int j = 0; j < SC; ++j) a_nxt[j] = fetch_next();   // super-chunk 1
-    __syncthreads();
+    for (int j = 0; j < SC; ++j) {
+        asm volatile("" : "+v"(a_nxt[j]));              // the loaded value is only defined from here on
+        store_a(a_nxt[j], j);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     int buf = 0;
 
     for (int t = 0; t < n_steps; ++t) {
         for (int kc = 0; kc < Kc; kc += SC) {
             const bool last = kc + SC == Kc;
             const bool more = !last || t + 1 < n_steps;
+            // VMEM issue order per super-chunk: SC spike-word loads, then 3*SC LDS-DMA pieces
 #pragma unroll
-            for (int j = 0; j < SC; ++j) a_nn[j] = fetch_next();     // super-chunk +2: global loads in flight
-            if (more) {
+            for (int j = 0; j < SC; ++j) fetch_next(a_nxt[j]);       // next super-chunk's spike words
+#ifndef SNN_EXP_NO_GLDS
 #pragma unroll
-                for (int j = 0; j < SC; ++j) stage_b((last ? 0 : kc + SC) + j, (buf ^ 1) * SC + j);   // other buffer
-            }
+            for (int j = 0; j < SC; ++j) stage_b((last ? 0 : kc + SC) + j, (buf ^ 1) * SC + j);   // other buffer
+#endif
 #pragma unroll
             for (int j = 0; j < SC; ++j) {
                 const unsigned char* Ab = smem + A_OFF + (buf * SC + j) * G3_A_BYTES + a_rd;
@@ -718,20 +731,40 @@ __global__ __launch_bounds__(512, FUSE ? 2 : 4) void k_gemm_bf16x3(const Gemm3Ar
                 ld_b(bq[1], 0, 1);
                 __builtin_amdgcn_sched_barrier(0);
                 mm(bq[0], 0);
-                if (more) store_a(a_nxt[j], (buf ^ 1) * SC + j);     // expansion VALU + 2 ds_write_b128 beside the MFMAs
+                __builtin_amdgcn_sched_barrier(0);
                 ld_b(bq[0], 1, 0);
+                __builtin_amdgcn_sched_barrier(0);
                 mm(bq[1], 1);
                 __builtin_amdgcn_sched_barrier(0);
                 ld_a(1); ld_b(bq[1], 1, 1);
                 __builtin_amdgcn_sched_barrier(0);
                 mm(bq[0], 0);
                 __builtin_amdgcn_sched_barrier(0);
+#ifndef SNN_EXP_NO_STORE_A
+                if (j == SC - 1) {
+                    // the spike words were issued BEFORE this super-chunk's 3*SC LDS-DMA pieces: wait until at
+                    // most those pieces are outstanding, then expand into the other buffer
+#ifdef SNN_EXP_NO_GLDS
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+                    if (SC == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+#endif
+#pragma unroll
+                    for (int jj = 0; jj < SC; ++jj) {
+                        asm volatile("" : "+v"(a_nxt[jj]));
+                        store_a(a_nxt[jj], (buf ^ 1) * SC + jj);
+                    }
+                }
+#endif
                 mm(bq[1], 1);
             }
-            __syncthreads();
+#ifndef SNN_EXP_NO_BARRIER
+            // weight planes landed (vmcnt), expanded spike image written (lgkmcnt), everyone done reading `buf`
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+#endif
             buf ^= 1;
-#pragma unroll
-            for (int j = 0; j < SC; ++j) a_nxt[j] = a_nn[j];
         }
         if (FUSE) {
             // ---- LIF epilogue in registers; spikes leave as ballots (2 position words per register) ----

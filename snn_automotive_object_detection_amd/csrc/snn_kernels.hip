@@ -124,26 +124,37 @@ __global__ __launch_bounds__(256) void k_encode_nchw(const float* __restrict__ f
     }
 }
 
-// K1b: encoder on row-major x[R][D] -> bit-planes [T][R][Dw]; a wave covers 64 consecutive
-// reduction indices, so one ballot per step IS two plane words.
+// K1b: encoder on row-major x[R][D] -> bit-planes [T][R][Dw]; a wave covers 64 consecutive reduction indices per
+// slot, so one ballot per step IS two plane words.  Each thread runs ENC_U independent elements (64 apart) to keep
+// several loads and scan chains in flight.
+#define ENC_U 4
 __global__ __launch_bounds__(256) void k_encode_rows(const float* __restrict__ x, int R, int D, int Dw, int T,
                                                      NeuronP p, uint32_t* __restrict__ planes,
                                                      size_t plane_stride) {
     const size_t Dp = (size_t)Dw * 32;
     const size_t total = (size_t)R * Dp;
-    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
-    float xv = 0.0f;
-    if (e < total) {
-        const size_t r = e / Dp, k = e % Dp;
-        if (k < (size_t)D) xv = x[r * D + k];
-    }
-    float v = 0.0f;                               // faster_rcnn.py:484
     const int lane = threadIdx.x & 63;
+    const size_t wave_base = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 * ENC_U);
+    float xv[ENC_U], v[ENC_U];
+    size_t e[ENC_U];
+#pragma unroll
+    for (int u = 0; u < ENC_U; ++u) {
+        e[u] = wave_base + (size_t)u * 64 + lane;
+        xv[u] = 0.0f;
+        v[u] = 0.0f;                              // faster_rcnn.py:484
+        if (e[u] < total) {
+            const size_t r = e[u] / Dp, k = e[u] % Dp;
+            if (k < (size_t)D) xv[u] = x[r * D + k];
+        }
+    }
     for (int t = 0; t < T; ++t) {
-        const bool z = enc_step(xv, v, p);
-        const unsigned long long m = __ballot(z);
-        if ((lane & 31) == 0 && e < total)
-            planes[(size_t)t * plane_stride + (e >> 5)] = (lane < 32) ? (uint32_t)m : (uint32_t)(m >> 32);
+#pragma unroll
+        for (int u = 0; u < ENC_U; ++u) {
+            const bool z = enc_step(xv[u], v[u], p);
+            const unsigned long long m = __ballot(z);
+            if ((lane & 31) == 0 && e[u] < total)
+                planes[(size_t)t * plane_stride + (e[u] >> 5)] = (lane < 32) ? (uint32_t)m : (uint32_t)(m >> 32);
+        }
     }
 }
 
@@ -1196,7 +1207,7 @@ int snn_encode_rows(const float* x, int R, int D, int T, const snn_params* p, ui
     if (check_T(T, "snn_encode_rows")) return -1;
     const int Dw = cdiv(D, 32);
     const size_t total = (size_t)R * Dw * 32;
-    hipLaunchKernelGGL(k_encode_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)s, x, R, D,
+    hipLaunchKernelGGL(k_encode_rows, dim3((unsigned)((total + 256 * ENC_U - 1) / (256 * ENC_U))), dim3(256), 0, (hipStream_t)s, x, R, D,
                        Dw, T, make_p(p, p->v_th_enc), planes, plane_stride);
     SNN_CHECK_LAUNCH("k_encode_rows");
     return 0;

@@ -130,6 +130,29 @@ int snn_det_head_forward(const float* x, int R, int D, int Hd, int K, int K4, in
                          uint32_t* spk6_count, uint32_t* spk7_count, float* sum_cls, float* sum_bbox,
                          void* workspace, size_t workspace_bytes, snn_stream_t stream);
 
+/* ---- RoIAlign fused with the detector encoder (the step in front of the head, roi_heads.py:1217) --------
+ * MultiScaleRoIAlign(7x7, sampling_ratio 2, aligned=False) + lif_current_encoder in one kernel: the [R,C,7,7]
+ * fp32 RoI features are never materialised.  The caller assigns each RoI its FPN level (torchvision's
+ * LevelMapper) and image index; rois are x1,y1,x2,y2 in (padded) image coordinates. */
+typedef struct snn_roi_level {
+    const float* feat;       /* [N][C][H][W] fp32 */
+    int32_t H, W;
+    float spatial_scale;     /* 1/4, 1/8, 1/16, 1/32 */
+    int32_t reserved;
+} snn_roi_level;
+int snn_roi_align_encode(const snn_roi_level* levels_host, int n_levels /* <= 4 */, int C, const float* rois /*[R][4]*/,
+                         const int* roi_batch /*[R]*/, const int* roi_level /*[R]*/, int R, int T,
+                         const snn_params* p_host, uint32_t* planes /*[T][R][ceil(C*49/32)]*/, size_t plane_stride_words,
+                         float* pooled_dbg /* nullable [R][C*49]: the pooled features, parity tests only */,
+                         snn_stream_t stream);
+/* snn_det_head_forward with the encoder fed by snn_roi_align_encode (D = C*49; same workspace size) */
+int snn_det_head_forward_roialign(const snn_roi_level* levels_host, int n_levels, int C, const float* rois,
+                                  const int* roi_batch, const int* roi_level, int R, int Hd, int K, int K4, int T,
+                                  const snn_params* p_host, const void* w6_packed, const void* w7_packed,
+                                  const float* w_heads_packed, float* out_cls, float* out_bbox,
+                                  uint32_t* spk6_count, uint32_t* spk7_count, float* sum_cls, float* sum_bbox,
+                                  void* workspace, size_t workspace_bytes, snn_stream_t stream);
+
 /* ---- stage-level entry points (parity tests drive the layers one by one, teacher-forced) ----- */
 /* constant-current LIF encoder -> bit-planes.  NCHW feature map -> planes[T][N*H*W][Cw]          */
 int snn_encode_nchw(const float* feat, int N, int C, int H, int W, int T, const snn_params* p_host,

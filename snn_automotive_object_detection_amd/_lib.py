@@ -26,6 +26,11 @@ class snn_rpn_level(C.Structure):
                 ("precision", C.c_int32)]
 
 
+class snn_roi_level(C.Structure):
+    _fields_ = [("feat", C.c_void_p), ("H", C.c_int32), ("W", C.c_int32), ("spatial_scale", C.c_float),
+                ("reserved", C.c_int32)]
+
+
 # every symbol include/snn_hip.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "snn_version": (C.c_int, []),
@@ -57,6 +62,11 @@ SYMBOLS = {
                                C.c_void_p, c_stream]),
     "snn_li_heads": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                C.POINTER(snn_params), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_stream]),
+    "snn_roi_align_encode": (C.c_int, [C.POINTER(snn_roi_level), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_int, C.c_int, C.POINTER(snn_params), C.c_void_p, C.c_size_t, C.c_void_p, c_stream]),
+    "snn_det_head_forward_roialign": (C.c_int, [C.POINTER(snn_roi_level), C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                                C.c_void_p] + [C.c_int] * 5 + [C.POINTER(snn_params)] +
+                                      [C.c_void_p] * 10 + [C.c_size_t, c_stream]),
     "snn_packed_bf16x3_elems": (C.c_size_t, [C.c_int, C.c_int]),
     "snn_packed_conv3x3_bf16x3_elems": (C.c_size_t, [C.c_int, C.c_int]),
     "snn_pack_conv3x3_weight_bf16x3": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, c_stream]),

@@ -159,6 +159,86 @@ __global__ __launch_bounds__(256) void k_encode_rows(const float* __restrict__ x
 }
 
 // ------------------------------------------------------------------------------------------------
+// K1c: MultiScaleRoIAlign (7x7, sampling_ratio 2, aligned=False) fused with the detector's constant-current
+// encoder (roi_heads.py:1217 -> faster_rcnn.py:473,494): the [R,C,7,7] fp32 RoI features (100 MB at R=2000) are
+// never materialised; each thread pools one (RoI, channel, bin) element - 4 samples x 4 bilinear taps - runs its
+// T encoder steps in registers and the wave ballots straight into the bit-planes [T][R][Dw] (flatten order
+// d = c*49 + ph*7 + pw).  Arithmetic follows torchvision's roi_align / the stock-torch stand-in op for op
+// (explicit roundings, no fma): sample = (hy*hx)*v1 + (hy*lx)*v2 + (ly*hx)*v3 + (ly*lx)*v4, bin = mean of 4.
+// ------------------------------------------------------------------------------------------------
+struct RoiLevel { const float* feat; int H, W; float scale; };
+struct RoiArgs {
+    RoiLevel lv[4];
+    const float* rois;        // [R][4] x1,y1,x2,y2 in image coordinates
+    const int* roi_batch;     // [R]
+    const int* roi_level;     // [R] index into lv
+    float* pooled;            // nullable test hook: [R][C*49] fp32
+    uint32_t* planes;
+    unsigned long long plane_stride;
+    int R, C, T, Dw;
+    NeuronP p;
+};
+
+__device__ __forceinline__ float roi_bilinear(const float* __restrict__ f, int H, int W, float y, float x) {
+    if (y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) return 0.0f;
+    y = fmaxf(y, 0.0f);
+    x = fmaxf(x, 0.0f);
+    int y_low = (int)y, x_low = (int)x, y_high, x_high;
+    if (y_low >= H - 1) { y_high = y_low = H - 1; y = (float)y_low; } else y_high = y_low + 1;
+    if (x_low >= W - 1) { x_high = x_low = W - 1; x = (float)x_low; } else x_high = x_low + 1;
+    const float ly = __fsub_rn(y, (float)y_low), lx = __fsub_rn(x, (float)x_low);
+    const float hy = __fsub_rn(1.0f, ly), hx = __fsub_rn(1.0f, lx);
+    const float v1 = f[y_low * W + x_low], v2 = f[y_low * W + x_high];
+    const float v3 = f[y_high * W + x_low], v4 = f[y_high * W + x_high];
+    float acc = __fmul_rn(__fmul_rn(hy, hx), v1);
+    acc = __fadd_rn(acc, __fmul_rn(__fmul_rn(hy, lx), v2));
+    acc = __fadd_rn(acc, __fmul_rn(__fmul_rn(ly, hx), v3));
+    acc = __fadd_rn(acc, __fmul_rn(__fmul_rn(ly, lx), v4));
+    return acc;
+}
+
+__global__ __launch_bounds__(256) void k_roi_align_encode(const RoiArgs a) {
+    const int r = blockIdx.y;
+    const int D = a.C * 49;
+    const int d = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    float val = 0.0f;
+    if (d < D) {
+        const int c = d / 49, ph = (d % 49) / 7, pw = d % 7;
+        const RoiLevel L = a.lv[a.roi_level[r]];
+        const float* roi = a.rois + (size_t)r * 4;
+        const float x1 = __fmul_rn(roi[0], L.scale), y1 = __fmul_rn(roi[1], L.scale);
+        const float rw = fmaxf(__fsub_rn(__fmul_rn(roi[2], L.scale), x1), 1.0f);
+        const float rh = fmaxf(__fsub_rn(__fmul_rn(roi[3], L.scale), y1), 1.0f);
+        const float bh = __fdiv_rn(rh, 7.0f), bw = __fdiv_rn(rw, 7.0f);
+        const float* f = L.feat + ((size_t)a.roi_batch[r] * a.C + c) * (size_t)(L.H * L.W);
+        // sample coordinate: start + (p + (i + .5)/2) * bin   (the stock op's grid form)
+        float s[2][2];
+#pragma unroll
+        for (int iy = 0; iy < 2; ++iy)
+#pragma unroll
+            for (int ix = 0; ix < 2; ++ix) {
+                const float gy = __fadd_rn((float)ph, __fdiv_rn((float)iy + 0.5f, 2.0f));
+                const float gx = __fadd_rn((float)pw, __fdiv_rn((float)ix + 0.5f, 2.0f));
+                s[iy][ix] = roi_bilinear(f, L.H, L.W, __fadd_rn(y1, __fmul_rn(gy, bh)), __fadd_rn(x1, __fmul_rn(gx, bw)));
+            }
+        // mean over the 2x2 samples (torch .mean(dim=(3,5)): sum in (iy, ix) order, then / 4)
+        val = __fdiv_rn(__fadd_rn(__fadd_rn(__fadd_rn(s[0][0], s[0][1]), s[1][0]), s[1][1]), 4.0f);
+        if (a.pooled) a.pooled[(size_t)r * D + d] = val;
+    }
+    // encoder over T steps; the wave's 64 consecutive d are two plane words
+    float v = 0.0f;
+    const size_t e = (size_t)r * a.Dw * 32 + d;
+    const bool in = d < a.Dw * 32;
+    for (int t = 0; t < a.T; ++t) {
+        const bool z = enc_step(val, v, a.p) && d < D;
+        const unsigned long long m = __ballot(z);
+        if ((lane & 31) == 0 && in)
+            a.planes[(size_t)t * a.plane_stride + (e >> 5)] = (lane < 32) ? (uint32_t)m : (uint32_t)(m >> 32);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K2: fused 3x3 spike convolution (implicit GEMM on the fp32 matrix cores) + LIF over the T loop.
 //
 // Work-group = 512 threads = 8 waves; tile = 64 positions (an 8x8 patch of one image of one level)
@@ -1213,6 +1293,30 @@ int snn_encode_rows(const float* x, int R, int D, int T, const snn_params* p, ui
     return 0;
 }
 
+
+int snn_roi_align_encode(const snn_roi_level* levels_host, int n_levels, int C, const float* rois, const int* roi_batch,
+                         const int* roi_level, int R, int T, const snn_params* p, uint32_t* planes,
+                         size_t plane_stride, float* pooled_dbg, snn_stream_t s) {
+    if (!levels_host || n_levels <= 0 || n_levels > 4 || C <= 0 || !rois || !roi_batch || !roi_level || R <= 0 || !p ||
+        !planes)
+        return fail(-1, "snn_roi_align_encode: bad argument");
+    if (check_T(T, "snn_roi_align_encode")) return -1;
+    RoiArgs a;
+    memset(&a, 0, sizeof(a));
+    for (int l = 0; l < n_levels; ++l) {
+        if (!levels_host[l].feat || levels_host[l].H <= 0 || levels_host[l].W <= 0)
+            return fail(-1, "snn_roi_align_encode: bad level %d", l);
+        a.lv[l].feat = levels_host[l].feat; a.lv[l].H = levels_host[l].H; a.lv[l].W = levels_host[l].W;
+        a.lv[l].scale = levels_host[l].spatial_scale;
+    }
+    a.rois = rois; a.roi_batch = roi_batch; a.roi_level = roi_level; a.pooled = pooled_dbg; a.planes = planes;
+    a.plane_stride = plane_stride; a.R = R; a.C = C; a.T = T; a.Dw = cdiv(C * 49, 32);
+    a.p = make_p(p, p->v_th_enc);
+    hipLaunchKernelGGL(k_roi_align_encode, dim3(cdiv(a.Dw * 32, 256), R), dim3(256), 0, (hipStream_t)s, a);
+    SNN_CHECK_LAUNCH("k_roi_align_encode");
+    return 0;
+}
+
 // shared by snn_conv3x3_lif (one level) and snn_rpn_head_forward (all levels in one launch)
 static int launch_conv(const snn_rpn_level* lv, int n_levels, int C_in, int C_out, int T, const snn_params* p,
                        const uint32_t* enc, size_t enc_stride, const float* wpk, uint32_t* spk,
@@ -1427,6 +1531,36 @@ size_t snn_det_head_workspace_bytes(int R, int D, int Hd, int K, int K4, int T, 
     return tot;
 }
 
+static int det_head_from_planes(int R, int D, int Hd, int K, int K4, int T, const snn_params* p, const void* w6_packed,
+                                const void* w7_packed, const float* w_heads_packed, float* out_cls, float* out_bbox,
+                                uint32_t* spk6_count, uint32_t* spk7_count, float* sum_cls, float* sum_bbox, void* ws,
+                                snn_stream_t stream) {
+    size_t o_enc, o_cur, o_s6, o_s7, need;
+    det_ws_layout(R, D, Hd, T, &o_enc, &o_cur, &o_s6, &o_s7, &need);
+    hipStream_t s = (hipStream_t)stream;
+    uint32_t* enc = (uint32_t*)((char*)ws + o_enc);
+    float* cur = (float*)((char*)ws + o_cur);
+    uint32_t* s6 = (uint32_t*)((char*)ws + o_s6);
+    uint32_t* s7 = (uint32_t*)((char*)ws + o_s7);
+    const int Hw = cdiv(Hd, 32), Hp = Hw * 32;
+    int rc;
+    if (spk6_count) { if (hipMemsetAsync(spk6_count, 0, sizeof(uint32_t) * R, s) != hipSuccess) return fail(-3, "hipMemsetAsync failed"); }
+    if (spk7_count) { if (hipMemsetAsync(spk7_count, 0, sizeof(uint32_t) * R, s) != hipSuccess) return fail(-3, "hipMemsetAsync failed"); }
+    const bool b3 = p->precision == SNN_PRECISION_BF16X3;
+    if (p->precision != SNN_PRECISION_F32 && !b3) return fail(-1, "snn_det_head_forward: unknown precision %d", p->precision);
+    // fc6 for all T steps at once: rows m = t*R + r   (faster_rcnn.py:498)
+    rc = b3 ? snn_spike_gemm_bf16x3(enc, T * R, D, Hd, (const uint16_t*)w6_packed, cur, Hp, stream)
+            : snn_spike_gemm(enc, T * R, D, Hd, (const float*)w6_packed, cur, Hp, stream);
+    if (rc) return rc;
+    if ((rc = snn_lif_scan(cur, T, R, Hd, Hp, p, s6, (size_t)R * Hw, spk6_count, stream))) return rc;   // :499
+    rc = b3 ? snn_spike_gemm_bf16x3(s6, T * R, Hd, Hd, (const uint16_t*)w7_packed, cur, Hp, stream)
+            : snn_spike_gemm(s6, T * R, Hd, Hd, (const float*)w7_packed, cur, Hp, stream);                       // :500
+    if (rc) return rc;
+    if ((rc = snn_lif_scan(cur, T, R, Hd, Hp, p, s7, (size_t)R * Hw, spk7_count, stream))) return rc;   // :501
+    return snn_li_heads(s7, (size_t)R * Hw, T, R, Hd, w_heads_packed, K, K4, p, out_cls, out_bbox, sum_cls,
+                        sum_bbox, stream);                                                               // :505-510
+}
+
 int snn_det_head_forward(const float* x, int R, int D, int Hd, int K, int K4, int T, const snn_params* p,
                          const void* w6_packed, const void* w7_packed, const float* w_heads_packed,
                          float* out_cls, float* out_bbox, uint32_t* spk6_count, uint32_t* spk7_count,
@@ -1438,29 +1572,30 @@ int snn_det_head_forward(const float* x, int R, int D, int Hd, int K, int K4, in
     size_t o_enc, o_cur, o_s6, o_s7, need;
     det_ws_layout(R, D, Hd, T, &o_enc, &o_cur, &o_s6, &o_s7, &need);
     if (ws_bytes < need) return fail(-2, "snn_det_head_forward: workspace %zu < %zu bytes", ws_bytes, need);
-    hipStream_t s = (hipStream_t)stream;
-    uint32_t* enc = (uint32_t*)((char*)ws + o_enc);
-    float* cur = (float*)((char*)ws + o_cur);
-    uint32_t* s6 = (uint32_t*)((char*)ws + o_s6);
-    uint32_t* s7 = (uint32_t*)((char*)ws + o_s7);
-    const int Dw = cdiv(D, 32), Hw = cdiv(Hd, 32), Hp = Hw * 32;
-    int rc;
-    if (spk6_count) { if (hipMemsetAsync(spk6_count, 0, sizeof(uint32_t) * R, s) != hipSuccess) return fail(-3, "hipMemsetAsync failed"); }
-    if (spk7_count) { if (hipMemsetAsync(spk7_count, 0, sizeof(uint32_t) * R, s) != hipSuccess) return fail(-3, "hipMemsetAsync failed"); }
-    if ((rc = snn_encode_rows(x, R, D, T, p, enc, (size_t)R * Dw, stream))) return rc;
-    // fc6 for all T steps at once: rows m = t*R + r   (faster_rcnn.py:498)
-    const bool b3 = p->precision == SNN_PRECISION_BF16X3;
-    if (p->precision != SNN_PRECISION_F32 && !b3) return fail(-1, "snn_det_head_forward: unknown precision %d", p->precision);
-    rc = b3 ? snn_spike_gemm_bf16x3(enc, T * R, D, Hd, (const uint16_t*)w6_packed, cur, Hp, stream)
-            : snn_spike_gemm(enc, T * R, D, Hd, (const float*)w6_packed, cur, Hp, stream);
+    int rc = snn_encode_rows(x, R, D, T, p, (uint32_t*)((char*)ws + o_enc), (size_t)R * cdiv(D, 32), stream);
     if (rc) return rc;
-    if ((rc = snn_lif_scan(cur, T, R, Hd, Hp, p, s6, (size_t)R * Hw, spk6_count, stream))) return rc;   // :499
-    rc = b3 ? snn_spike_gemm_bf16x3(s6, T * R, Hd, Hd, (const uint16_t*)w7_packed, cur, Hp, stream)
-            : snn_spike_gemm(s6, T * R, Hd, Hd, (const float*)w7_packed, cur, Hp, stream);                       // :500
+    return det_head_from_planes(R, D, Hd, K, K4, T, p, w6_packed, w7_packed, w_heads_packed, out_cls, out_bbox,
+                                spk6_count, spk7_count, sum_cls, sum_bbox, ws, stream);
+}
+
+int snn_det_head_forward_roialign(const snn_roi_level* levels_host, int n_levels, int C, const float* rois,
+                                  const int* roi_batch, const int* roi_level, int R, int Hd, int K, int K4, int T,
+                                  const snn_params* p, const void* w6_packed, const void* w7_packed,
+                                  const float* w_heads_packed, float* out_cls, float* out_bbox, uint32_t* spk6_count,
+                                  uint32_t* spk7_count, float* sum_cls, float* sum_bbox, void* ws, size_t ws_bytes,
+                                  snn_stream_t stream) {
+    if (!p || !w6_packed || !w7_packed || !w_heads_packed || !out_cls || !out_bbox || !ws)
+        return fail(-1, "snn_det_head_forward_roialign: null argument");
+    if (R <= 0 || C <= 0 || Hd <= 0 || K <= 0 || K4 <= 0) return fail(-1, "snn_det_head_forward_roialign: bad shape");
+    const int D = C * 49;
+    size_t o_enc, o_cur, o_s6, o_s7, need;
+    det_ws_layout(R, D, Hd, T, &o_enc, &o_cur, &o_s6, &o_s7, &need);
+    if (ws_bytes < need) return fail(-2, "snn_det_head_forward_roialign: workspace %zu < %zu bytes", ws_bytes, need);
+    int rc = snn_roi_align_encode(levels_host, n_levels, C, rois, roi_batch, roi_level, R, T, p,
+                                  (uint32_t*)((char*)ws + o_enc), (size_t)R * cdiv(D, 32), nullptr, stream);
     if (rc) return rc;
-    if ((rc = snn_lif_scan(cur, T, R, Hd, Hp, p, s7, (size_t)R * Hw, spk7_count, stream))) return rc;   // :501
-    return snn_li_heads(s7, (size_t)R * Hw, T, R, Hd, w_heads_packed, K, K4, p, out_cls, out_bbox, sum_cls,
-                        sum_bbox, stream);                                                               // :505-510
+    return det_head_from_planes(R, D, Hd, K, K4, T, p, w6_packed, w7_packed, w_heads_packed, out_cls, out_bbox,
+                                spk6_count, spk7_count, sum_cls, sum_bbox, ws, stream);
 }
 
 }  // extern "C"

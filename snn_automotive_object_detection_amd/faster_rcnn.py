@@ -47,24 +47,46 @@ class FastRCNNPredictorSNNFull(nn.Module):
     def _params(self):
         return ops.make_params(self.p_enc, self.p_lif, self.dt, self.li_order, self.precision)
 
+    def _packed(self):
+        pack = ops.pack_linear if self.precision == "f32" else ops.pack_linear_bf16x3
+        w6 = self._c6[self.precision].get((self.fc6.weight,), pack)
+        w7 = self._c7[self.precision].get((self.fc7.weight,), pack)
+        wh = self._ch.get((self.cls_score.weight, self.bbox_pred.weight), ops.pack_heads)
+        return w6, w7, wh
+
     @torch.no_grad()
     def forward(self, x):
         T = int(self.num_steps)
         Hd, K = self.representation_size, self.num_classes
         K4 = self.bbox_pred.weight.shape[0]
-        pack = ops.pack_linear if self.precision == "f32" else ops.pack_linear_bf16x3
-        w6 = self._c6[self.precision].get((self.fc6.weight,), pack)
-        w7 = self._c7[self.precision].get((self.fc7.weight,), pack)
-        wh = self._ch.get((self.cls_score.weight, self.bbox_pred.weight), ops.pack_heads)
+        w6, w7, wh = self._packed()
         x = x.flatten(start_dim=1)                                     # :473
         if x.shape[1] != self.in_channels:
             raise ValueError("expected %d input features, got %d" % (self.in_channels, x.shape[1]))
-        cls, bbox, (c6, c7, s_c, s_b) = ops.det_head_forward(x, Hd, K, K4, T, self._params(), w6, w7, wh,
-                                                            spike_rates=self.spike_rates)
+        out = ops.det_head_forward(x, Hd, K, K4, T, self._params(), w6, w7, wh, spike_rates=self.spike_rates)
+        return self._finish(out, x.shape[0], x.device)
+
+    @torch.no_grad()
+    def forward_roialign(self, feats, scales, rois, roi_level):
+        """Same head fed straight from the FPN maps: MultiScaleRoIAlign(7x7, sampling 2) is fused with the encoder
+        (the [R,C,7,7] RoI features of roi_heads.py:1217 are never materialised).  rois [R,5] = (image, x1,y1,x2,y2)."""
+        T = int(self.num_steps)
+        Hd, K = self.representation_size, self.num_classes
+        K4 = self.bbox_pred.weight.shape[0]
+        w6, w7, wh = self._packed()
+        if feats[0].shape[1] * 49 != self.in_channels:
+            raise ValueError("expected %d input features, got %d x 49" % (self.in_channels, feats[0].shape[1]))
+        out = ops.det_head_forward_roialign(feats, scales, rois[:, 1:5], rois[:, 0], roi_level, Hd, K, K4, T,
+                                            self._params(), w6, w7, wh, spike_rates=self.spike_rates)
+        return self._finish(out, rois.shape[0], rois.device)
+
+    def _finish(self, out, R, dev):
+        cls, bbox, (c6, c7, s_c, s_b) = out
+        T = int(self.num_steps)
+        Hd, K = self.representation_size, self.num_classes
         if not self.spike_rates:
             return cls, bbox                                           # :513-516
         # faster_rcnn.py:568-618: (count / T).mean(dim=1) and literal "FLOPs" per layer
-        R, dev = x.shape[0], x.device
         r6 = (c6.to(torch.float64) / float(T * Hd)).to(torch.float32).view(R, 1)
         r7 = (c7.to(torch.float64) / float(T * Hd)).to(torch.float32).view(R, 1)
         rc = (s_c / T).mean(dim=1, keepdim=True)

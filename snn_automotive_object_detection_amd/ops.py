@@ -7,7 +7,7 @@ from typing import List, NamedTuple, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import snn_params, snn_rpn_level
+from ._lib import snn_params, snn_rpn_level, snn_roi_level
 
 DT = 0.001                                   # rpn.py:55 / faster_rcnn.py:436
 
@@ -320,4 +320,65 @@ def det_head_forward(x: torch.Tensor, Hd: int, K: int, K4: int, T: int, p: snn_p
                                         _ptr(w_heads_packed), _ptr(out_cls), _ptr(out_bbox), _ptr(c6), _ptr(c7),
                                         _ptr(s_c), _ptr(s_b), _ptr(ws), ws.numel(), _stream()),
                "snn_det_head_forward")
+    return out_cls, out_bbox, (c6, c7, s_c, s_b)
+
+
+# ---------------------------------------------------------------------------------------------
+# RoIAlign fused with the detector encoder
+# ---------------------------------------------------------------------------------------------
+def _roi_levels(feats, scales):
+    lv = (snn_roi_level * len(feats))()
+    keep = []
+    for i, (f, sc) in enumerate(zip(feats, scales)):
+        _need_gpu(f, "feature map")
+        f = _f32c(f)
+        keep.append(f)
+        lv[i] = snn_roi_level(f.data_ptr(), f.shape[2], f.shape[3], float(sc), 0)
+    return lv, keep
+
+
+def roi_align_encode(feats, scales, rois: torch.Tensor, roi_batch: torch.Tensor, roi_level: torch.Tensor, T: int,
+                     p: snn_params, want_pooled: bool = False):
+    """feats: list of [N,C,H,W]; rois [R,4]; roi_batch/roi_level int32 [R] -> encoder planes int32 [T, R, Dw]
+    (+ the pooled [R, C*49] features when asked: parity tests)"""
+    lib = _lib.load()
+    lv, keep = _roi_levels(feats, scales)
+    Cc = keep[0].shape[1]
+    rois = _f32c(rois)
+    roi_batch = roi_batch.to(torch.int32).contiguous()
+    roi_level = roi_level.to(torch.int32).contiguous()
+    R = rois.shape[0]
+    Dw = cdiv(Cc * 49, 32)
+    planes = torch.empty((T, R, Dw), dtype=torch.int32, device=rois.device)
+    pooled = torch.empty((R, Cc * 49), dtype=torch.float32, device=rois.device) if want_pooled else None
+    _lib.check(lib.snn_roi_align_encode(lv, len(keep), Cc, _ptr(rois), _ptr(roi_batch), _ptr(roi_level), R, T, C.byref(p),
+                                        _ptr(planes), R * Dw, _ptr(pooled), _stream()), "snn_roi_align_encode")
+    return (planes, pooled) if want_pooled else planes
+
+
+def det_head_forward_roialign(feats, scales, rois, roi_batch, roi_level, Hd: int, K: int, K4: int, T: int, p: snn_params,
+                              w6_packed, w7_packed, w_heads_packed, spike_rates: bool = False):
+    lib = _lib.load()
+    lv, keep = _roi_levels(feats, scales)
+    Cc = keep[0].shape[1]
+    rois = _f32c(rois)
+    roi_batch = roi_batch.to(torch.int32).contiguous()
+    roi_level = roi_level.to(torch.int32).contiguous()
+    R, dev = rois.shape[0], rois.device
+    out_cls = torch.empty((R, K), dtype=torch.float32, device=dev)
+    out_bbox = torch.empty((R, K4), dtype=torch.float32, device=dev)
+    c6 = c7 = s_c = s_b = None
+    if spike_rates:
+        c6 = torch.empty((R,), dtype=torch.int32, device=dev)
+        c7 = torch.empty((R,), dtype=torch.int32, device=dev)
+        s_c = torch.empty_like(out_cls)
+        s_b = torch.empty_like(out_bbox)
+    if R == 0:
+        return out_cls, out_bbox, (c6, c7, s_c, s_b)
+    ws_bytes = lib.snn_det_head_workspace_bytes(R, Cc * 49, Hd, K, K4, T, p.precision)
+    ws = _WS.get(dev, ws_bytes)
+    _lib.check(lib.snn_det_head_forward_roialign(lv, len(keep), Cc, _ptr(rois), _ptr(roi_batch), _ptr(roi_level), R, Hd, K,
+                                                 K4, T, C.byref(p), _ptr(w6_packed), _ptr(w7_packed), _ptr(w_heads_packed),
+                                                 _ptr(out_cls), _ptr(out_bbox), _ptr(c6), _ptr(c7), _ptr(s_c), _ptr(s_b),
+                                                 _ptr(ws), ws.numel(), _stream()), "snn_det_head_forward_roialign")
     return out_cls, out_bbox, (c6, c7, s_c, s_b)

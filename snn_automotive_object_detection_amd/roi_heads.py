@@ -26,6 +26,7 @@ class RoIHeadsSNN(nn.Module):
         self.score_thresh = score_thresh
         self.nms_thresh = nms_thresh
         self.detections_per_img = detections_per_img
+        self.fuse_roi_align = True        # use the fused RoIAlign+encoder kernel when pool/head support it
         # training-side hyper-parameters are accepted for signature compatibility only
         self.fg_iou_thresh, self.bg_iou_thresh = fg_iou_thresh, bg_iou_thresh
         self.batch_size_per_image, self.positive_fraction = batch_size_per_image, positive_fraction
@@ -78,8 +79,15 @@ class RoIHeadsSNN(nn.Module):
                 targets: Optional[List[Dict[str, Tensor]]] = None):
         if self.training:
             raise NotImplementedError("inference only: training the RoI heads is out of scope (DESIGN.md §7)")
-        box_features = self.box_roi_pool(features, proposals, image_shapes)          # roi_heads.py:1217
-        head_out = self.box_head_and_predictor(box_features)                         # roi_heads.py:1230 (HIP)
+        pool, head = self.box_roi_pool, self.box_head_and_predictor
+        if (self.fuse_roi_align and hasattr(head, "forward_roialign") and hasattr(pool, "assign")
+                and tuple(pool.output_size) == (7, 7) and pool.sampling_ratio == 2):
+            # RoIAlign fused into the head's encoder kernel: same values as the two calls below
+            feats, scales, rois, lvl = pool.assign(features, proposals, image_shapes)
+            head_out = head.forward_roialign(feats, scales, rois, lvl)
+        else:
+            box_features = pool(features, proposals, image_shapes)                   # roi_heads.py:1217
+            head_out = head(box_features)                                            # roi_heads.py:1230 (HIP)
         if getattr(self.box_head_and_predictor, "spike_rates", False):
             return head_out                                                          # roi_heads.py:1219-1223
         class_logits, box_regression = head_out

@@ -71,26 +71,30 @@ class MultiScaleRoIAlign(nn.Module):
         self.sampling_ratio = sampling_ratio
         self.canonical_scale, self.canonical_level = canonical_scale, canonical_level
 
-    def forward(self, x: Dict[str, Tensor], boxes: List[Tensor], image_shapes: List[Tuple[int, int]]) -> Tensor:
+    def assign(self, x: Dict[str, Tensor], boxes: List[Tensor], image_shapes: List[Tuple[int, int]]):
+        """-> (feature maps used, their scales, rois [K,5] = (image index, x1,y1,x2,y2), FPN level index per RoI)"""
         feats = [v for k, v in x.items() if k in self.featmap_names]
         max_h = max(s[0] for s in image_shapes)
-        max_w = max(s[1] for s in image_shapes)
         scales = []
         for f in feats:                                   # scale = 2^round(log2(feature / image))
             approx = float(f.shape[-2]) / float(max_h)
             scales.append(2.0 ** float(torch.tensor(approx).log2().round()))
         ids = torch.cat([torch.full((b.shape[0], 1), i, dtype=b.dtype, device=b.device) for i, b in enumerate(boxes)])
-        rois = torch.cat([ids, torch.cat(list(boxes), dim=0)], dim=1)
-        C = feats[0].shape[1]
-        out = feats[0].new_zeros((rois.shape[0], C) + self.output_size)
+        allb = torch.cat(list(boxes), dim=0)
+        rois = torch.cat([ids, allb], dim=1)
         if len(feats) == 1:
-            return roi_align(feats[0], rois, scales[0], self.output_size[0], self.sampling_ratio)
+            return feats, scales, rois, torch.zeros((rois.shape[0],), dtype=torch.int64, device=rois.device)
         k_min = -int(round(float(torch.log2(torch.tensor(scales[0])))))
         k_max = -int(round(float(torch.log2(torch.tensor(scales[-1])))))
-        allb = torch.cat(list(boxes), dim=0)
         s = torch.sqrt((allb[:, 2] - allb[:, 0]) * (allb[:, 3] - allb[:, 1]))
         lvl = torch.floor(self.canonical_level + torch.log2(s / self.canonical_scale) + torch.tensor(1e-6, dtype=s.dtype))
         lvl = (torch.clamp(lvl, min=k_min, max=k_max).to(torch.int64) - k_min)
+        return feats, scales, rois, lvl
+
+    def forward(self, x: Dict[str, Tensor], boxes: List[Tensor], image_shapes: List[Tuple[int, int]]) -> Tensor:
+        feats, scales, rois, lvl = self.assign(x, boxes, image_shapes)
+        C = feats[0].shape[1]
+        out = feats[0].new_zeros((rois.shape[0], C) + self.output_size)
         for level, (f, sc) in enumerate(zip(feats, scales)):
             sel = torch.where(lvl == level)[0]
             if sel.numel():

@@ -18,6 +18,7 @@ def test_create_model_end_to_end_and_heads_in_situ(gpu_device):
     m = S.create_model("cityscapes", 9, True, True, 0, False, False, num_steps_rpn=8, num_steps_detector=12)
     m.transform.min_size, m.transform.max_size = 384, 768                 # 512x1024 images -> 384x768 canvas
     m = m.to(gpu_device).eval()
+    m.roi_heads.fuse_roi_align = False      # the hooks below observe the head's own forward (un-fused path)
     cap = {}
     m.rpn.head.register_forward_hook(lambda mod, inp, out: cap.update(rpn_in=[f.detach().cpu() for f in inp[0]],
                                                                       rpn_out=([t.cpu() for t in out[0]], [t.cpu() for t in out[1]])))

@@ -153,6 +153,14 @@ int snn_det_head_forward_roialign(const snn_roi_level* levels_host, int n_levels
                                   uint32_t* spk6_count, uint32_t* spk7_count, float* sum_cls, float* sum_bbox,
                                   void* workspace, size_t workspace_bytes, snn_stream_t stream);
 
+/* ---- greedy (batched) NMS for the callers either side of the heads (rpn.py:517, roi_heads.py:1160-1161) ----
+ * boxes [n][4] already sorted by decreasing score; category (nullable) restricts suppression to equal values
+ * (level for the RPN, class for the detector).  keep_out receives up to max_keep indices into the SORTED order,
+ * in that order; *n_keep_out their number (device memory).  n <= 16384. */
+size_t snn_nms_workspace_bytes(int n);
+int snn_nms_sorted(const float* boxes_sorted, const int* category_sorted, int n, float iou_threshold, int max_keep,
+                   int* keep_out, int* n_keep_out, void* workspace, size_t workspace_bytes, snn_stream_t stream);
+
 /* ---- stage-level entry points (parity tests drive the layers one by one, teacher-forced) ----- */
 /* constant-current LIF encoder -> bit-planes.  NCHW feature map -> planes[T][N*H*W][Cw]          */
 int snn_encode_nchw(const float* feat, int N, int C, int H, int W, int T, const snn_params* p_host,

@@ -62,6 +62,9 @@ SYMBOLS = {
                                C.c_void_p, c_stream]),
     "snn_li_heads": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                C.POINTER(snn_params), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_stream]),
+    "snn_nms_workspace_bytes": (C.c_size_t, [C.c_int]),
+    "snn_nms_sorted": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_size_t, c_stream]),
     "snn_roi_align_encode": (C.c_int, [C.POINTER(snn_roi_level), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_int, C.c_int, C.POINTER(snn_params), C.c_void_p, C.c_size_t, C.c_void_p, c_stream]),
     "snn_det_head_forward_roialign": (C.c_int, [C.POINTER(snn_roi_level), C.c_int, C.c_int, C.c_void_p, C.c_void_p,

@@ -1086,6 +1086,89 @@ __global__ __launch_bounds__(256) void k_count_spikes(const uint32_t* __restrict
     if (threadIdx.x == 0) counts[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
 }
 
+// ------------------------------------------------------------------------------------------------
+// Greedy (batched) NMS for the callers on either side of the heads (rpn.py:517, roi_heads.py:1160-1161):
+// boxes arrive sorted by decreasing score; k_nms_mask builds the suppression bit-matrix (box j > i, same
+// category, IoU > thr), k_nms_scan walks it in score order with the rows staged through LDS 64 at a time.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_nms_mask(const float* __restrict__ boxes, const int* __restrict__ cat, int n,
+                                                 float thr, unsigned long long* __restrict__ mask, int words) {
+    const int rb = blockIdx.y, cb = blockIdx.x;
+    if (cb < rb) return;                                  // only j > i matters
+    __shared__ float cbx[64][4];
+    __shared__ int ccat[64];
+    const int t = threadIdx.x;
+    const int j0 = cb * 64;
+    if (j0 + t < n) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cbx[t][q] = boxes[(size_t)(j0 + t) * 4 + q];
+        ccat[t] = cat ? cat[j0 + t] : 0;
+    }
+    __syncthreads();
+    const int i = rb * 64 + t;
+    if (i >= n) return;
+    const float x1 = boxes[(size_t)i * 4], y1 = boxes[(size_t)i * 4 + 1], x2 = boxes[(size_t)i * 4 + 2], y2 = boxes[(size_t)i * 4 + 3];
+    const float area_i = __fmul_rn(__fsub_rn(x2, x1), __fsub_rn(y2, y1));
+    const int ci = cat ? cat[i] : 0;
+    unsigned long long bits = 0;
+    const int jn = min(64, n - j0);
+    for (int jj = (rb == cb ? t + 1 : 0); jj < jn; ++jj) {
+        if (ccat[jj] != ci) continue;
+        const float w = fmaxf(__fsub_rn(fminf(x2, cbx[jj][2]), fmaxf(x1, cbx[jj][0])), 0.0f);
+        const float h = fmaxf(__fsub_rn(fminf(y2, cbx[jj][3]), fmaxf(y1, cbx[jj][1])), 0.0f);
+        const float inter = __fmul_rn(w, h);
+        const float area_j = __fmul_rn(__fsub_rn(cbx[jj][2], cbx[jj][0]), __fsub_rn(cbx[jj][3], cbx[jj][1]));
+        const float iou = __fdiv_rn(inter, __fsub_rn(__fadd_rn(area_i, area_j), inter));     // box_iou's formula
+        if (iou > thr) bits |= 1ull << jj;
+    }
+    mask[(size_t)i * words + cb] = bits;
+}
+
+// one work-group; thread w < words owns word w of the "removed" set
+__global__ __launch_bounds__(256) void k_nms_scan(const unsigned long long* __restrict__ mask, int n, int words,
+                                                  int max_keep, int* __restrict__ keep, int* __restrict__ n_keep) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long* rows = reinterpret_cast<unsigned long long*>(smem);     // [64][words]
+    __shared__ unsigned long long removed_cur;
+    __shared__ int count_s;
+    const int t = threadIdx.x;
+    unsigned long long removed = 0;          // thread t (< words): removed bits of boxes [64t, 64t+64)
+    if (t == 0) count_s = 0;
+    __syncthreads();
+    for (int c = 0; c * 64 < n; ++c) {
+        const int rn = min(64, n - c * 64);
+        for (int idx = t; idx < rn * words; idx += 256) rows[idx] = mask[(size_t)c * 64 * words + idx];
+        if (t == c) removed_cur = removed;
+        __syncthreads();
+        if (t < 64) {                         // wave 0 walks the 64 candidates of this chunk in score order
+            unsigned long long rc = removed_cur;              // same value in every lane
+            int count = count_s;
+            unsigned long long kept_bits = 0;
+            for (int b = 0; b < rn && count < max_keep; ++b) {
+                if (!((rc >> b) & 1ull)) {
+                    kept_bits |= 1ull << b;
+                    if (t == 0) keep[count] = c * 64 + b;
+                    ++count;
+                    rc |= rows[b * words + c];                // suppression inside this chunk
+                }
+            }
+            if (t == 0) { count_s = count; removed_cur = kept_bits; }    // hand the kept set to everyone
+        }
+        __syncthreads();
+        const unsigned long long kept = removed_cur;
+        if (t < words && t > c) {             // later words: OR the rows of the kept boxes
+            unsigned long long acc = removed;
+            for (int b = 0; b < rn; ++b)
+                if ((kept >> b) & 1ull) acc |= rows[b * words + t];
+            removed = acc;
+        }
+        const bool done = count_s >= max_keep;
+        __syncthreads();
+        if (done) break;
+    }
+    if (t == 0) *n_keep = count_s;
+}
+
 // impulse responses of the LI cell (norse leaky_integrator.py: li_feed_forward_step; v_leak = 0)
 static void li_kappa(const snn_params* p, int T, Kappa* k) {
     const double a = (double)p->dt_tau_mem, cb = (double)p->neg_dt_tau_syn;
@@ -1293,6 +1376,27 @@ int snn_encode_rows(const float* x, int R, int D, int T, const snn_params* p, ui
     return 0;
 }
 
+
+size_t snn_nms_workspace_bytes(int n) { return (size_t)n * cdiv(n, 64) * 8; }
+
+int snn_nms_sorted(const float* boxes_sorted, const int* category_sorted, int n, float iou_threshold, int max_keep,
+                   int* keep_out, int* n_keep_out, void* ws, size_t ws_bytes, snn_stream_t s) {
+    if (!boxes_sorted || !keep_out || !n_keep_out || !ws || n <= 0 || max_keep <= 0)
+        return fail(-1, "snn_nms_sorted: bad argument");
+    const int words = cdiv(n, 64);
+    if (words > 256) return fail(-1, "snn_nms_sorted: n=%d too large (max 16384)", n);
+    if (ws_bytes < snn_nms_workspace_bytes(n)) return fail(-2, "snn_nms_sorted: workspace too small");
+    unsigned long long* mask = (unsigned long long*)ws;
+    hipLaunchKernelGGL(k_nms_mask, dim3(words, words), dim3(64), 0, (hipStream_t)s, boxes_sorted, category_sorted, n,
+                       iou_threshold, mask, words);
+    SNN_CHECK_LAUNCH("k_nms_mask");
+    const size_t lds = (size_t)64 * words * 8;
+    hipError_t e = hipFuncSetAttribute((const void*)k_nms_scan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail(-3, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(k_nms_scan, dim3(1), dim3(256), lds, (hipStream_t)s, mask, n, words, max_keep, keep_out, n_keep_out);
+    SNN_CHECK_LAUNCH("k_nms_scan");
+    return 0;
+}
 
 int snn_roi_align_encode(const snn_roi_level* levels_host, int n_levels, int C, const float* rois, const int* roi_batch,
                          const int* roi_level, int R, int T, const snn_params* p, uint32_t* planes,

@@ -382,3 +382,27 @@ def det_head_forward_roialign(feats, scales, rois, roi_batch, roi_level, Hd: int
                                                  _ptr(out_cls), _ptr(out_bbox), _ptr(c6), _ptr(c7), _ptr(s_c), _ptr(s_b),
                                                  _ptr(ws), ws.numel(), _stream()), "snn_det_head_forward_roialign")
     return out_cls, out_bbox, (c6, c7, s_c, s_b)
+
+
+# ---------------------------------------------------------------------------------------------
+# greedy / batched NMS (glue on either side of the heads)
+# ---------------------------------------------------------------------------------------------
+def batched_nms(boxes: torch.Tensor, scores: torch.Tensor, idxs: Optional[torch.Tensor], iou_threshold: float,
+                max_keep: Optional[int] = None) -> torch.Tensor:
+    """indices of the kept boxes, by decreasing score; suppression only between boxes of equal idxs"""
+    _need_gpu(boxes, "boxes")
+    lib = _lib.load()
+    n = boxes.shape[0]
+    if n == 0:
+        return torch.empty((0,), dtype=torch.int64, device=boxes.device)
+    order = scores.argsort(descending=True, stable=True)
+    b = _f32c(boxes[order])
+    cat = idxs[order].to(torch.int32).contiguous() if idxs is not None else None
+    max_keep = n if max_keep is None else min(int(max_keep), n)
+    keep = torch.empty((max_keep,), dtype=torch.int32, device=boxes.device)
+    n_keep = torch.zeros((1,), dtype=torch.int32, device=boxes.device)
+    ws = _WS.get(boxes.device, lib.snn_nms_workspace_bytes(n))
+    _lib.check(lib.snn_nms_sorted(_ptr(b), _ptr(cat), n, float(iou_threshold), max_keep, _ptr(keep), _ptr(n_keep), _ptr(ws),
+                                  ws.numel(), _stream()), "snn_nms_sorted")
+    k = int(n_keep.item())
+    return order[keep[:k].to(torch.int64)]

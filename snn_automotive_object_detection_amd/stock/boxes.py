@@ -53,9 +53,13 @@ def nms(boxes: Tensor, scores: Tensor, iou_threshold: float) -> Tensor:
 
 
 def batched_nms(boxes: Tensor, scores: Tensor, idxs: Tensor, iou_threshold: float) -> Tensor:
-    """NMS per category: shift every category into its own coordinate range, then one NMS."""
+    """NMS per category.  GPU tensors go to the HIP kernels (ops.batched_nms: bit-matrix + in-order scan); CPU
+    tensors use the plain-torch form: shift every category into its own coordinate range, then one NMS."""
     if boxes.numel() == 0:
         return torch.empty((0,), dtype=torch.int64, device=boxes.device)
+    if boxes.is_cuda and boxes.shape[0] <= 16384:
+        from .. import ops
+        return ops.batched_nms(boxes, scores, idxs, iou_threshold)
     max_coordinate = boxes.max()
     offsets = idxs.to(boxes) * (max_coordinate + torch.tensor(1).to(boxes))
     return nms(boxes + offsets[:, None], scores, iou_threshold)

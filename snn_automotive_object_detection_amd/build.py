@@ -1,5 +1,6 @@
 """In-tree build of libsnnhip.so (gfx950 only).  hipcc cross-compiles without a GPU; the built .so
 is git-ignored but travels to the GPU box with the working tree."""
+import fcntl
 import os
 import subprocess
 import sys
@@ -26,15 +27,28 @@ def needs_build() -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile under an exclusive file lock and publish with an atomic rename, so that several ranks of one node
+    (torchrun starts them together) can call this concurrently: one compiles, the others wait and reuse."""
     if not force and not needs_build():
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [HIPCC] + FLAGS + ["-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-    if r.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + r.stdout)
+    with open(os.path.join(LIB_DIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not needs_build():          # somebody else built it while we waited
+                return LIB_PATH
+            tmp = LIB_PATH + ".tmp.%d" % os.getpid()
+            cmd = [HIPCC] + FLAGS + ["-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            if r.returncode != 0:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
+                raise RuntimeError("hipcc failed:\n" + r.stdout)
+            os.replace(tmp, LIB_PATH)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
 
 

@@ -243,12 +243,13 @@ def li_heads(spk: torch.Tensor, K: int, w_heads_packed: torch.Tensor, NA: int, N
 # whole heads
 # ---------------------------------------------------------------------------------------------
 class _Workspace:
-    """grow-only per-device scratch buffer (the C ABI never allocates)"""
+    """grow-only scratch buffer per (device, stream) (the C ABI never allocates).  Calls on one stream reuse it in
+    stream order; calls on different streams get different buffers, so they may overlap."""
     def __init__(self):
         self.buf = {}
 
     def get(self, device: torch.device, nbytes: int) -> torch.Tensor:
-        key = (device.type, device.index)
+        key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
         b = self.buf.get(key)
         if b is None or b.numel() < nbytes:
             b = torch.empty(int(nbytes), dtype=torch.uint8, device=device)

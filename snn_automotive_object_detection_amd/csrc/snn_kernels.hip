@@ -586,7 +586,9 @@ __global__ __launch_bounds__(512) void k_spike_gemm(const GemmArgs args) {
 // with fp32 accumulation inside v_mfma_f32_32x32x16_bf16.  Measured against fp64 the result is as accurate
 // as the fp32 MFMA chain (tools/bf16x3_numerics.hip: rms error 4.1e-8 vs 4.2e-8 at K=2304).
 //
-// cur[M][ldo] = A_bits[M][K] x W[K][N];   work-group = 8 waves = 256 rows x 128 columns, wave = 64 x 64.
+// cur[M][ldo] = A_bits[M][K] x W[K][N];   work-group = 8 waves = 256 rows x 128 columns, wave = 64 x 64
+// = 4 x 4 tiles of v_mfma_f32_16x16x32_bf16 (one 32-deep chunk = one k-step; in an LDS-fed loop with this
+// kernel's traffic the 16x16x32 shape sustains 2.47 PF against 1.90 PF for 32x32x16: tools/mfma_probe4.hip).
 // Per 32-deep chunk: B = 3 planes x 128 x 32 bf16 (24 KB) copied global->LDS, A = 256 spike words expanded
 // to bf16 in LDS (two 16-bit halves per row, one per thread); both double-buffered, one barrier per chunk.
 // LDS rows are 64 B (no padding) with an XOR swizzle of the 16-B units: conflict-free ds_read_b128 fragment
@@ -610,9 +612,10 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst_uniform) 
 #define G3_A_BYTES (G3_BM * G3_ROWB)                // 16384
 #define G3_B_BYTES (3 * G3_BN * G3_ROWB)            // 24576
 #define G3_LDS (2 * (G3_A_BYTES + G3_B_BYTES))      // 81920: two work-groups per CU
-// unit u of row r lives at physical unit u ^ ((r >> 2) & 3): the 16 lanes of a ds_read_b128 group (rows that
-// differ in r & 3 or in (r >> 2) & 3) then hit 16 distinct 16-B slots of the 256-B bank row - conflict-free
-#define G3_SWZ(r) (((r) >> 2) & 3)
+// unit u (= k-group 8u..8u+7) of row r lives at physical unit u ^ swz(r), swz = [0,3,2,1][(r >> 2) & 3].  A 16x16x32
+// fragment read has lane l on row l&15, unit l>>4; the four 16-lane groups of a ds_read_b128
+// ({0-3,12-15,20-27}, {4-11,16-19,28-31}, +32) then each hit 16 distinct 16-B slots of the 256-B bank row.
+#define G3_SWZ(r) ((0 - ((r) >> 2)) & 3)
 
 struct Gemm3Args {
     const uint32_t* A;           // fc: [M][Kw] spike words;  conv: encoder planes [T][P][Cw]
@@ -724,34 +727,35 @@ __global__ __launch_bounds__(512, FUSE ? 2 : 4) void k_gemm_bf16x3(const Gemm3Ar
         }
     };
 
-    f32x16 acc[2][2];
+    // 16x16 tiles: lane holds column lane&15, rows (lane>>4)*4 + reg of each tile
+    const int lr = lane & 15, lg = lane >> 4;
+    f32x4 acc[4][4];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
+        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
-    // fragment of k16-step s = logical unit 2s + lh; (row >> 2) & 3 == (li >> 2) & 3 for every tile row of this lane
-    const int u_rd = (lh ^ G3_SWZ(li)) << 4;                   // step 0; step 1 = u_rd ^ 32
-    const int a_rd = (wm * 64 + li) * G3_ROWB;                 // + mt*32*ROWB
-    const int b_rd = (wn * 64 + li) * G3_ROWB;                 // + pl*BN*ROWB + nt*32*ROWB
+    // fragment read: row (tile*16 + lr), logical unit lg (k = 8*lg .. 8*lg+7); swz depends on lr only
+    const int u_rd = (lg ^ G3_SWZ(lr)) << 4;
+    const int a_rd = (wm * 64 + lr) * G3_ROWB + u_rd;          // + mt*16*ROWB
+    const int b_rd = (wn * 64 + lr) * G3_ROWB + u_rd;          // + pl*BN*ROWB + nt*16*ROWB
 
-    // LIF state of the fused variant (registers, whole T loop)
-    float v[FUSE ? 2 : 1][FUSE ? 2 : 1][FUSE ? 16 : 1], ci[FUSE ? 2 : 1][FUSE ? 2 : 1][FUSE ? 16 : 1];
-    uint32_t valid_bits[2] = {0u, 0u};
+    // LIF state of the fused variant (registers, whole T loop): 64 + 64 per lane
+    f32x4 v[FUSE ? 4 : 1][FUSE ? 4 : 1], ci[FUSE ? 4 : 1][FUSE ? 4 : 1];
+    uint32_t valid_bits = 0;                            // bit mt*4 + reg: that accumulator row of this lane is < M
     if (FUSE) {
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+            for (int nt = 0; nt < 4; ++nt) {
+                v[mt][nt] = f32x4{args.p.v_leak, args.p.v_leak, args.p.v_leak, args.p.v_leak};
+                ci[mt][nt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            }
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { v[mt][nt][r] = args.p.v_leak; ci[mt][nt][r] = 0.0f; }
+        for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                valid_bits[mt] |= (uint32_t)(m0 + wm * 64 + mt * 32 + acc_row(r, lh) < M) << r;
+            for (int r = 0; r < 4; ++r)
+                valid_bits |= (uint32_t)(m0 + wm * 64 + mt * 16 + lg * 4 + r < M) << (mt * 4 + r);
     }
     const int n_steps = FUSE ? args.T : 1;
 
@@ -798,39 +802,25 @@ __global__ __launch_bounds__(512, FUSE ? 2 : 4) void k_gemm_bf16x3(const Gemm3Ar
             for (int j = 0; j < SC; ++j) {
                 const unsigned char* Ab = smem + A_OFF + (buf * SC + j) * G3_A_BYTES + a_rd;
                 const unsigned char* Bb = smem + B_OFF + (buf * SC + j) * G3_B_BYTES + b_rd;
-                // four groups g = (k16-step s, N-tile nt) of 6 MFMAs; the three B planes of group g+1 (and the A
-                // fragments of step 1) are read from LDS while group g multiplies
-                bf16x8 a[2], bq[2][3];
-                auto ld_a = [&](int s_) {
+                // one k-step of 32: 4 A fragments (kept), then per N-tile 3 weight planes x 4 M-tiles = 12 MFMAs;
+                // the planes of N-tile nt+1 are read from LDS while N-tile nt multiplies
+                bf16x8 a[4];
 #pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) a[mt] = *reinterpret_cast<const bf16x8*>(Ab + mt * 32 * G3_ROWB + (u_rd ^ (32 * s_)));
-                };
-                auto ld_b = [&](bf16x8 (&dst)[3], int s_, int nt_) {
+                for (int mt = 0; mt < 4; ++mt) a[mt] = *reinterpret_cast<const bf16x8*>(Ab + mt * 16 * G3_ROWB);
+                auto nt_step = [&](int nt_) {
+                    bf16x8 b[3];
 #pragma unroll
                     for (int pl = 0; pl < 3; ++pl)
-                        dst[pl] = *reinterpret_cast<const bf16x8*>(Bb + pl * (G3_BN * G3_ROWB) + nt_ * 32 * G3_ROWB + (u_rd ^ (32 * s_)));
-                };
-                auto mm = [&](const bf16x8 (&b)[3], int nt_) {
+                        b[pl] = *reinterpret_cast<const bf16x8*>(Bb + pl * (G3_BN * G3_ROWB) + nt_ * 16 * G3_ROWB);
 #pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) {     // small terms first: lo, mid, hi
-                        acc[mt][nt_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[2], acc[mt][nt_], 0, 0, 0);
-                        acc[mt][nt_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[1], acc[mt][nt_], 0, 0, 0);
-                        acc[mt][nt_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[0], acc[mt][nt_], 0, 0, 0);
-                    }
+                    for (int pl = 2; pl >= 0; --pl)          // small terms first: lo, mid, hi (per accumulator)
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt)
+                            acc[mt][nt_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b[pl], acc[mt][nt_], 0, 0, 0);
                 };
-                ld_a(0); ld_b(bq[0], 0, 0);
-                ld_b(bq[1], 0, 1);
-                __builtin_amdgcn_sched_barrier(0);
-                mm(bq[0], 0);
-                __builtin_amdgcn_sched_barrier(0);
-                ld_b(bq[0], 1, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                mm(bq[1], 1);
-                __builtin_amdgcn_sched_barrier(0);
-                ld_a(1); ld_b(bq[1], 1, 1);
-                __builtin_amdgcn_sched_barrier(0);
-                mm(bq[0], 0);
-                __builtin_amdgcn_sched_barrier(0);
+                nt_step(0);
+                nt_step(1);
+                nt_step(2);
 #ifndef SNN_EXP_NO_STORE_A
                 if (j == SC - 1) {
                     // the spike words were issued BEFORE this super-chunk's 3*SC LDS-DMA pieces: wait until at
@@ -848,7 +838,7 @@ __global__ __launch_bounds__(512, FUSE ? 2 : 4) void k_gemm_bf16x3(const Gemm3Ar
                     }
                 }
 #endif
-                mm(bq[1], 1);
+                nt_step(3);
             }
 #ifndef SNN_EXP_NO_BARRIER
             // weight planes landed (vmcnt), expanded spike image written (lgkmcnt), everyone done reading `buf`
@@ -858,41 +848,55 @@ __global__ __launch_bounds__(512, FUSE ? 2 : 4) void k_gemm_bf16x3(const Gemm3Ar
             buf ^= 1;
         }
         if (FUSE) {
-            // ---- LIF epilogue in registers; spikes leave as ballots (2 position words per register) ----
+            // ---- LIF epilogue in registers.  A ballot over accumulator register (mt, nt, reg) holds, for each of
+            // the 4 row groups rg, 16 channel bits of position mt*16 + rg*4 + reg; N-tiles (0,1) and (2,3) pair up
+            // into the two 32-channel words of that position, which lane = position finally stores (8 bytes) ----
+            uint32_t my0 = 0, my1 = 0;
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    uint32_t myword = 0;
+                for (int r = 0; r < 4; ++r) {
+                    unsigned long long bal[4];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        bool z = lif_step(acc[mt][nt][r], v[mt][nt][r], ci[mt][nt][r], args.p);
-                        z = z && ((valid_bits[mt] >> r) & 1u);
+                    for (int nt = 0; nt < 4; ++nt) {
+                        float vv = v[mt][nt][r], cc = ci[mt][nt][r];
+                        bool z = lif_step(acc[mt][nt][r], vv, cc, args.p);
+                        v[mt][nt][r] = vv; ci[mt][nt][r] = cc;
                         acc[mt][nt][r] = 0.0f;
-                        const unsigned long long m = __ballot(z);
-                        myword = (lane == 2 * r) ? (uint32_t)m : myword;
-                        myword = (lane == 2 * r + 1) ? (uint32_t)(m >> 32) : myword;
+                        z = z && ((valid_bits >> (mt * 4 + r)) & 1u);
+                        bal[nt] = __ballot(z);
                     }
-                    if (lane < 32) {      // lane -> (r = lane>>1, half = lane&1): one 32-channel word of one position
-                        const int row = m0 + wm * 64 + mt * 32 + acc_row(lane >> 1, lane & 1);
-                        const int ntile = (nb * G3_BN + wn * 64 + nt * 32) >> 5;
-                        if (row < M && ntile * 32 < Np)
-                            args.spk[(size_t)t * args.spk_stride + (size_t)row * (Np >> 5) + ntile] = myword;
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) {
+                        const uint32_t w0 = (uint32_t)((bal[0] >> (16 * rg)) & 0xffffull) | ((uint32_t)((bal[1] >> (16 * rg)) & 0xffffull) << 16);
+                        const uint32_t w1 = (uint32_t)((bal[2] >> (16 * rg)) & 0xffffull) | ((uint32_t)((bal[3] >> (16 * rg)) & 0xffffull) << 16);
+                        const bool mine = lane == mt * 16 + rg * 4 + r;
+                        my0 = mine ? w0 : my0;
+                        my1 = mine ? w1 : my1;
                     }
                 }
+            {
+                const int row = m0 + wm * 64 + lane;                  // lane = position within the wave's 64 rows
+                const int word0 = (nb * G3_BN + wn * 64) >> 5;
+                uint32_t* dst = args.spk + (size_t)t * args.spk_stride + (size_t)row * (Np >> 5) + word0;
+                if (row < M) {
+                    if (word0 * 32 < Np) dst[0] = my0;
+                    if ((word0 + 1) * 32 < Np) dst[1] = my1;
+                }
+            }
         }
     }
     if (FUSE) return;
-    // ---- store currents ----
+    // ---- store currents: per instruction 4 rows x 16 columns (64-B row segments) ----
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            const int col = nb * G3_BN + wn * 64 + nt * 32 + li;
+        for (int nt = 0; nt < 4; ++nt) {
+            const int col = nb * G3_BN + wn * 64 + nt * 16 + lr;
             if (col >= Np) continue;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + mt * 32 + acc_row(r, lh);
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * 64 + mt * 16 + lg * 4 + r;
                 if (m < M) args.out[(size_t)m * args.ldo + col] = acc[mt][nt][r];
             }
         }

@@ -742,7 +742,6 @@ __global__ __launch_bounds__(512, FUSE ? 2 : 4) void k_gemm_bf16x3(const Gemm3Ar
 
     // LIF state of the fused variant (registers, whole T loop): 64 + 64 per lane
     f32x4 v[FUSE ? 4 : 1][FUSE ? 4 : 1], ci[FUSE ? 4 : 1][FUSE ? 4 : 1];
-    uint32_t valid_bits = 0;                            // bit mt*4 + reg: that accumulator row of this lane is < M
     if (FUSE) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
@@ -751,11 +750,6 @@ __global__ __launch_bounds__(512, FUSE ? 2 : 4) void k_gemm_bf16x3(const Gemm3Ar
                 v[mt][nt] = f32x4{args.p.v_leak, args.p.v_leak, args.p.v_leak, args.p.v_leak};
                 ci[mt][nt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
             }
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                valid_bits |= (uint32_t)(m0 + wm * 64 + mt * 16 + lg * 4 + r < M) << (mt * 4 + r);
     }
     const int n_steps = FUSE ? args.T : 1;
 
@@ -855,25 +849,22 @@ __global__ __launch_bounds__(512, FUSE ? 2 : 4) void k_gemm_bf16x3(const Gemm3Ar
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    unsigned long long bal[4];
+                for (int np = 0; np < 2; ++np) {                       // N-tile pair -> word np of the position
+                    unsigned long long bal[2][4];                      // [nt & 1][reg]
 #pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) {
-                        float vv = v[mt][nt][r], cc = ci[mt][nt][r];
-                        bool z = lif_step(acc[mt][nt][r], vv, cc, args.p);
-                        v[mt][nt][r] = vv; ci[mt][nt][r] = cc;
-                        acc[mt][nt][r] = 0.0f;
-                        z = z && ((valid_bits >> (mt * 4 + r)) & 1u);
-                        bal[nt] = __ballot(z);
+                    for (int q = 0; q < 2; ++q) {
+                        lif_step4(acc[mt][2 * np + q], v[mt][2 * np + q], ci[mt][2 * np + q], args.p, bal[q]);
+                        acc[mt][2 * np + q] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
                     }
 #pragma unroll
-                    for (int rg = 0; rg < 4; ++rg) {
-                        const uint32_t w0 = (uint32_t)((bal[0] >> (16 * rg)) & 0xffffull) | ((uint32_t)((bal[1] >> (16 * rg)) & 0xffffull) << 16);
-                        const uint32_t w1 = (uint32_t)((bal[2] >> (16 * rg)) & 0xffffull) | ((uint32_t)((bal[3] >> (16 * rg)) & 0xffffull) << 16);
-                        const bool mine = lane == mt * 16 + rg * 4 + r;
-                        my0 = mine ? w0 : my0;
-                        my1 = mine ? w1 : my1;
-                    }
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int rg = 0; rg < 4; ++rg) {
+                            const uint32_t w = (uint32_t)((bal[0][r] >> (16 * rg)) & 0xffffull) | ((uint32_t)((bal[1][r] >> (16 * rg)) & 0xffffull) << 16);
+                            // lane (mt*16 + rg*4 + r) keeps the two words of its position (rows >= M are never stored)
+                            if (np == 0) asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(my0) : "s"(w), "n"(mt * 16 + rg * 4 + r));
+                            else         asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(my1) : "s"(w), "n"(mt * 16 + rg * 4 + r));
+                        }
                 }
             {
                 const int row = m0 + wm * 64 + lane;                  // lane = position within the wave's 64 rows

@@ -599,11 +599,26 @@ __global__ __launch_bounds__(512) void k_spike_gemm(const GemmArgs args) {
 // ------------------------------------------------------------------------------------------------
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
-// LDS-DMA: 16 B per lane straight from global memory into LDS at (wave-uniform dst) + 16*lane; no VGPR destination,
-// completion is counted on vmcnt (the __syncthreads() that ends a chunk waits for it)
-__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst_uniform) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_dst_uniform, 16, 0, 0);
+// LDS-DMA: 16 B per lane straight from global memory (wave-uniform 64-bit base + the lane's 32-bit byte offset)
+// into LDS at (wave-uniform byte address in M0) + 16*lane; no VGPR destination, completion is counted on vmcnt.
+// Issued as inline asm on purpose: once hipcc sees an LDS-DMA in flight it degrades every LDS wait of the loop to
+// s_waitcnt lgkmcnt(0) and puts vmcnt(0) in front of every ds_write (possible alias); hidden from it, the fragment
+// reads keep their exact counted waits.  The kernel waits for the DMA by hand (vmcnt(0) before the chunk barrier).
+// a wave-uniform pointer as an SGPR pair (inline asm "s" operands are not legalised by hipcc)
+__device__ __forceinline__ const void* sgpr_ptr(const void* p) {
+    const unsigned long long x = (unsigned long long)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)x), hi = __builtin_amdgcn_readfirstlane((uint32_t)(x >> 32));
+    return (const void*)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ void glds16(const void* sbase_uniform, uint32_t voff, uint32_t lds_addr_uniform) {
+    const unsigned char* p = reinterpret_cast<const unsigned char*>(sbase_uniform) + voff;
+#ifdef SNN_EXP_BUILTIN_GLDS
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
+                                     (__attribute__((address_space(3))) void*)(uintptr_t)lds_addr_uniform, 16, 0, 0);
+    return;
+#endif
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                 :: "v"(p), "s"(lds_addr_uniform) : "memory", "m0");
 }
 
 #define G3_BM 256
@@ -640,29 +655,34 @@ __device__ __forceinline__ uint32_t bf16_pair(uint32_t w, int j) {      // bits 
 
 // FUSE (conv only): M = positions; per time step the 9*Cw chunks are accumulated, then the LIF update runs
 // on the accumulators in registers (64 acc + 64 v + 64 i per lane) and only spike bits are written.
-// SC = 32-deep chunks per barrier: 1 (80 KB of LDS, two work-groups per CU) or 2 (160 KB, for the fused variant
-// that owns its CU anyway: half as many barriers).
-template <bool CONV, bool FUSE, int SC>
+// NB = LDS ring slots of one 32-deep chunk (40 KB each).  NB = 2 (80 KB, two work-groups per CU): chunk c+1 is
+// staged while chunk c multiplies.  NB >= 3 (the fused variant owns its CU anyway): staging runs two chunks ahead,
+// so the slot of chunk c+1 is already complete during chunk c and the first fragments of chunk c+1 are read from
+// LDS BEFORE the barrier that ends chunk c - the matrix pipe does not drain at the barrier.
+// PD = fragment prefetch distance inside a chunk, in groups of 4 MFMAs (one weight fragment per group).
+template <bool CONV, bool FUSE, int NB>
 __global__ __launch_bounds__(512, FUSE ? 2 : 4) void k_gemm_bf16x3(const Gemm3Args args) {
     static_assert(CONV || !FUSE, "LIF fusion is for the conv rows");
-    constexpr int A_OFF = 0, B_OFF = 2 * SC * G3_A_BYTES;       // LDS: [2 buffers][SC sub-chunks] of A, then of B
+    constexpr int SLOT = G3_A_BYTES + G3_B_BYTES;               // A image, then the three B planes
+    constexpr bool XPF = NB >= 3;                               // fragment prefetch across the chunk barrier
+    constexpr int PD = 3, RING = PD + 1;                        // 12 groups per chunk: RING must divide 12
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 31, lh = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
     const int nb = blockIdx.x % args.n_blocks;
     const int mb = blockIdx.x / args.n_blocks;
     const int m0 = mb * G3_BM;
     const int Kc = args.Kc, Np = args.Np, M = args.M;
 
-    // ---- A staging role: thread -> (row, 16-bit half) ----
+    // ---- A staging role: thread -> (row, 16-bit half).  A spike word is addressed as (wave-uniform 64-bit base in
+    // SGPRs) + (32-bit byte offset of the lane's row): no per-chunk 64-bit vector arithmetic ----
     const int xrow = tid >> 1, xhalf = tid & 1;
     const int xm = m0 + xrow;
-    const uint32_t* a_src = args.A;                 // fc: row base; conv: plane base of the row's time step
-    long long a_center = 0;                         // conv: word index of the centre tap, channel word 0
-    int a_W = 0;
+    uint32_t a_off = 0;                             // bytes: fc row / conv centre tap, channel word 0
+    int a_pitch = 0;                                // conv: bytes per image row of the lane's pyramid level
     uint32_t a_valid = 0;                           // conv: 9-bit tap validity
     if (CONV) {
         if (xm < M) {
@@ -673,9 +693,8 @@ __global__ __launch_bounds__(512, FUSE ? 2 : 4) void k_gemm_bf16x3(const Gemm3Ar
             const int local = p - args.lv[l].pos_base;
             const int rem = local % (H * W);
             const int y = rem / W, x = rem % W;
-            a_src = args.A + (size_t)t * args.enc_stride;
-            a_center = (long long)p * args.Cw;
-            a_W = W;
+            a_off = (uint32_t)(((size_t)t * args.enc_stride + (size_t)p * args.Cw) * 4);
+            a_pitch = W * args.Cw * 4;
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
@@ -683,33 +702,42 @@ __global__ __launch_bounds__(512, FUSE ? 2 : 4) void k_gemm_bf16x3(const Gemm3Ar
             }
         }
     } else {
-        a_src = args.A + (size_t)min(xm, M - 1) * Kc;
+        a_off = (uint32_t)((size_t)min(xm, M - 1) * Kc * 4);
     }
     // Spike-word loads are issued as inline asm: hipcc must not see them, or it drains the LDS-DMA queue
-    // (vmcnt(0)) at their first use while the next chunk's weight planes are still in flight.  Their completion
-    // is counted by hand (vmcnt is in issue order): see the two s_waitcnt in the chunk loop.
-    auto fetch_a = [&](int t_rel, int kc, uint32_t& w) {    // t_rel: time step of the fused T loop (0 otherwise)
-        const uint32_t* ptr;
-        bool ok = true;
-        if (CONV) {
-            const int tap = kc / args.Cw, cc = kc % args.Cw;
-            ok = (a_valid >> tap) & 1u;
-            const uint32_t* plane = FUSE ? a_src + (size_t)t_rel * args.enc_stride : a_src;
-            ptr = plane + a_center + (long long)((tap / 3 - 1) * a_W + (tap % 3 - 1)) * args.Cw + cc;
-        } else {
-            ptr = a_src + kc;
-        }
+    // (vmcnt(0)) at their first use while weight planes are still in flight.  A word is consumed only after the
+    // hand-written s_waitcnt vmcnt(0) that ends the chunk it was issued in.
+    // The fetch stream walks the chunk sequence (t, tap, channel word) with scalar counters.
+    // (s_nop 4: an SGPR written by SALU / v_readfirstlane needs 5 wait states before a VMEM instruction reads it as
+    // its base address, and hipcc's hazard recogniser does not look into inline asm.)
+    const int n_steps = FUSE ? args.T : 1;
+    int f_t = 0, f_kc = 0, f_tap = 0, f_cc = 0;
+    auto fetch_next = [&](uint32_t& w) {
+        const bool live = f_t < n_steps;            // past the end: harmless re-read of chunk (0, 0)
+        const int t_ = live ? f_t : 0, kc_ = live ? f_kc : 0, tap_ = live ? f_tap : 0, cc_ = live ? f_cc : 0;
         w = 0u;
-        if (ok) asm volatile("global_load_dword %0, %1, off" : "+v"(w) : "v"(ptr) : "memory");
+        if (CONV) {
+            const int dy = tap_ / 3 - 1, dx = tap_ - 3 * (tap_ / 3) - 1;
+            const void* sbase = sgpr_ptr(args.A + ((FUSE ? (long long)t_ * (long long)args.enc_stride : 0ll) + dx * args.Cw + cc_));
+            const uint32_t voff = a_off + (uint32_t)(dy * a_pitch);
+            if ((a_valid >> tap_) & 1u)
+                asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "+v"(w) : "v"(voff), "s"(sbase) : "memory");
+        } else {
+            const void* sbase = sgpr_ptr(args.A + kc_);
+            asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "+v"(w) : "v"(a_off), "s"(sbase) : "memory");
+        }
+        if (live) {
+            if (CONV && ++f_cc == args.Cw) { f_cc = 0; ++f_tap; }
+            if (++f_kc == Kc) { f_kc = 0; f_tap = 0; f_cc = 0; ++f_t; }
+        }
     };
-    auto store_a = [&](uint32_t w, int slot) {
-        const uint32_t hbits = (w >> (16 * xhalf)) & 0xffffu;
-        uint4 lo4, hi4;
-        lo4.x = bf16_pair(hbits, 0); lo4.y = bf16_pair(hbits, 1); lo4.z = bf16_pair(hbits, 2); lo4.w = bf16_pair(hbits, 3);
-        hi4.x = bf16_pair(hbits, 4); hi4.y = bf16_pair(hbits, 5); hi4.z = bf16_pair(hbits, 6); hi4.w = bf16_pair(hbits, 7);
-        unsigned char* d = smem + A_OFF + slot * G3_A_BYTES + xrow * G3_ROWB;
-        *reinterpret_cast<uint4*>(d + (((2 * xhalf) ^ G3_SWZ(xrow)) << 4)) = lo4;
-        *reinterpret_cast<uint4*>(d + (((2 * xhalf + 1) ^ G3_SWZ(xrow)) << 4)) = hi4;
+    unsigned char* const a_wr = smem + xrow * G3_ROWB;
+    const int a_wr_lo = ((2 * xhalf) ^ G3_SWZ(xrow)) << 4;     // unit 2*xhalf; unit 2*xhalf+1 = the same ^ 16 bytes
+    auto store_a_half = [&](uint32_t w, int slot, int hi) {     // 8 of the thread's 16 spike bits -> 8 bf16 (16 B)
+        const uint32_t hbits = (w >> (16 * xhalf + 8 * hi)) & 0xffu;
+        uint4 q;
+        q.x = bf16_pair(hbits, 0); q.y = bf16_pair(hbits, 1); q.z = bf16_pair(hbits, 2); q.w = bf16_pair(hbits, 3);
+        *reinterpret_cast<uint4*>(a_wr + slot * SLOT + (hi ? (a_wr_lo ^ 16) : a_wr_lo)) = q;
     };
 
     // ---- B staging: LDS-DMA.  Wave w copies rows [16w, 16w+16) of each of the 3 planes (1 KiB per instruction);
@@ -717,14 +745,23 @@ __global__ __launch_bounds__(512, FUSE ? 2 : 4) void k_gemm_bf16x3(const Gemm3Ar
     // swizzle is applied on the SOURCE address, the LDS image stays lane-linear ----
     const int brow = wave * 16 + (lane >> 2);
     const int bcol = min(nb * G3_BN + brow, Np - 1);           // columns past Np: any valid row (never stored)
-    const uint32_t b_off = (uint32_t)(bcol * 32 + (((lane & 3) ^ G3_SWZ(brow)) << 3));     // elements
-    auto stage_b = [&](int kc, int slot) {
-        unsigned char* d = smem + B_OFF + slot * G3_B_BYTES + wave * 1024;                  // wave-uniform
+    const uint32_t b_off = (uint32_t)(bcol * 64 + (((lane & 3) ^ G3_SWZ(brow)) << 4));     // bytes within a chunk plane
+    const unsigned long long b_chunk = (unsigned long long)Np * 64, b_plane = args.plane_elems * 2;   // bytes
+    unsigned long long s_ptr = (unsigned long long)args.wpk;   // weight stream: plane 0 of the next chunk (scalar)
+    int s_kc = 0;
+    auto stage_plane = [&](int slot, int pl) {      // one 1-KiB LDS-DMA piece per wave
+        const uint32_t d = smem_base + slot * SLOT + G3_A_BYTES + wave * 1024;              // wave-uniform LDS address
+        glds16(sgpr_ptr(reinterpret_cast<const void*>(s_ptr + pl * b_plane)), b_off,
+               __builtin_amdgcn_readfirstlane(d + pl * (G3_BN * G3_ROWB)));
+    };
+    auto stage_advance = [&]() {
+        s_ptr += b_chunk;
+        if (++s_kc == Kc) { s_kc = 0; s_ptr = (unsigned long long)args.wpk; }
+    };
+    auto stage_next = [&](int slot) {
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
-            const uint16_t* base = args.wpk + pl * args.plane_elems + (size_t)kc * Np * 32; // wave-uniform
-            glds16(base + b_off, d + pl * (G3_BN * G3_ROWB));
-        }
+        for (int pl = 0; pl < 3; ++pl) stage_plane(slot, pl);
+        stage_advance();
     };
 
     // 16x16 tiles: lane holds column lane&15, rows (lane>>4)*4 + reg of each tile
@@ -737,143 +774,166 @@ __global__ __launch_bounds__(512, FUSE ? 2 : 4) void k_gemm_bf16x3(const Gemm3Ar
 
     // fragment read: row (tile*16 + lr), logical unit lg (k = 8*lg .. 8*lg+7); swz depends on lr only
     const int u_rd = (lg ^ G3_SWZ(lr)) << 4;
-    const int a_rd = (wm * 64 + lr) * G3_ROWB + u_rd;          // + mt*16*ROWB
-    const int b_rd = (wn * 64 + lr) * G3_ROWB + u_rd;          // + pl*BN*ROWB + nt*16*ROWB
+    const unsigned char* const a_rd = smem + (wm * 64 + lr) * G3_ROWB + u_rd;                // + slot, mt*16*ROWB
+    const unsigned char* const b_rd = smem + G3_A_BYTES + (wn * 64 + lr) * G3_ROWB + u_rd;   // + slot, pl, nt
+    auto rd_a = [&](int slot, int mt) { return *reinterpret_cast<const bf16x8*>(a_rd + slot * SLOT + mt * 16 * G3_ROWB); };
+    // group g of a chunk = (N-tile g/3, plane 2 - g%3): per accumulator the small terms first (lo, mid, hi)
+    auto rd_b = [&](int slot, int g) {
+        return *reinterpret_cast<const bf16x8*>(b_rd + slot * SLOT + (2 - g % 3) * (G3_BN * G3_ROWB) + (g / 3) * 16 * G3_ROWB);
+    };
 
-    // LIF state of the fused variant (registers, whole T loop): 64 + 64 per lane
-    f32x4 v[FUSE ? 4 : 1][FUSE ? 4 : 1], ci[FUSE ? 4 : 1][FUSE ? 4 : 1];
+    // LIF state of the fused variant, whole T loop: v (64 registers) and the synaptic current i (48 registers;
+    // the 16 values of M-tile 3 live in the LDS left over beside the ring, private to the thread, touched once per
+    // time step - they are what keeps the main loop free of scratch spills)
+    f32x4 v[FUSE ? 4 : 1][FUSE ? 4 : 1], ci[FUSE ? 3 : 1][FUSE ? 4 : 1];
+    f32x4* const ci_lds = reinterpret_cast<f32x4*>(smem + NB * SLOT) + tid;          // [nt][512 threads]
     if (FUSE) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 v[mt][nt] = f32x4{args.p.v_leak, args.p.v_leak, args.p.v_leak, args.p.v_leak};
-                ci[mt][nt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                if (mt < 3) ci[mt][nt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                else ci_lds[nt * 512] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
             }
     }
-    const int n_steps = FUSE ? args.T : 1;
+    const int n_total = n_steps * Kc;
 
-    // Software pipeline over the chunk sequence (t, kc): spike words are fetched from global two chunks ahead,
-    // expanded into the other LDS buffer one chunk ahead (VALU + ds_write in the shadow of the MFMAs); weight
-    // planes arrive one chunk ahead by LDS-DMA.  One barrier per chunk.
-    int f_t = 0, f_kc = 0;                              // next chunk of the fetch stream (wave-uniform)
-    auto fetch_next = [&](uint32_t& w) {                // always issues exactly one VMEM op per active lane set
-        if (f_t < n_steps) {
-            fetch_a(f_t, f_kc, w);
-            if (++f_kc == Kc) { f_kc = 0; ++f_t; }
-        } else {
-            fetch_a(0, 0, w);                           // past the end: harmless re-read keeps the vmcnt count uniform
+    // Software pipeline over the chunk sequence c = (t, kc).  During chunk c:
+    //   the spike word of chunk c+NB is fetched from global memory (register),
+    //   the weight planes of chunk c+NB-1 are copied into ring slot (c-1) mod NB by LDS-DMA,
+    //   the spike word of chunk c+NB-1 (fetched during chunk c-1) is expanded into that slot (VALU + ds_write
+    //   in the shadow of the MFMAs),
+    //   the fragments of chunk c are read PD groups ahead of their MFMAs - with NB >= 3 also the first ones of
+    //   chunk c+1, whose slot has been complete since the previous barrier.
+    // One barrier per chunk; s_sched_barrier pins one fragment read + 4 MFMAs per group.
+    uint32_t w_hold, w_new;
+    {
+        uint32_t w0[NB - 1];
+#pragma unroll
+        for (int j = 0; j < NB - 1; ++j) {              // chunks 0 .. NB-2 -> slots 0 .. NB-2
+            fetch_next(w0[j]);
+            stage_next(j);
         }
-    };
-    uint32_t a_nxt[SC];
+        fetch_next(w_hold);                             // chunk NB-1
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int j = 0; j < SC; ++j) {                      // super-chunk 0 -> buffer 0
-        fetch_next(a_nxt[j]);
-        stage_b(j, j);
+        for (int j = 0; j < NB - 1; ++j) {
+            asm volatile("" : "+v"(w0[j]));             // the loaded value is only defined from here on
+            store_a_half(w0[j], j, 0);
+            store_a_half(w0[j], j, 1);
+        }
+        asm volatile("" : "+v"(w_hold));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    bf16x8 af[2][4], bq[RING];
 #pragma unroll
-    for (int j = 0; j < SC; ++j) {
-        asm volatile("" : "+v"(a_nxt[j]));              // the loaded value is only defined from here on
-        store_a(a_nxt[j], j);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    int buf = 0;
+    for (int mt = 0; mt < 4; ++mt) af[0][mt] = rd_a(0, mt);
+#pragma unroll
+    for (int g = 0; g < PD; ++g) bq[g] = rd_b(0, g);
 
-    for (int t = 0; t < n_steps; ++t) {
-        for (int kc = 0; kc < Kc; kc += SC) {
-            const bool last = kc + SC == Kc;
-            const bool more = !last || t + 1 < n_steps;
-            // VMEM issue order per super-chunk: SC spike-word loads, then 3*SC LDS-DMA pieces
+    int sl = 0;                                         // ring slot of the current chunk
+    int kc = 0, t = 0;
+    for (int c0 = 0; c0 < n_total; c0 += 2) {
 #pragma unroll
-            for (int j = 0; j < SC; ++j) fetch_next(a_nxt[j]);       // next super-chunk's spike words
-#ifndef SNN_EXP_NO_GLDS
+        for (int u = 0; u < 2; ++u) {
+            if (c0 + u >= n_total) break;
+            const int sl1 = sl + 1 == NB ? 0 : sl + 1;  // slot of chunk c+1
+            const int slw = sl == 0 ? NB - 1 : sl - 1;  // slot being filled (chunk c+NB-1)
 #pragma unroll
-            for (int j = 0; j < SC; ++j) stage_b((last ? 0 : kc + SC) + j, (buf ^ 1) * SC + j);   // other buffer
-#endif
-#pragma unroll
-            for (int j = 0; j < SC; ++j) {
-                const unsigned char* Ab = smem + A_OFF + (buf * SC + j) * G3_A_BYTES + a_rd;
-                const unsigned char* Bb = smem + B_OFF + (buf * SC + j) * G3_B_BYTES + b_rd;
-                // one k-step of 32: 4 A fragments (kept), then per N-tile 3 weight planes x 4 M-tiles = 12 MFMAs;
-                // the planes of N-tile nt+1 are read from LDS while N-tile nt multiplies
-                bf16x8 a[4];
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) a[mt] = *reinterpret_cast<const bf16x8*>(Ab + mt * 16 * G3_ROWB);
-                auto nt_step = [&](int nt_) {
-                    bf16x8 b[3];
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl)
-                        b[pl] = *reinterpret_cast<const bf16x8*>(Bb + pl * (G3_BN * G3_ROWB) + nt_ * 16 * G3_ROWB);
-#pragma unroll
-                    for (int pl = 2; pl >= 0; --pl)          // small terms first: lo, mid, hi (per accumulator)
-#pragma unroll
-                        for (int mt = 0; mt < 4; ++mt)
-                            acc[mt][nt_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b[pl], acc[mt][nt_], 0, 0, 0);
-                };
-                nt_step(0);
-                nt_step(1);
-                nt_step(2);
+            for (int g = 0; g < 12; ++g) {
+                const int gp = g + PD;
+                if (gp < 12) bq[gp % RING] = rd_b(sl, gp);
+                else if (XPF) bq[gp % RING] = rd_b(sl1, gp - 12);
+                if (XPF && g >= 8) af[u ^ 1][g - 8] = rd_a(sl1, g - 8);
+                // Staging order: hipcc puts an s_waitcnt vmcnt(0) in front of every ds_write that follows an LDS-DMA
+                // (possible alias), so the spike image is expanded FIRST, while nothing is in flight, and the
+                // chunk's global traffic is issued after it - it then has 9 groups of MFMAs to land.
 #ifndef SNN_EXP_NO_STORE_A
-                if (j == SC - 1) {
-                    // the spike words were issued BEFORE this super-chunk's 3*SC LDS-DMA pieces: wait until at
-                    // most those pieces are outstanding, then expand into the other buffer
-#ifdef SNN_EXP_NO_GLDS
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#else
-                    if (SC == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                if (g == 0) store_a_half(w_hold, slw, 0);
+                if (g == 1) store_a_half(w_hold, slw, 1);
 #endif
-#pragma unroll
-                    for (int jj = 0; jj < SC; ++jj) {
-                        asm volatile("" : "+v"(a_nxt[jj]));
-                        store_a(a_nxt[jj], (buf ^ 1) * SC + jj);
-                    }
+#ifdef SNN_EXP_SPREAD
+                if (g == 2) fetch_next(w_new);
+                if (g == 3) stage_plane(slw, 0);
+                if (g == 5) stage_plane(slw, 1);
+                if (g == 7) { stage_plane(slw, 2); stage_advance(); }
+#else
+                if (g == 2) {
+                    fetch_next(w_new);
+#ifndef SNN_EXP_NO_GLDS
+                    stage_next(slw);
+#endif
                 }
 #endif
-                nt_step(3);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+                    acc[mt][g / 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u][mt], bq[g % RING], acc[mt][g / 3], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
 #ifndef SNN_EXP_NO_BARRIER
-            // weight planes landed (vmcnt), expanded spike image written (lgkmcnt), everyone done reading `buf`
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            // weight planes landed (vmcnt), expanded spike image written (lgkmcnt), everyone done reading slot `sl`.
+            // The builtin (not inline asm) so that hipcc's own wait-count bookkeeping knows the prefetched
+            // fragments have arrived.
+            // The empty asm statements are compiler fences: neither builtin orders memory accesses for hipcc.
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_waitcnt(0x0070);         // vmcnt(0) lgkmcnt(0)
             __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
 #endif
-            buf ^= 1;
-        }
-        if (FUSE) {
-            // ---- LIF epilogue in registers.  A ballot over accumulator register (mt, nt, reg) holds, for each of
-            // the 4 row groups rg, 16 channel bits of position mt*16 + rg*4 + reg; N-tiles (0,1) and (2,3) pair up
-            // into the two 32-channel words of that position, which lane = position finally stores (8 bytes) ----
-            uint32_t my0 = 0, my1 = 0;
+            asm volatile("" : "+v"(w_new));
+            w_hold = w_new;
+            if (!XPF) {                                 // two slots: the next chunk is readable only now
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+                for (int mt = 0; mt < 4; ++mt) af[u ^ 1][mt] = rd_a(sl1, mt);
 #pragma unroll
-                for (int np = 0; np < 2; ++np) {                       // N-tile pair -> word np of the position
-                    unsigned long long bal[2][4];                      // [nt & 1][reg]
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        lif_step4(acc[mt][2 * np + q], v[mt][2 * np + q], ci[mt][2 * np + q], args.p, bal[q]);
-                        acc[mt][2 * np + q] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-#pragma unroll
-                        for (int rg = 0; rg < 4; ++rg) {
-                            const uint32_t w = (uint32_t)((bal[0][r] >> (16 * rg)) & 0xffffull) | ((uint32_t)((bal[1][r] >> (16 * rg)) & 0xffffull) << 16);
-                            // lane (mt*16 + rg*4 + r) keeps the two words of its position (rows >= M are never stored)
-                            if (np == 0) asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(my0) : "s"(w), "n"(mt * 16 + rg * 4 + r));
-                            else         asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(my1) : "s"(w), "n"(mt * 16 + rg * 4 + r));
+                for (int g = 0; g < PD; ++g) bq[g] = rd_b(sl1, g);
+            }
+            sl = sl1;
+            const bool step_done = ++kc == Kc;
+            if (step_done) kc = 0;
+            if (FUSE && step_done) {
+                // ---- LIF epilogue in registers.  A ballot over accumulator register (mt, nt, reg) holds, for each of
+                // the 4 row groups rg, 16 channel bits of position mt*16 + rg*4 + reg; N-tiles (0,1) and (2,3) pair up
+                // into the two 32-channel words of that position, which lane = position finally stores (8 bytes) ----
+                uint32_t my0 = 0, my1 = 0;
+    #pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+    #pragma unroll
+                    for (int np = 0; np < 2; ++np) {                       // N-tile pair -> word np of the position
+                        unsigned long long bal[2][4];                      // [nt & 1][reg]
+    #pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            if (mt < 3) {
+                                lif_step4(acc[mt][2 * np + q], v[mt][2 * np + q], ci[mt][2 * np + q], args.p, bal[q]);
+                            } else {
+                                f32x4 i3 = ci_lds[(2 * np + q) * 512];
+                                lif_step4(acc[mt][2 * np + q], v[mt][2 * np + q], i3, args.p, bal[q]);
+                                ci_lds[(2 * np + q) * 512] = i3;
+                            }
+                            acc[mt][2 * np + q] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
                         }
+    #pragma unroll
+                        for (int r = 0; r < 4; ++r)
+    #pragma unroll
+                            for (int rg = 0; rg < 4; ++rg) {
+                                const uint32_t w = (uint32_t)((bal[0][r] >> (16 * rg)) & 0xffffull) | ((uint32_t)((bal[1][r] >> (16 * rg)) & 0xffffull) << 16);
+                                // lane (mt*16 + rg*4 + r) keeps the two words of its position (rows >= M are never stored)
+                                if (np == 0) asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(my0) : "s"(w), "n"(mt * 16 + rg * 4 + r));
+                                else         asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(my1) : "s"(w), "n"(mt * 16 + rg * 4 + r));
+                            }
+                    }
+                {
+                    const int row = m0 + wm * 64 + lane;                  // lane = position within the wave's 64 rows
+                    const int word0 = (nb * G3_BN + wn * 64) >> 5;
+                    uint32_t* dst = args.spk + (size_t)t * args.spk_stride + (size_t)row * (Np >> 5) + word0;
+                    if (row < M) {
+                        if (word0 * 32 < Np) dst[0] = my0;
+                        if ((word0 + 1) * 32 < Np) dst[1] = my1;
+                    }
                 }
-            {
-                const int row = m0 + wm * 64 + lane;                  // lane = position within the wave's 64 rows
-                const int word0 = (nb * G3_BN + wn * 64) >> 5;
-                uint32_t* dst = args.spk + (size_t)t * args.spk_stride + (size_t)row * (Np >> 5) + word0;
-                if (row < M) {
-                    if (word0 * 32 < Np) dst[0] = my0;
-                    if ((word0 + 1) * 32 < Np) dst[1] = my1;
-                }
+                ++t;
             }
         }
     }
@@ -1262,10 +1322,9 @@ int snn_pack_linear_weight_bf16x3(const float* w, int N, int K, uint16_t* packed
 
 static int launch_gemm3(bool conv, const Gemm3Args& a, hipStream_t s) {
     const bool fuse = conv && a.spk != nullptr;
-    const int sc = (fuse && a.Kc % 2 == 0) ? 2 : 1;              // the fused variant owns its CU: 160 KB of LDS
-    auto kern = fuse ? (sc == 2 ? k_gemm_bf16x3<true, true, 2> : k_gemm_bf16x3<true, true, 1>)
-                     : (conv ? k_gemm_bf16x3<true, false, 1> : k_gemm_bf16x3<false, false, 1>);
-    const int lds = sc * G3_LDS;
+    // the fused variant owns its CU (registers): 3 ring slots = 120 KB; the others run two work-groups per CU
+    auto kern = fuse ? k_gemm_bf16x3<true, true, 3> : (conv ? k_gemm_bf16x3<true, false, 2> : k_gemm_bf16x3<false, false, 2>);
+    const int lds = (fuse ? 3 : 2) * (G3_A_BYTES + G3_B_BYTES) + (fuse ? 512 * 64 : 0);   // + 16 LIF state values per thread
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return fail(-3, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
     hipLaunchKernelGGL(kern, dim3(cdiv(a.M, G3_BM) * a.n_blocks), dim3(512), lds, s, a);

@@ -41,20 +41,14 @@ __device__ __forceinline__ bool lif_step(const float cur, float& v, float& i, co
     return z;
 }
 
-// The same step on four neurons at once (one 16x16 MFMA accumulator): plain vector expressions, which hipcc
-// lowers to packed fp32 instructions (v_pk_add_f32 / v_pk_mul_f32: IEEE-rounded per element, and the kernels are
-// built with -ffp-contract=off, so nothing is fused).  bal[r] = wave ballot of neuron r's spike (the compare
-// writes the SGPR pair that also drives the reset select).
-__device__ __forceinline__ void lif_step4(const f32x4 cur, f32x4& v, f32x4& i, const NeuronP& p, unsigned long long (&bal)[4]) {
-    const f32x4 v_dec = v + p.ca * ((p.v_leak - v) + i);
+// The decay / integrate part of the same step on four neurons at once (one 16x16 MFMA accumulator): plain vector
+// expressions, which hipcc lowers to packed fp32 instructions (v_pk_add_f32 / v_pk_mul_f32: IEEE-rounded per
+// element, and the kernels are built with -ffp-contract=off, so nothing is fused).  The caller thresholds
+// d = v_dec - v_th per element (z = d > 0) and sets v = z ? v_reset : v_dec.
+__device__ __forceinline__ void lif_decay4(const f32x4 cur, const f32x4 v, f32x4& i, const NeuronP& p, f32x4& v_dec, f32x4& d) {
+    v_dec = v + p.ca * ((p.v_leak - v) + i);
     const f32x4 i_dec = i + p.cb * i;
-    const f32x4 d = v_dec - p.v_th;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const bool z = d[r] > 0.0f;
-        bal[r] = __ballot(z);
-        v[r] = z ? p.v_reset : v_dec[r];
-    }
+    d = v_dec - p.v_th;
     i = i_dec + cur;
 }
 

@@ -610,25 +610,28 @@ __device__ __forceinline__ const void* sgpr_ptr(const void* p) {
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)x), hi = __builtin_amdgcn_readfirstlane((uint32_t)(x >> 32));
     return (const void*)(((unsigned long long)hi << 32) | lo);
 }
-__device__ __forceinline__ void glds16(const void* sbase_uniform, uint32_t voff, uint32_t lds_addr_uniform) {
-    const unsigned char* p = reinterpret_cast<const unsigned char*>(sbase_uniform) + voff;
-#ifdef SNN_EXP_BUILTIN_GLDS
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
-                                     (__attribute__((address_space(3))) void*)(uintptr_t)lds_addr_uniform, 16, 0, 0);
-    return;
-#endif
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
-                 :: "v"(p), "s"(lds_addr_uniform) : "memory", "m0");
+// Three pieces (the three weight planes of a chunk) per call; s_nop 4 / s_nop 0: SGPR -> VMEM-base and M0 -> LDS-DMA
+// wait states, which hipcc's hazard recogniser does not insert inside inline asm.
+__device__ __forceinline__ void glds16x3(const void* p0, const void* p1, const void* p2, uint32_t voff,
+                                         uint32_t d0, uint32_t d1, uint32_t d2) {
+    asm volatile("s_mov_b32 m0, %4\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1\n\t"
+                 "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2\n\t"
+                 "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %3"
+                 :: "v"(voff), "s"(p0), "s"(p1), "s"(p2), "s"(d0), "s"(d1), "s"(d2) : "memory", "m0");
 }
 
 #define G3_BM 256
 #define G3_BN 128
-#define G3_ROWB 64                                  // bytes per LDS row: 32 bf16, four 16-B units, XOR-swizzled
-#define G3_A_BYTES (G3_BM * G3_ROWB)                // 16384
-#define G3_B_BYTES (3 * G3_BN * G3_ROWB)            // 24576
-#define G3_LDS (2 * (G3_A_BYTES + G3_B_BYTES))      // 81920: two work-groups per CU
-// unit u (= k-group 8u..8u+7) of row r lives at physical unit u ^ swz(r), swz = [0,3,2,1][(r >> 2) & 3].  A 16x16x32
-// fragment read has lane l on row l&15, unit l>>4; the four 16-lane groups of a ds_read_b128
+#define G3_ROWB 64                                  // bytes per LDS weight row: 32 bf16, four 16-B units, XOR-swizzled
+#define G3_AW_BYTES (G3_BM * 4)                     // raw spike words of one chunk (one per row): 1 KB
+#define G3_B_BYTES (3 * G3_BN * G3_ROWB)            // 24576: three weight planes of one chunk
+#define G3_SLOT (G3_AW_BYTES + G3_B_BYTES)          // one ring slot = one 32-deep chunk
+#define G3_NB 3                                     // ring slots
+#define G3_LUT_BYTES 4096                           // byte -> 8 bf16 (0 / 1.0) expansion table
+#define G3_STATE_BYTES (512 * 64)                   // fused variant: 16 LIF state values per thread
+#define G3_LDS (G3_LUT_BYTES + G3_NB * G3_SLOT)     // 80896: two work-groups per CU (table at offset 0, then the ring)
+// unit u (= k-group 8u..8u+7) of weight row r lives at physical unit u ^ swz(r), swz = [0,3,2,1][(r >> 2) & 3].  A
+// 16x16x32 fragment read has lane l on row l&15, unit l>>4; the four 16-lane groups of a ds_read_b128
 // ({0-3,12-15,20-27}, {4-11,16-19,28-31}, +32) then each hit 16 distinct 16-B slots of the 256-B bank row.
 #define G3_SWZ(r) ((0 - ((r) >> 2)) & 3)
 
@@ -654,20 +657,26 @@ __device__ __forceinline__ uint32_t bf16_pair(uint32_t w, int j) {      // bits 
 }
 
 // FUSE (conv only): M = positions; per time step the 9*Cw chunks are accumulated, then the LIF update runs
-// on the accumulators in registers (64 acc + 64 v + 64 i per lane) and only spike bits are written.
-// NB = LDS ring slots of one 32-deep chunk (40 KB each).  NB = 2 (80 KB, two work-groups per CU): chunk c+1 is
-// staged while chunk c multiplies.  NB >= 3 (the fused variant owns its CU anyway): staging runs two chunks ahead,
-// so the slot of chunk c+1 is already complete during chunk c and the first fragments of chunk c+1 are read from
-// LDS BEFORE the barrier that ends chunk c - the matrix pipe does not drain at the barrier.
+// on the accumulators in registers and only spike bits are written.
+//
+// LDS: a ring of G3_NB = 3 slots (one 32-deep chunk each: 256 raw spike words + 3 weight planes), a 4-KB table
+// byte -> 8 bf16, and for FUSE 16 LIF state values per thread.  Staging runs two chunks ahead, so the slot of chunk
+// c+1 is already complete during chunk c and the first fragments of chunk c+1 are read from LDS BEFORE the barrier
+// that ends chunk c - the matrix pipe does not drain at the barrier.
+// The A (spike) fragment of a lane is 8 consecutive k of one row = ONE BYTE of that row's spike word: it is fetched
+// as table[byte] by a single ds_read_b128.  No expanded spike image is ever built (the first version spent 36 VALU
+// instructions + 2 ds_write_b128 per thread and chunk on it, 10 % of the kernel: every VALU instruction beside
+// v_mfma_f32_16x16x32_bf16 competes for the SIMD's vector issue, which the MFMAs alone hold half of the time).
 // PD = fragment prefetch distance inside a chunk, in groups of 4 MFMAs (one weight fragment per group).
-template <bool CONV, bool FUSE, int NB>
+template <bool CONV, bool FUSE>
 __global__ __launch_bounds__(512, FUSE ? 2 : 4) void k_gemm_bf16x3(const Gemm3Args args) {
     static_assert(CONV || !FUSE, "LIF fusion is for the conv rows");
-    constexpr int SLOT = G3_A_BYTES + G3_B_BYTES;               // A image, then the three B planes
-    constexpr bool XPF = NB >= 3;                               // fragment prefetch across the chunk barrier
+    constexpr int NB = G3_NB, SLOT = G3_SLOT;
     constexpr int PD = 3, RING = PD + 1;                        // 12 groups per chunk: RING must divide 12
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    unsigned char* const lut = smem;                // table at LDS offset 0: a fragment address is just (byte << 4)
+    unsigned char* const ring = smem + G3_LUT_BYTES;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -677,9 +686,16 @@ __global__ __launch_bounds__(512, FUSE ? 2 : 4) void k_gemm_bf16x3(const Gemm3Ar
     const int m0 = mb * G3_BM;
     const int Kc = args.Kc, Np = args.Np, M = args.M;
 
-    // ---- A staging role: thread -> (row, 16-bit half).  A spike word is addressed as (wave-uniform 64-bit base in
+    if (tid < 256) {                                // table entry e: element j = bit j of e as bf16
+        uint4 q;
+        q.x = bf16_pair(tid, 0); q.y = bf16_pair(tid, 1); q.z = bf16_pair(tid, 2); q.w = bf16_pair(tid, 3);
+        *reinterpret_cast<uint4*>(lut + tid * 16) = q;
+    }
+
+    // ---- A staging role: waves 0-3, thread -> row.  A spike word is addressed as (wave-uniform 64-bit base in
     // SGPRs) + (32-bit byte offset of the lane's row): no per-chunk 64-bit vector arithmetic ----
-    const int xrow = tid >> 1, xhalf = tid & 1;
+    const bool a_role = wave < 4;
+    const int xrow = tid & 255;
     const int xm = m0 + xrow;
     uint32_t a_off = 0;                             // bytes: fc row / conv centre tap, channel word 0
     int a_pitch = 0;                                // conv: bytes per image row of the lane's pyramid level
@@ -706,38 +722,43 @@ __global__ __launch_bounds__(512, FUSE ? 2 : 4) void k_gemm_bf16x3(const Gemm3Ar
     }
     // Spike-word loads are issued as inline asm: hipcc must not see them, or it drains the LDS-DMA queue
     // (vmcnt(0)) at their first use while weight planes are still in flight.  A word is consumed only after the
-    // hand-written s_waitcnt vmcnt(0) that ends the chunk it was issued in.
-    // The fetch stream walks the chunk sequence (t, tap, channel word) with scalar counters.
+    // s_waitcnt vmcnt(0) that ends the chunk it was issued in.
+    // The fetch stream walks the chunk sequence (t, tap dy, tap dx, channel word) with scalar counters.
     // (s_nop 4: an SGPR written by SALU / v_readfirstlane needs 5 wait states before a VMEM instruction reads it as
     // its base address, and hipcc's hazard recogniser does not look into inline asm.)
+    // The stream is a running scalar pointer: within one tap row (dy) the wave-uniform word offset dx*Cw + cc just
+    // increments by one per chunk; every 3*Cw chunks the lanes step one image row down, every Kc chunks one time
+    // step on.  Past the last chunk the stream wraps to the start (staged, never multiplied).
     const int n_steps = FUSE ? args.T : 1;
-    int f_t = 0, f_kc = 0, f_tap = 0, f_cc = 0;
+    const unsigned long long f_base0 = (unsigned long long)args.A - (CONV ? (unsigned long long)args.Cw * 4 : 0);
+    unsigned long long f_ptr = f_base0;             // scalar: A + t*enc_stride + dx*Cw + cc   (fc: A + kc)
+    uint32_t f_voff = CONV ? a_off - (uint32_t)a_pitch : a_off;     // lane: row offset of tap row dy
+    uint32_t f_mask = 1u;                           // conv: bit of the current tap
+    int f_t = 0, f_kc = 0, f_cc = 0, f_dx = 0;
     auto fetch_next = [&](uint32_t& w) {
-        const bool live = f_t < n_steps;            // past the end: harmless re-read of chunk (0, 0)
-        const int t_ = live ? f_t : 0, kc_ = live ? f_kc : 0, tap_ = live ? f_tap : 0, cc_ = live ? f_cc : 0;
         w = 0u;
+        const void* sbase = sgpr_ptr(reinterpret_cast<const void*>(f_ptr));
         if (CONV) {
-            const int dy = tap_ / 3 - 1, dx = tap_ - 3 * (tap_ / 3) - 1;
-            const void* sbase = sgpr_ptr(args.A + ((FUSE ? (long long)t_ * (long long)args.enc_stride : 0ll) + dx * args.Cw + cc_));
-            const uint32_t voff = a_off + (uint32_t)(dy * a_pitch);
-            if ((a_valid >> tap_) & 1u)
-                asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "+v"(w) : "v"(voff), "s"(sbase) : "memory");
+            if (a_role && (a_valid & f_mask))
+                asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "+v"(w) : "v"(f_voff), "s"(sbase) : "memory");
         } else {
-            const void* sbase = sgpr_ptr(args.A + kc_);
-            asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "+v"(w) : "v"(a_off), "s"(sbase) : "memory");
+            if (a_role) asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "+v"(w) : "v"(f_voff), "s"(sbase) : "memory");
         }
-        if (live) {
-            if (CONV && ++f_cc == args.Cw) { f_cc = 0; ++f_tap; }
-            if (++f_kc == Kc) { f_kc = 0; f_tap = 0; f_cc = 0; ++f_t; }
+        f_ptr += 4;
+        if (CONV && ++f_cc == args.Cw) {
+            f_cc = 0;
+            f_mask <<= 1;
+            if (++f_dx == 3) { f_dx = 0; f_ptr -= (unsigned long long)(12 * args.Cw); f_voff += (uint32_t)a_pitch; }
+        }
+        if (++f_kc == Kc) {
+            f_kc = 0; f_cc = 0; f_dx = 0; f_mask = 1u;
+            if (++f_t == n_steps) f_t = 0;
+            f_ptr = f_base0 + (FUSE ? (unsigned long long)f_t * args.enc_stride * 4 : 0ull);
+            f_voff = CONV ? a_off - (uint32_t)a_pitch : a_off;
         }
     };
-    unsigned char* const a_wr = smem + xrow * G3_ROWB;
-    const int a_wr_lo = ((2 * xhalf) ^ G3_SWZ(xrow)) << 4;     // unit 2*xhalf; unit 2*xhalf+1 = the same ^ 16 bytes
-    auto store_a_half = [&](uint32_t w, int slot, int hi) {     // 8 of the thread's 16 spike bits -> 8 bf16 (16 B)
-        const uint32_t hbits = (w >> (16 * xhalf + 8 * hi)) & 0xffu;
-        uint4 q;
-        q.x = bf16_pair(hbits, 0); q.y = bf16_pair(hbits, 1); q.z = bf16_pair(hbits, 2); q.w = bf16_pair(hbits, 3);
-        *reinterpret_cast<uint4*>(a_wr + slot * SLOT + (hi ? (a_wr_lo ^ 16) : a_wr_lo)) = q;
+    auto store_w = [&](uint32_t w, uint32_t slot_off) {     // the raw spike word of the thread's row
+        if (a_role) *reinterpret_cast<uint32_t*>(ring + slot_off + xrow * 4) = w;
     };
 
     // ---- B staging: LDS-DMA.  Wave w copies rows [16w, 16w+16) of each of the 3 planes (1 KiB per instruction);
@@ -749,19 +770,14 @@ __global__ __launch_bounds__(512, FUSE ? 2 : 4) void k_gemm_bf16x3(const Gemm3Ar
     const unsigned long long b_chunk = (unsigned long long)Np * 64, b_plane = args.plane_elems * 2;   // bytes
     unsigned long long s_ptr = (unsigned long long)args.wpk;   // weight stream: plane 0 of the next chunk (scalar)
     int s_kc = 0;
-    auto stage_plane = [&](int slot, int pl) {      // one 1-KiB LDS-DMA piece per wave
-        const uint32_t d = smem_base + slot * SLOT + G3_A_BYTES + wave * 1024;              // wave-uniform LDS address
-        glds16(sgpr_ptr(reinterpret_cast<const void*>(s_ptr + pl * b_plane)), b_off,
-               __builtin_amdgcn_readfirstlane(d + pl * (G3_BN * G3_ROWB)));
-    };
-    auto stage_advance = [&]() {
+    const uint32_t b_dst = smem_base + G3_LUT_BYTES + G3_AW_BYTES + wave * 1024;            // + slot offset, plane
+    auto stage_next = [&](uint32_t slot_off) {
+        const uint32_t d = __builtin_amdgcn_readfirstlane(b_dst + slot_off);                // wave-uniform LDS address
+        glds16x3(sgpr_ptr(reinterpret_cast<const void*>(s_ptr)), sgpr_ptr(reinterpret_cast<const void*>(s_ptr + b_plane)),
+                 sgpr_ptr(reinterpret_cast<const void*>(s_ptr + 2 * b_plane)), b_off,
+                 d, d + G3_BN * G3_ROWB, d + 2 * G3_BN * G3_ROWB);
         s_ptr += b_chunk;
         if (++s_kc == Kc) { s_kc = 0; s_ptr = (unsigned long long)args.wpk; }
-    };
-    auto stage_next = [&](int slot) {
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) stage_plane(slot, pl);
-        stage_advance();
     };
 
     // 16x16 tiles: lane holds column lane&15, rows (lane>>4)*4 + reg of each tile
@@ -772,21 +788,23 @@ __global__ __launch_bounds__(512, FUSE ? 2 : 4) void k_gemm_bf16x3(const Gemm3Ar
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
-    // fragment read: row (tile*16 + lr), logical unit lg (k = 8*lg .. 8*lg+7); swz depends on lr only
-    const int u_rd = (lg ^ G3_SWZ(lr)) << 4;
-    const unsigned char* const a_rd = smem + (wm * 64 + lr) * G3_ROWB + u_rd;                // + slot, mt*16*ROWB
-    const unsigned char* const b_rd = smem + G3_A_BYTES + (wn * 64 + lr) * G3_ROWB + u_rd;   // + slot, pl, nt
-    auto rd_a = [&](int slot, int mt) { return *reinterpret_cast<const bf16x8*>(a_rd + slot * SLOT + mt * 16 * G3_ROWB); };
+    // A fragment: row (wm*64 + mt*16 + lr), k = 8*lg .. 8*lg+7  ->  table[byte lg of the row's spike word]
+    const unsigned char* const w_rd = ring + (wm * 64 + lr) * 4;                             // + slot offset, mt*64
+    const int lg8 = 8 * lg;
+    auto rd_w = [&](uint32_t slot_off, int mt) { return *reinterpret_cast<const uint32_t*>(w_rd + slot_off + mt * 64); };
+    auto rd_a = [&](uint32_t w) { return *reinterpret_cast<const bf16x8*>(lut + (__builtin_amdgcn_ubfe(w, lg8, 8) << 4)); };
+    // B fragment: row (tile*16 + lr), logical unit lg; swz depends on lr only
+    const unsigned char* const b_rd = ring + G3_AW_BYTES + (wn * 64 + lr) * G3_ROWB + ((lg ^ G3_SWZ(lr)) << 4);
     // group g of a chunk = (N-tile g/3, plane 2 - g%3): per accumulator the small terms first (lo, mid, hi)
-    auto rd_b = [&](int slot, int g) {
-        return *reinterpret_cast<const bf16x8*>(b_rd + slot * SLOT + (2 - g % 3) * (G3_BN * G3_ROWB) + (g / 3) * 16 * G3_ROWB);
+    auto rd_b = [&](uint32_t slot_off, int g) {
+        return *reinterpret_cast<const bf16x8*>(b_rd + slot_off + (2 - g % 3) * (G3_BN * G3_ROWB) + (g / 3) * 16 * G3_ROWB);
     };
 
     // LIF state of the fused variant, whole T loop: v (64 registers) and the synaptic current i (48 registers;
-    // the 16 values of M-tile 3 live in the LDS left over beside the ring, private to the thread, touched once per
-    // time step - they are what keeps the main loop free of scratch spills)
+    // the 16 values of M-tile 3 live in LDS, private to the thread, touched once per time step - they are what
+    // keeps the main loop free of scratch spills)
     f32x4 v[FUSE ? 4 : 1][FUSE ? 4 : 1], ci[FUSE ? 3 : 1][FUSE ? 4 : 1];
-    f32x4* const ci_lds = reinterpret_cast<f32x4*>(smem + NB * SLOT) + tid;          // [nt][512 threads]
+    f32x4* const ci_lds = reinterpret_cast<f32x4*>(smem + G3_LDS) + tid;                    // [nt][512 threads]
     if (FUSE) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
@@ -800,83 +818,75 @@ __global__ __launch_bounds__(512, FUSE ? 2 : 4) void k_gemm_bf16x3(const Gemm3Ar
     const int n_total = n_steps * Kc;
 
     // Software pipeline over the chunk sequence c = (t, kc).  During chunk c:
-    //   the spike word of chunk c+NB is fetched from global memory (register),
-    //   the weight planes of chunk c+NB-1 are copied into ring slot (c-1) mod NB by LDS-DMA,
-    //   the spike word of chunk c+NB-1 (fetched during chunk c-1) is expanded into that slot (VALU + ds_write
-    //   in the shadow of the MFMAs),
-    //   the fragments of chunk c are read PD groups ahead of their MFMAs - with NB >= 3 also the first ones of
-    //   chunk c+1, whose slot has been complete since the previous barrier.
+    //   the spike word of chunk c+3 is fetched from global memory (register),
+    //   the spike word of chunk c+2 (fetched during chunk c-1) and, by LDS-DMA, the weight planes of chunk c+2 go
+    //   into ring slot (c-1) mod 3,
+    //   the weight fragments of chunk c are read PD groups ahead of their MFMAs, the first ones of chunk c+1 and
+    //   its spike words / table fragments at the end of chunk c (that slot has been complete since the last barrier).
     // One barrier per chunk; s_sched_barrier pins one fragment read + 4 MFMAs per group.
     uint32_t w_hold, w_new;
     {
         uint32_t w0[NB - 1];
 #pragma unroll
-        for (int j = 0; j < NB - 1; ++j) {              // chunks 0 .. NB-2 -> slots 0 .. NB-2
+        for (int j = 0; j < NB - 1; ++j) {              // chunks 0, 1 -> slots 0, 1
             fetch_next(w0[j]);
-            stage_next(j);
+            stage_next(j * SLOT);
         }
-        fetch_next(w_hold);                             // chunk NB-1
+        fetch_next(w_hold);                             // chunk 2
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
         for (int j = 0; j < NB - 1; ++j) {
             asm volatile("" : "+v"(w0[j]));             // the loaded value is only defined from here on
-            store_a_half(w0[j], j, 0);
-            store_a_half(w0[j], j, 1);
+            store_w(w0[j], j * SLOT);
         }
         asm volatile("" : "+v"(w_hold));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
     }
     bf16x8 af[2][4], bq[RING];
+    uint32_t wq[4];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) af[0][mt] = rd_a(0, mt);
+    for (int mt = 0; mt < 4; ++mt) wq[mt] = rd_w(0, mt);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) af[0][mt] = rd_a(wq[mt]);
 #pragma unroll
     for (int g = 0; g < PD; ++g) bq[g] = rd_b(0, g);
 
-    int sl = 0;                                         // ring slot of the current chunk
+    uint32_t o_cur = 0, o_nxt = SLOT, o_wr = 2 * SLOT;   // ring slots (byte offsets) of chunk c, c+1 and the one being filled
     int kc = 0, t = 0;
     for (int c0 = 0; c0 < n_total; c0 += 2) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             if (c0 + u >= n_total) break;
-            const int sl1 = sl + 1 == NB ? 0 : sl + 1;  // slot of chunk c+1
-            const int slw = sl == 0 ? NB - 1 : sl - 1;  // slot being filled (chunk c+NB-1)
 #pragma unroll
             for (int g = 0; g < 12; ++g) {
                 const int gp = g + PD;
-                if (gp < 12) bq[gp % RING] = rd_b(sl, gp);
-                else if (XPF) bq[gp % RING] = rd_b(sl1, gp - 12);
-                if (XPF && g >= 8) af[u ^ 1][g - 8] = rd_a(sl1, g - 8);
-                // Staging order: hipcc puts an s_waitcnt vmcnt(0) in front of every ds_write that follows an LDS-DMA
-                // (possible alias), so the spike image is expanded FIRST, while nothing is in flight, and the
-                // chunk's global traffic is issued after it - it then has 9 groups of MFMAs to land.
+                bq[gp % RING] = gp < 12 ? rd_b(o_cur, gp) : rd_b(o_nxt, gp - 12);
+                if (g == 4) {
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) wq[mt] = rd_w(o_nxt, mt);
+                }
+                if (g >= 8) af[u ^ 1][g - 8] = rd_a(wq[g - 8]);
 #ifndef SNN_EXP_NO_STORE_A
-                if (g == 0) store_a_half(w_hold, slw, 0);
-                if (g == 1) store_a_half(w_hold, slw, 1);
+                if (g == 0) store_w(w_hold, o_wr);
 #endif
-#ifdef SNN_EXP_SPREAD
-                if (g == 2) fetch_next(w_new);
-                if (g == 3) stage_plane(slw, 0);
-                if (g == 5) stage_plane(slw, 1);
-                if (g == 7) { stage_plane(slw, 2); stage_advance(); }
-#else
                 if (g == 2) {
                     fetch_next(w_new);
 #ifndef SNN_EXP_NO_GLDS
-                    stage_next(slw);
+                    stage_next(o_wr);
 #endif
                 }
-#endif
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt)
                     acc[mt][g / 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u][mt], bq[g % RING], acc[mt][g / 3], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
 #ifndef SNN_EXP_NO_BARRIER
-            // weight planes landed (vmcnt), expanded spike image written (lgkmcnt), everyone done reading slot `sl`.
-            // The builtin (not inline asm) so that hipcc's own wait-count bookkeeping knows the prefetched
-            // fragments have arrived.
-            // The empty asm statements are compiler fences: neither builtin orders memory accesses for hipcc.
+            // weight planes landed (vmcnt), spike words written (lgkmcnt), everyone done reading slot `sl`.
+            // The s_waitcnt builtin (not inline asm) so that hipcc's own wait-count bookkeeping knows the prefetched
+            // fragments have arrived; the empty asm statements are compiler fences (neither builtin orders memory
+            // accesses for hipcc, which otherwise moves LDS reads across the barrier).
             asm volatile("" ::: "memory");
             __builtin_amdgcn_s_waitcnt(0x0070);         // vmcnt(0) lgkmcnt(0)
             __builtin_amdgcn_s_barrier();
@@ -884,45 +894,45 @@ __global__ __launch_bounds__(512, FUSE ? 2 : 4) void k_gemm_bf16x3(const Gemm3Ar
 #endif
             asm volatile("" : "+v"(w_new));
             w_hold = w_new;
-            if (!XPF) {                                 // two slots: the next chunk is readable only now
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) af[u ^ 1][mt] = rd_a(sl1, mt);
-#pragma unroll
-                for (int g = 0; g < PD; ++g) bq[g] = rd_b(sl1, g);
-            }
-            sl = sl1;
+            { const uint32_t o = o_cur; o_cur = o_nxt; o_nxt = o_wr; o_wr = o; }
             const bool step_done = ++kc == Kc;
             if (step_done) kc = 0;
             if (FUSE && step_done) {
-                // ---- LIF epilogue in registers.  A ballot over accumulator register (mt, nt, reg) holds, for each of
-                // the 4 row groups rg, 16 channel bits of position mt*16 + rg*4 + reg; N-tiles (0,1) and (2,3) pair up
-                // into the two 32-channel words of that position, which lane = position finally stores (8 bytes) ----
+                // ---- LIF epilogue in registers.  A ballot over accumulator register (mt, nt, reg) holds, for each
+                // of the 4 row groups rg, 16 channel bits of position mt*16 + rg*4 + reg; N-tiles (0,1) and (2,3)
+                // pair up into the two 32-channel words of that position, which lane = position finally stores ----
                 uint32_t my0 = 0, my1 = 0;
-    #pragma unroll
+#pragma unroll
                 for (int mt = 0; mt < 4; ++mt)
-    #pragma unroll
-                    for (int np = 0; np < 2; ++np) {                       // N-tile pair -> word np of the position
-                        unsigned long long bal[2][4];                      // [nt & 1][reg]
-    #pragma unroll
+#pragma unroll
+                    for (int np = 0; np < 2; ++np) {                   // N-tile pair -> word np of the position
+                        f32x4 vd[2], d[2];
+#pragma unroll
                         for (int q = 0; q < 2; ++q) {
+                            const int nt = 2 * np + q;
                             if (mt < 3) {
-                                lif_step4(acc[mt][2 * np + q], v[mt][2 * np + q], ci[mt][2 * np + q], args.p, bal[q]);
+                                lif_decay4(acc[mt][nt], v[mt][nt], ci[mt][nt], args.p, vd[q], d[q]);
                             } else {
-                                f32x4 i3 = ci_lds[(2 * np + q) * 512];
-                                lif_step4(acc[mt][2 * np + q], v[mt][2 * np + q], i3, args.p, bal[q]);
-                                ci_lds[(2 * np + q) * 512] = i3;
+                                f32x4 i3 = ci_lds[nt * 512];
+                                lif_decay4(acc[mt][nt], v[mt][nt], i3, args.p, vd[q], d[q]);
+                                ci_lds[nt * 512] = i3;
                             }
-                            acc[mt][2 * np + q] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                            acc[mt][nt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
                         }
-    #pragma unroll
-                        for (int r = 0; r < 4; ++r)
-    #pragma unroll
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {                  // two ballots live at a time
+                            const bool z0 = d[0][r] > 0.0f, z1 = d[1][r] > 0.0f;
+                            const unsigned long long b0 = __ballot(z0), b1 = __ballot(z1);
+                            v[mt][2 * np][r] = z0 ? args.p.v_reset : vd[0][r];
+                            v[mt][2 * np + 1][r] = z1 ? args.p.v_reset : vd[1][r];
+#pragma unroll
                             for (int rg = 0; rg < 4; ++rg) {
-                                const uint32_t w = (uint32_t)((bal[0][r] >> (16 * rg)) & 0xffffull) | ((uint32_t)((bal[1][r] >> (16 * rg)) & 0xffffull) << 16);
+                                const uint32_t w = (uint32_t)((b0 >> (16 * rg)) & 0xffffull) | ((uint32_t)((b1 >> (16 * rg)) & 0xffffull) << 16);
                                 // lane (mt*16 + rg*4 + r) keeps the two words of its position (rows >= M are never stored)
                                 if (np == 0) asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(my0) : "s"(w), "n"(mt * 16 + rg * 4 + r));
                                 else         asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(my1) : "s"(w), "n"(mt * 16 + rg * 4 + r));
                             }
+                        }
                     }
                 {
                     const int row = m0 + wm * 64 + lane;                  // lane = position within the wave's 64 rows
@@ -1323,8 +1333,8 @@ int snn_pack_linear_weight_bf16x3(const float* w, int N, int K, uint16_t* packed
 static int launch_gemm3(bool conv, const Gemm3Args& a, hipStream_t s) {
     const bool fuse = conv && a.spk != nullptr;
     // the fused variant owns its CU (registers): 3 ring slots = 120 KB; the others run two work-groups per CU
-    auto kern = fuse ? k_gemm_bf16x3<true, true, 3> : (conv ? k_gemm_bf16x3<true, false, 2> : k_gemm_bf16x3<false, false, 2>);
-    const int lds = (fuse ? 3 : 2) * (G3_A_BYTES + G3_B_BYTES) + (fuse ? 512 * 64 : 0);   // + 16 LIF state values per thread
+    auto kern = fuse ? k_gemm_bf16x3<true, true> : (conv ? k_gemm_bf16x3<true, false> : k_gemm_bf16x3<false, false>);
+    const int lds = G3_LDS + (fuse ? G3_STATE_BYTES : 0);
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return fail(-3, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
     hipLaunchKernelGGL(kern, dim3(cdiv(a.M, G3_BM) * a.n_blocks), dim3(512), lds, s, a);

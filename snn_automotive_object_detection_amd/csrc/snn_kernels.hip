@@ -626,10 +626,9 @@ __device__ __forceinline__ void glds16x3(const void* p0, const void* p1, const v
 #define G3_AW_BYTES (G3_BM * 4)                     // raw spike words of one chunk (one per row): 1 KB
 #define G3_B_BYTES (3 * G3_BN * G3_ROWB)            // 24576: three weight planes of one chunk
 #define G3_SLOT (G3_AW_BYTES + G3_B_BYTES)          // one ring slot = one 32-deep chunk
-#define G3_NB 3                                     // ring slots
 #define G3_LUT_BYTES 4096                           // byte -> 8 bf16 (0 / 1.0) expansion table
 #define G3_STATE_BYTES (512 * 64)                   // fused variant: 16 LIF state values per thread
-#define G3_LDS (G3_LUT_BYTES + G3_NB * G3_SLOT)     // 80896: two work-groups per CU (table at offset 0, then the ring)
+#define G3_LDS(nb) (G3_LUT_BYTES + (nb) * G3_SLOT)   // table at offset 0, then the ring; 3 slots = 80896: two work-groups per CU
 // unit u (= k-group 8u..8u+7) of weight row r lives at physical unit u ^ swz(r), swz = [0,3,2,1][(r >> 2) & 3].  A
 // 16x16x32 fragment read has lane l on row l&15, unit l>>4; the four 16-lane groups of a ds_read_b128
 // ({0-3,12-15,20-27}, {4-11,16-19,28-31}, +32) then each hit 16 distinct 16-B slots of the 256-B bank row.
@@ -659,20 +658,26 @@ __device__ __forceinline__ uint32_t bf16_pair(uint32_t w, int j) {      // bits 
 // FUSE (conv only): M = positions; per time step the 9*Cw chunks are accumulated, then the LIF update runs
 // on the accumulators in registers and only spike bits are written.
 //
-// LDS: a ring of G3_NB = 3 slots (one 32-deep chunk each: 256 raw spike words + 3 weight planes), a 4-KB table
-// byte -> 8 bf16, and for FUSE 16 LIF state values per thread.  Staging runs two chunks ahead, so the slot of chunk
-// c+1 is already complete during chunk c and the first fragments of chunk c+1 are read from LDS BEFORE the barrier
-// that ends chunk c - the matrix pipe does not drain at the barrier.
+// LDS: a 4-KB table byte -> 8 bf16, a ring of NB slots (one 32-deep chunk each: 256 raw spike words + 3 weight
+// planes), and for FUSE 16 LIF state values per thread.  Staging runs ahead, so the slot of chunk c+1 is already
+// complete during chunk c and the first fragments of chunk c+1 are read from LDS BEFORE the barrier that ends chunk
+// c - the matrix pipe does not drain at the barrier.
+// NB = 3 (80 KB, two work-groups per CU): the weight planes of chunk c+2 are copied during chunk c and must have
+// landed at its end (s_waitcnt vmcnt(0)).  NB = 4 (fused variant, which owns its CU): the planes of chunk c+3 are
+// copied during chunk c and need to land only by the end of chunk c+1 (s_waitcnt vmcnt(3): the three youngest
+// operations, this chunk's copies, stay in flight across the barrier) - no L2 latency is ever waited for.
 // The A (spike) fragment of a lane is 8 consecutive k of one row = ONE BYTE of that row's spike word: it is fetched
 // as table[byte] by a single ds_read_b128.  No expanded spike image is ever built (the first version spent 36 VALU
 // instructions + 2 ds_write_b128 per thread and chunk on it, 10 % of the kernel: every VALU instruction beside
 // v_mfma_f32_16x16x32_bf16 competes for the SIMD's vector issue, which the MFMAs alone hold half of the time).
 // PD = fragment prefetch distance inside a chunk, in groups of 4 MFMAs (one weight fragment per group).
-template <bool CONV, bool FUSE>
+template <bool CONV, bool FUSE, int NB>
 __global__ __launch_bounds__(512, FUSE ? 2 : 4) void k_gemm_bf16x3(const Gemm3Args args) {
     static_assert(CONV || !FUSE, "LIF fusion is for the conv rows");
-    constexpr int NB = G3_NB, SLOT = G3_SLOT;
-    constexpr int PD = 3, RING = PD + 1;                        // 12 groups per chunk: RING must divide 12
+    static_assert(NB == 3 || NB == 4, "ring depth");
+    constexpr int SLOT = G3_SLOT;
+    constexpr int PD = (CONV && !FUSE) ? 2 : 3, RING = PD + 1;  // 12 groups per chunk: RING must divide 12 (the un-fused conv
+                                                               // rows have 128 registers: one fragment less in flight)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
     unsigned char* const lut = smem;                // table at LDS offset 0: a fragment address is just (byte << 4)
@@ -730,30 +735,31 @@ __global__ __launch_bounds__(512, FUSE ? 2 : 4) void k_gemm_bf16x3(const Gemm3Ar
     // increments by one per chunk; every 3*Cw chunks the lanes step one image row down, every Kc chunks one time
     // step on.  Past the last chunk the stream wraps to the start (staged, never multiplied).
     const int n_steps = FUSE ? args.T : 1;
-    const unsigned long long f_base0 = (unsigned long long)args.A - (CONV ? (unsigned long long)args.Cw * 4 : 0);
-    unsigned long long f_ptr = f_base0;             // scalar: A + t*enc_stride + dx*Cw + cc   (fc: A + kc)
+    const uint32_t* f_tbase = args.A;               // scalar: A + t*enc_stride
+    int f_off = CONV ? -args.Cw : 0;                // scalar: dx*Cw + cc   (fc: kc)
     uint32_t f_voff = CONV ? a_off - (uint32_t)a_pitch : a_off;     // lane: row offset of tap row dy
     uint32_t f_mask = 1u;                           // conv: bit of the current tap
     int f_t = 0, f_kc = 0, f_cc = 0, f_dx = 0;
     auto fetch_next = [&](uint32_t& w) {
         w = 0u;
-        const void* sbase = sgpr_ptr(reinterpret_cast<const void*>(f_ptr));
+        const void* sbase = sgpr_ptr(f_tbase + f_off);
         if (CONV) {
             if (a_role && (a_valid & f_mask))
                 asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "+v"(w) : "v"(f_voff), "s"(sbase) : "memory");
         } else {
             if (a_role) asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "+v"(w) : "v"(f_voff), "s"(sbase) : "memory");
         }
-        f_ptr += 4;
+        ++f_off;
         if (CONV && ++f_cc == args.Cw) {
             f_cc = 0;
             f_mask <<= 1;
-            if (++f_dx == 3) { f_dx = 0; f_ptr -= (unsigned long long)(12 * args.Cw); f_voff += (uint32_t)a_pitch; }
+            if (++f_dx == 3) { f_dx = 0; f_off -= 3 * args.Cw; f_voff += (uint32_t)a_pitch; }
         }
         if (++f_kc == Kc) {
             f_kc = 0; f_cc = 0; f_dx = 0; f_mask = 1u;
+            f_off = CONV ? -args.Cw : 0;
             if (++f_t == n_steps) f_t = 0;
-            f_ptr = f_base0 + (FUSE ? (unsigned long long)f_t * args.enc_stride * 4 : 0ull);
+            f_tbase = args.A + (FUSE ? (size_t)f_t * args.enc_stride : 0);
             f_voff = CONV ? a_off - (uint32_t)a_pitch : a_off;
         }
     };
@@ -804,7 +810,7 @@ __global__ __launch_bounds__(512, FUSE ? 2 : 4) void k_gemm_bf16x3(const Gemm3Ar
     // the 16 values of M-tile 3 live in LDS, private to the thread, touched once per time step - they are what
     // keeps the main loop free of scratch spills)
     f32x4 v[FUSE ? 4 : 1][FUSE ? 4 : 1], ci[FUSE ? 3 : 1][FUSE ? 4 : 1];
-    f32x4* const ci_lds = reinterpret_cast<f32x4*>(smem + G3_LDS) + tid;                    // [nt][512 threads]
+    f32x4* const ci_lds = reinterpret_cast<f32x4*>(smem + G3_LDS(NB)) + tid;                    // [nt][512 threads]
     if (FUSE) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
@@ -820,22 +826,21 @@ __global__ __launch_bounds__(512, FUSE ? 2 : 4) void k_gemm_bf16x3(const Gemm3Ar
     // Software pipeline over the chunk sequence c = (t, kc).  During chunk c:
     //   the spike word of chunk c+3 is fetched from global memory (register),
     //   the spike word of chunk c+2 (fetched during chunk c-1) and, by LDS-DMA, the weight planes of chunk c+2 go
-    //   into ring slot (c-1) mod 3,
+    //   into ring slot (c-1) mod NB (spike words: slot of chunk c+2),
     //   the weight fragments of chunk c are read PD groups ahead of their MFMAs, the first ones of chunk c+1 and
     //   its spike words / table fragments at the end of chunk c (that slot has been complete since the last barrier).
     // One barrier per chunk; s_sched_barrier pins one fragment read + 4 MFMAs per group.
     uint32_t w_hold, w_new;
     {
-        uint32_t w0[NB - 1];
+        uint32_t w0[2];
 #pragma unroll
-        for (int j = 0; j < NB - 1; ++j) {              // chunks 0, 1 -> slots 0, 1
-            fetch_next(w0[j]);
-            stage_next(j * SLOT);
-        }
+        for (int j = 0; j < 2; ++j) fetch_next(w0[j]);  // spike words of chunks 0, 1 -> slots 0, 1
         fetch_next(w_hold);                             // chunk 2
+#pragma unroll
+        for (int j = 0; j < NB - 1; ++j) stage_next(j * SLOT);      // weight planes of chunks 0 .. NB-2
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int j = 0; j < NB - 1; ++j) {
+        for (int j = 0; j < 2; ++j) {
             asm volatile("" : "+v"(w0[j]));             // the loaded value is only defined from here on
             store_w(w0[j], j * SLOT);
         }
@@ -853,7 +858,8 @@ __global__ __launch_bounds__(512, FUSE ? 2 : 4) void k_gemm_bf16x3(const Gemm3Ar
 #pragma unroll
     for (int g = 0; g < PD; ++g) bq[g] = rd_b(0, g);
 
-    uint32_t o_cur = 0, o_nxt = SLOT, o_wr = 2 * SLOT;   // ring slots (byte offsets) of chunk c, c+1 and the one being filled
+    // ring slots (byte offsets) of chunks c, c+1, c+2 (receives its spike words now) and c+NB-1 (receives its planes)
+    uint32_t o_cur = 0, o_nxt = SLOT, o_nn = 2 * SLOT, o_wr = (NB - 1) * SLOT;
     int kc = 0, t = 0;
     for (int c0 = 0; c0 < n_total; c0 += 2) {
 #pragma unroll
@@ -869,7 +875,7 @@ __global__ __launch_bounds__(512, FUSE ? 2 : 4) void k_gemm_bf16x3(const Gemm3Ar
                 }
                 if (g >= 8) af[u ^ 1][g - 8] = rd_a(wq[g - 8]);
 #ifndef SNN_EXP_NO_STORE_A
-                if (g == 0) store_w(w_hold, o_wr);
+                if (g == 0) store_w(w_hold, o_nn);
 #endif
                 if (g == 2) {
                     fetch_next(w_new);
@@ -888,13 +894,15 @@ __global__ __launch_bounds__(512, FUSE ? 2 : 4) void k_gemm_bf16x3(const Gemm3Ar
             // fragments have arrived; the empty asm statements are compiler fences (neither builtin orders memory
             // accesses for hipcc, which otherwise moves LDS reads across the barrier).
             asm volatile("" ::: "memory");
-            __builtin_amdgcn_s_waitcnt(0x0070);         // vmcnt(0) lgkmcnt(0)
+            if (NB == 3) __builtin_amdgcn_s_waitcnt(0x0070);        // vmcnt(0) lgkmcnt(0)
+            else __builtin_amdgcn_s_waitcnt(0x0073);                // vmcnt(3) lgkmcnt(0)
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
 #endif
             asm volatile("" : "+v"(w_new));
             w_hold = w_new;
-            { const uint32_t o = o_cur; o_cur = o_nxt; o_nxt = o_wr; o_wr = o; }
+            if (NB == 3) { const uint32_t o = o_cur; o_cur = o_nxt; o_nxt = o_nn; o_nn = o; o_wr = o; }
+            else { const uint32_t o = o_cur; o_cur = o_nxt; o_nxt = o_nn; o_nn = o_wr; o_wr = o; }
             const bool step_done = ++kc == Kc;
             if (step_done) kc = 0;
             if (FUSE && step_done) {
@@ -1333,8 +1341,9 @@ int snn_pack_linear_weight_bf16x3(const float* w, int N, int K, uint16_t* packed
 static int launch_gemm3(bool conv, const Gemm3Args& a, hipStream_t s) {
     const bool fuse = conv && a.spk != nullptr;
     // the fused variant owns its CU (registers): 3 ring slots = 120 KB; the others run two work-groups per CU
-    auto kern = fuse ? k_gemm_bf16x3<true, true> : (conv ? k_gemm_bf16x3<true, false> : k_gemm_bf16x3<false, false>);
-    const int lds = G3_LDS + (fuse ? G3_STATE_BYTES : 0);
+    // (a 4-slot ring - copies need to land only one chunk later - measured no faster for the fused variant: 3.85 vs 3.81 ms)
+    auto kern = fuse ? k_gemm_bf16x3<true, true, 3> : (conv ? k_gemm_bf16x3<true, false, 3> : k_gemm_bf16x3<false, false, 3>);
+    const int lds = G3_LDS(3) + (fuse ? G3_STATE_BYTES : 0);
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return fail(-3, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
     hipLaunchKernelGGL(kern, dim3(cdiv(a.M, G3_BM) * a.n_blocks), dim3(512), lds, s, a);

@@ -642,8 +642,9 @@ struct Gemm3Args {
     unsigned long long enc_stride;      // conv: words per time plane
     int M, Kc, Np, ldo, n_blocks;
     int Cw, P_total, n_levels;          // conv only
-    // fused conv + LIF (FUSE): rows are positions, the T loop runs inside, spikes leave as bit-planes
-    int T, pad;
+    // conv + LIF: spikes leave as bit-planes.  G3_CONV_LIF_REG: rows are positions, the T loop runs inside;
+    // G3_CONV_LIF_TILE: a 256-row tile = all T time steps of pb = 256/T positions (row = t*pb + position)
+    int T, pb;
     uint32_t* spk;
     unsigned long long spk_stride;
     NeuronP p;
@@ -671,12 +672,15 @@ __device__ __forceinline__ uint32_t bf16_pair(uint32_t w, int j) {      // bits 
 // instructions + 2 ds_write_b128 per thread and chunk on it, 10 % of the kernel: every VALU instruction beside
 // v_mfma_f32_16x16x32_bf16 competes for the SIMD's vector issue, which the MFMAs alone hold half of the time).
 // PD = fragment prefetch distance inside a chunk, in groups of 4 MFMAs (one weight fragment per group).
-template <bool CONV, bool FUSE, int NB>
-__global__ __launch_bounds__(512, FUSE ? 2 : 4) void k_gemm_bf16x3(const Gemm3Args args) {
-    static_assert(CONV || !FUSE, "LIF fusion is for the conv rows");
+enum { G3_FC = 0, G3_CONV = 1, G3_CONV_LIF_REG = 2, G3_CONV_LIF_TILE = 3 };
+#define G3_TILE_PITCH 68                            // floats per row of the LIF_TILE current tile in LDS (conflict-free)
+
+template <int MODE, int NB>
+__global__ __launch_bounds__(512, MODE == G3_CONV_LIF_REG ? 2 : 4) void k_gemm_bf16x3(const Gemm3Args args) {
+    constexpr bool CONV = MODE != G3_FC, FUSE = MODE == G3_CONV_LIF_REG, TILE = MODE == G3_CONV_LIF_TILE;
     static_assert(NB == 3 || NB == 4, "ring depth");
     constexpr int SLOT = G3_SLOT;
-    constexpr int PD = (CONV && !FUSE) ? 2 : 3, RING = PD + 1;  // 12 groups per chunk: RING must divide 12 (the un-fused conv
+    constexpr int PD = (CONV && !FUSE) ? 2 : 3, RING = PD + 1;  // 12 groups per chunk: RING must divide 12 (the 128-register conv
                                                                // rows have 128 registers: one fragment less in flight)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
@@ -688,7 +692,7 @@ __global__ __launch_bounds__(512, FUSE ? 2 : 4) void k_gemm_bf16x3(const Gemm3Ar
     const int wm = wave >> 1, wn = wave & 1;
     const int nb = blockIdx.x % args.n_blocks;
     const int mb = blockIdx.x / args.n_blocks;
-    const int m0 = mb * G3_BM;
+    const int m0 = TILE ? mb * args.pb : mb * G3_BM;            // first row (TILE: first position) of the tile
     const int Kc = args.Kc, Np = args.Np, M = args.M;
 
     if (tid < 256) {                                // table entry e: element j = bit j of e as bf16
@@ -701,13 +705,14 @@ __global__ __launch_bounds__(512, FUSE ? 2 : 4) void k_gemm_bf16x3(const Gemm3Ar
     // SGPRs) + (32-bit byte offset of the lane's row): no per-chunk 64-bit vector arithmetic ----
     const bool a_role = wave < 4;
     const int xrow = tid & 255;
-    const int xm = m0 + xrow;
+    const int xt = TILE ? xrow / args.pb : 0;       // TILE: time step of the row
+    const int xm = TILE ? (xt < args.T ? m0 + xrow % args.pb : M) : m0 + xrow;
     uint32_t a_off = 0;                             // bytes: fc row / conv centre tap, channel word 0
     int a_pitch = 0;                                // conv: bytes per image row of the lane's pyramid level
     uint32_t a_valid = 0;                           // conv: 9-bit tap validity
     if (CONV) {
         if (xm < M) {
-            const int t = FUSE ? 0 : xm / args.P_total, p = FUSE ? xm : xm % args.P_total;
+            const int t = FUSE ? 0 : (TILE ? xt : xm / args.P_total), p = (FUSE || TILE) ? xm : xm % args.P_total;
             int l = 0;
             while (l + 1 < args.n_levels && p >= args.lv[l + 1].pos_base) ++l;
             const int H = args.lv[l].H, W = args.lv[l].W;
@@ -764,7 +769,11 @@ __global__ __launch_bounds__(512, FUSE ? 2 : 4) void k_gemm_bf16x3(const Gemm3Ar
         }
     };
     auto store_w = [&](uint32_t w, uint32_t slot_off) {     // the raw spike word of the thread's row
-        if (a_role) *reinterpret_cast<uint32_t*>(ring + slot_off + xrow * 4) = w;
+        if (a_role) {
+            uint32_t l;                             // lane id, re-derived (2 VALU) instead of a register held all loop
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+            *reinterpret_cast<uint32_t*>(ring + slot_off + wave * 256 + l * 4) = w;
+        }
     };
 
     // ---- B staging: LDS-DMA.  Wave w copies rows [16w, 16w+16) of each of the 3 planes (1 KiB per instruction);
@@ -956,6 +965,51 @@ __global__ __launch_bounds__(512, FUSE ? 2 : 4) void k_gemm_bf16x3(const Gemm3Ar
         }
     }
     if (FUSE) return;
+    if (TILE) {
+        // ---- LIF over the T time steps held in this tile.  The accumulators are the complete input currents
+        // cur[t][position][column] of pb positions; in two halves of 64 columns they go through LDS (the ring is
+        // free now), where thread (wave w, lane l) runs the neurons (position w + 8j, column l) over t and the wave
+        // ballot of each step is the 64-bit spike word pair of that (t, position) ----
+        float* const tile = reinterpret_cast<float*>(smem);
+        const int pb = args.pb, T = args.T;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // staged-ahead copies of chunks past the end have landed
+#pragma unroll 1
+        for (int h = 0; h < 2; ++h) {
+            __syncthreads();                               // ring reads done / previous half consumed
+            if (wn == h) {
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            tile[(wm * 64 + mt * 16 + lg * 4 + r) * G3_TILE_PITCH + nt * 16 + lr] = acc[mt][nt][r];
+            }
+            __syncthreads();
+            const int word0 = (nb * G3_BN + h * 64) >> 5;
+            if (word0 * 32 >= Np) continue;                // block-uniform
+            const bool two = (word0 + 1) * 32 < Np;
+            for (int pi = wave; pi < pb; pi += 8) {        // wave-uniform
+                const int pos = m0 + pi;
+                if (pos >= M) break;
+                float vv = args.p.v_leak, ii = 0.0f;
+                uint32_t my0 = 0, my1 = 0;                 // lane t keeps the word pair of time step t
+                const float* src = tile + pi * G3_TILE_PITCH + lane;
+                for (int t = 0; t < T; ++t) {
+                    const bool z = lif_step(src[(size_t)t * pb * G3_TILE_PITCH], vv, ii, args.p);
+                    const unsigned long long b = __ballot(z);
+                    my0 = lane == t ? (uint32_t)b : my0;
+                    my1 = lane == t ? (uint32_t)(b >> 32) : my1;
+                }
+                if (lane < T) {
+                    uint32_t* dst = args.spk + (size_t)lane * args.spk_stride + (size_t)pos * (Np >> 5) + word0;
+                    dst[0] = my0;
+                    if (two) dst[1] = my1;
+                }
+            }
+        }
+        return;
+    }
     // ---- store currents: per instruction 4 rows x 16 columns (64-B row segments) ----
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
@@ -1338,15 +1392,25 @@ int snn_pack_linear_weight_bf16x3(const float* w, int N, int K, uint16_t* packed
     return 0;
 }
 
-static int launch_gemm3(bool conv, const Gemm3Args& a, hipStream_t s) {
-    const bool fuse = conv && a.spk != nullptr;
-    // the fused variant owns its CU (registers): 3 ring slots = 120 KB; the others run two work-groups per CU
-    // (a 4-slot ring - copies need to land only one chunk later - measured no faster for the fused variant: 3.85 vs 3.81 ms)
-    auto kern = fuse ? k_gemm_bf16x3<true, true, 3> : (conv ? k_gemm_bf16x3<true, false, 3> : k_gemm_bf16x3<false, false, 3>);
-    const int lds = G3_LDS(3) + (fuse ? G3_STATE_BYTES : 0);
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+// T-in-tile LIF fusion needs T <= 64 (one lane per time step keeps the spike words) and wastes 256 - T*(256/T) rows
+static bool g3_tile_ok(int T) { return T >= 1 && T <= 64 && T * (G3_BM / T) * 10 >= G3_BM * 9; }
+
+static int launch_gemm3(int mode, const Gemm3Args& a, hipStream_t s) {
+    // LIF_REG owns its CU (256 registers per wave); the others run two work-groups per CU on an 80-KB ring
+    const void* kern;
+    int lds = G3_LDS(3), tiles = cdiv(a.M, G3_BM);
+    switch (mode) {
+    case G3_FC: kern = (const void*)k_gemm_bf16x3<G3_FC, 3>; break;
+    case G3_CONV: kern = (const void*)k_gemm_bf16x3<G3_CONV, 3>; break;
+    case G3_CONV_LIF_REG: kern = (const void*)k_gemm_bf16x3<G3_CONV_LIF_REG, 3>; lds += G3_STATE_BYTES; break;
+    default: kern = (const void*)k_gemm_bf16x3<G3_CONV_LIF_TILE, 3>; tiles = cdiv(a.M, a.pb); break;
+    }
+    static_assert(G3_BM * G3_TILE_PITCH * 4 <= G3_LDS(3), "the LIF_TILE current tile reuses the ring");
+    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return fail(-3, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(kern, dim3(cdiv(a.M, G3_BM) * a.n_blocks), dim3(512), lds, s, a);
+    void* kargs[] = {(void*)&a};
+    e = hipLaunchKernel(kern, dim3(tiles * a.n_blocks), dim3(512), kargs, lds, s);
+    if (e != hipSuccess) return fail(-3, "k_gemm_bf16x3 launch failed: %s", hipGetErrorString(e));
     SNN_CHECK_LAUNCH("k_gemm_bf16x3");
     return 0;
 }
@@ -1360,7 +1424,7 @@ int snn_spike_gemm_bf16x3(const uint32_t* a_rows, int M, int K, int N, const uin
     a.A = a_rows; a.wpk = w_packed; a.out = cur; a.M = M; a.Kc = cdiv(K, 32); a.Np = cdiv(N, 32) * 32; a.ldo = ldo;
     a.plane_elems = (unsigned long long)a.Kc * a.Np * 32;
     a.n_blocks = cdiv(a.Np, G3_BN);
-    return launch_gemm3(false, a, (hipStream_t)s);
+    return launch_gemm3(G3_FC, a, (hipStream_t)s);
 }
 
 static int conv3_common(const char* who, const uint32_t* enc, size_t enc_stride, const snn_rpn_level* lv, int n_levels,
@@ -1394,7 +1458,10 @@ int snn_conv3x3_lif_bf16x3(const uint32_t* enc, size_t enc_stride, const snn_rpn
     int rc = conv3_common("snn_conv3x3_lif_bf16x3", enc, enc_stride, lv, n_levels, C_in, C_out, T, w_packed, a, &P);
     if (rc) return rc;
     a.M = (int)P; a.T = T; a.spk = spk; a.spk_stride = spk_stride; a.p = make_p(p, p->v_th_lif);
-    return launch_gemm3(true, a, (hipStream_t)s);
+    // debug / A-B knob: SNN_BF16X3_LIF=reg forces the register-resident variant (the fallback for T > 64)
+    const char* force = getenv("SNN_BF16X3_LIF");
+    a.pb = (g3_tile_ok(T) && !(force && !strcmp(force, "reg"))) ? G3_BM / T : 0;
+    return launch_gemm3(a.pb ? G3_CONV_LIF_TILE : G3_CONV_LIF_REG, a, (hipStream_t)s);
 }
 
 int snn_spike_conv3x3_bf16x3(const uint32_t* enc, size_t enc_stride, const snn_rpn_level* lv, int n_levels, int C_in,
@@ -1417,7 +1484,7 @@ int snn_spike_conv3x3_bf16x3(const uint32_t* enc, size_t enc_stride, const snn_r
     a.plane_elems = (unsigned long long)a.Kc * a.Np * 32;
     a.P_total = (int)P; a.n_levels = n_levels; a.M = (int)(T * P);
     a.n_blocks = cdiv(a.Np, G3_BN);
-    return launch_gemm3(true, a, (hipStream_t)s);
+    return launch_gemm3(G3_CONV, a, (hipStream_t)s);
 }
 
 static int check_T(int T, const char* who) {

@@ -11,6 +11,7 @@
 
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 // ------------------------------------------------------------------------------------------------
@@ -675,9 +676,13 @@ __device__ __forceinline__ uint32_t bf16_pair(uint32_t w, int j) {      // bits 
 enum { G3_FC = 0, G3_CONV = 1, G3_CONV_LIF_REG = 2, G3_CONV_LIF_TILE = 3 };
 #define G3_TILE_PITCH 68                            // floats per row of the LIF_TILE current tile in LDS (conflict-free)
 
-template <int MODE, int NB>
+// MT = 16-row M-tiles per wave: the work-group tile is 64*MT rows (256; 192 / 128 only where a small problem spreads
+// better over the CUs that way - per unit of work the smaller tiles are slower: fc6 1.03 / 1.07 / 1.21 ms at MT 4 / 3 / 2).
+template <int MODE, int NB, int MT>
 __global__ __launch_bounds__(512, MODE == G3_CONV_LIF_REG ? 2 : 4) void k_gemm_bf16x3(const Gemm3Args args) {
     constexpr bool CONV = MODE != G3_FC, FUSE = MODE == G3_CONV_LIF_REG, TILE = MODE == G3_CONV_LIF_TILE;
+    static_assert(MT >= 2 && MT <= 4 && (MT == 4 || !FUSE), "M-tiles per wave");
+    constexpr int BM = 64 * MT, WROWS = 16 * MT;                // rows per work-group / per wave
     static_assert(NB == 3 || NB == 4, "ring depth");
     constexpr int SLOT = G3_SLOT;
     constexpr int PD = (CONV && !FUSE) ? 2 : 3, RING = PD + 1;  // 12 groups per chunk: RING must divide 12 (the 128-register conv
@@ -692,7 +697,7 @@ __global__ __launch_bounds__(512, MODE == G3_CONV_LIF_REG ? 2 : 4) void k_gemm_b
     const int wm = wave >> 1, wn = wave & 1;
     const int nb = blockIdx.x % args.n_blocks;
     const int mb = blockIdx.x / args.n_blocks;
-    const int m0 = TILE ? mb * args.pb : mb * G3_BM;            // first row (TILE: first position) of the tile
+    const int m0 = TILE ? mb * args.pb : mb * BM;            // first row (TILE: first position) of the tile
     const int Kc = args.Kc, Np = args.Np, M = args.M;
 
     if (tid < 256) {                                // table entry e: element j = bit j of e as bf16
@@ -703,7 +708,7 @@ __global__ __launch_bounds__(512, MODE == G3_CONV_LIF_REG ? 2 : 4) void k_gemm_b
 
     // ---- A staging role: waves 0-3, thread -> row.  A spike word is addressed as (wave-uniform 64-bit base in
     // SGPRs) + (32-bit byte offset of the lane's row): no per-chunk 64-bit vector arithmetic ----
-    const bool a_role = wave < 4;
+    const bool a_role = wave < MT;
     const int xrow = tid & 255;
     const int xt = TILE ? xrow / args.pb : 0;       // TILE: time step of the row
     const int xm = TILE ? (xt < args.T ? m0 + xrow % args.pb : M) : m0 + xrow;
@@ -797,14 +802,14 @@ __global__ __launch_bounds__(512, MODE == G3_CONV_LIF_REG ? 2 : 4) void k_gemm_b
 
     // 16x16 tiles: lane holds column lane&15, rows (lane>>4)*4 + reg of each tile
     const int lr = lane & 15, lg = lane >> 4;
-    f32x4 acc[4][4];
+    f32x4 acc[MT][4];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
     // A fragment: row (wm*64 + mt*16 + lr), k = 8*lg .. 8*lg+7  ->  table[byte lg of the row's spike word]
-    const unsigned char* const w_rd = ring + (wm * 64 + lr) * 4;                             // + slot offset, mt*64
+    const unsigned char* const w_rd = ring + (wm * WROWS + lr) * 4;                          // + slot offset, mt*64
     const int lg8 = 8 * lg;
     auto rd_w = [&](uint32_t slot_off, int mt) { return *reinterpret_cast<const uint32_t*>(w_rd + slot_off + mt * 64); };
     auto rd_a = [&](uint32_t w) { return *reinterpret_cast<const bf16x8*>(lut + (__builtin_amdgcn_ubfe(w, lg8, 8) << 4)); };
@@ -858,12 +863,12 @@ __global__ __launch_bounds__(512, MODE == G3_CONV_LIF_REG ? 2 : 4) void k_gemm_b
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     }
-    bf16x8 af[2][4], bq[RING];
-    uint32_t wq[4];
+    bf16x8 af[2][MT], bq[RING];
+    uint32_t wq[MT];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) wq[mt] = rd_w(0, mt);
+    for (int mt = 0; mt < MT; ++mt) wq[mt] = rd_w(0, mt);
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) af[0][mt] = rd_a(wq[mt]);
+    for (int mt = 0; mt < MT; ++mt) af[0][mt] = rd_a(wq[mt]);
 #pragma unroll
     for (int g = 0; g < PD; ++g) bq[g] = rd_b(0, g);
 
@@ -880,9 +885,9 @@ __global__ __launch_bounds__(512, MODE == G3_CONV_LIF_REG ? 2 : 4) void k_gemm_b
                 bq[gp % RING] = gp < 12 ? rd_b(o_cur, gp) : rd_b(o_nxt, gp - 12);
                 if (g == 4) {
 #pragma unroll
-                    for (int mt = 0; mt < 4; ++mt) wq[mt] = rd_w(o_nxt, mt);
+                    for (int mt = 0; mt < MT; ++mt) wq[mt] = rd_w(o_nxt, mt);
                 }
-                if (g >= 8) af[u ^ 1][g - 8] = rd_a(wq[g - 8]);
+                if (g >= 8 && g - 8 < MT) af[u ^ 1][g - 8] = rd_a(wq[g - 8]);
 #ifndef SNN_EXP_NO_STORE_A
                 if (g == 0) store_w(w_hold, o_nn);
 #endif
@@ -893,7 +898,7 @@ __global__ __launch_bounds__(512, MODE == G3_CONV_LIF_REG ? 2 : 4) void k_gemm_b
 #endif
                 }
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
+                for (int mt = 0; mt < MT; ++mt)
                     acc[mt][g / 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u][mt], bq[g % RING], acc[mt][g / 3], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -978,12 +983,12 @@ __global__ __launch_bounds__(512, MODE == G3_CONV_LIF_REG ? 2 : 4) void k_gemm_b
             __syncthreads();                               // ring reads done / previous half consumed
             if (wn == h) {
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
+                for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            tile[(wm * 64 + mt * 16 + lg * 4 + r) * G3_TILE_PITCH + nt * 16 + lr] = acc[mt][nt][r];
+                            tile[(wm * WROWS + mt * 16 + lg * 4 + r) * G3_TILE_PITCH + nt * 16 + lr] = acc[mt][nt][r];
             }
             __syncthreads();
             const int word0 = (nb * G3_BN + h * 64) >> 5;
@@ -1012,14 +1017,14 @@ __global__ __launch_bounds__(512, MODE == G3_CONV_LIF_REG ? 2 : 4) void k_gemm_b
     }
     // ---- store currents: per instruction 4 rows x 16 columns (64-B row segments) ----
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             const int col = nb * G3_BN + wn * 64 + nt * 16 + lr;
             if (col >= Np) continue;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wm * 64 + mt * 16 + lg * 4 + r;
+                const int m = m0 + wm * WROWS + mt * 16 + lg * 4 + r;
                 if (m < M) args.out[(size_t)m * args.ldo + col] = acc[mt][nt][r];
             }
         }
@@ -1322,6 +1327,39 @@ static void li_kappa(const snn_params* p, int T, Kappa* k) {
 // ================================================================================================
 // C ABI
 // ================================================================================================
+static int g3_slots() {                       // CUs: two co-resident work-groups share a CU's matrix pipe, so the tail is
+                                              // quantised per CU, not per work-group slot (fc6: MT=4 1.03 ms, MT=3 1.07 ms)
+    static int slots = 0;
+    if (!slots) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+        slots = cus;
+    }
+    return slots;
+}
+
+// M-tiles per wave (work-group rows = 64*MT): fewest rounds of work-groups x (tile work + per-chunk staging overhead)
+template <typename F>
+static int g3_pick_mt(F tiles_of) {
+    int best = 0;
+    double best_cost = 0;
+    const char* force = getenv("SNN_BF16X3_MT");              // debug / A-B knob: 2, 3 or 4
+    for (int mt = 4; mt >= 2; --mt) {
+        const long long wgs = tiles_of(mt);
+        if (wgs <= 0) continue;
+        if (force && atoi(force) == mt) return mt;
+        const double cost = (double)((wgs + g3_slots() - 1) / g3_slots()) * (mt + 0.5);
+        if (best_cost == 0 || cost < best_cost * 0.97) { best = mt; best_cost = cost; }
+    }
+    return best;
+}
+
+template <int MODE>
+static const void* g3_kernel(int mt) {
+    return mt == 4 ? (const void*)k_gemm_bf16x3<MODE, 3, 4> : mt == 3 ? (const void*)k_gemm_bf16x3<MODE, 3, 3> : (const void*)k_gemm_bf16x3<MODE, 3, 2>;
+}
+
 extern "C" {
 
 int snn_version(void) { return 1; }
@@ -1392,18 +1430,18 @@ int snn_pack_linear_weight_bf16x3(const float* w, int N, int K, uint16_t* packed
     return 0;
 }
 
-// T-in-tile LIF fusion needs T <= 64 (one lane per time step keeps the spike words) and wastes 256 - T*(256/T) rows
-static bool g3_tile_ok(int T) { return T >= 1 && T <= 64 && T * (G3_BM / T) * 10 >= G3_BM * 9; }
+// T-in-tile LIF fusion needs T <= 64 (one lane per time step keeps the spike words) and wastes rows % T rows per tile
+static bool g3_tile_ok(int T, int rows) { return T >= 1 && T <= 64 && T <= rows && T * (rows / T) * 10 >= rows * 9; }
 
-static int launch_gemm3(int mode, const Gemm3Args& a, hipStream_t s) {
+static int launch_gemm3(int mode, int mt, const Gemm3Args& a, hipStream_t s) {
     // LIF_REG owns its CU (256 registers per wave); the others run two work-groups per CU on an 80-KB ring
     const void* kern;
-    int lds = G3_LDS(3), tiles = cdiv(a.M, G3_BM);
+    int lds = G3_LDS(3), tiles = cdiv(a.M, 64 * mt);
     switch (mode) {
-    case G3_FC: kern = (const void*)k_gemm_bf16x3<G3_FC, 3>; break;
-    case G3_CONV: kern = (const void*)k_gemm_bf16x3<G3_CONV, 3>; break;
-    case G3_CONV_LIF_REG: kern = (const void*)k_gemm_bf16x3<G3_CONV_LIF_REG, 3>; lds += G3_STATE_BYTES; break;
-    default: kern = (const void*)k_gemm_bf16x3<G3_CONV_LIF_TILE, 3>; tiles = cdiv(a.M, a.pb); break;
+    case G3_FC: kern = g3_kernel<G3_FC>(mt); break;
+    case G3_CONV: kern = g3_kernel<G3_CONV>(mt); break;
+    case G3_CONV_LIF_REG: kern = (const void*)k_gemm_bf16x3<G3_CONV_LIF_REG, 3, 4>; lds += G3_STATE_BYTES; break;
+    default: kern = g3_kernel<G3_CONV_LIF_TILE>(mt); tiles = cdiv(a.M, a.pb); break;
     }
     static_assert(G3_BM * G3_TILE_PITCH * 4 <= G3_LDS(3), "the LIF_TILE current tile reuses the ring");
     hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -1424,7 +1462,8 @@ int snn_spike_gemm_bf16x3(const uint32_t* a_rows, int M, int K, int N, const uin
     a.A = a_rows; a.wpk = w_packed; a.out = cur; a.M = M; a.Kc = cdiv(K, 32); a.Np = cdiv(N, 32) * 32; a.ldo = ldo;
     a.plane_elems = (unsigned long long)a.Kc * a.Np * 32;
     a.n_blocks = cdiv(a.Np, G3_BN);
-    return launch_gemm3(G3_FC, a, (hipStream_t)s);
+    const int mt = g3_pick_mt([&](int m) { return (long long)cdiv(M, 64 * m) * a.n_blocks; });
+    return launch_gemm3(G3_FC, mt, a, (hipStream_t)s);
 }
 
 static int conv3_common(const char* who, const uint32_t* enc, size_t enc_stride, const snn_rpn_level* lv, int n_levels,
@@ -1460,8 +1499,13 @@ int snn_conv3x3_lif_bf16x3(const uint32_t* enc, size_t enc_stride, const snn_rpn
     a.M = (int)P; a.T = T; a.spk = spk; a.spk_stride = spk_stride; a.p = make_p(p, p->v_th_lif);
     // debug / A-B knob: SNN_BF16X3_LIF=reg forces the register-resident variant (the fallback for T > 64)
     const char* force = getenv("SNN_BF16X3_LIF");
-    a.pb = (g3_tile_ok(T) && !(force && !strcmp(force, "reg"))) ? G3_BM / T : 0;
-    return launch_gemm3(a.pb ? G3_CONV_LIF_TILE : G3_CONV_LIF_REG, a, (hipStream_t)s);
+    if (force && !strcmp(force, "reg")) return launch_gemm3(G3_CONV_LIF_REG, 4, a, (hipStream_t)s);
+    int mt = 0;
+    if (g3_tile_ok(T, 256) || g3_tile_ok(T, 192) || g3_tile_ok(T, 128))
+        mt = g3_pick_mt([&](int m) { return g3_tile_ok(T, 64 * m) ? (long long)cdiv(P, (64 * m) / T) * a.n_blocks : 0ll; });
+    if (!mt) return launch_gemm3(G3_CONV_LIF_REG, 4, a, (hipStream_t)s);
+    a.pb = (64 * mt) / T;
+    return launch_gemm3(G3_CONV_LIF_TILE, mt, a, (hipStream_t)s);
 }
 
 int snn_spike_conv3x3_bf16x3(const uint32_t* enc, size_t enc_stride, const snn_rpn_level* lv, int n_levels, int C_in,
@@ -1484,7 +1528,8 @@ int snn_spike_conv3x3_bf16x3(const uint32_t* enc, size_t enc_stride, const snn_r
     a.plane_elems = (unsigned long long)a.Kc * a.Np * 32;
     a.P_total = (int)P; a.n_levels = n_levels; a.M = (int)(T * P);
     a.n_blocks = cdiv(a.Np, G3_BN);
-    return launch_gemm3(G3_CONV, a, (hipStream_t)s);
+    const int mt = g3_pick_mt([&](int m) { return (long long)cdiv(a.M, 64 * m) * a.n_blocks; });
+    return launch_gemm3(G3_CONV, mt, a, (hipStream_t)s);
 }
 
 static int check_T(int T, const char* who) {

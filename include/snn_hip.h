@@ -199,6 +199,12 @@ int snn_pack_linear_weight_bf16x3(const float* w_nk, int N, int K, uint16_t* pac
 /* cur[M][ldo] = A_bits[M][K] x W[K][N] */
 int snn_spike_gemm_bf16x3(const uint32_t* a_rows, int M, int K, int N, const uint16_t* w_packed, float* cur,
                           int ldo, snn_stream_t stream);
+/* Linear layer + LIF over all T steps in one launch (faster_rcnn.py:498-499 / 500-501): a_planes [T][R][K/32] spike
+ * bit-planes in, spk [T][R][N/32 words] out (spk_stride = words per time plane).  A row tile of the GEMM holds all T
+ * steps of its RoIs, so the input currents and the LIF state never leave the chip.  Returns -4 when T does not fit a
+ * row tile (T > 64 or a poor divisor of 256/192/128): use snn_spike_gemm_bf16x3 + snn_lif_scan then. */
+int snn_spike_gemm_lif_bf16x3(const uint32_t* a_planes, int T, int R, int K, int N, const snn_params* p,
+                              const uint16_t* w_packed, uint32_t* spk, size_t spk_stride, snn_stream_t stream);
 /* 3x3 spike convolution + LIF fused over T on the bf16 matrix cores, all levels in one launch:
  * enc planes [T][P][Cw] -> spk planes [T][P][Nw]; the membrane state never leaves the registers */
 int snn_conv3x3_lif_bf16x3(const uint32_t* enc, size_t enc_stride_words, const snn_rpn_level* levels_host,

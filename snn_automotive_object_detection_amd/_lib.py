@@ -76,6 +76,8 @@ SYMBOLS = {
     "snn_packed_linear_bf16x3_elems": (C.c_size_t, [C.c_int, C.c_int]),
     "snn_pack_linear_weight_bf16x3": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, c_stream]),
     "snn_spike_gemm_bf16x3": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, c_stream]),
+    "snn_spike_gemm_lif_bf16x3": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_size_t, c_stream]),
     "snn_conv3x3_lif_bf16x3": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(snn_rpn_level), C.c_int, C.c_int, C.c_int,
                                          C.c_int, C.POINTER(snn_params), C.c_void_p, C.c_void_p, C.c_size_t, c_stream]),
     "snn_spike_conv3x3_bf16x3": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(snn_rpn_level), C.c_int, C.c_int, C.c_int,

@@ -673,14 +673,15 @@ __device__ __forceinline__ uint32_t bf16_pair(uint32_t w, int j) {      // bits 
 // instructions + 2 ds_write_b128 per thread and chunk on it, 10 % of the kernel: every VALU instruction beside
 // v_mfma_f32_16x16x32_bf16 competes for the SIMD's vector issue, which the MFMAs alone hold half of the time).
 // PD = fragment prefetch distance inside a chunk, in groups of 4 MFMAs (one weight fragment per group).
-enum { G3_FC = 0, G3_CONV = 1, G3_CONV_LIF_REG = 2, G3_CONV_LIF_TILE = 3 };
+enum { G3_FC = 0, G3_CONV = 1, G3_CONV_LIF_REG = 2, G3_CONV_LIF_TILE = 3, G3_FC_LIF_TILE = 4 };
 #define G3_TILE_PITCH 68                            // floats per row of the LIF_TILE current tile in LDS (conflict-free)
 
 // MT = 16-row M-tiles per wave: the work-group tile is 64*MT rows (256; 192 / 128 only where a small problem spreads
 // better over the CUs that way - per unit of work the smaller tiles are slower: fc6 1.03 / 1.07 / 1.21 ms at MT 4 / 3 / 2).
 template <int MODE, int NB, int MT>
 __global__ __launch_bounds__(512, MODE == G3_CONV_LIF_REG ? 2 : 4) void k_gemm_bf16x3(const Gemm3Args args) {
-    constexpr bool CONV = MODE != G3_FC, FUSE = MODE == G3_CONV_LIF_REG, TILE = MODE == G3_CONV_LIF_TILE;
+    constexpr bool CONV = MODE == G3_CONV || MODE == G3_CONV_LIF_REG || MODE == G3_CONV_LIF_TILE;
+    constexpr bool FUSE = MODE == G3_CONV_LIF_REG, TILE = MODE == G3_CONV_LIF_TILE || MODE == G3_FC_LIF_TILE;
     static_assert(MT >= 2 && MT <= 4 && (MT == 4 || !FUSE), "M-tiles per wave");
     constexpr int BM = 64 * MT, WROWS = 16 * MT;                // rows per work-group / per wave
     static_assert(NB == 3 || NB == 4, "ring depth");
@@ -732,6 +733,8 @@ __global__ __launch_bounds__(512, MODE == G3_CONV_LIF_REG ? 2 : 4) void k_gemm_b
                 a_valid |= (uint32_t)(yy >= 0 && yy < H && xx >= 0 && xx < W) << tap;
             }
         }
+    } else if (TILE) {                              // fc rows of the spike planes [T][M][Kc]; unused tile rows read row 0
+        a_off = xm < M ? (uint32_t)(((size_t)xt * M + xm) * Kc * 4) : 0u;
     } else {
         a_off = (uint32_t)((size_t)min(xm, M - 1) * Kc * 4);
     }
@@ -1441,7 +1444,8 @@ static int launch_gemm3(int mode, int mt, const Gemm3Args& a, hipStream_t s) {
     case G3_FC: kern = g3_kernel<G3_FC>(mt); break;
     case G3_CONV: kern = g3_kernel<G3_CONV>(mt); break;
     case G3_CONV_LIF_REG: kern = (const void*)k_gemm_bf16x3<G3_CONV_LIF_REG, 3, 4>; lds += G3_STATE_BYTES; break;
-    default: kern = g3_kernel<G3_CONV_LIF_TILE>(mt); tiles = cdiv(a.M, a.pb); break;
+    case G3_CONV_LIF_TILE: kern = g3_kernel<G3_CONV_LIF_TILE>(mt); tiles = cdiv(a.M, a.pb); break;
+    default: kern = g3_kernel<G3_FC_LIF_TILE>(mt); tiles = cdiv(a.M, a.pb); break;
     }
     static_assert(G3_BM * G3_TILE_PITCH * 4 <= G3_LDS(3), "the LIF_TILE current tile reuses the ring");
     hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -1464,6 +1468,24 @@ int snn_spike_gemm_bf16x3(const uint32_t* a_rows, int M, int K, int N, const uin
     a.n_blocks = cdiv(a.Np, G3_BN);
     const int mt = g3_pick_mt([&](int m) { return (long long)cdiv(M, 64 * m) * a.n_blocks; });
     return launch_gemm3(G3_FC, mt, a, (hipStream_t)s);
+}
+
+int snn_spike_gemm_lif_bf16x3(const uint32_t* a_planes, int T, int R, int K, int N, const snn_params* p,
+                              const uint16_t* w_packed, uint32_t* spk, size_t spk_stride, snn_stream_t s) {
+    if (!a_planes || !w_packed || !spk || !p || R <= 0 || K <= 0 || N <= 0)
+        return fail(-1, "snn_spike_gemm_lif_bf16x3: bad argument");
+    if (check_T(T, "snn_spike_gemm_lif_bf16x3")) return -1;
+    if ((long long)T * R * cdiv(K, 32) * 4 > 0xffffffffLL) return fail(-1, "snn_spike_gemm_lif_bf16x3: input planes over 4 GB");
+    Gemm3Args a;
+    memset(&a, 0, sizeof(a));
+    a.A = a_planes; a.wpk = w_packed; a.M = R; a.Kc = cdiv(K, 32); a.Np = cdiv(N, 32) * 32;
+    a.plane_elems = (unsigned long long)a.Kc * a.Np * 32;
+    a.n_blocks = cdiv(a.Np, G3_BN);
+    a.T = T; a.spk = spk; a.spk_stride = spk_stride; a.p = make_p(p, p->v_th_lif);
+    const int mt = g3_pick_mt([&](int m) { return g3_tile_ok(T, 64 * m) ? (long long)cdiv(R, (64 * m) / T) * a.n_blocks : 0ll; });
+    if (!mt) return fail(-4, "snn_spike_gemm_lif_bf16x3: T=%d does not fit a row tile (use snn_spike_gemm_bf16x3 + snn_lif_scan)", T);
+    a.pb = (64 * mt) / T;
+    return launch_gemm3(G3_FC_LIF_TILE, mt, a, (hipStream_t)s);
 }
 
 static int conv3_common(const char* who, const uint32_t* enc, size_t enc_stride, const snn_rpn_level* lv, int n_levels,
@@ -1837,6 +1859,14 @@ static int det_head_from_planes(int R, int D, int Hd, int K, int K4, int T, cons
     if (spk7_count) { if (hipMemsetAsync(spk7_count, 0, sizeof(uint32_t) * R, s) != hipSuccess) return fail(-3, "hipMemsetAsync failed"); }
     const bool b3 = p->precision == SNN_PRECISION_BF16X3;
     if (p->precision != SNN_PRECISION_F32 && !b3) return fail(-1, "snn_det_head_forward: unknown precision %d", p->precision);
+    if (b3 && !spk6_count && !spk7_count && (g3_tile_ok(T, 256) || g3_tile_ok(T, 192) || g3_tile_ok(T, 128))) {
+        // fc6 + LIF and fc7 + LIF, each one launch: a row tile holds all T steps of its RoIs, the currents never
+        // leave the chip (faster_rcnn.py:498-501)
+        if ((rc = snn_spike_gemm_lif_bf16x3(enc, T, R, D, Hd, p, (const uint16_t*)w6_packed, s6, (size_t)R * Hw, stream))) return rc;
+        if ((rc = snn_spike_gemm_lif_bf16x3(s6, T, R, Hd, Hd, p, (const uint16_t*)w7_packed, s7, (size_t)R * Hw, stream))) return rc;
+        return snn_li_heads(s7, (size_t)R * Hw, T, R, Hd, w_heads_packed, K, K4, p, out_cls, out_bbox, sum_cls,
+                            sum_bbox, stream);
+    }
     // fc6 for all T steps at once: rows m = t*R + r   (faster_rcnn.py:498)
     rc = b3 ? snn_spike_gemm_bf16x3(enc, T * R, D, Hd, (const uint16_t*)w6_packed, cur, Hp, stream)
             : snn_spike_gemm(enc, T * R, D, Hd, (const float*)w6_packed, cur, Hp, stream);

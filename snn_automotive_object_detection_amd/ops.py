@@ -129,6 +129,18 @@ def spike_gemm_bf16x3(a_rows: torch.Tensor, K: int, N: int, w_packed: torch.Tens
     return cur
 
 
+def spike_gemm_lif_bf16x3(a_planes: torch.Tensor, K: int, N: int, p: snn_params, w_packed: torch.Tensor) -> torch.Tensor:
+    """a_planes int32 [T, R, Kw] -> LIF spike planes int32 [T, R, Nw]: linear layer + LIF over T in one launch"""
+    _need_gpu(a_planes, "spike planes")
+    lib = _lib.load()
+    T, R, _ = a_planes.shape
+    Nw = cdiv(N, 32)
+    spk = torch.empty((T, R, Nw), dtype=torch.int32, device=a_planes.device)
+    _lib.check(lib.snn_spike_gemm_lif_bf16x3(_ptr(a_planes), T, R, K, N, C.byref(p), _ptr(w_packed), _ptr(spk), R * Nw,
+                                             _stream()), "snn_spike_gemm_lif_bf16x3")
+    return spk
+
+
 def conv3x3_lif_bf16x3(enc: torch.Tensor, shapes, C_in: int, C_out: int, p: snn_params, w_packed: torch.Tensor) -> torch.Tensor:
     """enc int32 [T, P, Cw] over levels `shapes` = [(N,H,W), ...] -> shared-LIF spike planes int32 [T, P, Nw]"""
     _need_gpu(enc, "enc planes")

@@ -15,7 +15,7 @@ import torch.nn.functional as F
 
 from oracle import fixtures as FX
 from oracle import snn_oracle as OR
-from tests._util import planes_to_dense, dense_to_planes, nchw_to_rows
+from tests._util import planes_to_dense, dense_to_planes, nchw_to_rows, flip_budget
 
 pytestmark = pytest.mark.gpu
 
@@ -163,6 +163,28 @@ def test_spike_gemm_bf16x3_teacher_forced(S, gpu_device, name):
     # the two kernel families agree far below the tolerance
     cur6_f32 = S.spike_gemm(zp.view(T * R, -1), D, Hd, S.pack_linear(w6.to(gpu_device)))
     assert (cur6 - cur6_f32).abs().max() <= 5e-6
+
+
+@pytest.mark.parametrize("name", sorted(FX.DET_SPECS))
+def test_spike_gemm_lif_bf16x3_teacher_forced(S, gpu_device, name):
+    """fc + LIF fused over T inside the row tile: spikes of fc6 / fc7 from the oracle's input spikes"""
+    spec = FX.DET_SPECS[name]
+    T, Hd = spec["T"], spec["Hd"]
+    x, w6, w7, wc, wb = FX.det_inputs(spec)
+    R, D = x.shape[0], x[0].numel()
+    _, _, tr = OR.det_head_forward(x, w6, w7, wc, wb, T, trace=True)
+    p = _params(S)
+    zp = dense_to_planes(tr["z"].numpy()).to(gpu_device)
+    s6 = S.spike_gemm_lif_bf16x3(zp, D, Hd, p, S.pack_linear_bf16x3(w6.to(gpu_device)))
+    got6 = planes_to_dense(s6, Hd)
+    assert (got6 != tr["spk6"].numpy()).any(axis=(0, 2)).sum() <= flip_budget(R, Hd, T)
+    # identical to the un-fused pair on the same operands (same accumulation order, same LIF arithmetic)
+    cur6 = S.spike_gemm_bf16x3(zp.view(T * R, -1), D, Hd, S.pack_linear_bf16x3(w6.to(gpu_device)))
+    ref6 = S.lif_scan(cur6.view(T, R, -1), Hd, p)
+    assert torch.equal(ref6[..., :s6.shape[-1]], s6)
+    s6p = dense_to_planes(tr["spk6"].numpy()).to(gpu_device)
+    s7 = S.spike_gemm_lif_bf16x3(s6p, Hd, Hd, p, S.pack_linear_bf16x3(w7.to(gpu_device)))
+    assert (planes_to_dense(s7, Hd) != tr["spk7"].numpy()).any(axis=(0, 2)).sum() <= flip_budget(R, Hd, T)
 
 
 @pytest.mark.parametrize("name", sorted(FX.RPN_SPECS))

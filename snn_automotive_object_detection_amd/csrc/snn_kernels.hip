@@ -696,6 +696,9 @@ __global__ __launch_bounds__(512, MODE == G3_CONV_LIF_REG ? 2 : 4) void k_gemm_b
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
+    // Plain row-major tile order: column blocks of a row tile are neighbours in dispatch order.  (An XCD-aware order -
+    // each XCD a contiguous eighth of the row tiles - ran at the same speed and TRIPLED the L2 fills of the conv
+    // kernel, FETCH_SIZE 102 -> 323 MB per launch: profiles/r1_h_*; removed.)
     const int nb = blockIdx.x % args.n_blocks;
     const int mb = blockIdx.x / args.n_blocks;
     const int m0 = TILE ? mb * args.pb : mb * BM;            // first row (TILE: first position) of the tile

@@ -28,6 +28,37 @@ __device__ __forceinline__ bool enc_step(const float x, float& v, const NeuronP&
     return z;
 }
 
+// The encoders are VALU-bound, not HBM-bound (10 instructions per neuron-step against 4 bytes read once), and packed
+// fp32 instructions run at half rate on gfx950, so what helps is fewer operations.  ZR = (v_leak == 0 && v_reset == 0),
+// Norse's defaults and the reference's: three identities, each exact in IEEE arithmetic with gradual underflow,
+//   (0 - v) + x == x - v,      v - (v - 0) == +0 (finite v),      (v - v_th > 0) == (v > v_th)
+// bring a step to  sub, mul, add, cmp, select  (+ v_addc for  word = 2*word + spike).  Any other parameters take the
+// op-for-op path.  Callers of enc_step_word feed the elements of a plane word from bit 31 down to bit 0.
+template <bool ZR>
+__device__ __forceinline__ void enc_step_word(const float x, float& v, const NeuronP& p, uint32_t& word) {
+    if (ZR) {
+        v = __fadd_rn(v, __fmul_rn(p.ca, __fsub_rn(x, v)));
+        asm("v_cmp_lt_f32 vcc, %2, %1\n\tv_cndmask_b32 %1, %1, 0, vcc\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+            : "+v"(word), "+v"(v) : "s"(p.v_th) : "vcc");
+    } else {
+        v = __fadd_rn(v, __fmul_rn(p.ca, __fadd_rn(__fsub_rn(p.v_leak, v), x)));
+        const float th = __fsub_rn(v, p.v_th), vr = __fsub_rn(v, __fsub_rn(v, p.v_reset));
+        asm("v_cmp_lt_f32 vcc, 0, %2\n\tv_cndmask_b32 %1, %1, %3, vcc\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+            : "+v"(word), "+v"(v) : "v"(th), "v"(vr) : "vcc");
+    }
+}
+// same arithmetic, the spike returned as a predicate (for ballot-based plane words)
+template <bool ZR>
+__device__ __forceinline__ bool enc_step_t(const float x, float& v, const NeuronP& p) {
+    if (ZR) {
+        v = __fadd_rn(v, __fmul_rn(p.ca, __fsub_rn(x, v)));
+        const bool z = v > p.v_th;
+        v = z ? 0.0f : v;
+        return z;
+    }
+    return enc_step(x, v, p);
+}
+
 // lif_feed_forward_step (norse lif.py; reference rpn.py:106, faster_rcnn.py:499,501)
 //   v_dec = v + ca*((v_leak - v) + i)   (OLD i);   i_dec = i + cb*i;   z = (v_dec - v_th > 0)
 //   v = (1-z)*v_dec + z*v_reset;   i = i_dec + cur

@@ -99,29 +99,41 @@ __global__ void k_pack_heads(const float* __restrict__ wa, int NA, const float* 
 
 // ------------------------------------------------------------------------------------------------
 // K1a: constant-current LIF encoder, NCHW fp32 -> bit-planes [T][N*HW][Cw]
-// one thread = one position x one group of 32 channels; global reads are coalesced along W.
-// HBM-bound streaming kernel: reads 4 B/element once, writes T/8 B/element... (T bits)
+// Block = 32 positions x 8 channel words; thread = one position x 32 channels (reads coalesced along W, two 128-B
+// segments per wave instruction).  The T words of a thread go through LDS so that every plane store of the block is
+// one contiguous run of 32 positions x 8 words (1 KB at C = 256) instead of 4-byte pieces at a 32-byte pitch.
+// VALU-bound (32 x T encoder steps per thread): packed fp32 arithmetic, see enc_step2_word.
 // ------------------------------------------------------------------------------------------------
+#define ENC_PB 32                                   // positions per block
+template <bool ZR>
 __global__ __launch_bounds__(256) void k_encode_nchw(const float* __restrict__ feat, int C, int HW, int Cw,
                                                      int T, NeuronP p, uint32_t* __restrict__ planes,
                                                      size_t plane_stride) {
-    const int pos = blockIdx.x * 256 + threadIdx.x;
-    const int cg = blockIdx.y;
+    __shared__ uint32_t wbuf[SNN_MAX_STEPS * ENC_PB * 9];      // [t][position][8 words + 1 pad]
+    const int pl = threadIdx.x & 31, cgl = threadIdx.x >> 5;
+    const int pos = blockIdx.x * ENC_PB + pl;
+    const int cg = blockIdx.y * 8 + cgl;
     const int n = blockIdx.z;
-    if (pos >= HW) return;
     float x[32], v[32];
 #pragma unroll
     for (int j = 0; j < 32; ++j) {
         const int c = cg * 32 + j;
-        x[j] = (c < C) ? feat[((size_t)n * C + c) * HW + pos] : 0.0f;
+        x[j] = (pos < HW && c < C) ? feat[((size_t)n * C + c) * HW + pos] : 0.0f;
         v[j] = 0.0f;                              // rpn.py:93  v = zeros
     }
-    uint32_t* out = planes + ((size_t)n * HW + pos) * Cw + cg;
     for (int t = 0; t < T; ++t) {
         uint32_t word = 0;
 #pragma unroll
-        for (int j = 0; j < 32; ++j) word |= (uint32_t)enc_step(x[j], v[j], p) << j;
-        out[(size_t)t * plane_stride] = word;
+        for (int j = 31; j >= 0; --j) enc_step_word<ZR>(x[j], v[j], p, word);   // bit 31 first ... bit 0 last
+        wbuf[(t * ENC_PB + pl) * 9 + cgl] = word;
+    }
+    __syncthreads();
+    // store: thread -> (position tid >> 3, word tid & 7): consecutive threads write consecutive plane words
+    const int sp = threadIdx.x >> 3, sw = threadIdx.x & 7;
+    const int spos = blockIdx.x * ENC_PB + sp, scg = blockIdx.y * 8 + sw;
+    if (spos < HW && scg < Cw) {
+        uint32_t* out = planes + ((size_t)n * HW + spos) * Cw + scg;
+        for (int t = 0; t < T; ++t) out[(size_t)t * plane_stride] = wbuf[(t * ENC_PB + sp) * 9 + sw];
     }
 }
 
@@ -129,6 +141,7 @@ __global__ __launch_bounds__(256) void k_encode_nchw(const float* __restrict__ f
 // slot, so one ballot per step IS two plane words.  Each thread runs ENC_U independent elements (64 apart) to keep
 // several loads and scan chains in flight.
 #define ENC_U 4
+template <bool ZR>
 __global__ __launch_bounds__(256) void k_encode_rows(const float* __restrict__ x, int R, int D, int Dw, int T,
                                                      NeuronP p, uint32_t* __restrict__ planes,
                                                      size_t plane_stride) {
@@ -151,7 +164,7 @@ __global__ __launch_bounds__(256) void k_encode_rows(const float* __restrict__ x
     for (int t = 0; t < T; ++t) {
 #pragma unroll
         for (int u = 0; u < ENC_U; ++u) {
-            const bool z = enc_step(xv[u], v[u], p);
+            const bool z = enc_step_t<ZR>(xv[u], v[u], p);
             const unsigned long long m = __ballot(z);
             if ((lane & 31) == 0 && e[u] < total)
                 planes[(size_t)t * plane_stride + (e[u] >> 5)] = (lane < 32) ? (uint32_t)m : (uint32_t)(m >> 32);
@@ -1333,6 +1346,12 @@ static void li_kappa(const snn_params* p, int T, Kappa* k) {
 // ================================================================================================
 // C ABI
 // ================================================================================================
+// encoder fast path: Norse's default rest / reset potentials (SNN_ENC_GENERIC=1 forces the op-for-op kernels: test knob)
+static bool enc_zero_rest(const NeuronP& p) {
+    const char* g = getenv("SNN_ENC_GENERIC");
+    return p.v_leak == 0.0f && p.v_reset == 0.0f && !(g && g[0] == '1');
+}
+
 static int g3_slots() {                       // CUs: two co-resident work-groups share a CU's matrix pipe, so the tail is
                                               // quantised per CU, not per work-group slot (fc6: MT=4 1.03 ms, MT=3 1.07 ms)
     static int slots = 0;
@@ -1466,6 +1485,7 @@ int snn_spike_gemm_bf16x3(const uint32_t* a_rows, int M, int K, int N, const uin
         return fail(-1, "snn_spike_gemm_bf16x3: bad argument");
     Gemm3Args a;
     memset(&a, 0, sizeof(a));
+    if ((long long)M * cdiv(K, 32) * 4 > 0xffffffffLL) return fail(-1, "snn_spike_gemm_bf16x3: spike rows over 4 GB");
     a.A = a_rows; a.wpk = w_packed; a.out = cur; a.M = M; a.Kc = cdiv(K, 32); a.Np = cdiv(N, 32) * 32; a.ldo = ldo;
     a.plane_elems = (unsigned long long)a.Kc * a.Np * 32;
     a.n_blocks = cdiv(a.Np, G3_BN);
@@ -1504,6 +1524,9 @@ static int conv3_common(const char* who, const uint32_t* enc, size_t enc_stride,
         P += (long long)lv[l].N * lv[l].H * lv[l].W;
     }
     if ((long long)T * P > 0x7fffffffLL) return fail(-1, "%s: T*P too large", who);
+    // the kernels address a spike word as 64-bit scalar base + 32-bit lane byte offset
+    if (((long long)(T - 1) * (long long)enc_stride + P * cdiv(C_in, 32)) * 4 > 0xffffffffLL)
+        return fail(-1, "%s: encoder planes over 4 GB", who);
     a.A = enc; a.wpk = w_packed; a.enc_stride = enc_stride;
     a.Cw = cdiv(C_in, 32); a.Kc = 9 * a.Cw; a.Np = cdiv(C_out, 32) * 32;
     a.plane_elems = (unsigned long long)a.Kc * a.Np * 32;
@@ -1548,6 +1571,8 @@ int snn_spike_conv3x3_bf16x3(const uint32_t* enc, size_t enc_stride, const snn_r
         P += (long long)lv[l].N * lv[l].H * lv[l].W;
     }
     if ((long long)T * P > 0x7fffffffLL) return fail(-1, "snn_spike_conv3x3_bf16x3: T*P too large");
+    if (((long long)(T - 1) * (long long)enc_stride + P * cdiv(C_in, 32)) * 4 > 0xffffffffLL)
+        return fail(-1, "snn_spike_conv3x3_bf16x3: encoder planes over 4 GB");
     a.A = enc; a.wpk = w_packed; a.out = cur; a.enc_stride = enc_stride;
     a.Cw = cdiv(C_in, 32); a.Kc = 9 * a.Cw; a.Np = cdiv(C_out, 32) * 32; a.ldo = ldo;
     a.plane_elems = (unsigned long long)a.Kc * a.Np * 32;
@@ -1568,8 +1593,11 @@ int snn_encode_nchw(const float* feat, int N, int C, int H, int W, int T, const 
         return fail(-1, "snn_encode_nchw: bad argument");
     if (check_T(T, "snn_encode_nchw")) return -1;
     const int Cw = cdiv(C, 32), HW = H * W;
-    hipLaunchKernelGGL(k_encode_nchw, dim3(cdiv(HW, 256), Cw, N), dim3(256), 0, (hipStream_t)s, feat, C, HW, Cw, T,
-                       make_p(p, p->v_th_enc), planes, plane_stride);
+    const NeuronP np = make_p(p, p->v_th_enc);
+    if (enc_zero_rest(np))
+        hipLaunchKernelGGL(k_encode_nchw<true>, dim3(cdiv(HW, ENC_PB), cdiv(Cw, 8), N), dim3(256), 0, (hipStream_t)s, feat, C, HW, Cw, T, np, planes, plane_stride);
+    else
+        hipLaunchKernelGGL(k_encode_nchw<false>, dim3(cdiv(HW, ENC_PB), cdiv(Cw, 8), N), dim3(256), 0, (hipStream_t)s, feat, C, HW, Cw, T, np, planes, plane_stride);
     SNN_CHECK_LAUNCH("k_encode_nchw");
     return 0;
 }
@@ -1580,8 +1608,10 @@ int snn_encode_rows(const float* x, int R, int D, int T, const snn_params* p, ui
     if (check_T(T, "snn_encode_rows")) return -1;
     const int Dw = cdiv(D, 32);
     const size_t total = (size_t)R * Dw * 32;
-    hipLaunchKernelGGL(k_encode_rows, dim3((unsigned)((total + 256 * ENC_U - 1) / (256 * ENC_U))), dim3(256), 0, (hipStream_t)s, x, R, D,
-                       Dw, T, make_p(p, p->v_th_enc), planes, plane_stride);
+    const NeuronP np = make_p(p, p->v_th_enc);
+    const dim3 grid((unsigned)((total + 256 * ENC_U - 1) / (256 * ENC_U)));
+    if (enc_zero_rest(np)) hipLaunchKernelGGL(k_encode_rows<true>, grid, dim3(256), 0, (hipStream_t)s, x, R, D, Dw, T, np, planes, plane_stride);
+    else hipLaunchKernelGGL(k_encode_rows<false>, grid, dim3(256), 0, (hipStream_t)s, x, R, D, Dw, T, np, planes, plane_stride);
     SNN_CHECK_LAUNCH("k_encode_rows");
     return 0;
 }

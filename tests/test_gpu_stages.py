@@ -57,6 +57,20 @@ def test_encoder_rows_bit_exact(S, gpu_device, name):
     assert np.array_equal(planes_to_dense(planes, x.shape[1]), z.numpy())
 
 
+def test_encoder_fast_path_equals_op_for_op(S, gpu_device, monkeypatch):
+    """v_leak = v_reset = 0 takes a 5-operation encoder step; SNN_ENC_GENERIC=1 forces the op-for-op kernels"""
+    g = torch.Generator().manual_seed(5)
+    f = (torch.randn(2, 70, 13, 17, generator=g) * 2.0).to(gpu_device)
+    x = (torch.randn(37, 300, generator=g) * 2.0).to(gpu_device)
+    # values that sit exactly on / next to the threshold after one step: v1 = 0.1 * x
+    x[0, :4] = torch.tensor([2.5, 2.4999998, 2.5000002, 0.0])
+    fast = S.encode_nchw(f, 16, _params(S)), S.encode_rows(x, 16, _params(S))
+    monkeypatch.setenv("SNN_ENC_GENERIC", "1")
+    slow = S.encode_nchw(f, 16, _params(S)), S.encode_rows(x, 16, _params(S))
+    assert torch.equal(fast[0], slow[0]) and torch.equal(fast[1], slow[1])
+    assert fast[0].ne(0).any() and fast[1].ne(0).any()
+
+
 def _first_flip_margins(spk_got, spk_exp, vdec_exp, theta=0.1):
     """for every neuron whose spike train differs: oracle margin at the first differing step"""
     diff = spk_got != spk_exp                                     # [T, ...]

@@ -106,14 +106,12 @@ __global__ void k_pack_heads(const float* __restrict__ wa, int NA, const float* 
 // ------------------------------------------------------------------------------------------------
 #define ENC_PB 32                                   // positions per block
 template <bool ZR>
-__global__ __launch_bounds__(256) void k_encode_nchw(const float* __restrict__ feat, int C, int HW, int Cw,
-                                                     int T, NeuronP p, uint32_t* __restrict__ planes,
-                                                     size_t plane_stride) {
+__device__ __forceinline__ void encode_block(const float* __restrict__ feat, int C, int HW, int Cw, int T, const NeuronP& p,
+                                             uint32_t* __restrict__ planes, size_t plane_stride, int n, int bx, int by) {
     __shared__ uint32_t wbuf[SNN_MAX_STEPS * ENC_PB * 9];      // [t][position][8 words + 1 pad]
     const int pl = threadIdx.x & 31, cgl = threadIdx.x >> 5;
-    const int pos = blockIdx.x * ENC_PB + pl;
-    const int cg = blockIdx.y * 8 + cgl;
-    const int n = blockIdx.z;
+    const int pos = bx * ENC_PB + pl;
+    const int cg = by * 8 + cgl;
     float x[32], v[32];
 #pragma unroll
     for (int j = 0; j < 32; ++j) {
@@ -130,11 +128,36 @@ __global__ __launch_bounds__(256) void k_encode_nchw(const float* __restrict__ f
     __syncthreads();
     // store: thread -> (position tid >> 3, word tid & 7): consecutive threads write consecutive plane words
     const int sp = threadIdx.x >> 3, sw = threadIdx.x & 7;
-    const int spos = blockIdx.x * ENC_PB + sp, scg = blockIdx.y * 8 + sw;
+    const int spos = bx * ENC_PB + sp, scg = by * 8 + sw;
     if (spos < HW && scg < Cw) {
         uint32_t* out = planes + ((size_t)n * HW + spos) * Cw + scg;
         for (int t = 0; t < T; ++t) out[(size_t)t * plane_stride] = wbuf[(t * ENC_PB + sp) * 9 + sw];
     }
+}
+
+template <bool ZR>
+__global__ __launch_bounds__(256) void k_encode_nchw(const float* __restrict__ feat, int C, int HW, int Cw,
+                                                     int T, NeuronP p, uint32_t* __restrict__ planes,
+                                                     size_t plane_stride) {
+    encode_block<ZR>(feat, C, HW, Cw, T, p, planes, plane_stride, blockIdx.z, blockIdx.x, blockIdx.y);
+}
+
+// all pyramid levels of the RPN head in one launch (the small levels are launch-latency bound on their own)
+struct EncLevels {
+    const float* feat[SNN_MAX_LEVELS];
+    int HW[SNN_MAX_LEVELS], bpi[SNN_MAX_LEVELS];   // positions / blocks per image
+    int blk_base[SNN_MAX_LEVELS + 1];               // first block of the level
+    int pos_base[SNN_MAX_LEVELS];                   // first plane row of the level
+    int n_levels;
+};
+template <bool ZR>
+__global__ __launch_bounds__(256) void k_encode_levels(const EncLevels lv, int C, int Cw, int T, NeuronP p,
+                                                       uint32_t* __restrict__ planes, size_t plane_stride) {
+    int l = 0;
+    while (l + 1 < lv.n_levels && (int)blockIdx.x >= lv.blk_base[l + 1]) ++l;
+    const int local = blockIdx.x - lv.blk_base[l];
+    encode_block<ZR>(lv.feat[l], C, lv.HW[l], Cw, T, p, planes + (size_t)lv.pos_base[l] * Cw, plane_stride,
+                     local / lv.bpi[l], local % lv.bpi[l], blockIdx.y);
 }
 
 // K1b: encoder on row-major x[R][D] -> bit-planes [T][R][Dw]; a wave covers 64 consecutive reduction indices per
@@ -1809,11 +1832,25 @@ int snn_rpn_head_forward_stages(const snn_rpn_level* lv, int n_levels, int C, in
     uint32_t* enc = (uint32_t*)ws;
     uint32_t* spk = (uint32_t*)((char*)ws + o_spk);
     hipStream_t s = (hipStream_t)stream;
-    long long pos = 0;
-    for (int l = 0; l < n_levels && (stage_mask & SNN_STAGE_ENCODE); ++l) {
-        const int rc = snn_encode_nchw(lv[l].feat, lv[l].N, C, lv[l].H, lv[l].W, T, p, enc + (size_t)pos * Cw, stride, stream);
-        if (rc) return rc;
-        pos += (long long)lv[l].N * lv[l].H * lv[l].W;
+    if (stage_mask & SNN_STAGE_ENCODE) {                        // rpn.py:101, all levels in one launch
+        EncLevels el;
+        memset(&el, 0, sizeof(el));
+        long long pos = 0;
+        int blocks = 0;
+        for (int l = 0; l < n_levels; ++l) {
+            if (!lv[l].feat) return fail(-1, "snn_rpn_head_forward: level %d has no features", l);
+            el.feat[l] = lv[l].feat; el.HW[l] = lv[l].H * lv[l].W; el.bpi[l] = cdiv(el.HW[l], ENC_PB);
+            el.blk_base[l] = blocks; el.pos_base[l] = (int)pos;
+            blocks += lv[l].N * el.bpi[l];
+            pos += (long long)lv[l].N * el.HW[l];
+        }
+        el.blk_base[n_levels] = blocks; el.n_levels = n_levels;
+        const NeuronP np = make_p(p, p->v_th_enc);
+        if (enc_zero_rest(np))
+            hipLaunchKernelGGL(k_encode_levels<true>, dim3(blocks, cdiv(Cw, 8)), dim3(256), 0, s, el, C, Cw, T, np, enc, (size_t)stride);
+        else
+            hipLaunchKernelGGL(k_encode_levels<false>, dim3(blocks, cdiv(Cw, 8)), dim3(256), 0, s, el, C, Cw, T, np, enc, (size_t)stride);
+        SNN_CHECK_LAUNCH("k_encode_levels");
     }
     if (stage_mask & SNN_STAGE_CONV_LIF) {
         if (p->precision == SNN_PRECISION_F32) {

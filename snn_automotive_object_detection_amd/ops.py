@@ -419,3 +419,24 @@ def batched_nms(boxes: torch.Tensor, scores: torch.Tensor, idxs: Optional[torch.
                                   ws.numel(), _stream()), "snn_nms_sorted")
     k = int(n_keep.item())
     return order[keep[:k].to(torch.int64)]
+
+
+def nms_keep_mask(boxes: torch.Tensor, scores: torch.Tensor, idxs: Optional[torch.Tensor], iou_threshold: float):
+    """Greedy NMS without a host synchronisation: returns (order, kept) where `order` sorts the boxes by decreasing
+    score (stable) and kept[i] says whether box order[i] survives; suppression only between boxes of equal idxs."""
+    _need_gpu(boxes, "boxes")
+    lib = _lib.load()
+    n = boxes.shape[0]
+    order = scores.argsort(descending=True, stable=True)
+    if n == 0:
+        return order, torch.zeros((0,), dtype=torch.bool, device=boxes.device)
+    b = _f32c(boxes[order])
+    cat = idxs[order].to(torch.int32).contiguous() if idxs is not None else None
+    keep = torch.full((n,), n, dtype=torch.int32, device=boxes.device)      # unused slots point at a dummy element
+    n_keep = torch.zeros((1,), dtype=torch.int32, device=boxes.device)
+    ws = _WS.get(boxes.device, lib.snn_nms_workspace_bytes(n))
+    _lib.check(lib.snn_nms_sorted(_ptr(b), _ptr(cat), n, float(iou_threshold), n, _ptr(keep), _ptr(n_keep), _ptr(ws),
+                                  ws.numel(), _stream()), "snn_nms_sorted")
+    kept = torch.zeros((n + 1,), dtype=torch.bool, device=boxes.device)
+    kept[keep.to(torch.int64)] = True
+    return order, kept[:n]

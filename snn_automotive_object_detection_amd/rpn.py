@@ -140,6 +140,7 @@ class RegionProposalNetwork(nn.Module):
         self.nms_thresh = nms_thresh
         self.score_thresh = score_thresh
         self.min_size = 1e-3                                                          # rpn.py:371
+        self.reference_post = False       # True: the reference's per-image post-processing order (filter_proposals_reference)
 
     def pre_nms_top_n(self):
         return self._pre_nms_top_n["training" if self.training else "testing"]
@@ -147,7 +148,7 @@ class RegionProposalNetwork(nn.Module):
     def post_nms_top_n(self):
         return self._post_nms_top_n["training" if self.training else "testing"]
 
-    def filter_proposals(self, proposals, objectness, image_shapes, num_anchors_per_level):
+    def filter_proposals_reference(self, proposals, objectness, image_shapes, num_anchors_per_level):
         from .stock import boxes as box_ops
         num_images = proposals.shape[0]
         device = proposals.device
@@ -176,6 +177,55 @@ class RegionProposalNetwork(nn.Module):
             final_scores.append(scores[keep])
         return final_boxes, final_scores, pre_nms
 
+    def filter_proposals(self, objectness, pred_bbox_deltas, anchors, image_shapes, num_anchors_per_level):
+        """rpn.py:420-499 restructured for the GPU: per-level top-k on the logits FIRST, then decode / sigmoid / clip /
+        size and score filters on the <= 1000 candidates per level only, all images batched, and one NMS launch for
+        the whole batch (category = image x level).  Same proposals as `filter_proposals_reference` (tested); two
+        host synchronisations instead of about ten per image."""
+        from .stock import boxes as box_ops
+        from . import ops
+        num_images = objectness.numel() // sum(num_anchors_per_level)
+        device = objectness.device
+        n_levels = len(num_anchors_per_level)
+        objectness = objectness.detach().reshape(num_images, -1)
+        deltas = pred_bbox_deltas.detach().reshape(num_images, -1, 4)
+        idx, lvl, offset = [], [], 0
+        for i, ob in enumerate(objectness.split(num_anchors_per_level, 1)):           # rpn.py:434-446
+            k = min(self.pre_nms_top_n(), ob.shape[1])
+            idx.append(ob.topk(k, dim=1)[1] + offset)
+            lvl.append(torch.full((k,), i, dtype=torch.int64, device=device))
+            offset += ob.shape[1]
+        top = torch.cat(idx, dim=1)                                                   # [N, K]
+        levels = torch.cat(lvl)                                                       # [K]
+        K = top.shape[1]
+        logits = objectness.gather(1, top)
+        d_sel = deltas.gather(1, top[..., None].expand(-1, -1, 4))
+        a_sel = anchors[0][top]                                                       # anchors are per-shape, not per-image
+        proposals = self.box_coder.decode_single(d_sel.reshape(-1, 4), a_sel.reshape(-1, 4)).view(num_images, K, 4)
+        prob = torch.sigmoid(logits)
+        pre_nms = [{"proposals": p, "objectness": prob[i]} for i, p in enumerate(proposals)]   # rpn.py:493-499
+        hw = torch.tensor([[float(s[1]), float(s[0])] * 2 for s in image_shapes], dtype=proposals.dtype, device=device)
+        boxes = torch.minimum(proposals.clamp(min=0), hw[:, None, :])                 # clip_boxes_to_image
+        ws, hs = boxes[..., 2] - boxes[..., 0], boxes[..., 3] - boxes[..., 1]
+        valid = (ws >= self.min_size) & (hs >= self.min_size) & (prob >= self.score_thresh)
+        scores = torch.where(valid, prob, prob.new_full((), -1.0))                    # invalid boxes sort last
+        keep_sorted, order_all = [], []
+        for i in range(num_images):                  # NMS per image (pairs across images would be wasted IoUs)
+            order, kept = ops.nms_keep_mask(boxes[i], scores[i], levels, self.nms_thresh)
+            kept = kept & valid[i][order]
+            kept = kept & (kept.cumsum(0) <= self.post_nms_top_n())
+            keep_sorted.append(kept)
+            order_all.append(order)
+        keep_sorted = torch.stack(keep_sorted)                                         # [N, K] in score order
+        order_all = torch.stack(order_all)
+        counts = keep_sorted.sum(1).tolist()                                           # host sync 1
+        sel = keep_sorted.reshape(-1).nonzero().squeeze(1)                             # host sync 2; row-major = by image
+        img_of = sel // K
+        pick = order_all.reshape(-1)[sel]
+        final_boxes = list(boxes[img_of, pick].split(counts))
+        final_scores = list(prob[img_of, pick].split(counts))
+        return final_boxes, final_scores, pre_nms
+
     def forward(self, images, features, targets=None):
         if self.training:
             raise NotImplementedError("inference only: training the RPN is out of scope (DESIGN.md §7)")
@@ -185,6 +235,11 @@ class RegionProposalNetwork(nn.Module):
         num_images = len(anchors)
         num_anchors_per_level = [o.shape[1] * o.shape[2] * o.shape[3] for o in objectness]
         objectness, pred_bbox_deltas = concat_box_prediction_layers(objectness, pred_bbox_deltas)
-        proposals = self.box_coder.decode(pred_bbox_deltas.detach(), anchors).view(num_images, -1, 4)
-        boxes, scores, pre_nms = self.filter_proposals(proposals, objectness, images.image_sizes, num_anchors_per_level)
+        if objectness.is_cuda and not self.reference_post:
+            boxes, scores, pre_nms = self.filter_proposals(objectness, pred_bbox_deltas, anchors, images.image_sizes,
+                                                           num_anchors_per_level)
+        else:
+            proposals = self.box_coder.decode(pred_bbox_deltas.detach(), anchors).view(num_images, -1, 4)
+            boxes, scores, pre_nms = self.filter_proposals_reference(proposals, objectness, images.image_sizes,
+                                                                     num_anchors_per_level)
         return boxes, pre_nms

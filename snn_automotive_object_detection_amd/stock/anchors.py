@@ -24,6 +24,7 @@ class AnchorGenerator(nn.Module):
         self.sizes = sizes
         self.aspect_ratios = aspect_ratios
         self.cell_anchors = [self._base(s, a) for s, a in zip(sizes, aspect_ratios)]
+        self._cache = {}                                # (grid sizes, image size, dtype, device) -> anchors
 
     @staticmethod
     def _base(scales, ratios, dtype=torch.float32):
@@ -42,6 +43,10 @@ class AnchorGenerator(nn.Module):
         grid_sizes = [f.shape[-2:] for f in feature_maps]
         image_size = image_list.tensors.shape[-2:]
         dtype, device = feature_maps[0].dtype, feature_maps[0].device
+        key = (tuple(tuple(g) for g in grid_sizes), tuple(image_size), dtype, device)
+        hit = self._cache.get(key)
+        if hit is not None:                             # the anchors depend on the shapes only
+            return [hit for _ in image_list.image_sizes]
         per_level = []
         for (gh, gw), base in zip(grid_sizes, self.cell_anchors):
             sh, sw = image_size[0] // gh, image_size[1] // gw
@@ -52,4 +57,7 @@ class AnchorGenerator(nn.Module):
             shifts = torch.stack((xx, yy, xx, yy), dim=1)
             per_level.append((shifts.view(-1, 1, 4) + base.to(device=device, dtype=dtype).view(1, -1, 4)).reshape(-1, 4))
         all_anchors = torch.cat(per_level)
+        if len(self._cache) > 8:
+            self._cache.clear()
+        self._cache[key] = all_anchors
         return [all_anchors for _ in image_list.image_sizes]

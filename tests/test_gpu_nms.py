@@ -35,3 +35,37 @@ def test_hip_batched_nms_equals_greedy(gpu_device, n, ncat, thr):
     # the stock dispatcher routes GPU tensors here and CPU tensors to the plain-torch form: same answer
     assert torch.equal(B.batched_nms(boxes.to(gpu_device), scores.to(gpu_device), idxs.to(gpu_device), thr).cpu(),
                        B.batched_nms(boxes, scores, idxs, thr))
+
+
+def _greedy_vec(boxes, scores, idxs, thr):
+    """the same greedy definition with one vector operation per candidate (for the large cases)"""
+    order = scores.argsort(descending=True, stable=True)
+    b, c = boxes[order], idxs[order]
+    iou = B.box_iou(b, b)
+    sup = (iou > thr) & (c[:, None] == c[None, :])
+    alive = torch.ones(len(order), dtype=torch.bool)
+    keep = []
+    for i in range(len(order)):
+        if alive[i]:
+            keep.append(i)
+            alive &= ~sup[i]
+    return order[torch.tensor(keep, dtype=torch.int64)]
+
+
+@pytest.mark.parametrize("n,ncat", [(4768, 5), (9984, 4), (10500, 3)])
+def test_hip_nms_large_and_keep_mask(gpu_device, n, ncat):
+    """RPN-sized candidate sets (double-buffered scan) and one past the double-buffer limit (single buffer)"""
+    from snn_automotive_object_detection_amd import ops
+    g = torch.Generator().manual_seed(n)
+    xy = torch.rand((n, 2), generator=g) * 1500
+    wh = torch.rand((n, 2), generator=g) * 120 + 1
+    boxes = torch.cat([xy, xy + wh], dim=1)
+    scores = torch.rand((n,), generator=g)
+    idxs = torch.randint(0, ncat, (n,), generator=g)
+    exp = _greedy_vec(boxes, scores, idxs, 0.7)
+    got = ops.batched_nms(boxes.to(gpu_device), scores.to(gpu_device), idxs.to(gpu_device), 0.7).cpu()
+    assert torch.equal(got, exp)
+    top = ops.batched_nms(boxes.to(gpu_device), scores.to(gpu_device), idxs.to(gpu_device), 0.7, max_keep=1000).cpu()
+    assert torch.equal(top, exp[:1000])
+    order, kept = ops.nms_keep_mask(boxes.to(gpu_device), scores.to(gpu_device), idxs.to(gpu_device), 0.7)
+    assert torch.equal(order[kept].cpu(), exp)

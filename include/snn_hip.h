@@ -161,6 +161,26 @@ size_t snn_nms_workspace_bytes(int n);
 int snn_nms_sorted(const float* boxes_sorted, const int* category_sorted, int n, float iou_threshold, int max_keep,
                    int* keep_out, int* n_keep_out, void* workspace, size_t workspace_bytes, snn_stream_t stream);
 
+/* ---- RPN proposal selection (rpn.py:420-499: per-level top-k, box decode, sigmoid, clip, size / score filters,
+ * per-level NMS, post_nms_top_n) for the whole batch in six launches, no host synchronisation ----------------
+ * Inputs are the head's own position-major outputs.  Candidates are ordered by decreasing score per image (the
+ * reference orders them per level); outputs are padded to post_nms_top_n rows, out_counts[N] holds the valid rows. */
+typedef struct {
+    const float* logits;        /* [N*H*W][A]  objectness logits, rows n*H*W + y*W + x                  */
+    const float* deltas;        /* [N*H*W][4A] box regression                                           */
+    int32_t H, W;
+    float stride_h, stride_w;   /* image size // feature size (AnchorGenerator)                         */
+    float base_anchors[16][4];  /* the level's cell anchors (rounded, as AnchorGenerator builds them)   */
+} snn_rpn_post_level;
+int snn_rpn_proposals_candidates(const snn_rpn_post_level* levels, int n_levels, int A, int pre_nms_top_n);
+size_t snn_rpn_proposals_workspace_bytes(int N, int K_candidates);
+int snn_rpn_proposals(const snn_rpn_post_level* levels, int n_levels, int N, int A, const float* image_hw_host,
+                      int pre_nms_top_n, int post_nms_top_n, float nms_thresh, float score_thresh, float min_size,
+                      float* out_boxes, float* out_scores, int* out_counts,
+                      float* pre_boxes /* nullable [N][K][4]: decoded un-clipped candidates */,
+                      float* pre_prob /* nullable [N][K] */, void* workspace, size_t workspace_bytes,
+                      snn_stream_t stream);
+
 /* ---- stage-level entry points (parity tests drive the layers one by one, teacher-forced) ----- */
 /* constant-current LIF encoder -> bit-planes.  NCHW feature map -> planes[T][N*H*W][Cw]          */
 int snn_encode_nchw(const float* feat, int N, int C, int H, int W, int T, const snn_params* p_host,

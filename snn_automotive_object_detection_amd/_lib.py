@@ -31,6 +31,11 @@ class snn_roi_level(C.Structure):
                 ("reserved", C.c_int32)]
 
 
+class snn_rpn_post_level(C.Structure):
+    _fields_ = [("logits", C.c_void_p), ("deltas", C.c_void_p), ("H", C.c_int32), ("W", C.c_int32),
+                ("stride_h", C.c_float), ("stride_w", C.c_float), ("base_anchors", (C.c_float * 4) * 16)]
+
+
 # every symbol include/snn_hip.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "snn_version": (C.c_int, []),
@@ -63,6 +68,11 @@ SYMBOLS = {
     "snn_li_heads": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                C.POINTER(snn_params), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_stream]),
     "snn_nms_workspace_bytes": (C.c_size_t, [C.c_int]),
+    "snn_rpn_proposals_candidates": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "snn_rpn_proposals_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "snn_rpn_proposals": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float,
+                                    C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                    c_stream]),
     "snn_nms_sorted": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.c_size_t, c_stream]),
     "snn_roi_align_encode": (C.c_int, [C.POINTER(snn_roi_level), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -1265,10 +1265,20 @@ __global__ __launch_bounds__(256) void k_count_spikes(const uint32_t* __restrict
 // boxes arrive sorted by decreasing score; k_nms_mask builds the suppression bit-matrix (box j > i, same
 // category, IoU > thr), k_nms_scan walks it in score order with the rows staged through LDS 64 at a time.
 // ------------------------------------------------------------------------------------------------
+// Batched form (blockIdx.z = image): per-image strides (elements) and a device-side candidate count; a plain call
+// passes zero strides and n_dev = nullptr.
+struct NmsBatch { const int* n_dev; long long boxes_stride, cat_stride, mask_stride, keep_stride; };
+
 __global__ __launch_bounds__(64) void k_nms_mask(const float* __restrict__ boxes, const int* __restrict__ cat, int n,
-                                                 float thr, unsigned long long* __restrict__ mask, int words) {
+                                                 float thr, unsigned long long* __restrict__ mask, int words,
+                                                 const NmsBatch nb) {
     const int rb = blockIdx.y, cb = blockIdx.x;
     if (cb < rb) return;                                  // only j > i matters
+    if (nb.n_dev) n = nb.n_dev[blockIdx.z];
+    if (rb * 64 >= n || cb * 64 >= n) return;
+    boxes += (size_t)blockIdx.z * nb.boxes_stride;
+    if (cat) cat += (size_t)blockIdx.z * nb.cat_stride;
+    mask += (size_t)blockIdx.z * nb.mask_stride;
     __shared__ float cbx[64][4];
     __shared__ int ccat[64];
     const int t = threadIdx.x;
@@ -1309,9 +1319,15 @@ __global__ __launch_bounds__(64) void k_nms_mask(const float* __restrict__ boxes
 // two thirds of the RPN post-processing time.)
 // dbl = 0 (n > 9984: two buffers do not fit the LDS): one buffer, blocking copy at the top of each chunk.
 __global__ __launch_bounds__(256) void k_nms_scan(const unsigned long long* __restrict__ mask, int n, int words,
-                                                  int max_keep, int dbl, int* __restrict__ keep, int* __restrict__ n_keep) {
+                                                  int max_keep, int dbl, int* __restrict__ keep, int* __restrict__ n_keep,
+                                                  const NmsBatch nb) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long* rows = reinterpret_cast<unsigned long long*>(smem);     // [1 + dbl][64][words]
+    if (nb.n_dev) n = nb.n_dev[blockIdx.x];
+    mask += (size_t)blockIdx.x * nb.mask_stride;
+    keep += (size_t)blockIdx.x * nb.keep_stride;
+    n_keep += blockIdx.x;
+    if (n <= 0) { if (threadIdx.x == 0) *n_keep = 0; return; }
     __shared__ unsigned long long removed_cur, kept_cur;
     __shared__ int count_s;
     const int t = threadIdx.x;
@@ -1376,6 +1392,219 @@ __global__ __launch_bounds__(256) void k_nms_scan(const unsigned long long* __re
         if (done) break;
     }
     if (t == 0) *n_keep = count_s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// RPN proposal selection (rpn.py:420-499 + 262-296 + the box coder), one call for the batch:
+//   k_rpn_topk    per (level, image): the pre_nms_top_n largest logits by a 3-pass radix select (11+11+10 bits)
+//   k_rpn_decode  per candidate: anchor from the level geometry, box decode, sigmoid, clip, size/score filters
+//   k_rpn_sort    per image: bitonic sort of the candidates by decreasing score in LDS, gather into sorted order
+//   k_nms_mask / k_nms_scan (batched over images, category = level)
+//   k_rpn_output  kept boxes -> [N][post_nms_top_n] padded + counts
+// ------------------------------------------------------------------------------------------------
+#define RPN_MAX_ANCHORS 16
+#define RPN_MAX_IMAGES 64
+#define RPN_SORT_MAX 8192
+struct RpnPostLevel {
+    const float* logits;          // [N*H*W][A]   position-major (the head's own output buffer)
+    const float* deltas;          // [N*H*W][4A]
+    int H, W, n, k, koff;         // n = H*W*A elements per image, k = min(pre_nms_top_n, n), koff = first candidate slot
+    float sh, sw;                 // anchor strides (image size // feature size)
+    float base[RPN_MAX_ANCHORS * 4];
+};
+struct RpnPostArgs {
+    RpnPostLevel lv[SNN_MAX_LEVELS];
+    float img_h[RPN_MAX_IMAGES], img_w[RPN_MAX_IMAGES];
+    int n_levels, N, A, Ktot, post_n;
+    float score_thresh, min_size, clip;
+    int* cand_idx;                // [N][Ktot] level-local element index
+    float* cand_logit;            // [N][Ktot]
+    float* boxes;                 // [N][Ktot][4] clipped
+    float* pre;                   // [N][Ktot][4] decoded, un-clipped
+    float* prob;                  // [N][Ktot]
+    float* skey;                  // [N][Ktot] prob, or -1 for filtered candidates
+    float* s_boxes; float* s_pre; float* s_prob; int* s_cat; int* n_valid;     // sorted by decreasing score
+};
+
+__device__ __forceinline__ uint32_t f2key(float f) {           // monotone: larger float -> larger key
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ __launch_bounds__(1024) void k_rpn_topk(const RpnPostArgs a) {
+    const RpnPostLevel& L = a.lv[blockIdx.x];
+    const int img = blockIdx.y, tid = threadIdx.x;
+    const float* src = L.logits + (size_t)img * L.n;
+    __shared__ uint32_t hist[2048];
+    __shared__ uint32_t s_prefix, s_need, s_cnt_gt, s_cnt_eq;
+    uint32_t prefix = 0, pmask = 0;           // bits of the k-th largest key decided so far
+    uint32_t need = (uint32_t)L.k;            // how many are still to be taken among keys matching the prefix
+    const int shifts[3] = {21, 10, 0}, bits[3] = {11, 11, 10};
+    for (int pass = 0; pass < 3; ++pass) {
+        for (int b = tid; b < 2048; b += 1024) hist[b] = 0;
+        __syncthreads();
+        const uint32_t bm = (1u << bits[pass]) - 1u;
+        for (int e = tid; e < L.n; e += 1024) {
+            const uint32_t key = f2key(src[e]);
+            if ((key & pmask) == prefix) atomicAdd(&hist[(key >> shifts[pass]) & bm], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {                       // walk the bins from the top until `need` keys are covered
+            uint32_t cum = 0;
+            int b = (int)bm;
+            for (; b > 0; --b) {
+                if (cum + hist[b] >= need) break;
+                cum += hist[b];
+            }
+            s_prefix = prefix | ((uint32_t)b << shifts[pass]);
+            s_need = need - cum;              // taken from bin b (all bins above it are taken whole)
+        }
+        __syncthreads();
+        prefix = s_prefix; need = s_need;
+        pmask |= bm << shifts[pass];
+        __syncthreads();
+    }
+    // prefix = key of the k-th largest logit; `need` of the keys equal to it are taken: those with the lowest element
+    // index (deterministic; an ordered pass with a block scan, run only when there are more ties than needed)
+    __shared__ uint32_t s_eq_total;
+    if (tid == 0) { s_cnt_gt = 0; s_cnt_eq = 0; s_eq_total = hist[prefix & 1023u]; }
+    __syncthreads();
+    int* out_idx = a.cand_idx + (size_t)img * a.Ktot + L.koff;
+    float* out_logit = a.cand_logit + (size_t)img * a.Ktot + L.koff;
+    const uint32_t n_gt = (uint32_t)L.k - need;
+    const bool ordered_ties = s_eq_total > need;
+    for (int e = tid; e < L.n; e += 1024) {
+        const float x = src[e];
+        const uint32_t key = f2key(x);
+        int slot = -1;
+        if (key > prefix) slot = (int)atomicAdd(&s_cnt_gt, 1u);
+        else if (key == prefix && !ordered_ties) slot = (int)(n_gt + atomicAdd(&s_cnt_eq, 1u));
+        if (slot >= 0) { out_idx[slot] = e; out_logit[slot] = x; }
+    }
+    if (ordered_ties) {
+        __shared__ uint32_t wsum[16];
+        uint32_t taken = 0;                   // block-uniform
+        for (int e0 = 0; e0 < L.n && taken < need; e0 += 1024) {
+            const int e = e0 + tid;
+            const bool tie = e < L.n && f2key(src[e]) == prefix;
+            const unsigned long long bal = __ballot(tie);
+            const int lane = tid & 63, wv = tid >> 6;
+            if (lane == 0) wsum[wv] = (uint32_t)__popcll(bal);
+            __syncthreads();
+            uint32_t before = 0, total = 0;
+            for (int w = 0; w < 16; ++w) { if (w < wv) before += wsum[w]; total += wsum[w]; }
+            const uint32_t rank = taken + before + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+            if (tie && rank < need) { out_idx[n_gt + rank] = e; out_logit[n_gt + rank] = src[e]; }
+            taken += total;
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_rpn_decode(const RpnPostArgs a) {
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= a.N * a.Ktot) return;
+    const int img = g / a.Ktot, c = g % a.Ktot;
+    int l = 0;
+    while (l + 1 < a.n_levels && c >= a.lv[l + 1].koff) ++l;
+    const RpnPostLevel& L = a.lv[l];
+    const int e = a.cand_idx[g];
+    const int pos = e / a.A, an = e % a.A;
+    const int y = pos / L.W, x = pos % L.W;
+    const float fx = (float)(x * (int)L.sw), fy = (float)(y * (int)L.sh);     // integer shifts, as the reference's
+    const float ax1 = __fadd_rn(fx, L.base[4 * an]), ay1 = __fadd_rn(fy, L.base[4 * an + 1]);
+    const float ax2 = __fadd_rn(fx, L.base[4 * an + 2]), ay2 = __fadd_rn(fy, L.base[4 * an + 3]);
+    const float* d = L.deltas + ((size_t)img * L.H * L.W + pos) * 4 * a.A + 4 * an;
+    // BoxCoder.decode_single, weights (1, 1, 1, 1)
+    const float w = __fsub_rn(ax2, ax1), h = __fsub_rn(ay2, ay1);
+    const float cx = __fadd_rn(ax1, __fmul_rn(0.5f, w)), cy = __fadd_rn(ay1, __fmul_rn(0.5f, h));
+    const float dw = fminf(d[2], a.clip), dh = fminf(d[3], a.clip);
+    const float pcx = __fadd_rn(__fmul_rn(d[0], w), cx), pcy = __fadd_rn(__fmul_rn(d[1], h), cy);
+    const float hw = __fmul_rn(0.5f, __fmul_rn(expf(dw), w)), hh = __fmul_rn(0.5f, __fmul_rn(expf(dh), h));
+    const float x1 = __fsub_rn(pcx, hw), y1 = __fsub_rn(pcy, hh), x2 = __fadd_rn(pcx, hw), y2 = __fadd_rn(pcy, hh);
+    const float prob = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-a.cand_logit[g])));
+    const float W_ = a.img_w[img], H_ = a.img_h[img];
+    const float bx1 = fminf(fmaxf(x1, 0.0f), W_), by1 = fminf(fmaxf(y1, 0.0f), H_);
+    const float bx2 = fminf(fmaxf(x2, 0.0f), W_), by2 = fminf(fmaxf(y2, 0.0f), H_);
+    const bool valid = __fsub_rn(bx2, bx1) >= a.min_size && __fsub_rn(by2, by1) >= a.min_size && prob >= a.score_thresh;
+    reinterpret_cast<float4*>(a.pre)[g] = make_float4(x1, y1, x2, y2);
+    reinterpret_cast<float4*>(a.boxes)[g] = make_float4(bx1, by1, bx2, by2);
+    a.prob[g] = prob;
+    a.skey[g] = valid ? prob : -1.0f;
+}
+
+__global__ __launch_bounds__(1024) void k_rpn_sort(const RpnPostArgs a) {
+    __shared__ unsigned long long v[RPN_SORT_MAX];
+    __shared__ uint16_t slot_of[RPN_SORT_MAX];
+    const int img = blockIdx.x, tid = threadIdx.x, K = a.Ktot;
+    int np2 = 1;
+    while (np2 < K) np2 <<= 1;
+    // descending on (score, then level, then lower element index): the candidate's slot rides in the low 13 bits.
+    // (The slots inside a level are filled in atomic order; the element index makes the result run-to-run identical.)
+    for (int i = tid; i < np2; i += 1024) {
+        unsigned long long key = 0ull;
+        if (i < K) {
+            int l = 0;
+            while (l + 1 < a.n_levels && i >= a.lv[l + 1].koff) ++l;
+            const uint32_t ident = ((uint32_t)l << 28) | (uint32_t)a.cand_idx[(size_t)img * K + i];    // e < 2^28
+            key = ((unsigned long long)f2key(a.skey[(size_t)img * K + i]) << 32) | (uint32_t)(~ident);
+        }
+        v[i] = key;
+        slot_of[i] = (uint16_t)i;
+    }
+    __syncthreads();
+    for (int k = 2; k <= np2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < np2; i += 1024) {
+                const int p = i ^ j;
+                if (p > i) {
+                    const unsigned long long x = v[i], y = v[p];
+                    const bool desc = (i & k) == 0;
+                    if (desc ? x < y : x > y) {
+                        v[i] = y; v[p] = x;
+                        const uint16_t q = slot_of[i]; slot_of[i] = slot_of[p]; slot_of[p] = q;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    int valid = 0;
+    for (int i = tid; i < K; i += 1024) {
+        const int c = slot_of[i];
+        const size_t src = (size_t)img * K + c, dst = (size_t)img * K + i;
+        reinterpret_cast<float4*>(a.s_boxes)[dst] = reinterpret_cast<const float4*>(a.boxes)[src];
+        reinterpret_cast<float4*>(a.s_pre)[dst] = reinterpret_cast<const float4*>(a.pre)[src];
+        a.s_prob[dst] = a.prob[src];
+        int l = 0;
+        while (l + 1 < a.n_levels && c >= a.lv[l + 1].koff) ++l;
+        a.s_cat[dst] = l;
+        valid += a.skey[src] >= 0.0f;
+    }
+    __shared__ int s_valid;
+    if (tid == 0) s_valid = 0;
+    __syncthreads();
+    if (valid) atomicAdd(&s_valid, valid);
+    __syncthreads();
+    if (tid == 0) a.n_valid[img] = s_valid;
+}
+
+__global__ __launch_bounds__(256) void k_rpn_output(const RpnPostArgs a, const int* __restrict__ keep, const int* __restrict__ n_keep,
+                                                    float* __restrict__ out_boxes, float* __restrict__ out_scores,
+                                                    int* __restrict__ out_counts) {
+    const int img = blockIdx.x;
+    const int cnt = min(n_keep[img], a.post_n);
+    for (int r = threadIdx.x; r < a.post_n; r += 256) {
+        float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+        float sc = 0.f;
+        if (r < cnt) {
+            const size_t src = (size_t)img * a.Ktot + keep[(size_t)img * a.Ktot + r];
+            b = reinterpret_cast<const float4*>(a.s_boxes)[src];
+            sc = a.s_prob[src];
+        }
+        reinterpret_cast<float4*>(out_boxes)[(size_t)img * a.post_n + r] = b;
+        out_scores[(size_t)img * a.post_n + r] = sc;
+    }
+    if (threadIdx.x == 0) out_counts[img] = cnt;
 }
 
 // impulse responses of the LI cell (norse leaky_integrator.py: li_feed_forward_step; v_leak = 0)
@@ -1685,14 +1914,16 @@ int snn_nms_sorted(const float* boxes_sorted, const int* category_sorted, int n,
     if (words > 256) return fail(-1, "snn_nms_sorted: n=%d too large (max 16384)", n);
     if (ws_bytes < snn_nms_workspace_bytes(n)) return fail(-2, "snn_nms_sorted: workspace too small");
     unsigned long long* mask = (unsigned long long*)ws;
+    NmsBatch nb;
+    memset(&nb, 0, sizeof(nb));
     hipLaunchKernelGGL(k_nms_mask, dim3(words, words), dim3(64), 0, (hipStream_t)s, boxes_sorted, category_sorted, n,
-                       iou_threshold, mask, words);
+                       iou_threshold, mask, words, nb);
     SNN_CHECK_LAUNCH("k_nms_mask");
     const int dbl = words <= 156 ? 1 : 0;                   // two chunk buffers fit the LDS up to n = 9984
     const size_t lds = (size_t)(1 + dbl) * 64 * words * 8;
     hipError_t e = hipFuncSetAttribute((const void*)k_nms_scan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return fail(-3, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(k_nms_scan, dim3(1), dim3(256), lds, (hipStream_t)s, mask, n, words, max_keep, dbl, keep_out, n_keep_out);
+    hipLaunchKernelGGL(k_nms_scan, dim3(1), dim3(256), lds, (hipStream_t)s, mask, n, words, max_keep, dbl, keep_out, n_keep_out, nb);
     SNN_CHECK_LAUNCH("k_nms_scan");
     return 0;
 }
@@ -1930,6 +2161,90 @@ int snn_rpn_head_forward(const snn_rpn_level* lv, int n_levels, int C, int A, in
     return snn_rpn_head_forward_stages(lv, n_levels, C, A, T, p, w_shared_packed, w_heads_packed, out_logits,
                                        out_bbox, spike_counts, sum_logits, sum_bbox, ws, ws_bytes, SNN_STAGE_ALL,
                                        stream);
+}
+
+// ---- RPN proposal selection -------------------------------------------------------------------
+int snn_rpn_proposals_candidates(const snn_rpn_post_level* lv, int n_levels, int A, int pre_nms_top_n) {
+    if (!lv || n_levels <= 0 || n_levels > SNN_MAX_LEVELS || A <= 0 || pre_nms_top_n <= 0) return -1;
+    long long k = 0;
+    for (int l = 0; l < n_levels; ++l) k += min((long long)pre_nms_top_n, (long long)lv[l].H * lv[l].W * A);
+    return k > 0x7fffffffLL ? -1 : (int)k;
+}
+
+static size_t rpn_post_layout(int N, int K, size_t off[14]) {
+    const size_t nk = (size_t)N * K;
+    const size_t sz[14] = {nk * 4, nk * 4, nk * 16, nk * 16, nk * 4, nk * 4, nk * 16, nk * 16, nk * 4, nk * 4,
+                           (size_t)N * 4, nk * 4, (size_t)N * 4, nk * cdiv(K, 64) * 8};
+    size_t o = 0;
+    for (int i = 0; i < 14; ++i) { off[i] = o; o += align_up(sz[i], 256); }
+    return o;
+}
+
+size_t snn_rpn_proposals_workspace_bytes(int N, int K_candidates) {
+    size_t off[14];
+    return (N > 0 && K_candidates > 0) ? rpn_post_layout(N, K_candidates, off) : 0;
+}
+
+int snn_rpn_proposals(const snn_rpn_post_level* lv, int n_levels, int N, int A, const float* image_hw_host,
+                      int pre_nms_top_n, int post_nms_top_n, float nms_thresh, float score_thresh, float min_size,
+                      float* out_boxes, float* out_scores, int* out_counts, float* pre_boxes, float* pre_prob,
+                      void* ws, size_t ws_bytes, snn_stream_t stream) {
+    if (!lv || !image_hw_host || !out_boxes || !out_scores || !out_counts || !ws)
+        return fail(-1, "snn_rpn_proposals: null argument");
+    if (n_levels <= 0 || n_levels > SNN_MAX_LEVELS || N <= 0 || N > RPN_MAX_IMAGES || A <= 0 || A > RPN_MAX_ANCHORS ||
+        pre_nms_top_n <= 0 || post_nms_top_n <= 0)
+        return fail(-1, "snn_rpn_proposals: bad argument (levels <= %d, images <= %d, anchors <= %d)", SNN_MAX_LEVELS,
+                    RPN_MAX_IMAGES, RPN_MAX_ANCHORS);
+    const int K = snn_rpn_proposals_candidates(lv, n_levels, A, pre_nms_top_n);
+    if (K <= 0 || K > RPN_SORT_MAX) return fail(-1, "snn_rpn_proposals: %d candidates per image (max %d)", K, RPN_SORT_MAX);
+    size_t off[14];
+    if (ws_bytes < rpn_post_layout(N, K, off)) return fail(-2, "snn_rpn_proposals: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    RpnPostArgs a;
+    memset(&a, 0, sizeof(a));
+    int koff = 0;
+    for (int l = 0; l < n_levels; ++l) {
+        if (!lv[l].logits || !lv[l].deltas || lv[l].H <= 0 || lv[l].W <= 0) return fail(-1, "snn_rpn_proposals: bad level %d", l);
+        if ((long long)lv[l].H * lv[l].W * A * N > 0x7fffffffLL || (long long)lv[l].H * lv[l].W * A >= (1 << 28))
+            return fail(-1, "snn_rpn_proposals: level %d too large", l);
+        RpnPostLevel& L = a.lv[l];
+        L.logits = lv[l].logits; L.deltas = lv[l].deltas; L.H = lv[l].H; L.W = lv[l].W;
+        L.n = lv[l].H * lv[l].W * A; L.k = min(pre_nms_top_n, L.n); L.koff = koff; koff += L.k;
+        L.sh = lv[l].stride_h; L.sw = lv[l].stride_w;
+        memcpy(L.base, lv[l].base_anchors, sizeof(float) * 4 * A);
+    }
+    for (int i = 0; i < N; ++i) { a.img_h[i] = image_hw_host[2 * i]; a.img_w[i] = image_hw_host[2 * i + 1]; }
+    a.n_levels = n_levels; a.N = N; a.A = A; a.Ktot = K; a.post_n = post_nms_top_n;
+    a.score_thresh = score_thresh; a.min_size = min_size; a.clip = (float)4.135166556742356;     // log(1000/16), boxes.py
+    char* w = (char*)ws;
+    a.cand_idx = (int*)(w + off[0]); a.cand_logit = (float*)(w + off[1]); a.boxes = (float*)(w + off[2]);
+    a.pre = (float*)(w + off[3]); a.prob = (float*)(w + off[4]); a.skey = (float*)(w + off[5]);
+    a.s_boxes = (float*)(w + off[6]); a.s_pre = pre_boxes ? pre_boxes : (float*)(w + off[7]);
+    a.s_prob = pre_prob ? pre_prob : (float*)(w + off[8]); a.s_cat = (int*)(w + off[9]); a.n_valid = (int*)(w + off[10]);
+    int* keep = (int*)(w + off[11]);
+    int* n_keep = (int*)(w + off[12]);
+    unsigned long long* mask = (unsigned long long*)(w + off[13]);
+    hipLaunchKernelGGL(k_rpn_topk, dim3(n_levels, N), dim3(1024), 0, s, a);
+    SNN_CHECK_LAUNCH("k_rpn_topk");
+    hipLaunchKernelGGL(k_rpn_decode, dim3(cdiv((long long)N * K, 256)), dim3(256), 0, s, a);
+    SNN_CHECK_LAUNCH("k_rpn_decode");
+    hipLaunchKernelGGL(k_rpn_sort, dim3(N), dim3(1024), 0, s, a);
+    SNN_CHECK_LAUNCH("k_rpn_sort");
+    const int words = cdiv(K, 64);
+    NmsBatch nb;
+    nb.n_dev = a.n_valid; nb.boxes_stride = (long long)K * 4; nb.cat_stride = K; nb.mask_stride = (long long)K * words;
+    nb.keep_stride = K;
+    hipLaunchKernelGGL(k_nms_mask, dim3(words, words, N), dim3(64), 0, s, a.s_boxes, a.s_cat, K, nms_thresh, mask, words, nb);
+    SNN_CHECK_LAUNCH("k_nms_mask");
+    const int dbl = words <= 156 ? 1 : 0;
+    const size_t lds = (size_t)(1 + dbl) * 64 * words * 8;
+    hipError_t e = hipFuncSetAttribute((const void*)k_nms_scan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail(-3, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(k_nms_scan, dim3(N), dim3(256), lds, s, mask, K, words, post_nms_top_n, dbl, keep, n_keep, nb);
+    SNN_CHECK_LAUNCH("k_nms_scan");
+    hipLaunchKernelGGL(k_rpn_output, dim3(N), dim3(256), 0, s, a, keep, n_keep, out_boxes, out_scores, out_counts);
+    SNN_CHECK_LAUNCH("k_rpn_output");
+    return 0;
 }
 
 static void det_ws_layout(int R, int D, int Hd, int T, size_t* o_enc, size_t* o_cur, size_t* o_s6, size_t* o_s7,

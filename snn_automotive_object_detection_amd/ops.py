@@ -440,3 +440,46 @@ def nms_keep_mask(boxes: torch.Tensor, scores: torch.Tensor, idxs: Optional[torc
     kept = torch.zeros((n + 1,), dtype=torch.bool, device=boxes.device)
     kept[keep.to(torch.int64)] = True
     return order, kept[:n]
+
+
+def rpn_proposals(logits: Sequence[torch.Tensor], deltas: Sequence[torch.Tensor], level_hw, strides, base_anchors,
+                  image_sizes, pre_nms_top_n: int, post_nms_top_n: int, nms_thresh: float, score_thresh: float,
+                  min_size: float, want_pre: bool = True):
+    """RPN proposal selection for a batch (rpn.py:420-499) in six launches.
+    logits[l] fp32 [N*H*W, A], deltas[l] fp32 [N*H*W, 4A] (position-major), level_hw[l] = (H, W), strides[l] = (sh, sw),
+    base_anchors[l] = [A, 4] cell anchors, image_sizes = [(h, w)] * N.
+    Returns (boxes [N, post, 4], scores [N, post], counts [N] int32, pre_boxes [N, K, 4] | None, pre_prob [N, K] | None)
+    with rows beyond counts[i] zero; candidates ordered by decreasing score."""
+    lib = _lib.load()
+    L, N = len(logits), len(image_sizes)
+    A = logits[0].shape[1]
+    dev = logits[0].device
+    _need_gpu(logits[0], "RPN logits")
+    keep_alive = []
+    lv = (_lib.snn_rpn_post_level * L)()
+    for l in range(L):
+        lo, de = _f32c(logits[l]), _f32c(deltas[l])
+        keep_alive += [lo, de]
+        H, W = level_hw[l]
+        if lo.shape != (N * H * W, A) or de.shape != (N * H * W, 4 * A):
+            raise _lib.SnnHipError("rpn_proposals: level %d has shapes %s / %s" % (l, tuple(lo.shape), tuple(de.shape)))
+        lv[l].logits, lv[l].deltas, lv[l].H, lv[l].W = lo.data_ptr(), de.data_ptr(), H, W
+        lv[l].stride_h, lv[l].stride_w = float(strides[l][0]), float(strides[l][1])
+        ba = base_anchors[l].detach().cpu().to(torch.float32)
+        for a in range(A):
+            for q in range(4):
+                lv[l].base_anchors[a][q] = float(ba[a, q])
+    K = lib.snn_rpn_proposals_candidates(lv, L, A, int(pre_nms_top_n))
+    if K <= 0:
+        raise _lib.SnnHipError("rpn_proposals: bad level description")
+    hw = (C.c_float * (2 * N))(*[float(v) for s in image_sizes for v in (s[0], s[1])])
+    boxes = torch.empty((N, post_nms_top_n, 4), dtype=torch.float32, device=dev)
+    scores = torch.empty((N, post_nms_top_n), dtype=torch.float32, device=dev)
+    counts = torch.empty((N,), dtype=torch.int32, device=dev)
+    pre_b = torch.empty((N, K, 4), dtype=torch.float32, device=dev) if want_pre else None
+    pre_p = torch.empty((N, K), dtype=torch.float32, device=dev) if want_pre else None
+    ws = _WS.get(dev, lib.snn_rpn_proposals_workspace_bytes(N, K))
+    _lib.check(lib.snn_rpn_proposals(lv, L, N, A, hw, int(pre_nms_top_n), int(post_nms_top_n), float(nms_thresh),
+                                     float(score_thresh), float(min_size), _ptr(boxes), _ptr(scores), _ptr(counts),
+                                     _ptr(pre_b), _ptr(pre_p), _ptr(ws), ws.numel(), _stream()), "snn_rpn_proposals")
+    return boxes, scores, counts, pre_b, pre_p

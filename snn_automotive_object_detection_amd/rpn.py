@@ -140,7 +140,10 @@ class RegionProposalNetwork(nn.Module):
         self.nms_thresh = nms_thresh
         self.score_thresh = score_thresh
         self.min_size = 1e-3                                                          # rpn.py:371
-        self.reference_post = False       # True: the reference's per-image post-processing order (filter_proposals_reference)
+        # proposal selection: "hip" = snn_rpn_proposals (six launches, one host sync), "batched" = stock torch ops with
+        # top-k before decode, "reference" = the reference's per-image order of operations; all three give the same
+        # proposals (tests/test_gpu_e2e.py).  CPU tensors always take "reference".
+        self.post = "hip"
 
     def pre_nms_top_n(self):
         return self._pre_nms_top_n["training" if self.training else "testing"]
@@ -226,16 +229,39 @@ class RegionProposalNetwork(nn.Module):
         final_scores = list(prob[img_of, pick].split(counts))
         return final_boxes, final_scores, pre_nms
 
+    def _proposals_hip(self, objectness, pred_bbox_deltas, images, feats):
+        from . import ops
+        N = objectness[0].shape[0]
+        A = objectness[0].shape[1]
+        lg, dl, hw, strides = [], [], [], []
+        image_size = images.tensors.shape[-2:]
+        for o, d in zip(objectness, pred_bbox_deltas):
+            H, W = o.shape[-2:]
+            # [N, A, H, W] views of position-major buffers (RPNHeadSNN): permute + reshape is copy-free
+            lg.append(o.detach().permute(0, 2, 3, 1).reshape(N * H * W, A))
+            dl.append(d.detach().permute(0, 2, 3, 1).reshape(N * H * W, 4 * A))
+            hw.append((H, W))
+            strides.append((image_size[0] // H, image_size[1] // W))
+        boxes, scores, counts, pre_b, pre_p = ops.rpn_proposals(
+            lg, dl, hw, strides, self.anchor_generator.cell_anchors, images.image_sizes, self.pre_nms_top_n(),
+            self.post_nms_top_n(), self.nms_thresh, self.score_thresh, self.min_size)
+        cnt = counts.tolist()                                                          # the one host synchronisation
+        final = [boxes[i, :c] for i, c in enumerate(cnt)]
+        pre_nms = [{"proposals": pre_b[i], "objectness": pre_p[i]} for i in range(N)]
+        return final, pre_nms
+
     def forward(self, images, features, targets=None):
         if self.training:
             raise NotImplementedError("inference only: training the RPN is out of scope (DESIGN.md §7)")
         feats = list(features.values())
         objectness, pred_bbox_deltas = self.head(feats)[:2]                           # rpn.py:613
+        if objectness[0].is_cuda and self.post == "hip":
+            return self._proposals_hip(objectness, pred_bbox_deltas, images, feats)
         anchors = self.anchor_generator(images, feats)
         num_images = len(anchors)
         num_anchors_per_level = [o.shape[1] * o.shape[2] * o.shape[3] for o in objectness]
         objectness, pred_bbox_deltas = concat_box_prediction_layers(objectness, pred_bbox_deltas)
-        if objectness.is_cuda and not self.reference_post:
+        if objectness.is_cuda and self.post == "batched":
             boxes, scores, pre_nms = self.filter_proposals(objectness, pred_bbox_deltas, anchors, images.image_sizes,
                                                            num_anchors_per_level)
         else:

@@ -1179,31 +1179,32 @@ __global__ __launch_bounds__(256) void k_li_heads(const uint32_t* __restrict__ s
             f32x4* dst = reinterpret_cast<f32x4*>(Wl);
             for (int i = tid; i < nw * 32 * NOp / 4; i += 256) dst[i] = src[i];
         }
-        // phase 1
-        for (int item = tid; item < RB * (HEADS_KS / 32); item += 256) {
-            const int row = item / (HEADS_KS / 32), wi = item % (HEADS_KS / 32);
+        // phase 1: item = (row, channel word, byte of the word) - 8 channels each, so that small row blocks (detector
+        // heads: RB = 16) still give every thread an item
+        for (int item = tid; item < RB * (HEADS_KS / 32) * 4; item += 256) {
+            const int q = item & 3, wi = (item >> 2) % (HEADS_KS / 32), row = (item >> 2) / (HEADS_KS / 32);
             const int m = m0 + row;
-            float sl_[32], ss_[32];
+            float sl_[8], ss_[8];
 #pragma unroll
-            for (int b = 0; b < 32; ++b) { sl_[b] = 0.f; ss_[b] = 0.f; }
+            for (int b = 0; b < 8; ++b) { sl_[b] = 0.f; ss_[b] = 0.f; }
             if (m < M && wi < nw) {
                 const uint32_t* wp = spk + (size_t)m * Kw + w0 + wi;
 #pragma unroll 4
                 for (int t = 0; t < T; ++t) {
-                    const uint32_t w = wp[(size_t)t * spk_stride];
+                    const uint32_t w = wp[(size_t)t * spk_stride] >> (8 * q);
                     const float kl = kap.last[t], ks = kap.sum[t];
 #pragma unroll
-                    for (int b = 0; b < 32; ++b) {
+                    for (int b = 0; b < 8; ++b) {
                         const float bit = (float)((w >> b) & 1u);
                         sl_[b] = fmaf(bit, kl, sl_[b]);            // exact: bit is 0 or 1
                         if (want_sum) ss_[b] = fmaf(bit, ks, ss_[b]);
                     }
                 }
             }
-            f32x4* dl = reinterpret_cast<f32x4*>(S_last + row * SST + wi * 32);
-            f32x4* ds = reinterpret_cast<f32x4*>(S_sum + row * SST + wi * 32);
+            f32x4* dl = reinterpret_cast<f32x4*>(S_last + row * SST + wi * 32 + q * 8);
+            f32x4* ds = reinterpret_cast<f32x4*>(S_sum + row * SST + wi * 32 + q * 8);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < 2; ++j) {
                 dl[j] = f32x4{sl_[4 * j], sl_[4 * j + 1], sl_[4 * j + 2], sl_[4 * j + 3]};
                 if (want_sum) ds[j] = f32x4{ss_[4 * j], ss_[4 * j + 1], ss_[4 * j + 2], ss_[4 * j + 3]};
             }
@@ -1239,6 +1240,162 @@ __global__ __launch_bounds__(256) void k_li_heads(const uint32_t* __restrict__ s
             else if (j < NA + NB) {
                 out_b[(size_t)m * NB + (j - NA)] = acc_l[r];
                 if (want_sum) sum_b[(size_t)m * NB + (j - NA)] = acc_s[r];
+            }
+        }
+    }
+}
+
+// K5b: the same heads on the bf16 matrix cores.  mem_T = sum_t kappa[t] * (spk_t . W): each  spk_t . W  is an exact
+// bf16x3 spike GEMM (spikes {0,1}, W = hi + mid + lo, fp32 accumulate) with all NOp <= 64 outputs in 1-4 MFMA column
+// tiles, and the kappa-weighted sum over t is an fma chain in the epilogue.  Wave = 16 rows x all T steps; the A
+// fragments come from the byte -> 8 bf16 table (as in k_gemm_bf16x3), the weights are split into their three bf16
+// planes while they are staged into LDS (no second packed copy): resident when all of W fits, else streamed per
+// 32-deep chunk (double-buffered).  Time steps go in groups of 8 (8 x NT accumulators).
+// RPN heads (196k rows, K=256, 15 outputs): 137 -> ~40 us;  detector heads (2000 rows, K=1024, 45 outputs): 88 -> ~15 us.
+#define LIH_TG 8
+struct LiHeadsArgs {
+    const uint32_t* spk; unsigned long long spk_stride;
+    const float* wT;              // [Kp][NOp] fp32 (snn_pack_heads_weight)
+    float *out_a, *out_b, *sum_a, *sum_b;
+    int T, M, Kw, NOp, NA, NB, n_groups, resident;
+    Kappa kap;
+};
+
+template <int NT>
+__global__ __launch_bounds__(256) void k_li_heads_mfma(const LiHeadsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const lut = smem;                           // 4 KB
+    unsigned char* const bbase = smem + G3_LUT_BYTES;          // [chunk slot][3][NOp][64 B]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lg = lane >> 4, lg8 = 8 * lg;
+    const int NOp = a.NOp, Kc = a.Kw;
+    const uint32_t slot_bytes = 3u * NOp * 64u;
+    {
+        uint4 q;
+        q.x = bf16_pair(tid, 0); q.y = bf16_pair(tid, 1); q.z = bf16_pair(tid, 2); q.w = bf16_pair(tid, 3);
+        *reinterpret_cast<uint4*>(lut + tid * 16) = q;
+    }
+    auto stage = [&](int kc, int slot) {                       // split W[32kc .. 32kc+31][NOp] into 3 bf16 planes
+        unsigned char* dst = bbase + (size_t)slot * slot_bytes;
+        for (int item = tid; item < 16 * NOp; item += 256) {
+            const int n = item % NOp, kp = item / NOp;
+            const float* src = a.wT + (size_t)(32 * kc + 2 * kp) * NOp + n;
+            uint32_t pl[3] = {0u, 0u, 0u};
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float w = src[(size_t)h * NOp];
+                const uint16_t hi = f2bf_rn(w);
+                const float r1 = __fsub_rn(w, bf2f(hi));
+                const uint16_t mid = f2bf_rn(r1);
+                const uint16_t lo = f2bf_rn(__fsub_rn(r1, bf2f(mid)));
+                pl[0] |= (uint32_t)hi << (16 * h); pl[1] |= (uint32_t)mid << (16 * h); pl[2] |= (uint32_t)lo << (16 * h);
+            }
+            const int off = n * 64 + ((((kp >> 2) ^ G3_SWZ(n)) << 4) | ((kp & 3) << 2));
+#pragma unroll
+            for (int q = 0; q < 3; ++q) *reinterpret_cast<uint32_t*>(dst + q * NOp * 64 + off) = pl[q];
+        }
+    };
+    if (a.resident)
+        for (int kc = 0; kc < Kc; ++kc) stage(kc, kc);
+    __syncthreads();
+    const unsigned char* const b_rd = bbase + lr * 64 + ((lg ^ G3_SWZ(lr)) << 4);
+    for (int g = blockIdx.x; g < a.n_groups; g += gridDim.x) {
+        const int m0 = (g * 4 + wave) * 16;
+        const int mrow = min(m0 + lr, a.M - 1);                 // rows past M: recomputed, never stored
+        const uint32_t* wsrc = a.spk + (size_t)mrow * a.Kw;
+        f32x4 o_last[NT], o_sum[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) { o_last[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; o_sum[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int tg0 = 0; tg0 < a.T; tg0 += LIH_TG) {
+            const int tn = min(LIH_TG, a.T - tg0);              // block-uniform
+            f32x4 acc[LIH_TG][NT];
+#pragma unroll
+            for (int t = 0; t < LIH_TG; ++t)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[t][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            auto chunk = [&](int kc, const uint32_t (&w_cur)[LIH_TG]) {
+                const unsigned char* bs = b_rd + (size_t)(a.resident ? kc : (kc & 1)) * slot_bytes;
+                bf16x8 b[3][NT];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        b[pl][nt] = *reinterpret_cast<const bf16x8*>(bs + (pl * NOp + nt * 16) * 64);
+#pragma unroll
+                for (int t = 0; t < LIH_TG; ++t) {
+                    if (t < tn) {
+                        const bf16x8 af = *reinterpret_cast<const bf16x8*>(lut + (__builtin_amdgcn_ubfe(w_cur[t], lg8, 8) << 4));
+#pragma unroll
+                        for (int pl = 2; pl >= 0; --pl)
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+                                acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, b[pl][nt], acc[t][nt], 0, 0, 0);
+                    }
+                }
+            };
+            if (a.resident && Kc == 8) {
+                // C = 256: the 8 spike words of a (t, row) are one 32-byte line - all T x 8 words are requested up
+                // front (one memory latency per row tile instead of one per chunk)
+                uint4 wl[LIH_TG][2];
+#pragma unroll
+                for (int t = 0; t < LIH_TG; ++t) {
+                    const uint4* q = reinterpret_cast<const uint4*>(wsrc + (size_t)(tg0 + (t < tn ? t : 0)) * a.spk_stride);
+                    wl[t][0] = q[0]; wl[t][1] = q[1];
+                }
+#pragma unroll
+                for (int kc = 0; kc < 8; ++kc) {
+                    uint32_t w_cur[LIH_TG];
+#pragma unroll
+                    for (int t = 0; t < LIH_TG; ++t) {
+                        const uint4 v = wl[t][kc >> 2];
+                        w_cur[t] = (kc & 3) == 0 ? v.x : (kc & 3) == 1 ? v.y : (kc & 3) == 2 ? v.z : v.w;
+                    }
+                    chunk(kc, w_cur);
+                }
+            } else {
+                uint32_t w_nxt[LIH_TG];
+#pragma unroll
+                for (int t = 0; t < LIH_TG; ++t) w_nxt[t] = t < tn ? wsrc[(size_t)(tg0 + t) * a.spk_stride] : 0u;
+                if (!a.resident) { stage(0, 0); __syncthreads(); }
+                for (int kc = 0; kc < Kc; ++kc) {
+                    uint32_t w_cur[LIH_TG];
+#pragma unroll
+                    for (int t = 0; t < LIH_TG; ++t) w_cur[t] = w_nxt[t];
+                    if (kc + 1 < Kc) {
+#pragma unroll
+                        for (int t = 0; t < LIH_TG; ++t) w_nxt[t] = t < tn ? wsrc[(size_t)(tg0 + t) * a.spk_stride + kc + 1] : 0u;
+                        if (!a.resident) stage(kc + 1, (kc + 1) & 1);
+                    }
+                    chunk(kc, w_cur);
+                    if (!a.resident) __syncthreads();           // chunk kc+1 staged, chunk kc consumed
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < LIH_TG; ++t)
+                if (t < tn) {
+                    const float kl = a.kap.last[tg0 + t], ks = a.kap.sum[tg0 + t];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            o_last[nt][r] = fmaf(kl, acc[t][nt][r], o_last[nt][r]);
+                            o_sum[nt][r] = fmaf(ks, acc[t][nt][r], o_sum[nt][r]);
+                        }
+                }
+        }
+        // lane holds rows lg*4 + r, output column nt*16 + lr
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int j = nt * 16 + lr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + lg * 4 + r;
+                if (m >= a.M) continue;
+                if (j < a.NA) { a.out_a[(size_t)m * a.NA + j] = o_last[nt][r]; if (a.sum_a) a.sum_a[(size_t)m * a.NA + j] = o_sum[nt][r]; }
+                else if (j < a.NA + a.NB) {
+                    a.out_b[(size_t)m * a.NB + (j - a.NA)] = o_last[nt][r];
+                    if (a.sum_b) a.sum_b[(size_t)m * a.NB + (j - a.NA)] = o_sum[nt][r];
+                }
             }
         }
     }
@@ -2031,6 +2188,32 @@ int snn_li_heads(const uint32_t* spk, size_t spk_stride, int T, int M, int K, co
     li_kappa(p, T, &kap);
     const int Kw = cdiv(K, 32), NOp = cdiv(NA + NB, 16) * 16;
     if (NOp > 256) return fail(-1, "snn_li_heads: %d outputs per row not supported", NA + NB);
+    const char* force = getenv("SNN_LI_HEADS");               // debug / A-B knob: "valu" forces the fp32 VALU kernel
+    // matrix-core kernel where all of W (as three bf16 planes) stays resident in LDS; the streamed form is latency
+    // bound on small row counts (detector heads: 164 us against 88 us for the VALU kernel) and only runs when forced
+    const bool fits = (size_t)Kw * 3 * NOp * 64 <= 96 * 1024;
+    if (NOp <= 64 && (force ? !strcmp(force, "mfma") : fits)) {
+        LiHeadsArgs a;
+        memset(&a, 0, sizeof(a));
+        a.spk = spk; a.spk_stride = spk_stride; a.wT = w_heads_packed; a.out_a = out_a; a.out_b = out_b;
+        a.sum_a = sum_a; a.sum_b = sum_b; a.T = T; a.M = M; a.Kw = Kw; a.NOp = NOp; a.NA = NA; a.NB = NB; a.kap = kap;
+        a.n_groups = cdiv(M, 64);
+        const size_t all = (size_t)Kw * 3 * NOp * 64;
+        a.resident = all <= 96 * 1024;
+        const size_t lds = G3_LUT_BYTES + (a.resident ? all : (size_t)2 * 3 * NOp * 64);
+        const int nt = NOp / 16;
+        const void* kern = nt == 1 ? (const void*)k_li_heads_mfma<1> : nt == 2 ? (const void*)k_li_heads_mfma<2>
+                         : nt == 3 ? (const void*)k_li_heads_mfma<3> : (const void*)k_li_heads_mfma<4>;
+        hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail(-3, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+        // resident weights: persistent work-groups (staging once per work-group); streamed: one row group each
+        const int grid = a.resident ? min(a.n_groups, 4 * g3_slots()) : a.n_groups;
+        void* kargs[] = {(void*)&a};
+        e = hipLaunchKernel(kern, dim3(grid), dim3(256), kargs, lds, (hipStream_t)s);
+        if (e != hipSuccess) return fail(-3, "k_li_heads_mfma launch failed: %s", hipGetErrorString(e));
+        SNN_CHECK_LAUNCH("k_li_heads_mfma");
+        return 0;
+    }
     // rows per block: as many as 256 threads can own (row, 4-output group) pairs for
     const int jg = NOp / 4;
     const int rb = (256 / jg >= 64) ? 64 : (256 / jg >= 32) ? 32 : (256 / jg >= 16) ? 16 : (256 / jg >= 8) ? 8 : 4;

@@ -229,3 +229,40 @@ def test_spike_conv3x3_bf16x3_teacher_forced(S, gpu_device, name):
     # un-fused pair bit for bit: same MFMA order, same element-wise arithmetic
     fused = S.conv3x3_lif_bf16x3(enc, shapes, C, C, p, wp)
     assert torch.equal(fused, spk)
+
+
+@pytest.mark.parametrize("T", [4, 12])
+def test_bf16x3_kernel_variants_bit_identical(S, gpu_device, monkeypatch, T):
+    """The fallbacks / alternative tilings of k_gemm_bf16x3 give the same bits as the default launch: register-resident
+    LIF (SNN_BF16X3_LIF=reg, the any-T fallback) vs T-in-tile fusion, and 128/192-row work-group tiles
+    (SNN_BF16X3_MT) vs 256-row tiles - same products, same accumulation order per output, same LIF arithmetic."""
+    g = torch.Generator().manual_seed(11 + T)
+    C = 96
+    shapes = [(2, 9, 14), (2, 5, 7), (1, 3, 3)]
+    P = sum(n * h * w for n, h, w in shapes)
+    p = _params(S)
+    enc = torch.randint(-2**31, 2**31 - 1, (T, P, 3), generator=g, dtype=torch.int64).to(torch.int32)
+    enc = (enc & torch.randint(-2**31, 2**31 - 1, (T, P, 3), generator=g, dtype=torch.int64).to(torch.int32)).to(gpu_device)
+    w = (torch.randn(C, C, 3, 3, generator=g) * 0.05).to(gpu_device)
+    wp = S.pack_conv3x3_bf16x3(w)
+    base = S.conv3x3_lif_bf16x3(enc, shapes, C, C, p, wp)
+    assert base.ne(0).any()
+    for mt in ("2", "3", "4"):
+        monkeypatch.setenv("SNN_BF16X3_MT", mt)
+        assert torch.equal(S.conv3x3_lif_bf16x3(enc, shapes, C, C, p, wp), base), "MT=" + mt
+    monkeypatch.delenv("SNN_BF16X3_MT")
+    monkeypatch.setenv("SNN_BF16X3_LIF", "reg")
+    assert torch.equal(S.conv3x3_lif_bf16x3(enc, shapes, C, C, p, wp), base)
+    monkeypatch.delenv("SNN_BF16X3_LIF")
+    # linear layer + LIF: tile variants, and the un-fused pair
+    R, K, N = 45, 200, 70
+    a = torch.randint(-2**31, 2**31 - 1, (T, R, 7), generator=g, dtype=torch.int64).to(torch.int32).to(gpu_device)
+    a[..., 6] &= 0xFF                                             # K = 200: bits past K are zero in real planes
+    wl = (torch.randn(N, K, generator=g) * 0.1).to(gpu_device)
+    wlp = S.pack_linear_bf16x3(wl)
+    base = S.spike_gemm_lif_bf16x3(a, K, N, p, wlp)
+    for mt in ("2", "3", "4"):
+        monkeypatch.setenv("SNN_BF16X3_MT", mt)
+        assert torch.equal(S.spike_gemm_lif_bf16x3(a, K, N, p, wlp), base), "MT=" + mt
+        cur = S.spike_gemm_bf16x3(a.view(T * R, -1), K, N, wlp)
+        assert torch.equal(S.lif_scan(cur.view(T, R, -1), N, p)[..., :base.shape[-1]], base)

@@ -181,6 +181,20 @@ int snn_rpn_proposals(const snn_rpn_post_level* levels, int n_levels, int N, int
                       float* pre_prob /* nullable [N][K] */, void* workspace, size_t workspace_bytes,
                       snn_stream_t stream);
 
+/* ---- detection post-processing (roi_heads.py:1075-1176, incl. the reference's background-box report): softmax,
+ * per-class box decode, clip, score / size filters, per-class NMS, detections_per_img - five
+ * launches for the batch, no host synchronisation.  Rows of image i in out_* [N][out_cap]: out_counts[2i] foreground
+ * detections by decreasing score, then out_counts[2i+1] background boxes (RoIs without any class above the score
+ * threshold).  all_scores [R][K] / all_boxes [R][K][4] receive the softmax scores and clipped boxes of every class.
+ * out_cap >= detections_per_img + max RoIs per image; (K-1) * max RoIs per image <= 16384, else -4. */
+size_t snn_det_postprocess_workspace_bytes(int N, int max_rois_per_image, int K);
+int snn_det_postprocess(const float* class_logits, const float* box_regression, const float* proposals,
+                        const int* rois_per_image_host, int N, int K, const float* image_hw_host,
+                        const float* box_weights_host /* [4]: BoxCoder weights, (10, 10, 5, 5) in the reference */,
+                        float score_thresh, float nms_thresh, int detections_per_img, float min_size,
+                        float* all_scores, float* all_boxes, float* out_boxes, float* out_scores, int* out_labels,
+                        int* out_counts, int out_cap, void* workspace, size_t workspace_bytes, snn_stream_t stream);
+
 /* ---- stage-level entry points (parity tests drive the layers one by one, teacher-forced) ----- */
 /* constant-current LIF encoder -> bit-planes.  NCHW feature map -> planes[T][N*H*W][Cw]          */
 int snn_encode_nchw(const float* feat, int N, int C, int H, int W, int T, const snn_params* p_host,

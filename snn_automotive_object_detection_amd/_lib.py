@@ -73,6 +73,10 @@ SYMBOLS = {
     "snn_rpn_proposals": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float,
                                     C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                     c_stream]),
+    "snn_det_postprocess_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "snn_det_postprocess": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float,
+                                      C.c_float, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, c_stream]),
     "snn_nms_sorted": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.c_size_t, c_stream]),
     "snn_roi_align_encode": (C.c_int, [C.POINTER(snn_roi_level), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,

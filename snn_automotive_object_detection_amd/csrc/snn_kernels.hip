@@ -1764,6 +1764,131 @@ __global__ __launch_bounds__(256) void k_rpn_output(const RpnPostArgs a, const i
     if (threadIdx.x == 0) out_counts[img] = cnt;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Detection post-processing (roi_heads.py:1075-1176, the reference's variant that also reports background boxes),
+// one call for the batch.  Per image two candidate lists: foreground (RoI x class >= 1) and background (RoIs without
+// any class above the score threshold, class-0 box); each list is sorted by decreasing score (ties: lower candidate
+// index, as a stable sort), goes through NMS (category = class) and the kept boxes are written fg first, then bg.
+//   k_det_candidates  per list slot: softmax, BoxCoder(10,10,5,5).decode, clip, score / size filters; also all_scores / all_boxes
+//   k_sort_lists      per list: bitonic sort in LDS (<= 16384 slots), gather into score order
+//   k_nms_mask / k_nms_scan (batched over the 2N lists),  k_det_output
+// ------------------------------------------------------------------------------------------------
+#define DET_SORT_MAX 16384
+struct DetPostArgs {
+    const float* logits;          // [R][K]
+    const float* deltas;          // [R][4K]
+    const float* props;           // [R][4]
+    int roi_base[RPN_MAX_IMAGES + 1];
+    float img_h[RPN_MAX_IMAGES], img_w[RPN_MAX_IMAGES];
+    int N, K, Kcap, det_per_img, out_cap;
+    float score_thresh, min_size, clip, wx, wy, ww, wh;
+    float* all_scores; float* all_boxes;                       // [R][K], [R][K][4]
+    float* boxes; float* skey; int* cat;                       // [2N][Kcap] candidate lists
+    float* s_boxes; float* s_score; int* s_cat; int* n_valid;   // sorted
+};
+
+__global__ __launch_bounds__(256) void k_det_candidates(const DetPostArgs a) {
+    const int list = blockIdx.y, img = list >> 1, bg = list & 1;
+    const int slot = blockIdx.x * 256 + threadIdx.x;
+    if (slot >= a.Kcap) return;
+    const int Ri = a.roi_base[img + 1] - a.roi_base[img];
+    const int rl = bg ? slot : slot / (a.K - 1), k = bg ? 0 : slot % (a.K - 1) + 1;
+    const size_t o = (size_t)list * a.Kcap + slot;
+    if (rl >= Ri) { a.skey[o] = -1.0f; a.cat[o] = 0; reinterpret_cast<float4*>(a.boxes)[o] = make_float4(0.f, 0.f, 0.f, 0.f); return; }
+    const int r = a.roi_base[img] + rl;
+    const float* lg = a.logits + (size_t)r * a.K;
+    float mx = lg[0];
+    for (int j = 1; j < a.K; ++j) mx = fmaxf(mx, lg[j]);
+    float sum = 0.0f;
+    bool has_fg_cand = false;                                   // filled below once the scores are known
+    for (int j = 0; j < a.K; ++j) sum = __fadd_rn(sum, expf(__fsub_rn(lg[j], mx)));
+    const float score = __fdiv_rn(expf(__fsub_rn(lg[k], mx)), sum);
+    if (bg)
+        for (int j = 1; j < a.K; ++j) has_fg_cand |= __fdiv_rn(expf(__fsub_rn(lg[j], mx)), sum) > a.score_thresh;
+    // BoxCoder(weights).decode_single
+    const float4 pb = reinterpret_cast<const float4*>(a.props)[r];
+    const float* d = a.deltas + (size_t)r * 4 * a.K + 4 * k;
+    const float w = __fsub_rn(pb.z, pb.x), h = __fsub_rn(pb.w, pb.y);
+    const float cx = __fadd_rn(pb.x, __fmul_rn(0.5f, w)), cy = __fadd_rn(pb.y, __fmul_rn(0.5f, h));
+    const float dx = __fdiv_rn(d[0], a.wx), dy = __fdiv_rn(d[1], a.wy);
+    const float dw = fminf(__fdiv_rn(d[2], a.ww), a.clip), dh = fminf(__fdiv_rn(d[3], a.wh), a.clip);
+    const float pcx = __fadd_rn(__fmul_rn(dx, w), cx), pcy = __fadd_rn(__fmul_rn(dy, h), cy);
+    const float hw = __fmul_rn(0.5f, __fmul_rn(expf(dw), w)), hh = __fmul_rn(0.5f, __fmul_rn(expf(dh), h));
+    const float W_ = a.img_w[img], H_ = a.img_h[img];
+    const float x1 = fminf(fmaxf(__fsub_rn(pcx, hw), 0.0f), W_), y1 = fminf(fmaxf(__fsub_rn(pcy, hh), 0.0f), H_);
+    const float x2 = fminf(fmaxf(__fadd_rn(pcx, hw), 0.0f), W_), y2 = fminf(fmaxf(__fadd_rn(pcy, hh), 0.0f), H_);
+    a.all_scores[(size_t)r * a.K + k] = score;
+    reinterpret_cast<float4*>(a.all_boxes)[(size_t)r * a.K + k] = make_float4(x1, y1, x2, y2);
+    const bool big = __fsub_rn(x2, x1) >= a.min_size && __fsub_rn(y2, y1) >= a.min_size;
+    const bool valid = big && (bg ? !has_fg_cand : score > a.score_thresh);
+    reinterpret_cast<float4*>(a.boxes)[o] = make_float4(x1, y1, x2, y2);
+    a.skey[o] = valid ? score : -1.0f;
+    a.cat[o] = k;
+}
+
+// one block per list: order = decreasing (score, then lower slot); n_valid = candidates with score >= 0
+__global__ __launch_bounds__(1024) void k_sort_lists(const float* __restrict__ skey, const float* __restrict__ boxes,
+                                                     const int* __restrict__ cat, int Kcap, float* __restrict__ s_boxes,
+                                                     float* __restrict__ s_score, int* __restrict__ s_cat,
+                                                     int* __restrict__ n_valid) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long* v = reinterpret_cast<unsigned long long*>(smem);
+    const int list = blockIdx.x, tid = threadIdx.x;
+    int np2 = 1;
+    while (np2 < Kcap) np2 <<= 1;
+    for (int i = tid; i < np2; i += 1024)
+        v[i] = i < Kcap ? ((unsigned long long)f2key(skey[(size_t)list * Kcap + i]) << 32) | (uint32_t)(~(uint32_t)i) : 0ull;
+    __syncthreads();
+    for (int k = 2; k <= np2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < np2; i += 1024) {
+                const int p = i ^ j;
+                if (p > i) {
+                    const unsigned long long x = v[i], y = v[p];
+                    const bool desc = (i & k) == 0;
+                    if (desc ? x < y : x > y) { v[i] = y; v[p] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    int valid = 0;
+    for (int i = tid; i < Kcap; i += 1024) {
+        const int c = (int)(~(uint32_t)v[i]);
+        const size_t src = (size_t)list * Kcap + c, dst = (size_t)list * Kcap + i;
+        reinterpret_cast<float4*>(s_boxes)[dst] = reinterpret_cast<const float4*>(boxes)[src];
+        const float sc = skey[src];
+        s_score[dst] = sc;
+        s_cat[dst] = cat[src];
+        valid += sc >= 0.0f;
+    }
+    for (int off = 32; off > 0; off >>= 1) valid += __shfl_down(valid, off);
+    __syncthreads();                                            // v[] is free now
+    int* part = reinterpret_cast<int*>(smem);
+    if ((tid & 63) == 0) part[tid >> 6] = valid;
+    __syncthreads();
+    if (tid == 0) {
+        int t = 0;
+        for (int w = 0; w < 16; ++w) t += part[w];
+        n_valid[list] = t;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_det_output(const DetPostArgs a, const int* __restrict__ keep, const int* __restrict__ n_keep,
+                                                    float* __restrict__ out_boxes, float* __restrict__ out_scores,
+                                                    int* __restrict__ out_labels, int* __restrict__ out_counts) {
+    const int img = blockIdx.x;
+    const int n_fg = min(n_keep[2 * img], a.det_per_img), n_bg = n_keep[2 * img + 1];
+    for (int r = threadIdx.x; r < n_fg + n_bg; r += 256) {
+        const int list = r < n_fg ? 2 * img : 2 * img + 1;
+        const size_t src = (size_t)list * a.Kcap + keep[(size_t)list * a.Kcap + (r < n_fg ? r : r - n_fg)];
+        const size_t dst = (size_t)img * a.out_cap + r;
+        reinterpret_cast<float4*>(out_boxes)[dst] = reinterpret_cast<const float4*>(a.s_boxes)[src];
+        out_scores[dst] = a.s_score[src];
+        out_labels[dst] = a.s_cat[src];
+    }
+    if (threadIdx.x == 0) { out_counts[2 * img] = n_fg; out_counts[2 * img + 1] = n_bg; }
+}
+
 // impulse responses of the LI cell (norse leaky_integrator.py: li_feed_forward_step; v_leak = 0)
 static void li_kappa(const snn_params* p, int T, Kappa* k) {
     const double a = (double)p->dt_tau_mem, cb = (double)p->neg_dt_tau_syn;
@@ -2427,6 +2552,88 @@ int snn_rpn_proposals(const snn_rpn_post_level* lv, int n_levels, int N, int A, 
     SNN_CHECK_LAUNCH("k_nms_scan");
     hipLaunchKernelGGL(k_rpn_output, dim3(N), dim3(256), 0, s, a, keep, n_keep, out_boxes, out_scores, out_counts);
     SNN_CHECK_LAUNCH("k_rpn_output");
+    return 0;
+}
+
+// ---- detection post-processing ------------------------------------------------------------------
+static size_t det_post_layout(int N, int Kcap, size_t off[11]) {
+    const size_t L = 2 * (size_t)N, lk = L * Kcap;
+    const size_t sz[11] = {lk * 16, lk * 4, lk * 4, lk * 16, lk * 4, lk * 4, L * 4, lk * 4, L * 4, lk * cdiv(Kcap, 64) * 8, 0};
+    size_t o = 0;
+    for (int i = 0; i < 11; ++i) { off[i] = o; o += align_up(sz[i], 256); }
+    return o;
+}
+
+size_t snn_det_postprocess_workspace_bytes(int N, int max_rois_per_image, int K) {
+    size_t off[11];
+    if (N <= 0 || max_rois_per_image <= 0 || K < 2) return 0;
+    return det_post_layout(N, max_rois_per_image * (K - 1), off);
+}
+
+int snn_det_postprocess(const float* class_logits, const float* box_regression, const float* proposals,
+                        const int* rois_per_image_host, int N, int K, const float* image_hw_host,
+                        const float* box_weights_host, float score_thresh, float nms_thresh, int detections_per_img,
+                        float min_size, float* all_scores, float* all_boxes, float* out_boxes, float* out_scores,
+                        int* out_labels, int* out_counts, int out_cap, void* ws, size_t ws_bytes, snn_stream_t stream) {
+    if (!class_logits || !box_regression || !proposals || !rois_per_image_host || !image_hw_host || !box_weights_host || !all_scores ||
+        !all_boxes || !out_boxes || !out_scores || !out_labels || !out_counts || !ws)
+        return fail(-1, "snn_det_postprocess: null argument");
+    if (N <= 0 || N > RPN_MAX_IMAGES || K < 2 || detections_per_img <= 0)
+        return fail(-1, "snn_det_postprocess: bad argument (images <= %d)", RPN_MAX_IMAGES);
+    DetPostArgs a;
+    memset(&a, 0, sizeof(a));
+    int rmax = 0;
+    for (int i = 0; i < N; ++i) {
+        if (rois_per_image_host[i] < 0) return fail(-1, "snn_det_postprocess: negative RoI count");
+        a.roi_base[i + 1] = a.roi_base[i] + rois_per_image_host[i];
+        rmax = max(rmax, rois_per_image_host[i]);
+        a.img_h[i] = image_hw_host[2 * i]; a.img_w[i] = image_hw_host[2 * i + 1];
+    }
+    if (rmax == 0) {
+        if (hipMemsetAsync(out_counts, 0, sizeof(int) * 2 * N, (hipStream_t)stream) != hipSuccess) return fail(-3, "hipMemsetAsync failed");
+        return 0;
+    }
+    const int Kcap = rmax * (K - 1);
+    if (Kcap > DET_SORT_MAX) return fail(-4, "snn_det_postprocess: %d candidates per image (max %d)", Kcap, DET_SORT_MAX);
+    if (out_cap < detections_per_img + rmax) return fail(-1, "snn_det_postprocess: out_cap %d < %d", out_cap, detections_per_img + rmax);
+    size_t off[11];
+    if (ws_bytes < det_post_layout(N, Kcap, off)) return fail(-2, "snn_det_postprocess: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    a.logits = class_logits; a.deltas = box_regression; a.props = proposals;
+    a.N = N; a.K = K; a.Kcap = Kcap; a.det_per_img = detections_per_img; a.out_cap = out_cap;
+    a.score_thresh = score_thresh; a.min_size = min_size; a.clip = (float)4.135166556742356;
+    a.wx = box_weights_host[0]; a.wy = box_weights_host[1]; a.ww = box_weights_host[2]; a.wh = box_weights_host[3];
+    a.all_scores = all_scores; a.all_boxes = all_boxes;
+    char* w = (char*)ws;
+    a.boxes = (float*)(w + off[0]); a.skey = (float*)(w + off[1]); a.cat = (int*)(w + off[2]);
+    a.s_boxes = (float*)(w + off[3]); a.s_score = (float*)(w + off[4]); a.s_cat = (int*)(w + off[5]); a.n_valid = (int*)(w + off[6]);
+    int* keep = (int*)(w + off[7]);
+    int* n_keep = (int*)(w + off[8]);
+    unsigned long long* mask = (unsigned long long*)(w + off[9]);
+    const int L = 2 * N;
+    hipLaunchKernelGGL(k_det_candidates, dim3(cdiv(Kcap, 256), L), dim3(256), 0, s, a);
+    SNN_CHECK_LAUNCH("k_det_candidates");
+    int np2 = 1;
+    while (np2 < Kcap) np2 <<= 1;
+    const size_t sort_lds = (size_t)np2 * 8;
+    hipError_t e = hipFuncSetAttribute((const void*)k_sort_lists, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds);
+    if (e != hipSuccess) return fail(-3, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(k_sort_lists, dim3(L), dim3(1024), sort_lds, s, a.skey, a.boxes, a.cat, Kcap, a.s_boxes, a.s_score, a.s_cat, a.n_valid);
+    SNN_CHECK_LAUNCH("k_sort_lists");
+    const int words = cdiv(Kcap, 64);
+    NmsBatch nb;
+    nb.n_dev = a.n_valid; nb.boxes_stride = (long long)Kcap * 4; nb.cat_stride = Kcap; nb.mask_stride = (long long)Kcap * words;
+    nb.keep_stride = Kcap;
+    hipLaunchKernelGGL(k_nms_mask, dim3(words, words, L), dim3(64), 0, s, a.s_boxes, a.s_cat, Kcap, nms_thresh, mask, words, nb);
+    SNN_CHECK_LAUNCH("k_nms_mask");
+    const int dbl = words <= 156 ? 1 : 0;
+    const size_t lds = (size_t)(1 + dbl) * 64 * words * 8;
+    e = hipFuncSetAttribute((const void*)k_nms_scan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail(-3, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(k_nms_scan, dim3(L), dim3(256), lds, s, mask, Kcap, words, Kcap, dbl, keep, n_keep, nb);
+    SNN_CHECK_LAUNCH("k_nms_scan");
+    hipLaunchKernelGGL(k_det_output, dim3(N), dim3(256), 0, s, a, keep, n_keep, out_boxes, out_scores, out_labels, out_counts);
+    SNN_CHECK_LAUNCH("k_det_output");
     return 0;
 }
 

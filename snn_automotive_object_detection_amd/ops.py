@@ -483,3 +483,35 @@ def rpn_proposals(logits: Sequence[torch.Tensor], deltas: Sequence[torch.Tensor]
                                      float(score_thresh), float(min_size), _ptr(boxes), _ptr(scores), _ptr(counts),
                                      _ptr(pre_b), _ptr(pre_p), _ptr(ws), ws.numel(), _stream()), "snn_rpn_proposals")
     return boxes, scores, counts, pre_b, pre_p
+
+
+def det_postprocess(class_logits: torch.Tensor, box_regression: torch.Tensor, proposals: torch.Tensor, rois_per_image,
+                    image_sizes, box_weights, score_thresh: float, nms_thresh: float, detections_per_img: int,
+                    min_size: float = 1e-2):
+    """Detection post-processing for a batch (roi_heads.py:1075-1176) in five launches.
+    class_logits [R, K], box_regression [R, 4K], proposals [R, 4] (all images concatenated), rois_per_image = [R_i].
+    Returns (boxes [N, cap, 4], scores [N, cap], labels [N, cap] int32, counts [N, 2] int32 (fg, bg), all_scores [R, K],
+    all_boxes [R, K, 4]); rows of image i: counts[i,0] foreground detections, then counts[i,1] background boxes."""
+    lib = _lib.load()
+    _need_gpu(class_logits, "class logits")
+    dev = class_logits.device
+    N, K = len(rois_per_image), class_logits.shape[1]
+    R = class_logits.shape[0]
+    lg, dl, pr = _f32c(class_logits), _f32c(box_regression), _f32c(proposals)
+    rmax = max(rois_per_image) if N else 0
+    cap = int(detections_per_img) + rmax
+    boxes = torch.empty((N, cap, 4), dtype=torch.float32, device=dev)
+    scores = torch.empty((N, cap), dtype=torch.float32, device=dev)
+    labels = torch.empty((N, cap), dtype=torch.int32, device=dev)
+    counts = torch.empty((N, 2), dtype=torch.int32, device=dev)
+    all_scores = torch.empty((R, K), dtype=torch.float32, device=dev)
+    all_boxes = torch.empty((R, K, 4), dtype=torch.float32, device=dev)
+    rpi = (C.c_int * N)(*[int(r) for r in rois_per_image])
+    hw = (C.c_float * (2 * N))(*[float(v) for s in image_sizes for v in (s[0], s[1])])
+    ws = _WS.get(dev, max(1, lib.snn_det_postprocess_workspace_bytes(N, rmax, K)))
+    bw = (C.c_float * 4)(*[float(v) for v in box_weights])
+    _lib.check(lib.snn_det_postprocess(_ptr(lg), _ptr(dl), _ptr(pr), rpi, N, K, hw, bw, float(score_thresh), float(nms_thresh),
+                                       int(detections_per_img), float(min_size), _ptr(all_scores), _ptr(all_boxes),
+                                       _ptr(boxes), _ptr(scores), _ptr(labels), _ptr(counts), cap, _ptr(ws), ws.numel(),
+                                       _stream()), "snn_det_postprocess")
+    return boxes, scores, labels, counts, all_scores, all_boxes

@@ -27,6 +27,7 @@ class RoIHeadsSNN(nn.Module):
         self.nms_thresh = nms_thresh
         self.detections_per_img = detections_per_img
         self.fuse_roi_align = True        # use the fused RoIAlign+encoder kernel when pool/head support it
+        self.post = "hip"                 # "hip": snn_det_postprocess; "reference": the reference's order on stock torch ops
         # training-side hyper-parameters are accepted for signature compatibility only
         self.fg_iou_thresh, self.bg_iou_thresh = fg_iou_thresh, bg_iou_thresh
         self.batch_size_per_image, self.positive_fraction = batch_size_per_image, positive_fraction
@@ -42,6 +43,26 @@ class RoIHeadsSNN(nn.Module):
 
     def postprocess_detections(self, class_logits: Tensor, box_regression: Tensor, proposals: List[Tensor],
                                image_shapes: List[Tuple[int, int]]):
+        per_image = [p.shape[0] for p in proposals]
+        if (class_logits.is_cuda and self.post == "hip" and per_image and max(per_image) > 0
+                and max(per_image) * (class_logits.shape[-1] - 1) <= 16384):
+            return self._postprocess_hip(class_logits, box_regression, proposals, image_shapes, per_image)
+        return self.postprocess_detections_reference(class_logits, box_regression, proposals, image_shapes)
+
+    def _postprocess_hip(self, class_logits, box_regression, proposals, image_shapes, per_image):
+        """snn_det_postprocess: five launches and one host synchronisation for the batch"""
+        from . import ops
+        boxes, scores, labels, counts, all_scores, all_boxes = ops.det_postprocess(
+            class_logits.detach(), box_regression.detach(), torch.cat(proposals, 0), per_image, image_shapes,
+            self.box_coder.weights, self.score_thresh, self.nms_thresh, self.detections_per_img)
+        cnt = counts.sum(1).tolist()                                                   # the one host synchronisation
+        out = ([], [], [], list(all_scores.split(per_image, 0)), list(all_boxes.split(per_image, 0)))
+        for i, c in enumerate(cnt):
+            out[0].append(boxes[i, :c]); out[1].append(scores[i, :c]); out[2].append(labels[i, :c].to(torch.int64))
+        return out
+
+    def postprocess_detections_reference(self, class_logits: Tensor, box_regression: Tensor, proposals: List[Tensor],
+                                         image_shapes: List[Tuple[int, int]]):
         device = class_logits.device
         num_classes = class_logits.shape[-1]
         per_image = [p.shape[0] for p in proposals]

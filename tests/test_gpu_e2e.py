@@ -137,3 +137,33 @@ def test_rpn_hip_proposals_filters(gpu_device, score_thresh, min_size, post_n):
         if n:
             assert ((bh[:n] - br[:n]).abs().amax(1) > 1e-3).sum() <= 2 + 0.05 * n
             assert (bh[:, 2] - bh[:, 0]).min() >= min_size and (bh[:, 3] - bh[:, 1]).min() >= min_size
+
+
+@pytest.mark.parametrize("score_thresh", [0.05, 0.3])
+def test_det_postprocess_hip_equals_reference_order(gpu_device, score_thresh):
+    """RoIHeadsSNN.postprocess_detections: snn_det_postprocess against the reference's order on stock torch ops"""
+    import snn_automotive_object_detection_amd as S
+    torch.manual_seed(2)
+    m = S.create_model("cityscapes", 9, True, True, 0, False, False, num_steps_rpn=4, num_steps_detector=4)
+    rh = m.roi_heads.to(gpu_device).eval()
+    rh.score_thresh = score_thresh
+    g = torch.Generator().manual_seed(7)
+    per_image, shapes = [300, 1, 170], [(384, 768), (200, 500), (256, 300)]
+    R, K = sum(per_image), 9
+    logits = (torch.randn(R, K, generator=g) * 2.0).to(gpu_device)
+    logits[:40, 0] += 6.0                                                 # some RoIs that are background only
+    deltas = (torch.randn(R, 4 * K, generator=g) * 1.5).to(gpu_device)
+    xy = torch.rand(R, 2, generator=g) * 250
+    props = torch.cat([xy, xy + torch.rand(R, 2, generator=g) * 200 + 1], 1).to(gpu_device)
+    props = list(props.split(per_image, 0))
+    rh.post = "hip"
+    o_h = rh.postprocess_detections(logits, deltas, props, shapes)
+    rh.post = "reference"
+    o_r = rh.postprocess_detections(logits, deltas, props, shapes)
+    for i in range(3):
+        assert o_h[0][i].shape == o_r[0][i].shape, (i, o_h[0][i].shape, o_r[0][i].shape)
+        assert torch.allclose(o_h[0][i], o_r[0][i], atol=1e-3, rtol=1e-5)
+        assert torch.allclose(o_h[1][i], o_r[1][i], atol=1e-6)
+        assert torch.equal(o_h[2][i], o_r[2][i])
+        assert torch.allclose(o_h[3][i], o_r[3][i], atol=1e-6) and torch.allclose(o_h[4][i], o_r[4][i], atol=1e-3, rtol=1e-5)
+    assert any(bool((lab == 0).any()) for lab in o_h[2])                   # the background-only RoIs are reported

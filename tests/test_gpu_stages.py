@@ -266,3 +266,38 @@ def test_bf16x3_kernel_variants_bit_identical(S, gpu_device, monkeypatch, T):
         assert torch.equal(S.spike_gemm_lif_bf16x3(a, K, N, p, wlp), base), "MT=" + mt
         cur = S.spike_gemm_bf16x3(a.view(T * R, -1), K, N, wlp)
         assert torch.equal(S.lif_scan(cur.view(T, R, -1), N, p)[..., :base.shape[-1]], base)
+
+
+@pytest.mark.parametrize("C_in,C_out,T,shapes", [
+    (40, 200, 8, [(1, 7, 9), (2, 3, 4)]),          # padded input word, two column blocks, the second one partial
+    (256, 32, 5, [(1, 16, 16)]),                   # one 32-channel output word: half of a 64-column epilogue half
+    (33, 129, 16, [(3, 5, 5), (1, 1, 1), (1, 2, 9)]),
+    (64, 64, 24, [(1, 11, 13)]),                   # T = 24: 10 positions per 256-row tile, 16 rows idle
+    (96, 320, 3, [(2, 6, 6)]),                     # three column blocks
+])
+def test_conv3x3_lif_bf16x3_odd_shapes_equal_unfused_pair(S, gpu_device, C_in, C_out, T, shapes):
+    """T-in-tile fused conv + LIF == un-fused conv GEMM followed by the LIF scan, bit for bit, on shapes that exercise
+    channel padding, partial column blocks, 1x1 levels and T values that do not divide the row tile"""
+    g = torch.Generator().manual_seed(C_in * 1000 + C_out + T)
+    P = sum(n * h * w for n, h, w in shapes)
+    Cw = (C_in + 31) // 32
+    bits = torch.rand(T, P, Cw * 32, generator=g) < 0.2
+    bits[..., C_in:] = False
+    enc = dense_to_planes(bits.numpy().astype(np.float32)).to(gpu_device)
+    w = (torch.randn(C_out, C_in, 3, 3, generator=g) * 0.08).to(gpu_device)
+    wp = S.pack_conv3x3_bf16x3(w)
+    p = _params(S)
+    fused = S.conv3x3_lif_bf16x3(enc, shapes, C_in, C_out, p, wp)
+    cur = S.spike_conv3x3_bf16x3(enc, shapes, C_in, C_out, wp)
+    ref = S.lif_scan(cur, C_out, p)
+    assert fused.shape == ref.shape and torch.equal(fused, ref)
+    assert fused.ne(0).any()
+    # and the currents are the convolution (fp64 reference on the host)
+    x = bits[..., :C_in].double()
+    pos = 0
+    for n, h, wd in shapes:
+        xi = x[:, pos:pos + n * h * wd].reshape(T * n, h, wd, C_in).permute(0, 3, 1, 2)
+        exp = F.conv2d(xi, w.double().cpu(), padding=1).permute(0, 2, 3, 1).reshape(T, n * h * wd, C_out)
+        got = cur[:, pos:pos + n * h * wd, :C_out].double().cpu()
+        assert (got - exp).abs().max() <= 1e-5
+        pos += n * h * wd

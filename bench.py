@@ -169,9 +169,9 @@ def main():
         kernel, peak, exec_factor, kernel_ms = "k_conv3x3_lif<false>", PEAK_F32_MFMA_TFLOPS, 1.0, conv_ms
         traffic_key = "f32"
     else:
-        # stage 2 = k_gemm_bf16x3<3, 3, 4> (MODE = G3_CONV_LIF_TILE, 3-slot ring, 4 M-tiles per wave): 3x3 conv + LIF over T fused in the tile,
+        # stage 2 = k_gemm_bf16x3<3, 3, 4, 2> (MODE = G3_CONV_LIF_TILE, 3-slot ring, 4 M-tiles per wave, 4 x 2 wave grid): 3x3 conv + LIF over T fused in the tile,
         # on the bf16 matrix cores
-        kernel, peak, exec_factor, kernel_ms = "k_gemm_bf16x3<3, 3, 4>", PEAK_BF16_MFMA_TFLOPS, 3.0, conv_ms
+        kernel, peak, exec_factor, kernel_ms = "k_gemm_bf16x3<3, 3, 4, 2>", PEAK_BF16_MFMA_TFLOPS, 3.0, conv_ms
         traffic_key = "bf16x3"
     achieved = conv_fl / (kernel_ms * 1e-3) / 1e12             # ALGORITHMIC (dense-equivalent) TFLOP/s
     traffic = None                    # HBM bytes per launch of the dominant kernel, from the committed PMC passes

@@ -649,6 +649,9 @@ __device__ __forceinline__ const void* sgpr_ptr(const void* p) {
 }
 // Three pieces (the three weight planes of a chunk) per call; s_nop 4 / s_nop 0: SGPR -> VMEM-base and M0 -> LDS-DMA
 // wait states, which hipcc's hazard recogniser does not insert inside inline asm.
+__device__ __forceinline__ void glds16(const void* p0, uint32_t voff, uint32_t d0) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(p0), "s"(d0) : "memory", "m0");
+}
 __device__ __forceinline__ void glds16x3(const void* p0, const void* p1, const void* p2, uint32_t voff,
                                          uint32_t d0, uint32_t d1, uint32_t d2) {
     asm volatile("s_mov_b32 m0, %4\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1\n\t"
@@ -657,15 +660,19 @@ __device__ __forceinline__ void glds16x3(const void* p0, const void* p1, const v
                  :: "v"(voff), "s"(p0), "s"(p1), "s"(p2), "s"(d0), "s"(d1), "s"(d2) : "memory", "m0");
 }
 
-#define G3_BM 256
-#define G3_BN 128
+// Work-group tile: the 8 waves form (8 / WN) x WN; a wave is 16*MT rows x 64 columns.
+//   WN = 2: 64*MT rows x 128 columns (256 x 128 at MT = 4): 24 KB of weight planes per chunk
+//   WN = 1: 128*MT rows x 64 columns (512 x 64):            12 KB per chunk for the same MFMA work - half the L2 -> LDS
+//           copies per FLOP (the 256 x 128 tile pulls 14 B/clk/CU = 7 TB/s chip-wide out of the L2).  Measured equal.
+#define G3_BM(wn, mt) ((8 / (wn)) * 16 * (mt))
+#define G3_BN(wn) (64 * (wn))
 #define G3_ROWB 64                                  // bytes per LDS weight row: 32 bf16, four 16-B units, XOR-swizzled
-#define G3_AW_BYTES (G3_BM * 4)                     // raw spike words of one chunk (one per row): 1 KB
-#define G3_B_BYTES (3 * G3_BN * G3_ROWB)            // 24576: three weight planes of one chunk
-#define G3_SLOT (G3_AW_BYTES + G3_B_BYTES)          // one ring slot = one 32-deep chunk
+#define G3_AW_BYTES(wn) (G3_BM(wn, 4) * 4)          // raw spike words of one chunk (one per row): 1 or 2 KB
+#define G3_B_BYTES(wn) (3 * G3_BN(wn) * G3_ROWB)    // three weight planes of one chunk: 24 or 12 KB
+#define G3_SLOT(wn) (G3_AW_BYTES(wn) + G3_B_BYTES(wn))   // one ring slot = one 32-deep chunk
 #define G3_LUT_BYTES 4096                           // byte -> 8 bf16 (0 / 1.0) expansion table
-#define G3_STATE_BYTES (512 * 64)                   // fused variant: 16 LIF state values per thread
-#define G3_LDS(nb) (G3_LUT_BYTES + (nb) * G3_SLOT)   // table at offset 0, then the ring; 3 slots = 80896: two work-groups per CU
+#define G3_STATE_BYTES (512 * 64)                   // register-fused variant: 16 LIF state values per thread
+#define G3_LDS(nb, wn) (G3_LUT_BYTES + (nb) * G3_SLOT(wn))   // table at offset 0, then the ring (3 slots: 80896 / 47104 B)
 // unit u (= k-group 8u..8u+7) of weight row r lives at physical unit u ^ swz(r), swz = [0,3,2,1][(r >> 2) & 3].  A
 // 16x16x32 fragment read has lane l on row l&15, unit l>>4; the four 16-lane groups of a ds_read_b128
 // ({0-3,12-15,20-27}, {4-11,16-19,28-31}, +32) then each hit 16 distinct 16-B slots of the 256-B bank row.
@@ -710,18 +717,24 @@ __device__ __forceinline__ uint32_t bf16_pair(uint32_t w, int j) {      // bits 
 // v_mfma_f32_16x16x32_bf16 competes for the SIMD's vector issue, which the MFMAs alone hold half of the time).
 // PD = fragment prefetch distance inside a chunk, in groups of 4 MFMAs (one weight fragment per group).
 enum { G3_FC = 0, G3_CONV = 1, G3_CONV_LIF_REG = 2, G3_CONV_LIF_TILE = 3, G3_FC_LIF_TILE = 4 };
-#define G3_TILE_PITCH 68                            // floats per row of the LIF_TILE current tile in LDS (conflict-free)
+// LIF_TILE epilogue: the current tile goes through LDS in two passes of CG = 32*WN columns, row pitch CG + 4 floats
+// (conflict-free for the accumulator writes and the column reads)
+#define G3_TILE_CG(wn) (32 * (wn))
+#define G3_TILE_BYTES(wn) (G3_BM(wn, 4) * (G3_TILE_CG(wn) + 4) * 4)     // 69632 / 73728 B
 
 // MT = 16-row M-tiles per wave: the work-group tile is 64*MT rows (256; 192 / 128 only where a small problem spreads
 // better over the CUs that way - per unit of work the smaller tiles are slower: fc6 1.03 / 1.07 / 1.21 ms at MT 4 / 3 / 2).
-template <int MODE, int NB, int MT>
+template <int MODE, int NB, int MT, int WN>
 __global__ __launch_bounds__(512, MODE == G3_CONV_LIF_REG ? 2 : 4) void k_gemm_bf16x3(const Gemm3Args args) {
     constexpr bool CONV = MODE == G3_CONV || MODE == G3_CONV_LIF_REG || MODE == G3_CONV_LIF_TILE;
     constexpr bool FUSE = MODE == G3_CONV_LIF_REG, TILE = MODE == G3_CONV_LIF_TILE || MODE == G3_FC_LIF_TILE;
     static_assert(MT >= 2 && MT <= 4 && (MT == 4 || !FUSE), "M-tiles per wave");
-    constexpr int BM = 64 * MT, WROWS = 16 * MT;                // rows per work-group / per wave
+    static_assert(WN == 1 || (WN == 2 && true), "waves along N");
+    static_assert(WN == 2 || !FUSE, "the register-fused variant keeps the 4 x 2 wave grid");
+    constexpr int BM = G3_BM(WN, MT), BN = G3_BN(WN), WROWS = 16 * MT;   // rows, columns per work-group; rows per wave
+    constexpr int AW_BYTES = G3_AW_BYTES(WN);
     static_assert(NB == 3 || NB == 4, "ring depth");
-    constexpr int SLOT = G3_SLOT;
+    constexpr int SLOT = G3_SLOT(WN);
     constexpr int PD = (CONV && !FUSE) ? 2 : 3, RING = PD + 1;  // 12 groups per chunk: RING must divide 12 (the 128-register conv
                                                                // rows have 128 registers: one fragment less in flight)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -731,7 +744,7 @@ __global__ __launch_bounds__(512, MODE == G3_CONV_LIF_REG ? 2 : 4) void k_gemm_b
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     // Plain row-major tile order: column blocks of a row tile are neighbours in dispatch order.  (An XCD-aware order -
     // each XCD a contiguous eighth of the row tiles - ran at the same speed and TRIPLED the L2 fills of the conv
     // kernel, FETCH_SIZE 102 -> 323 MB per launch: profiles/r1_h_*; removed.)
@@ -746,10 +759,10 @@ __global__ __launch_bounds__(512, MODE == G3_CONV_LIF_REG ? 2 : 4) void k_gemm_b
         *reinterpret_cast<uint4*>(lut + tid * 16) = q;
     }
 
-    // ---- A staging role: waves 0-3, thread -> row.  A spike word is addressed as (wave-uniform 64-bit base in
-    // SGPRs) + (32-bit byte offset of the lane's row): no per-chunk 64-bit vector arithmetic ----
-    const bool a_role = wave < MT;
-    const int xrow = tid & 255;
+    // ---- A staging role: thread -> row (the first BM threads).  A spike word is addressed as (wave-uniform 64-bit
+    // base in SGPRs) + (32-bit byte offset of the lane's row): no per-chunk 64-bit vector arithmetic ----
+    const bool a_role = wave * 64 < BM;
+    const int xrow = tid & (G3_BM(WN, 4) - 1);
     const int xt = TILE ? xrow / args.pb : 0;       // TILE: time step of the row
     const int xm = TILE ? (xt < args.T ? m0 + xrow % args.pb : M) : m0 + xrow;
     uint32_t a_off = 0;                             // bytes: fc row / conv centre tap, channel word 0
@@ -823,21 +836,34 @@ __global__ __launch_bounds__(512, MODE == G3_CONV_LIF_REG ? 2 : 4) void k_gemm_b
         }
     };
 
-    // ---- B staging: LDS-DMA.  Wave w copies rows [16w, 16w+16) of each of the 3 planes (1 KiB per instruction);
-    // lane L lands in physical unit L&3 of row 16w + (L>>2), so it fetches logical unit (L&3) ^ swz(row): the
-    // swizzle is applied on the SOURCE address, the LDS image stays lane-linear ----
-    const int brow = wave * 16 + (lane >> 2);
-    const int bcol = min(nb * G3_BN + brow, Np - 1);           // columns past Np: any valid row (never stored)
+    // ---- B staging: LDS-DMA, one 1-KiB piece (16 rows of one plane) per instruction; the 3 * BN/16 pieces of a chunk
+    // go round the 8 waves (piece p = wave, wave + 8, wave + 16: all of them on row block wave % (BN/16)).  Lane L
+    // lands in physical unit L&3 of row (L>>2) of the piece, so it fetches logical unit (L&3) ^ swz(row): the swizzle
+    // is applied on the SOURCE address, the LDS image stays lane-linear ----
+    constexpr int RBLK = BN / 16, NPIECE = 3 * RBLK;            // row blocks per plane, pieces per chunk (24 / 12)
+    const int brow = (wave % RBLK) * 16 + (lane >> 2);
+    const int bcol = min(nb * BN + brow, Np - 1);               // columns past Np: any valid row (never stored)
     const uint32_t b_off = (uint32_t)(bcol * 64 + (((lane & 3) ^ G3_SWZ(brow)) << 4));     // bytes within a chunk plane
     const unsigned long long b_chunk = (unsigned long long)Np * 64, b_plane = args.plane_elems * 2;   // bytes
     unsigned long long s_ptr = (unsigned long long)args.wpk;   // weight stream: plane 0 of the next chunk (scalar)
     int s_kc = 0;
-    const uint32_t b_dst = smem_base + G3_LUT_BYTES + G3_AW_BYTES + wave * 1024;            // + slot offset, plane
+    const uint32_t b_dst = smem_base + G3_LUT_BYTES + AW_BYTES + (wave % RBLK) * 1024;      // + slot offset, plane
     auto stage_next = [&](uint32_t slot_off) {
         const uint32_t d = __builtin_amdgcn_readfirstlane(b_dst + slot_off);                // wave-uniform LDS address
-        glds16x3(sgpr_ptr(reinterpret_cast<const void*>(s_ptr)), sgpr_ptr(reinterpret_cast<const void*>(s_ptr + b_plane)),
-                 sgpr_ptr(reinterpret_cast<const void*>(s_ptr + 2 * b_plane)), b_off,
-                 d, d + G3_BN * G3_ROWB, d + 2 * G3_BN * G3_ROWB);
+        if (WN == 2) {
+            glds16x3(sgpr_ptr(reinterpret_cast<const void*>(s_ptr)), sgpr_ptr(reinterpret_cast<const void*>(s_ptr + b_plane)),
+                     sgpr_ptr(reinterpret_cast<const void*>(s_ptr + 2 * b_plane)), b_off,
+                     d, d + BN * G3_ROWB, d + 2 * BN * G3_ROWB);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int piece = wave + 8 * j;                 // wave-uniform
+                if (piece < NPIECE) {
+                    const int pl = piece / RBLK;
+                    glds16(sgpr_ptr(reinterpret_cast<const void*>(s_ptr + pl * b_plane)), b_off, d + pl * (BN * G3_ROWB));
+                }
+            }
+        }
         s_ptr += b_chunk;
         if (++s_kc == Kc) { s_kc = 0; s_ptr = (unsigned long long)args.wpk; }
     };
@@ -856,17 +882,17 @@ __global__ __launch_bounds__(512, MODE == G3_CONV_LIF_REG ? 2 : 4) void k_gemm_b
     auto rd_w = [&](uint32_t slot_off, int mt) { return *reinterpret_cast<const uint32_t*>(w_rd + slot_off + mt * 64); };
     auto rd_a = [&](uint32_t w) { return *reinterpret_cast<const bf16x8*>(lut + (__builtin_amdgcn_ubfe(w, lg8, 8) << 4)); };
     // B fragment: row (tile*16 + lr), logical unit lg; swz depends on lr only
-    const unsigned char* const b_rd = ring + G3_AW_BYTES + (wn * 64 + lr) * G3_ROWB + ((lg ^ G3_SWZ(lr)) << 4);
+    const unsigned char* const b_rd = ring + AW_BYTES + (wn * 64 + lr) * G3_ROWB + ((lg ^ G3_SWZ(lr)) << 4);
     // group g of a chunk = (N-tile g/3, plane 2 - g%3): per accumulator the small terms first (lo, mid, hi)
     auto rd_b = [&](uint32_t slot_off, int g) {
-        return *reinterpret_cast<const bf16x8*>(b_rd + slot_off + (2 - g % 3) * (G3_BN * G3_ROWB) + (g / 3) * 16 * G3_ROWB);
+        return *reinterpret_cast<const bf16x8*>(b_rd + slot_off + (2 - g % 3) * (BN * G3_ROWB) + (g / 3) * 16 * G3_ROWB);
     };
 
     // LIF state of the fused variant, whole T loop: v (64 registers) and the synaptic current i (48 registers;
     // the 16 values of M-tile 3 live in LDS, private to the thread, touched once per time step - they are what
     // keeps the main loop free of scratch spills)
     f32x4 v[FUSE ? 4 : 1][FUSE ? 4 : 1], ci[FUSE ? 3 : 1][FUSE ? 4 : 1];
-    f32x4* const ci_lds = reinterpret_cast<f32x4*>(smem + G3_LDS(NB)) + tid;                    // [nt][512 threads]
+    f32x4* const ci_lds = reinterpret_cast<f32x4*>(smem + G3_LDS(NB, WN)) + tid;                    // [nt][512 threads]
     if (FUSE) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
@@ -886,6 +912,14 @@ __global__ __launch_bounds__(512, MODE == G3_CONV_LIF_REG ? 2 : 4) void k_gemm_b
     //   the weight fragments of chunk c are read PD groups ahead of their MFMAs, the first ones of chunk c+1 and
     //   its spike words / table fragments at the end of chunk c (that slot has been complete since the last barrier).
     // One barrier per chunk; s_sched_barrier pins one fragment read + 4 MFMAs per group.
+#ifdef SNN_EXP_FILL_RING           // timing only: random bf16 bits in the whole ring (for the no-copy experiment)
+    for (int i = tid; i < NB * SLOT / 4; i += 512) {
+        uint32_t h = (uint32_t)i * 2654435761u + blockIdx.x * 40503u;
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        reinterpret_cast<uint32_t*>(ring)[i] = (h & 0x3fff3fffu) | 0x38003800u;      // two bf16 of magnitude ~1e-5 .. 1
+    }
+    __syncthreads();
+#endif
     uint32_t w_hold, w_new;
     {
         uint32_t w0[2];
@@ -950,8 +984,12 @@ __global__ __launch_bounds__(512, MODE == G3_CONV_LIF_REG ? 2 : 4) void k_gemm_b
             // fragments have arrived; the empty asm statements are compiler fences (neither builtin orders memory
             // accesses for hipcc, which otherwise moves LDS reads across the barrier).
             asm volatile("" ::: "memory");
+            // NB = 4: this chunk's own copies (the youngest vector-memory operations of the wave: 3, or 2 / 1 on the
+            // 8 x 1 wave grid) may stay in flight across the barrier
             if (NB == 3) __builtin_amdgcn_s_waitcnt(0x0070);        // vmcnt(0) lgkmcnt(0)
-            else __builtin_amdgcn_s_waitcnt(0x0073);                // vmcnt(3) lgkmcnt(0)
+            else if (WN == 2) __builtin_amdgcn_s_waitcnt(0x0073);   // vmcnt(3) lgkmcnt(0)
+            else if (wave + 8 < NPIECE) __builtin_amdgcn_s_waitcnt(0x0072);   // vmcnt(2)
+            else __builtin_amdgcn_s_waitcnt(0x0071);                // vmcnt(1)
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
 #endif
@@ -1000,7 +1038,7 @@ __global__ __launch_bounds__(512, MODE == G3_CONV_LIF_REG ? 2 : 4) void k_gemm_b
                     }
                 {
                     const int row = m0 + wm * 64 + lane;                  // lane = position within the wave's 64 rows
-                    const int word0 = (nb * G3_BN + wn * 64) >> 5;
+                    const int word0 = (nb * BN + wn * 64) >> 5;
                     uint32_t* dst = args.spk + (size_t)t * args.spk_stride + (size_t)row * (Np >> 5) + word0;
                     if (row < M) {
                         if (word0 * 32 < Np) dst[0] = my0;
@@ -1014,44 +1052,75 @@ __global__ __launch_bounds__(512, MODE == G3_CONV_LIF_REG ? 2 : 4) void k_gemm_b
     if (FUSE) return;
     if (TILE) {
         // ---- LIF over the T time steps held in this tile.  The accumulators are the complete input currents
-        // cur[t][position][column] of pb positions; in two halves of 64 columns they go through LDS (the ring is
-        // free now), where thread (wave w, lane l) runs the neurons (position w + 8j, column l) over t and the wave
-        // ballot of each step is the 64-bit spike word pair of that (t, position) ----
+        // cur[t][position][column] of pb positions; in two passes of CG = 32*WN columns they go through LDS (the ring
+        // is free now), where each thread runs neurons over t and the wave ballot of a step is the spike word(s):
+        //   WN = 2 (CG = 64): lane = column, wave w takes positions w, w+8, ...; ballot = the word pair of (t, position)
+        //   WN = 1 (CG = 32): lane = (position parity, column), wave w takes the position pairs; ballot = one word of
+        //                     the even position (low half) and one of the odd position (high half)
+        constexpr int CG = G3_TILE_CG(WN), PITCH = CG + 4;
         float* const tile = reinterpret_cast<float*>(smem);
         const int pb = args.pb, T = args.T;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // staged-ahead copies of chunks past the end have landed
 #pragma unroll 1
         for (int h = 0; h < 2; ++h) {
-            __syncthreads();                               // ring reads done / previous half consumed
-            if (wn == h) {
+            __syncthreads();                               // ring reads done / previous pass consumed
+            if (WN == 1 || wn == h) {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int nt = 0; nt < 4; ++nt)
+                    for (int nq = 0; nq < CG / 16; ++nq) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            tile[(wm * WROWS + mt * 16 + lg * 4 + r) * G3_TILE_PITCH + nt * 16 + lr] = acc[mt][nt][r];
+                        for (int r = 0; r < 4; ++r) {
+                            float val;
+                            if (WN == 1) val = h == 0 ? acc[mt][nq][r] : acc[mt][2 + nq][r];
+                            else val = acc[mt][nq][r];
+                            tile[(wm * WROWS + mt * 16 + lg * 4 + r) * PITCH + nq * 16 + lr] = val;
+                        }
+                    }
             }
             __syncthreads();
-            const int word0 = (nb * G3_BN + h * 64) >> 5;
+            const int word0 = (nb * BN + h * CG) >> 5;     // first output word of this pass
             if (word0 * 32 >= Np) continue;                // block-uniform
-            const bool two = (word0 + 1) * 32 < Np;
-            for (int pi = wave; pi < pb; pi += 8) {        // wave-uniform
-                const int pos = m0 + pi;
-                if (pos >= M) break;
-                float vv = args.p.v_leak, ii = 0.0f;
-                uint32_t my0 = 0, my1 = 0;                 // lane t keeps the word pair of time step t
-                const float* src = tile + pi * G3_TILE_PITCH + lane;
-                for (int t = 0; t < T; ++t) {
-                    const bool z = lif_step(src[(size_t)t * pb * G3_TILE_PITCH], vv, ii, args.p);
-                    const unsigned long long b = __ballot(z);
-                    my0 = lane == t ? (uint32_t)b : my0;
-                    my1 = lane == t ? (uint32_t)(b >> 32) : my1;
+            if (WN == 2) {
+                const bool two = (word0 + 1) * 32 < Np;
+                for (int pi = wave; pi < pb; pi += 8) {    // wave-uniform
+                    const int pos = m0 + pi;
+                    if (pos >= M) break;
+                    float vv = args.p.v_leak, ii = 0.0f;
+                    uint32_t my0 = 0, my1 = 0;             // lane t keeps the word pair of time step t
+                    const float* src = tile + pi * PITCH + lane;
+                    for (int t = 0; t < T; ++t) {
+                        const bool z = lif_step(src[(size_t)t * pb * PITCH], vv, ii, args.p);
+                        const unsigned long long b = __ballot(z);
+                        my0 = lane == t ? (uint32_t)b : my0;
+                        my1 = lane == t ? (uint32_t)(b >> 32) : my1;
+                    }
+                    if (lane < T) {
+                        uint32_t* dst = args.spk + (size_t)lane * args.spk_stride + (size_t)pos * (Np >> 5) + word0;
+                        dst[0] = my0;
+                        if (two) dst[1] = my1;
+                    }
                 }
-                if (lane < T) {
-                    uint32_t* dst = args.spk + (size_t)lane * args.spk_stride + (size_t)pos * (Np >> 5) + word0;
-                    dst[0] = my0;
-                    if (two) dst[1] = my1;
+            } else {
+                const int par = lane >> 5, col = lane & 31;
+                for (int pp = wave; 2 * pp < pb; pp += 8) {            // wave-uniform: position pair pp
+                    const int pi = 2 * pp + par;                       // this half-wave's position
+                    const bool live = pi < pb && m0 + pi < M;
+                    if (m0 + 2 * pp >= M) break;
+                    float vv = args.p.v_leak, ii = 0.0f;
+                    uint32_t my0 = 0, my1 = 0;             // lane t keeps the words of (t, even position), (t, odd position)
+                    const float* src = tile + (live ? pi : 2 * pp) * PITCH + col;
+                    for (int t = 0; t < T; ++t) {
+                        const bool z = lif_step(src[(size_t)t * pb * PITCH], vv, ii, args.p);
+                        const unsigned long long b = __ballot(z);
+                        my0 = lane == t ? (uint32_t)b : my0;
+                        my1 = lane == t ? (uint32_t)(b >> 32) : my1;
+                    }
+                    if (lane < T) {
+                        uint32_t* dst = args.spk + (size_t)lane * args.spk_stride + (size_t)(m0 + 2 * pp) * (Np >> 5) + word0;
+                        dst[0] = my0;
+                        if (2 * pp + 1 < pb && m0 + 2 * pp + 1 < M) dst[Np >> 5] = my1;
+                    }
                 }
             }
         }
@@ -1062,7 +1131,7 @@ __global__ __launch_bounds__(512, MODE == G3_CONV_LIF_REG ? 2 : 4) void k_gemm_b
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
-            const int col = nb * G3_BN + wn * 64 + nt * 16 + lr;
+            const int col = nb * BN + wn * 64 + nt * 16 + lr;
             if (col >= Np) continue;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -1949,9 +2018,25 @@ static int g3_pick_mt(F tiles_of) {
     return best;
 }
 
+#ifndef G3_NB1
+#define G3_NB1 4                                    // ring slots of the 8 x 1 wave grid (14 KB each)
+#endif
+// waves along N of the bf16x3 tile: 2 (256 x 128 tile, default) or 1 (512 x 64 tile: half the weight copies per
+// FLOP, 4-slot ring).  Both run at the same speed (conv+LIF 2.95 / 2.94 ms on one box): the copies are not what the
+// kernel waits for - timing builds without them run faster because MFMAs on all-zero operands draw less power and
+// the chip clocks up, not because the copies cost time.  SNN_BF16X3_WN=1|2 is an A-B / test knob.
+static int g3_wn() {
+    const char* f = getenv("SNN_BF16X3_WN");
+    return (f && f[0] == '1') ? 1 : 2;
+}
+
 template <int MODE>
-static const void* g3_kernel(int mt) {
-    return mt == 4 ? (const void*)k_gemm_bf16x3<MODE, 3, 4> : mt == 3 ? (const void*)k_gemm_bf16x3<MODE, 3, 3> : (const void*)k_gemm_bf16x3<MODE, 3, 2>;
+static const void* g3_kernel(int mt, int wn) {
+    if (wn == 2)
+        return mt == 4 ? (const void*)k_gemm_bf16x3<MODE, 3, 4, 2> : mt == 3 ? (const void*)k_gemm_bf16x3<MODE, 3, 3, 2>
+                                                                              : (const void*)k_gemm_bf16x3<MODE, 3, 2, 2>;
+    return mt == 4 ? (const void*)k_gemm_bf16x3<MODE, G3_NB1, 4, 1> : mt == 3 ? (const void*)k_gemm_bf16x3<MODE, G3_NB1, 3, 1>
+                                                                                : (const void*)k_gemm_bf16x3<MODE, G3_NB1, 2, 1>;
 }
 
 extern "C" {
@@ -2027,18 +2112,19 @@ int snn_pack_linear_weight_bf16x3(const float* w, int N, int K, uint16_t* packed
 // T-in-tile LIF fusion needs T <= 64 (one lane per time step keeps the spike words) and wastes rows % T rows per tile
 static bool g3_tile_ok(int T, int rows) { return T >= 1 && T <= 64 && T <= rows && T * (rows / T) * 10 >= rows * 9; }
 
-static int launch_gemm3(int mode, int mt, const Gemm3Args& a, hipStream_t s) {
-    // LIF_REG owns its CU (256 registers per wave); the others run two work-groups per CU on an 80-KB ring
+static int launch_gemm3(int mode, int mt, int wn, const Gemm3Args& a, hipStream_t s) {
+    // LIF_REG owns its CU (256 registers per wave); the others run two work-groups per CU
     const void* kern;
-    int lds = G3_LDS(3), tiles = cdiv(a.M, 64 * mt);
+    int lds = G3_LDS(wn == 1 ? G3_NB1 : 3, wn), tiles = cdiv(a.M, G3_BM(wn, mt));
+    const int tile_lds = wn == 2 ? G3_TILE_BYTES(2) : G3_TILE_BYTES(1);       // the LIF_TILE epilogue reuses the ring
     switch (mode) {
-    case G3_FC: kern = g3_kernel<G3_FC>(mt); break;
-    case G3_CONV: kern = g3_kernel<G3_CONV>(mt); break;
-    case G3_CONV_LIF_REG: kern = (const void*)k_gemm_bf16x3<G3_CONV_LIF_REG, 3, 4>; lds += G3_STATE_BYTES; break;
-    case G3_CONV_LIF_TILE: kern = g3_kernel<G3_CONV_LIF_TILE>(mt); tiles = cdiv(a.M, a.pb); break;
-    default: kern = g3_kernel<G3_FC_LIF_TILE>(mt); tiles = cdiv(a.M, a.pb); break;
+    case G3_FC: kern = g3_kernel<G3_FC>(mt, wn); break;
+    case G3_CONV: kern = g3_kernel<G3_CONV>(mt, wn); break;
+    case G3_CONV_LIF_REG: kern = (const void*)k_gemm_bf16x3<G3_CONV_LIF_REG, 3, 4, 2>; lds = G3_LDS(3, 2) + G3_STATE_BYTES; break;
+    case G3_CONV_LIF_TILE: kern = g3_kernel<G3_CONV_LIF_TILE>(mt, wn); tiles = cdiv(a.M, a.pb); lds = max(lds, tile_lds); break;
+    default: kern = g3_kernel<G3_FC_LIF_TILE>(mt, wn); tiles = cdiv(a.M, a.pb); lds = max(lds, tile_lds); break;
     }
-    static_assert(G3_BM * G3_TILE_PITCH * 4 <= G3_LDS(3), "the LIF_TILE current tile reuses the ring");
+    static_assert(2 * G3_TILE_BYTES(1) <= 160 * 1024 && 2 * G3_LDS(3, 2) <= 160 * 1024, "two work-groups per CU");
     hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return fail(-3, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
     void* kargs[] = {(void*)&a};
@@ -2057,9 +2143,10 @@ int snn_spike_gemm_bf16x3(const uint32_t* a_rows, int M, int K, int N, const uin
     if ((long long)M * cdiv(K, 32) * 4 > 0xffffffffLL) return fail(-1, "snn_spike_gemm_bf16x3: spike rows over 4 GB");
     a.A = a_rows; a.wpk = w_packed; a.out = cur; a.M = M; a.Kc = cdiv(K, 32); a.Np = cdiv(N, 32) * 32; a.ldo = ldo;
     a.plane_elems = (unsigned long long)a.Kc * a.Np * 32;
-    a.n_blocks = cdiv(a.Np, G3_BN);
-    const int mt = g3_pick_mt([&](int m) { return (long long)cdiv(M, 64 * m) * a.n_blocks; });
-    return launch_gemm3(G3_FC, mt, a, (hipStream_t)s);
+    const int wn = g3_wn();
+    a.n_blocks = cdiv(a.Np, G3_BN(wn));
+    const int mt = g3_pick_mt([&](int m) { return (long long)cdiv(M, G3_BM(wn, m)) * a.n_blocks; });
+    return launch_gemm3(G3_FC, mt, wn, a, (hipStream_t)s);
 }
 
 int snn_spike_gemm_lif_bf16x3(const uint32_t* a_planes, int T, int R, int K, int N, const snn_params* p,
@@ -2072,12 +2159,13 @@ int snn_spike_gemm_lif_bf16x3(const uint32_t* a_planes, int T, int R, int K, int
     memset(&a, 0, sizeof(a));
     a.A = a_planes; a.wpk = w_packed; a.M = R; a.Kc = cdiv(K, 32); a.Np = cdiv(N, 32) * 32;
     a.plane_elems = (unsigned long long)a.Kc * a.Np * 32;
-    a.n_blocks = cdiv(a.Np, G3_BN);
+    const int wn = g3_wn();
+    a.n_blocks = cdiv(a.Np, G3_BN(wn));
     a.T = T; a.spk = spk; a.spk_stride = spk_stride; a.p = make_p(p, p->v_th_lif);
-    const int mt = g3_pick_mt([&](int m) { return g3_tile_ok(T, 64 * m) ? (long long)cdiv(R, (64 * m) / T) * a.n_blocks : 0ll; });
+    const int mt = g3_pick_mt([&](int m) { return g3_tile_ok(T, G3_BM(wn, m)) ? (long long)cdiv(R, G3_BM(wn, m) / T) * a.n_blocks : 0ll; });
     if (!mt) return fail(-4, "snn_spike_gemm_lif_bf16x3: T=%d does not fit a row tile (use snn_spike_gemm_bf16x3 + snn_lif_scan)", T);
-    a.pb = (64 * mt) / T;
-    return launch_gemm3(G3_FC_LIF_TILE, mt, a, (hipStream_t)s);
+    a.pb = G3_BM(wn, mt) / T;
+    return launch_gemm3(G3_FC_LIF_TILE, mt, wn, a, (hipStream_t)s);
 }
 
 static int conv3_common(const char* who, const uint32_t* enc, size_t enc_stride, const snn_rpn_level* lv, int n_levels,
@@ -2100,7 +2188,6 @@ static int conv3_common(const char* who, const uint32_t* enc, size_t enc_stride,
     a.Cw = cdiv(C_in, 32); a.Kc = 9 * a.Cw; a.Np = cdiv(C_out, 32) * 32;
     a.plane_elems = (unsigned long long)a.Kc * a.Np * 32;
     a.P_total = (int)P; a.n_levels = n_levels;
-    a.n_blocks = cdiv(a.Np, G3_BN);
     *P_out = P;
     return 0;
 }
@@ -2116,13 +2203,18 @@ int snn_conv3x3_lif_bf16x3(const uint32_t* enc, size_t enc_stride, const snn_rpn
     a.M = (int)P; a.T = T; a.spk = spk; a.spk_stride = spk_stride; a.p = make_p(p, p->v_th_lif);
     // debug / A-B knob: SNN_BF16X3_LIF=reg forces the register-resident variant (the fallback for T > 64)
     const char* force = getenv("SNN_BF16X3_LIF");
-    if (force && !strcmp(force, "reg")) return launch_gemm3(G3_CONV_LIF_REG, 4, a, (hipStream_t)s);
+    const int wn = g3_wn();
     int mt = 0;
-    if (g3_tile_ok(T, 256) || g3_tile_ok(T, 192) || g3_tile_ok(T, 128))
-        mt = g3_pick_mt([&](int m) { return g3_tile_ok(T, 64 * m) ? (long long)cdiv(P, (64 * m) / T) * a.n_blocks : 0ll; });
-    if (!mt) return launch_gemm3(G3_CONV_LIF_REG, 4, a, (hipStream_t)s);
-    a.pb = (64 * mt) / T;
-    return launch_gemm3(G3_CONV_LIF_TILE, mt, a, (hipStream_t)s);
+    if (!(force && !strcmp(force, "reg"))) {
+        a.n_blocks = cdiv(a.Np, G3_BN(wn));
+        mt = g3_pick_mt([&](int m) { return g3_tile_ok(T, G3_BM(wn, m)) ? (long long)cdiv(P, G3_BM(wn, m) / T) * a.n_blocks : 0ll; });
+    }
+    if (!mt) {
+        a.n_blocks = cdiv(a.Np, G3_BN(2));
+        return launch_gemm3(G3_CONV_LIF_REG, 4, 2, a, (hipStream_t)s);
+    }
+    a.pb = G3_BM(wn, mt) / T;
+    return launch_gemm3(G3_CONV_LIF_TILE, mt, wn, a, (hipStream_t)s);
 }
 
 int snn_spike_conv3x3_bf16x3(const uint32_t* enc, size_t enc_stride, const snn_rpn_level* lv, int n_levels, int C_in,
@@ -2146,9 +2238,10 @@ int snn_spike_conv3x3_bf16x3(const uint32_t* enc, size_t enc_stride, const snn_r
     a.Cw = cdiv(C_in, 32); a.Kc = 9 * a.Cw; a.Np = cdiv(C_out, 32) * 32; a.ldo = ldo;
     a.plane_elems = (unsigned long long)a.Kc * a.Np * 32;
     a.P_total = (int)P; a.n_levels = n_levels; a.M = (int)(T * P);
-    a.n_blocks = cdiv(a.Np, G3_BN);
-    const int mt = g3_pick_mt([&](int m) { return (long long)cdiv(a.M, 64 * m) * a.n_blocks; });
-    return launch_gemm3(G3_CONV, mt, a, (hipStream_t)s);
+    const int wn = g3_wn();
+    a.n_blocks = cdiv(a.Np, G3_BN(wn));
+    const int mt = g3_pick_mt([&](int m) { return (long long)cdiv(a.M, G3_BM(wn, m)) * a.n_blocks; });
+    return launch_gemm3(G3_CONV, mt, wn, a, (hipStream_t)s);
 }
 
 static int check_T(int T, const char* who) {
@@ -2670,7 +2763,7 @@ static int det_head_from_planes(int R, int D, int Hd, int K, int K4, int T, cons
     if (spk7_count) { if (hipMemsetAsync(spk7_count, 0, sizeof(uint32_t) * R, s) != hipSuccess) return fail(-3, "hipMemsetAsync failed"); }
     const bool b3 = p->precision == SNN_PRECISION_BF16X3;
     if (p->precision != SNN_PRECISION_F32 && !b3) return fail(-1, "snn_det_head_forward: unknown precision %d", p->precision);
-    if (b3 && !spk6_count && !spk7_count && (g3_tile_ok(T, 256) || g3_tile_ok(T, 192) || g3_tile_ok(T, 128))) {
+    if (b3 && !spk6_count && !spk7_count && (g3_tile_ok(T, G3_BM(g3_wn(), 4)) || g3_tile_ok(T, G3_BM(g3_wn(), 3)) || g3_tile_ok(T, G3_BM(g3_wn(), 2)))) {
         // fc6 + LIF and fc7 + LIF, each one launch: a row tile holds all T steps of its RoIs, the currents never
         // leave the chip (faster_rcnn.py:498-501)
         if ((rc = snn_spike_gemm_lif_bf16x3(enc, T, R, D, Hd, p, (const uint16_t*)w6_packed, s6, (size_t)R * Hw, stream))) return rc;

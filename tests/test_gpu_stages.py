@@ -234,8 +234,8 @@ def test_spike_conv3x3_bf16x3_teacher_forced(S, gpu_device, name):
 @pytest.mark.parametrize("T", [4, 12])
 def test_bf16x3_kernel_variants_bit_identical(S, gpu_device, monkeypatch, T):
     """The fallbacks / alternative tilings of k_gemm_bf16x3 give the same bits as the default launch: register-resident
-    LIF (SNN_BF16X3_LIF=reg, the any-T fallback) vs T-in-tile fusion, and 128/192-row work-group tiles
-    (SNN_BF16X3_MT) vs 256-row tiles - same products, same accumulation order per output, same LIF arithmetic."""
+    LIF (SNN_BF16X3_LIF=reg, the any-T fallback) vs T-in-tile fusion, the 4x2 / 8x1 wave grids (SNN_BF16X3_WN) and the
+    smaller work-group tiles (SNN_BF16X3_MT) - same products, same accumulation order per output, same LIF arithmetic."""
     g = torch.Generator().manual_seed(11 + T)
     C = 96
     shapes = [(2, 9, 14), (2, 5, 7), (1, 3, 3)]
@@ -247,10 +247,13 @@ def test_bf16x3_kernel_variants_bit_identical(S, gpu_device, monkeypatch, T):
     wp = S.pack_conv3x3_bf16x3(w)
     base = S.conv3x3_lif_bf16x3(enc, shapes, C, C, p, wp)
     assert base.ne(0).any()
-    for mt in ("2", "3", "4"):
-        monkeypatch.setenv("SNN_BF16X3_MT", mt)
-        assert torch.equal(S.conv3x3_lif_bf16x3(enc, shapes, C, C, p, wp), base), "MT=" + mt
+    for wn in ("1", "2"):
+        monkeypatch.setenv("SNN_BF16X3_WN", wn)
+        for mt in ("2", "3", "4"):
+            monkeypatch.setenv("SNN_BF16X3_MT", mt)
+            assert torch.equal(S.conv3x3_lif_bf16x3(enc, shapes, C, C, p, wp), base), "WN=%s MT=%s" % (wn, mt)
     monkeypatch.delenv("SNN_BF16X3_MT")
+    monkeypatch.delenv("SNN_BF16X3_WN")
     monkeypatch.setenv("SNN_BF16X3_LIF", "reg")
     assert torch.equal(S.conv3x3_lif_bf16x3(enc, shapes, C, C, p, wp), base)
     monkeypatch.delenv("SNN_BF16X3_LIF")
@@ -261,11 +264,13 @@ def test_bf16x3_kernel_variants_bit_identical(S, gpu_device, monkeypatch, T):
     wl = (torch.randn(N, K, generator=g) * 0.1).to(gpu_device)
     wlp = S.pack_linear_bf16x3(wl)
     base = S.spike_gemm_lif_bf16x3(a, K, N, p, wlp)
-    for mt in ("2", "3", "4"):
-        monkeypatch.setenv("SNN_BF16X3_MT", mt)
-        assert torch.equal(S.spike_gemm_lif_bf16x3(a, K, N, p, wlp), base), "MT=" + mt
-        cur = S.spike_gemm_bf16x3(a.view(T * R, -1), K, N, wlp)
-        assert torch.equal(S.lif_scan(cur.view(T, R, -1), N, p)[..., :base.shape[-1]], base)
+    for wn in ("1", "2"):
+        monkeypatch.setenv("SNN_BF16X3_WN", wn)
+        for mt in ("2", "3", "4"):
+            monkeypatch.setenv("SNN_BF16X3_MT", mt)
+            assert torch.equal(S.spike_gemm_lif_bf16x3(a, K, N, p, wlp), base), "WN=%s MT=%s" % (wn, mt)
+            cur = S.spike_gemm_bf16x3(a.view(T * R, -1), K, N, wlp)
+            assert torch.equal(S.lif_scan(cur.view(T, R, -1), N, p)[..., :base.shape[-1]], base)
 
 
 @pytest.mark.parametrize("C_in,C_out,T,shapes", [

@@ -745,9 +745,11 @@ __global__ __launch_bounds__(512, MODE == G3_CONV_LIF_REG ? 2 : 4) void k_gemm_b
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    // Plain row-major tile order: column blocks of a row tile are neighbours in dispatch order.  (An XCD-aware order -
-    // each XCD a contiguous eighth of the row tiles - ran at the same speed and TRIPLED the L2 fills of the conv
-    // kernel, FETCH_SIZE 102 -> 323 MB per launch: profiles/r1_h_*; removed.)
+    // Plain row-major tile order, column block fastest: work-group b runs on XCD b % 8 (round-robin dispatch), so with
+    // 2 (or 4, 8) column blocks every XCD only ever sees ONE weight panel - half of the 3.5 MB of conv weight planes,
+    // which then stay resident in its 4-MB L2 beside the streaming spike planes.  Both re-orderings tried (each XCD a
+    // contiguous eighth of the tiles; both column blocks of a tile on one XCD) put all panels on every XCD and
+    // multiplied the L2 fills: FETCH_SIZE 102 -> 323 / 535 MB per launch at unchanged kernel time (profiles/r1_h_*).
     const int nb = blockIdx.x % args.n_blocks;
     const int mb = blockIdx.x / args.n_blocks;
     const int m0 = TILE ? mb * args.pb : mb * BM;            // first row (TILE: first position) of the tile

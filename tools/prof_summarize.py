@@ -7,7 +7,7 @@ for f in glob.glob(os.path.join(root, 'stats', '**', '*kernel_stats.csv'), recur
     rows = list(csv.DictReader(open(f)))
     for r in rows[:14]:
         print('  %-70s calls %5s  avg %10.1f us  total %5.1f %%' % (r['Name'][:70], r['Calls'], float(r['AverageNs']) / 1e3, float(r['Percentage'])))
-for d in sorted(glob.glob(os.path.join(root, 'pmc*'))):
+for d in sorted(glob.glob(os.path.join(root, 'pmc*')) + glob.glob(os.path.join(root, '[fw]'))):
     if not os.path.isdir(d):
         continue
     acc = defaultdict(lambda: defaultdict(list))

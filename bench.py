@@ -38,6 +38,17 @@ PEAK_F32_MFMA_TFLOPS = 157.3                                     # MI355X_MICROA
 PEAK_BF16_MFMA_TFLOPS = 2500.0                                   # dense bf16 (no sparsity)
 
 
+WORKLOADS = {
+    "cityscapes": {"levels": LEVELS, "K": 9, "T_rpn": 8, "T_det": 12, "batch": 2, "spike_rates": False,
+                   "name": "cityscapes_1024x2048_b2_heads"},
+    # BDD 720x1280 -> 768x1376 canvas (SURVEY.md §8 shape table), 4 images per GPU
+    "bdd": {"levels": [(192, 344), (96, 172), (48, 86), (24, 43), (12, 22)], "K": 11, "T_rpn": 8, "T_det": 12, "batch": 4,
+            "spike_rates": False, "name": "bdd_720x1280_b4_heads"},
+    "stress": {"levels": LEVELS, "K": 9, "T_rpn": 16, "T_det": 24, "batch": 2, "spike_rates": True,
+               "name": "cityscapes_1024x2048_b2_heads_T16_T24_spike_rates"},
+}
+
+
 def algorithmic_flops():
     pos = BATCH * sum(h * w for h, w in LEVELS)
     conv = pos * 2 * 9 * C * C * T_RPN                            # dominant kernel
@@ -101,7 +112,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", choices=["bf16x3", "f32"], default="bf16x3")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cityscapes",
+                    help="cityscapes = BASELINE.json's headline configuration (default); bdd = config[3] per-rank share "
+                         "(720x1280, 4 images per GPU, K=11); stress = config[4] (T=16/24, spike-rate outputs on)")
     args = ap.parse_args()
+    global LEVELS, K_CLS, T_RPN, T_DET, BATCH
+    wl = WORKLOADS[args.workload]
+    LEVELS, K_CLS, T_RPN, T_DET, BATCH = wl["levels"], wl["K"], wl["T_rpn"], wl["T_det"], wl["batch"]
 
     import snn_automotive_object_detection_amd as S
     from snn_automotive_object_detection_amd import dp, ops
@@ -119,11 +136,15 @@ def main():
     rpn_head = S.RPNHeadSNN(C, A, T_RPN).to(dev)
     det_head = S.FastRCNNPredictorSNNFull(C * 49, HD, K_CLS, T_DET).to(dev)
     rpn_head.precision = det_head.precision = args.precision
+    rpn_head.spike_rates = det_head.spike_rates = wl["spike_rates"]
     feats, rois = make_inputs(dev, 1000 + rank)                  # inputs resident in HBM
 
     def step():
-        logits, bbox = rpn_head(feats)
-        cls, deltas = det_head(rois)
+        rpn_out = rpn_head(feats)
+        det_out = det_head(rois)
+        if wl["spike_rates"]:            # the spike-rate variants return rate tensors only (faster_rcnn.py:520-618)
+            return rpn_out, det_out
+        cls, deltas = det_out
         payload, counts = detections_from_heads(cls, deltas)
         return dp.all_gather_detection_tensors(payload, counts)  # no-op at world == 1
 
@@ -182,13 +203,17 @@ def main():
         pass
 
     out = {
-        "metric": "images/sec (T_rpn=8,T_det=12, 1024x2048 b=2) spiking RPN+RoI heads forward",
+        "metric": "images/sec (T_rpn=%d,T_det=%d, %s b=%d) spiking RPN+RoI heads forward" % (
+            T_RPN, T_DET, "720x1280" if args.workload == "bdd" else "1024x2048", BATCH),
         "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "f32 (weights as exact bf16x3 split, fp32 accumulate)",
         "data": "synthetic",
-        "config": {"precision": args.precision, "workload": "cityscapes_1024x2048_b2_heads: RPNHeadSNN(T=8) on 5-level pyramid 2x256x{192x384..12x24}"
-                               " + FastRCNNPredictorSNNFull(T=12) on 2000 RoIs x 12544, K=9; random-init weights",
+        "config": {"precision": args.precision,
+                   "workload": "%s: RPNHeadSNN(T=%d) on 5-level pyramid %dx256x{%dx%d..%dx%d} + FastRCNNPredictorSNNFull(T=%d) on "
+                               "%d RoIs x 12544, K=%d; random-init weights" % (
+                                   wl["name"], T_RPN, BATCH, LEVELS[0][0], LEVELS[0][1], LEVELS[-1][0], LEVELS[-1][1], T_DET,
+                                   BATCH * ROIS_PER_IMG, K_CLS),
                    "global_batch": BATCH * world, "parallelism": "dp%d" % world,
                    "exchange": "all-gather of per-image detections [100x6] (RCCL)" if world > 1 else "none"},
         # achieved = ALGORITHMIC FLOPs of the launch / its duration.  For bf16x3 the peak is what the bf16 matrix pipe

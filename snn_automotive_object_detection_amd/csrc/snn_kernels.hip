@@ -1472,20 +1472,36 @@ __global__ __launch_bounds__(256) void k_li_heads_mfma(const LiHeadsArgs a) {
     }
 }
 
-// spikes per image of one level, counted from the bit-planes (spike-rate mode of the bf16x3 path)
+// spikes per image of one level, counted from the bit-planes (spike-rate mode of the bf16x3 path): blockIdx.x = image,
+// blockIdx.y = slice of the image's words; integer atomics, so the result does not depend on the order.
+// counts must be zeroed by the caller.
 __global__ __launch_bounds__(256) void k_count_spikes(const uint32_t* __restrict__ spk, unsigned long long spk_stride,
                                                       int T, int words_per_image,
                                                       unsigned long long* __restrict__ counts) {
     unsigned long long sum = 0;
     for (int t = 0; t < T; ++t) {
         const uint32_t* src = spk + (size_t)t * spk_stride + (size_t)blockIdx.x * words_per_image;
-        for (int i = threadIdx.x; i < words_per_image; i += 256) sum += __popc(src[i]);
+        for (int i = blockIdx.y * 256 + threadIdx.x; i < words_per_image; i += gridDim.y * 256) sum += __popc(src[i]);
     }
     for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off);
     __shared__ unsigned long long part[4];
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sum;
     __syncthreads();
-    if (threadIdx.x == 0) counts[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+    if (threadIdx.x == 0) atomicAdd(&counts[blockIdx.x], part[0] + part[1] + part[2] + part[3]);
+}
+
+// spikes per row (RoI) over all T planes: one wave per row  (spike-rate mode of the fused linear layers)
+__global__ __launch_bounds__(256) void k_count_rows(const uint32_t* __restrict__ spk, unsigned long long spk_stride, int T,
+                                                    int R, int words, uint32_t* __restrict__ counts) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= R) return;
+    uint32_t sum = 0;
+    for (int t = 0; t < T; ++t) {
+        const uint32_t* src = spk + (size_t)t * spk_stride + (size_t)row * words;
+        for (int i = lane; i < words; i += 64) sum += __popc(src[i]);
+    }
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off);
+    if (lane == 0) counts[row] = sum;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2544,7 +2560,7 @@ int snn_rpn_head_forward_stages(const snn_rpn_level* lv, int n_levels, int C, in
                 long long pb = 0;
                 for (int l = 0; l < n_levels; ++l) {
                     const int hw = lv[l].H * lv[l].W;
-                    hipLaunchKernelGGL(k_count_spikes, dim3(lv[l].N), dim3(256), 0, s, spk + (size_t)pb * Cw,
+                    hipLaunchKernelGGL(k_count_spikes, dim3(lv[l].N, max(1, min(256, hw * Cw / 2048))), dim3(256), 0, s, spk + (size_t)pb * Cw,
                                        (unsigned long long)stride, T, hw * Cw, spike_counts + (size_t)l * max_n);
                     SNN_CHECK_LAUNCH("k_count_spikes");
                     pb += (long long)lv[l].N * hw;
@@ -2765,11 +2781,19 @@ static int det_head_from_planes(int R, int D, int Hd, int K, int K4, int T, cons
     if (spk7_count) { if (hipMemsetAsync(spk7_count, 0, sizeof(uint32_t) * R, s) != hipSuccess) return fail(-3, "hipMemsetAsync failed"); }
     const bool b3 = p->precision == SNN_PRECISION_BF16X3;
     if (p->precision != SNN_PRECISION_F32 && !b3) return fail(-1, "snn_det_head_forward: unknown precision %d", p->precision);
-    if (b3 && !spk6_count && !spk7_count && (g3_tile_ok(T, G3_BM(g3_wn(), 4)) || g3_tile_ok(T, G3_BM(g3_wn(), 3)) || g3_tile_ok(T, G3_BM(g3_wn(), 2)))) {
+    if (b3 && (g3_tile_ok(T, G3_BM(g3_wn(), 4)) || g3_tile_ok(T, G3_BM(g3_wn(), 3)) || g3_tile_ok(T, G3_BM(g3_wn(), 2)))) {
         // fc6 + LIF and fc7 + LIF, each one launch: a row tile holds all T steps of its RoIs, the currents never
         // leave the chip (faster_rcnn.py:498-501)
         if ((rc = snn_spike_gemm_lif_bf16x3(enc, T, R, D, Hd, p, (const uint16_t*)w6_packed, s6, (size_t)R * Hw, stream))) return rc;
         if ((rc = snn_spike_gemm_lif_bf16x3(s6, T, R, Hd, Hd, p, (const uint16_t*)w7_packed, s7, (size_t)R * Hw, stream))) return rc;
+        if (spk6_count) {                                       // spike-rate mode: per-RoI counts from the planes
+            hipLaunchKernelGGL(k_count_rows, dim3(cdiv(R, 4)), dim3(256), 0, s, s6, (unsigned long long)R * Hw, T, R, Hw, spk6_count);
+            SNN_CHECK_LAUNCH("k_count_rows");
+        }
+        if (spk7_count) {
+            hipLaunchKernelGGL(k_count_rows, dim3(cdiv(R, 4)), dim3(256), 0, s, s7, (unsigned long long)R * Hw, T, R, Hw, spk7_count);
+            SNN_CHECK_LAUNCH("k_count_rows");
+        }
         return snn_li_heads(s7, (size_t)R * Hw, T, R, Hd, w_heads_packed, K, K4, p, out_cls, out_bbox, sum_cls,
                             sum_bbox, stream);
     }

@@ -230,6 +230,13 @@ size_t snn_packed_conv3x3_bf16x3_elems(int C_out, int C_in);
 int snn_pack_conv3x3_weight_bf16x3(const float* w_oihw, int C_out, int C_in, uint16_t* packed, snn_stream_t s);
 size_t snn_packed_linear_bf16x3_elems(int N, int K);
 int snn_pack_linear_weight_bf16x3(const float* w_nk, int N, int K, uint16_t* packed, snn_stream_t s);
+/* Block-scaled fp6 digit planes (precision "mxfp6", csrc/snn_mx.h): the fp32 weights as 6 planes of signed base-32
+ * digits in fp6 e2m3 with one E8M0 scale per (32 consecutive k, column).  Exact for every weight within 2^5 of the
+ * largest magnitude of its block, else rounded at 2^-28 of that magnitude.  Packed operand: uint32 words. */
+size_t snn_packed_linear_mx_words(int N, int K);
+size_t snn_packed_conv3x3_mx_words(int C_out, int C_in);
+int snn_pack_linear_weight_mx(const float* w_nk, int N, int K, uint32_t* packed, snn_stream_t s);
+int snn_pack_conv3x3_weight_mx(const float* w_oihw, int C_out, int C_in, uint32_t* packed, snn_stream_t s);
 /* cur[M][ldo] = A_bits[M][K] x W[K][N] */
 int snn_spike_gemm_bf16x3(const uint32_t* a_rows, int M, int K, int N, const uint16_t* w_packed, float* cur,
                           int ldo, snn_stream_t stream);

@@ -1999,6 +1999,8 @@ static void li_kappa(const snn_params* p, int T, Kappa* k) {
     }
 }
 
+#include "snn_mx.h"
+
 // ================================================================================================
 // C ABI
 // ================================================================================================
@@ -2124,6 +2126,30 @@ int snn_pack_linear_weight_bf16x3(const float* w, int N, int K, uint16_t* packed
     hipLaunchKernelGGL(k_pack_bf16x3, dim3((unsigned)min((size_t)4096, (total + 255) / 256)), dim3(256), 0,
                        (hipStream_t)s, w, packed, (int)PACK_LINEAR, K, N, Kc, Np, 0, 32);
     SNN_CHECK_LAUNCH("k_pack_bf16x3");
+    return 0;
+}
+
+// ---- block-scaled fp6 digit planes (snn_mx.h) ---------------------------------------------------
+size_t snn_packed_linear_mx_words(int N, int K) { return mx_words(cdiv(K, 128), cdiv(N, 32) * 32); }
+size_t snn_packed_conv3x3_mx_words(int C_out, int C_in) { return mx_words(9 * cdiv(C_in, 128), cdiv(C_out, 32) * 32); }
+
+int snn_pack_linear_weight_mx(const float* w, int N, int K, uint32_t* packed, snn_stream_t s) {
+    if (!w || !packed || N <= 0 || K <= 0) return fail(-1, "snn_pack_linear_weight_mx: bad argument");
+    const int Kc = cdiv(K, 128), Np = cdiv(N, 32) * 32;
+    const size_t blocks = (size_t)Kc * Np * 4;
+    hipLaunchKernelGGL(k_pack_mx, dim3((unsigned)min((size_t)8192, (blocks + 127) / 128)), dim3(128), 0, (hipStream_t)s, w, packed,
+                       (int)PACK_LINEAR, K, N, Kc, Np, 0, 128);
+    SNN_CHECK_LAUNCH("k_pack_mx");
+    return 0;
+}
+
+int snn_pack_conv3x3_weight_mx(const float* w, int C_out, int C_in, uint32_t* packed, snn_stream_t s) {
+    if (!w || !packed || C_out <= 0 || C_in <= 0) return fail(-1, "snn_pack_conv3x3_weight_mx: bad argument");
+    const int Cp = cdiv(C_in, 128) * 128, Kc = 9 * Cp / 128, Np = cdiv(C_out, 32) * 32;
+    const size_t blocks = (size_t)Kc * Np * 4;
+    hipLaunchKernelGGL(k_pack_mx, dim3((unsigned)min((size_t)8192, (blocks + 127) / 128)), dim3(128), 0, (hipStream_t)s, w, packed,
+                       (int)PACK_CONV3X3, 9 * Cp, C_out, Kc, Np, C_in, Cp);
+    SNN_CHECK_LAUNCH("k_pack_mx");
     return 0;
 }
 

@@ -114,6 +114,28 @@ def pack_linear_bf16x3(w: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def pack_linear_mx(w: torch.Tensor) -> torch.Tensor:
+    """[N, K] fp32 -> block-scaled fp6 digit planes (int32 words, csrc/snn_mx.h)"""
+    _need_gpu(w, "weight")
+    lib = _lib.load()
+    w = _f32c(w)
+    n, k = w.shape
+    out = torch.empty(lib.snn_packed_linear_mx_words(n, k), dtype=torch.int32, device=w.device)
+    _lib.check(lib.snn_pack_linear_weight_mx(_ptr(w), n, k, _ptr(out), _stream()), "snn_pack_linear_weight_mx")
+    return out
+
+
+def pack_conv3x3_mx(w: torch.Tensor) -> torch.Tensor:
+    """[C_out, C_in, 3, 3] fp32 -> block-scaled fp6 digit planes, reduction index k = tap * Cp128 + ci"""
+    _need_gpu(w, "weight")
+    lib = _lib.load()
+    w = _f32c(w)
+    co, ci = w.shape[0], w.shape[1]
+    out = torch.empty(lib.snn_packed_conv3x3_mx_words(co, ci), dtype=torch.int32, device=w.device)
+    _lib.check(lib.snn_pack_conv3x3_weight_mx(_ptr(w), co, ci, _ptr(out), _stream()), "snn_pack_conv3x3_weight_mx")
+    return out
+
+
 # ---------------------------------------------------------------------------------------------
 # stage-level ops (used by the teacher-forced parity tests)
 # ---------------------------------------------------------------------------------------------

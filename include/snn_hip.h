@@ -237,6 +237,17 @@ size_t snn_packed_linear_mx_words(int N, int K);
 size_t snn_packed_conv3x3_mx_words(int C_out, int C_in);
 int snn_pack_linear_weight_mx(const float* w_nk, int N, int K, uint32_t* packed, snn_stream_t s);
 int snn_pack_conv3x3_weight_mx(const float* w_oihw, int C_out, int C_in, uint32_t* packed, snn_stream_t s);
+/* the spike GEMMs on the fp4 x fp6 block-scaled matrix path (k_gemm_mx); K / C_in must be a multiple of 128 (-4 else),
+ * same operands and results as the _bf16x3 entry points */
+int snn_spike_gemm_mx(const uint32_t* a_rows, int M, int K, int N, const uint32_t* w_packed, float* cur, int ldo,
+                      snn_stream_t stream);
+int snn_spike_gemm_lif_mx(const uint32_t* a_planes, int T, int R, int K, int N, const snn_params* p,
+                          const uint32_t* w_packed, uint32_t* spk, size_t spk_stride, snn_stream_t stream);
+int snn_conv3x3_lif_mx(const uint32_t* enc, size_t enc_stride, const snn_rpn_level* lv, int n_levels, int C_in, int C_out,
+                       int T, const snn_params* p, const uint32_t* w_packed, uint32_t* spk, size_t spk_stride,
+                       snn_stream_t stream);
+int snn_spike_conv3x3_mx(const uint32_t* enc, size_t enc_stride, const snn_rpn_level* lv, int n_levels, int C_in,
+                         int C_out, int T, const uint32_t* w_packed, float* cur, int ldo, snn_stream_t stream);
 /* cur[M][ldo] = A_bits[M][K] x W[K][N] */
 int snn_spike_gemm_bf16x3(const uint32_t* a_rows, int M, int K, int N, const uint16_t* w_packed, float* cur,
                           int ldo, snn_stream_t stream);

@@ -93,6 +93,13 @@ SYMBOLS = {
     "snn_packed_conv3x3_mx_words": (C.c_size_t, [C.c_int, C.c_int]),
     "snn_pack_linear_weight_mx": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, c_stream]),
     "snn_pack_conv3x3_weight_mx": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, c_stream]),
+    "snn_spike_gemm_mx": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, c_stream]),
+    "snn_spike_gemm_lif_mx": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_size_t, c_stream]),
+    "snn_conv3x3_lif_mx": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_size_t, c_stream]),
+    "snn_spike_conv3x3_mx": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                       C.c_void_p, C.c_int, c_stream]),
     "snn_spike_gemm_bf16x3": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, c_stream]),
     "snn_spike_gemm_lif_bf16x3": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_size_t, c_stream]),

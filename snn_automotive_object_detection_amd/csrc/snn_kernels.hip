@@ -2212,6 +2212,101 @@ int snn_spike_gemm_lif_bf16x3(const uint32_t* a_planes, int T, int R, int K, int
     return launch_gemm3(G3_FC_LIF_TILE, mt, wn, a, (hipStream_t)s);
 }
 
+// ---- spike GEMMs on the block-scaled fp4 x fp6 path (snn_mx.h) ------------------------------------
+static bool mx_tile_ok(int T) { return g3_tile_ok(T, MX_BM); }
+
+static int launch_gemm_mx(int mode, MxArgs& a, hipStream_t s) {
+    const void* kern;
+    int lds = MX_LDS, tiles = cdiv(a.g.M, MX_BM);
+    switch (mode) {
+    case G3_FC: kern = (const void*)k_gemm_mx<G3_FC>; break;
+    case G3_CONV: kern = (const void*)k_gemm_mx<G3_CONV>; break;
+    case G3_CONV_LIF_TILE: kern = (const void*)k_gemm_mx<G3_CONV_LIF_TILE>; tiles = cdiv(a.g.M, a.g.pb); lds = max(lds, (int)G3_TILE_BYTES(1)); break;
+    default: kern = (const void*)k_gemm_mx<G3_FC_LIF_TILE>; tiles = cdiv(a.g.M, a.g.pb); lds = max(lds, (int)G3_TILE_BYTES(1)); break;
+    }
+    a.g.n_blocks = cdiv(a.g.Np, MX_BN);
+    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return fail(-3, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+    void* kargs[] = {(void*)&a};
+    e = hipLaunchKernel(kern, dim3(tiles * a.g.n_blocks), dim3(512), kargs, lds, s);
+    if (e != hipSuccess) return fail(-3, "k_gemm_mx launch failed: %s", hipGetErrorString(e));
+    SNN_CHECK_LAUNCH("k_gemm_mx");
+    return 0;
+}
+
+int snn_spike_gemm_mx(const uint32_t* a_rows, int M, int K, int N, const uint32_t* w_packed, float* cur, int ldo,
+                      snn_stream_t s) {
+    if (!a_rows || !w_packed || !cur || M <= 0 || K <= 0 || N <= 0 || ldo < N) return fail(-1, "snn_spike_gemm_mx: bad argument");
+    if (K % 128) return fail(-4, "snn_spike_gemm_mx: K=%d is not a multiple of 128 (use the bf16x3 kernels)", K);
+    if ((long long)M * (K / 32) * 4 > 0xffffffffLL) return fail(-1, "snn_spike_gemm_mx: spike rows over 4 GB");
+    MxArgs a;
+    memset(&a, 0, sizeof(a));
+    a.g.A = a_rows; a.g.out = cur; a.g.M = M; a.g.Np = cdiv(N, 32) * 32; a.g.ldo = ldo;
+    a.wq = w_packed; a.Kc = K / 128;
+    return launch_gemm_mx(G3_FC, a, (hipStream_t)s);
+}
+
+int snn_spike_gemm_lif_mx(const uint32_t* a_planes, int T, int R, int K, int N, const snn_params* p,
+                          const uint32_t* w_packed, uint32_t* spk, size_t spk_stride, snn_stream_t s) {
+    if (!a_planes || !w_packed || !spk || !p || R <= 0 || K <= 0 || N <= 0) return fail(-1, "snn_spike_gemm_lif_mx: bad argument");
+    if (check_T(T, "snn_spike_gemm_lif_mx")) return -1;
+    if (K % 128) return fail(-4, "snn_spike_gemm_lif_mx: K=%d is not a multiple of 128", K);
+    if (!mx_tile_ok(T)) return fail(-4, "snn_spike_gemm_lif_mx: T=%d does not fit a row tile", T);
+    if ((long long)T * R * (K / 32) * 4 > 0xffffffffLL) return fail(-1, "snn_spike_gemm_lif_mx: input planes over 4 GB");
+    MxArgs a;
+    memset(&a, 0, sizeof(a));
+    a.g.A = a_planes; a.g.M = R; a.g.Np = cdiv(N, 32) * 32;
+    a.g.T = T; a.g.spk = spk; a.g.spk_stride = spk_stride; a.g.p = make_p(p, p->v_th_lif); a.g.pb = MX_BM / T;
+    a.wq = w_packed; a.Kc = K / 128;
+    return launch_gemm_mx(G3_FC_LIF_TILE, a, (hipStream_t)s);
+}
+
+static int conv_mx_common(const char* who, const uint32_t* enc, size_t enc_stride, const snn_rpn_level* lv, int n_levels,
+                          int C_in, int C_out, int T, const uint32_t* w_packed, MxArgs& a, long long* P_out) {
+    if (!enc || !lv || !w_packed || n_levels <= 0 || n_levels > SNN_MAX_LEVELS || C_in <= 0 || C_out <= 0)
+        return fail(-1, "%s: bad argument", who);
+    if (C_in % 128) return fail(-4, "%s: C_in=%d is not a multiple of 128 (use the bf16x3 kernels)", who, C_in);
+    if (check_T(T, who)) return -1;
+    memset(&a, 0, sizeof(a));
+    long long P = 0;
+    for (int l = 0; l < n_levels; ++l) {
+        if (lv[l].N <= 0 || lv[l].H <= 0 || lv[l].W <= 0) return fail(-1, "%s: bad level %d", who, l);
+        a.g.lv[l].pos_base = (int)P; a.g.lv[l].N = lv[l].N; a.g.lv[l].H = lv[l].H; a.g.lv[l].W = lv[l].W;
+        P += (long long)lv[l].N * lv[l].H * lv[l].W;
+    }
+    if ((long long)T * P > 0x7fffffffLL) return fail(-1, "%s: T*P too large", who);
+    if (((long long)(T - 1) * (long long)enc_stride + P * (C_in / 32)) * 4 > 0xffffffffLL) return fail(-1, "%s: encoder planes over 4 GB", who);
+    a.g.A = enc; a.g.enc_stride = enc_stride; a.g.Cw = C_in / 32; a.g.Np = cdiv(C_out, 32) * 32;
+    a.g.P_total = (int)P; a.g.n_levels = n_levels;
+    a.wq = w_packed; a.Kc = 9 * C_in / 128;
+    *P_out = P;
+    return 0;
+}
+
+int snn_conv3x3_lif_mx(const uint32_t* enc, size_t enc_stride, const snn_rpn_level* lv, int n_levels, int C_in, int C_out,
+                       int T, const snn_params* p, const uint32_t* w_packed, uint32_t* spk, size_t spk_stride,
+                       snn_stream_t s) {
+    if (!spk || !p) return fail(-1, "snn_conv3x3_lif_mx: bad argument");
+    MxArgs a;
+    long long P;
+    int rc = conv_mx_common("snn_conv3x3_lif_mx", enc, enc_stride, lv, n_levels, C_in, C_out, T, w_packed, a, &P);
+    if (rc) return rc;
+    if (!mx_tile_ok(T)) return fail(-4, "snn_conv3x3_lif_mx: T=%d does not fit a row tile", T);
+    a.g.M = (int)P; a.g.T = T; a.g.spk = spk; a.g.spk_stride = spk_stride; a.g.p = make_p(p, p->v_th_lif); a.g.pb = MX_BM / T;
+    return launch_gemm_mx(G3_CONV_LIF_TILE, a, (hipStream_t)s);
+}
+
+int snn_spike_conv3x3_mx(const uint32_t* enc, size_t enc_stride, const snn_rpn_level* lv, int n_levels, int C_in, int C_out,
+                         int T, const uint32_t* w_packed, float* cur, int ldo, snn_stream_t s) {
+    if (!cur || ldo < C_out) return fail(-1, "snn_spike_conv3x3_mx: bad argument");
+    MxArgs a;
+    long long P;
+    int rc = conv_mx_common("snn_spike_conv3x3_mx", enc, enc_stride, lv, n_levels, C_in, C_out, T, w_packed, a, &P);
+    if (rc) return rc;
+    a.g.M = (int)(T * P); a.g.out = cur; a.g.ldo = ldo;
+    return launch_gemm_mx(G3_CONV, a, (hipStream_t)s);
+}
+
 static int conv3_common(const char* who, const uint32_t* enc, size_t enc_stride, const snn_rpn_level* lv, int n_levels,
                         int C_in, int C_out, int T, const uint16_t* w_packed, Gemm3Args& a, long long* P_out) {
     if (!enc || !lv || !w_packed || n_levels <= 0 || n_levels > SNN_MAX_LEVELS || C_in <= 0 || C_out <= 0)

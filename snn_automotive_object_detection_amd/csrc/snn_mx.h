@@ -97,3 +97,357 @@ __global__ void k_pack_mx(const float* __restrict__ src, uint32_t* __restrict__ 
         S[((size_t)kc * Np + n) * 4 + lg] = (uint8_t)eb;
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// k_gemm_mx<MODE>: the spike GEMMs on the block-scaled fp4 x fp6 matrix path.
+//
+// Work-group = 8 waves x 1 = 512 rows x 64 columns, wave = 64 x 64 = 4 x 4 tiles of v_mfma_scale_f32_16x16x128_f8f6f4.
+// A 128-deep chunk (4 spike words per row) is multiplied in two micro-steps of 3 digit planes each (least significant
+// planes first): 12 groups (plane, N-tile) of 4 MFMAs per micro-step - the cadence of k_gemm_bf16x3.
+//   A: the row's 4 spike words come by one 16-B load (inline asm, scalar base + lane offset), go through LDS as raw
+//      words, and a lane's fragment (32 fp4 = one spike word) is 4 reads of a byte -> 8-nibble table; built once per
+//      chunk, used by all 6 planes.
+//   B: per micro-step 3 planes x (64 rows x 64 B + 64 rows x 32 B) = 18 KB by LDS-DMA into a 3-slot ring, two
+//      micro-steps ahead; a lane's 24-B fragment = ds_read_b128 + ds_read_b64.  Scales: one dword (4 bytes = the 4
+//      k-groups) per column and chunk, staged with the spike words.
+// Modes: G3_FC, G3_CONV, G3_CONV_LIF_TILE, G3_FC_LIF_TILE as in k_gemm_bf16x3 (the T-in-tile epilogue is the 8 x 1 one).
+// Requires K (fc) / C_in (conv) to be a multiple of 128.
+// ------------------------------------------------------------------------------------------------
+typedef int v8i_t __attribute__((ext_vector_type(8)));
+typedef unsigned int v4u_t __attribute__((ext_vector_type(4)));
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef int v2i_t __attribute__((ext_vector_type(2)));
+struct MxB { v4i_t lo; v2i_t hi; };             // a lane's 24-B fp6 fragment
+#define MX_BM 512
+#define MX_BN 64
+#define MX_LUT_BYTES 1024
+#define MX_AW_BYTES (MX_BM * 16)                    // 4 spike words per row
+#define MX_SC_BYTES 256                             // 64 columns x 4 scale bytes
+#define MX_SLOT (3 * (MX_BN * 64 + MX_BN * 32))     // 18432: X and Y parts of three planes
+#define MX_RING_OFF (MX_LUT_BYTES + 2 * MX_AW_BYTES + 2 * MX_SC_BYTES)
+#define MX_LDS (MX_RING_OFF + 3 * MX_SLOT)          // 73216 B
+
+struct MxArgs {
+    Gemm3Args g;                 // shared fields: A, out, M, Np, ldo, n_blocks, Cw, P_total, n_levels, T, pb, spk, spk_stride, p, lv, enc_stride
+    const uint32_t* wq;          // digit planes (snn_mx.h layout)
+    int Kc;                      // 128-deep chunks
+};
+
+__device__ __forceinline__ void mx_load16(v4u_t& w, uint32_t voff, const void* sbase) {
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "+v"(w) : "v"(voff), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void mx_load4(uint32_t& w, uint32_t voff, const void* sbase) {
+    asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "+v"(w) : "v"(voff), "s"(sbase) : "memory");
+}
+
+// fp4 (A, scale 1.0) x fp6 e2m3 (B, scale = byte `opsel` of `sc`); the op_sel field is an immediate
+// (the builtin takes 8-dword operands; only 4 (fp4) / 6 (fp6) are read.  They are widened HERE with undefined upper
+// lanes: fragments carried through the loop as 8-dword values cost 8 registers each and zero fills)
+__device__ __forceinline__ f32x4 mx_mfma(const v4i_t a4, const MxB b6, const f32x4 c, const int opsel, const uint32_t sc) {
+    const v8i_t a = __builtin_shufflevector(a4, a4, 0, 1, 2, 3, -1, -1, -1, -1);
+    const v4i_t h4 = __builtin_shufflevector(b6.hi, b6.hi, 0, 1, -1, -1);
+    const v8i_t b = __builtin_shufflevector(b6.lo, h4, 0, 1, 2, 3, 4, 5, -1, -1);
+    switch (opsel) {
+    case 0: return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 4, 2, 0, 127, 0, sc);
+    case 1: return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 4, 2, 0, 127, 1, sc);
+    case 2: return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 4, 2, 0, 127, 2, sc);
+    default: return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 4, 2, 0, 127, 3, sc);
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(512, 4) void k_gemm_mx(const MxArgs ma) {
+    constexpr bool CONV = MODE == G3_CONV || MODE == G3_CONV_LIF_TILE;
+    constexpr bool TILE = MODE == G3_CONV_LIF_TILE || MODE == G3_FC_LIF_TILE;
+    constexpr int PD = 1, RING = PD + 1;                        // fragment prefetch distance in groups; RING divides 12
+                                                                // (128 registers: 64 acc + 16 A + 12 B fragments + addresses)
+    const Gemm3Args& args = ma.g;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    unsigned char* const lut = smem;                                        // byte -> 8 fp4 nibbles (0 / 1.0 = 0x2)
+    unsigned char* const awb = smem + MX_LUT_BYTES;                         // [2][512 rows][16 B]
+    unsigned char* const scb = awb + 2 * MX_AW_BYTES;                       // [2][64 columns] dword
+    unsigned char* const ring = smem + MX_RING_OFF;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);              // = row block of 64
+    const int nb = blockIdx.x % args.n_blocks, mb = blockIdx.x / args.n_blocks;
+    const int m0 = TILE ? mb * args.pb : mb * MX_BM;
+    const int Kc = ma.Kc, Np = args.Np, M = args.M;
+    const int lr = lane & 15, lg = lane >> 4;
+
+    if (tid < 256) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) v |= ((tid >> b) & 1u) << (4 * b + 1);
+        reinterpret_cast<uint32_t*>(lut)[tid] = v;
+    }
+
+    // ---- A staging: thread = row.  One 16-B load per chunk: scalar base + 32-bit lane offset ----
+    const int xrow = tid;
+    const int xt = TILE ? xrow / args.pb : 0;
+    const int xm = TILE ? (xt < args.T ? m0 + xrow % args.pb : M) : m0 + xrow;
+    uint32_t a_off = 0;
+    int a_pitch = 0;
+    uint32_t a_valid = 0;
+    const int Kw = CONV ? args.Cw : Kc * 4;                                 // spike words per row (fc: K / 32)
+    if (CONV) {
+        if (xm < M) {
+            const int t = TILE ? xt : xm / args.P_total, p = TILE ? xm : xm % args.P_total;
+            int l = 0;
+            while (l + 1 < args.n_levels && p >= args.lv[l + 1].pos_base) ++l;
+            const int H = args.lv[l].H, W = args.lv[l].W;
+            const int local = p - args.lv[l].pos_base;
+            const int rem = local % (H * W);
+            const int y = rem / W, x = rem % W;
+            a_off = (uint32_t)(((size_t)t * args.enc_stride + (size_t)p * args.Cw) * 4);
+            a_pitch = W * args.Cw * 4;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+                a_valid |= (uint32_t)(yy >= 0 && yy < H && xx >= 0 && xx < W) << tap;
+            }
+        }
+    } else if (TILE) {
+        a_off = xm < M ? (uint32_t)(((size_t)xt * M + xm) * Kw * 4) : 0u;
+    } else {
+        a_off = (uint32_t)((size_t)min(xm, M - 1) * Kw * 4);
+    }
+    // fetch stream over the chunk sequence (tap dy, tap dx, 128-channel group): running scalar word offset
+    const int cpt = CONV ? args.Cw / 4 : 0;                                 // chunks per tap
+    int f_off = CONV ? -args.Cw : 0;
+    uint32_t f_voff = CONV ? a_off - (uint32_t)a_pitch : a_off;
+    uint32_t f_mask = 1u;
+    int f_kc = 0, f_cc = 0, f_dx = 0;
+    auto fetch_next = [&](v4u_t& w, uint32_t& sc) {                         // spike words + column scales of the next chunk
+        w = v4u_t{0u, 0u, 0u, 0u};
+        const void* sbase = sgpr_ptr(args.A + f_off);
+        if (!CONV || (a_valid & f_mask)) mx_load16(w, f_voff, sbase);
+        sc = 0u;
+        if (wave == 0) {
+            const uint32_t* S = ma.wq + mx_x_words(Kc, Np) + mx_y_words(Kc, Np) + (size_t)f_kc * Np + nb * MX_BN;
+            mx_load4(sc, (uint32_t)min(lane, Np - nb * MX_BN - 1) * 4u, sgpr_ptr(S));
+        }
+        f_off += 4;
+        if (CONV && ++f_cc == cpt) {
+            f_cc = 0;
+            f_mask <<= 1;
+            if (++f_dx == 3) { f_dx = 0; f_off -= 3 * args.Cw; f_voff += (uint32_t)a_pitch; }
+        }
+        if (++f_kc == Kc) {                                                 // past the end: wrap (staged, never multiplied)
+            f_kc = 0; f_cc = 0; f_dx = 0; f_mask = 1u;
+            f_off = CONV ? -args.Cw : 0;
+            f_voff = CONV ? a_off - (uint32_t)a_pitch : a_off;
+        }
+    };
+    auto store_a = [&](const v4u_t& w, uint32_t sc, int par) {
+        *reinterpret_cast<v4u_t*>(awb + par * MX_AW_BYTES + xrow * 16) = w;
+        if (wave == 0) *reinterpret_cast<uint32_t*>(scb + par * MX_SC_BYTES + lane * 4) = sc;
+    };
+
+    // ---- B staging: per micro-step 3 planes x (4 X pieces + 2 Y pieces) of 1 KiB = 18 pieces; every wave issues
+    // exactly 3 (piece = wave, wave + 8, wave + 16; slots 18..23 repeat Y pieces - same bytes, harmless), with all
+    // piece parameters fixed before the loop: branch-free staging, running scalar source pointers ----
+    const unsigned long long xplane = (unsigned long long)Kc * Np * 64, yplane = (unsigned long long)Kc * Np * 32;   // bytes per plane
+    const unsigned char* const Xg = reinterpret_cast<const unsigned char*>(ma.wq);
+    const unsigned char* const Yg = Xg + (size_t)MX_P * xplane;
+    unsigned long long pc_base[3], pc_plane3[3], pc_ptr[3];                 // scalar: source of (chunk 0, half 0), 3 planes, running
+    uint32_t pc_cstride[3], pc_dst[3], pc_voff[3];                          // chunk stride, LDS offset in the slot (scalar); lane offset
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        int piece = wave + 8 * j;
+        if (piece >= 18) piece -= 6;                                        // repeat Y pieces 0..5
+        const bool isx = piece < 12;
+        const int q = isx ? piece : piece - 12;
+        const int pj = isx ? q >> 2 : q >> 1, part = isx ? q & 3 : q & 1;   // plane slot 0..2, 1-KiB part
+        const int r = part * 16 + (lane >> 2);
+        const int ncols = Np - nb * MX_BN;                                  // columns this block really has (>= 32)
+        pc_voff[j] = isx ? (uint32_t)(min(r, ncols - 1) * 64 + (((lane & 3) ^ G3_SWZ(r)) << 4))
+                         : (uint32_t)min(part * 1024 + lane * 16, ncols * 32 - 16);
+        pc_dst[j] = isx ? pj * (MX_BN * 64) + part * 1024 : 3 * (MX_BN * 64) + pj * (MX_BN * 32) + part * 1024;
+        const unsigned long long plane = isx ? xplane : yplane;
+        pc_base[j] = (unsigned long long)(isx ? Xg : Yg) + (5 - pj) * plane + (unsigned long long)nb * MX_BN * (isx ? 64 : 32);
+        pc_plane3[j] = 3 * plane;
+        pc_cstride[j] = (uint32_t)Np * (isx ? 64u : 32u);
+        pc_ptr[j] = pc_base[j];
+    }
+    int s_kc = 0, s_h = 0;                                                  // staging stream position (chunk, half)
+    auto stage_next = [&](uint32_t slot_off) {
+        const uint32_t dbase = smem_base + MX_RING_OFF + slot_off;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            glds16(sgpr_ptr(reinterpret_cast<const void*>(pc_ptr[j])), pc_voff[j], __builtin_amdgcn_readfirstlane(dbase + pc_dst[j]));
+        if (s_h == 0) {                                                     // next: the three more significant planes of this chunk
+            s_h = 1;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) pc_ptr[j] -= pc_plane3[j];
+        } else {
+            s_h = 0;
+            const bool wrap = ++s_kc == Kc;
+            if (wrap) s_kc = 0;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) pc_ptr[j] = wrap ? pc_base[j] : pc_ptr[j] + pc_plane3[j] + pc_cstride[j];
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // fragment readers
+    const unsigned char* const w_rd = awb + (wave * 64 + lr) * 16 + lg * 4;           // + parity, mt * 256
+    auto rd_w = [&](int par, int mt) { return *reinterpret_cast<const uint32_t*>(w_rd + par * MX_AW_BYTES + mt * 256); };
+    auto rd_a = [&](uint32_t w) {                                                    // 32 spike bits -> 32 fp4
+        v4i_t a = {0, 0, 0, 0};
+#pragma unroll
+        for (int b = 0; b < 4; ++b) a[b] = *reinterpret_cast<const int*>(lut + (__builtin_amdgcn_ubfe(w, 8 * b, 8) << 2));
+        return a;
+    };
+    const unsigned char* const bx_rd = ring + lr * 64 + ((lg ^ G3_SWZ(lr)) << 4);     // + slot, plane slot * 4096, nt * 1024
+    const unsigned char* const by_rd = ring + 3 * (MX_BN * 64) + lr * 32 + lg * 8;    // + slot, plane slot * 2048, nt * 512
+    auto rd_b = [&](uint32_t slot_off, int g) {                                      // group g = (N-tile g / 3, plane slot g % 3)
+        const int nt = g / 3, pj = g % 3;
+        MxB b;
+        b.lo = *reinterpret_cast<const v4i_t*>(bx_rd + slot_off + pj * (MX_BN * 64) + nt * 1024);
+        b.hi = *reinterpret_cast<const v2i_t*>(by_rd + slot_off + pj * (MX_BN * 32) + nt * 512);
+        return b;
+    };
+
+    const int n_ms = 2 * Kc;                                                // micro-steps
+    // ---- prologue: spike words + scales of chunks 0 and 1 in LDS; planes of micro-steps 0, 1 staged ----
+    v4u_t w_new;
+    uint32_t s_new;
+    {
+        v4u_t w0;
+        uint32_t c0;
+        fetch_next(w0, c0);
+        fetch_next(w_new, s_new);
+        stage_next(0);
+        stage_next(MX_SLOT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("" : "+v"(w0), "+v"(c0), "+v"(w_new), "+v"(s_new));
+        store_a(w0, c0, 0);
+        store_a(w_new, s_new, 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+    v4i_t af[4];
+    MxB bq[RING];
+    uint32_t wq4[4], scq[4];                                                // scq[nt]: bytes Eb, Eb-5, Eb-10, Eb-15 of the lane's block
+    auto load_scales = [&](int par) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const uint32_t dw = *reinterpret_cast<const uint32_t*>(scb + par * MX_SC_BYTES + (nt * 16 + lr) * 4);
+            scq[nt] = __builtin_amdgcn_ubfe(dw, 8 * lg, 8) * 0x01010101u - 0x0F0A0500u;     // Eb >= 32: no borrow
+        }
+    };
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) af[mt] = rd_a(rd_w(0, mt));
+    load_scales(0);
+#pragma unroll
+    for (int g = 0; g < PD; ++g) bq[g] = rd_b(0, g);
+
+    uint32_t o_cur = 0, o_nxt = MX_SLOT, o_wr = 2 * MX_SLOT;
+    int kc = 0;                                                              // chunk of the current micro-step
+    for (int ms0 = 0; ms0 < n_ms; ms0 += 2) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {                                        // micro-step ms0 + h: planes 5-3h .. 3-3h
+            const int par = kc & 1;
+#pragma unroll
+            for (int g = 0; g < 12; ++g) {
+                const int gp = g + PD;
+                bq[gp % RING] = gp < 12 ? rd_b(o_cur, gp) : rd_b(o_nxt, gp - 12);
+                if (h == 0 && g == 2) fetch_next(w_new, s_new);              // spike words + scales of chunk kc+2 ...
+                if (h == 1 && g == 0) {                                      // ... landed at the last barrier: into the buffer of
+                    asm volatile("" : "+v"(w_new), "+v"(s_new));             // chunk kc, whose fragments were built a chunk ago
+                    store_a(w_new, s_new, par);
+                }
+                if (g == 3) stage_next(o_wr);                                // planes of micro-step +2
+                if (h == 1 && g == 4) {
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) wq4[mt] = rd_w(par ^ 1, mt);
+                }
+                const int nt = g / 3, pl = 5 - 3 * h - g % 3;
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    // planes 4, 5: Eb - 20, Eb - 25 = bytes 0, 1 of (scq - 0x14141414)
+                    acc[mt][nt] = mx_mfma(af[mt], bq[g % RING], acc[mt][nt], pl & 3, pl < 4 ? scq[nt] : scq[nt] - 0x14141414u);
+                    // the chunk's last use of af[mt]: rebuild it for the next chunk right away
+                    if (h == 1 && g == 11) af[mt] = rd_a(wq4[mt]);
+                }
+                // Pin the group: the MFMAs are pure register operations whose only users are the next MFMAs of their
+                // accumulation chains, and hipcc otherwise SINKS a whole micro-step of them past the barrier into the next
+                // one (all 12 fragments live across it, accumulators spilled).  An empty volatile asm that "modifies" the
+                // four accumulators keeps them in program order with the staging asm and the barrier fences.
+                asm volatile("" : "+v"(acc[0][nt]), "+v"(acc[1][nt]), "+v"(acc[2][nt]), "+v"(acc[3][nt]) :: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_waitcnt(0x0070);                              // vmcnt(0) lgkmcnt(0)
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (h == 1) {
+                load_scales(par ^ 1);                                        // scales of chunk kc+1
+                if (++kc == Kc) kc = 0;
+            }
+            { const uint32_t o = o_cur; o_cur = o_nxt; o_nxt = o_wr; o_wr = o; }
+        }
+    }
+
+    if (TILE) {
+        // ---- LIF over the T time steps held in this tile (the 8 x 1 epilogue of k_gemm_bf16x3): two passes of 32 columns ----
+        constexpr int CG = 32, PITCH = CG + 4;
+        float* const tile = reinterpret_cast<float*>(smem);
+        const int pb = args.pb, T = args.T;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll 1
+        for (int h = 0; h < 2; ++h) {
+            __syncthreads();
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nq = 0; nq < 2; ++nq)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        tile[(wave * 64 + mt * 16 + lg * 4 + r) * PITCH + nq * 16 + lr] = h == 0 ? acc[mt][nq][r] : acc[mt][2 + nq][r];
+            __syncthreads();
+            const int word0 = (nb * MX_BN + h * CG) >> 5;
+            if (word0 * 32 >= Np) continue;
+            const int par = lane >> 5, col = lane & 31;
+            for (int pp = wave; 2 * pp < pb; pp += 8) {
+                const int pi = 2 * pp + par;
+                const bool live = pi < pb && m0 + pi < M;
+                if (m0 + 2 * pp >= M) break;
+                float vv = args.p.v_leak, ii = 0.0f;
+                uint32_t my0 = 0, my1 = 0;
+                const float* src = tile + (live ? pi : 2 * pp) * PITCH + col;
+                for (int t = 0; t < T; ++t) {
+                    const bool z = lif_step(src[(size_t)t * pb * PITCH], vv, ii, args.p);
+                    const unsigned long long b = __ballot(z);
+                    my0 = lane == t ? (uint32_t)b : my0;
+                    my1 = lane == t ? (uint32_t)(b >> 32) : my1;
+                }
+                if (lane < T) {
+                    uint32_t* dst = args.spk + (size_t)lane * args.spk_stride + (size_t)(m0 + 2 * pp) * (Np >> 5) + word0;
+                    dst[0] = my0;
+                    if (2 * pp + 1 < pb && m0 + 2 * pp + 1 < M) dst[Np >> 5] = my1;
+                }
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int col = nb * MX_BN + nt * 16 + lr;
+            if (col >= Np) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wave * 64 + mt * 16 + lg * 4 + r;
+                if (m < M) args.out[(size_t)m * args.ldo + col] = acc[mt][nt][r];
+            }
+        }
+}

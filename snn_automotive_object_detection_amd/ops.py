@@ -163,6 +163,54 @@ def spike_gemm_lif_bf16x3(a_planes: torch.Tensor, K: int, N: int, p: snn_params,
     return spk
 
 
+def spike_gemm_mx(a_rows: torch.Tensor, K: int, N: int, w_packed: torch.Tensor) -> torch.Tensor:
+    """a_rows int32 [M, Kw] -> cur fp32 [M, Np] on the fp4 x fp6 block-scaled matrix path"""
+    _need_gpu(a_rows, "spike rows")
+    lib = _lib.load()
+    M, Np = a_rows.shape[0], cdiv(N, 32) * 32
+    cur = torch.empty((M, Np), dtype=torch.float32, device=a_rows.device)
+    _lib.check(lib.snn_spike_gemm_mx(_ptr(a_rows), M, K, N, _ptr(w_packed), _ptr(cur), Np, _stream()), "snn_spike_gemm_mx")
+    return cur
+
+
+def spike_gemm_lif_mx(a_planes: torch.Tensor, K: int, N: int, p: snn_params, w_packed: torch.Tensor) -> torch.Tensor:
+    """a_planes int32 [T, R, Kw] -> LIF spike planes int32 [T, R, Nw] (fp4 x fp6 path, LIF fused in the row tile)"""
+    _need_gpu(a_planes, "spike planes")
+    lib = _lib.load()
+    T, R, _ = a_planes.shape
+    Nw = cdiv(N, 32)
+    spk = torch.empty((T, R, Nw), dtype=torch.int32, device=a_planes.device)
+    _lib.check(lib.snn_spike_gemm_lif_mx(_ptr(a_planes), T, R, K, N, C.byref(p), _ptr(w_packed), _ptr(spk), R * Nw, _stream()),
+               "snn_spike_gemm_lif_mx")
+    return spk
+
+
+def conv3x3_lif_mx(enc: torch.Tensor, shapes, C_in: int, C_out: int, p: snn_params, w_packed: torch.Tensor) -> torch.Tensor:
+    """enc int32 [T, P, Cw] over levels `shapes` -> shared-LIF spike planes int32 [T, P, Nw] (fp4 x fp6 path)"""
+    _need_gpu(enc, "enc planes")
+    lib = _lib.load()
+    T, P, Cw = enc.shape
+    lv = (snn_rpn_level * len(shapes))(*[snn_rpn_level(None, n, h, w, 0) for n, h, w in shapes])
+    Nw = cdiv(C_out, 32)
+    spk = torch.empty((T, P, Nw), dtype=torch.int32, device=enc.device)
+    _lib.check(lib.snn_conv3x3_lif_mx(_ptr(enc), P * Cw, lv, len(shapes), C_in, C_out, T, C.byref(p), _ptr(w_packed), _ptr(spk),
+                                      P * Nw, _stream()), "snn_conv3x3_lif_mx")
+    return spk
+
+
+def spike_conv3x3_mx(enc: torch.Tensor, shapes, C_in: int, C_out: int, w_packed: torch.Tensor) -> torch.Tensor:
+    """enc int32 [T, P, Cw] over levels `shapes` -> cur fp32 [T, P, Np] (fp4 x fp6 path)"""
+    _need_gpu(enc, "enc planes")
+    lib = _lib.load()
+    T, P, Cw = enc.shape
+    lv = (snn_rpn_level * len(shapes))(*[snn_rpn_level(None, n, h, w, 0) for n, h, w in shapes])
+    Np = cdiv(C_out, 32) * 32
+    cur = torch.empty((T, P, Np), dtype=torch.float32, device=enc.device)
+    _lib.check(lib.snn_spike_conv3x3_mx(_ptr(enc), P * Cw, lv, len(shapes), C_in, C_out, T, _ptr(w_packed), _ptr(cur), Np,
+                                        _stream()), "snn_spike_conv3x3_mx")
+    return cur
+
+
 def conv3x3_lif_bf16x3(enc: torch.Tensor, shapes, C_in: int, C_out: int, p: snn_params, w_packed: torch.Tensor) -> torch.Tensor:
     """enc int32 [T, P, Cw] over levels `shapes` = [(N,H,W), ...] -> shared-LIF spike planes int32 [T, P, Nw]"""
     _need_gpu(enc, "enc planes")

@@ -25,7 +25,9 @@ __device__ __forceinline__ uint32_t mx_fp6_code(int d) {
 // Kc = 128-deep chunks; conv: k = tap*Cp + ci with Cp = C_in rounded up to 128.
 __host__ __device__ inline size_t mx_x_words(int Kc, int Np) { return (size_t)MX_P * Kc * Np * 16; }
 __host__ __device__ inline size_t mx_y_words(int Kc, int Np) { return (size_t)MX_P * Kc * Np * 8; }
-__host__ __device__ inline size_t mx_words(int Kc, int Np) { return mx_x_words(Kc, Np) + mx_y_words(Kc, Np) + (size_t)Kc * Np; }
+__host__ __device__ inline size_t mx_s_words(int Kc, int Np) { return (size_t)Kc * Np; }
+// + 16 zero words: where the spike-word copies of rows outside the image read from
+__host__ __device__ inline size_t mx_words(int Kc, int Np) { return mx_x_words(Kc, Np) + mx_y_words(Kc, Np) + mx_s_words(Kc, Np) + 16; }
 
 __global__ void k_pack_mx(const float* __restrict__ src, uint32_t* __restrict__ dst, int mode, int K, int N, int Kc, int Np,
                           int Cin, int Cp) {
@@ -33,6 +35,7 @@ __global__ void k_pack_mx(const float* __restrict__ src, uint32_t* __restrict__ 
     uint32_t* const X = dst;
     uint32_t* const Y = dst + mx_x_words(Kc, Np);
     uint8_t* const S = reinterpret_cast<uint8_t*>(dst + mx_x_words(Kc, Np) + mx_y_words(Kc, Np));
+    if (blockIdx.x == 0 && threadIdx.x < 16) dst[mx_words(Kc, Np) - 16 + threadIdx.x] = 0u;
     for (size_t blk = (size_t)blockIdx.x * blockDim.x + threadIdx.x; blk < blocks; blk += (size_t)gridDim.x * blockDim.x) {
         const int lg = (int)(blk & 3);
         const int n = (int)((blk >> 2) % Np);
@@ -104,8 +107,8 @@ __global__ void k_pack_mx(const float* __restrict__ src, uint32_t* __restrict__ 
 // Work-group = 8 waves x 1 = 512 rows x 64 columns, wave = 64 x 64 = 4 x 4 tiles of v_mfma_scale_f32_16x16x128_f8f6f4.
 // A 128-deep chunk (4 spike words per row) is multiplied in two micro-steps of 3 digit planes each (least significant
 // planes first): 12 groups (plane, N-tile) of 4 MFMAs per micro-step - the cadence of k_gemm_bf16x3.
-//   A: the row's 4 spike words come by one 16-B load (inline asm, scalar base + lane offset), go through LDS as raw
-//      words, and a lane's fragment (32 fp4 = one spike word) is 4 reads of a byte -> 8-nibble table; built once per
+//   A: the row's 4 spike words are copied global -> LDS by LDS-DMA (16 B per row, no registers) as raw words, and a
+//      lane's fragment (32 fp4 = one spike word) is 4 reads of a byte -> 8-nibble table; built once per
 //      chunk, used by all 6 planes.
 //   B: per micro-step 3 planes x (64 rows x 64 B + 64 rows x 32 B) = 18 KB by LDS-DMA into a 3-slot ring, two
 //      micro-steps ahead; a lane's 24-B fragment = ds_read_b128 + ds_read_b64.  Scales: one dword (4 bytes = the 4
@@ -125,20 +128,14 @@ struct MxB { v4i_t lo; v2i_t hi; };             // a lane's 24-B fp6 fragment
 #define MX_SC_BYTES 256                             // 64 columns x 4 scale bytes
 #define MX_SLOT (3 * (MX_BN * 64 + MX_BN * 32))     // 18432: X and Y parts of three planes
 #define MX_RING_OFF (MX_LUT_BYTES + 2 * MX_AW_BYTES + 2 * MX_SC_BYTES)
-#define MX_LDS (MX_RING_OFF + 3 * MX_SLOT)          // 73216 B
+#define MX_PARK_OFF (MX_RING_OFF + 3 * MX_SLOT)     // conv: 8 bytes per thread of rarely used addressing state
+#define MX_LDS (MX_PARK_OFF + 512 * 8)              // 77312 B
 
 struct MxArgs {
     Gemm3Args g;                 // shared fields: A, out, M, Np, ldo, n_blocks, Cw, P_total, n_levels, T, pb, spk, spk_stride, p, lv, enc_stride
     const uint32_t* wq;          // digit planes (snn_mx.h layout)
     int Kc;                      // 128-deep chunks
 };
-
-__device__ __forceinline__ void mx_load16(v4u_t& w, uint32_t voff, const void* sbase) {
-    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "+v"(w) : "v"(voff), "s"(sbase) : "memory");
-}
-__device__ __forceinline__ void mx_load4(uint32_t& w, uint32_t voff, const void* sbase) {
-    asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "+v"(w) : "v"(voff), "s"(sbase) : "memory");
-}
 
 // fp4 (A, scale 1.0) x fp6 e2m3 (B, scale = byte `opsel` of `sc`); the op_sel field is an immediate
 // (the builtin takes 8-dword operands; only 4 (fp4) / 6 (fp6) are read.  They are widened HERE with undefined upper
@@ -212,36 +209,66 @@ __global__ __launch_bounds__(512, 4) void k_gemm_mx(const MxArgs ma) {
     } else {
         a_off = (uint32_t)((size_t)min(xm, M - 1) * Kw * 4);
     }
+    // conv: a_off and a_pitch are needed once per tap row / per pass only; parked in LDS so that they do not hold two
+    // of the 128 registers through the MFMA loop
+    if (CONV) reinterpret_cast<uint2*>(smem + MX_PARK_OFF)[tid] = make_uint2(a_off, (uint32_t)a_pitch);
+    auto park_get = [&]() {
+        uint32_t l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+        return reinterpret_cast<const uint2*>(smem + MX_PARK_OFF)[wave * 64 + l];
+    };
     // fetch stream over the chunk sequence (tap dy, tap dx, 128-channel group): running scalar word offset
     const int cpt = CONV ? args.Cw / 4 : 0;                                 // chunks per tap
     int f_off = CONV ? -args.Cw : 0;
-    uint32_t f_voff = CONV ? a_off - (uint32_t)a_pitch : a_off;
+    uint32_t f_voff = CONV ? a_off - (uint32_t)a_pitch : a_off;            // fc: constant
     uint32_t f_mask = 1u;
     int f_kc = 0, f_cc = 0, f_dx = 0;
-    auto fetch_next = [&](v4u_t& w, uint32_t& sc) {                         // spike words + column scales of the next chunk
-        w = v4u_t{0u, 0u, 0u, 0u};
-        const void* sbase = sgpr_ptr(args.A + f_off);
-        if (!CONV || (a_valid & f_mask)) mx_load16(w, f_voff, sbase);
-        sc = 0u;
+    // The row's 16 bytes and (wave 0) the chunk's column scales go straight into LDS by LDS-DMA (lane L -> base + 16 L /
+    // 4 L: exactly the [row][4 words] / [column] layout); lanes whose tap lies outside the image copy from a 16-byte
+    // zero block behind the packed weights instead.
+    const unsigned char* const zero16 = reinterpret_cast<const unsigned char*>(ma.wq + mx_words(Kc, Np) - 16);
+    const uint32_t* const Sg = ma.wq + mx_x_words(Kc, Np) + mx_y_words(Kc, Np) + nb * MX_BN;
+    auto fetch_next = [&](int par) {                                        // spike words + column scales of the next chunk
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(smem_base + MX_LUT_BYTES + par * MX_AW_BYTES + wave * 1024);
+        if (CONV) {                                                         // branch-free: taps outside the image copy zeros
+            const unsigned long long sp = (unsigned long long)(args.A + f_off) + f_voff;
+            uint32_t lo = (uint32_t)sp, hi = (uint32_t)(sp >> 32);
+            const uint32_t ok = a_valid & f_mask;
+            // the select takes the zero block's address from SGPRs (as a C expression hipcc keeps VGPR copies of the
+            // two halves alive through the whole loop - and spills them)
+            asm volatile("v_cmp_ne_u32 vcc, 0, %2\n\tv_cndmask_b32 %0, %3, %0, vcc\n\tv_cndmask_b32 %1, %4, %1, vcc"
+                         : "+v"(lo), "+v"(hi) : "v"(ok), "s"((uint32_t)(unsigned long long)zero16), "s"((uint32_t)((unsigned long long)zero16 >> 32)) : "vcc");
+            const unsigned long long src = ((unsigned long long)hi << 32) | lo;
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src), "s"(dst) : "memory", "m0");
+        } else {
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(f_voff), "s"(sgpr_ptr(args.A + f_off)), "s"(dst) : "memory", "m0");
+        }
         if (wave == 0) {
-            const uint32_t* S = ma.wq + mx_x_words(Kc, Np) + mx_y_words(Kc, Np) + (size_t)f_kc * Np + nb * MX_BN;
-            mx_load4(sc, (uint32_t)min(lane, Np - nb * MX_BN - 1) * 4u, sgpr_ptr(S));
+            const uint32_t sdst = __builtin_amdgcn_readfirstlane(smem_base + MX_LUT_BYTES + 2 * MX_AW_BYTES + par * MX_SC_BYTES);
+            uint32_t l;                             // lane id, re-derived instead of a register held all loop
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+            const uint32_t sc_voff = min(l, (uint32_t)(Np - nb * MX_BN - 1)) * 4u;
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dword %0, %1" :: "v"(sc_voff), "s"(sgpr_ptr(Sg + (size_t)f_kc * Np)), "s"(sdst) : "memory", "m0");
         }
-        f_off += 4;
-        if (CONV && ++f_cc == cpt) {
-            f_cc = 0;
-            f_mask <<= 1;
-            if (++f_dx == 3) { f_dx = 0; f_off -= 3 * args.Cw; f_voff += (uint32_t)a_pitch; }
+        // (readfirstlane: the counters are wave-uniform; hipcc otherwise carries them in VGPRs behind the divergent
+        //  tap-validity branch above)
+        const auto U = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+        f_off = U(f_off + 4);
+        if (CONV) {
+            f_cc = U(f_cc + 1);
+            if (f_cc == cpt) {
+                f_cc = 0;
+                f_mask = (uint32_t)U((int)(f_mask << 1));
+                f_dx = U(f_dx + 1);
+                if (f_dx == 3) { f_dx = 0; f_off = U(f_off - 3 * args.Cw); f_voff += park_get().y; }
+            }
         }
-        if (++f_kc == Kc) {                                                 // past the end: wrap (staged, never multiplied)
+        f_kc = U(f_kc + 1);
+        if (f_kc == Kc) {                                                   // past the end: wrap (staged, never multiplied)
             f_kc = 0; f_cc = 0; f_dx = 0; f_mask = 1u;
             f_off = CONV ? -args.Cw : 0;
-            f_voff = CONV ? a_off - (uint32_t)a_pitch : a_off;
+            if (CONV) { const uint2 pk = park_get(); f_voff = pk.x - pk.y; }
         }
-    };
-    auto store_a = [&](const v4u_t& w, uint32_t sc, int par) {
-        *reinterpret_cast<v4u_t*>(awb + par * MX_AW_BYTES + xrow * 16) = w;
-        if (wave == 0) *reinterpret_cast<uint32_t*>(scb + par * MX_SC_BYTES + lane * 4) = sc;
     };
 
     // ---- B staging: per micro-step 3 planes x (4 X pieces + 2 Y pieces) of 1 KiB = 18 pieces; every wave issues
@@ -315,24 +342,14 @@ __global__ __launch_bounds__(512, 4) void k_gemm_mx(const MxArgs ma) {
     };
 
     const int n_ms = 2 * Kc;                                                // micro-steps
-    // ---- prologue: spike words + scales of chunks 0 and 1 in LDS; planes of micro-steps 0, 1 staged ----
-    v4u_t w_new;
-    uint32_t s_new;
-    {
-        v4u_t w0;
-        uint32_t c0;
-        fetch_next(w0, c0);
-        fetch_next(w_new, s_new);
-        stage_next(0);
-        stage_next(MX_SLOT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("" : "+v"(w0), "+v"(c0), "+v"(w_new), "+v"(s_new));
-        store_a(w0, c0, 0);
-        store_a(w_new, s_new, 1);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-    }
+    // ---- prologue: spike words + scales of chunks 0 and 1, planes of micro-steps 0 and 1 ----
+    fetch_next(0);
+    fetch_next(1);
+    stage_next(0);
+    stage_next(MX_SLOT);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
     v4i_t af[4];
     MxB bq[RING];
     uint32_t wq4[4], scq[4];                                                // scq[nt]: bytes Eb, Eb-5, Eb-10, Eb-15 of the lane's block
@@ -359,12 +376,10 @@ __global__ __launch_bounds__(512, 4) void k_gemm_mx(const MxArgs ma) {
             for (int g = 0; g < 12; ++g) {
                 const int gp = g + PD;
                 bq[gp % RING] = gp < 12 ? rd_b(o_cur, gp) : rd_b(o_nxt, gp - 12);
-                if (h == 0 && g == 2) fetch_next(w_new, s_new);              // spike words + scales of chunk kc+2 ...
-                if (h == 1 && g == 0) {                                      // ... landed at the last barrier: into the buffer of
-                    asm volatile("" : "+v"(w_new), "+v"(s_new));             // chunk kc, whose fragments were built a chunk ago
-                    store_a(w_new, s_new, par);
-                }
-                if (g == 3) stage_next(o_wr);                                // planes of micro-step +2
+                // spike words + scales of chunk kc+2 into the buffer of chunk kc, whose fragments were built a chunk ago
+                if (h == 0 && g == 2) fetch_next(par);
+                if (g == 5) stage_next(o_wr);                                // planes of micro-step +2 (after the h = 1 word reads:
+                                                                             // a spill reload there would wait for these copies)
                 if (h == 1 && g == 4) {
 #pragma unroll
                     for (int mt = 0; mt < 4; ++mt) wq4[mt] = rd_w(par ^ 1, mt);

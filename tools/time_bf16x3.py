@@ -13,6 +13,7 @@ def tm(fn, n=5):
     return min(a.elapsed_time(b) for a, b in ev)
 # fc6
 R, D, Hd, T = 2000, 12544, 1024, 12
+T6 = T
 x = torch.randn(R, D, device=dev)
 enc = ops.encode_rows(x, T, p)
 w6 = torch.randn(Hd, D, device=dev) / D ** 0.5
@@ -37,3 +38,12 @@ fl = 2.0 * T * P * 9 * 256 * 256
 print('conv bf16x3 gemm %.3f ms (%.1f TF algorithmic, %.1f TF executed)  + lif_scan %.3f ms  [fused f32 kernel: 13.1 ms]' % (t3, fl / t3 / 1e9, 3 * fl / t3 / 1e9, t4))
 t5 = tm(lambda: ops.conv3x3_lif_bf16x3(encs, shapes, 256, 256, p, wb), 3)
 print('conv bf16x3 FUSED conv+LIF %.3f ms   (un-fused pair %.3f ms)' % (t5, t3 + t4))
+# ---- fp4 x fp6 block-scaled path (k_gemm_mx)
+w6m = ops.pack_linear_mx(w6)
+t6 = tm(lambda: ops.spike_gemm_mx(enc.view(T6 * R, -1), D, Hd, w6m))
+fl6 = 2.0 * T6 * R * D * Hd
+print('fc6  mxfp6 %.3f ms (%.1f TF algorithmic)' % (t6, fl6 / t6 / 1e9))
+wm = ops.pack_conv3x3_mx(w)
+t7 = tm(lambda: ops.spike_conv3x3_mx(encs, shapes, 256, 256, wm), 3)
+t8 = tm(lambda: ops.conv3x3_lif_mx(encs, shapes, 256, 256, p, wm), 3)
+print('conv mxfp6 gemm %.3f ms (%.1f TF algorithmic)   FUSED conv+LIF %.3f ms' % (t7, fl / t7 / 1e9, t8))

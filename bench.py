@@ -111,7 +111,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", choices=["bf16x3", "f32"], default="bf16x3")
+    ap.add_argument("--precision", choices=["bf16x3", "f32", "mxfp6"], default="bf16x3")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cityscapes",
                     help="cityscapes = BASELINE.json's headline configuration (default); bdd = config[3] per-rank share "
                          "(720x1280, 4 images per GPU, K=11); stress = config[4] (T=16/24, spike-rate outputs on)")

@@ -58,6 +58,9 @@ typedef struct snn_params {
 } snn_params;
 
 #define SNN_PRECISION_F32 0      /* fp32 matrix cores (v_mfma_f32_32x32x2_f32); 3x3 conv + LIF fused over T */
+#define SNN_PRECISION_MXFP6 2    /* fp4 x fp6 block-scaled matrix path, weights as 6 planes of base-32 digits (snn_pack_*_mx):
+                                    exact for weights within 2^5 of their block maximum, else rounded at 2^-28 of it;
+                                    needs C / D / Hd multiples of 128 (else -4: use SNN_PRECISION_BF16X3) */
 #define SNN_PRECISION_BF16X3 1   /* bf16 matrix cores, exact 3-way bf16 split of the fp32 weights; the conv runs
                                     time-batched (currents through HBM) followed by the LIF scan */
 

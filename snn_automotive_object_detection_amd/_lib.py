@@ -12,7 +12,7 @@ c_stream = C.c_void_p
 
 SNN_MAX_LEVELS = 8
 SNN_MAX_STEPS = 32
-PRECISIONS = {"f32": 0, "bf16x3": 1}
+PRECISIONS = {"f32": 0, "bf16x3": 1, "mxfp6": 2}
 
 
 class snn_params(C.Structure):

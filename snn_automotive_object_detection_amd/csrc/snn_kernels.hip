@@ -2623,8 +2623,10 @@ int snn_rpn_head_forward_stages(const snn_rpn_level* lv, int n_levels, int C, in
         return fail(-1, "snn_rpn_head_forward: null argument");
     if (n_levels <= 0 || n_levels > SNN_MAX_LEVELS) return fail(-1, "snn_rpn_head_forward: n_levels=%d", n_levels);
     if (C <= 0 || A <= 0) return fail(-1, "snn_rpn_head_forward: bad C/A");
-    if (p->precision != SNN_PRECISION_F32 && p->precision != SNN_PRECISION_BF16X3)
+    if (p->precision != SNN_PRECISION_F32 && p->precision != SNN_PRECISION_BF16X3 && p->precision != SNN_PRECISION_MXFP6)
         return fail(-1, "snn_rpn_head_forward: unknown precision %d", p->precision);
+    if (p->precision == SNN_PRECISION_MXFP6 && (C % 128 || !mx_tile_ok(T)))
+        return fail(-4, "snn_rpn_head_forward: the mxfp6 kernels need C %% 128 == 0 and a T that fits a 512-row tile (C=%d, T=%d)", C, T);
     if (check_T(T, "snn_rpn_head_forward")) return -1;
     for (int l = 0; l < n_levels; ++l)
         if (!lv[l].feat || lv[l].N <= 0 || lv[l].H <= 0 || lv[l].W <= 0)
@@ -2672,8 +2674,10 @@ int snn_rpn_head_forward_stages(const snn_rpn_level* lv, int n_levels, int C, in
             // conv + LIF fused over T on the bf16 matrix cores (rpn.py:98-106): membrane state in registers, only
             // spike planes written (4.5 ms against 4.2 + 0.5 ms for snn_spike_conv3x3_bf16x3 + snn_lif_scan, which
             // give bit-identical planes)
-            int rc = snn_conv3x3_lif_bf16x3(enc, stride, lv, n_levels, C, C, T, p, (const uint16_t*)w_shared_packed,
-                                            spk, stride, stream);
+            int rc = p->precision == SNN_PRECISION_MXFP6
+                         ? snn_conv3x3_lif_mx(enc, stride, lv, n_levels, C, C, T, p, (const uint32_t*)w_shared_packed, spk, stride, stream)
+                         : snn_conv3x3_lif_bf16x3(enc, stride, lv, n_levels, C, C, T, p, (const uint16_t*)w_shared_packed,
+                                                  spk, stride, stream);
             if (rc) return rc;
             if (spike_counts) {
                 if (hipMemsetAsync(spike_counts, 0, sizeof(unsigned long long) * n_levels * max_n, s) != hipSuccess)
@@ -2900,8 +2904,24 @@ static int det_head_from_planes(int R, int D, int Hd, int K, int K4, int T, cons
     int rc;
     if (spk6_count) { if (hipMemsetAsync(spk6_count, 0, sizeof(uint32_t) * R, s) != hipSuccess) return fail(-3, "hipMemsetAsync failed"); }
     if (spk7_count) { if (hipMemsetAsync(spk7_count, 0, sizeof(uint32_t) * R, s) != hipSuccess) return fail(-3, "hipMemsetAsync failed"); }
-    const bool b3 = p->precision == SNN_PRECISION_BF16X3;
-    if (p->precision != SNN_PRECISION_F32 && !b3) return fail(-1, "snn_det_head_forward: unknown precision %d", p->precision);
+    const bool b3 = p->precision == SNN_PRECISION_BF16X3, mx = p->precision == SNN_PRECISION_MXFP6;
+    if (p->precision != SNN_PRECISION_F32 && !b3 && !mx) return fail(-1, "snn_det_head_forward: unknown precision %d", p->precision);
+    if (mx) {
+        if (D % 128 || Hd % 128 || !mx_tile_ok(T))
+            return fail(-4, "snn_det_head_forward: the mxfp6 kernels need D, Hd %% 128 == 0 and a T that fits a 512-row tile");
+        if ((rc = snn_spike_gemm_lif_mx(enc, T, R, D, Hd, p, (const uint32_t*)w6_packed, s6, (size_t)R * Hw, stream))) return rc;
+        if ((rc = snn_spike_gemm_lif_mx(s6, T, R, Hd, Hd, p, (const uint32_t*)w7_packed, s7, (size_t)R * Hw, stream))) return rc;
+        if (spk6_count) {
+            hipLaunchKernelGGL(k_count_rows, dim3(cdiv(R, 4)), dim3(256), 0, s, s6, (unsigned long long)R * Hw, T, R, Hw, spk6_count);
+            SNN_CHECK_LAUNCH("k_count_rows");
+        }
+        if (spk7_count) {
+            hipLaunchKernelGGL(k_count_rows, dim3(cdiv(R, 4)), dim3(256), 0, s, s7, (unsigned long long)R * Hw, T, R, Hw, spk7_count);
+            SNN_CHECK_LAUNCH("k_count_rows");
+        }
+        return snn_li_heads(s7, (size_t)R * Hw, T, R, Hd, w_heads_packed, K, K4, p, out_cls, out_bbox, sum_cls,
+                            sum_bbox, stream);
+    }
     if (b3 && (g3_tile_ok(T, G3_BM(g3_wn(), 4)) || g3_tile_ok(T, G3_BM(g3_wn(), 3)) || g3_tile_ok(T, G3_BM(g3_wn(), 2)))) {
         // fc6 + LIF and fc7 + LIF, each one launch: a row tile holds all T steps of its RoIs, the currents never
         // leave the chip (faster_rcnn.py:498-501)

@@ -236,8 +236,10 @@ __global__ __launch_bounds__(512, 4) void k_gemm_mx(const MxArgs ma) {
             const uint32_t ok = a_valid & f_mask;
             // the select takes the zero block's address from SGPRs (as a C expression hipcc keeps VGPR copies of the
             // two halves alive through the whole loop - and spills them)
-            asm volatile("v_cmp_ne_u32 vcc, 0, %2\n\tv_cndmask_b32 %0, %3, %0, vcc\n\tv_cndmask_b32 %1, %4, %1, vcc"
-                         : "+v"(lo), "+v"(hi) : "v"(ok), "s"((uint32_t)(unsigned long long)zero16), "s"((uint32_t)((unsigned long long)zero16 >> 32)) : "vcc");
+            uint32_t tmp;
+            asm volatile("v_cmp_ne_u32 vcc, 0, %3\n\tv_mov_b32 %2, %4\n\tv_cndmask_b32 %0, %2, %0, vcc\n\t"
+                         "v_mov_b32 %2, %5\n\tv_cndmask_b32 %1, %2, %1, vcc"
+                         : "+v"(lo), "+v"(hi), "=&v"(tmp) : "v"(ok), "s"((uint32_t)(unsigned long long)zero16), "s"((uint32_t)((unsigned long long)zero16 >> 32)) : "vcc");
             const unsigned long long src = ((unsigned long long)hi << 32) | lo;
             asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src), "s"(dst) : "memory", "m0");
         } else {
@@ -323,8 +325,15 @@ __global__ __launch_bounds__(512, 4) void k_gemm_mx(const MxArgs ma) {
         for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // fragment readers
-    const unsigned char* const w_rd = awb + (wave * 64 + lr) * 16 + lg * 4;           // + parity, mt * 256
-    auto rd_w = [&](int par, int mt) { return *reinterpret_cast<const uint32_t*>(w_rd + par * MX_AW_BYTES + mt * 256); };
+    // word (row wave*64 + mt*16 + lr, k-group lg) of a chunk; the lane part of the address is re-derived at each use
+    // (once per chunk) instead of holding a register through the loop
+    auto rd_w4 = [&](int par, uint32_t (&w)[4]) {
+        uint32_t l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+        const unsigned char* base = awb + par * MX_AW_BYTES + wave * 1024 + (l & 15u) * 16 + (l >> 4) * 4;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) w[mt] = *reinterpret_cast<const uint32_t*>(base + mt * 256);
+    };
     auto rd_a = [&](uint32_t w) {                                                    // 32 spike bits -> 32 fp4
         v4i_t a = {0, 0, 0, 0};
 #pragma unroll
@@ -360,8 +369,9 @@ __global__ __launch_bounds__(512, 4) void k_gemm_mx(const MxArgs ma) {
             scq[nt] = __builtin_amdgcn_ubfe(dw, 8 * lg, 8) * 0x01010101u - 0x0F0A0500u;     // Eb >= 32: no borrow
         }
     };
+    rd_w4(0, wq4);
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) af[mt] = rd_a(rd_w(0, mt));
+    for (int mt = 0; mt < 4; ++mt) af[mt] = rd_a(wq4[mt]);
     load_scales(0);
 #pragma unroll
     for (int g = 0; g < PD; ++g) bq[g] = rd_b(0, g);
@@ -378,11 +388,9 @@ __global__ __launch_bounds__(512, 4) void k_gemm_mx(const MxArgs ma) {
                 bq[gp % RING] = gp < 12 ? rd_b(o_cur, gp) : rd_b(o_nxt, gp - 12);
                 // spike words + scales of chunk kc+2 into the buffer of chunk kc, whose fragments were built a chunk ago
                 if (h == 0 && g == 2) fetch_next(par);
-                if (g == 5) stage_next(o_wr);                                // planes of micro-step +2 (after the h = 1 word reads:
-                                                                             // a spill reload there would wait for these copies)
+                if (g == 3) stage_next(o_wr);                                // planes of micro-step +2
                 if (h == 1 && g == 4) {
-#pragma unroll
-                    for (int mt = 0; mt < 4; ++mt) wq4[mt] = rd_w(par ^ 1, mt);
+                    rd_w4(par ^ 1, wq4);
                 }
                 const int nt = g / 3, pl = 5 - 3 * h - g % 3;
 #pragma unroll

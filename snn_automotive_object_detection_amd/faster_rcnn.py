@@ -34,23 +34,29 @@ class FastRCNNPredictorSNNFull(nn.Module):
         self.p_lif = ops.LIFParameters(alpha=100, v_th=torch.tensor(0.1))   # :449,452
         self.li_order = "jump_first"
         self.spike_rates = False
-        self.precision = "bf16x3"          # or "f32" (fp32 matrix cores); see RPNHeadSNN
+        self.precision = "bf16x3"          # or "f32" (fp32 matrix cores) / "mxfp6" (fp4 x fp6 digit planes); see RPNHeadSNN
         self.fc6 = nn.Linear(in_channels, representation_size, bias=False)          # :448
         self.fc7 = nn.Linear(representation_size, representation_size, bias=False)  # :451
         self.cls_score = nn.Linear(representation_size, num_classes, bias=False)    # :455
         self.only_one_bbox = only_one_bbox                                           # :460-467
         self.bbox_pred = nn.Linear(representation_size, 4 if only_one_bbox else num_classes * 4, bias=False)
-        self._c6 = {"f32": _WeightCache(), "bf16x3": _WeightCache()}
-        self._c7 = {"f32": _WeightCache(), "bf16x3": _WeightCache()}
+        self._c6 = {"f32": _WeightCache(), "bf16x3": _WeightCache(), "mxfp6": _WeightCache()}
+        self._c7 = {"f32": _WeightCache(), "bf16x3": _WeightCache(), "mxfp6": _WeightCache()}
         self._ch = _WeightCache()
 
+    def _eff_precision(self) -> str:
+        if self.precision == "mxfp6" and (self.in_channels % 128 or self.representation_size % 128):
+            return "bf16x3"
+        return self.precision
+
     def _params(self):
-        return ops.make_params(self.p_enc, self.p_lif, self.dt, self.li_order, self.precision)
+        return ops.make_params(self.p_enc, self.p_lif, self.dt, self.li_order, self._eff_precision())
 
     def _packed(self):
-        pack = ops.pack_linear if self.precision == "f32" else ops.pack_linear_bf16x3
-        w6 = self._c6[self.precision].get((self.fc6.weight,), pack)
-        w7 = self._c7[self.precision].get((self.fc7.weight,), pack)
+        prec = self._eff_precision()
+        pack = {"f32": ops.pack_linear, "bf16x3": ops.pack_linear_bf16x3, "mxfp6": ops.pack_linear_mx}[prec]
+        w6 = self._c6[prec].get((self.fc6.weight,), pack)
+        w7 = self._c7[prec].get((self.fc7.weight,), pack)
         wh = self._ch.get((self.cls_score.weight, self.bbox_pred.weight), ops.pack_heads)
         return w6, w7, wh
 

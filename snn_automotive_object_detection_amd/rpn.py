@@ -50,8 +50,11 @@ class RPNHeadSNN(nn.Module):
         self.num_anchors = num_anchors
         self.li_order = "jump_first"      # Norse LI update order
         self.spike_rates = False          # True: forward returns the rpn.py:126-200 third value too
-        # "bf16x3": bf16 matrix cores with an exact 3-way split of the fp32 weights (default, ~3x faster);
+        # "bf16x3": bf16 matrix cores with an exact 3-way split of the fp32 weights (default);
         # "f32": fp32 matrix cores with the conv + LIF fused over T.  Both give fp32-exact contractions.
+        # "mxfp6": fp4 x fp6 block-scaled matrix path, weights as 6 planes of base-32 digits (exact within 2^5 of the
+        #          block maximum, else rounded at 2^-28 of it; ~1.4x faster); needs in_channels % 128 == 0, otherwise
+        #          the bf16x3 kernels run.
         self.precision = "bf16x3"
         # parameters: identical modules so that state_dict keys/shapes match the reference
         self.shared_conv = nn.Conv2d(in_channels, in_channels, kernel_size=(3, 3), stride=(1, 1),
@@ -61,15 +64,21 @@ class RPNHeadSNN(nn.Module):
         for layer in self.modules():                                  # rpn.py:78-82
             if isinstance(layer, nn.Conv2d):
                 torch.nn.init.normal_(layer.weight, std=0.01)
-        self._cache_shared = {"f32": _WeightCache(), "bf16x3": _WeightCache()}
+        self._cache_shared = {"f32": _WeightCache(), "bf16x3": _WeightCache(), "mxfp6": _WeightCache()}
         self._cache_heads = _WeightCache()
 
+    def _eff_precision(self) -> str:
+        if self.precision == "mxfp6" and self.in_channels % 128:
+            return "bf16x3"
+        return self.precision
+
     def _params(self):
-        return ops.make_params(self.p_enc, self.p_lif, self.dt, self.li_order, self.precision)
+        return ops.make_params(self.p_enc, self.p_lif, self.dt, self.li_order, self._eff_precision())
 
     def _packed_shared(self):
-        pack = ops.pack_conv3x3 if self.precision == "f32" else ops.pack_conv3x3_bf16x3
-        return self._cache_shared[self.precision].get((self.shared_conv.weight,), pack)
+        prec = self._eff_precision()
+        pack = {"f32": ops.pack_conv3x3, "bf16x3": ops.pack_conv3x3_bf16x3, "mxfp6": ops.pack_conv3x3_mx}[prec]
+        return self._cache_shared[prec].get((self.shared_conv.weight,), pack)
 
     @torch.no_grad()
     def forward(self, x: List[Tensor]) -> Tuple[List[Tensor], List[Tensor]]:

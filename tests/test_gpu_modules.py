@@ -22,7 +22,7 @@ def pkg():
     return pkg
 
 
-PRECISIONS = ["bf16x3", "f32"]
+PRECISIONS = ["bf16x3", "f32", "mxfp6"]     # mxfp6 falls back to bf16x3 where C % 128 != 0
 
 
 def _rpn_module(pkg, spec, dev, feats_w, precision="bf16x3"):

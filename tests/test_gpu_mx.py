@@ -62,7 +62,7 @@ def test_pack_linear_mx_definition(gpu_device):
     w[11, :32] = torch.tensor([2.0 ** (-i) for i in range(32)])            # 31 binades in one block
     packed = ops.pack_linear_mx(w.to(gpu_device)).cpu().numpy().view(np.uint32)
     Kc, Np = 3, 96
-    assert packed.size == P * Kc * Np * 24 + Kc * Np
+    assert packed.size == P * Kc * Np * 24 + Kc * Np + 16 and (packed[-16:] == 0).all()
     digits, Eb = _decode(packed, Kc, Np)
     ref = np.zeros((Np, Kc * 128), dtype=np.float64)
     ref[:N, :K] = w.numpy().astype(np.float64)

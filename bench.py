@@ -36,6 +36,7 @@ T_RPN, T_DET = 8, 12
 BATCH, ROIS_PER_IMG = 2, 1000
 PEAK_F32_MFMA_TFLOPS = 157.3                                     # MI355X_MICROARCH.md chip table
 PEAK_BF16_MFMA_TFLOPS = 2500.0                                   # dense bf16 (no sparsity)
+PEAK_MX_MFMA_TFLOPS = 10000.0                                    # dense fp6 / fp4 block-scaled (spec, no sparsity)
 
 
 WORKLOADS = {
@@ -111,6 +112,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt", action="store_true", help="skip the extra timing leg with the other precision")
     ap.add_argument("--precision", choices=["bf16x3", "f32", "mxfp6"], default="bf16x3")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cityscapes",
                     help="cityscapes = BASELINE.json's headline configuration (default); bdd = config[3] per-rank share "
@@ -168,6 +170,24 @@ def main():
     ms = dt / args.steps * 1e3
     value = world * BATCH * args.steps / dt
 
+    # ---- the same K steps with the other matrix path of the two big contractions (outside the headline number):
+    # "mxfp6" = fp4 x fp6 block-scaled MFMA on 6 digit planes per weight (passes the same parity tests)
+    alt = None
+    if not args.no_alt and world == 1:
+        alt_prec = "bf16x3" if args.precision == "mxfp6" else "mxfp6"
+        rpn_head.precision = det_head.precision = alt_prec
+        for _ in range(max(1, args.warmup)):
+            step()
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        dt_alt = time.perf_counter() - t1
+        alt = {"precision": alt_prec, "value": round(BATCH * args.steps / dt_alt, 3), "unit": "images/s",
+               "ms_per_step": round(dt_alt / args.steps * 1e3, 4)}
+        rpn_head.precision = det_head.precision = args.precision
+
     # ---- per-kernel timing with HIP events on the launch stream (outside the timed region) ----
     def time_ms(fn, iters):
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
@@ -189,6 +209,11 @@ def main():
     if args.precision == "f32":
         kernel, peak, exec_factor, kernel_ms = "k_conv3x3_lif<false>", PEAK_F32_MFMA_TFLOPS, 1.0, conv_ms
         traffic_key = "f32"
+    elif args.precision == "mxfp6":
+        # stage 2 = k_gemm_mx<3> (G3_CONV_LIF_TILE): fp4 x fp6 block-scaled MFMA, 6 digit planes per weight at 4x the K per
+        # instruction: executed work = 6/4 of the bf16-equivalent; peak = 10 PF dense fp6/fp4 (spec)
+        kernel, peak, exec_factor, kernel_ms = "k_gemm_mx<3>", PEAK_MX_MFMA_TFLOPS, 6.0, conv_ms
+        traffic_key = "mxfp6"
     else:
         # stage 2 = k_gemm_bf16x3<3, 3, 4, 2> (MODE = G3_CONV_LIF_TILE, 3-slot ring, 4 M-tiles per wave, 4 x 2 wave grid): 3x3 conv + LIF over T fused in the tile,
         # on the bf16 matrix cores
@@ -207,7 +232,8 @@ def main():
             T_RPN, T_DET, "720x1280" if args.workload == "bdd" else "1024x2048", BATCH),
         "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "f32 (weights as exact bf16x3 split, fp32 accumulate)",
+        "vs_baseline": None, "dtype": {"f32": "f32", "bf16x3": "f32 (weights as exact bf16x3 split, fp32 accumulate)",
+                                        "mxfp6": "f32 (weights as 6 fp6 digit planes with block scales, fp32 accumulate)"}[args.precision],
         "data": "synthetic",
         "config": {"precision": args.precision,
                    "workload": "%s: RPNHeadSNN(T=%d) on 5-level pyramid %dx256x{%dx%d..%dx%d} + FastRCNNPredictorSNNFull(T=%d) on "
@@ -228,6 +254,7 @@ def main():
         "breakdown_ms": {"rpn_head": round(rpn_ms, 3), "rpn_encode": round(enc_ms, 3), "rpn_conv3x3_lif": round(conv_ms, 3),
                          "det_head": round(det_ms, 3)},
         "heads_tflops": round((rpn_fl + det_fl) / ((rpn_ms + det_ms) * 1e-3) / 1e12, 2),
+        "alt_precision": alt,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()

@@ -241,7 +241,9 @@ size_t snn_packed_conv3x3_mx_words(int C_out, int C_in);
 int snn_pack_linear_weight_mx(const float* w_nk, int N, int K, uint32_t* packed, snn_stream_t s);
 int snn_pack_conv3x3_weight_mx(const float* w_oihw, int C_out, int C_in, uint32_t* packed, snn_stream_t s);
 /* the spike GEMMs on the fp4 x fp6 block-scaled matrix path (k_gemm_mx); K / C_in must be a multiple of 128 (-4 else),
- * same operands and results as the _bf16x3 entry points */
+ * same operands and results as the _bf16x3 entry points - except that the two conv entry points read encoder planes
+ * with a one-position ZERO HALO around every image (row (n, y, x) of an H x W level at (n (H+2) + y+1) (W+2) + x+1,
+ * levels back to back, enc_stride >= sum N (H+2) (W+2) C_in/32 words): 3x3 taps then need no border logic */
 int snn_spike_gemm_mx(const uint32_t* a_rows, int M, int K, int N, const uint32_t* w_packed, float* cur, int ldo,
                       snn_stream_t stream);
 int snn_spike_gemm_lif_mx(const uint32_t* a_planes, int T, int R, int K, int N, const snn_params* p,

@@ -105,9 +105,13 @@ __global__ void k_pack_heads(const float* __restrict__ wa, int NA, const float* 
 // VALU-bound (32 x T encoder steps per thread): packed fp32 arithmetic, see enc_step2_word.
 // ------------------------------------------------------------------------------------------------
 #define ENC_PB 32                                   // positions per block
+// Wpad > 0: the planes carry a one-position zero halo around every image (row (n, y, x) -> (n*(H+2) + y+1)*(W+2) + x+1,
+// W = Wpad); the halo itself is zeroed by the caller.  The fp4 x fp6 conv kernel reads its 3x3 taps from such planes
+// without any border logic.
 template <bool ZR>
 __device__ __forceinline__ void encode_block(const float* __restrict__ feat, int C, int HW, int Cw, int T, const NeuronP& p,
-                                             uint32_t* __restrict__ planes, size_t plane_stride, int n, int bx, int by) {
+                                             uint32_t* __restrict__ planes, size_t plane_stride, int n, int bx, int by,
+                                             int Wpad = 0) {
     __shared__ uint32_t wbuf[SNN_MAX_STEPS * ENC_PB * 9];      // [t][position][8 words + 1 pad]
     const int pl = threadIdx.x & 31, cgl = threadIdx.x >> 5;
     const int pos = bx * ENC_PB + pl;
@@ -130,7 +134,12 @@ __device__ __forceinline__ void encode_block(const float* __restrict__ feat, int
     const int sp = threadIdx.x >> 3, sw = threadIdx.x & 7;
     const int spos = bx * ENC_PB + sp, scg = by * 8 + sw;
     if (spos < HW && scg < Cw) {
-        uint32_t* out = planes + ((size_t)n * HW + spos) * Cw + scg;
+        size_t row = (size_t)n * HW + spos;
+        if (Wpad) {
+            const int H = HW / Wpad, y = spos / Wpad, x = spos % Wpad;
+            row = ((size_t)n * (H + 2) + y + 1) * (Wpad + 2) + x + 1;
+        }
+        uint32_t* out = planes + row * Cw + scg;
         for (int t = 0; t < T; ++t) out[(size_t)t * plane_stride] = wbuf[(t * ENC_PB + sp) * 9 + sw];
     }
 }
@@ -148,6 +157,7 @@ struct EncLevels {
     int HW[SNN_MAX_LEVELS], bpi[SNN_MAX_LEVELS];   // positions / blocks per image
     int blk_base[SNN_MAX_LEVELS + 1];               // first block of the level
     int pos_base[SNN_MAX_LEVELS];                   // first plane row of the level
+    int Wpad[SNN_MAX_LEVELS];                       // 0, or the level's width when the planes carry a zero halo
     int n_levels;
 };
 template <bool ZR>
@@ -157,7 +167,7 @@ __global__ __launch_bounds__(256) void k_encode_levels(const EncLevels lv, int C
     while (l + 1 < lv.n_levels && (int)blockIdx.x >= lv.blk_base[l + 1]) ++l;
     const int local = blockIdx.x - lv.blk_base[l];
     encode_block<ZR>(lv.feat[l], C, lv.HW[l], Cw, T, p, planes + (size_t)lv.pos_base[l] * Cw, plane_stride,
-                     local / lv.bpi[l], local % lv.bpi[l], blockIdx.y);
+                     local / lv.bpi[l], local % lv.bpi[l], blockIdx.y, lv.Wpad[l]);
 }
 
 // K1b: encoder on row-major x[R][D] -> bit-planes [T][R][Dw]; a wave covers 64 consecutive reduction indices per
@@ -2268,14 +2278,17 @@ static int conv_mx_common(const char* who, const uint32_t* enc, size_t enc_strid
     if (C_in % 128) return fail(-4, "%s: C_in=%d is not a multiple of 128 (use the bf16x3 kernels)", who, C_in);
     if (check_T(T, who)) return -1;
     memset(&a, 0, sizeof(a));
-    long long P = 0;
+    long long P = 0, Pp = 0;
     for (int l = 0; l < n_levels; ++l) {
         if (lv[l].N <= 0 || lv[l].H <= 0 || lv[l].W <= 0) return fail(-1, "%s: bad level %d", who, l);
         a.g.lv[l].pos_base = (int)P; a.g.lv[l].N = lv[l].N; a.g.lv[l].H = lv[l].H; a.g.lv[l].W = lv[l].W;
+        a.g.lv[l].tile_begin = (int)Pp;                // first row of the level in the padded (zero-halo) encoder planes
         P += (long long)lv[l].N * lv[l].H * lv[l].W;
+        Pp += (long long)lv[l].N * (lv[l].H + 2) * (lv[l].W + 2);
     }
     if ((long long)T * P > 0x7fffffffLL) return fail(-1, "%s: T*P too large", who);
-    if (((long long)(T - 1) * (long long)enc_stride + P * (C_in / 32)) * 4 > 0xffffffffLL) return fail(-1, "%s: encoder planes over 4 GB", who);
+    if (enc_stride < (size_t)Pp * (C_in / 32)) return fail(-1, "%s: enc_stride %zu < %lld words (planes with a one-position zero halo)", who, enc_stride, Pp * (C_in / 32));
+    if (((long long)(T - 1) * (long long)enc_stride + Pp * (C_in / 32)) * 4 > 0xffffffffLL) return fail(-1, "%s: encoder planes over 4 GB", who);
     a.g.A = enc; a.g.enc_stride = enc_stride; a.g.Cw = C_in / 32; a.g.Np = cdiv(C_out, 32) * 32;
     a.g.P_total = (int)P; a.g.n_levels = n_levels;
     a.wq = w_packed; a.Kc = 9 * C_in / 128;
@@ -2595,9 +2608,16 @@ static long long rpn_positions(const snn_rpn_level* lv, int n_levels, int* max_n
     return P;
 }
 
-static void rpn_ws_layout(long long P, int C, int T, int precision, size_t* o_spk, size_t* o_cur, size_t* o_cnt,
+static long long rpn_positions_padded(const snn_rpn_level* lv, int n_levels) {
+    long long P = 0;
+    for (int l = 0; l < n_levels; ++l) P += (long long)lv[l].N * (lv[l].H + 2) * (lv[l].W + 2);
+    return P;
+}
+
+// Pe = rows of an encoder plane (positions; with the zero halo for the mxfp6 path)
+static void rpn_ws_layout(long long P, long long Pe, int C, int T, int precision, size_t* o_spk, size_t* o_cur, size_t* o_cnt,
                           size_t* total) {
-    const size_t plane = align_up((size_t)T * P * cdiv(C, 32) * 4, 256);
+    const size_t plane = align_up((size_t)T * (Pe > P ? Pe : P) * cdiv(C, 32) * 4, 256);
     *o_spk = plane;
     *o_cur = 2 * plane;
     const size_t cur = 0;     // (only the un-fused snn_spike_conv3x3_bf16x3 + snn_lif_scan pair needs currents)
@@ -2611,7 +2631,8 @@ size_t snn_rpn_head_workspace_bytes(const snn_rpn_level* lv, int n_levels, int C
     (void)A;
     if (!lv || n_levels <= 0 || n_levels > SNN_MAX_LEVELS || C <= 0 || T < 1) return 0;
     size_t a, b, c, tot;
-    rpn_ws_layout(rpn_positions(lv, n_levels, nullptr), C, T, precision, &a, &b, &c, &tot);
+    rpn_ws_layout(rpn_positions(lv, n_levels, nullptr), precision == SNN_PRECISION_MXFP6 ? rpn_positions_padded(lv, n_levels) : 0,
+                  C, T, precision, &a, &b, &c, &tot);
     return tot;
 }
 
@@ -2634,10 +2655,13 @@ int snn_rpn_head_forward_stages(const snn_rpn_level* lv, int n_levels, int C, in
     int max_n = 0;
     const long long P = rpn_positions(lv, n_levels, &max_n);
     size_t o_spk, o_cur, o_cnt, need;
-    rpn_ws_layout(P, C, T, p->precision, &o_spk, &o_cur, &o_cnt, &need);
+    const bool mxp = p->precision == SNN_PRECISION_MXFP6;          // encoder planes with a zero halo (k_gemm_mx)
+    const long long Pe = mxp ? rpn_positions_padded(lv, n_levels) : P;
+    rpn_ws_layout(P, mxp ? Pe : 0, C, T, p->precision, &o_spk, &o_cur, &o_cnt, &need);
     if (ws_bytes < need) return fail(-2, "snn_rpn_head_forward: workspace %zu < %zu bytes", ws_bytes, need);
     const int Cw = cdiv(C, 32);
-    const size_t stride = (size_t)P * Cw;            // words per time plane
+    const size_t stride = (size_t)P * Cw;            // words per time plane (spike planes)
+    const size_t enc_stride = (size_t)Pe * Cw;       // ... of the encoder planes
     uint32_t* enc = (uint32_t*)ws;
     uint32_t* spk = (uint32_t*)((char*)ws + o_spk);
     hipStream_t s = (hipStream_t)stream;
@@ -2646,19 +2670,20 @@ int snn_rpn_head_forward_stages(const snn_rpn_level* lv, int n_levels, int C, in
         memset(&el, 0, sizeof(el));
         long long pos = 0;
         int blocks = 0;
+        if (mxp && hipMemsetAsync(enc, 0, (size_t)T * enc_stride * 4, s) != hipSuccess) return fail(-3, "hipMemsetAsync failed");
         for (int l = 0; l < n_levels; ++l) {
             if (!lv[l].feat) return fail(-1, "snn_rpn_head_forward: level %d has no features", l);
             el.feat[l] = lv[l].feat; el.HW[l] = lv[l].H * lv[l].W; el.bpi[l] = cdiv(el.HW[l], ENC_PB);
-            el.blk_base[l] = blocks; el.pos_base[l] = (int)pos;
+            el.blk_base[l] = blocks; el.pos_base[l] = (int)pos; el.Wpad[l] = mxp ? lv[l].W : 0;
             blocks += lv[l].N * el.bpi[l];
-            pos += (long long)lv[l].N * el.HW[l];
+            pos += mxp ? (long long)lv[l].N * (lv[l].H + 2) * (lv[l].W + 2) : (long long)lv[l].N * el.HW[l];
         }
         el.blk_base[n_levels] = blocks; el.n_levels = n_levels;
         const NeuronP np = make_p(p, p->v_th_enc);
         if (enc_zero_rest(np))
-            hipLaunchKernelGGL(k_encode_levels<true>, dim3(blocks, cdiv(Cw, 8)), dim3(256), 0, s, el, C, Cw, T, np, enc, (size_t)stride);
+            hipLaunchKernelGGL(k_encode_levels<true>, dim3(blocks, cdiv(Cw, 8)), dim3(256), 0, s, el, C, Cw, T, np, enc, enc_stride);
         else
-            hipLaunchKernelGGL(k_encode_levels<false>, dim3(blocks, cdiv(Cw, 8)), dim3(256), 0, s, el, C, Cw, T, np, enc, (size_t)stride);
+            hipLaunchKernelGGL(k_encode_levels<false>, dim3(blocks, cdiv(Cw, 8)), dim3(256), 0, s, el, C, Cw, T, np, enc, enc_stride);
         SNN_CHECK_LAUNCH("k_encode_levels");
     }
     if (stage_mask & SNN_STAGE_CONV_LIF) {
@@ -2675,7 +2700,7 @@ int snn_rpn_head_forward_stages(const snn_rpn_level* lv, int n_levels, int C, in
             // spike planes written (4.5 ms against 4.2 + 0.5 ms for snn_spike_conv3x3_bf16x3 + snn_lif_scan, which
             // give bit-identical planes)
             int rc = p->precision == SNN_PRECISION_MXFP6
-                         ? snn_conv3x3_lif_mx(enc, stride, lv, n_levels, C, C, T, p, (const uint32_t*)w_shared_packed, spk, stride, stream)
+                         ? snn_conv3x3_lif_mx(enc, enc_stride, lv, n_levels, C, C, T, p, (const uint32_t*)w_shared_packed, spk, stride, stream)
                          : snn_conv3x3_lif_bf16x3(enc, stride, lv, n_levels, C, C, T, p, (const uint16_t*)w_shared_packed,
                                                   spk, stride, stream);
             if (rc) return rc;

@@ -26,7 +26,7 @@ __device__ __forceinline__ uint32_t mx_fp6_code(int d) {
 __host__ __device__ inline size_t mx_x_words(int Kc, int Np) { return (size_t)MX_P * Kc * Np * 16; }
 __host__ __device__ inline size_t mx_y_words(int Kc, int Np) { return (size_t)MX_P * Kc * Np * 8; }
 __host__ __device__ inline size_t mx_s_words(int Kc, int Np) { return (size_t)Kc * Np; }
-// + 16 zero words: where the spike-word copies of rows outside the image read from
+// + 16 spare zero words
 __host__ __device__ inline size_t mx_words(int Kc, int Np) { return mx_x_words(Kc, Np) + mx_y_words(Kc, Np) + mx_s_words(Kc, Np) + 16; }
 
 __global__ void k_pack_mx(const float* __restrict__ src, uint32_t* __restrict__ dst, int mode, int K, int N, int Kc, int Np,
@@ -107,7 +107,8 @@ __global__ void k_pack_mx(const float* __restrict__ src, uint32_t* __restrict__ 
 // Work-group = 8 waves x 1 = 512 rows x 64 columns, wave = 64 x 64 = 4 x 4 tiles of v_mfma_scale_f32_16x16x128_f8f6f4.
 // A 128-deep chunk (4 spike words per row) is multiplied in two micro-steps of 3 digit planes each (least significant
 // planes first): 12 groups (plane, N-tile) of 4 MFMAs per micro-step - the cadence of k_gemm_bf16x3.
-//   A: the row's 4 spike words are copied global -> LDS by LDS-DMA (16 B per row, no registers) as raw words, and a
+//   A: the row's 4 spike words are copied global -> LDS by LDS-DMA (16 B per row, no registers) as raw words (conv: the
+//      encoder planes carry a one-position zero halo, so a 3x3 tap is a plain offset with no border logic), and a
 //      lane's fragment (32 fp4 = one spike word) is 4 reads of a byte -> 8-nibble table; built once per
 //      chunk, used by all 6 planes.
 //   B: per micro-step 3 planes x (64 rows x 64 B + 64 rows x 32 B) = 18 KB by LDS-DMA into a 3-slot ring, two
@@ -185,24 +186,24 @@ __global__ __launch_bounds__(512, 4) void k_gemm_mx(const MxArgs ma) {
     const int xm = TILE ? (xt < args.T ? m0 + xrow % args.pb : M) : m0 + xrow;
     uint32_t a_off = 0;
     int a_pitch = 0;
-    uint32_t a_valid = 0;
     const int Kw = CONV ? args.Cw : Kc * 4;                                 // spike words per row (fc: K / 32)
     if (CONV) {
+        // the encoder planes carry a one-position zero halo around every image: every tap of every position is a plain
+        // read (rows past M read the first halo row: zeros)
         if (xm < M) {
             const int t = TILE ? xt : xm / args.P_total, p = TILE ? xm : xm % args.P_total;
             int l = 0;
             while (l + 1 < args.n_levels && p >= args.lv[l + 1].pos_base) ++l;
             const int H = args.lv[l].H, W = args.lv[l].W;
             const int local = p - args.lv[l].pos_base;
-            const int rem = local % (H * W);
+            const int n = local / (H * W), rem = local % (H * W);
             const int y = rem / W, x = rem % W;
-            a_off = (uint32_t)(((size_t)t * args.enc_stride + (size_t)p * args.Cw) * 4);
-            a_pitch = W * args.Cw * 4;
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
-                a_valid |= (uint32_t)(yy >= 0 && yy < H && xx >= 0 && xx < W) << tap;
-            }
+            const size_t prow = (size_t)args.lv[l].tile_begin + ((size_t)n * (H + 2) + y + 1) * (W + 2) + x + 1;
+            a_off = (uint32_t)(((size_t)t * args.enc_stride + prow * args.Cw) * 4);
+            a_pitch = (W + 2) * args.Cw * 4;
+        } else {
+            a_off = (uint32_t)((args.lv[0].W + 3) * args.Cw * 4);          // (y, x) = (0, 0) of level 0, image 0: its taps are in range
+            a_pitch = (args.lv[0].W + 2) * args.Cw * 4;
         }
     } else if (TILE) {
         a_off = xm < M ? (uint32_t)(((size_t)xt * M + xm) * Kw * 4) : 0u;
@@ -221,30 +222,13 @@ __global__ __launch_bounds__(512, 4) void k_gemm_mx(const MxArgs ma) {
     const int cpt = CONV ? args.Cw / 4 : 0;                                 // chunks per tap
     int f_off = CONV ? -args.Cw : 0;
     uint32_t f_voff = CONV ? a_off - (uint32_t)a_pitch : a_off;            // fc: constant
-    uint32_t f_mask = 1u;
     int f_kc = 0, f_cc = 0, f_dx = 0;
     // The row's 16 bytes and (wave 0) the chunk's column scales go straight into LDS by LDS-DMA (lane L -> base + 16 L /
-    // 4 L: exactly the [row][4 words] / [column] layout); lanes whose tap lies outside the image copy from a 16-byte
-    // zero block behind the packed weights instead.
-    const unsigned char* const zero16 = reinterpret_cast<const unsigned char*>(ma.wq + mx_words(Kc, Np) - 16);
+    // 4 L: exactly the [row][4 words] / [column] layout).
     const uint32_t* const Sg = ma.wq + mx_x_words(Kc, Np) + mx_y_words(Kc, Np) + nb * MX_BN;
     auto fetch_next = [&](int par) {                                        // spike words + column scales of the next chunk
         const uint32_t dst = __builtin_amdgcn_readfirstlane(smem_base + MX_LUT_BYTES + par * MX_AW_BYTES + wave * 1024);
-        if (CONV) {                                                         // branch-free: taps outside the image copy zeros
-            const unsigned long long sp = (unsigned long long)(args.A + f_off) + f_voff;
-            uint32_t lo = (uint32_t)sp, hi = (uint32_t)(sp >> 32);
-            const uint32_t ok = a_valid & f_mask;
-            // the select takes the zero block's address from SGPRs (as a C expression hipcc keeps VGPR copies of the
-            // two halves alive through the whole loop - and spills them)
-            uint32_t tmp;
-            asm volatile("v_cmp_ne_u32 vcc, 0, %3\n\tv_mov_b32 %2, %4\n\tv_cndmask_b32 %0, %2, %0, vcc\n\t"
-                         "v_mov_b32 %2, %5\n\tv_cndmask_b32 %1, %2, %1, vcc"
-                         : "+v"(lo), "+v"(hi), "=&v"(tmp) : "v"(ok), "s"((uint32_t)(unsigned long long)zero16), "s"((uint32_t)((unsigned long long)zero16 >> 32)) : "vcc");
-            const unsigned long long src = ((unsigned long long)hi << 32) | lo;
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src), "s"(dst) : "memory", "m0");
-        } else {
-            asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(f_voff), "s"(sgpr_ptr(args.A + f_off)), "s"(dst) : "memory", "m0");
-        }
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(f_voff), "s"(sgpr_ptr(args.A + f_off)), "s"(dst) : "memory", "m0");
         if (wave == 0) {
             const uint32_t sdst = __builtin_amdgcn_readfirstlane(smem_base + MX_LUT_BYTES + 2 * MX_AW_BYTES + par * MX_SC_BYTES);
             uint32_t l;                             // lane id, re-derived instead of a register held all loop
@@ -252,22 +236,13 @@ __global__ __launch_bounds__(512, 4) void k_gemm_mx(const MxArgs ma) {
             const uint32_t sc_voff = min(l, (uint32_t)(Np - nb * MX_BN - 1)) * 4u;
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dword %0, %1" :: "v"(sc_voff), "s"(sgpr_ptr(Sg + (size_t)f_kc * Np)), "s"(sdst) : "memory", "m0");
         }
-        // (readfirstlane: the counters are wave-uniform; hipcc otherwise carries them in VGPRs behind the divergent
-        //  tap-validity branch above)
-        const auto U = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
-        f_off = U(f_off + 4);
-        if (CONV) {
-            f_cc = U(f_cc + 1);
-            if (f_cc == cpt) {
-                f_cc = 0;
-                f_mask = (uint32_t)U((int)(f_mask << 1));
-                f_dx = U(f_dx + 1);
-                if (f_dx == 3) { f_dx = 0; f_off = U(f_off - 3 * args.Cw); f_voff += park_get().y; }
-            }
+        f_off += 4;
+        if (CONV && ++f_cc == cpt) {
+            f_cc = 0;
+            if (++f_dx == 3) { f_dx = 0; f_off -= 3 * args.Cw; f_voff += park_get().y; }      // next tap row
         }
-        f_kc = U(f_kc + 1);
-        if (f_kc == Kc) {                                                   // past the end: wrap (staged, never multiplied)
-            f_kc = 0; f_cc = 0; f_dx = 0; f_mask = 1u;
+        if (++f_kc == Kc) {                                                 // past the end: wrap (staged, never multiplied)
+            f_kc = 0; f_cc = 0; f_dx = 0;
             f_off = CONV ? -args.Cw : 0;
             if (CONV) { const uint2 pk = park_get(); f_voff = pk.x - pk.y; }
         }

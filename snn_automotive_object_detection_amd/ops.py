@@ -186,27 +186,32 @@ def spike_gemm_lif_mx(a_planes: torch.Tensor, K: int, N: int, p: snn_params, w_p
 
 
 def conv3x3_lif_mx(enc: torch.Tensor, shapes, C_in: int, C_out: int, p: snn_params, w_packed: torch.Tensor) -> torch.Tensor:
-    """enc int32 [T, P, Cw] over levels `shapes` -> shared-LIF spike planes int32 [T, P, Nw] (fp4 x fp6 path)"""
+    """enc int32 [T, Pp, Cw]: planes over levels `shapes` WITH a one-position zero halo around every image
+    (Pp = sum n (h+2) (w+2)) -> shared-LIF spike planes int32 [T, P, Nw] (fp4 x fp6 path)"""
     _need_gpu(enc, "enc planes")
     lib = _lib.load()
-    T, P, Cw = enc.shape
+    T, Pp, Cw = enc.shape
+    P = sum(n * h * w for n, h, w in shapes)
+    assert Pp == sum(n * (h + 2) * (w + 2) for n, h, w in shapes)
     lv = (snn_rpn_level * len(shapes))(*[snn_rpn_level(None, n, h, w, 0) for n, h, w in shapes])
     Nw = cdiv(C_out, 32)
     spk = torch.empty((T, P, Nw), dtype=torch.int32, device=enc.device)
-    _lib.check(lib.snn_conv3x3_lif_mx(_ptr(enc), P * Cw, lv, len(shapes), C_in, C_out, T, C.byref(p), _ptr(w_packed), _ptr(spk),
+    _lib.check(lib.snn_conv3x3_lif_mx(_ptr(enc), Pp * Cw, lv, len(shapes), C_in, C_out, T, C.byref(p), _ptr(w_packed), _ptr(spk),
                                       P * Nw, _stream()), "snn_conv3x3_lif_mx")
     return spk
 
 
 def spike_conv3x3_mx(enc: torch.Tensor, shapes, C_in: int, C_out: int, w_packed: torch.Tensor) -> torch.Tensor:
-    """enc int32 [T, P, Cw] over levels `shapes` -> cur fp32 [T, P, Np] (fp4 x fp6 path)"""
+    """enc int32 [T, Pp, Cw] zero-halo planes over levels `shapes` -> cur fp32 [T, P, Np] (fp4 x fp6 path)"""
     _need_gpu(enc, "enc planes")
     lib = _lib.load()
-    T, P, Cw = enc.shape
+    T, Pp, Cw = enc.shape
+    P = sum(n * h * w for n, h, w in shapes)
+    assert Pp == sum(n * (h + 2) * (w + 2) for n, h, w in shapes)
     lv = (snn_rpn_level * len(shapes))(*[snn_rpn_level(None, n, h, w, 0) for n, h, w in shapes])
     Np = cdiv(C_out, 32) * 32
     cur = torch.empty((T, P, Np), dtype=torch.float32, device=enc.device)
-    _lib.check(lib.snn_spike_conv3x3_mx(_ptr(enc), P * Cw, lv, len(shapes), C_in, C_out, T, _ptr(w_packed), _ptr(cur), Np,
+    _lib.check(lib.snn_spike_conv3x3_mx(_ptr(enc), Pp * Cw, lv, len(shapes), C_in, C_out, T, _ptr(w_packed), _ptr(cur), Np,
                                         _stream()), "snn_spike_conv3x3_mx")
     return cur
 

@@ -127,6 +127,19 @@ def test_spike_gemm_lif_mx_vs_unfused(gpu_device, T, R, K, N):
     assert fused.ne(0).any()
 
 
+def _pad_planes(planes: torch.Tensor, shapes) -> torch.Tensor:
+    """[T, P, Cw] spike words over levels `shapes` -> the same with a one-position zero halo around every image"""
+    T, _, Cw = planes.shape
+    out, pos = [], 0
+    for n, h, w in shapes:
+        blk = planes[:, pos:pos + n * h * w].reshape(T, n, h, w, Cw)
+        pad = torch.zeros((T, n, h + 2, w + 2, Cw), dtype=planes.dtype)
+        pad[:, :, 1:h + 1, 1:w + 1] = blk
+        out.append(pad.reshape(T, n * (h + 2) * (w + 2), Cw))
+        pos += n * h * w
+    return torch.cat(out, dim=1).contiguous()
+
+
 @pytest.mark.parametrize("C_in,C_out,T,shapes", [
     (128, 64, 8, [(1, 7, 9), (2, 3, 4)]),
     (256, 200, 4, [(2, 16, 12), (1, 1, 1)]),
@@ -141,7 +154,7 @@ def test_conv3x3_mx_vs_fp64_and_fused(gpu_device, C_in, C_out, T, shapes):
     bits = torch.rand(T, P_, C_in, generator=g) < 0.2
     w = torch.randn(C_out, C_in, 3, 3, generator=g) * 0.05
     p = ops.make_params(LIFParameters(v_th=torch.tensor(0.25)), LIFParameters(alpha=100, v_th=torch.tensor(0.1)))
-    enc = _planes(bits).to(gpu_device)
+    enc = _pad_planes(_planes(bits), shapes).to(gpu_device)              # the mx conv reads zero-halo planes
     wp = ops.pack_conv3x3_mx(w.to(gpu_device))
     cur = ops.spike_conv3x3_mx(enc, shapes, C_in, C_out, wp)
     pos = 0

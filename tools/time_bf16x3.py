@@ -44,6 +44,14 @@ t6 = tm(lambda: ops.spike_gemm_mx(enc.view(T6 * R, -1), D, Hd, w6m))
 fl6 = 2.0 * T6 * R * D * Hd
 print('fc6  mxfp6 %.3f ms (%.1f TF algorithmic)' % (t6, fl6 / t6 / 1e9))
 wm = ops.pack_conv3x3_mx(w)
-t7 = tm(lambda: ops.spike_conv3x3_mx(encs, shapes, 256, 256, wm), 3)
-t8 = tm(lambda: ops.conv3x3_lif_mx(encs, shapes, 256, 256, p, wm), 3)
+def pad_planes(pl, shapes):          # zero halo around every image (the mx conv's input format)
+    out, pos = [], 0
+    for n, h, w_ in shapes:
+        blk = pl[:, pos:pos + n * h * w_].reshape(pl.shape[0], n, h, w_, -1)
+        out.append(torch.nn.functional.pad(blk, (0, 0, 1, 1, 1, 1)).reshape(pl.shape[0], n * (h + 2) * (w_ + 2), -1))
+        pos += n * h * w_
+    return torch.cat(out, dim=1).contiguous()
+encs_p = pad_planes(encs, shapes)
+t7 = tm(lambda: ops.spike_conv3x3_mx(encs_p, shapes, 256, 256, wm), 3)
+t8 = tm(lambda: ops.conv3x3_lif_mx(encs_p, shapes, 256, 256, p, wm), 3)
 print('conv mxfp6 gemm %.3f ms (%.1f TF algorithmic)   FUSED conv+LIF %.3f ms' % (t7, fl / t7 / 1e9, t8))

@@ -11,6 +11,9 @@
 #pragma once
 
 #define MX_P 6
+#ifndef MX_PD
+#define MX_PD 1
+#endif
 
 // fp6 e2m3 code of an integer digit d in [-16, 16] (value d/8)
 __device__ __forceinline__ uint32_t mx_fp6_code(int d) {
@@ -157,7 +160,7 @@ template <int MODE>
 __global__ __launch_bounds__(512, 4) void k_gemm_mx(const MxArgs ma) {
     constexpr bool CONV = MODE == G3_CONV || MODE == G3_CONV_LIF_TILE;
     constexpr bool TILE = MODE == G3_CONV_LIF_TILE || MODE == G3_FC_LIF_TILE;
-    constexpr int PD = 1, RING = PD + 1;                        // fragment prefetch distance in groups; RING divides 12
+    constexpr int PD = MX_PD, RING = PD + 1;                    // fragment prefetch distance in groups; RING divides 12
                                                                 // (128 registers: 64 acc + 16 A + 12 B fragments + addresses)
     const Gemm3Args& args = ma.g;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

@@ -268,8 +268,11 @@ __global__ __launch_bounds__(512, 4) void k_gemm_mx(const MxArgs ma) {
         const int pj = isx ? q >> 2 : q >> 1, part = isx ? q & 3 : q & 1;   // plane slot 0..2, 1-KiB part
         const int r = part * 16 + (lane >> 2);
         const int ncols = Np - nb * MX_BN;                                  // columns this block really has (>= 32)
+        // Y rows are 32 B: rows r and r + 8 share banks for an 8-byte read, so rows with bit 3 set keep their two 16-B
+        // halves swapped (the copy permutes the SOURCE address; LDS-DMA always lands lane L at base + 16 L)
+        const int ry = part * 32 + (lane >> 1);
         pc_voff[j] = isx ? (uint32_t)(min(r, ncols - 1) * 64 + (((lane & 3) ^ G3_SWZ(r)) << 4))
-                         : (uint32_t)min(part * 1024 + lane * 16, ncols * 32 - 16);
+                         : (uint32_t)(min(ry, ncols - 1) * 32 + (((lane & 1) ^ ((ry >> 3) & 1)) << 4));
         pc_dst[j] = isx ? pj * (MX_BN * 64) + part * 1024 : 3 * (MX_BN * 64) + pj * (MX_BN * 32) + part * 1024;
         const unsigned long long plane = isx ? xplane : yplane;
         pc_base[j] = (unsigned long long)(isx ? Xg : Yg) + (5 - pj) * plane + (unsigned long long)nb * MX_BN * (isx ? 64 : 32);
@@ -319,7 +322,7 @@ __global__ __launch_bounds__(512, 4) void k_gemm_mx(const MxArgs ma) {
         return a;
     };
     const unsigned char* const bx_rd = ring + lr * 64 + ((lg ^ G3_SWZ(lr)) << 4);     // + slot, plane slot * 4096, nt * 1024
-    const unsigned char* const by_rd = ring + 3 * (MX_BN * 64) + lr * 32 + lg * 8;    // + slot, plane slot * 2048, nt * 512
+    const unsigned char* const by_rd = ring + 3 * (MX_BN * 64) + lr * 32 + (((lg >> 1) ^ (lr >> 3)) << 4) + (lg & 1) * 8;   // + slot, plane slot * 2048, nt * 512
     auto rd_b = [&](uint32_t slot_off, int g) {                                      // group g = (N-tile g / 3, plane slot g % 3)
         const int nt = g / 3, pj = g % 3;
         MxB b;

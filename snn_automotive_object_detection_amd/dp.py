@@ -18,11 +18,14 @@ def init_distributed(backend: str = None) -> Tuple[int, int, int]:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if "SNN_DP_DEVICE" in os.environ:
+        local = int(os.environ["SNN_DP_DEVICE"])
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # SNN_DIST_BACKEND=gloo (with SNN_DP_DEVICE=0) exercises the multi-rank path on a one-GPU box
+            backend = os.environ.get("SNN_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)

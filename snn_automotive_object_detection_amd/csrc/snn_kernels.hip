@@ -2225,20 +2225,30 @@ int snn_spike_gemm_lif_bf16x3(const uint32_t* a_planes, int T, int R, int K, int
 // ---- spike GEMMs on the block-scaled fp4 x fp6 path (snn_mx.h) ------------------------------------
 static bool mx_tile_ok(int T) { return g3_tile_ok(T, MX_BM); }
 
+// rows per wave: 4 M-tiles (8 waves, 128 registers; default) or 8 (4 waves, 256 registers: half the LDS fragment reads
+// per MFMA - measured equal in the loop, slower in the LIF epilogue); SNN_MX_MW=4|8 overrides (debug / A-B switch)
+static int mx_mw() {
+    const char* e = getenv("SNN_MX_MW");
+    return e && e[0] == '8' ? 8 : (e && e[0] == '4' ? 4 : MX_MW_DEFAULT);
+}
+
+#define MX_KERNEL_OF(MW, mode)                                                                        \
+    ((mode) == G3_FC ? (const void*)k_gemm_mx<G3_FC, MW>                                              \
+     : (mode) == G3_CONV ? (const void*)k_gemm_mx<G3_CONV, MW>                                        \
+     : (mode) == G3_CONV_LIF_TILE ? (const void*)k_gemm_mx<G3_CONV_LIF_TILE, MW>                      \
+                                  : (const void*)k_gemm_mx<G3_FC_LIF_TILE, MW>)
+
 static int launch_gemm_mx(int mode, MxArgs& a, hipStream_t s) {
-    const void* kern;
-    int lds = MX_LDS, tiles = cdiv(a.g.M, MX_BM);
-    switch (mode) {
-    case G3_FC: kern = (const void*)k_gemm_mx<G3_FC>; break;
-    case G3_CONV: kern = (const void*)k_gemm_mx<G3_CONV>; break;
-    case G3_CONV_LIF_TILE: kern = (const void*)k_gemm_mx<G3_CONV_LIF_TILE>; tiles = cdiv(a.g.M, a.g.pb); lds = max(lds, (int)G3_TILE_BYTES(1)); break;
-    default: kern = (const void*)k_gemm_mx<G3_FC_LIF_TILE>; tiles = cdiv(a.g.M, a.g.pb); lds = max(lds, (int)G3_TILE_BYTES(1)); break;
-    }
+    const int mw = mx_mw();
+    const void* kern = mw == 8 ? MX_KERNEL_OF(8, mode) : MX_KERNEL_OF(4, mode);
+    const bool tile = mode == G3_CONV_LIF_TILE || mode == G3_FC_LIF_TILE;
+    const int lds = tile ? max((int)MX_LDS, (int)G3_TILE_BYTES(1)) : MX_LDS;
+    const int tiles = tile ? cdiv(a.g.M, a.g.pb) : cdiv(a.g.M, MX_BM);
     a.g.n_blocks = cdiv(a.g.Np, MX_BN);
     hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return fail(-3, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
     void* kargs[] = {(void*)&a};
-    e = hipLaunchKernel(kern, dim3(tiles * a.g.n_blocks), dim3(512), kargs, lds, s);
+    e = hipLaunchKernel(kern, dim3(tiles * a.g.n_blocks), dim3(2048 / mw), kargs, lds, s);
     if (e != hipSuccess) return fail(-3, "k_gemm_mx launch failed: %s", hipGetErrorString(e));
     SNN_CHECK_LAUNCH("k_gemm_mx");
     return 0;

@@ -93,8 +93,31 @@ def _planes(bits: torch.Tensor) -> torch.Tensor:
     return torch.where(v >= 2 ** 31, v - 2 ** 32, v).to(torch.int32)
 
 
+@pytest.fixture(params=["4", "8"], ids=["mw4", "mw8"])
+def mx_mw(request, monkeypatch):
+    """both work-group shapes of k_gemm_mx (8 waves x 64 rows / 4 waves x 128 rows)"""
+    monkeypatch.setenv("SNN_MX_MW", request.param)
+    return request.param
+
+
+def test_spike_gemm_mx_repeated_calls_are_stable(gpu_device, mx_mw):
+    """regression: the chunk scales are shared by all waves of a work-group; their buffer used to be overwritten one
+    micro-step too early, which only showed on warm repeats with >= 3 chunks (lagging waves read the next chunk's scales)"""
+    from snn_automotive_object_detection_amd import ops
+    g = torch.Generator().manual_seed(7)
+    for (M, K, N) in [(512, 384, 64), (1024, 640, 128)]:
+        bits = torch.rand(M, K, generator=g) < 0.25
+        w = torch.randn(N, K, generator=g) * 0.05
+        a = _planes(bits).to(gpu_device)
+        wp = ops.pack_linear_mx(w.to(gpu_device))
+        ref = bits.double() @ w.double().t()
+        for _ in range(6):
+            cur = ops.spike_gemm_mx(a, K, N, wp)[:, :N].double().cpu()
+            assert float((cur - ref).abs().max()) <= 2e-6
+
+
 @pytest.mark.parametrize("M,K,N", [(64, 128, 32), (700, 384, 96), (513, 1280, 200)])
-def test_spike_gemm_mx_vs_fp64(gpu_device, M, K, N):
+def test_spike_gemm_mx_vs_fp64(gpu_device, mx_mw, M, K, N):
     from snn_automotive_object_detection_amd import ops
     g = torch.Generator().manual_seed(M + K)
     bits = torch.rand(M, K, generator=g) < 0.25
@@ -110,7 +133,7 @@ def test_spike_gemm_mx_vs_fp64(gpu_device, M, K, N):
 
 
 @pytest.mark.parametrize("T,R,K,N", [(8, 100, 256, 64), (12, 45, 384, 70), (5, 130, 128, 200)])
-def test_spike_gemm_lif_mx_vs_unfused(gpu_device, T, R, K, N):
+def test_spike_gemm_lif_mx_vs_unfused(gpu_device, mx_mw, T, R, K, N):
     """linear layer + LIF fused in the row tile == GEMM on the same path followed by the LIF scan (bit for bit)"""
     from snn_automotive_object_detection_amd import ops
     from snn_automotive_object_detection_amd.ops import LIFParameters
@@ -145,7 +168,7 @@ def _pad_planes(planes: torch.Tensor, shapes) -> torch.Tensor:
     (256, 200, 4, [(2, 16, 12), (1, 1, 1)]),
     (384, 32, 12, [(1, 5, 6)]),
 ])
-def test_conv3x3_mx_vs_fp64_and_fused(gpu_device, C_in, C_out, T, shapes):
+def test_conv3x3_mx_vs_fp64_and_fused(gpu_device, mx_mw, C_in, C_out, T, shapes):
     import torch.nn.functional as F
     from snn_automotive_object_detection_amd import ops
     from snn_automotive_object_detection_amd.ops import LIFParameters

@@ -210,9 +210,9 @@ def main():
         kernel, peak, exec_factor, kernel_ms = "k_conv3x3_lif<false>", PEAK_F32_MFMA_TFLOPS, 1.0, conv_ms
         traffic_key = "f32"
     elif args.precision == "mxfp6":
-        # stage 2 = k_gemm_mx<3> (G3_CONV_LIF_TILE): fp4 x fp6 block-scaled MFMA, 6 digit planes per weight at 4x the K per
+        # stage 2 = k_gemm_mx<3, 4> (G3_CONV_LIF_TILE): fp4 x fp6 block-scaled MFMA, 6 digit planes per weight at 4x the K per
         # instruction: executed work = 6/4 of the bf16-equivalent; peak = 10 PF dense fp6/fp4 (spec)
-        kernel, peak, exec_factor, kernel_ms = "k_gemm_mx<3>", PEAK_MX_MFMA_TFLOPS, 6.0, conv_ms
+        kernel, peak, exec_factor, kernel_ms = "k_gemm_mx<3, 4>", PEAK_MX_MFMA_TFLOPS, 6.0, conv_ms
         traffic_key = "mxfp6"
     else:
         # stage 2 = k_gemm_bf16x3<3, 3, 4, 2> (MODE = G3_CONV_LIF_TILE, 3-slot ring, 4 M-tiles per wave, 4 x 2 wave grid): 3x3 conv + LIF over T fused in the tile,

@@ -4,8 +4,8 @@ path's ONE exchange step: an all-gather of the per-image detections (the referen
 the pickled ``all_gather_object`` in coco_eval.py:158-177, disabled under NCCL at train.py:874-880).
 
 Detections are variable-length; they are padded to ``max_det`` rows and exchanged as two fixed-size
-tensors (payload + counts) with ONE ``all_gather_into_tensor`` each — KB-scale, latency-bound, so a
-single collective per batch over RCCL/xGMI (backend "nccl" on ROCm) or gloo on CPU."""
+tensors (payload + counts) in ONE ``all_gather_into_tensor`` (the counts ride as an extra payload row) — KB-scale,
+latency-bound, so a single collective per batch over RCCL/xGMI (backend "nccl" on ROCm) or gloo on CPU."""
 import os
 from typing import Dict, List, Tuple
 
@@ -64,16 +64,18 @@ def unpack_detections(payload: torch.Tensor, counts: torch.Tensor) -> List[Dict[
 
 
 def all_gather_detection_tensors(payload: torch.Tensor, counts: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-    """the exchange step proper (device tensors in, device tensors out; equal per-rank image counts)"""
+    """the exchange step proper (device tensors in, device tensors out; equal per-rank image counts): ONE collective per
+    batch - the per-image counts travel as an extra payload row (exact in fp32: counts < 2^24)"""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return payload, counts
     world = dist.get_world_size()
-    g_payload = torch.empty((world * payload.shape[0],) + tuple(payload.shape[1:]), dtype=payload.dtype,
-                            device=payload.device)
-    g_counts = torch.empty((world * counts.shape[0],), dtype=counts.dtype, device=counts.device)
-    dist.all_gather_into_tensor(g_payload, payload.contiguous())
-    dist.all_gather_into_tensor(g_counts, counts.contiguous())
-    return g_payload, g_counts
+    n, max_det, width = payload.shape
+    buf = torch.empty((n, max_det + 1, width), dtype=payload.dtype, device=payload.device)
+    buf[:, :max_det] = payload
+    buf[:, max_det] = counts.to(payload.dtype)[:, None]
+    gathered = torch.empty((world * n, max_det + 1, width), dtype=payload.dtype, device=payload.device)
+    dist.all_gather_into_tensor(gathered, buf)
+    return gathered[:, :max_det], gathered[:, max_det, 0].to(counts.dtype)
 
 
 def all_gather_detections(dets: List[Dict[str, torch.Tensor]], max_det: int = 1100) -> List[Dict[str, torch.Tensor]]:

@@ -72,7 +72,7 @@ def detections_from_heads(cls_logits, box_deltas, max_det=100):
     best, lab = scores.max(dim=1)
     best = best.view(BATCH, ROIS_PER_IMG)
     lab = lab.view(BATCH, ROIS_PER_IMG) + 1
-    top, idx = best.topk(max_det, dim=1)
+    top, idx = best.topk(max_det, dim=1, sorted=False)       # the payload's order is free (the exchange is a gather)
     deltas = box_deltas.view(BATCH, ROIS_PER_IMG, -1, 4)
     li = lab.gather(1, idx)
     boxes = deltas.gather(1, idx[:, :, None, None].expand(-1, -1, deltas.shape[2], 4))

@@ -1482,6 +1482,127 @@ __global__ __launch_bounds__(256) void k_li_heads_mfma(const LiHeadsArgs a) {
     }
 }
 
+// K5c: the same heads when W does not fit in LDS (detector: K = 1024, 45 outputs) and there are few rows (2000): one
+// work-group per 16-row tile, its 4 waves split the reduction into quarters (so 125 work-groups of independent waves
+// instead of 32 that march through K together).  A wave keeps the accumulators of ALL time steps (T <= 16; 12 with 4 column
+// tiles), builds the
+// three bf16 planes of its weight fragments in registers straight from the fp32 W^T (read through L2, next chunk's
+// values requested before this chunk's MFMAs), and needs no barrier until the four partial results meet in LDS and are
+// added in wave order (deterministic).  2000 x 1024 x 45, T = 12: 68 us (fp32 VALU kernel) -> ~15 us.
+#define LIH_KS_TM(nt) ((nt) <= 3 ? 16 : 12)     // time steps whose accumulators fit in registers beside NT column tiles
+template <int NT>
+__global__ __launch_bounds__(256) void k_li_heads_ksplit(const LiHeadsArgs a) {
+    constexpr int TM = LIH_KS_TM(NT);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const lut = smem;                           // 4 KB
+    f32x4* const red = reinterpret_cast<f32x4*>(smem + G3_LUT_BYTES);      // [4 waves][2][NT][64 lanes]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, lg = lane >> 4, lg8 = 8 * lg;
+    const int NOp = a.NOp, Kc = a.Kw, T = a.T;
+    {
+        uint4 q;
+        q.x = bf16_pair(tid, 0); q.y = bf16_pair(tid, 1); q.z = bf16_pair(tid, 2); q.w = bf16_pair(tid, 3);
+        *reinterpret_cast<uint4*>(lut + tid * 16) = q;
+    }
+    __syncthreads();
+    const int m0 = blockIdx.x * 16;
+    const int mrow = min(m0 + lr, a.M - 1);                    // rows past M: recomputed, never stored
+    const uint32_t* wsrc = a.spk + (size_t)mrow * a.Kw;
+    const int c0 = wave * Kc / 4, c1 = (wave + 1) * Kc / 4;    // this wave's chunks
+    f32x4 acc[TM][NT];
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[t][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // element (k = 32 kc + 8 lg + j, n = nt*16 + lr) of W^T: the lane's B fragment is j = 0..7
+    const float* const wlane = a.wT + (size_t)lg8 * NOp + lr;
+    float wf[NT][8];
+    uint32_t w_nxt[TM];
+    auto request = [&](int kc) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) wf[nt][j] = wlane[(size_t)(32 * kc + j) * NOp + nt * 16];
+#pragma unroll
+        for (int t = 0; t < TM; ++t) w_nxt[t] = t < T ? wsrc[(size_t)t * a.spk_stride + kc] : 0u;
+    };
+    if (c0 < c1) request(c0);
+    for (int kc = c0; kc < c1; ++kc) {
+        bf16x8 b[3][NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float w = wf[nt][j];
+                const uint16_t hi = f2bf_rn(w);
+                const float r1 = __fsub_rn(w, bf2f(hi));
+                const uint16_t mid = f2bf_rn(r1);
+                const uint16_t lo = f2bf_rn(__fsub_rn(r1, bf2f(mid)));
+                b[0][nt][j] = (short)hi; b[1][nt][j] = (short)mid; b[2][nt][j] = (short)lo;
+            }
+        uint32_t w_cur[TM];
+#pragma unroll
+        for (int t = 0; t < TM; ++t) w_cur[t] = w_nxt[t];
+        if (kc + 1 < c1) request(kc + 1);
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+            if (t < T) {                                        // block-uniform
+                const bf16x8 af = *reinterpret_cast<const bf16x8*>(lut + (__builtin_amdgcn_ubfe(w_cur[t], lg8, 8) << 4));
+#pragma unroll
+                for (int pl = 2; pl >= 0; --pl)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, b[pl][nt], acc[t][nt], 0, 0, 0);
+            }
+        }
+    }
+    f32x4 o_last[NT], o_sum[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { o_last[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; o_sum[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+        if (t < T) {
+            const float kl = a.kap.last[t], ks = a.kap.sum[t];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    o_last[nt][r] = fmaf(kl, acc[t][nt][r], o_last[nt][r]);
+                    o_sum[nt][r] = fmaf(ks, acc[t][nt][r], o_sum[nt][r]);
+                }
+        }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        red[((wave * 2 + 0) * NT + nt) * 64 + lane] = o_last[nt];
+        red[((wave * 2 + 1) * NT + nt) * 64 + lane] = o_sum[nt];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        f32x4 ol = red[(0 * NT + nt) * 64 + lane], os = red[(1 * NT + nt) * 64 + lane];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const f32x4 pl = red[((w * 2 + 0) * NT + nt) * 64 + lane], ps = red[((w * 2 + 1) * NT + nt) * 64 + lane];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { ol[r] = __fadd_rn(ol[r], pl[r]); os[r] = __fadd_rn(os[r], ps[r]); }
+        }
+        // lane holds rows lg*4 + r, output column nt*16 + lr
+        const int j = nt * 16 + lr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + lg * 4 + r;
+            if (m >= a.M) continue;
+            if (j < a.NA) { a.out_a[(size_t)m * a.NA + j] = ol[r]; if (a.sum_a) a.sum_a[(size_t)m * a.NA + j] = os[r]; }
+            else if (j < a.NA + a.NB) {
+                a.out_b[(size_t)m * a.NB + (j - a.NA)] = ol[r];
+                if (a.sum_b) a.sum_b[(size_t)m * a.NB + (j - a.NA)] = os[r];
+            }
+        }
+    }
+}
+
 // spikes per image of one level, counted from the bit-planes (spike-rate mode of the bf16x3 path): blockIdx.x = image,
 // blockIdx.y = slice of the image's words; integer atomics, so the result does not depend on the order.
 // counts must be zeroed by the caller.
@@ -2572,6 +2693,22 @@ int snn_li_heads(const uint32_t* spk, size_t spk_stride, int T, int M, int K, co
     // matrix-core kernel where all of W (as three bf16 planes) stays resident in LDS; the streamed form is latency
     // bound on small row counts (detector heads: 164 us against 88 us for the VALU kernel) and only runs when forced
     const bool fits = (size_t)Kw * 3 * NOp * 64 <= 96 * 1024;
+    // W too large for LDS: one work-group per 16 rows, the reduction split over its 4 waves ("ksplit" forces it)
+    if (NOp <= 64 && T <= LIH_KS_TM(NOp / 16) && Kw >= 4 && (force ? !strcmp(force, "ksplit") : !fits)) {
+        LiHeadsArgs a;
+        memset(&a, 0, sizeof(a));
+        a.spk = spk; a.spk_stride = spk_stride; a.wT = w_heads_packed; a.out_a = out_a; a.out_b = out_b;
+        a.sum_a = sum_a; a.sum_b = sum_b; a.T = T; a.M = M; a.Kw = Kw; a.NOp = NOp; a.NA = NA; a.NB = NB; a.kap = kap;
+        const int nt = NOp / 16;
+        const size_t lds = G3_LUT_BYTES + (size_t)4 * 2 * nt * 64 * 16;
+        const void* kern = nt == 1 ? (const void*)k_li_heads_ksplit<1> : nt == 2 ? (const void*)k_li_heads_ksplit<2>
+                         : nt == 3 ? (const void*)k_li_heads_ksplit<3> : (const void*)k_li_heads_ksplit<4>;
+        void* kargs[] = {(void*)&a};
+        hipError_t e = hipLaunchKernel(kern, dim3(cdiv(M, 16)), dim3(256), kargs, lds, (hipStream_t)s);
+        if (e != hipSuccess) return fail(-3, "k_li_heads_ksplit launch failed: %s", hipGetErrorString(e));
+        SNN_CHECK_LAUNCH("k_li_heads_ksplit");
+        return 0;
+    }
     if (NOp <= 64 && (force ? !strcmp(force, "mfma") : fits)) {
         LiHeadsArgs a;
         memset(&a, 0, sizeof(a));

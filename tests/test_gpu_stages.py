@@ -158,6 +158,40 @@ def test_li_heads_both_orders(S, gpu_device, li_order):
     assert (o_b.cpu().view(N, H, W, 4 * A).permute(0, 3, 1, 2) - exp_b).abs().max() <= CUR_TOL
 
 
+@pytest.mark.parametrize("T,M,K,NA,NB", [(12, 300, 1024, 9, 36), (16, 45, 160, 2, 8), (12, 130, 1024, 11, 44), (5, 17, 2048, 3, 12)])
+@pytest.mark.parametrize("li_order", ["jump_first", "voltage_first"])
+def test_li_heads_kernel_forms_agree_with_fp64(S, gpu_device, monkeypatch, li_order, T, M, K, NA, NB):
+    """the three kernels behind snn_li_heads (fp32 VALU, matrix cores with W resident in LDS, matrix cores with the reduction
+    split over the waves of a 16-row work-group) against the LI recursion in fp64 on the same spikes"""
+    g = torch.Generator().manual_seed(T * M + K)
+    spk = torch.rand(T, M, K, generator=g) < 0.1
+    wa = torch.randn(NA, K, generator=g) / K ** 0.5
+    wb = torch.randn(NB, K, generator=g) / K ** 0.5
+    a, b = float(torch.tensor(0.001) * torch.tensor(100.0)), float(torch.tensor(0.001) * torch.tensor(200.0))
+    cur = torch.einsum("tmk,nk->tmn", spk.double(), torch.cat([wa, wb]).double())
+    v = torch.zeros(M, NA + NB, dtype=torch.float64)
+    i = torch.zeros_like(v)
+    vsum = torch.zeros_like(v)
+    for t in range(T):
+        if li_order == "jump_first":
+            i = i + cur[t]; v = v + a * (i - v); i = i - b * i
+        else:
+            v = v + a * (i - v); i = i - b * i + cur[t]
+        vsum = vsum + v
+    planes = dense_to_planes(spk.numpy()).to(gpu_device)
+    wh = S.pack_heads(wa.to(gpu_device), wb.to(gpu_device))
+    outs = {}
+    for form in ("valu", "ksplit", "mfma"):
+        monkeypatch.setenv("SNN_LI_HEADS", form)      # a form that does not apply to the shape falls through to the VALU kernel
+        o_a, o_b, s_a, s_b = S.li_heads(planes, K, wh, NA, NB, _params(S, li_order), want_sums=True)
+        got = torch.cat([o_a, o_b], dim=1).double().cpu()
+        gsum = torch.cat([s_a, s_b], dim=1).double().cpu()
+        assert float((got - v).abs().max()) <= CUR_TOL, form
+        assert float((gsum - vsum).abs().max()) <= T * CUR_TOL, form
+        outs[form] = got
+    assert float((outs["valu"] - outs["ksplit"]).abs().max()) <= 2 * CUR_TOL
+
+
 # ---------------------------------------------------------------------------------------------
 # exact bf16x3 contractions (bf16 matrix cores): same teacher-forced bars as the fp32 MFMA kernels
 # ---------------------------------------------------------------------------------------------

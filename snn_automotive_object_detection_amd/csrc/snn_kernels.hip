@@ -205,6 +205,46 @@ __global__ __launch_bounds__(256) void k_encode_rows(const float* __restrict__ x
     }
 }
 
+// K1b': the same encoder when D is a multiple of 32 (the detector: 12544): the [R][D] elements are then one contiguous
+// run of plane words, and a LANE owns a whole word.  A work-group copies 256 words (32 KB) with 16-byte coalesced loads
+// through LDS (row pitch 36 dwords: the 8 ds_read_b128 of a lane are conflict-free), then every lane scans its 32
+// neurons with the 6-instruction step whose carry chain builds the plane word (enc_step_word) and the wave stores 64
+// consecutive words per time step.  Against the ballot form: 6 instead of 11 vector instructions per neuron-step and 8
+// times the bytes in flight per thread.
+#define ENC_W_PITCH 36
+template <bool ZR>
+__global__ __launch_bounds__(256) void k_encode_rows_w(const float* __restrict__ x, size_t n_words, int T, NeuronP p,
+                                                       uint32_t* __restrict__ planes, size_t plane_stride) {
+    __shared__ __attribute__((aligned(16))) float tile[256 * ENC_W_PITCH];
+    const int tid = threadIdx.x;
+    const size_t w0 = (size_t)blockIdx.x * 256;                 // first plane word of the work-group
+    const size_t nw = n_words - w0 < 256 ? n_words - w0 : 256;
+    const f32x4* src = reinterpret_cast<const f32x4*>(x + w0 * 32);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int q = tid + 256 * j;                            // 16-byte piece q of the work-group: word q / 8, elements 4 (q % 8) ..
+        f32x4 v4 = {0.f, 0.f, 0.f, 0.f};
+        if ((size_t)(q >> 3) < nw) v4 = src[q];
+        *reinterpret_cast<f32x4*>(tile + (q >> 3) * ENC_W_PITCH + (q & 7) * 4) = v4;
+    }
+    __syncthreads();
+    if ((size_t)tid >= nw) return;
+    float xv[32], v[32];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const f32x4 t4 = *reinterpret_cast<const f32x4*>(tile + tid * ENC_W_PITCH + 4 * q);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { xv[4 * q + r] = t4[r]; v[4 * q + r] = 0.0f; }      // v = 0: faster_rcnn.py:484
+    }
+    uint32_t* dst = planes + w0 + tid;
+    for (int t = 0; t < T; ++t) {
+        uint32_t word = 0;
+#pragma unroll
+        for (int b = 31; b >= 0; --b) enc_step_word<ZR>(xv[b], v[b], p, word);          // bit 31 first
+        dst[(size_t)t * plane_stride] = word;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K1c: MultiScaleRoIAlign (7x7, sampling_ratio 2, aligned=False) fused with the detector's constant-current
 // encoder (roi_heads.py:1217 -> faster_rcnn.py:473,494): the [R,C,7,7] fp32 RoI features (100 MB at R=2000) are
@@ -2554,6 +2594,15 @@ int snn_encode_rows(const float* x, int R, int D, int T, const snn_params* p, ui
     const int Dw = cdiv(D, 32);
     const size_t total = (size_t)R * Dw * 32;
     const NeuronP np = make_p(p, p->v_th_enc);
+    const char* force = getenv("SNN_ENC_ROWS");                // debug / A-B knob: "ballot" forces the element-per-lane kernel
+    if (D % 32 == 0 && ((uintptr_t)x & 15) == 0 && !(force && !strcmp(force, "ballot"))) {
+        const size_t n_words = (size_t)R * Dw;
+        const dim3 gw((unsigned)((n_words + 255) / 256));
+        if (enc_zero_rest(np)) hipLaunchKernelGGL(k_encode_rows_w<true>, gw, dim3(256), 0, (hipStream_t)s, x, n_words, T, np, planes, plane_stride);
+        else hipLaunchKernelGGL(k_encode_rows_w<false>, gw, dim3(256), 0, (hipStream_t)s, x, n_words, T, np, planes, plane_stride);
+        SNN_CHECK_LAUNCH("k_encode_rows_w");
+        return 0;
+    }
     const dim3 grid((unsigned)((total + 256 * ENC_U - 1) / (256 * ENC_U)));
     if (enc_zero_rest(np)) hipLaunchKernelGGL(k_encode_rows<true>, grid, dim3(256), 0, (hipStream_t)s, x, R, D, Dw, T, np, planes, plane_stride);
     else hipLaunchKernelGGL(k_encode_rows<false>, grid, dim3(256), 0, (hipStream_t)s, x, R, D, Dw, T, np, planes, plane_stride);

@@ -57,6 +57,24 @@ def test_encoder_rows_bit_exact(S, gpu_device, name):
     assert np.array_equal(planes_to_dense(planes, x.shape[1]), z.numpy())
 
 
+@pytest.mark.parametrize("R,D,T", [(37, 12544, 12), (5, 64, 3), (300, 1024, 32), (1, 32, 1)])
+def test_encoder_rows_word_per_lane_equals_ballot_form_and_oracle(S, gpu_device, monkeypatch, R, D, T):
+    """D % 32 == 0 runs the word-per-lane kernel (k_encode_rows_w); SNN_ENC_ROWS=ballot forces the element-per-lane one"""
+    g = torch.Generator().manual_seed(R + D)
+    x = torch.randn(R, D, generator=g) * 1.5
+    x[0, :7] = torch.tensor([0.25, 0.26, 0.3, 1.0, 2.5, 2.6, -1.0])[:min(7, D)]      # threshold neighbours (SURVEY 8c)
+    xg = x.to(gpu_device)
+    for generic in ("0", "1"):
+        monkeypatch.setenv("SNN_ENC_GENERIC", generic)
+        monkeypatch.delenv("SNN_ENC_ROWS", raising=False)
+        a = S.encode_rows(xg, T, _params(S))
+        monkeypatch.setenv("SNN_ENC_ROWS", "ballot")
+        b = S.encode_rows(xg, T, _params(S))
+        assert torch.equal(a, b)
+    z = OR.encoder_spikes(x, T)
+    assert np.array_equal(planes_to_dense(a, D), z.numpy())
+
+
 def test_encoder_fast_path_equals_op_for_op(S, gpu_device, monkeypatch):
     """v_leak = v_reset = 0 takes a 5-operation encoder step; SNN_ENC_GENERIC=1 forces the op-for-op kernels"""
     g = torch.Generator().manual_seed(5)

@@ -18,12 +18,24 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 
 
+STAMP = os.path.join(LIB_DIR, "libsnnhip.stamp")
+
+
+def source_digest() -> str:
+    """content hash of everything the library is built from (file times do not survive a copy to another machine)"""
+    import hashlib
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for d in [os.path.join(CSRC, s) for s in SOURCES] + HEADERS:
+        with open(d, "rb") as f:
+            h.update(os.path.basename(d).encode() + b"\0" + f.read())
+    return h.hexdigest()
+
+
 def needs_build() -> bool:
-    if not os.path.exists(LIB_PATH):
+    if not os.path.exists(LIB_PATH) or not os.path.exists(STAMP):
         return True
-    t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS + [os.path.abspath(__file__)]
-    return any(os.path.getmtime(d) > t for d in deps)
+    with open(STAMP) as f:
+        return f.read().strip() != source_digest()
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -47,6 +59,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
                     os.remove(tmp)
                 raise RuntimeError("hipcc failed:\n" + r.stdout)
             os.replace(tmp, LIB_PATH)
+            with open(STAMP + ".tmp", "w") as f:
+                f.write(source_digest() + "\n")
+            os.replace(STAMP + ".tmp", STAMP)
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH

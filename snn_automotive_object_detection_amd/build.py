@@ -24,7 +24,7 @@ STAMP = os.path.join(LIB_DIR, "libsnnhip.stamp")
 def source_digest() -> str:
     """content hash of everything the library is built from (file times do not survive a copy to another machine)"""
     import hashlib
-    h = hashlib.sha256(" ".join(FLAGS).encode())
+    h = hashlib.sha256(" ".join(f for f in FLAGS if not f.startswith("-I")).encode())    # include paths move with the tree
     for d in [os.path.join(CSRC, s) for s in SOURCES] + HEADERS:
         with open(d, "rb") as f:
             h.update(os.path.basename(d).encode() + b"\0" + f.read())

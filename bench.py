@@ -8,7 +8,8 @@ One "step" = one pass of the hot path over one batch of synthetic input resident
 RPNHeadSNN.forward (T_rpn=8) on the 5-level FPN pyramid of a 1024x2048 Cityscapes batch of 2
 (768x1536 after the transform: 192x384 ... 12x24, 256 ch) followed by
 FastRCNNPredictorSNNFull.forward (T_det=12) on the 2x1000 RoI features [2000,256,7,7], K=9, fp32,
-then the path's one exchange step (all-gather of per-image detections, dp.py) when N>1.
+then the exchange payload (top-100 RoIs per image, snn_det_exchange_payload) and, when N>1, the path's one exchange
+step (all-gather of those rows, dp.py).
 Images shard over ranks (weak scaling: every rank runs its own batch of 2).
 
 Prints ONE JSON line (rank 0): metric images/s + "roofline" (dominant kernel, timed live with HIP events
@@ -63,23 +64,6 @@ def make_inputs(dev, seed):
     feats = [torch.randn((BATCH, C, h, w), generator=g).to(dev) for h, w in LEVELS]
     rois = torch.randn((BATCH * ROIS_PER_IMG, C, 7, 7), generator=g).to(dev)
     return feats, rois
-
-
-def detections_from_heads(cls_logits, box_deltas, max_det=100):
-    """stock-torch stand-in for the tail of postprocess_detections (roi_heads.py:1075-1176): softmax,
-    best foreground class, top-`max_det` RoIs per image -> fixed-size payload for the all-gather"""
-    scores = torch.softmax(cls_logits, -1)[:, 1:]
-    best, lab = scores.max(dim=1)
-    best = best.view(BATCH, ROIS_PER_IMG)
-    lab = lab.view(BATCH, ROIS_PER_IMG) + 1
-    top, idx = best.topk(max_det, dim=1, sorted=False)       # the payload's order is free (the exchange is a gather)
-    deltas = box_deltas.view(BATCH, ROIS_PER_IMG, -1, 4)
-    li = lab.gather(1, idx)
-    boxes = deltas.gather(1, idx[:, :, None, None].expand(-1, -1, deltas.shape[2], 4))
-    boxes = boxes.gather(2, li[:, :, None, None].expand(-1, -1, 1, 4)).squeeze(2)
-    payload = torch.cat([boxes, top[:, :, None], li[:, :, None].to(torch.float32)], dim=2).contiguous()
-    counts = torch.full((BATCH,), max_det, dtype=torch.int32, device=payload.device)
-    return payload, counts
 
 
 def cpu_baseline():
@@ -147,7 +131,7 @@ def main():
         if wl["spike_rates"]:            # the spike-rate variants return rate tensors only (faster_rcnn.py:520-618)
             return rpn_out, det_out
         cls, deltas = det_out
-        payload, counts = detections_from_heads(cls, deltas)
+        payload, counts = ops.det_exchange_payload(cls, deltas, BATCH, 100)     # top-100 RoIs per image, one launch
         return dp.all_gather_detection_tensors(payload, counts)  # no-op at world == 1
 
     def fence():

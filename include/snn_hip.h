@@ -198,6 +198,15 @@ int snn_det_postprocess(const float* class_logits, const float* box_regression, 
                         float* all_scores, float* all_boxes, float* out_boxes, float* out_scores, int* out_labels,
                         int* out_counts, int out_cap, void* workspace, size_t workspace_bytes, snn_stream_t stream);
 
+/* ---- exchange payload of the data-parallel path: what each rank hands to the ONE all-gather of a batch (the reference's
+ * counterpart is the pickled all_gather_object of coco_eval.py:158-177, disabled under NCCL at train.py:874-880).  Per
+ * image the max_det RoIs with the highest foreground score (softmax over K, best class >= 1; the selection of
+ * roi_heads.py:1103-1110 without NMS) as rows (the 4 regression values of that class, score, label) by decreasing
+ * score, ties by RoI index; counts[i] = min(max_det, rois_per_image).  One launch; rois_per_image <= 4096. */
+int snn_det_exchange_payload(const float* class_logits /* [N*rois_per_image][K] */,
+                             const float* box_regression /* [N*rois_per_image][4K] */, int N, int rois_per_image, int K,
+                             int max_det, float* payload /* [N][max_det][6] */, int* counts /* [N] */, snn_stream_t stream);
+
 /* ---- stage-level entry points (parity tests drive the layers one by one, teacher-forced) ----- */
 /* constant-current LIF encoder -> bit-planes.  NCHW feature map -> planes[T][N*H*W][Cw]          */
 int snn_encode_nchw(const float* feat, int N, int C, int H, int W, int T, const snn_params* p_host,

@@ -77,6 +77,8 @@ SYMBOLS = {
     "snn_det_postprocess": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float,
                                       C.c_float, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, c_stream]),
+    "snn_det_exchange_payload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                           c_stream]),
     "snn_nms_sorted": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.c_size_t, c_stream]),
     "snn_roi_align_encode": (C.c_int, [C.POINTER(snn_roi_level), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -2230,6 +2230,67 @@ static const void* g3_kernel(int mt, int wn) {
                                                                                 : (const void*)k_gemm_bf16x3<MODE, G3_NB1, 2, 1>;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Exchange payload of the data-parallel path: per image the max_det RoIs with the highest foreground score
+// (softmax over K, best class >= 1) as rows (the 4 regression values of that class, score, label), by decreasing score,
+// ties by RoI index.  One work-group per image: scores -> 64-bit keys (score bits | 0xFFFF - RoI | label) -> bitonic
+// sort in LDS -> gather.  Replaces ~12 small torch launches per batch in front of the all-gather.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_det_payload(const float* __restrict__ cls, const float* __restrict__ reg, int Rn,
+                                                     int K, int max_det, int npad, float* __restrict__ payload,
+                                                     int* __restrict__ counts) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long* const keys = reinterpret_cast<unsigned long long*>(smem);
+    const int img = blockIdx.x, tid = threadIdx.x;
+    const size_t base = (size_t)img * Rn;
+    for (int r = tid; r < npad; r += 256) {
+        unsigned long long key = 0ull;                          // padding sorts last
+        if (r < Rn) {
+            const float* l = cls + (base + r) * K;
+            float m = l[0];
+            for (int c = 1; c < K; ++c) m = fmaxf(m, l[c]);
+            float sum = 0.0f, best = -1.0f;
+            int lab = 1;
+            for (int c = 0; c < K; ++c) {
+                const float e = expf(l[c] - m);
+                sum += e;
+                if (c >= 1 && e > best) { best = e; lab = c; }
+            }
+            const float score = best / sum;                     // > 0
+            key = ((unsigned long long)__float_as_uint(score) << 32) | ((unsigned long long)(0xFFFFu - (unsigned)r) << 16) | (unsigned)lab;
+        }
+        keys[r] = key;
+    }
+    __syncthreads();
+    for (int k = 2; k <= npad; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < npad; i += 256) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned long long a = keys[i], b = keys[ixj];
+                    const bool desc = (i & k) == 0;             // descending overall
+                    if (desc ? a < b : a > b) { keys[i] = b; keys[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    const int n = min(max_det, Rn);
+    for (int t = tid; t < max_det; t += 256) {
+        float* out = payload + ((size_t)img * max_det + t) * 6;
+        if (t < n) {
+            const unsigned long long key = keys[t];
+            const int r = 0xFFFF - (int)((key >> 16) & 0xFFFFu), lab = (int)(key & 0xFFFFu);
+            const float* d = reg + (base + r) * 4 * K + 4 * lab;
+            out[0] = d[0]; out[1] = d[1]; out[2] = d[2]; out[3] = d[3];
+            out[4] = __uint_as_float((uint32_t)(key >> 32));
+            out[5] = (float)lab;
+        } else {
+            for (int q = 0; q < 6; ++q) out[q] = 0.0f;
+        }
+    }
+    if (tid == 0) counts[img] = n;
+}
+
 extern "C" {
 
 int snn_version(void) { return 1; }
@@ -3207,6 +3268,19 @@ int snn_det_head_forward_roialign(const snn_roi_level* levels_host, int n_levels
     if (rc) return rc;
     return det_head_from_planes(R, D, Hd, K, K4, T, p, w6_packed, w7_packed, w_heads_packed, out_cls, out_bbox,
                                 spk6_count, spk7_count, sum_cls, sum_bbox, ws, stream);
+}
+
+int snn_det_exchange_payload(const float* class_logits, const float* box_regression, int N, int rois_per_image, int K,
+                             int max_det, float* payload, int* counts, snn_stream_t s) {
+    if (!class_logits || !box_regression || !payload || !counts || N <= 0 || rois_per_image <= 0 || K < 2 || max_det <= 0)
+        return fail(-1, "snn_det_exchange_payload: bad argument");
+    if (rois_per_image > 4096 || K > 0xFFFF) return fail(-4, "snn_det_exchange_payload: %d RoIs per image (max 4096)", rois_per_image);
+    int npad = 256;
+    while (npad < rois_per_image) npad <<= 1;
+    hipLaunchKernelGGL(k_det_payload, dim3(N), dim3(256), (size_t)npad * 8, (hipStream_t)s, class_logits, box_regression,
+                       rois_per_image, K, max_det, npad, payload, counts);
+    SNN_CHECK_LAUNCH("k_det_payload");
+    return 0;
 }
 
 }  // extern "C"

@@ -311,6 +311,24 @@ def lif_scan(cur: torch.Tensor, N: int, p: snn_params, want_counts: bool = False
     return (spk, counts) if want_counts else spk
 
 
+def det_exchange_payload(class_logits: torch.Tensor, box_regression: torch.Tensor, n_images: int, max_det: int = 100):
+    """the rows each rank hands to the batch's one all-gather (dp.all_gather_detection_tensors): per image the `max_det`
+    RoIs with the highest foreground score as (4 regression values of the best class, score, label), by decreasing score.
+    class_logits [N*R, K], box_regression [N*R, 4K] -> payload [N, max_det, 6] fp32, counts [N] int32 (one launch)"""
+    _need_gpu(class_logits, "class logits")
+    lib = _lib.load()
+    RN, K = class_logits.shape
+    if RN % n_images or tuple(box_regression.shape) != (RN, 4 * K):
+        raise _lib.SnnHipError("det_exchange_payload: %d rows for %d images / box_regression %s" % (RN, n_images, tuple(box_regression.shape)))
+    cls = class_logits.contiguous().float()
+    reg = box_regression.contiguous().float()
+    payload = torch.empty((n_images, max_det, 6), dtype=torch.float32, device=cls.device)
+    counts = torch.empty((n_images,), dtype=torch.int32, device=cls.device)
+    _lib.check(lib.snn_det_exchange_payload(_ptr(cls), _ptr(reg), n_images, RN // n_images, K, max_det, _ptr(payload),
+                                            _ptr(counts), _stream()), "snn_det_exchange_payload")
+    return payload, counts
+
+
 def li_heads(spk: torch.Tensor, K: int, w_heads_packed: torch.Tensor, NA: int, NB: int, p: snn_params,
              want_sums: bool = False):
     _need_gpu(spk, "spike planes")

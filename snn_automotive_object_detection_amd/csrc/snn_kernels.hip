@@ -2236,46 +2236,67 @@ static const void* g3_kernel(int mt, int wn) {
 // ties by RoI index.  One work-group per image: scores -> 64-bit keys (score bits | 0xFFFF - RoI | label) -> bitonic
 // sort in LDS -> gather.  Replaces ~12 small torch launches per batch in front of the all-gather.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_det_payload(const float* __restrict__ cls, const float* __restrict__ reg, int Rn,
-                                                     int K, int max_det, int npad, float* __restrict__ payload,
-                                                     int* __restrict__ counts) {
+__device__ __forceinline__ unsigned long long det_payload_key(const float* __restrict__ l, int K, int r) {
+    float m = l[0];
+    for (int c = 1; c < K; ++c) m = fmaxf(m, l[c]);
+    float sum = 0.0f, best = -1.0f;
+    int lab = 1;
+    for (int c = 0; c < K; ++c) {
+        const float e = expf(l[c] - m);
+        sum += e;
+        if (c >= 1 && e > best) { best = e; lab = c; }
+    }
+    const float score = best / sum;                             // > 0
+    return ((unsigned long long)__float_as_uint(score) << 32) | ((unsigned long long)(0xFFFFu - (unsigned)r) << 16) | (unsigned)lab;
+}
+
+// E = keys per thread (npad = E * blockDim.x).  E == 1: the key lives in a register, partners closer than a wave are
+// exchanged by lane shuffles (45 of the 55 stages at 1024 keys need no barrier).
+template <int E>
+__global__ __launch_bounds__(1024) void k_det_payload(const float* __restrict__ cls, const float* __restrict__ reg, int Rn,
+                                                      int K, int max_det, int npad, float* __restrict__ payload,
+                                                      int* __restrict__ counts) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long* const keys = reinterpret_cast<unsigned long long*>(smem);
-    const int img = blockIdx.x, tid = threadIdx.x;
+    const int img = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
     const size_t base = (size_t)img * Rn;
-    for (int r = tid; r < npad; r += 256) {
-        unsigned long long key = 0ull;                          // padding sorts last
-        if (r < Rn) {
-            const float* l = cls + (base + r) * K;
-            float m = l[0];
-            for (int c = 1; c < K; ++c) m = fmaxf(m, l[c]);
-            float sum = 0.0f, best = -1.0f;
-            int lab = 1;
-            for (int c = 0; c < K; ++c) {
-                const float e = expf(l[c] - m);
-                sum += e;
-                if (c >= 1 && e > best) { best = e; lab = c; }
-            }
-            const float score = best / sum;                     // > 0
-            key = ((unsigned long long)__float_as_uint(score) << 32) | ((unsigned long long)(0xFFFFu - (unsigned)r) << 16) | (unsigned)lab;
-        }
-        keys[r] = key;
-    }
-    __syncthreads();
-    for (int k = 2; k <= npad; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < npad; i += 256) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const unsigned long long a = keys[i], b = keys[ixj];
-                    const bool desc = (i & k) == 0;             // descending overall
-                    if (desc ? a < b : a > b) { keys[i] = b; keys[ixj] = a; }
+    if (E == 1) {
+        unsigned long long key = tid < Rn ? det_payload_key(cls + (base + tid) * K, K, tid) : 0ull;   // padding sorts last
+        for (int k = 2; k <= npad; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                unsigned long long other;
+                if (j < 64) {
+                    other = __shfl_xor(key, j);
+                } else {
+                    __syncthreads();
+                    keys[tid] = key;
+                    __syncthreads();
+                    other = keys[tid ^ j];
                 }
+                const bool desc = (tid & k) == 0, lower = (tid & j) == 0;
+                const bool take_max = desc == lower;            // descending overall
+                key = take_max ? (key > other ? key : other) : (key < other ? key : other);
             }
-            __syncthreads();
-        }
+        __syncthreads();
+        keys[tid] = key;
+        __syncthreads();
+    } else {
+        for (int r = tid; r < npad; r += nthr) keys[r] = r < Rn ? det_payload_key(cls + (base + r) * K, K, r) : 0ull;
+        __syncthreads();
+        for (int k = 2; k <= npad; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = tid; i < npad; i += nthr) {
+                    const int ixj = i ^ j;
+                    if (ixj > i) {
+                        const unsigned long long a = keys[i], b = keys[ixj];
+                        if ((i & k) == 0 ? a < b : a > b) { keys[i] = b; keys[ixj] = a; }
+                    }
+                }
+                __syncthreads();
+            }
+    }
     const int n = min(max_det, Rn);
-    for (int t = tid; t < max_det; t += 256) {
+    for (int t = tid; t < max_det; t += nthr) {
         float* out = payload + ((size_t)img * max_det + t) * 6;
         if (t < n) {
             const unsigned long long key = keys[t];
@@ -3275,10 +3296,14 @@ int snn_det_exchange_payload(const float* class_logits, const float* box_regress
     if (!class_logits || !box_regression || !payload || !counts || N <= 0 || rois_per_image <= 0 || K < 2 || max_det <= 0)
         return fail(-1, "snn_det_exchange_payload: bad argument");
     if (rois_per_image > 4096 || K > 0xFFFF) return fail(-4, "snn_det_exchange_payload: %d RoIs per image (max 4096)", rois_per_image);
-    int npad = 256;
+    int npad = 64;
     while (npad < rois_per_image) npad <<= 1;
-    hipLaunchKernelGGL(k_det_payload, dim3(N), dim3(256), (size_t)npad * 8, (hipStream_t)s, class_logits, box_regression,
-                       rois_per_image, K, max_det, npad, payload, counts);
+    if (npad <= 1024)
+        hipLaunchKernelGGL(k_det_payload<1>, dim3(N), dim3(npad), (size_t)npad * 8, (hipStream_t)s, class_logits,
+                           box_regression, rois_per_image, K, max_det, npad, payload, counts);
+    else
+        hipLaunchKernelGGL(k_det_payload<4>, dim3(N), dim3(1024), (size_t)npad * 8, (hipStream_t)s, class_logits,
+                           box_regression, rois_per_image, K, max_det, npad, payload, counts);
     SNN_CHECK_LAUNCH("k_det_payload");
     return 0;
 }

@@ -2854,8 +2854,18 @@ int snn_li_heads(const uint32_t* spk, size_t spk_stride, int T, int M, int K, co
                          : nt == 3 ? (const void*)k_li_heads_mfma<3> : (const void*)k_li_heads_mfma<4>;
         hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fail(-3, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-        // resident weights: persistent work-groups (staging once per work-group); streamed: one row group each
-        const int grid = a.resident ? min(a.n_groups, 4 * g3_slots()) : a.n_groups;
+        // resident weights: persistent work-groups (staging once per work-group), exactly as many as are co-resident
+        // (registers allow 3 per SIMD: a grid of 4 per CU ran a third of them as a second, mostly empty round);
+        // streamed: one row group each
+        static int per_cu_cache[5] = {0, 0, 0, 0, 0};           // by column tiles; the LDS size of the resident form follows from them and Kw
+        static size_t per_cu_lds[5] = {0, 0, 0, 0, 0};
+        if (per_cu_cache[nt] == 0 || per_cu_lds[nt] != lds) {
+            int v = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, kern, 256, lds) != hipSuccess || v <= 0) v = 3;
+            per_cu_cache[nt] = v; per_cu_lds[nt] = lds;
+        }
+        const int per_cu = per_cu_cache[nt];
+        const int grid = a.resident ? min(a.n_groups, per_cu * g3_slots()) : a.n_groups;
         void* kargs[] = {(void*)&a};
         e = hipLaunchKernel(kern, dim3(grid), dim3(256), kargs, lds, (hipStream_t)s);
         if (e != hipSuccess) return fail(-3, "k_li_heads_mfma launch failed: %s", hipGetErrorString(e));

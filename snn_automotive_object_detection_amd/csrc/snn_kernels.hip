@@ -2424,6 +2424,11 @@ static int launch_gemm3(int mode, int mt, int wn, const Gemm3Args& a, hipStream_
     static_assert(2 * G3_TILE_BYTES(1) <= 160 * 1024 && 2 * G3_LDS(3, 2) <= 160 * 1024, "two work-groups per CU");
     hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return fail(-3, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+    if (getenv("SNN_DEBUG_OCC")) {                             // debug: co-resident work-groups per CU
+        int v = 0;
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, kern, 512, lds);
+        fprintf(stderr, "k_gemm_bf16x3 mode %d mt %d wn %d: lds %d B, %d work-groups per CU, grid %d\n", mode, mt, wn, lds, v, tiles * a.n_blocks);
+    }
     void* kargs[] = {(void*)&a};
     e = hipLaunchKernel(kern, dim3(tiles * a.n_blocks), dim3(512), kargs, lds, s);
     if (e != hipSuccess) return fail(-3, "k_gemm_bf16x3 launch failed: %s", hipGetErrorString(e));
@@ -2490,6 +2495,11 @@ static int launch_gemm_mx(int mode, MxArgs& a, hipStream_t s) {
     a.g.n_blocks = cdiv(a.g.Np, MX_BN);
     hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return fail(-3, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+    if (getenv("SNN_DEBUG_OCC")) {
+        int v = 0;
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, kern, 2048 / mw, lds);
+        fprintf(stderr, "k_gemm_mx mode %d mw %d: lds %d B, %d work-groups per CU, grid %d\n", mode, mw, lds, v, tiles * a.g.n_blocks);
+    }
     void* kargs[] = {(void*)&a};
     e = hipLaunchKernel(kern, dim3(tiles * a.g.n_blocks), dim3(2048 / mw), kargs, lds, s);
     if (e != hipSuccess) return fail(-3, "k_gemm_mx launch failed: %s", hipGetErrorString(e));

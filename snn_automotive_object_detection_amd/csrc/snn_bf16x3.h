@@ -1,0 +1,566 @@
+// exact bf16x3 family (default): k_gemm_bf16x3 - the four big contractions on the bf16 matrix cores with T-in-tile LIF
+// fusion (K3b) - and its weight packer.  Included by snn_kernels.hip.
+#pragma once
+
+// ------------------------------------------------------------------------------------------------
+// K3b: exact bf16x3 spike GEMM on the bf16 matrix cores (16x the fp32 MFMA rate, 3 MFMAs per product).
+//
+// Spikes are exactly {0,1} and every fp32 weight is exactly hi + mid + lo with three bf16 values, so
+//   A_bits x W  ==  A_bf16 x W_hi + A_bf16 x W_mid + A_bf16 x W_lo     (every product exact)
+// with fp32 accumulation inside v_mfma_f32_32x32x16_bf16.  Measured against fp64 the result is as accurate
+// as the fp32 MFMA chain (tools/bf16x3_numerics.hip: rms error 4.1e-8 vs 4.2e-8 at K=2304).
+//
+// cur[M][ldo] = A_bits[M][K] x W[K][N];   work-group = 8 waves = 256 rows x 128 columns, wave = 64 x 64
+// = 4 x 4 tiles of v_mfma_f32_16x16x32_bf16 (one 32-deep chunk = one k-step; in an LDS-fed loop with this
+// kernel's traffic the 16x16x32 shape sustains 2.47 PF against 1.90 PF for 32x32x16: tools/mfma_probe4.hip).
+// Per 32-deep chunk: B = 3 planes x 128 x 32 bf16 (24 KB) copied global->LDS, A = 256 spike words expanded
+// to bf16 in LDS (two 16-bit halves per row, one per thread); both double-buffered, one barrier per chunk.
+// LDS rows are 64 B (no padding) with an XOR swizzle of the 16-B units: conflict-free ds_read_b128 fragment
+// reads at 80 KB of LDS per work-group, so TWO work-groups share a CU and one's barrier/staging phase hides
+// behind the other's MFMAs.
+// CONV = true: row m = (t, position) and the chunk (tap, channel word) is gathered straight from the
+// encoder bit-planes (9 taps, zero outside the image) - the un-fused time-batched 3x3 convolution.
+// ------------------------------------------------------------------------------------------------
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+// LDS-DMA: 16 B per lane straight from global memory (wave-uniform 64-bit base + the lane's 32-bit byte offset)
+// into LDS at (wave-uniform byte address in M0) + 16*lane; no VGPR destination, completion is counted on vmcnt.
+// Issued as inline asm on purpose: once hipcc sees an LDS-DMA in flight it degrades every LDS wait of the loop to
+// s_waitcnt lgkmcnt(0) and puts vmcnt(0) in front of every ds_write (possible alias); hidden from it, the fragment
+// reads keep their exact counted waits.  The kernel waits for the DMA by hand (vmcnt(0) before the chunk barrier).
+// a wave-uniform pointer as an SGPR pair (inline asm "s" operands are not legalised by hipcc)
+__device__ __forceinline__ const void* sgpr_ptr(const void* p) {
+    const unsigned long long x = (unsigned long long)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)x), hi = __builtin_amdgcn_readfirstlane((uint32_t)(x >> 32));
+    return (const void*)(((unsigned long long)hi << 32) | lo);
+}
+// Three pieces (the three weight planes of a chunk) per call; s_nop 4 / s_nop 0: SGPR -> VMEM-base and M0 -> LDS-DMA
+// wait states, which hipcc's hazard recogniser does not insert inside inline asm.
+__device__ __forceinline__ void glds16(const void* p0, uint32_t voff, uint32_t d0) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(p0), "s"(d0) : "memory", "m0");
+}
+__device__ __forceinline__ void glds16x3(const void* p0, const void* p1, const void* p2, uint32_t voff,
+                                         uint32_t d0, uint32_t d1, uint32_t d2) {
+    asm volatile("s_mov_b32 m0, %4\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1\n\t"
+                 "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2\n\t"
+                 "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %3"
+                 :: "v"(voff), "s"(p0), "s"(p1), "s"(p2), "s"(d0), "s"(d1), "s"(d2) : "memory", "m0");
+}
+
+// Work-group tile: the 8 waves form (8 / WN) x WN; a wave is 16*MT rows x 64 columns.
+//   WN = 2: 64*MT rows x 128 columns (256 x 128 at MT = 4): 24 KB of weight planes per chunk
+//   WN = 1: 128*MT rows x 64 columns (512 x 64):            12 KB per chunk for the same MFMA work - half the L2 -> LDS
+//           copies per FLOP (the 256 x 128 tile pulls 14 B/clk/CU = 7 TB/s chip-wide out of the L2).  Measured equal.
+#define G3_BM(wn, mt) ((8 / (wn)) * 16 * (mt))
+#define G3_BN(wn) (64 * (wn))
+#define G3_ROWB 64                                  // bytes per LDS weight row: 32 bf16, four 16-B units, XOR-swizzled
+#define G3_AW_BYTES(wn) (G3_BM(wn, 4) * 4)          // raw spike words of one chunk (one per row): 1 or 2 KB
+#define G3_B_BYTES(wn) (3 * G3_BN(wn) * G3_ROWB)    // three weight planes of one chunk: 24 or 12 KB
+#define G3_SLOT(wn) (G3_AW_BYTES(wn) + G3_B_BYTES(wn))   // one ring slot = one 32-deep chunk
+#define G3_LUT_BYTES 4096                           // byte -> 8 bf16 (0 / 1.0) expansion table
+#define G3_STATE_BYTES (512 * 64)                   // register-fused variant: 16 LIF state values per thread
+#define G3_LDS(nb, wn) (G3_LUT_BYTES + (nb) * G3_SLOT(wn))   // table at offset 0, then the ring (3 slots: 80896 / 47104 B)
+// unit u (= k-group 8u..8u+7) of weight row r lives at physical unit u ^ swz(r), swz = [0,3,2,1][(r >> 2) & 3].  A
+// 16x16x32 fragment read has lane l on row l&15, unit l>>4; the four 16-lane groups of a ds_read_b128
+// ({0-3,12-15,20-27}, {4-11,16-19,28-31}, +32) then each hit 16 distinct 16-B slots of the 256-B bank row.
+#define G3_SWZ(r) ((0 - ((r) >> 2)) & 3)
+
+struct Gemm3Args {
+    const uint32_t* A;           // fc: [M][Kw] spike words;  conv: encoder planes [T][P][Cw]
+    const uint16_t* wpk;         // [3][Kc][Np][32] bf16
+    float* out;                  // [M][ldo]
+    unsigned long long plane_elems;     // Kc*Np*32
+    unsigned long long enc_stride;      // conv: words per time plane
+    int M, Kc, Np, ldo, n_blocks;
+    int Cw, P_total, n_levels;          // conv only
+    // conv + LIF: spikes leave as bit-planes.  G3_CONV_LIF_REG: rows are positions, the T loop runs inside;
+    // G3_CONV_LIF_TILE: a 256-row tile = all T time steps of pb = 256/T positions (row = t*pb + position)
+    int T, pb;
+    uint32_t* spk;
+    unsigned long long spk_stride;
+    NeuronP p;
+    ConvLevelDev lv[SNN_MAX_LEVELS];
+};
+
+__device__ __forceinline__ uint32_t bf16_pair(uint32_t w, int j) {      // bits 2j, 2j+1 -> two bf16 (0 / 1.0)
+    const uint32_t t = (w >> (2 * j)) & 3u;
+    return ((t | (t << 15)) & 0x10001u) * 0x3F80u;
+}
+
+// FUSE (conv only): M = positions; per time step the 9*Cw chunks are accumulated, then the LIF update runs
+// on the accumulators in registers and only spike bits are written.
+//
+// LDS: a 4-KB table byte -> 8 bf16, a ring of NB slots (one 32-deep chunk each: 256 raw spike words + 3 weight
+// planes), and for FUSE 16 LIF state values per thread.  Staging runs ahead, so the slot of chunk c+1 is already
+// complete during chunk c and the first fragments of chunk c+1 are read from LDS BEFORE the barrier that ends chunk
+// c - the matrix pipe does not drain at the barrier.
+// NB = 3 (80 KB, two work-groups per CU): the weight planes of chunk c+2 are copied during chunk c and must have
+// landed at its end (s_waitcnt vmcnt(0)).  NB = 4 (fused variant, which owns its CU): the planes of chunk c+3 are
+// copied during chunk c and need to land only by the end of chunk c+1 (s_waitcnt vmcnt(3): the three youngest
+// operations, this chunk's copies, stay in flight across the barrier) - no L2 latency is ever waited for.
+// The A (spike) fragment of a lane is 8 consecutive k of one row = ONE BYTE of that row's spike word: it is fetched
+// as table[byte] by a single ds_read_b128.  No expanded spike image is ever built (the first version spent 36 VALU
+// instructions + 2 ds_write_b128 per thread and chunk on it, 10 % of the kernel: every VALU instruction beside
+// v_mfma_f32_16x16x32_bf16 competes for the SIMD's vector issue, which the MFMAs alone hold half of the time).
+// PD = fragment prefetch distance inside a chunk, in groups of 4 MFMAs (one weight fragment per group).
+enum { G3_FC = 0, G3_CONV = 1, G3_CONV_LIF_REG = 2, G3_CONV_LIF_TILE = 3, G3_FC_LIF_TILE = 4 };
+// LIF_TILE epilogue: the current tile goes through LDS in two passes of CG = 32*WN columns, row pitch CG + 4 floats
+// (conflict-free for the accumulator writes and the column reads)
+#define G3_TILE_CG(wn) (32 * (wn))
+#define G3_TILE_BYTES(wn) (G3_BM(wn, 4) * (G3_TILE_CG(wn) + 4) * 4)     // 69632 / 73728 B
+
+// MT = 16-row M-tiles per wave: the work-group tile is 64*MT rows (256; 192 / 128 only where a small problem spreads
+// better over the CUs that way - per unit of work the smaller tiles are slower: fc6 1.03 / 1.07 / 1.21 ms at MT 4 / 3 / 2).
+template <int MODE, int NB, int MT, int WN>
+__global__ __launch_bounds__(512, MODE == G3_CONV_LIF_REG ? 2 : 4) void k_gemm_bf16x3(const Gemm3Args args) {
+    constexpr bool CONV = MODE == G3_CONV || MODE == G3_CONV_LIF_REG || MODE == G3_CONV_LIF_TILE;
+    constexpr bool FUSE = MODE == G3_CONV_LIF_REG, TILE = MODE == G3_CONV_LIF_TILE || MODE == G3_FC_LIF_TILE;
+    static_assert(MT >= 2 && MT <= 4 && (MT == 4 || !FUSE), "M-tiles per wave");
+    static_assert(WN == 1 || (WN == 2 && true), "waves along N");
+    static_assert(WN == 2 || !FUSE, "the register-fused variant keeps the 4 x 2 wave grid");
+    constexpr int BM = G3_BM(WN, MT), BN = G3_BN(WN), WROWS = 16 * MT;   // rows, columns per work-group; rows per wave
+    constexpr int AW_BYTES = G3_AW_BYTES(WN);
+    static_assert(NB == 3 || NB == 4, "ring depth");
+    constexpr int SLOT = G3_SLOT(WN);
+    constexpr int PD = (CONV && !FUSE) ? 2 : 3, RING = PD + 1;  // 12 groups per chunk: RING must divide 12 (the 128-register conv
+                                                               // rows have 128 registers: one fragment less in flight)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    unsigned char* const lut = smem;                // table at LDS offset 0: a fragment address is just (byte << 4)
+    unsigned char* const ring = smem + G3_LUT_BYTES;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    // Plain row-major tile order, column block fastest: work-group b runs on XCD b % 8 (round-robin dispatch), so with
+    // 2 (or 4, 8) column blocks every XCD only ever sees ONE weight panel - half of the 3.5 MB of conv weight planes,
+    // which then stay resident in its 4-MB L2 beside the streaming spike planes.  Both re-orderings tried (each XCD a
+    // contiguous eighth of the tiles; both column blocks of a tile on one XCD) put all panels on every XCD and
+    // multiplied the L2 fills: FETCH_SIZE 102 -> 323 / 535 MB per launch at unchanged kernel time (profiles/r1_h_*).
+    const int nb = blockIdx.x % args.n_blocks;
+    const int mb = blockIdx.x / args.n_blocks;
+    const int m0 = TILE ? mb * args.pb : mb * BM;            // first row (TILE: first position) of the tile
+    const int Kc = args.Kc, Np = args.Np, M = args.M;
+
+    if (tid < 256) {                                // table entry e: element j = bit j of e as bf16
+        uint4 q;
+        q.x = bf16_pair(tid, 0); q.y = bf16_pair(tid, 1); q.z = bf16_pair(tid, 2); q.w = bf16_pair(tid, 3);
+        *reinterpret_cast<uint4*>(lut + tid * 16) = q;
+    }
+
+    // ---- A staging role: thread -> row (the first BM threads).  A spike word is addressed as (wave-uniform 64-bit
+    // base in SGPRs) + (32-bit byte offset of the lane's row): no per-chunk 64-bit vector arithmetic ----
+    const bool a_role = wave * 64 < BM;
+    const int xrow = tid & (G3_BM(WN, 4) - 1);
+    const int xt = TILE ? xrow / args.pb : 0;       // TILE: time step of the row
+    const int xm = TILE ? (xt < args.T ? m0 + xrow % args.pb : M) : m0 + xrow;
+    uint32_t a_off = 0;                             // bytes: fc row / conv centre tap, channel word 0
+    int a_pitch = 0;                                // conv: bytes per image row of the lane's pyramid level
+    uint32_t a_valid = 0;                           // conv: 9-bit tap validity
+    if (CONV) {
+        if (xm < M) {
+            const int t = FUSE ? 0 : (TILE ? xt : xm / args.P_total), p = (FUSE || TILE) ? xm : xm % args.P_total;
+            int l = 0;
+            while (l + 1 < args.n_levels && p >= args.lv[l + 1].pos_base) ++l;
+            const int H = args.lv[l].H, W = args.lv[l].W;
+            const int local = p - args.lv[l].pos_base;
+            const int rem = local % (H * W);
+            const int y = rem / W, x = rem % W;
+            a_off = (uint32_t)(((size_t)t * args.enc_stride + (size_t)p * args.Cw) * 4);
+            a_pitch = W * args.Cw * 4;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+                a_valid |= (uint32_t)(yy >= 0 && yy < H && xx >= 0 && xx < W) << tap;
+            }
+        }
+    } else if (TILE) {                              // fc rows of the spike planes [T][M][Kc]; unused tile rows read row 0
+        a_off = xm < M ? (uint32_t)(((size_t)xt * M + xm) * Kc * 4) : 0u;
+    } else {
+        a_off = (uint32_t)((size_t)min(xm, M - 1) * Kc * 4);
+    }
+    // Spike-word loads are issued as inline asm: hipcc must not see them, or it drains the LDS-DMA queue
+    // (vmcnt(0)) at their first use while weight planes are still in flight.  A word is consumed only after the
+    // s_waitcnt vmcnt(0) that ends the chunk it was issued in.
+    // The fetch stream walks the chunk sequence (t, tap dy, tap dx, channel word) with scalar counters.
+    // (s_nop 4: an SGPR written by SALU / v_readfirstlane needs 5 wait states before a VMEM instruction reads it as
+    // its base address, and hipcc's hazard recogniser does not look into inline asm.)
+    // The stream is a running scalar pointer: within one tap row (dy) the wave-uniform word offset dx*Cw + cc just
+    // increments by one per chunk; every 3*Cw chunks the lanes step one image row down, every Kc chunks one time
+    // step on.  Past the last chunk the stream wraps to the start (staged, never multiplied).
+    const int n_steps = FUSE ? args.T : 1;
+    const uint32_t* f_tbase = args.A;               // scalar: A + t*enc_stride
+    int f_off = CONV ? -args.Cw : 0;                // scalar: dx*Cw + cc   (fc: kc)
+    uint32_t f_voff = CONV ? a_off - (uint32_t)a_pitch : a_off;     // lane: row offset of tap row dy
+    uint32_t f_mask = 1u;                           // conv: bit of the current tap
+    int f_t = 0, f_kc = 0, f_cc = 0, f_dx = 0;
+    auto fetch_next = [&](uint32_t& w) {
+        w = 0u;
+        const void* sbase = sgpr_ptr(f_tbase + f_off);
+        if (CONV) {
+            if (a_role && (a_valid & f_mask))
+                asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "+v"(w) : "v"(f_voff), "s"(sbase) : "memory");
+        } else {
+            if (a_role) asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "+v"(w) : "v"(f_voff), "s"(sbase) : "memory");
+        }
+        ++f_off;
+        if (CONV && ++f_cc == args.Cw) {
+            f_cc = 0;
+            f_mask <<= 1;
+            if (++f_dx == 3) { f_dx = 0; f_off -= 3 * args.Cw; f_voff += (uint32_t)a_pitch; }
+        }
+        if (++f_kc == Kc) {
+            f_kc = 0; f_cc = 0; f_dx = 0; f_mask = 1u;
+            f_off = CONV ? -args.Cw : 0;
+            if (++f_t == n_steps) f_t = 0;
+            f_tbase = args.A + (FUSE ? (size_t)f_t * args.enc_stride : 0);
+            f_voff = CONV ? a_off - (uint32_t)a_pitch : a_off;
+        }
+    };
+    auto store_w = [&](uint32_t w, uint32_t slot_off) {     // the raw spike word of the thread's row
+        if (a_role) {
+            uint32_t l;                             // lane id, re-derived (2 VALU) instead of a register held all loop
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+            *reinterpret_cast<uint32_t*>(ring + slot_off + wave * 256 + l * 4) = w;
+        }
+    };
+
+    // ---- B staging: LDS-DMA, one 1-KiB piece (16 rows of one plane) per instruction; the 3 * BN/16 pieces of a chunk
+    // go round the 8 waves (piece p = wave, wave + 8, wave + 16: all of them on row block wave % (BN/16)).  Lane L
+    // lands in physical unit L&3 of row (L>>2) of the piece, so it fetches logical unit (L&3) ^ swz(row): the swizzle
+    // is applied on the SOURCE address, the LDS image stays lane-linear ----
+    constexpr int RBLK = BN / 16, NPIECE = 3 * RBLK;            // row blocks per plane, pieces per chunk (24 / 12)
+    const int brow = (wave % RBLK) * 16 + (lane >> 2);
+    const int bcol = min(nb * BN + brow, Np - 1);               // columns past Np: any valid row (never stored)
+    const uint32_t b_off = (uint32_t)(bcol * 64 + (((lane & 3) ^ G3_SWZ(brow)) << 4));     // bytes within a chunk plane
+    const unsigned long long b_chunk = (unsigned long long)Np * 64, b_plane = args.plane_elems * 2;   // bytes
+    unsigned long long s_ptr = (unsigned long long)args.wpk;   // weight stream: plane 0 of the next chunk (scalar)
+    int s_kc = 0;
+    const uint32_t b_dst = smem_base + G3_LUT_BYTES + AW_BYTES + (wave % RBLK) * 1024;      // + slot offset, plane
+    auto stage_next = [&](uint32_t slot_off) {
+        const uint32_t d = __builtin_amdgcn_readfirstlane(b_dst + slot_off);                // wave-uniform LDS address
+        if (WN == 2) {
+            glds16x3(sgpr_ptr(reinterpret_cast<const void*>(s_ptr)), sgpr_ptr(reinterpret_cast<const void*>(s_ptr + b_plane)),
+                     sgpr_ptr(reinterpret_cast<const void*>(s_ptr + 2 * b_plane)), b_off,
+                     d, d + BN * G3_ROWB, d + 2 * BN * G3_ROWB);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int piece = wave + 8 * j;                 // wave-uniform
+                if (piece < NPIECE) {
+                    const int pl = piece / RBLK;
+                    glds16(sgpr_ptr(reinterpret_cast<const void*>(s_ptr + pl * b_plane)), b_off, d + pl * (BN * G3_ROWB));
+                }
+            }
+        }
+        s_ptr += b_chunk;
+        if (++s_kc == Kc) { s_kc = 0; s_ptr = (unsigned long long)args.wpk; }
+    };
+
+    // 16x16 tiles: lane holds column lane&15, rows (lane>>4)*4 + reg of each tile
+    const int lr = lane & 15, lg = lane >> 4;
+    f32x4 acc[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    // A fragment: row (wm*64 + mt*16 + lr), k = 8*lg .. 8*lg+7  ->  table[byte lg of the row's spike word]
+    const unsigned char* const w_rd = ring + (wm * WROWS + lr) * 4;                          // + slot offset, mt*64
+    const int lg8 = 8 * lg;
+    auto rd_w = [&](uint32_t slot_off, int mt) { return *reinterpret_cast<const uint32_t*>(w_rd + slot_off + mt * 64); };
+    auto rd_a = [&](uint32_t w) { return *reinterpret_cast<const bf16x8*>(lut + (__builtin_amdgcn_ubfe(w, lg8, 8) << 4)); };
+    // B fragment: row (tile*16 + lr), logical unit lg; swz depends on lr only
+    const unsigned char* const b_rd = ring + AW_BYTES + (wn * 64 + lr) * G3_ROWB + ((lg ^ G3_SWZ(lr)) << 4);
+    // group g of a chunk = (N-tile g/3, plane 2 - g%3): per accumulator the small terms first (lo, mid, hi)
+    auto rd_b = [&](uint32_t slot_off, int g) {
+        return *reinterpret_cast<const bf16x8*>(b_rd + slot_off + (2 - g % 3) * (BN * G3_ROWB) + (g / 3) * 16 * G3_ROWB);
+    };
+
+    // LIF state of the fused variant, whole T loop: v (64 registers) and the synaptic current i (48 registers;
+    // the 16 values of M-tile 3 live in LDS, private to the thread, touched once per time step - they are what
+    // keeps the main loop free of scratch spills)
+    f32x4 v[FUSE ? 4 : 1][FUSE ? 4 : 1], ci[FUSE ? 3 : 1][FUSE ? 4 : 1];
+    f32x4* const ci_lds = reinterpret_cast<f32x4*>(smem + G3_LDS(NB, WN)) + tid;                    // [nt][512 threads]
+    if (FUSE) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                v[mt][nt] = f32x4{args.p.v_leak, args.p.v_leak, args.p.v_leak, args.p.v_leak};
+                if (mt < 3) ci[mt][nt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                else ci_lds[nt * 512] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            }
+    }
+    const int n_total = n_steps * Kc;
+
+    // Software pipeline over the chunk sequence c = (t, kc).  During chunk c:
+    //   the spike word of chunk c+3 is fetched from global memory (register),
+    //   the spike word of chunk c+2 (fetched during chunk c-1) and, by LDS-DMA, the weight planes of chunk c+2 go
+    //   into ring slot (c-1) mod NB (spike words: slot of chunk c+2),
+    //   the weight fragments of chunk c are read PD groups ahead of their MFMAs, the first ones of chunk c+1 and
+    //   its spike words / table fragments at the end of chunk c (that slot has been complete since the last barrier).
+    // One barrier per chunk; s_sched_barrier pins one fragment read + 4 MFMAs per group.
+#ifdef SNN_EXP_FILL_RING           // timing only: random bf16 bits in the whole ring (for the no-copy experiment)
+    for (int i = tid; i < NB * SLOT / 4; i += 512) {
+        uint32_t h = (uint32_t)i * 2654435761u + blockIdx.x * 40503u;
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        reinterpret_cast<uint32_t*>(ring)[i] = (h & 0x3fff3fffu) | 0x38003800u;      // two bf16 of magnitude ~1e-5 .. 1
+    }
+    __syncthreads();
+#endif
+    uint32_t w_hold, w_new;
+    {
+        uint32_t w0[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fetch_next(w0[j]);  // spike words of chunks 0, 1 -> slots 0, 1
+        fetch_next(w_hold);                             // chunk 2
+#pragma unroll
+        for (int j = 0; j < NB - 1; ++j) stage_next(j * SLOT);      // weight planes of chunks 0 .. NB-2
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            asm volatile("" : "+v"(w0[j]));             // the loaded value is only defined from here on
+            store_w(w0[j], j * SLOT);
+        }
+        asm volatile("" : "+v"(w_hold));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+    bf16x8 af[2][MT], bq[RING];
+    uint32_t wq[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) wq[mt] = rd_w(0, mt);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) af[0][mt] = rd_a(wq[mt]);
+#pragma unroll
+    for (int g = 0; g < PD; ++g) bq[g] = rd_b(0, g);
+
+    // ring slots (byte offsets) of chunks c, c+1, c+2 (receives its spike words now) and c+NB-1 (receives its planes)
+    uint32_t o_cur = 0, o_nxt = SLOT, o_nn = 2 * SLOT, o_wr = (NB - 1) * SLOT;
+    int kc = 0, t = 0;
+    for (int c0 = 0; c0 < n_total; c0 += 2) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (c0 + u >= n_total) break;
+#pragma unroll
+            for (int g = 0; g < 12; ++g) {
+                const int gp = g + PD;
+                bq[gp % RING] = gp < 12 ? rd_b(o_cur, gp) : rd_b(o_nxt, gp - 12);
+                if (g == 4) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) wq[mt] = rd_w(o_nxt, mt);
+                }
+                if (g >= 8 && g - 8 < MT) af[u ^ 1][g - 8] = rd_a(wq[g - 8]);
+#ifndef SNN_EXP_NO_STORE_A
+                if (g == 0) store_w(w_hold, o_nn);
+#endif
+                if (g == 2) {
+                    fetch_next(w_new);
+#ifndef SNN_EXP_NO_GLDS
+                    stage_next(o_wr);
+#endif
+                }
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[mt][g / 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u][mt], bq[g % RING], acc[mt][g / 3], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#ifndef SNN_EXP_NO_BARRIER
+            // weight planes landed (vmcnt), spike words written (lgkmcnt), everyone done reading slot `sl`.
+            // The s_waitcnt builtin (not inline asm) so that hipcc's own wait-count bookkeeping knows the prefetched
+            // fragments have arrived; the empty asm statements are compiler fences (neither builtin orders memory
+            // accesses for hipcc, which otherwise moves LDS reads across the barrier).
+            asm volatile("" ::: "memory");
+            // NB = 4: this chunk's own copies (the youngest vector-memory operations of the wave: 3, or 2 / 1 on the
+            // 8 x 1 wave grid) may stay in flight across the barrier
+            if (NB == 3) __builtin_amdgcn_s_waitcnt(0x0070);        // vmcnt(0) lgkmcnt(0)
+            else if (WN == 2) __builtin_amdgcn_s_waitcnt(0x0073);   // vmcnt(3) lgkmcnt(0)
+            else if (wave + 8 < NPIECE) __builtin_amdgcn_s_waitcnt(0x0072);   // vmcnt(2)
+            else __builtin_amdgcn_s_waitcnt(0x0071);                // vmcnt(1)
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+#endif
+            asm volatile("" : "+v"(w_new));
+            w_hold = w_new;
+            if (NB == 3) { const uint32_t o = o_cur; o_cur = o_nxt; o_nxt = o_nn; o_nn = o; o_wr = o; }
+            else { const uint32_t o = o_cur; o_cur = o_nxt; o_nxt = o_nn; o_nn = o_wr; o_wr = o; }
+            const bool step_done = ++kc == Kc;
+            if (step_done) kc = 0;
+            if (FUSE && step_done) {
+                // ---- LIF epilogue in registers.  A ballot over accumulator register (mt, nt, reg) holds, for each
+                // of the 4 row groups rg, 16 channel bits of position mt*16 + rg*4 + reg; N-tiles (0,1) and (2,3)
+                // pair up into the two 32-channel words of that position, which lane = position finally stores ----
+                uint32_t my0 = 0, my1 = 0;
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int np = 0; np < 2; ++np) {                   // N-tile pair -> word np of the position
+                        f32x4 vd[2], d[2];
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const int nt = 2 * np + q;
+                            if (mt < 3) {
+                                lif_decay4(acc[mt][nt], v[mt][nt], ci[mt][nt], args.p, vd[q], d[q]);
+                            } else {
+                                f32x4 i3 = ci_lds[nt * 512];
+                                lif_decay4(acc[mt][nt], v[mt][nt], i3, args.p, vd[q], d[q]);
+                                ci_lds[nt * 512] = i3;
+                            }
+                            acc[mt][nt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {                  // two ballots live at a time
+                            const bool z0 = d[0][r] > 0.0f, z1 = d[1][r] > 0.0f;
+                            const unsigned long long b0 = __ballot(z0), b1 = __ballot(z1);
+                            v[mt][2 * np][r] = z0 ? args.p.v_reset : vd[0][r];
+                            v[mt][2 * np + 1][r] = z1 ? args.p.v_reset : vd[1][r];
+#pragma unroll
+                            for (int rg = 0; rg < 4; ++rg) {
+                                const uint32_t w = (uint32_t)((b0 >> (16 * rg)) & 0xffffull) | ((uint32_t)((b1 >> (16 * rg)) & 0xffffull) << 16);
+                                // lane (mt*16 + rg*4 + r) keeps the two words of its position (rows >= M are never stored)
+                                if (np == 0) asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(my0) : "s"(w), "n"(mt * 16 + rg * 4 + r));
+                                else         asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(my1) : "s"(w), "n"(mt * 16 + rg * 4 + r));
+                            }
+                        }
+                    }
+                {
+                    const int row = m0 + wm * 64 + lane;                  // lane = position within the wave's 64 rows
+                    const int word0 = (nb * BN + wn * 64) >> 5;
+                    uint32_t* dst = args.spk + (size_t)t * args.spk_stride + (size_t)row * (Np >> 5) + word0;
+                    if (row < M) {
+                        if (word0 * 32 < Np) dst[0] = my0;
+                        if ((word0 + 1) * 32 < Np) dst[1] = my1;
+                    }
+                }
+                ++t;
+            }
+        }
+    }
+    if (FUSE) return;
+    if (TILE) {
+        // ---- LIF over the T time steps held in this tile.  The accumulators are the complete input currents
+        // cur[t][position][column] of pb positions; in two passes of CG = 32*WN columns they go through LDS (the ring
+        // is free now), where each thread runs neurons over t and the wave ballot of a step is the spike word(s):
+        //   WN = 2 (CG = 64): lane = column, wave w takes positions w, w+8, ...; ballot = the word pair of (t, position)
+        //   WN = 1 (CG = 32): lane = (position parity, column), wave w takes the position pairs; ballot = one word of
+        //                     the even position (low half) and one of the odd position (high half)
+        constexpr int CG = G3_TILE_CG(WN), PITCH = CG + 4;
+        float* const tile = reinterpret_cast<float*>(smem);
+        const int pb = args.pb, T = args.T;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // staged-ahead copies of chunks past the end have landed
+#pragma unroll 1
+        for (int h = 0; h < 2; ++h) {
+            __syncthreads();                               // ring reads done / previous pass consumed
+            if (WN == 1 || wn == h) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nq = 0; nq < CG / 16; ++nq) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float val;
+                            if (WN == 1) val = h == 0 ? acc[mt][nq][r] : acc[mt][2 + nq][r];
+                            else val = acc[mt][nq][r];
+                            tile[(wm * WROWS + mt * 16 + lg * 4 + r) * PITCH + nq * 16 + lr] = val;
+                        }
+                    }
+            }
+            __syncthreads();
+            const int word0 = (nb * BN + h * CG) >> 5;     // first output word of this pass
+            if (word0 * 32 >= Np) continue;                // block-uniform
+            if (WN == 2) {
+                const bool two = (word0 + 1) * 32 < Np;
+                for (int pi = wave; pi < pb; pi += 8) {    // wave-uniform
+                    const int pos = m0 + pi;
+                    if (pos >= M) break;
+                    float vv = args.p.v_leak, ii = 0.0f;
+                    uint32_t my0 = 0, my1 = 0;             // lane t keeps the word pair of time step t
+                    const float* src = tile + pi * PITCH + lane;
+                    for (int t = 0; t < T; ++t) {
+                        const bool z = lif_step(src[(size_t)t * pb * PITCH], vv, ii, args.p);
+                        const unsigned long long b = __ballot(z);
+                        my0 = lane == t ? (uint32_t)b : my0;
+                        my1 = lane == t ? (uint32_t)(b >> 32) : my1;
+                    }
+                    if (lane < T) {
+                        uint32_t* dst = args.spk + (size_t)lane * args.spk_stride + (size_t)pos * (Np >> 5) + word0;
+                        dst[0] = my0;
+                        if (two) dst[1] = my1;
+                    }
+                }
+            } else {
+                const int par = lane >> 5, col = lane & 31;
+                for (int pp = wave; 2 * pp < pb; pp += 8) {            // wave-uniform: position pair pp
+                    const int pi = 2 * pp + par;                       // this half-wave's position
+                    const bool live = pi < pb && m0 + pi < M;
+                    if (m0 + 2 * pp >= M) break;
+                    float vv = args.p.v_leak, ii = 0.0f;
+                    uint32_t my0 = 0, my1 = 0;             // lane t keeps the words of (t, even position), (t, odd position)
+                    const float* src = tile + (live ? pi : 2 * pp) * PITCH + col;
+                    for (int t = 0; t < T; ++t) {
+                        const bool z = lif_step(src[(size_t)t * pb * PITCH], vv, ii, args.p);
+                        const unsigned long long b = __ballot(z);
+                        my0 = lane == t ? (uint32_t)b : my0;
+                        my1 = lane == t ? (uint32_t)(b >> 32) : my1;
+                    }
+                    if (lane < T) {
+                        uint32_t* dst = args.spk + (size_t)lane * args.spk_stride + (size_t)(m0 + 2 * pp) * (Np >> 5) + word0;
+                        dst[0] = my0;
+                        if (2 * pp + 1 < pb && m0 + 2 * pp + 1 < M) dst[Np >> 5] = my1;
+                    }
+                }
+            }
+        }
+        return;
+    }
+    // ---- store currents: per instruction 4 rows x 16 columns (64-B row segments) ----
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int col = nb * BN + wn * 64 + nt * 16 + lr;
+            if (col >= Np) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * WROWS + mt * 16 + lg * 4 + r;
+                if (m < M) args.out[(size_t)m * args.ldo + col] = acc[mt][nt][r];
+            }
+        }
+}
+
+// fp32 weights -> three bf16 planes [3][Kc][Np][32]  (hi = rn(w), mid = rn(w - hi), lo = rn(w - hi - mid): exact)
+__device__ __forceinline__ uint16_t f2bf_rn(float f) {
+    uint32_t u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(uint16_t b) { return __uint_as_float((uint32_t)b << 16); }
+
+__global__ void k_pack_bf16x3(const float* __restrict__ src, uint16_t* __restrict__ dst, int mode, int K, int N,
+                              int Kc, int Np, int Cin, int Cp) {
+    const size_t plane = (size_t)Kc * Np * 32;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < plane; idx += (size_t)gridDim.x * blockDim.x) {
+        const int kk = idx & 31;
+        const size_t rest = idx >> 5;
+        const int n = (int)(rest % Np);
+        const int kc = (int)(rest / Np);
+        const int k = kc * 32 + kk;
+        float w = 0.0f;
+        if (n < N) {
+            if (mode == PACK_CONV3X3) {
+                const int tap = k / Cp, ci = k % Cp;
+                if (ci < Cin) w = src[((size_t)n * Cin + ci) * 9 + tap];
+            } else if (k < K) {
+                w = src[(size_t)n * K + k];
+            }
+        }
+        const uint16_t hi = f2bf_rn(w);
+        const float r1 = __fsub_rn(w, bf2f(hi));
+        const uint16_t mid = f2bf_rn(r1);
+        const float r2 = __fsub_rn(r1, bf2f(mid));
+        const uint16_t lo = f2bf_rn(r2);
+        dst[idx] = hi; dst[plane + idx] = mid; dst[2 * plane + idx] = lo;
+    }
+}

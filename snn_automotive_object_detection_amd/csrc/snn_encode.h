@@ -1,0 +1,231 @@
+// constant-current LIF encoders -> spike bit-planes: NCHW pyramid levels (K1a), row-major RoI features (K1b, K1b'),
+// and the RoIAlign-fused form (K1c).  Included by snn_kernels.hip.
+#pragma once
+
+// ------------------------------------------------------------------------------------------------
+// K1a: constant-current LIF encoder, NCHW fp32 -> bit-planes [T][N*HW][Cw]
+// Block = 32 positions x 8 channel words; thread = one position x 32 channels (reads coalesced along W, two 128-B
+// segments per wave instruction).  The T words of a thread go through LDS so that every plane store of the block is
+// one contiguous run of 32 positions x 8 words (1 KB at C = 256) instead of 4-byte pieces at a 32-byte pitch.
+// VALU-bound (32 x T encoder steps per thread): packed fp32 arithmetic, see enc_step2_word.
+// ------------------------------------------------------------------------------------------------
+#define ENC_PB 32                                   // positions per block
+// Wpad > 0: the planes carry a one-position zero halo around every image (row (n, y, x) -> (n*(H+2) + y+1)*(W+2) + x+1,
+// W = Wpad); the halo itself is zeroed by the caller.  The fp4 x fp6 conv kernel reads its 3x3 taps from such planes
+// without any border logic.
+template <bool ZR>
+__device__ __forceinline__ void encode_block(const float* __restrict__ feat, int C, int HW, int Cw, int T, const NeuronP& p,
+                                             uint32_t* __restrict__ planes, size_t plane_stride, int n, int bx, int by,
+                                             int Wpad = 0) {
+    __shared__ uint32_t wbuf[SNN_MAX_STEPS * ENC_PB * 9];      // [t][position][8 words + 1 pad]
+    const int pl = threadIdx.x & 31, cgl = threadIdx.x >> 5;
+    const int pos = bx * ENC_PB + pl;
+    const int cg = by * 8 + cgl;
+    float x[32], v[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        const int c = cg * 32 + j;
+        x[j] = (pos < HW && c < C) ? feat[((size_t)n * C + c) * HW + pos] : 0.0f;
+        v[j] = 0.0f;                              // rpn.py:93  v = zeros
+    }
+    for (int t = 0; t < T; ++t) {
+        uint32_t word = 0;
+#pragma unroll
+        for (int j = 31; j >= 0; --j) enc_step_word<ZR>(x[j], v[j], p, word);   // bit 31 first ... bit 0 last
+        wbuf[(t * ENC_PB + pl) * 9 + cgl] = word;
+    }
+    __syncthreads();
+    // store: thread -> (position tid >> 3, word tid & 7): consecutive threads write consecutive plane words
+    const int sp = threadIdx.x >> 3, sw = threadIdx.x & 7;
+    const int spos = bx * ENC_PB + sp, scg = by * 8 + sw;
+    if (spos < HW && scg < Cw) {
+        size_t row = (size_t)n * HW + spos;
+        if (Wpad) {
+            const int H = HW / Wpad, y = spos / Wpad, x = spos % Wpad;
+            row = ((size_t)n * (H + 2) + y + 1) * (Wpad + 2) + x + 1;
+        }
+        uint32_t* out = planes + row * Cw + scg;
+        for (int t = 0; t < T; ++t) out[(size_t)t * plane_stride] = wbuf[(t * ENC_PB + sp) * 9 + sw];
+    }
+}
+
+template <bool ZR>
+__global__ __launch_bounds__(256) void k_encode_nchw(const float* __restrict__ feat, int C, int HW, int Cw,
+                                                     int T, NeuronP p, uint32_t* __restrict__ planes,
+                                                     size_t plane_stride) {
+    encode_block<ZR>(feat, C, HW, Cw, T, p, planes, plane_stride, blockIdx.z, blockIdx.x, blockIdx.y);
+}
+
+// all pyramid levels of the RPN head in one launch (the small levels are launch-latency bound on their own)
+struct EncLevels {
+    const float* feat[SNN_MAX_LEVELS];
+    int HW[SNN_MAX_LEVELS], bpi[SNN_MAX_LEVELS];   // positions / blocks per image
+    int blk_base[SNN_MAX_LEVELS + 1];               // first block of the level
+    int pos_base[SNN_MAX_LEVELS];                   // first plane row of the level
+    int Wpad[SNN_MAX_LEVELS];                       // 0, or the level's width when the planes carry a zero halo
+    int n_levels;
+};
+template <bool ZR>
+__global__ __launch_bounds__(256) void k_encode_levels(const EncLevels lv, int C, int Cw, int T, NeuronP p,
+                                                       uint32_t* __restrict__ planes, size_t plane_stride) {
+    int l = 0;
+    while (l + 1 < lv.n_levels && (int)blockIdx.x >= lv.blk_base[l + 1]) ++l;
+    const int local = blockIdx.x - lv.blk_base[l];
+    encode_block<ZR>(lv.feat[l], C, lv.HW[l], Cw, T, p, planes + (size_t)lv.pos_base[l] * Cw, plane_stride,
+                     local / lv.bpi[l], local % lv.bpi[l], blockIdx.y, lv.Wpad[l]);
+}
+
+// K1b: encoder on row-major x[R][D] -> bit-planes [T][R][Dw]; a wave covers 64 consecutive reduction indices per
+// slot, so one ballot per step IS two plane words.  Each thread runs ENC_U independent elements (64 apart) to keep
+// several loads and scan chains in flight.
+#define ENC_U 4
+template <bool ZR>
+__global__ __launch_bounds__(256) void k_encode_rows(const float* __restrict__ x, int R, int D, int Dw, int T,
+                                                     NeuronP p, uint32_t* __restrict__ planes,
+                                                     size_t plane_stride) {
+    const size_t Dp = (size_t)Dw * 32;
+    const size_t total = (size_t)R * Dp;
+    const int lane = threadIdx.x & 63;
+    const size_t wave_base = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 * ENC_U);
+    float xv[ENC_U], v[ENC_U];
+    size_t e[ENC_U];
+#pragma unroll
+    for (int u = 0; u < ENC_U; ++u) {
+        e[u] = wave_base + (size_t)u * 64 + lane;
+        xv[u] = 0.0f;
+        v[u] = 0.0f;                              // faster_rcnn.py:484
+        if (e[u] < total) {
+            const size_t r = e[u] / Dp, k = e[u] % Dp;
+            if (k < (size_t)D) xv[u] = x[r * D + k];
+        }
+    }
+    for (int t = 0; t < T; ++t) {
+#pragma unroll
+        for (int u = 0; u < ENC_U; ++u) {
+            const bool z = enc_step_t<ZR>(xv[u], v[u], p);
+            const unsigned long long m = __ballot(z);
+            if ((lane & 31) == 0 && e[u] < total)
+                planes[(size_t)t * plane_stride + (e[u] >> 5)] = (lane < 32) ? (uint32_t)m : (uint32_t)(m >> 32);
+        }
+    }
+}
+
+// K1b': the same encoder when D is a multiple of 32 (the detector: 12544): the [R][D] elements are then one contiguous
+// run of plane words, and a LANE owns a whole word.  A work-group copies 256 words (32 KB) with 16-byte coalesced loads
+// through LDS (row pitch 36 dwords: the 8 ds_read_b128 of a lane are conflict-free), then every lane scans its 32
+// neurons with the 6-instruction step whose carry chain builds the plane word (enc_step_word) and the wave stores 64
+// consecutive words per time step.  Against the ballot form: 6 instead of 11 vector instructions per neuron-step and 8
+// times the bytes in flight per thread.
+#define ENC_W_PITCH 36
+template <bool ZR>
+__global__ __launch_bounds__(256) void k_encode_rows_w(const float* __restrict__ x, size_t n_words, int T, NeuronP p,
+                                                       uint32_t* __restrict__ planes, size_t plane_stride) {
+    __shared__ __attribute__((aligned(16))) float tile[256 * ENC_W_PITCH];
+    const int tid = threadIdx.x;
+    const size_t w0 = (size_t)blockIdx.x * 256;                 // first plane word of the work-group
+    const size_t nw = n_words - w0 < 256 ? n_words - w0 : 256;
+    const f32x4* src = reinterpret_cast<const f32x4*>(x + w0 * 32);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int q = tid + 256 * j;                            // 16-byte piece q of the work-group: word q / 8, elements 4 (q % 8) ..
+        f32x4 v4 = {0.f, 0.f, 0.f, 0.f};
+        if ((size_t)(q >> 3) < nw) v4 = src[q];
+        *reinterpret_cast<f32x4*>(tile + (q >> 3) * ENC_W_PITCH + (q & 7) * 4) = v4;
+    }
+    __syncthreads();
+    if ((size_t)tid >= nw) return;
+    float xv[32], v[32];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const f32x4 t4 = *reinterpret_cast<const f32x4*>(tile + tid * ENC_W_PITCH + 4 * q);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { xv[4 * q + r] = t4[r]; v[4 * q + r] = 0.0f; }      // v = 0: faster_rcnn.py:484
+    }
+    uint32_t* dst = planes + w0 + tid;
+    for (int t = 0; t < T; ++t) {
+        uint32_t word = 0;
+#pragma unroll
+        for (int b = 31; b >= 0; --b) enc_step_word<ZR>(xv[b], v[b], p, word);          // bit 31 first
+        dst[(size_t)t * plane_stride] = word;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1c: MultiScaleRoIAlign (7x7, sampling_ratio 2, aligned=False) fused with the detector's constant-current
+// encoder (roi_heads.py:1217 -> faster_rcnn.py:473,494): the [R,C,7,7] fp32 RoI features (100 MB at R=2000) are
+// never materialised; each thread pools one (RoI, channel, bin) element - 4 samples x 4 bilinear taps - runs its
+// T encoder steps in registers and the wave ballots straight into the bit-planes [T][R][Dw] (flatten order
+// d = c*49 + ph*7 + pw).  Arithmetic follows torchvision's roi_align / the stock-torch stand-in op for op
+// (explicit roundings, no fma): sample = (hy*hx)*v1 + (hy*lx)*v2 + (ly*hx)*v3 + (ly*lx)*v4, bin = mean of 4.
+// ------------------------------------------------------------------------------------------------
+struct RoiLevel { const float* feat; int H, W; float scale; };
+struct RoiArgs {
+    RoiLevel lv[4];
+    const float* rois;        // [R][4] x1,y1,x2,y2 in image coordinates
+    const int* roi_batch;     // [R]
+    const int* roi_level;     // [R] index into lv
+    float* pooled;            // nullable test hook: [R][C*49] fp32
+    uint32_t* planes;
+    unsigned long long plane_stride;
+    int R, C, T, Dw;
+    NeuronP p;
+};
+
+__device__ __forceinline__ float roi_bilinear(const float* __restrict__ f, int H, int W, float y, float x) {
+    if (y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) return 0.0f;
+    y = fmaxf(y, 0.0f);
+    x = fmaxf(x, 0.0f);
+    int y_low = (int)y, x_low = (int)x, y_high, x_high;
+    if (y_low >= H - 1) { y_high = y_low = H - 1; y = (float)y_low; } else y_high = y_low + 1;
+    if (x_low >= W - 1) { x_high = x_low = W - 1; x = (float)x_low; } else x_high = x_low + 1;
+    const float ly = __fsub_rn(y, (float)y_low), lx = __fsub_rn(x, (float)x_low);
+    const float hy = __fsub_rn(1.0f, ly), hx = __fsub_rn(1.0f, lx);
+    const float v1 = f[y_low * W + x_low], v2 = f[y_low * W + x_high];
+    const float v3 = f[y_high * W + x_low], v4 = f[y_high * W + x_high];
+    float acc = __fmul_rn(__fmul_rn(hy, hx), v1);
+    acc = __fadd_rn(acc, __fmul_rn(__fmul_rn(hy, lx), v2));
+    acc = __fadd_rn(acc, __fmul_rn(__fmul_rn(ly, hx), v3));
+    acc = __fadd_rn(acc, __fmul_rn(__fmul_rn(ly, lx), v4));
+    return acc;
+}
+
+__global__ __launch_bounds__(256) void k_roi_align_encode(const RoiArgs a) {
+    const int r = blockIdx.y;
+    const int D = a.C * 49;
+    const int d = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    float val = 0.0f;
+    if (d < D) {
+        const int c = d / 49, ph = (d % 49) / 7, pw = d % 7;
+        const RoiLevel L = a.lv[a.roi_level[r]];
+        const float* roi = a.rois + (size_t)r * 4;
+        const float x1 = __fmul_rn(roi[0], L.scale), y1 = __fmul_rn(roi[1], L.scale);
+        const float rw = fmaxf(__fsub_rn(__fmul_rn(roi[2], L.scale), x1), 1.0f);
+        const float rh = fmaxf(__fsub_rn(__fmul_rn(roi[3], L.scale), y1), 1.0f);
+        const float bh = __fdiv_rn(rh, 7.0f), bw = __fdiv_rn(rw, 7.0f);
+        const float* f = L.feat + ((size_t)a.roi_batch[r] * a.C + c) * (size_t)(L.H * L.W);
+        // sample coordinate: start + (p + (i + .5)/2) * bin   (the stock op's grid form)
+        float s[2][2];
+#pragma unroll
+        for (int iy = 0; iy < 2; ++iy)
+#pragma unroll
+            for (int ix = 0; ix < 2; ++ix) {
+                const float gy = __fadd_rn((float)ph, __fdiv_rn((float)iy + 0.5f, 2.0f));
+                const float gx = __fadd_rn((float)pw, __fdiv_rn((float)ix + 0.5f, 2.0f));
+                s[iy][ix] = roi_bilinear(f, L.H, L.W, __fadd_rn(y1, __fmul_rn(gy, bh)), __fadd_rn(x1, __fmul_rn(gx, bw)));
+            }
+        // mean over the 2x2 samples (torch .mean(dim=(3,5)): sum in (iy, ix) order, then / 4)
+        val = __fdiv_rn(__fadd_rn(__fadd_rn(__fadd_rn(s[0][0], s[0][1]), s[1][0]), s[1][1]), 4.0f);
+        if (a.pooled) a.pooled[(size_t)r * D + d] = val;
+    }
+    // encoder over T steps; the wave's 64 consecutive d are two plane words
+    float v = 0.0f;
+    const size_t e = (size_t)r * a.Dw * 32 + d;
+    const bool in = d < a.Dw * 32;
+    for (int t = 0; t < a.T; ++t) {
+        const bool z = enc_step(val, v, a.p) && d < D;
+        const unsigned long long m = __ballot(z);
+        if ((lane & 31) == 0 && in)
+            a.planes[(size_t)t * a.plane_stride + (e >> 5)] = (lane < 32) ? (uint32_t)m : (uint32_t)(m >> 32);
+    }
+}

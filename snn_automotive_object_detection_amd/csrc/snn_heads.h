@@ -1,0 +1,450 @@
+// LIF scan (K4), the leaky-integrator heads in their three forms (K5, K5b, K5c) and the spike counters of the
+// spike-rate outputs.  Included by snn_kernels.hip (after snn_bf16x3.h: table and swizzle helpers).
+#pragma once
+
+// ------------------------------------------------------------------------------------------------
+// K4: LIF scan over T of currents cur[T][R][ldc] -> spike planes [T][R][Nw]  (+ per-row counts)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_lif_scan(const float* __restrict__ cur, int T, int R, int N, int Nw,
+                                                  int ldc, NeuronP p, uint32_t* __restrict__ spk,
+                                                  size_t spk_stride, uint32_t* __restrict__ row_counts) {
+    const size_t Np = (size_t)Nw * 32;
+    const size_t total = (size_t)R * Np;
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const bool in = e < total;
+    const size_t r = in ? e / Np : 0;
+    const int n = in ? (int)(e % Np) : 0;
+    const bool live = in && n < N;
+    const float* c = cur + r * ldc + n;
+    const size_t tstride = (size_t)R * ldc;
+    float v = p.v_leak, i = 0.0f;
+    const int lane = threadIdx.x & 63;
+    uint32_t cnt = 0;
+    for (int t = 0; t < T; ++t) {
+        const float x = live ? c[(size_t)t * tstride] : 0.0f;
+        const bool z = lif_step(x, v, i, p) && live;
+        const unsigned long long m = __ballot(z);
+        if ((lane & 31) == 0 && in) {
+            const uint32_t w = (lane < 32) ? (uint32_t)m : (uint32_t)(m >> 32);
+            spk[(size_t)t * spk_stride + (e >> 5)] = w;
+            cnt += __popc(w);
+        }
+    }
+    if (row_counts != nullptr && (lane & 31) == 0 && in && cnt != 0) atomicAdd(&row_counts[r], cnt);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5: both leaky-integrator heads, time-collapsed.  The LI cell and the bias-free 1x1 conv / linear
+// in front of it are linear and only the last membrane is used (rpn.py:118-119,
+// faster_rcnn.py:513-514), so  mem_T = W . (sum_t kappa_last[t] * spk_t)  and the spike-rate
+// variant's sum over t of the membranes is  W . (sum_t kappa_sum[t] * spk_t).
+// ------------------------------------------------------------------------------------------------
+struct Kappa { float last[SNN_MAX_STEPS]; float sum[SNN_MAX_STEPS]; };
+
+// Block = 256 threads = RB rows; the reduction runs in slabs of HEADS_KS channels:
+//   phase 1  thread = (row, 32-channel word): S[row][k] = sum_t kappa[t] * bit_t(row, k)  -> LDS (fp32)
+//   phase 2  thread = (row, group of 4 outputs): acc4 += S[row][k] * Wt[k][4jg..4jg+3]   (Wt slab in LDS)
+// NOp (outputs rounded up to 16) * RB / 4 <= 256.
+#define HEADS_KS 128
+template <int RB>
+__global__ __launch_bounds__(256) void k_li_heads(const uint32_t* __restrict__ spk, size_t spk_stride, int T,
+                                                  int M, int Kw, const float* __restrict__ wT, int NOp, int NA,
+                                                  int NB, const Kappa kap, float* __restrict__ out_a,
+                                                  float* __restrict__ out_b, float* __restrict__ sum_a,
+                                                  float* __restrict__ sum_b) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int SST = HEADS_KS + 4;                          // padded row of S
+    float* S_last = reinterpret_cast<float*>(smem);            // [RB][SST]
+    const bool want_sum = (sum_a != nullptr);
+    float* S_sum = S_last + RB * SST;                          // [RB][SST], present only if sums are requested
+    float* Wl = S_last + (want_sum ? 2 : 1) * RB * SST;        // [HEADS_KS][NOp]
+    const int tid = threadIdx.x;
+    const int m0 = blockIdx.x * RB;
+    const int JG = NOp / 4;                                    // output groups per row
+    const int prow = tid / JG, pjg = tid % JG;                 // phase-2 role
+    const bool pact = prow < RB;
+    f32x4 acc_l = {0.f, 0.f, 0.f, 0.f}, acc_s = {0.f, 0.f, 0.f, 0.f};
+    const int n_slabs = (Kw * 32 + HEADS_KS - 1) / HEADS_KS;
+    for (int sl = 0; sl < n_slabs; ++sl) {
+        const int w0 = sl * (HEADS_KS / 32);                   // first channel word of the slab
+        const int nw = min(HEADS_KS / 32, Kw - w0);
+        // weights of the slab -> LDS (coalesced float4 copy; rows beyond Kp are never touched)
+        {
+            const f32x4* src = reinterpret_cast<const f32x4*>(wT + (size_t)w0 * 32 * NOp);
+            f32x4* dst = reinterpret_cast<f32x4*>(Wl);
+            for (int i = tid; i < nw * 32 * NOp / 4; i += 256) dst[i] = src[i];
+        }
+        // phase 1: item = (row, channel word, byte of the word) - 8 channels each, so that small row blocks (detector
+        // heads: RB = 16) still give every thread an item
+        for (int item = tid; item < RB * (HEADS_KS / 32) * 4; item += 256) {
+            const int q = item & 3, wi = (item >> 2) % (HEADS_KS / 32), row = (item >> 2) / (HEADS_KS / 32);
+            const int m = m0 + row;
+            float sl_[8], ss_[8];
+#pragma unroll
+            for (int b = 0; b < 8; ++b) { sl_[b] = 0.f; ss_[b] = 0.f; }
+            if (m < M && wi < nw) {
+                const uint32_t* wp = spk + (size_t)m * Kw + w0 + wi;
+#pragma unroll 4
+                for (int t = 0; t < T; ++t) {
+                    const uint32_t w = wp[(size_t)t * spk_stride] >> (8 * q);
+                    const float kl = kap.last[t], ks = kap.sum[t];
+#pragma unroll
+                    for (int b = 0; b < 8; ++b) {
+                        const float bit = (float)((w >> b) & 1u);
+                        sl_[b] = fmaf(bit, kl, sl_[b]);            // exact: bit is 0 or 1
+                        if (want_sum) ss_[b] = fmaf(bit, ks, ss_[b]);
+                    }
+                }
+            }
+            f32x4* dl = reinterpret_cast<f32x4*>(S_last + row * SST + wi * 32 + q * 8);
+            f32x4* ds = reinterpret_cast<f32x4*>(S_sum + row * SST + wi * 32 + q * 8);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                dl[j] = f32x4{sl_[4 * j], sl_[4 * j + 1], sl_[4 * j + 2], sl_[4 * j + 3]};
+                if (want_sum) ds[j] = f32x4{ss_[4 * j], ss_[4 * j + 1], ss_[4 * j + 2], ss_[4 * j + 3]};
+            }
+        }
+        __syncthreads();
+        // phase 2
+        if (pact) {
+            const float* sl_row = S_last + prow * SST;
+            const float* ss_row = S_sum + prow * SST;
+            const float* wcol = Wl + 4 * pjg;
+            const int kn = nw * 32;
+#pragma unroll 4
+            for (int k = 0; k < kn; ++k) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(wcol + (size_t)k * NOp);
+                const float a = sl_row[k];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc_l[r] = fmaf(a, w[r], acc_l[r]);
+                if (want_sum) {
+                    const float c = ss_row[k];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc_s[r] = fmaf(c, w[r], acc_s[r]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    const int m = m0 + prow;
+    if (pact && m < M) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = 4 * pjg + r;
+            if (j < NA) { out_a[(size_t)m * NA + j] = acc_l[r]; if (want_sum) sum_a[(size_t)m * NA + j] = acc_s[r]; }
+            else if (j < NA + NB) {
+                out_b[(size_t)m * NB + (j - NA)] = acc_l[r];
+                if (want_sum) sum_b[(size_t)m * NB + (j - NA)] = acc_s[r];
+            }
+        }
+    }
+}
+
+// K5b: the same heads on the bf16 matrix cores.  mem_T = sum_t kappa[t] * (spk_t . W): each  spk_t . W  is an exact
+// bf16x3 spike GEMM (spikes {0,1}, W = hi + mid + lo, fp32 accumulate) with all NOp <= 64 outputs in 1-4 MFMA column
+// tiles, and the kappa-weighted sum over t is an fma chain in the epilogue.  Wave = 16 rows x all T steps; the A
+// fragments come from the byte -> 8 bf16 table (as in k_gemm_bf16x3), the weights are split into their three bf16
+// planes while they are staged into LDS (no second packed copy): resident when all of W fits, else streamed per
+// 32-deep chunk (double-buffered).  Time steps go in groups of 8 (8 x NT accumulators).
+// RPN heads (196k rows, K=256, 15 outputs): 137 -> ~40 us;  detector heads (2000 rows, K=1024, 45 outputs): 88 -> ~15 us.
+#define LIH_TG 8
+struct LiHeadsArgs {
+    const uint32_t* spk; unsigned long long spk_stride;
+    const float* wT;              // [Kp][NOp] fp32 (snn_pack_heads_weight)
+    float *out_a, *out_b, *sum_a, *sum_b;
+    int T, M, Kw, NOp, NA, NB, n_groups, resident;
+    Kappa kap;
+};
+
+template <int NT>
+__global__ __launch_bounds__(256) void k_li_heads_mfma(const LiHeadsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const lut = smem;                           // 4 KB
+    unsigned char* const bbase = smem + G3_LUT_BYTES;          // [chunk slot][3][NOp][64 B]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lg = lane >> 4, lg8 = 8 * lg;
+    const int NOp = a.NOp, Kc = a.Kw;
+    const uint32_t slot_bytes = 3u * NOp * 64u;
+    {
+        uint4 q;
+        q.x = bf16_pair(tid, 0); q.y = bf16_pair(tid, 1); q.z = bf16_pair(tid, 2); q.w = bf16_pair(tid, 3);
+        *reinterpret_cast<uint4*>(lut + tid * 16) = q;
+    }
+    auto stage = [&](int kc, int slot) {                       // split W[32kc .. 32kc+31][NOp] into 3 bf16 planes
+        unsigned char* dst = bbase + (size_t)slot * slot_bytes;
+        for (int item = tid; item < 16 * NOp; item += 256) {
+            const int n = item % NOp, kp = item / NOp;
+            const float* src = a.wT + (size_t)(32 * kc + 2 * kp) * NOp + n;
+            uint32_t pl[3] = {0u, 0u, 0u};
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float w = src[(size_t)h * NOp];
+                const uint16_t hi = f2bf_rn(w);
+                const float r1 = __fsub_rn(w, bf2f(hi));
+                const uint16_t mid = f2bf_rn(r1);
+                const uint16_t lo = f2bf_rn(__fsub_rn(r1, bf2f(mid)));
+                pl[0] |= (uint32_t)hi << (16 * h); pl[1] |= (uint32_t)mid << (16 * h); pl[2] |= (uint32_t)lo << (16 * h);
+            }
+            const int off = n * 64 + ((((kp >> 2) ^ G3_SWZ(n)) << 4) | ((kp & 3) << 2));
+#pragma unroll
+            for (int q = 0; q < 3; ++q) *reinterpret_cast<uint32_t*>(dst + q * NOp * 64 + off) = pl[q];
+        }
+    };
+    if (a.resident)
+        for (int kc = 0; kc < Kc; ++kc) stage(kc, kc);
+    __syncthreads();
+    const unsigned char* const b_rd = bbase + lr * 64 + ((lg ^ G3_SWZ(lr)) << 4);
+    for (int g = blockIdx.x; g < a.n_groups; g += gridDim.x) {
+        const int m0 = (g * 4 + wave) * 16;
+        const int mrow = min(m0 + lr, a.M - 1);                 // rows past M: recomputed, never stored
+        const uint32_t* wsrc = a.spk + (size_t)mrow * a.Kw;
+        f32x4 o_last[NT], o_sum[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) { o_last[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; o_sum[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int tg0 = 0; tg0 < a.T; tg0 += LIH_TG) {
+            const int tn = min(LIH_TG, a.T - tg0);              // block-uniform
+            f32x4 acc[LIH_TG][NT];
+#pragma unroll
+            for (int t = 0; t < LIH_TG; ++t)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[t][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            auto chunk = [&](int kc, const uint32_t (&w_cur)[LIH_TG]) {
+                const unsigned char* bs = b_rd + (size_t)(a.resident ? kc : (kc & 1)) * slot_bytes;
+                bf16x8 b[3][NT];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        b[pl][nt] = *reinterpret_cast<const bf16x8*>(bs + (pl * NOp + nt * 16) * 64);
+#pragma unroll
+                for (int t = 0; t < LIH_TG; ++t) {
+                    if (t < tn) {
+                        const bf16x8 af = *reinterpret_cast<const bf16x8*>(lut + (__builtin_amdgcn_ubfe(w_cur[t], lg8, 8) << 4));
+#pragma unroll
+                        for (int pl = 2; pl >= 0; --pl)
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+                                acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, b[pl][nt], acc[t][nt], 0, 0, 0);
+                    }
+                }
+            };
+            if (a.resident && Kc == 8) {
+                // C = 256: the 8 spike words of a (t, row) are one 32-byte line - all T x 8 words are requested up
+                // front (one memory latency per row tile instead of one per chunk)
+                uint4 wl[LIH_TG][2];
+#pragma unroll
+                for (int t = 0; t < LIH_TG; ++t) {
+                    const uint4* q = reinterpret_cast<const uint4*>(wsrc + (size_t)(tg0 + (t < tn ? t : 0)) * a.spk_stride);
+                    wl[t][0] = q[0]; wl[t][1] = q[1];
+                }
+#pragma unroll
+                for (int kc = 0; kc < 8; ++kc) {
+                    uint32_t w_cur[LIH_TG];
+#pragma unroll
+                    for (int t = 0; t < LIH_TG; ++t) {
+                        const uint4 v = wl[t][kc >> 2];
+                        w_cur[t] = (kc & 3) == 0 ? v.x : (kc & 3) == 1 ? v.y : (kc & 3) == 2 ? v.z : v.w;
+                    }
+                    chunk(kc, w_cur);
+                }
+            } else {
+                uint32_t w_nxt[LIH_TG];
+#pragma unroll
+                for (int t = 0; t < LIH_TG; ++t) w_nxt[t] = t < tn ? wsrc[(size_t)(tg0 + t) * a.spk_stride] : 0u;
+                if (!a.resident) { stage(0, 0); __syncthreads(); }
+                for (int kc = 0; kc < Kc; ++kc) {
+                    uint32_t w_cur[LIH_TG];
+#pragma unroll
+                    for (int t = 0; t < LIH_TG; ++t) w_cur[t] = w_nxt[t];
+                    if (kc + 1 < Kc) {
+#pragma unroll
+                        for (int t = 0; t < LIH_TG; ++t) w_nxt[t] = t < tn ? wsrc[(size_t)(tg0 + t) * a.spk_stride + kc + 1] : 0u;
+                        if (!a.resident) stage(kc + 1, (kc + 1) & 1);
+                    }
+                    chunk(kc, w_cur);
+                    if (!a.resident) __syncthreads();           // chunk kc+1 staged, chunk kc consumed
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < LIH_TG; ++t)
+                if (t < tn) {
+                    const float kl = a.kap.last[tg0 + t], ks = a.kap.sum[tg0 + t];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            o_last[nt][r] = fmaf(kl, acc[t][nt][r], o_last[nt][r]);
+                            o_sum[nt][r] = fmaf(ks, acc[t][nt][r], o_sum[nt][r]);
+                        }
+                }
+        }
+        // lane holds rows lg*4 + r, output column nt*16 + lr
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int j = nt * 16 + lr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + lg * 4 + r;
+                if (m >= a.M) continue;
+                if (j < a.NA) { a.out_a[(size_t)m * a.NA + j] = o_last[nt][r]; if (a.sum_a) a.sum_a[(size_t)m * a.NA + j] = o_sum[nt][r]; }
+                else if (j < a.NA + a.NB) {
+                    a.out_b[(size_t)m * a.NB + (j - a.NA)] = o_last[nt][r];
+                    if (a.sum_b) a.sum_b[(size_t)m * a.NB + (j - a.NA)] = o_sum[nt][r];
+                }
+            }
+        }
+    }
+}
+
+// K5c: the same heads when W does not fit in LDS (detector: K = 1024, 45 outputs) and there are few rows (2000): one
+// work-group per 16-row tile, its 4 waves split the reduction into quarters (so 125 work-groups of independent waves
+// instead of 32 that march through K together).  A wave keeps the accumulators of ALL time steps (T <= 16; 12 with 4 column
+// tiles), builds the
+// three bf16 planes of its weight fragments in registers straight from the fp32 W^T (read through L2, next chunk's
+// values requested before this chunk's MFMAs), and needs no barrier until the four partial results meet in LDS and are
+// added in wave order (deterministic).  2000 x 1024 x 45, T = 12: 68 us (fp32 VALU kernel) -> ~15 us.
+#define LIH_KS_TM(nt) ((nt) <= 3 ? 16 : 12)     // time steps whose accumulators fit in registers beside NT column tiles
+template <int NT>
+__global__ __launch_bounds__(256) void k_li_heads_ksplit(const LiHeadsArgs a) {
+    constexpr int TM = LIH_KS_TM(NT);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const lut = smem;                           // 4 KB
+    f32x4* const red = reinterpret_cast<f32x4*>(smem + G3_LUT_BYTES);      // [4 waves][2][NT][64 lanes]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, lg = lane >> 4, lg8 = 8 * lg;
+    const int NOp = a.NOp, Kc = a.Kw, T = a.T;
+    {
+        uint4 q;
+        q.x = bf16_pair(tid, 0); q.y = bf16_pair(tid, 1); q.z = bf16_pair(tid, 2); q.w = bf16_pair(tid, 3);
+        *reinterpret_cast<uint4*>(lut + tid * 16) = q;
+    }
+    __syncthreads();
+    const int m0 = blockIdx.x * 16;
+    const int mrow = min(m0 + lr, a.M - 1);                    // rows past M: recomputed, never stored
+    const uint32_t* wsrc = a.spk + (size_t)mrow * a.Kw;
+    const int c0 = wave * Kc / 4, c1 = (wave + 1) * Kc / 4;    // this wave's chunks
+    f32x4 acc[TM][NT];
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[t][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // element (k = 32 kc + 8 lg + j, n = nt*16 + lr) of W^T: the lane's B fragment is j = 0..7
+    const float* const wlane = a.wT + (size_t)lg8 * NOp + lr;
+    float wf[NT][8];
+    uint32_t w_nxt[TM];
+    auto request = [&](int kc) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) wf[nt][j] = wlane[(size_t)(32 * kc + j) * NOp + nt * 16];
+#pragma unroll
+        for (int t = 0; t < TM; ++t) w_nxt[t] = t < T ? wsrc[(size_t)t * a.spk_stride + kc] : 0u;
+    };
+    if (c0 < c1) request(c0);
+    for (int kc = c0; kc < c1; ++kc) {
+        bf16x8 b[3][NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float w = wf[nt][j];
+                const uint16_t hi = f2bf_rn(w);
+                const float r1 = __fsub_rn(w, bf2f(hi));
+                const uint16_t mid = f2bf_rn(r1);
+                const uint16_t lo = f2bf_rn(__fsub_rn(r1, bf2f(mid)));
+                b[0][nt][j] = (short)hi; b[1][nt][j] = (short)mid; b[2][nt][j] = (short)lo;
+            }
+        uint32_t w_cur[TM];
+#pragma unroll
+        for (int t = 0; t < TM; ++t) w_cur[t] = w_nxt[t];
+        if (kc + 1 < c1) request(kc + 1);
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+            if (t < T) {                                        // block-uniform
+                const bf16x8 af = *reinterpret_cast<const bf16x8*>(lut + (__builtin_amdgcn_ubfe(w_cur[t], lg8, 8) << 4));
+#pragma unroll
+                for (int pl = 2; pl >= 0; --pl)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, b[pl][nt], acc[t][nt], 0, 0, 0);
+            }
+        }
+    }
+    f32x4 o_last[NT], o_sum[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { o_last[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; o_sum[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+        if (t < T) {
+            const float kl = a.kap.last[t], ks = a.kap.sum[t];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    o_last[nt][r] = fmaf(kl, acc[t][nt][r], o_last[nt][r]);
+                    o_sum[nt][r] = fmaf(ks, acc[t][nt][r], o_sum[nt][r]);
+                }
+        }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        red[((wave * 2 + 0) * NT + nt) * 64 + lane] = o_last[nt];
+        red[((wave * 2 + 1) * NT + nt) * 64 + lane] = o_sum[nt];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        f32x4 ol = red[(0 * NT + nt) * 64 + lane], os = red[(1 * NT + nt) * 64 + lane];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const f32x4 pl = red[((w * 2 + 0) * NT + nt) * 64 + lane], ps = red[((w * 2 + 1) * NT + nt) * 64 + lane];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { ol[r] = __fadd_rn(ol[r], pl[r]); os[r] = __fadd_rn(os[r], ps[r]); }
+        }
+        // lane holds rows lg*4 + r, output column nt*16 + lr
+        const int j = nt * 16 + lr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + lg * 4 + r;
+            if (m >= a.M) continue;
+            if (j < a.NA) { a.out_a[(size_t)m * a.NA + j] = ol[r]; if (a.sum_a) a.sum_a[(size_t)m * a.NA + j] = os[r]; }
+            else if (j < a.NA + a.NB) {
+                a.out_b[(size_t)m * a.NB + (j - a.NA)] = ol[r];
+                if (a.sum_b) a.sum_b[(size_t)m * a.NB + (j - a.NA)] = os[r];
+            }
+        }
+    }
+}
+
+// spikes per image of one level, counted from the bit-planes (spike-rate mode of the bf16x3 path): blockIdx.x = image,
+// blockIdx.y = slice of the image's words; integer atomics, so the result does not depend on the order.
+// counts must be zeroed by the caller.
+__global__ __launch_bounds__(256) void k_count_spikes(const uint32_t* __restrict__ spk, unsigned long long spk_stride,
+                                                      int T, int words_per_image,
+                                                      unsigned long long* __restrict__ counts) {
+    unsigned long long sum = 0;
+    for (int t = 0; t < T; ++t) {
+        const uint32_t* src = spk + (size_t)t * spk_stride + (size_t)blockIdx.x * words_per_image;
+        for (int i = blockIdx.y * 256 + threadIdx.x; i < words_per_image; i += gridDim.y * 256) sum += __popc(src[i]);
+    }
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off);
+    __shared__ unsigned long long part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&counts[blockIdx.x], part[0] + part[1] + part[2] + part[3]);
+}
+
+// spikes per row (RoI) over all T planes: one wave per row  (spike-rate mode of the fused linear layers)
+__global__ __launch_bounds__(256) void k_count_rows(const uint32_t* __restrict__ spk, unsigned long long spk_stride, int T,
+                                                    int R, int words, uint32_t* __restrict__ counts) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= R) return;
+    uint32_t sum = 0;
+    for (int t = 0; t < T; ++t) {
+        const uint32_t* src = spk + (size_t)t * spk_stride + (size_t)row * words;
+        for (int i = lane; i < words; i += 64) sum += __popc(src[i]);
+    }
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off);
+    if (lane == 0) counts[row] = sum;
+}

@@ -1,0 +1,498 @@
+// callers on either side of the heads: batched NMS, RPN proposal selection, detection post-processing.
+// Included by snn_kernels.hip.
+#pragma once
+
+// ------------------------------------------------------------------------------------------------
+// Greedy (batched) NMS for the callers on either side of the heads (rpn.py:517, roi_heads.py:1160-1161):
+// boxes arrive sorted by decreasing score; k_nms_mask builds the suppression bit-matrix (box j > i, same
+// category, IoU > thr), k_nms_scan walks it in score order with the rows staged through LDS 64 at a time.
+// ------------------------------------------------------------------------------------------------
+// Batched form (blockIdx.z = image): per-image strides (elements) and a device-side candidate count; a plain call
+// passes zero strides and n_dev = nullptr.
+struct NmsBatch { const int* n_dev; long long boxes_stride, cat_stride, mask_stride, keep_stride; };
+
+__global__ __launch_bounds__(64) void k_nms_mask(const float* __restrict__ boxes, const int* __restrict__ cat, int n,
+                                                 float thr, unsigned long long* __restrict__ mask, int words,
+                                                 const NmsBatch nb) {
+    const int rb = blockIdx.y, cb = blockIdx.x;
+    if (cb < rb) return;                                  // only j > i matters
+    if (nb.n_dev) n = nb.n_dev[blockIdx.z];
+    if (rb * 64 >= n || cb * 64 >= n) return;
+    boxes += (size_t)blockIdx.z * nb.boxes_stride;
+    if (cat) cat += (size_t)blockIdx.z * nb.cat_stride;
+    mask += (size_t)blockIdx.z * nb.mask_stride;
+    __shared__ float cbx[64][4];
+    __shared__ int ccat[64];
+    const int t = threadIdx.x;
+    const int j0 = cb * 64;
+    if (j0 + t < n) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cbx[t][q] = boxes[(size_t)(j0 + t) * 4 + q];
+        ccat[t] = cat ? cat[j0 + t] : 0;
+    }
+    __syncthreads();
+    const int i = rb * 64 + t;
+    if (i >= n) return;
+    const float x1 = boxes[(size_t)i * 4], y1 = boxes[(size_t)i * 4 + 1], x2 = boxes[(size_t)i * 4 + 2], y2 = boxes[(size_t)i * 4 + 3];
+    const float area_i = __fmul_rn(__fsub_rn(x2, x1), __fsub_rn(y2, y1));
+    const int ci = cat ? cat[i] : 0;
+    unsigned long long bits = 0;
+    const int jn = min(64, n - j0);
+    for (int jj = (rb == cb ? t + 1 : 0); jj < jn; ++jj) {
+        if (ccat[jj] != ci) continue;
+        const float w = fmaxf(__fsub_rn(fminf(x2, cbx[jj][2]), fmaxf(x1, cbx[jj][0])), 0.0f);
+        const float h = fmaxf(__fsub_rn(fminf(y2, cbx[jj][3]), fmaxf(y1, cbx[jj][1])), 0.0f);
+        const float inter = __fmul_rn(w, h);
+        const float area_j = __fmul_rn(__fsub_rn(cbx[jj][2], cbx[jj][0]), __fsub_rn(cbx[jj][3], cbx[jj][1]));
+        const float iou = __fdiv_rn(inter, __fsub_rn(__fadd_rn(area_i, area_j), inter));     // box_iou's formula
+        if (iou > thr) bits |= 1ull << jj;
+    }
+    mask[(size_t)i * words + cb] = bits;
+}
+
+// One work-group walks the candidates in score order, 64 (one mask word) per step.  Thread w < words owns word w of
+// the "removed" set.  Per chunk c:
+//   waves 1-3 copy the mask rows of chunk c+1 (words >= c+1 only: the upper triangle) into the other LDS buffer -
+//     the rows do not depend on any decision, so the copy runs beside the walk;
+//   wave 0 resolves the chunk's own 64x64 block in registers: lane b holds the diagonal word of row b, the walk is
+//     64 scalar steps (v_readlane of a constant lane, s_or) with no memory access;
+//   everyone ORs the rows of the kept boxes into the later words.
+// (The first version staged each chunk with a blocking copy and read LDS inside the walk: 965 us for 4768 boxes,
+// two thirds of the RPN post-processing time.)
+// dbl = 0 (n > 9984: two buffers do not fit the LDS): one buffer, blocking copy at the top of each chunk.
+__global__ __launch_bounds__(256) void k_nms_scan(const unsigned long long* __restrict__ mask, int n, int words,
+                                                  int max_keep, int dbl, int* __restrict__ keep, int* __restrict__ n_keep,
+                                                  const NmsBatch nb) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long* rows = reinterpret_cast<unsigned long long*>(smem);     // [1 + dbl][64][words]
+    if (nb.n_dev) n = nb.n_dev[blockIdx.x];
+    mask += (size_t)blockIdx.x * nb.mask_stride;
+    keep += (size_t)blockIdx.x * nb.keep_stride;
+    n_keep += blockIdx.x;
+    if (n <= 0) { if (threadIdx.x == 0) *n_keep = 0; return; }
+    __shared__ unsigned long long removed_cur, kept_cur;
+    __shared__ int count_s;
+    const int t = threadIdx.x;
+    const int n_chunks = (n + 63) / 64;
+    unsigned long long removed = 0;          // thread t (< words): removed bits of boxes [64t, 64t+64)
+    auto copy_chunk = [&](int c, int first, int step) {       // rows of chunk c, words [c, words) -> buffer c & 1
+        const int rn = min(64, n - c * 64), wn = words - c;
+        unsigned long long* dst = rows + (size_t)(c & dbl) * 64 * words;
+        const unsigned long long* src = mask + (size_t)c * 64 * words;
+        for (int idx = first; idx < rn * wn; idx += step) {
+            const int r = idx / wn, w = c + idx % wn;
+            dst[r * words + w] = src[(size_t)r * words + w];
+        }
+    };
+    copy_chunk(0, t, 256);
+    if (t == 0) { count_s = 0; removed_cur = 0; }
+    __syncthreads();
+    for (int c = 0; c < n_chunks; ++c) {
+        const int rn = min(64, n - c * 64);
+        const unsigned long long* cur = rows + (size_t)(c & dbl) * 64 * words;
+        if (!dbl && c > 0) {
+            copy_chunk(c, t, 256);
+            __syncthreads();
+        }
+        if (t >= 64) {
+            if (dbl && c + 1 < n_chunks) copy_chunk(c + 1, t - 64, 192);
+        } else {                              // wave 0: the chunk's own block
+            const unsigned long long diag = t < rn ? cur[t * words + c] : 0ull;
+            const uint32_t dlo = (uint32_t)diag, dhi = (uint32_t)(diag >> 32);
+            unsigned long long rc = removed_cur;              // wave-uniform
+            if (rn < 64) rc |= ~0ull << rn;                   // lanes past the end count as removed
+            int count = count_s;
+            const int base = count;
+            unsigned long long kept_bits = 0;
+#pragma unroll
+            for (int b = 0; b < 64; ++b) {
+                if (!((rc >> b) & 1ull) && count < max_keep) {
+                    kept_bits |= 1ull << b;
+                    ++count;
+                    rc |= ((unsigned long long)__builtin_amdgcn_readlane(dhi, b) << 32) | __builtin_amdgcn_readlane(dlo, b);
+                }
+            }
+            // kept boxes -> keep[] in order: lane b is kept box number base + popcount(kept_bits below b)
+            if ((kept_bits >> t) & 1ull)
+                keep[base + __popcll(kept_bits & ((1ull << t) - 1ull))] = c * 64 + t;
+            if (t == 0) { count_s = count; kept_cur = kept_bits; }
+        }
+        __syncthreads();
+        const unsigned long long kept = kept_cur;
+        if (t < words && t > c) {             // later words: OR the rows of the kept boxes
+            unsigned long long acc = removed, k = kept;
+            while (k) {
+                const int b = __ffsll((long long)k) - 1;
+                k &= k - 1;
+                acc |= cur[b * words + t];
+            }
+            removed = acc;
+        }
+        if (t == c + 1) removed_cur = removed;
+        const bool done = count_s >= max_keep;
+        __syncthreads();
+        if (done) break;
+    }
+    if (t == 0) *n_keep = count_s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// RPN proposal selection (rpn.py:420-499 + 262-296 + the box coder), one call for the batch:
+//   k_rpn_topk    per (level, image): the pre_nms_top_n largest logits by a 3-pass radix select (11+11+10 bits)
+//   k_rpn_decode  per candidate: anchor from the level geometry, box decode, sigmoid, clip, size/score filters
+//   k_rpn_sort    per image: bitonic sort of the candidates by decreasing score in LDS, gather into sorted order
+//   k_nms_mask / k_nms_scan (batched over images, category = level)
+//   k_rpn_output  kept boxes -> [N][post_nms_top_n] padded + counts
+// ------------------------------------------------------------------------------------------------
+#define RPN_MAX_ANCHORS 16
+#define RPN_MAX_IMAGES 64
+#define RPN_SORT_MAX 8192
+struct RpnPostLevel {
+    const float* logits;          // [N*H*W][A]   position-major (the head's own output buffer)
+    const float* deltas;          // [N*H*W][4A]
+    int H, W, n, k, koff;         // n = H*W*A elements per image, k = min(pre_nms_top_n, n), koff = first candidate slot
+    float sh, sw;                 // anchor strides (image size // feature size)
+    float base[RPN_MAX_ANCHORS * 4];
+};
+struct RpnPostArgs {
+    RpnPostLevel lv[SNN_MAX_LEVELS];
+    float img_h[RPN_MAX_IMAGES], img_w[RPN_MAX_IMAGES];
+    int n_levels, N, A, Ktot, post_n;
+    float score_thresh, min_size, clip;
+    int* cand_idx;                // [N][Ktot] level-local element index
+    float* cand_logit;            // [N][Ktot]
+    float* boxes;                 // [N][Ktot][4] clipped
+    float* pre;                   // [N][Ktot][4] decoded, un-clipped
+    float* prob;                  // [N][Ktot]
+    float* skey;                  // [N][Ktot] prob, or -1 for filtered candidates
+    float* s_boxes; float* s_pre; float* s_prob; int* s_cat; int* n_valid;     // sorted by decreasing score
+};
+
+__device__ __forceinline__ uint32_t f2key(float f) {           // monotone: larger float -> larger key
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ __launch_bounds__(1024) void k_rpn_topk(const RpnPostArgs a) {
+    const RpnPostLevel& L = a.lv[blockIdx.x];
+    const int img = blockIdx.y, tid = threadIdx.x;
+    const float* src = L.logits + (size_t)img * L.n;
+    __shared__ uint32_t hist[2048];
+    __shared__ uint32_t s_prefix, s_need, s_cnt_gt, s_cnt_eq;
+    uint32_t prefix = 0, pmask = 0;           // bits of the k-th largest key decided so far
+    uint32_t need = (uint32_t)L.k;            // how many are still to be taken among keys matching the prefix
+    const int shifts[3] = {21, 10, 0}, bits[3] = {11, 11, 10};
+    for (int pass = 0; pass < 3; ++pass) {
+        for (int b = tid; b < 2048; b += 1024) hist[b] = 0;
+        __syncthreads();
+        const uint32_t bm = (1u << bits[pass]) - 1u;
+        for (int e = tid; e < L.n; e += 1024) {
+            const uint32_t key = f2key(src[e]);
+            if ((key & pmask) == prefix) atomicAdd(&hist[(key >> shifts[pass]) & bm], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {                       // walk the bins from the top until `need` keys are covered
+            uint32_t cum = 0;
+            int b = (int)bm;
+            for (; b > 0; --b) {
+                if (cum + hist[b] >= need) break;
+                cum += hist[b];
+            }
+            s_prefix = prefix | ((uint32_t)b << shifts[pass]);
+            s_need = need - cum;              // taken from bin b (all bins above it are taken whole)
+        }
+        __syncthreads();
+        prefix = s_prefix; need = s_need;
+        pmask |= bm << shifts[pass];
+        __syncthreads();
+    }
+    // prefix = key of the k-th largest logit; `need` of the keys equal to it are taken: those with the lowest element
+    // index (deterministic; an ordered pass with a block scan, run only when there are more ties than needed)
+    __shared__ uint32_t s_eq_total;
+    if (tid == 0) { s_cnt_gt = 0; s_cnt_eq = 0; s_eq_total = hist[prefix & 1023u]; }
+    __syncthreads();
+    int* out_idx = a.cand_idx + (size_t)img * a.Ktot + L.koff;
+    float* out_logit = a.cand_logit + (size_t)img * a.Ktot + L.koff;
+    const uint32_t n_gt = (uint32_t)L.k - need;
+    const bool ordered_ties = s_eq_total > need;
+    for (int e = tid; e < L.n; e += 1024) {
+        const float x = src[e];
+        const uint32_t key = f2key(x);
+        int slot = -1;
+        if (key > prefix) slot = (int)atomicAdd(&s_cnt_gt, 1u);
+        else if (key == prefix && !ordered_ties) slot = (int)(n_gt + atomicAdd(&s_cnt_eq, 1u));
+        if (slot >= 0) { out_idx[slot] = e; out_logit[slot] = x; }
+    }
+    if (ordered_ties) {
+        __shared__ uint32_t wsum[16];
+        uint32_t taken = 0;                   // block-uniform
+        for (int e0 = 0; e0 < L.n && taken < need; e0 += 1024) {
+            const int e = e0 + tid;
+            const bool tie = e < L.n && f2key(src[e]) == prefix;
+            const unsigned long long bal = __ballot(tie);
+            const int lane = tid & 63, wv = tid >> 6;
+            if (lane == 0) wsum[wv] = (uint32_t)__popcll(bal);
+            __syncthreads();
+            uint32_t before = 0, total = 0;
+            for (int w = 0; w < 16; ++w) { if (w < wv) before += wsum[w]; total += wsum[w]; }
+            const uint32_t rank = taken + before + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+            if (tie && rank < need) { out_idx[n_gt + rank] = e; out_logit[n_gt + rank] = src[e]; }
+            taken += total;
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_rpn_decode(const RpnPostArgs a) {
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= a.N * a.Ktot) return;
+    const int img = g / a.Ktot, c = g % a.Ktot;
+    int l = 0;
+    while (l + 1 < a.n_levels && c >= a.lv[l + 1].koff) ++l;
+    const RpnPostLevel& L = a.lv[l];
+    const int e = a.cand_idx[g];
+    const int pos = e / a.A, an = e % a.A;
+    const int y = pos / L.W, x = pos % L.W;
+    const float fx = (float)(x * (int)L.sw), fy = (float)(y * (int)L.sh);     // integer shifts, as the reference's
+    const float ax1 = __fadd_rn(fx, L.base[4 * an]), ay1 = __fadd_rn(fy, L.base[4 * an + 1]);
+    const float ax2 = __fadd_rn(fx, L.base[4 * an + 2]), ay2 = __fadd_rn(fy, L.base[4 * an + 3]);
+    const float* d = L.deltas + ((size_t)img * L.H * L.W + pos) * 4 * a.A + 4 * an;
+    // BoxCoder.decode_single, weights (1, 1, 1, 1)
+    const float w = __fsub_rn(ax2, ax1), h = __fsub_rn(ay2, ay1);
+    const float cx = __fadd_rn(ax1, __fmul_rn(0.5f, w)), cy = __fadd_rn(ay1, __fmul_rn(0.5f, h));
+    const float dw = fminf(d[2], a.clip), dh = fminf(d[3], a.clip);
+    const float pcx = __fadd_rn(__fmul_rn(d[0], w), cx), pcy = __fadd_rn(__fmul_rn(d[1], h), cy);
+    const float hw = __fmul_rn(0.5f, __fmul_rn(expf(dw), w)), hh = __fmul_rn(0.5f, __fmul_rn(expf(dh), h));
+    const float x1 = __fsub_rn(pcx, hw), y1 = __fsub_rn(pcy, hh), x2 = __fadd_rn(pcx, hw), y2 = __fadd_rn(pcy, hh);
+    const float prob = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-a.cand_logit[g])));
+    const float W_ = a.img_w[img], H_ = a.img_h[img];
+    const float bx1 = fminf(fmaxf(x1, 0.0f), W_), by1 = fminf(fmaxf(y1, 0.0f), H_);
+    const float bx2 = fminf(fmaxf(x2, 0.0f), W_), by2 = fminf(fmaxf(y2, 0.0f), H_);
+    const bool valid = __fsub_rn(bx2, bx1) >= a.min_size && __fsub_rn(by2, by1) >= a.min_size && prob >= a.score_thresh;
+    reinterpret_cast<float4*>(a.pre)[g] = make_float4(x1, y1, x2, y2);
+    reinterpret_cast<float4*>(a.boxes)[g] = make_float4(bx1, by1, bx2, by2);
+    a.prob[g] = prob;
+    a.skey[g] = valid ? prob : -1.0f;
+}
+
+__global__ __launch_bounds__(1024) void k_rpn_sort(const RpnPostArgs a) {
+    __shared__ unsigned long long v[RPN_SORT_MAX];
+    __shared__ uint16_t slot_of[RPN_SORT_MAX];
+    const int img = blockIdx.x, tid = threadIdx.x, K = a.Ktot;
+    int np2 = 1;
+    while (np2 < K) np2 <<= 1;
+    // descending on (score, then level, then lower element index): the candidate's slot rides in the low 13 bits.
+    // (The slots inside a level are filled in atomic order; the element index makes the result run-to-run identical.)
+    for (int i = tid; i < np2; i += 1024) {
+        unsigned long long key = 0ull;
+        if (i < K) {
+            int l = 0;
+            while (l + 1 < a.n_levels && i >= a.lv[l + 1].koff) ++l;
+            const uint32_t ident = ((uint32_t)l << 28) | (uint32_t)a.cand_idx[(size_t)img * K + i];    // e < 2^28
+            key = ((unsigned long long)f2key(a.skey[(size_t)img * K + i]) << 32) | (uint32_t)(~ident);
+        }
+        v[i] = key;
+        slot_of[i] = (uint16_t)i;
+    }
+    __syncthreads();
+    for (int k = 2; k <= np2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < np2; i += 1024) {
+                const int p = i ^ j;
+                if (p > i) {
+                    const unsigned long long x = v[i], y = v[p];
+                    const bool desc = (i & k) == 0;
+                    if (desc ? x < y : x > y) {
+                        v[i] = y; v[p] = x;
+                        const uint16_t q = slot_of[i]; slot_of[i] = slot_of[p]; slot_of[p] = q;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    int valid = 0;
+    for (int i = tid; i < K; i += 1024) {
+        const int c = slot_of[i];
+        const size_t src = (size_t)img * K + c, dst = (size_t)img * K + i;
+        reinterpret_cast<float4*>(a.s_boxes)[dst] = reinterpret_cast<const float4*>(a.boxes)[src];
+        reinterpret_cast<float4*>(a.s_pre)[dst] = reinterpret_cast<const float4*>(a.pre)[src];
+        a.s_prob[dst] = a.prob[src];
+        int l = 0;
+        while (l + 1 < a.n_levels && c >= a.lv[l + 1].koff) ++l;
+        a.s_cat[dst] = l;
+        valid += a.skey[src] >= 0.0f;
+    }
+    __shared__ int s_valid;
+    if (tid == 0) s_valid = 0;
+    __syncthreads();
+    if (valid) atomicAdd(&s_valid, valid);
+    __syncthreads();
+    if (tid == 0) a.n_valid[img] = s_valid;
+}
+
+__global__ __launch_bounds__(256) void k_rpn_output(const RpnPostArgs a, const int* __restrict__ keep, const int* __restrict__ n_keep,
+                                                    float* __restrict__ out_boxes, float* __restrict__ out_scores,
+                                                    int* __restrict__ out_counts) {
+    const int img = blockIdx.x;
+    const int cnt = min(n_keep[img], a.post_n);
+    for (int r = threadIdx.x; r < a.post_n; r += 256) {
+        float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+        float sc = 0.f;
+        if (r < cnt) {
+            const size_t src = (size_t)img * a.Ktot + keep[(size_t)img * a.Ktot + r];
+            b = reinterpret_cast<const float4*>(a.s_boxes)[src];
+            sc = a.s_prob[src];
+        }
+        reinterpret_cast<float4*>(out_boxes)[(size_t)img * a.post_n + r] = b;
+        out_scores[(size_t)img * a.post_n + r] = sc;
+    }
+    if (threadIdx.x == 0) out_counts[img] = cnt;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Detection post-processing (roi_heads.py:1075-1176, the reference's variant that also reports background boxes),
+// one call for the batch.  Per image two candidate lists: foreground (RoI x class >= 1) and background (RoIs without
+// any class above the score threshold, class-0 box); each list is sorted by decreasing score (ties: lower candidate
+// index, as a stable sort), goes through NMS (category = class) and the kept boxes are written fg first, then bg.
+//   k_det_candidates  per list slot: softmax, BoxCoder(10,10,5,5).decode, clip, score / size filters; also all_scores / all_boxes
+//   k_sort_lists      per list: bitonic sort in LDS (<= 16384 slots), gather into score order
+//   k_nms_mask / k_nms_scan (batched over the 2N lists),  k_det_output
+// ------------------------------------------------------------------------------------------------
+#define DET_SORT_MAX 16384
+struct DetPostArgs {
+    const float* logits;          // [R][K]
+    const float* deltas;          // [R][4K]
+    const float* props;           // [R][4]
+    int roi_base[RPN_MAX_IMAGES + 1];
+    float img_h[RPN_MAX_IMAGES], img_w[RPN_MAX_IMAGES];
+    int N, K, Kcap, det_per_img, out_cap;
+    float score_thresh, min_size, clip, wx, wy, ww, wh;
+    float* all_scores; float* all_boxes;                       // [R][K], [R][K][4]
+    float* boxes; float* skey; int* cat;                       // [2N][Kcap] candidate lists
+    float* s_boxes; float* s_score; int* s_cat; int* n_valid;   // sorted
+};
+
+__global__ __launch_bounds__(256) void k_det_candidates(const DetPostArgs a) {
+    const int list = blockIdx.y, img = list >> 1, bg = list & 1;
+    const int slot = blockIdx.x * 256 + threadIdx.x;
+    if (slot >= a.Kcap) return;
+    const int Ri = a.roi_base[img + 1] - a.roi_base[img];
+    const int rl = bg ? slot : slot / (a.K - 1), k = bg ? 0 : slot % (a.K - 1) + 1;
+    const size_t o = (size_t)list * a.Kcap + slot;
+    if (rl >= Ri) { a.skey[o] = -1.0f; a.cat[o] = 0; reinterpret_cast<float4*>(a.boxes)[o] = make_float4(0.f, 0.f, 0.f, 0.f); return; }
+    const int r = a.roi_base[img] + rl;
+    const float* lg = a.logits + (size_t)r * a.K;
+    float mx = lg[0];
+    for (int j = 1; j < a.K; ++j) mx = fmaxf(mx, lg[j]);
+    float sum = 0.0f;
+    bool has_fg_cand = false;                                   // filled below once the scores are known
+    for (int j = 0; j < a.K; ++j) sum = __fadd_rn(sum, expf(__fsub_rn(lg[j], mx)));
+    const float score = __fdiv_rn(expf(__fsub_rn(lg[k], mx)), sum);
+    if (bg)
+        for (int j = 1; j < a.K; ++j) has_fg_cand |= __fdiv_rn(expf(__fsub_rn(lg[j], mx)), sum) > a.score_thresh;
+    // BoxCoder(weights).decode_single
+    const float4 pb = reinterpret_cast<const float4*>(a.props)[r];
+    const float* d = a.deltas + (size_t)r * 4 * a.K + 4 * k;
+    const float w = __fsub_rn(pb.z, pb.x), h = __fsub_rn(pb.w, pb.y);
+    const float cx = __fadd_rn(pb.x, __fmul_rn(0.5f, w)), cy = __fadd_rn(pb.y, __fmul_rn(0.5f, h));
+    const float dx = __fdiv_rn(d[0], a.wx), dy = __fdiv_rn(d[1], a.wy);
+    const float dw = fminf(__fdiv_rn(d[2], a.ww), a.clip), dh = fminf(__fdiv_rn(d[3], a.wh), a.clip);
+    const float pcx = __fadd_rn(__fmul_rn(dx, w), cx), pcy = __fadd_rn(__fmul_rn(dy, h), cy);
+    const float hw = __fmul_rn(0.5f, __fmul_rn(expf(dw), w)), hh = __fmul_rn(0.5f, __fmul_rn(expf(dh), h));
+    const float W_ = a.img_w[img], H_ = a.img_h[img];
+    const float x1 = fminf(fmaxf(__fsub_rn(pcx, hw), 0.0f), W_), y1 = fminf(fmaxf(__fsub_rn(pcy, hh), 0.0f), H_);
+    const float x2 = fminf(fmaxf(__fadd_rn(pcx, hw), 0.0f), W_), y2 = fminf(fmaxf(__fadd_rn(pcy, hh), 0.0f), H_);
+    a.all_scores[(size_t)r * a.K + k] = score;
+    reinterpret_cast<float4*>(a.all_boxes)[(size_t)r * a.K + k] = make_float4(x1, y1, x2, y2);
+    const bool big = __fsub_rn(x2, x1) >= a.min_size && __fsub_rn(y2, y1) >= a.min_size;
+    const bool valid = big && (bg ? !has_fg_cand : score > a.score_thresh);
+    reinterpret_cast<float4*>(a.boxes)[o] = make_float4(x1, y1, x2, y2);
+    a.skey[o] = valid ? score : -1.0f;
+    a.cat[o] = k;
+}
+
+// one block per list: order = decreasing (score, then lower slot); n_valid = candidates with score >= 0
+__global__ __launch_bounds__(1024) void k_sort_lists(const float* __restrict__ skey, const float* __restrict__ boxes,
+                                                     const int* __restrict__ cat, int Kcap, float* __restrict__ s_boxes,
+                                                     float* __restrict__ s_score, int* __restrict__ s_cat,
+                                                     int* __restrict__ n_valid) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long* v = reinterpret_cast<unsigned long long*>(smem);
+    const int list = blockIdx.x, tid = threadIdx.x;
+    int np2 = 1;
+    while (np2 < Kcap) np2 <<= 1;
+    for (int i = tid; i < np2; i += 1024)
+        v[i] = i < Kcap ? ((unsigned long long)f2key(skey[(size_t)list * Kcap + i]) << 32) | (uint32_t)(~(uint32_t)i) : 0ull;
+    __syncthreads();
+    for (int k = 2; k <= np2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < np2; i += 1024) {
+                const int p = i ^ j;
+                if (p > i) {
+                    const unsigned long long x = v[i], y = v[p];
+                    const bool desc = (i & k) == 0;
+                    if (desc ? x < y : x > y) { v[i] = y; v[p] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    int valid = 0;
+    for (int i = tid; i < Kcap; i += 1024) {
+        const int c = (int)(~(uint32_t)v[i]);
+        const size_t src = (size_t)list * Kcap + c, dst = (size_t)list * Kcap + i;
+        reinterpret_cast<float4*>(s_boxes)[dst] = reinterpret_cast<const float4*>(boxes)[src];
+        const float sc = skey[src];
+        s_score[dst] = sc;
+        s_cat[dst] = cat[src];
+        valid += sc >= 0.0f;
+    }
+    for (int off = 32; off > 0; off >>= 1) valid += __shfl_down(valid, off);
+    __syncthreads();                                            // v[] is free now
+    int* part = reinterpret_cast<int*>(smem);
+    if ((tid & 63) == 0) part[tid >> 6] = valid;
+    __syncthreads();
+    if (tid == 0) {
+        int t = 0;
+        for (int w = 0; w < 16; ++w) t += part[w];
+        n_valid[list] = t;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_det_output(const DetPostArgs a, const int* __restrict__ keep, const int* __restrict__ n_keep,
+                                                    float* __restrict__ out_boxes, float* __restrict__ out_scores,
+                                                    int* __restrict__ out_labels, int* __restrict__ out_counts) {
+    const int img = blockIdx.x;
+    const int n_fg = min(n_keep[2 * img], a.det_per_img), n_bg = n_keep[2 * img + 1];
+    for (int r = threadIdx.x; r < n_fg + n_bg; r += 256) {
+        const int list = r < n_fg ? 2 * img : 2 * img + 1;
+        const size_t src = (size_t)list * a.Kcap + keep[(size_t)list * a.Kcap + (r < n_fg ? r : r - n_fg)];
+        const size_t dst = (size_t)img * a.out_cap + r;
+        reinterpret_cast<float4*>(out_boxes)[dst] = reinterpret_cast<const float4*>(a.s_boxes)[src];
+        out_scores[dst] = a.s_score[src];
+        out_labels[dst] = a.s_cat[src];
+    }
+    if (threadIdx.x == 0) { out_counts[2 * img] = n_fg; out_counts[2 * img + 1] = n_bg; }
+}
+
+// impulse responses of the LI cell (norse leaky_integrator.py: li_feed_forward_step; v_leak = 0)
+static void li_kappa(const snn_params* p, int T, Kappa* k) {
+    const double a = (double)p->dt_tau_mem, cb = (double)p->neg_dt_tau_syn;
+    for (int s = 0; s < SNN_MAX_STEPS; ++s) { k->last[s] = 0.f; k->sum[s] = 0.f; }
+    for (int s = 0; s < T; ++s) {
+        double v = 0.0, i = 0.0, acc = 0.0;
+        for (int t = s; t < T; ++t) {
+            const double x = (t == s) ? 1.0 : 0.0;
+            if (p->li_order == 0) {          // jump-first
+                const double in = i + x;
+                v = v + a * (in - v);
+                i = in + cb * in;
+            } else {                         // voltage-first
+                v = v + a * (i - v);
+                i = i + cb * i + x;
+            }
+            acc += v;
+        }
+        k->last[s] = (float)v;
+        k->sum[s] = (float)acc;
+    }
+}

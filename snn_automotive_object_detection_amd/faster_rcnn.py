@@ -43,6 +43,7 @@ class FastRCNNPredictorSNNFull(nn.Module):
         self._c6 = {"f32": _WeightCache(), "bf16x3": _WeightCache(), "mxfp6": _WeightCache()}
         self._c7 = {"f32": _WeightCache(), "bf16x3": _WeightCache(), "mxfp6": _WeightCache()}
         self._ch = _WeightCache()
+        self._flops_cache = {}
 
     def _eff_precision(self) -> str:
         if self.precision == "mxfp6" and (self.in_channels % 128 or self.representation_size % 128):
@@ -97,7 +98,11 @@ class FastRCNNPredictorSNNFull(nn.Module):
         r7 = (c7.to(torch.float64) / float(T * Hd)).to(torch.float32).view(R, 1)
         rc = (s_c / T).mean(dim=1, keepdim=True)
         rb = (s_b / T).mean(dim=1, keepdim=True)
-        fl = lambda v: torch.tensor([v], device=dev).repeat(R, 1)
+        def fl(v):                                                # cached: no host-to-device copy per call
+            key = (int(v), int(R), str(dev))
+            if key not in self._flops_cache:
+                self._flops_cache[key] = torch.tensor([v], device=dev).repeat(R, 1)
+            return self._flops_cache[key]
         D = self.in_channels
         return [torch.hstack((r6, fl(D * Hd))), torch.hstack((r7, fl(Hd * Hd))),
                 torch.hstack((rc, fl(Hd * K))),

@@ -66,6 +66,16 @@ class RPNHeadSNN(nn.Module):
                 torch.nn.init.normal_(layer.weight, std=0.01)
         self._cache_shared = {"f32": _WeightCache(), "bf16x3": _WeightCache(), "mxfp6": _WeightCache()}
         self._cache_heads = _WeightCache()
+        self._flops_cache = {}
+
+    def _flops_const(self, v: int, N: int, dev) -> Tensor:
+        """[N, 1] int64 tensor holding the FLOP constant v of the spike-rate output (rpn.py:177-188), made once per value"""
+        key = (int(v), int(N), str(dev))
+        t = self._flops_cache.get(key)
+        if t is None:
+            t = torch.tensor([v], device=dev).repeat(N, 1)
+            self._flops_cache[key] = t
+        return t
 
     def _eff_precision(self) -> str:
         if self.precision == "mxfp6" and self.in_channels % 128:
@@ -101,7 +111,7 @@ class RPNHeadSNN(nn.Module):
                 r_sh = (counts[l, :N].to(torch.float64) / float(T * C * H * W)).to(torch.float32).view(N, 1)
                 r_ob = (sum_l[pos:pos + n].view(N, -1) / T).mean(dim=1, keepdim=True)
                 r_bb = (sum_b[pos:pos + n].view(N, -1) / T).mean(dim=1, keepdim=True)
-                fl = lambda v: torch.tensor([v], device=dev).repeat(N, 1)
+                fl = lambda v: self._flops_const(v, N, dev)           # cached: no host-to-device copy per call
                 rates += [torch.hstack((r_sh, fl(9 * (H * W) * C * C))),
                           torch.hstack((r_ob, fl(1 * (H * W) * C * A * 4))),   # labels swapped in the
                           torch.hstack((r_bb, fl(1 * (H * W) * C * A)))]       # reference; kept as is

@@ -298,12 +298,12 @@ __global__ __launch_bounds__(256) void k_li_heads_mfma(const LiHeadsArgs a) {
 
 // K5c: the same heads when W does not fit in LDS (detector: K = 1024, 45 outputs) and there are few rows (2000): one
 // work-group per 16-row tile, its 4 waves split the reduction into quarters (so 125 work-groups of independent waves
-// instead of 32 that march through K together).  A wave keeps the accumulators of ALL time steps (T <= 16; 12 with 4 column
-// tiles), builds the
+// instead of 32 that march through K together).  A wave keeps the accumulators of 16 time steps (12 with 4 column tiles;
+// longer T runs in groups, each a pass over the wave's chunks), builds the
 // three bf16 planes of its weight fragments in registers straight from the fp32 W^T (read through L2, next chunk's
 // values requested before this chunk's MFMAs), and needs no barrier until the four partial results meet in LDS and are
 // added in wave order (deterministic).  2000 x 1024 x 45, T = 12: 68 us (fp32 VALU kernel) -> ~15 us.
-#define LIH_KS_TM(nt) ((nt) <= 3 ? 16 : 12)     // time steps whose accumulators fit in registers beside NT column tiles
+#define LIH_KS_TM(nt) ((nt) <= 2 ? 16 : 12)     // time steps per group: accumulators beside NT column tiles
 template <int NT>
 __global__ __launch_bounds__(256) void k_li_heads_ksplit(const LiHeadsArgs a) {
     constexpr int TM = LIH_KS_TM(NT);
@@ -324,13 +324,19 @@ __global__ __launch_bounds__(256) void k_li_heads_ksplit(const LiHeadsArgs a) {
     const int mrow = min(m0 + lr, a.M - 1);                    // rows past M: recomputed, never stored
     const uint32_t* wsrc = a.spk + (size_t)mrow * a.Kw;
     const int c0 = wave * Kc / 4, c1 = (wave + 1) * Kc / 4;    // this wave's chunks
+    // element (k = 32 kc + 8 lg + j, n = nt*16 + lr) of W^T: the lane's B fragment is j = 0..7
+    const float* const wlane = a.wT + (size_t)lg8 * NOp + lr;
+    f32x4 o_last[NT], o_sum[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { o_last[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; o_sum[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    // time steps in groups of TM (one group up to T = 16 / 12; T = 24: two passes over this wave's chunks)
+    for (int tg0 = 0; tg0 < T; tg0 += TM) {
+    const int tn = min(TM, T - tg0);                            // block-uniform
     f32x4 acc[TM][NT];
 #pragma unroll
     for (int t = 0; t < TM; ++t)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[t][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // element (k = 32 kc + 8 lg + j, n = nt*16 + lr) of W^T: the lane's B fragment is j = 0..7
-    const float* const wlane = a.wT + (size_t)lg8 * NOp + lr;
     float wf[NT][8];
     uint32_t w_nxt[TM];
     auto request = [&](int kc) {
@@ -339,7 +345,7 @@ __global__ __launch_bounds__(256) void k_li_heads_ksplit(const LiHeadsArgs a) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) wf[nt][j] = wlane[(size_t)(32 * kc + j) * NOp + nt * 16];
 #pragma unroll
-        for (int t = 0; t < TM; ++t) w_nxt[t] = t < T ? wsrc[(size_t)t * a.spk_stride + kc] : 0u;
+        for (int t = 0; t < TM; ++t) w_nxt[t] = t < tn ? wsrc[(size_t)(tg0 + t) * a.spk_stride + kc] : 0u;
     };
     if (c0 < c1) request(c0);
     for (int kc = c0; kc < c1; ++kc) {
@@ -361,7 +367,7 @@ __global__ __launch_bounds__(256) void k_li_heads_ksplit(const LiHeadsArgs a) {
         if (kc + 1 < c1) request(kc + 1);
 #pragma unroll
         for (int t = 0; t < TM; ++t) {
-            if (t < T) {                                        // block-uniform
+            if (t < tn) {                                       // block-uniform
                 const bf16x8 af = *reinterpret_cast<const bf16x8*>(lut + (__builtin_amdgcn_ubfe(w_cur[t], lg8, 8) << 4));
 #pragma unroll
                 for (int pl = 2; pl >= 0; --pl)
@@ -371,13 +377,10 @@ __global__ __launch_bounds__(256) void k_li_heads_ksplit(const LiHeadsArgs a) {
             }
         }
     }
-    f32x4 o_last[NT], o_sum[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) { o_last[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; o_sum[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
     for (int t = 0; t < TM; ++t)
-        if (t < T) {
-            const float kl = a.kap.last[t], ks = a.kap.sum[t];
+        if (t < tn) {
+            const float kl = a.kap.last[tg0 + t], ks = a.kap.sum[tg0 + t];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -386,6 +389,7 @@ __global__ __launch_bounds__(256) void k_li_heads_ksplit(const LiHeadsArgs a) {
                     o_sum[nt][r] = fmaf(ks, acc[t][nt][r], o_sum[nt][r]);
                 }
         }
+    }   // time groups
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         red[((wave * 2 + 0) * NT + nt) * 64 + lane] = o_last[nt];

@@ -768,7 +768,7 @@ int snn_li_heads(const uint32_t* spk, size_t spk_stride, int T, int M, int K, co
     // bound on small row counts (detector heads: 164 us against 88 us for the VALU kernel) and only runs when forced
     const bool fits = (size_t)Kw * 3 * NOp * 64 <= 96 * 1024;
     // W too large for LDS: one work-group per 16 rows, the reduction split over its 4 waves ("ksplit" forces it)
-    if (NOp <= 64 && T <= LIH_KS_TM(NOp / 16) && Kw >= 4 && (force ? !strcmp(force, "ksplit") : !fits)) {
+    if (NOp <= 64 && Kw >= 4 && (force ? !strcmp(force, "ksplit") : !fits)) {
         LiHeadsArgs a;
         memset(&a, 0, sizeof(a));
         a.spk = spk; a.spk_stride = spk_stride; a.wT = w_heads_packed; a.out_a = out_a; a.out_b = out_b;

@@ -176,7 +176,8 @@ def test_li_heads_both_orders(S, gpu_device, li_order):
     assert (o_b.cpu().view(N, H, W, 4 * A).permute(0, 3, 1, 2) - exp_b).abs().max() <= CUR_TOL
 
 
-@pytest.mark.parametrize("T,M,K,NA,NB", [(12, 300, 1024, 9, 36), (16, 45, 160, 2, 8), (12, 130, 1024, 11, 44), (5, 17, 2048, 3, 12)])
+@pytest.mark.parametrize("T,M,K,NA,NB", [(12, 300, 1024, 9, 36), (16, 45, 160, 2, 8), (12, 130, 1024, 11, 44), (5, 17, 2048, 3, 12),
+                                          (24, 70, 1024, 9, 36), (20, 33, 512, 11, 44)])     # the last two: more than one time group
 @pytest.mark.parametrize("li_order", ["jump_first", "voltage_first"])
 def test_li_heads_kernel_forms_agree_with_fp64(S, gpu_device, monkeypatch, li_order, T, M, K, NA, NB):
     """the three kernels behind snn_li_heads (fp32 VALU, matrix cores with W resident in LDS, matrix cores with the reduction

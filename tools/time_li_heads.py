@@ -12,7 +12,7 @@ def tm(fn, n=20):
         a.record(); fn(); b.record()
     torch.cuda.synchronize()
     return min(a.elapsed_time(b) for a, b in ev) * 1e3
-for (T, M, K, NA, NB) in [(12, 2000, 1024, 9, 36), (12, 4000, 1024, 11, 44), (8, 2000, 1024, 9, 36), (16, 2000, 1024, 9, 36)]:
+for (T, M, K, NA, NB) in [(12, 2000, 1024, 9, 36), (12, 4000, 1024, 11, 44), (8, 2000, 1024, 9, 36), (16, 2000, 1024, 9, 36), (24, 2000, 1024, 9, 36)]:
     spk = (torch.rand(T, M, K, device=dev) < 0.08)
     words = (spk.view(T, M, K // 32, 32).to(torch.int64) << torch.arange(32, device=dev)).sum(-1).to(torch.int32).contiguous()
     wa = torch.randn(NA, K, device=dev) / 32; wb = torch.randn(NB, K, device=dev) / 32

@@ -2,18 +2,29 @@
 """Benchmark of the spiking-heads hot path on MI355X.
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
-  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+N > 1 works both ways: under torchrun (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py
+--gpus N ...`: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment, /root/reference/utils.py:268-312's
+contract) and stand-alone (`python bench.py --gpus N`: this process starts the N ranks itself as child processes BEFORE
+anything touches the GPU, waits for them and passes rank 0's JSON line through; a rank that dies gives a non-zero exit).
 
 One "step" = one pass of the hot path over one batch of synthetic input resident in HBM:
 RPNHeadSNN.forward (T_rpn=8) on the 5-level FPN pyramid of a 1024x2048 Cityscapes batch of 2
 (768x1536 after the transform: 192x384 ... 12x24, 256 ch) followed by
 FastRCNNPredictorSNNFull.forward (T_det=12) on the 2x1000 RoI features [2000,256,7,7], K=9, fp32,
 then the exchange payload (top-100 RoIs per image, snn_det_exchange_payload) and, when N>1, the path's one exchange
-step (all-gather of those rows, dp.py).
-Images shard over ranks (weak scaling: every rank runs its own batch of 2).
+step (all-gather of those rows over RCCL, dp.py).  Images shard over ranks (weak scaling: every rank runs its own batch
+of 2 - contiguous image blocks per rank like the reference's DistributedSampler(shuffle=False), train.py:598-601).
+
+Inputs (`--inputs backbone`, default): the pyramid is the FPN output of the (random-init) ResNet-50-FPN on seeded
+`torch.rand(3,1024,2048)` images through the reference's transform, the RoI features are the
+7x7 RoIAlign of 1000 seeded boxes per image on that pyramid.  `--inputs randn`: N(0,1) tensors (round-1 behaviour).
 
 Prints ONE JSON line (rank 0): metric images/s + "roofline" (dominant kernel, timed live with HIP events
-on the launch stream) + "cpu_baseline" (the oracle on the host cores, bounded sample, rank 0 at N=1 only).
+on the launch stream, on this workload's own encoder planes) + "cpu_baseline" (the oracle on the host cores, bounded sample,
+rank 0 at N=1 only) + "extra" (outside the headline timing, N=1 only): a sustained >= 2 s window of the same step, the
+end-to-end model (BASELINE config[2]), the BDD per-rank share (config[3]) and the T=16/24 spike-rate stress workload
+(config[4]), each with the launch time and roofline fraction of its own conv+LIF kernel.
 
 --precision bf16x3 (default): both big contractions run on the bf16 matrix cores with an EXACT 3-way bf16
   split of the fp32 weights (spikes are exactly {0,1}; fp32 accumulation; as accurate as the fp32 MFMA chain,
@@ -23,71 +34,281 @@ on the launch stream) + "cpu_baseline" (the oracle on the host cores, bounded sa
 import argparse
 import json
 import os
+import platform
+import statistics
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-LEVELS = [(192, 384), (96, 192), (48, 96), (24, 48), (12, 24)]   # 768x1536 / (4,8,16,32,64)
-C, A, K_CLS, HD = 256, 3, 9, 1024
-T_RPN, T_DET = 8, 12
-BATCH, ROIS_PER_IMG = 2, 1000
+LEVELS_CITY = [(192, 384), (96, 192), (48, 96), (24, 48), (12, 24)]   # 768x1536 / (4,8,16,32,64)
+LEVELS_BDD = [(192, 344), (96, 172), (48, 86), (24, 43), (12, 22)]    # 720x1280 -> 768x1365 -> canvas 768x1376
+C, A, HD = 256, 3, 1024
+ROIS_PER_IMG = 1000
 PEAK_F32_MFMA_TFLOPS = 157.3                                     # MI355X_MICROARCH.md chip table
 PEAK_BF16_MFMA_TFLOPS = 2500.0                                   # dense bf16 (no sparsity)
 PEAK_MX_MFMA_TFLOPS = 10000.0                                    # dense fp6 / fp4 block-scaled (spec, no sparsity)
 
-
 WORKLOADS = {
-    "cityscapes": {"levels": LEVELS, "K": 9, "T_rpn": 8, "T_det": 12, "batch": 2, "spike_rates": False,
-                   "name": "cityscapes_1024x2048_b2_heads"},
+    "cityscapes": {"levels": LEVELS_CITY, "image": (1024, 2048), "K": 9, "T_rpn": 8, "T_det": 12, "batch": 2, "spike_rates": False,
+                   "dataset": "cityscapes", "name": "cityscapes_1024x2048_b2_heads"},
     # BDD 720x1280 -> 768x1376 canvas (SURVEY.md §8 shape table), 4 images per GPU
-    "bdd": {"levels": [(192, 344), (96, 172), (48, 86), (24, 43), (12, 22)], "K": 11, "T_rpn": 8, "T_det": 12, "batch": 4,
-            "spike_rates": False, "name": "bdd_720x1280_b4_heads"},
-    "stress": {"levels": LEVELS, "K": 9, "T_rpn": 16, "T_det": 24, "batch": 2, "spike_rates": True,
-               "name": "cityscapes_1024x2048_b2_heads_T16_T24_spike_rates"},
+    "bdd": {"levels": LEVELS_BDD, "image": (720, 1280), "K": 11, "T_rpn": 8, "T_det": 12, "batch": 4, "spike_rates": False,
+            "dataset": "bdd", "name": "bdd_720x1280_b4_heads"},
+    "stress": {"levels": LEVELS_CITY, "image": (1024, 2048), "K": 9, "T_rpn": 16, "T_det": 24, "batch": 2, "spike_rates": True,
+               "dataset": "cityscapes", "name": "cityscapes_1024x2048_b2_heads_T16_T24_spike_rates"},
 }
+# reference CLI spelling of the step counts (train.py:60-63 `-t-rpn`, `-t-det`; `--rpn-snn --detector-snn` are implied:
+# only the spiking heads exist here)
+PRECISIONS = ("bf16x3", "f32", "mxfp6")
 
 
-def algorithmic_flops():
-    pos = BATCH * sum(h * w for h, w in LEVELS)
-    conv = pos * 2 * 9 * C * C * T_RPN                            # dominant kernel
-    rpn = pos * 2 * (9 * C * C + C * A + C * 4 * A) * T_RPN
-    det = BATCH * ROIS_PER_IMG * 2 * (C * 49 * HD + HD * HD + HD * 5 * K_CLS) * T_DET
+def algorithmic_flops(wl):
+    pos = wl["batch"] * sum(h * w for h, w in wl["levels"])
+    conv = pos * 2 * 9 * C * C * wl["T_rpn"]                      # dominant kernel
+    rpn = pos * 2 * (9 * C * C + C * A + C * 4 * A) * wl["T_rpn"]
+    det = wl["batch"] * ROIS_PER_IMG * 2 * (C * 49 * HD + HD * HD + HD * 5 * wl["K"]) * wl["T_det"]
     return conv, rpn, det
 
 
-def make_inputs(dev, seed):
-    g = torch.Generator(device="cpu").manual_seed(seed)
-    feats = [torch.randn((BATCH, C, h, w), generator=g).to(dev) for h, w in LEVELS]
-    rois = torch.randn((BATCH * ROIS_PER_IMG, C, 7, 7), generator=g).to(dev)
-    return feats, rois
+def kernel_of(precision):
+    """(kernel name, matrix-pipe peak TFLOP/s, executed MFMA work / algorithmic FLOPs)"""
+    if precision == "f32":
+        return "k_conv3x3_lif<false>", PEAK_F32_MFMA_TFLOPS, 1.0
+    if precision == "mxfp6":
+        # fp4 x fp6 block-scaled MFMA, 6 digit planes per weight at 4x the K per instruction: executed work = 6/4 of the
+        # bf16-equivalent; peak = 10 PF dense fp6/fp4 (spec)
+        return "k_gemm_mx<3, 4>", PEAK_MX_MFMA_TFLOPS, 6.0
+    # MODE = G3_CONV_LIF_TILE: 3x3 conv + LIF over T fused in the tile, on the bf16 matrix cores
+    return "k_gemm_bf16x3<G3_CONV_LIF_TILE>", PEAK_BF16_MFMA_TFLOPS, 3.0
 
 
-def cpu_baseline():
-    """the oracle (CPU restatement of the reference loops, un-fused torch ops) on a bounded sample:
-    ONE of the two images — RPN head on the b=1 pyramid + detector head on its 1000 RoIs"""
+# ---------------------------------------------------------------------------------------------
+# CPU baseline: the oracle on the host cores (bounded sample), outside every timed region
+# ---------------------------------------------------------------------------------------------
+def cpu_model_name():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return platform.processor() or "unknown"
+
+
+def cpu_baseline(repeats=3):
+    """the oracle (CPU restatement of the reference loops, un-fused torch ops) on the headline batch: both images
+    (b=2 pyramid, T=8) + the detector head on their 2000 RoIs (T=12); 1 warm-up (levels 1..4 + 256 RoIs: pages the
+    thread pool and allocator in without doubling the cost) + `repeats` timed passes, median reported"""
+    import torch
     from oracle import snn_oracle as OR
+    wl = WORKLOADS["cityscapes"]
     g = torch.Generator().manual_seed(0)
-    feats = [torch.randn((1, C, h, w), generator=g) for h, w in LEVELS]
-    rois = torch.randn((ROIS_PER_IMG, C, 7, 7), generator=g)
+    feats = [torch.randn((wl["batch"], C, h, w), generator=g) for h, w in wl["levels"]]
+    rois = torch.randn((wl["batch"] * ROIS_PER_IMG, C, 7, 7), generator=g)
     w_s = torch.randn((C, C, 3, 3), generator=g) * 0.01
     w_c = torch.randn((A, C, 1, 1), generator=g) * 0.01
     w_b = torch.randn((4 * A, C, 1, 1), generator=g) * 0.01
+    K = wl["K"]
     w6 = (torch.rand((HD, C * 49), generator=g) * 2 - 1) / (C * 49) ** 0.5
     w7 = (torch.rand((HD, HD), generator=g) * 2 - 1) / HD ** 0.5
-    wc = (torch.rand((K_CLS, HD), generator=g) * 2 - 1) / HD ** 0.5
-    wb = (torch.rand((4 * K_CLS, HD), generator=g) * 2 - 1) / HD ** 0.5
+    wc = (torch.rand((K, HD), generator=g) * 2 - 1) / HD ** 0.5
+    wb = (torch.rand((4 * K, HD), generator=g) * 2 - 1) / HD ** 0.5
     threads = torch.get_num_threads()
+    times = []
     with torch.no_grad():
-        t0 = time.perf_counter()
-        OR.rpn_head_forward(feats, w_s, w_c, w_b, T_RPN)
-        OR.det_head_forward(rois, w6, w7, wc, wb, T_DET)
-        dt = time.perf_counter() - t0
-    return {"value": round(1.0 / dt, 4), "unit": "images/s", "cores": threads, "kind": "port",
-            "sample": "1 image: oracle RPN head (b=1 pyramid, T=8) + detector head (1000 RoIs, T=12), %.1f s" % dt}
+        OR.rpn_head_forward(feats[1:], w_s, w_c, w_b, wl["T_rpn"])          # warm-up
+        OR.det_head_forward(rois[:256], w6, w7, wc, wb, wl["T_det"])
+        for _ in range(repeats):
+            t0 = time.perf_counter()
+            OR.rpn_head_forward(feats, w_s, w_c, w_b, wl["T_rpn"])
+            OR.det_head_forward(rois, w6, w7, wc, wb, wl["T_det"])
+            times.append(time.perf_counter() - t0)
+    med = statistics.median(times)
+    return {"value": round(wl["batch"] / med, 4), "unit": "images/s", "cores": threads, "kind": "port",
+            "cpu": cpu_model_name(), "repeats": repeats, "seconds": [round(t, 2) for t in times],
+            "sample": "b=2: oracle RPN head (5-level pyramid, T=8) + detector head (2000 RoIs, T=12); 1 warm-up + %d repeats, "
+                      "median %.1f s per batch" % (repeats, med)}
+
+
+# ---------------------------------------------------------------------------------------------
+# one workload on one device
+# ---------------------------------------------------------------------------------------------
+class Leg:
+    """modules + HBM-resident inputs of one workload"""
+
+    def __init__(self, wl, precision, dev, seed, inputs, backbone_model=None):
+        import torch
+        import snn_automotive_object_detection_amd as S
+        self.wl, self.dev, self.precision = wl, dev, precision
+        torch.manual_seed(1234)                                  # same weights on every rank
+        self.rpn_head = S.RPNHeadSNN(C, A, wl["T_rpn"]).to(dev)
+        self.det_head = S.FastRCNNPredictorSNNFull(C * 49, HD, wl["K"], wl["T_det"]).to(dev)
+        self.set_precision(precision)
+        self.rpn_head.spike_rates = self.det_head.spike_rates = wl["spike_rates"]
+        self.input_note = None
+        if inputs == "backbone":
+            self.feats, self.rois, self.input_note = self._backbone_inputs(seed, backbone_model)
+        else:
+            g = torch.Generator(device="cpu").manual_seed(seed)
+            self.feats = [torch.randn((wl["batch"], C, h, w), generator=g).to(dev) for h, w in wl["levels"]]
+            self.rois = torch.randn((wl["batch"] * ROIS_PER_IMG, C, 7, 7), generator=g).to(dev)
+            self.input_note = "N(0,1) tensors"
+
+    def set_precision(self, precision):
+        self.precision = precision
+        self.rpn_head.precision = self.det_head.precision = precision
+
+    def _backbone_inputs(self, seed, model):
+        """FPN pyramid of seeded rand images through transform + ResNet-50-FPN (random init, reference hyper-parameters);
+        RoI features = MultiScaleRoIAlign of 1000 seeded boxes per image (sizes log-uniform 16..512 px)"""
+        import torch
+        from snn_automotive_object_detection_amd.stock.roi_align import MultiScaleRoIAlign
+        wl, dev = self.wl, self.dev
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        H, W = wl["image"]
+        images = [torch.rand((3, H, W), generator=g).to(dev) for _ in range(wl["batch"])]
+        with torch.no_grad():
+            il, _ = model.transform(images)
+            fmap = model.backbone(il.tensors)
+            feats = [f.contiguous() for f in fmap.values()]
+            assert [tuple(f.shape[-2:]) for f in feats] == [tuple(l) for l in wl["levels"]], [f.shape for f in feats]
+            props = []
+            for (h, w) in il.image_sizes:
+                size = torch.exp(torch.rand((ROIS_PER_IMG, 2), generator=g) * (6.238 - 2.773) + 2.773)   # 16..512 px
+                ctr = torch.rand((ROIS_PER_IMG, 2), generator=g) * torch.tensor([float(w), float(h)])
+                b = torch.cat([ctr - size / 2, ctr + size / 2], 1)
+                b[:, 0::2] = b[:, 0::2].clamp(0, float(w))
+                b[:, 1::2] = b[:, 1::2].clamp(0, float(h))
+                props.append(b.to(dev))
+            pool = MultiScaleRoIAlign(featmap_names=["0", "1", "2", "3"], output_size=7, sampling_ratio=2)
+            rois = pool(fmap, props, il.image_sizes).contiguous()
+        del images, fmap
+        note = ("FPN output of the random-init ResNet-50-FPN on seeded rand(3,%d,%d) images (transform 768/1536); RoI features = "
+                "7x7 RoIAlign of 1000 seeded boxes per image" % (H, W))
+        return feats, rois, note
+
+    def step(self):
+        from snn_automotive_object_detection_amd import dp, ops
+        rpn_out = self.rpn_head(self.feats)
+        det_out = self.det_head(self.rois)
+        if self.wl["spike_rates"]:       # the spike-rate variants return rate tensors only (faster_rcnn.py:520-618)
+            return rpn_out, det_out
+        cls, deltas = det_out
+        payload, counts = ops.det_exchange_payload(cls, deltas, self.wl["batch"], 100)   # top-100 RoIs per image, one launch
+        return dp.all_gather_detection_tensors(payload, counts)  # no-op at world == 1
+
+    def exchange_only(self):
+        """(payload, counts) of one step, for timing the exchange by itself"""
+        from snn_automotive_object_detection_amd import ops
+        cls, deltas = self.det_head(self.rois)
+        return ops.det_exchange_payload(cls, deltas, self.wl["batch"], 100)
+
+    # ---- per-kernel timing with HIP events on the launch stream ----
+    @staticmethod
+    def time_ms(fn, iters):
+        import torch
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+        for a, b in ev:
+            a.record(); fn(); b.record()
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in ev) / iters
+
+    def kernel_breakdown(self, iters):
+        """conv+LIF launch timed on THIS pyramid's encoder planes: a full RPN-head call leaves them in the workspace, and
+        nothing else runs on that workspace until the stage-2 launches are done"""
+        from snn_automotive_object_detection_amd import ops
+        wl = self.wl
+        p = self.rpn_head._params()
+        w_sh = self.rpn_head._packed_shared()
+        w_hd = self.rpn_head._cache_heads.val
+        T = wl["T_rpn"]
+        ops.rpn_head_forward(self.feats, C, A, T, p, w_sh, w_hd, stage_mask=7)
+        conv_ms = self.time_ms(lambda: ops.rpn_head_forward(self.feats, C, A, T, p, w_sh, w_hd, stage_mask=2), iters)
+        enc_ms = self.time_ms(lambda: ops.rpn_head_forward(self.feats, C, A, T, p, w_sh, w_hd, stage_mask=1), iters)
+        rpn_ms = self.time_ms(lambda: self.rpn_head(self.feats), iters)
+        det_ms = self.time_ms(lambda: self.det_head(self.rois), iters)
+        return {"rpn_head": rpn_ms, "rpn_encode": enc_ms, "rpn_conv3x3_lif": conv_ms, "det_head": det_ms}
+
+    def roofline(self, conv_ms, traffic=None):
+        conv_fl, _, _ = algorithmic_flops(self.wl)
+        kernel, peak, exec_factor = kernel_of(self.precision)
+        achieved = conv_fl / (conv_ms * 1e-3) / 1e12            # ALGORITHMIC (dense-equivalent) TFLOP/s
+        # achieved = ALGORITHMIC FLOPs of the launch / its duration.  For bf16x3 the peak is what the bf16 matrix pipe
+        # can deliver of this arithmetic: the dense bf16 MFMA peak / 3 MFMAs per exact fp32 product (the executed
+        # rate against the full 2.5 PF is the same fraction; both are spelled out).
+        return {"bound": "mfma", "kernel": kernel, "achieved": round(achieved, 2), "peak": round(peak / exec_factor, 1),
+                "unit": "TFLOP/s", "frac": round(achieved * exec_factor / peak, 4), "traffic": traffic,
+                "launch_ms": round(conv_ms, 4), "algorithmic_gflop_per_launch": round(conv_fl / 1e9, 1),
+                "executed_over_algorithmic": exec_factor, "executed_tflops": round(achieved * exec_factor, 2),
+                "mfma_peak_tflops": peak, "algorithmic_frac_of_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4)}
+
+    def spike_stats(self):
+        """measured firing rates of this workload's inputs: encoder planes (popcount) and shared-LIF (the head's counts)"""
+        import torch
+        from snn_automotive_object_detection_amd import ops
+        wl = self.wl
+        T = wl["T_rpn"]
+        p = self.rpn_head._params()
+        lut = torch.tensor([bin(i).count("1") for i in range(256)], dtype=torch.int64, device=self.dev)
+        enc_bits = enc_n = 0
+        for f in self.feats:
+            planes = ops.encode_nchw(f, T, p)
+            enc_bits += int(lut[planes.view(torch.uint8).to(torch.int64)].sum())
+            enc_n += T * f.numel()
+        _, _, rows, (counts, _, _) = ops.rpn_head_forward(self.feats, C, A, T, p, self.rpn_head._packed_shared(),
+                                                          self.rpn_head._cache_heads.get((self.rpn_head.conv_cls.weight, self.rpn_head.conv_bbox.weight), ops.pack_heads),
+                                                          spike_rates=True)
+        lif_bits = int(counts[:, :wl["batch"]].sum())
+        planes = ops.encode_rows(self.rois.flatten(1), wl["T_det"], self.det_head._params())
+        det_bits = int(lut[planes.view(torch.uint8).to(torch.int64)].sum())
+        return {"rpn_encoder_rate": round(enc_bits / enc_n, 4), "rpn_shared_lif_rate": round(lif_bits / enc_n, 4),
+                "det_encoder_rate": round(det_bits / (wl["T_det"] * self.rois.numel()), 4)}
+
+
+def timed_steps(leg, steps, warmup, fence):
+    for _ in range(warmup):
+        leg.step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        leg.step()
+    fence()
+    return time.perf_counter() - t0
+
+
+def e2e_leg(model, dev, iters=5):
+    """BASELINE config[2]: the whole model through create_model on 2 x rand(3,1024,2048) (generalized_rcnn.py:80-122):
+    images/s and the stage split, each stage fenced by a device synchronisation"""
+    import torch
+    g = torch.Generator(device="cpu").manual_seed(7)
+    imgs = [torch.rand((3, 1024, 2048), generator=g).to(dev) for _ in range(2)]
+    sync = torch.cuda.synchronize
+    for _ in range(2):
+        out = model(imgs)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        out = model(imgs)
+    sync()
+    ms = (time.perf_counter() - t0) / iters * 1e3
+    st = [0.0] * 4
+    with torch.no_grad():
+        for _ in range(iters):
+            sync(); a = time.perf_counter()
+            il, _ = model.transform(imgs); sync(); b = time.perf_counter()
+            feats = model.backbone(il.tensors); sync(); c = time.perf_counter()
+            props, _ = model.rpn(il, feats); sync(); d = time.perf_counter()
+            model.roi_heads(feats, props, il.image_sizes); sync(); e = time.perf_counter()
+            for i, v in enumerate((b - a, c - b, d - c, e - d)):
+                st[i] += v * 1e3 / iters
+    return {"workload": "create_model('cityscapes', 9, T_rpn=8, T_det=12) on 2 x rand(3,1024,2048), random init, fp32 backbone (stock MIOpen)",
+            "value": round(2 / (ms * 1e-3), 2), "unit": "images/s", "ms_per_batch": round(ms, 3),
+            "stage_ms": {"transform": round(st[0], 3), "backbone_fpn": round(st[1], 3),
+                         "rpn_head_and_proposals": round(st[2], 3), "roi_heads_roialign_dethead_postprocess": round(st[3], 3)},
+            "detections": [int(d["boxes"].shape[0]) for d in out], "proposals": [int(p.shape[0]) for p in props]}
 
 
 def main():
@@ -96,20 +317,41 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the legs outside the headline timing (sustained / e2e / bdd / stress / alt precision)")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra timing leg with the other precision")
-    ap.add_argument("--precision", choices=["bf16x3", "f32", "mxfp6"], default="bf16x3")
+    ap.add_argument("--precision", choices=PRECISIONS, default="bf16x3")
+    ap.add_argument("--inputs", choices=["backbone", "randn"], default="backbone")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cityscapes",
                     help="cityscapes = BASELINE.json's headline configuration (default); bdd = config[3] per-rank share "
                          "(720x1280, 4 images per GPU, K=11); stress = config[4] (T=16/24, spike-rate outputs on)")
+    ap.add_argument("-t-rpn", "--t-rpn", dest="t_rpn", type=int, default=None, help="RPN time steps (reference CLI: -t-rpn)")
+    ap.add_argument("-t-det", "--t-det", dest="t_det", type=int, default=None, help="detector time steps (reference CLI: -t-det)")
+    ap.add_argument("--rpn-snn", action="store_true", help="accepted for CLI compatibility (always on)")
+    ap.add_argument("--detector-snn", action="store_true", help="accepted for CLI compatibility (always on)")
+    ap.add_argument("--cpu-repeats", type=int, default=3)
+    ap.add_argument("--sustain-s", type=float, default=2.0)
     args = ap.parse_args()
-    global LEVELS, K_CLS, T_RPN, T_DET, BATCH
-    wl = WORKLOADS[args.workload]
-    LEVELS, K_CLS, T_RPN, T_DET, BATCH = wl["levels"], wl["K"], wl["T_rpn"], wl["T_det"], wl["batch"]
 
+    # ---- stand-alone multi-rank launch: start the ranks BEFORE anything initialises the GPU in this process ----
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import torch                                             # device_count() does not initialise the GPU
+        from snn_automotive_object_detection_amd import dp
+        n_dev = torch.cuda.device_count()
+        if n_dev < args.gpus and "SNN_DP_DEVICE" not in os.environ:
+            raise SystemExit("--gpus %d but only %d device(s) visible (a test run of the N-rank path on fewer devices: "
+                             "SNN_DIST_BACKEND=gloo SNN_DP_DEVICE=0)" % (args.gpus, n_dev))
+        sys.exit(dp.launch_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+
+    import torch
     import snn_automotive_object_detection_amd as S
-    from snn_automotive_object_detection_amd import dp, ops
+    from snn_automotive_object_detection_amd import dp
     import torch.distributed as dist
 
+    wl = dict(WORKLOADS[args.workload])
+    if args.t_rpn:
+        wl["T_rpn"] = args.t_rpn
+    if args.t_det:
+        wl["T_det"] = args.t_det
     rank, local, world = dp.init_distributed()
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
@@ -118,102 +360,64 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    torch.manual_seed(1234)                                      # same weights on every rank
-    rpn_head = S.RPNHeadSNN(C, A, T_RPN).to(dev)
-    det_head = S.FastRCNNPredictorSNNFull(C * 49, HD, K_CLS, T_DET).to(dev)
-    rpn_head.precision = det_head.precision = args.precision
-    rpn_head.spike_rates = det_head.spike_rates = wl["spike_rates"]
-    feats, rois = make_inputs(dev, 1000 + rank)                  # inputs resident in HBM
+    models = {}
 
-    def step():
-        rpn_out = rpn_head(feats)
-        det_out = det_head(rois)
-        if wl["spike_rates"]:            # the spike-rate variants return rate tensors only (faster_rcnn.py:520-618)
-            return rpn_out, det_out
-        cls, deltas = det_out
-        payload, counts = ops.det_exchange_payload(cls, deltas, BATCH, 100)     # top-100 RoIs per image, one launch
-        return dp.all_gather_detection_tensors(payload, counts)  # no-op at world == 1
+    def model_for(dataset, K):
+        if (dataset, K) not in models:                           # the backbone that feeds the heads (and the e2e leg)
+            torch.manual_seed(4321)
+            models[(dataset, K)] = S.create_model(dataset, K, True, True, 0, False, False, 8, 12).to(dev).eval()
+        return models[(dataset, K)]
+
+    def make_leg(w, precision):
+        m = model_for(w["dataset"], w["K"]) if args.inputs == "backbone" else None
+        return Leg(w, precision, dev, 1000 + rank, args.inputs, m)
+
+    leg = make_leg(wl, args.precision)
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
+    dt = timed_steps(leg, args.steps, args.warmup, fence)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if dp.backend_name() != "gloo" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
     ms = dt / args.steps * 1e3
-    value = world * BATCH * args.steps / dt
+    value = world * wl["batch"] * args.steps / dt
 
-    # ---- the same K steps with the other matrix path of the two big contractions (outside the headline number):
-    # "mxfp6" = fp4 x fp6 block-scaled MFMA on 6 digit planes per weight (passes the same parity tests)
-    alt = None
-    if not args.no_alt and world == 1:
-        alt_prec = "bf16x3" if args.precision == "mxfp6" else "mxfp6"
-        rpn_head.precision = det_head.precision = alt_prec
-        for _ in range(max(1, args.warmup)):
-            step()
+    # ---- the exchange step by itself (outside the headline timing) ----
+    exchange = {"backend": dp.backend_name(), "ranks": world, "ms": None}
+    if world > 1:
+        payload, counts = leg.exchange_only()
         fence()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        fence()
-        dt_alt = time.perf_counter() - t1
-        alt = {"precision": alt_prec, "value": round(BATCH * args.steps / dt_alt, 3), "unit": "images/s",
-               "ms_per_step": round(dt_alt / args.steps * 1e3, 4)}
-        rpn_head.precision = det_head.precision = args.precision
+        xs = []
+        for _ in range(max(5, args.warmup)):
+            fence()
+            t0 = time.perf_counter()
+            g_payload, g_counts = dp.all_gather_detection_tensors(payload, counts)
+            torch.cuda.synchronize()
+            xs.append((time.perf_counter() - t0) * 1e3)
+        exchange.update(ms=round(statistics.median(xs), 4), ranks=dist.get_world_size(),
+                        rows_gathered=int(g_payload.shape[0]), payload_bytes_per_rank=int(payload.numel() * 4 + counts.numel() * 4))
+        assert g_payload.shape[0] == world * wl["batch"] and int(g_counts.min()) >= 0
 
-    # ---- per-kernel timing with HIP events on the launch stream (outside the timed region) ----
-    def time_ms(fn, iters):
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
-        for a, b in ev:
-            a.record(); fn(); b.record()
-        torch.cuda.synchronize()
-        return sum(a.elapsed_time(b) for a, b in ev) / iters
-
-    p = rpn_head._params()
-    w_sh = rpn_head._packed_shared()
-    w_hd = rpn_head._cache_heads.val
     iters = max(3, min(args.steps, 10))
-    conv_ms = time_ms(lambda: ops.rpn_head_forward(feats, C, A, T_RPN, p, w_sh, w_hd, stage_mask=2), iters)
-    enc_ms = time_ms(lambda: ops.rpn_head_forward(feats, C, A, T_RPN, p, w_sh, w_hd, stage_mask=1), iters)
-    rpn_ms = time_ms(lambda: rpn_head(feats), iters)
-    det_ms = time_ms(lambda: det_head(rois), iters)
-    conv_fl, rpn_fl, det_fl = algorithmic_flops()
-    P = BATCH * sum(h * w for h, w in LEVELS)
-    if args.precision == "f32":
-        kernel, peak, exec_factor, kernel_ms = "k_conv3x3_lif<false>", PEAK_F32_MFMA_TFLOPS, 1.0, conv_ms
-        traffic_key = "f32"
-    elif args.precision == "mxfp6":
-        # stage 2 = k_gemm_mx<3, 4> (G3_CONV_LIF_TILE): fp4 x fp6 block-scaled MFMA, 6 digit planes per weight at 4x the K per
-        # instruction: executed work = 6/4 of the bf16-equivalent; peak = 10 PF dense fp6/fp4 (spec)
-        kernel, peak, exec_factor, kernel_ms = "k_gemm_mx<3, 4>", PEAK_MX_MFMA_TFLOPS, 6.0, conv_ms
-        traffic_key = "mxfp6"
-    else:
-        # stage 2 = k_gemm_bf16x3<3, 3, 4, 2> (MODE = G3_CONV_LIF_TILE, 3-slot ring, 4 M-tiles per wave, 4 x 2 wave grid): 3x3 conv + LIF over T fused in the tile,
-        # on the bf16 matrix cores
-        kernel, peak, exec_factor, kernel_ms = "k_gemm_bf16x3<3, 3, 4, 2>", PEAK_BF16_MFMA_TFLOPS, 3.0, conv_ms
-        traffic_key = "bf16x3"
-    achieved = conv_fl / (kernel_ms * 1e-3) / 1e12             # ALGORITHMIC (dense-equivalent) TFLOP/s
+    bd = leg.kernel_breakdown(iters)
+    conv_fl, rpn_fl, det_fl = algorithmic_flops(wl)
     traffic = None                    # HBM bytes per launch of the dominant kernel, from the committed PMC passes
-    try:
-        with open(os.path.join(ROOT, "profiles", "r1_traffic.json")) as f:
-            traffic = json.load(f)[traffic_key]["hbm_bytes_per_launch"]
-    except Exception:
-        pass
+    for name in ("r2_traffic.json", "r1_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                traffic = json.load(f)[args.precision]["hbm_bytes_per_launch"]
+            break
+        except Exception:
+            pass
 
     out = {
-        "metric": "images/sec (T_rpn=%d,T_det=%d, %s b=%d) spiking RPN+RoI heads forward" % (
-            T_RPN, T_DET, "720x1280" if args.workload == "bdd" else "1024x2048", BATCH),
+        "metric": "images/sec (T_rpn=%d,T_det=%d, %dx%d b=%d) spiking RPN+RoI heads forward" % (
+            wl["T_rpn"], wl["T_det"], wl["image"][0], wl["image"][1], wl["batch"]),
         "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": {"f32": "f32", "bf16x3": "f32 (weights as exact bf16x3 split, fp32 accumulate)",
@@ -221,27 +425,62 @@ def main():
         "data": "synthetic",
         "config": {"precision": args.precision,
                    "workload": "%s: RPNHeadSNN(T=%d) on 5-level pyramid %dx256x{%dx%d..%dx%d} + FastRCNNPredictorSNNFull(T=%d) on "
-                               "%d RoIs x 12544, K=%d; random-init weights" % (
-                                   wl["name"], T_RPN, BATCH, LEVELS[0][0], LEVELS[0][1], LEVELS[-1][0], LEVELS[-1][1], T_DET,
-                                   BATCH * ROIS_PER_IMG, K_CLS),
-                   "global_batch": BATCH * world, "parallelism": "dp%d" % world,
-                   "exchange": "all-gather of per-image detections [100x6] (RCCL)" if world > 1 else "none"},
-        # achieved = ALGORITHMIC FLOPs of the launch / its duration.  For bf16x3 the peak is what the bf16 matrix pipe
-        # can deliver of this arithmetic: the dense bf16 MFMA peak / 3 MFMAs per exact fp32 product (the executed
-        # rate against the full 2.5 PF is the same fraction; both are spelled out).
-        "roofline": {"bound": "mfma", "kernel": kernel, "achieved": round(achieved, 2),
-                     "peak": round(peak / exec_factor, 1), "unit": "TFLOP/s", "frac": round(achieved * exec_factor / peak, 4),
-                     "traffic": traffic, "launch_ms": round(kernel_ms, 4),
-                     "algorithmic_gflop_per_launch": round(conv_fl / 1e9, 1), "executed_over_algorithmic": exec_factor,
-                     "executed_tflops": round(achieved * exec_factor, 2), "mfma_peak_tflops": peak,
-                     "algorithmic_frac_of_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4)},
-        "breakdown_ms": {"rpn_head": round(rpn_ms, 3), "rpn_encode": round(enc_ms, 3), "rpn_conv3x3_lif": round(conv_ms, 3),
-                         "det_head": round(det_ms, 3)},
-        "heads_tflops": round((rpn_fl + det_fl) / ((rpn_ms + det_ms) * 1e-3) / 1e12, 2),
-        "alt_precision": alt,
+                               "%d RoIs x 12544, K=%d; random-init weights; inputs: %s" % (
+                                   wl["name"], wl["T_rpn"], wl["batch"], wl["levels"][0][0], wl["levels"][0][1], wl["levels"][-1][0],
+                                   wl["levels"][-1][1], wl["T_det"], wl["batch"] * ROIS_PER_IMG, wl["K"], leg.input_note),
+                   "global_batch": wl["batch"] * world, "parallelism": "dp%d" % world,
+                   "exchange": ("all-gather of per-image detections [100x6] (%s, %d ranks)" % (
+                       "RCCL" if exchange["backend"] == "nccl" else exchange["backend"], exchange["ranks"])) if world > 1 else "none"},
+        "roofline": leg.roofline(bd["rpn_conv3x3_lif"], traffic),
+        "breakdown_ms": {k: round(v, 3) for k, v in bd.items()},
+        "heads_tflops": round((rpn_fl + det_fl) / ((bd["rpn_head"] + bd["det_head"]) * 1e-3) / 1e12, 2),
+        "exchange": exchange,
     }
+    if "SNN_DP_DEVICE" in os.environ and world > 1:
+        out["config"]["oversubscribed"] = "%d ranks on device %s (test of the N-rank path, not a scaling measurement)" % (world, os.environ["SNN_DP_DEVICE"])
+
+    if world == 1 and rank == 0 and not args.no_extra:
+        extra = {}
+        if not wl["spike_rates"]:
+            extra["input_spike_rates"] = leg.spike_stats()
+        # the same step held for >= sustain_s seconds: the clock the chip sustains, not a burst
+        n, t_acc = 0, 0.0
+        chunk = max(25, args.steps)
+        while t_acc < args.sustain_s:
+            t_acc += timed_steps(leg, chunk, 0, fence)
+            n += chunk
+        extra["sustained"] = {"value": round(wl["batch"] * n / t_acc, 3), "unit": "images/s", "steps": n,
+                              "seconds": round(t_acc, 3), "ms_per_step": round(t_acc / n * 1e3, 4)}
+        if not args.no_alt:
+            # the same K steps with the other matrix path of the two big contractions: "mxfp6" = fp4 x fp6 block-scaled MFMA
+            # on 6 digit planes per weight (passes the same parity tests; weights are rounded at 2^-28 of their block maximum,
+            # so it is NOT the headline)
+            alt_prec = "bf16x3" if args.precision == "mxfp6" else "mxfp6"
+            leg.set_precision(alt_prec)
+            dt_alt = timed_steps(leg, args.steps, max(1, args.warmup), fence)
+            extra["alt_precision"] = {"precision": alt_prec, "value": round(wl["batch"] * args.steps / dt_alt, 3), "unit": "images/s",
+                                      "ms_per_step": round(dt_alt / args.steps * 1e3, 4)}
+            leg.set_precision(args.precision)
+        for name in ("bdd", "stress"):
+            if name == args.workload:
+                continue
+            w2 = WORKLOADS[name]
+            l2 = make_leg(w2, args.precision)
+            dt2 = timed_steps(l2, args.steps, max(1, args.warmup), fence)
+            bd2 = l2.kernel_breakdown(iters)
+            c2, r2, d2 = algorithmic_flops(w2)
+            extra[name] = {"workload": "%s (T_rpn=%d, T_det=%d, b=%d, K=%d%s)" % (w2["name"], w2["T_rpn"], w2["T_det"], w2["batch"], w2["K"],
+                                                                           ", spike-rate outputs on" if w2["spike_rates"] else ""),
+                           "value": round(w2["batch"] * args.steps / dt2, 3), "unit": "images/s",
+                           "ms_per_step": round(dt2 / args.steps * 1e3, 4), "roofline": l2.roofline(bd2["rpn_conv3x3_lif"]),
+                           "breakdown_ms": {k: round(v, 3) for k, v in bd2.items()},
+                           "kernels_over_step": round((bd2["rpn_head"] + bd2["det_head"]) / (dt2 / args.steps * 1e3), 4)}
+            del l2
+        if args.workload == "cityscapes":
+            extra["e2e"] = e2e_leg(model_for("cityscapes", 9), dev)
+        out["extra"] = extra
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline()
+        out["cpu_baseline"] = cpu_baseline(args.cpu_repeats)
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:

@@ -79,3 +79,108 @@ def load_expected(name):
 def unpack_spikes(packed: np.ndarray, shape) -> np.ndarray:
     n = int(np.prod(shape))
     return np.unpackbits(packed)[:n].reshape(tuple(int(s) for s in shape)).astype(np.float32)
+
+
+# ---------------------------------------------------------------------------------------------
+# post-processing fixtures: tests/golden/post_*.npz hold what the reference's own
+# RegionProposalNetwork.forward (rpn.py:563-703) / RoIHeadsSNN.postprocess_detections (roi_heads.py:1075-1176)
+# return for these inputs (oracle/make_golden.py)
+# ---------------------------------------------------------------------------------------------
+ANCHOR_SIZES = ((32,), (64,), (128,), (256,), (512,))            # faster_rcnn.py:31-34
+ASPECT_RATIOS = ((0.5, 1.0, 2.0),) * 5
+
+# canvas = padded batch tensor (H, W); image_sizes = per-image size after the transform; grids = FPN maps; A = 3.
+# model.py:50-59: pre/post_nms_top_n 1000, nms 0.7, score_thresh 0.0
+RPN_POST_SPECS = {
+    # 2 images of different size on a 192x320 canvas; level 0 has 48*80*3 = 11520 anchors (> 1000: the per-level top-k bites)
+    "post_rpn_base":   dict(canvas=(192, 320), image_sizes=[(192, 320), (170, 301)], grids=[(48, 80), (24, 40), (12, 20), (6, 10), (3, 5)],
+                            seed=301, logit_std=2.0, delta_std=0.5, pre=1000, post=1000, nms=0.7, score_thresh=0.0),
+    # proposals mostly unmoved anchors (small deltas, like a random-init head): heavy NMS suppression between neighbours
+    "post_rpn_tight":  dict(canvas=(192, 320), image_sizes=[(192, 320)], grids=[(48, 80), (24, 40), (12, 20), (6, 10), (3, 5)],
+                            seed=302, logit_std=0.05, delta_std=0.02, pre=1000, post=1000, nms=0.7, score_thresh=0.0),
+    # truncation after NMS, a score threshold that removes candidates (>= keeps logits that are exactly 0 at thresh 0.5),
+    # and boxes collapsed below min_size by very negative size deltas
+    "post_rpn_edges":  dict(canvas=(96, 160), image_sizes=[(96, 160), (90, 150), (64, 100)], grids=[(24, 40), (12, 20), (6, 10), (3, 5), (2, 3)],
+                            seed=303, logit_std=1.5, delta_std=0.7, pre=300, post=50, nms=0.7, score_thresh=0.5,
+                            zero_logit_every=7, collapse_every=11),
+    # an image that ends up with no proposal at all (threshold above every sigmoid)
+    "post_rpn_empty":  dict(canvas=(64, 96), image_sizes=[(64, 96), (64, 96)], grids=[(16, 24), (8, 12), (4, 6), (2, 3), (1, 2)],
+                            seed=304, logit_std=1.0, delta_std=0.3, pre=1000, post=1000, nms=0.7, score_thresh=0.9999,
+                            boost_image=1),
+    # quantised logits: many exactly tied scores (order inside a tie is unspecified in the reference; tests compare tie-aware)
+    "post_rpn_ties":   dict(canvas=(96, 160), image_sizes=[(96, 160)], grids=[(24, 40), (12, 20), (6, 10), (3, 5), (2, 3)],
+                            seed=305, logit_std=1.0, delta_std=0.4, pre=200, post=100, nms=0.7, score_thresh=0.0, quant=0.25),
+}
+
+# model.py:98-106: score_thresh 0.4, nms 0.5, 100 detections per image, box weights (10,10,5,5)
+DET_POST_SPECS = {
+    "post_det_base":    dict(K=9, rois=[300, 200], image_shapes=[(768, 1536), (700, 1400)], seed=401, logit_std=2.5, delta_std=1.0),
+    # every RoI background: only the background list survives
+    "post_det_bgonly":  dict(K=9, rois=[120], image_shapes=[(768, 1536)], seed=402, logit_std=0.3, delta_std=0.5, bg_bias=6.0),
+    # > 100 foreground candidates per image after NMS (truncation to detections_per_img), K = 11 (BDD)
+    "post_det_many":    dict(K=11, rois=[400, 350], image_shapes=[(768, 1376), (768, 1376)], seed=403, logit_std=4.0, delta_std=0.3,
+                             fg_bias=2.0, spread=True),
+    # an image without RoIs, one with a single RoI, degenerate (collapsed) boxes
+    "post_det_ragged":  dict(K=9, rois=[0, 1, 57], image_shapes=[(768, 1536), (768, 1536), (400, 900)], seed=404, logit_std=2.5,
+                             delta_std=1.0, collapse_every=5),
+    # clustered RoIs (proposals piled on a few objects, as after a trained RPN): dense NMS interaction per class
+    "post_det_cluster": dict(K=9, rois=[250, 250], image_shapes=[(768, 1536), (768, 1536)], seed=405, logit_std=3.0, delta_std=0.2,
+                             clusters=6),
+}
+
+
+def rpn_post_inputs(spec):
+    """-> (objectness [N,A,H,W] per level, deltas [N,4A,H,W] per level) as the head returns them (NCHW)"""
+    N, A, s = len(spec["image_sizes"]), 3, spec["seed"]
+    obj, dl = [], []
+    for l, (h, w) in enumerate(spec["grids"]):
+        o = PR.normalish((N, A, h, w), s * 100 + 2 * l, std=spec["logit_std"])
+        d = PR.normalish((N, 4 * A, h, w), s * 100 + 2 * l + 1, std=spec["delta_std"])
+        if spec.get("quant"):
+            o = (np.round(o / spec["quant"]) * spec["quant"]).astype(np.float32)
+        flat = o.reshape(-1)
+        if spec.get("zero_logit_every"):
+            flat[:: spec["zero_logit_every"]] = 0.0                      # sigmoid = 0.5 exactly: kept by `>= 0.5`
+        if spec.get("collapse_every"):
+            d4 = d.reshape(N, A, 4, h, w)
+            m = (np.arange(N * A * h * w) % spec["collapse_every"] == 0).reshape(N, A, h, w)
+            d4[:, :, 2][m] = -40.0                                       # width exp(-40) * w < min_size
+            d = d4.reshape(N, 4 * A, h, w)
+        if spec.get("boost_image") is not None:
+            o[spec["boost_image"]] += 12.0                               # sigmoid > 0.9999 for this image only
+        obj.append(_t(o))
+        dl.append(_t(d))
+    return obj, dl
+
+
+def det_post_inputs(spec):
+    """-> (class_logits [R,K], box_regression [R,4K], proposals: list of [R_i,4])"""
+    K, s = spec["K"], spec["seed"]
+    R = sum(spec["rois"])
+    logits = PR.normalish((R, K), s * 100 + 1, std=spec["logit_std"])
+    if spec.get("bg_bias"):
+        logits[:, 0] += spec["bg_bias"]
+    if spec.get("fg_bias"):
+        logits[:, 1:] += spec["fg_bias"] * (PR.uniform((R, K - 1), s * 100 + 5, 0.0, 1.0) > 0.8)
+    reg = PR.normalish((R, 4 * K), s * 100 + 2, std=spec["delta_std"])
+    props, base = [], 0
+    for i, (r, (h, w)) in enumerate(zip(spec["rois"], spec["image_shapes"])):
+        u = PR.uniform((r, 4), s * 100 + 10 + i, 0.0, 1.0)
+        if spec.get("clusters"):
+            c = PR.uniform((spec["clusters"], 4), s * 100 + 50 + i, 0.1, 0.9)
+            which = (np.arange(r) % spec["clusters"])
+            cx = c[which, 0] * w + (u[:, 0] - 0.5) * 12; cy = c[which, 1] * h + (u[:, 1] - 0.5) * 12
+            bw = (40 + 200 * c[which, 2]) * (0.9 + 0.2 * u[:, 2]); bh = (40 + 150 * c[which, 3]) * (0.9 + 0.2 * u[:, 3])
+        else:
+            cx, cy = u[:, 0] * w, u[:, 1] * h
+            bw = np.exp(np.log(16.0) + u[:, 2] * np.log(32.0)); bh = np.exp(np.log(16.0) + u[:, 3] * np.log(24.0))
+        b = np.stack([cx - bw / 2, cy - bh / 2, cx + bw / 2, cy + bh / 2], 1).astype(np.float32)
+        b[:, 0::2] = np.clip(b[:, 0::2], 0, w); b[:, 1::2] = np.clip(b[:, 1::2], 0, h)
+        props.append(_t(b))
+        if spec.get("collapse_every") and r:
+            rows = np.arange(base, base + r)[:: spec["collapse_every"]]
+            reg.reshape(R, K, 4)[rows, :, 2] = -300.0                    # dw / 5 = -60: width below min_size for every class
+        base += r
+    if spec.get("spread"):                                              # keep boxes apart so that > 100 survive NMS
+        reg *= np.float32(0.2)
+    return _t(logits.astype(np.float32)), _t(reg.astype(np.float32)), props

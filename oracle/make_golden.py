@@ -36,6 +36,8 @@ REF = "/root/reference"
 from oracle import norse_restated as NR          # noqa: E402
 from oracle import snn_oracle as OR              # noqa: E402
 from oracle import fixtures as FX                # noqa: E402
+from oracle import post_oracle as PO             # noqa: E402
+from oracle import torchvision_restated as TV    # noqa: E402
 
 
 def _mod(name, **attrs):
@@ -66,18 +68,21 @@ def install_shims():
     _mod("norse.torch.functional.lif", lif_current_encoder=NR.lif_current_encoder,
          LIFParameters=NR.LIFParameters)
     # ---- torchvision placeholders (names touched at import time only) ----
-    _mod("torchvision")
+    # (the box ops, BoxCoder, AnchorGenerator and ImageList resolve to oracle/torchvision_restated.py so that the reference's
+    # own RegionProposalNetwork.forward / RoIHeadsSNN.postprocess_detections bodies can run: rows f2 / f3)
+    _mod("torchvision", _is_tracing=TV._is_tracing)
     _mod("torchvision.ops", MultiScaleRoIAlign=_Inert, roi_align=lambda *a, **k: None)
-    _mod("torchvision.ops.boxes")
+    _mod("torchvision.ops.boxes", clip_boxes_to_image=TV.clip_boxes_to_image, remove_small_boxes=TV.remove_small_boxes,
+         batched_nms=TV.batched_nms, nms=TV.nms, box_iou=TV.box_iou)
     _mod("torchvision.ops.misc", FrozenBatchNorm2d=_Inert, Conv2dNormActivation=_Inert)
     _mod("torchvision.models")
     _mod("torchvision.models.mobilenetv3", mobilenet_v3_large=lambda *a, **k: None)
     _mod("torchvision.models.resnet", resnet50=lambda *a, **k: None)
     _mod("torchvision.models.detection")
-    _mod("torchvision.models.detection._utils", BoxCoder=_Inert, Matcher=_Inert,
-         BalancedPositiveNegativeSampler=_Inert, overwrite_eps=lambda *a, **k: None)
-    _mod("torchvision.models.detection.anchor_utils", AnchorGenerator=_Inert)
-    _mod("torchvision.models.detection.image_list", ImageList=_Inert)
+    _mod("torchvision.models.detection._utils", BoxCoder=TV.BoxCoder, Matcher=TV.Matcher,
+         BalancedPositiveNegativeSampler=TV.BalancedPositiveNegativeSampler, overwrite_eps=lambda *a, **k: None)
+    _mod("torchvision.models.detection.anchor_utils", AnchorGenerator=TV.AnchorGenerator)
+    _mod("torchvision.models.detection.image_list", ImageList=TV.ImageList)
     _mod("torchvision.models.detection.backbone_utils", _resnet_fpn_extractor=None,
          _validate_trainable_layers=None, _mobilenet_extractor=None, resnet_fpn_backbone=None)
     _mod("torchvision.models.detection.transform", GeneralizedRCNNTransform=_Inert)
@@ -94,6 +99,77 @@ def load_reference():
         import rpn as ref_rpn                      # noqa
         import faster_rcnn as ref_frcnn            # noqa
     return ref_rpn, ref_frcnn
+
+
+def load_reference_roi_heads():
+    with contextlib.redirect_stdout(io.StringIO()):
+        import roi_heads as ref_roi_heads          # noqa
+    return ref_roi_heads
+
+
+class _StoredHead(torch.nn.Module):
+    """stands in for RPNHeadSNN inside the reference's RegionProposalNetwork: returns stored head outputs (rpn.py:613)"""
+    def __init__(self, objectness, deltas):
+        super().__init__()
+        self.objectness, self.deltas = objectness, deltas
+
+    def forward(self, features):
+        return self.objectness, self.deltas
+
+
+def _save_lists(d, key, tensors):
+    d[key + "_n"] = np.array([int(t.shape[0]) for t in tensors], dtype=np.int64)
+    d[key] = np_(torch.cat([t.reshape(t.shape[0], -1) for t in tensors], 0)) if tensors else np.zeros((0,))
+
+
+def gen_rpn_post(ref_rpn, name, spec, out):
+    """runs the reference's own RegionProposalNetwork.forward (rpn.py:563-703: anchors, concat_box_prediction_layers,
+    BoxCoder.decode, filter_proposals) in eval mode on stored head outputs"""
+    obj, dl = FX.rpn_post_inputs(spec)
+    N = len(spec["image_sizes"])
+    rpn = ref_rpn.RegionProposalNetwork(TV.AnchorGenerator(FX.ANCHOR_SIZES, FX.ASPECT_RATIOS), _StoredHead(obj, dl), 0.7, 0.3, 256, 0.5,
+                                        dict(training=2000, testing=spec["pre"]), dict(training=2000, testing=spec["post"]),
+                                        spec["nms"], score_thresh=spec["score_thresh"]).eval()
+    images = TV.ImageList(torch.zeros((N, 3) + tuple(spec["canvas"])), list(spec["image_sizes"]))
+    feats = {str(l): torch.zeros((N, 1) + tuple(g)) for l, g in enumerate(spec["grids"])}
+    with torch.no_grad():
+        boxes, extras = rpn(images, feats)                    # the reference's own forward
+        scores = rpn.filter_proposals(                        # (forward drops the scores; same body called once more for them)
+            TV.BoxCoder((1.0, 1.0, 1.0, 1.0)).decode(ref_rpn.concat_box_prediction_layers(obj, dl)[1], rpn.anchor_generator(images, list(feats.values()))).view(N, -1, 4),
+            ref_rpn.concat_box_prediction_layers(obj, dl)[0], images.image_sizes, [o.shape[1] * o.shape[2] * o.shape[3] for o in obj])[1]
+    st = {}
+    o_b, o_s, o_pre = PO.rpn_proposals(obj, dl, spec["canvas"], spec["image_sizes"], FX.ANCHOR_SIZES, FX.ASPECT_RATIOS, spec["pre"],
+                                       spec["post"], spec["nms"], spec["score_thresh"], stats=st)
+    for i in range(N):
+        assert torch.equal(boxes[i], o_b[i]) and torch.equal(scores[i], o_s[i]), "oracle != reference filter_proposals (%s)" % name
+        assert torch.equal(extras[i]["proposals"], o_pre[i]["proposals"]) and torch.equal(extras[i]["objectness"], o_pre[i]["objectness"])
+    d = {"min_gap": np.array(st.get("min_gap", 1.0))}
+    _save_lists(d, "boxes", boxes)
+    _save_lists(d, "scores", scores)
+    d["pre_boxes"] = np_(torch.stack([e["proposals"] for e in extras]))
+    d["pre_prob"] = np_(torch.stack([e["objectness"] for e in extras]))
+    np.savez_compressed(os.path.join(out, name + ".npz"), **d)
+    print("wrote %-20s proposals %s of %d candidates, min |IoU - thr| %.2e" % (name, [int(b.shape[0]) for b in boxes],
+          extras[0]["proposals"].shape[0], st.get("min_gap", 1.0)))
+
+
+def gen_det_post(ref_roi, name, spec, out):
+    """runs the reference's own RoIHeadsSNN.postprocess_detections (roi_heads.py:1075-1176)"""
+    logits, reg, props = FX.det_post_inputs(spec)
+    heads = ref_roi.RoIHeadsSNN(None, None, 0.5, 0.5, 512, 0.25, None, 0.4, 0.5, 100).eval()      # model.py:98-106
+    with torch.no_grad():
+        res = heads.postprocess_detections(logits, reg, props, list(spec["image_shapes"]))
+    st = {}
+    ora = PO.det_postprocess(logits, reg, props, list(spec["image_shapes"]), stats=st)
+    for a, b in zip(res, ora):
+        for x, y in zip(a, b):
+            assert x.dtype == y.dtype and torch.equal(x, y), "oracle != reference postprocess_detections (%s)" % name
+    d = {"min_gap": np.array(st.get("min_gap", 1.0))}
+    for key, lst in zip(("boxes", "scores", "labels", "all_scores", "all_boxes"), res):
+        _save_lists(d, key, list(lst))
+    np.savez_compressed(os.path.join(out, name + ".npz"), **d)
+    print("wrote %-20s detections %s (fg %s), min |IoU - thr| %.2e" % (name, [int(b.shape[0]) for b in res[0]],
+          [int((l > 0).sum()) for l in res[2]], st.get("min_gap", 1.0)))
 
 
 def _exec_literal_forward(path, first, last):
@@ -191,6 +267,11 @@ def main():
         gen_rpn(ref_rpn, name, spec, args.out)
     for name, spec in FX.DET_SPECS.items():
         gen_det(ref_frcnn, name, spec, args.out)
+    ref_roi = load_reference_roi_heads()
+    for name, spec in FX.RPN_POST_SPECS.items():
+        gen_rpn_post(ref_rpn, name, spec, args.out)
+    for name, spec in FX.DET_POST_SPECS.items():
+        gen_det_post(ref_roi, name, spec, args.out)
 
 
 if __name__ == "__main__":

@@ -2,19 +2,34 @@
 reference's ``DistributedSampler(shuffle=False)`` does, train.py:598-601), weights replicated, and the
 path's ONE exchange step: an all-gather of the per-image detections (the reference's counterpart is
 the pickled ``all_gather_object`` in coco_eval.py:158-177, disabled under NCCL at train.py:874-880).
+Process-group set-up follows the reference's env-driven ``init_distributed_mode`` (utils.py:268-312:
+RANK / WORLD_SIZE / LOCAL_RANK, backend "nccl" = RCCL on ROCm) with an explicit collective time-out.
 
 Detections are variable-length; they are padded to ``max_det`` rows and exchanged as two fixed-size
 tensors (payload + counts) in ONE ``all_gather_into_tensor`` (the counts ride as an extra payload row) — KB-scale,
-latency-bound, so a single collective per batch over RCCL/xGMI (backend "nccl" on ROCm) or gloo on CPU."""
+latency-bound, so a single collective per batch over RCCL/xGMI (backend "nccl" on ROCm) or gloo on CPU.
+Ranks may hold different numbers of images (``shard_range`` hands the first ``n % world`` ranks one more):
+``all_gather_detections`` pads every rank's block to the largest one with count -1 rows and drops them after the gather."""
+import datetime
 import os
-from typing import Dict, List, Tuple
+import subprocess
+import sys
+import time
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
 
+DEFAULT_TIMEOUT_S = 120.0           # collective time-out (SNN_DIST_TIMEOUT_S overrides)
 
-def init_distributed(backend: str = None) -> Tuple[int, int, int]:
-    """(rank, local_rank, world_size) from the torchrun environment; no-op for a single process."""
+
+def dist_timeout_s() -> float:
+    return float(os.environ.get("SNN_DIST_TIMEOUT_S", DEFAULT_TIMEOUT_S))
+
+
+def init_distributed(backend: str = None, timeout_s: float = None) -> Tuple[int, int, int]:
+    """(rank, local_rank, world_size) from the torchrun environment; no-op for a single process.
+    ``timeout_s``: every collective (and the rendezvous) fails after this many seconds instead of hanging."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -28,8 +43,14 @@ def init_distributed(backend: str = None) -> Tuple[int, int, int]:
             backend = os.environ.get("SNN_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")    # a timed-out collective aborts the rank
+        timeout = datetime.timedelta(seconds=dist_timeout_s() if timeout_s is None else timeout_s)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=timeout)
     return rank, local, world
+
+
+def backend_name() -> str:
+    return dist.get_backend() if (dist.is_available() and dist.is_initialized()) else "none"
 
 
 def shard_range(n_items: int, rank: int, world: int) -> range:
@@ -55,18 +76,37 @@ def pack_detections(dets: List[Dict[str, torch.Tensor]], max_det: int, device) -
 
 
 def unpack_detections(payload: torch.Tensor, counts: torch.Tensor) -> List[Dict[str, torch.Tensor]]:
+    """rows with a negative count are padding of a short rank and are dropped"""
     out = []
+    cnt = counts.tolist()
     for i in range(payload.shape[0]):
-        k = int(counts[i])
+        k = int(cnt[i])
+        if k < 0:
+            continue
         out.append({"boxes": payload[i, :k, 0:4], "scores": payload[i, :k, 4],
                     "labels": payload[i, :k, 5].to(torch.int64)})
     return out
 
 
-def all_gather_detection_tensors(payload: torch.Tensor, counts: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-    """the exchange step proper (device tensors in, device tensors out; equal per-rank image counts): ONE collective per
-    batch - the per-image counts travel as an extra payload row (exact in fp32: counts < 2^24)"""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+def _collective_all_gather(out: torch.Tensor, inp: torch.Tensor) -> None:
+    """all_gather_into_tensor; gloo has no device collectives for this op, so device tensors are staged through the
+    host there (test configuration only: N ranks on one GPU)"""
+    if inp.is_cuda and dist.get_backend() == "gloo":
+        h_out = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(h_out, inp.cpu())
+        out.copy_(h_out)
+    else:
+        dist.all_gather_into_tensor(out, inp)
+
+
+def all_gather_detection_tensors(payload: torch.Tensor, counts: torch.Tensor,
+                                 force: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+    """the exchange step proper (device tensors in, device tensors out): ONE collective per batch - the per-image
+    counts travel as an extra payload row (exact in fp32: |counts| < 2^24).  Every rank must pass the same number of
+    images n (all_gather_into_tensor needs equal shapes; ``all_gather_detections`` pads short ranks).
+    ``force``: run the collective even in a one-rank group (exercises RCCL on a single GPU)."""
+    active = dist.is_available() and dist.is_initialized()
+    if not active or (dist.get_world_size() == 1 and not force):
         return payload, counts
     world = dist.get_world_size()
     n, max_det, width = payload.shape
@@ -74,13 +114,79 @@ def all_gather_detection_tensors(payload: torch.Tensor, counts: torch.Tensor) ->
     buf[:, :max_det] = payload
     buf[:, max_det] = counts.to(payload.dtype)[:, None]
     gathered = torch.empty((world * n, max_det + 1, width), dtype=payload.dtype, device=payload.device)
-    dist.all_gather_into_tensor(gathered, buf)
+    _collective_all_gather(gathered, buf)
     return gathered[:, :max_det], gathered[:, max_det, 0].to(counts.dtype)
 
 
-def all_gather_detections(dets: List[Dict[str, torch.Tensor]], max_det: int = 1100) -> List[Dict[str, torch.Tensor]]:
-    """every rank returns the detections of ALL images, in global image order (rank-major)."""
-    device = dets[0]["boxes"].device if dets else torch.device("cpu")
+def all_gather_detections(dets: List[Dict[str, torch.Tensor]], max_det: int = 1100,
+                          device: Optional[torch.device] = None) -> List[Dict[str, torch.Tensor]]:
+    """every rank returns the detections of ALL images, in global image order (rank-major).  Ranks may pass
+    different numbers of images (also zero): the block size is agreed with one MAX all-reduce first."""
+    if device is None:
+        device = dets[0]["boxes"].device if dets else torch.device("cpu")
     payload, counts = pack_detections(dets, max_det, device)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        n_max = torch.tensor([len(dets)], dtype=torch.int64, device=device if dist.get_backend() != "gloo" else "cpu")
+        dist.all_reduce(n_max, op=dist.ReduceOp.MAX)
+        n_max = int(n_max.item())
+        if n_max > len(dets):                              # short rank: pad with rows marked count = -1
+            pad = n_max - len(dets)
+            payload = torch.cat([payload, payload.new_zeros((pad, max_det, 6))], 0)
+            counts = torch.cat([counts, counts.new_full((pad,), -1)], 0)
     g_payload, g_counts = all_gather_detection_tensors(payload, counts)
     return unpack_detections(g_payload, g_counts)
+
+
+# ---------------------------------------------------------------------------------------------
+# rank launcher: `python bench.py --gpus N` without torchrun (the parent never touches the GPU)
+# ---------------------------------------------------------------------------------------------
+def _free_port() -> int:
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(script: str, argv: Sequence[str], world: int, timeout_s: float = 1500.0, extra_env: Dict[str, str] = None) -> int:
+    """Start ``world`` child processes of ``script`` (one per GPU: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
+    environment, utils.py:268-275's contract), pass rank 0's stdout through, and return 0 only if every rank exits 0.
+    A rank that dies or the time-out takes the others down (terminate, then kill).  The caller must not have
+    initialised the GPU: children are started with subprocess (fork + exec of a GPU-less parent)."""
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        if extra_env:
+            env.update(extra_env)
+        out = None if r == 0 else subprocess.DEVNULL         # rank 0 prints the JSON line; errors of all ranks reach stderr
+        procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env, stdout=out))
+    deadline = time.time() + timeout_s
+    rc = 0
+    alive = list(procs)
+    while alive:
+        for p in list(alive):
+            code = p.poll()
+            if code is not None:
+                alive.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    print("rank %d exited with code %d; stopping the other ranks" % (procs.index(p), code), file=sys.stderr)
+        if alive and (rc != 0 or time.time() > deadline):
+            if rc == 0:
+                rc = 124
+                print("ranks still running after %.0f s; stopping them" % timeout_s, file=sys.stderr)
+            for p in alive:
+                p.terminate()
+            t_end = time.time() + 10
+            for p in alive:
+                try:
+                    p.wait(timeout=max(0.1, t_end - time.time()))
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            break
+        time.sleep(0.05)
+    return rc

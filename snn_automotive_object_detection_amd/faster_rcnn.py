@@ -45,6 +45,21 @@ class FastRCNNPredictorSNNFull(nn.Module):
         self._ch = _WeightCache()
         self._flops_cache = {}
 
+    def invalidate_packed_weights(self) -> None:
+        """drop the packed copies of the weights (needed after in-place edits through ``param.data``, which do not bump the
+        version counter the cache is keyed on); rebuilt on the next forward"""
+        for c in list(self._c6.values()) + list(self._c7.values()) + [self._ch]:
+            c.invalidate()
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self.invalidate_packed_weights()
+        return out
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        super()._load_from_state_dict(*args, **kwargs)
+        self.invalidate_packed_weights()
+
     def _eff_precision(self) -> str:
         if self.precision == "mxfp6" and (self.in_channels % 128 or self.representation_size % 128):
             return "bf16x3"

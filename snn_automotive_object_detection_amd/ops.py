@@ -28,6 +28,19 @@ def make_params(p_enc: LIFParameters, p_lif: LIFParameters, dt: float = DT,
                 li_order: str = "jump_first", precision: str = "bf16x3") -> snn_params:
     """Form the fp32 constants exactly as Norse forms them: 0-dim fp32 tensor products
     ``dt * tau_mem_inv`` and ``-dt * tau_syn_inv`` (norse lif.py / leaky_integrator.py)."""
+    # The C ABI carries ONE set of time constants / rest / reset potentials (snn_params) for the encoder, the LIF cells and
+    # the LI heads, which is what the reference builds (p_enc and p_lif differ in v_th only, rpn.py:58,67; the LI cells
+    # use Norse's defaults, rpn.py:71,75).  Anything else would be silently ignored by the kernels, so it is refused.
+    for name in ("tau_mem_inv", "v_leak", "v_reset"):
+        if float(getattr(p_enc, name)) != float(getattr(p_lif, name)):
+            raise ValueError("p_enc.%s = %r differs from p_lif.%s = %r: the kernels take one value for the encoder and the "
+                             "LIF cells" % (name, float(getattr(p_enc, name)), name, float(getattr(p_lif, name))))
+    li_default = LIFParameters()
+    for name in ("tau_mem_inv", "tau_syn_inv", "v_leak"):
+        if float(getattr(p_lif, name)) != float(getattr(li_default, name)):
+            raise ValueError("p_lif.%s = %r differs from the LI cells' default %r: the time-collapsed LI heads use the default "
+                             "LIParameters (rpn.py:71,75 / faster_rcnn.py:456,468)" % (
+                                 name, float(getattr(p_lif, name)), float(getattr(li_default, name))))
     ca = dt * p_lif.tau_mem_inv.to(torch.float32)
     cb = -dt * p_lif.tau_syn_inv.to(torch.float32)
     assert ca.dtype == torch.float32 and cb.dtype == torch.float32
@@ -586,10 +599,16 @@ def det_postprocess(class_logits: torch.Tensor, box_regression: torch.Tensor, pr
     Returns (boxes [N, cap, 4], scores [N, cap], labels [N, cap] int32, counts [N, 2] int32 (fg, bg), all_scores [R, K],
     all_boxes [R, K, 4]); rows of image i: counts[i,0] foreground detections, then counts[i,1] background boxes."""
     lib = _lib.load()
-    _need_gpu(class_logits, "class logits")
     dev = class_logits.device
     N, K = len(rois_per_image), class_logits.shape[1]
     R = class_logits.shape[0]
+    # the kernels index box_regression as [R, 4K] and proposals as [R, 4]: anything else (e.g. the 4-wide output of an
+    # only_one_bbox head) would be an out-of-bounds device read
+    if tuple(box_regression.shape) != (R, 4 * K) or tuple(proposals.shape) != (R, 4) or sum(int(r) for r in rois_per_image) != R:
+        raise _lib.SnnHipError("det_postprocess: class_logits %s needs box_regression [%d, %d] and proposals [%d, 4] "
+                               "(got %s, %s; %d RoIs listed per image)" % (tuple(class_logits.shape), R, 4 * K, R, tuple(box_regression.shape),
+                                                                          tuple(proposals.shape), sum(int(r) for r in rois_per_image)))
+    _need_gpu(class_logits, "class logits")
     lg, dl, pr = _f32c(class_logits), _f32c(box_regression), _f32c(proposals)
     rmax = max(rois_per_image) if N else 0
     cap = int(detections_per_img) + rmax

@@ -44,6 +44,12 @@ class RoIHeadsSNN(nn.Module):
     def postprocess_detections(self, class_logits: Tensor, box_regression: Tensor, proposals: List[Tensor],
                                image_shapes: List[Tuple[int, int]]):
         per_image = [p.shape[0] for p in proposals]
+        if box_regression.shape[-1] != 4 * class_logits.shape[-1]:
+            # --only-one-bbox heads (faster_rcnn.py:460-467) give [R, 4]: the reference's own post-processing then slices
+            # boxes[:, 1:] (roi_heads.py:1115) down to nothing while scores keep K-1 columns - not a usable path
+            raise NotImplementedError("postprocess_detections needs %d box outputs per RoI (4 per class), got %d "
+                                      "(only_one_bbox heads are not supported past the head, SURVEY.md appendix C.6)"
+                                      % (4 * class_logits.shape[-1], box_regression.shape[-1]))
         if (class_logits.is_cuda and self.post == "hip" and per_image and max(per_image) > 0
                 and max(per_image) * (class_logits.shape[-1] - 1) <= 16384):
             return self._postprocess_hip(class_logits, box_regression, proposals, image_shapes, per_image)

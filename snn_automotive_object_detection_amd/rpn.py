@@ -14,8 +14,14 @@ from . import ops
 
 
 class _WeightCache:
-    """packed-weight cache keyed on the parameter's storage and version counter"""
+    """packed-weight cache keyed on the parameter's storage and version counter.  In-place writes through ``param.data``
+    do not bump the version counter: after such an edit call the module's ``invalidate_packed_weights()`` (``_apply`` -
+    .to() / .half() / .cuda() - and ``load_state_dict`` do it themselves)."""
     def __init__(self):
+        self.key = None
+        self.val = None
+
+    def invalidate(self):
         self.key = None
         self.val = None
 
@@ -76,6 +82,20 @@ class RPNHeadSNN(nn.Module):
             t = torch.tensor([v], device=dev).repeat(N, 1)
             self._flops_cache[key] = t
         return t
+
+    def invalidate_packed_weights(self) -> None:
+        """drop the packed (bf16x3 / mxfp6 / f32 fragment-major) copies of the weights; they are rebuilt on the next forward"""
+        for c in list(self._cache_shared.values()) + [self._cache_heads]:
+            c.invalidate()
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self.invalidate_packed_weights()
+        return out
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        super()._load_from_state_dict(*args, **kwargs)
+        self.invalidate_packed_weights()
 
     def _eff_precision(self) -> str:
         if self.precision == "mxfp6" and self.in_channels % 128:

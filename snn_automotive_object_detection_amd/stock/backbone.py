@@ -1,5 +1,5 @@
 """ResNet-50 + FPN(256) + LastLevelMaxPool with FrozenBatchNorm2d (faster_rcnn.py:693-694), random init
-(pretrained weights need the network).  Returns OrderedDict '0','1','2','3','pool' of [N,256,H_l,W_l]."""
+(pretrained weights need the network), parameter names as in torchvision 0.13.1 (`body.*`, `fpn.inner_blocks.N.0.*`).  Returns OrderedDict '0','1','2','3','pool' of [N,256,H_l,W_l]."""
 from collections import OrderedDict
 
 import torch
@@ -43,10 +43,17 @@ class Bottleneck(nn.Module):
         return F.relu(out + idt)
 
 
-class ResNet50FPN(nn.Module):
-    def __init__(self, out_channels: int = 256):
+class _ConvBlock(nn.Sequential):
+    """torchvision 0.13's Conv2dNormActivation(norm_layer=None, activation_layer=None): a Sequential holding one biased
+    Conv2d, so that the parameter keys read `<block>.0.weight` / `<block>.0.bias`"""
+    def __init__(self, cin: int, cout: int, k: int):
+        super().__init__(nn.Conv2d(cin, cout, k, padding=(k - 1) // 2))
+
+
+class ResNetBody(nn.Module):
+    """ResNet-50 trunk as torchvision's IntermediateLayerGetter exposes it (`backbone.body.*`): conv1, bn1, layer1..4"""
+    def __init__(self):
         super().__init__()
-        self.out_channels = out_channels
         self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
         self.bn1 = FrozenBatchNorm2d(64)
         self.inplanes = 64
@@ -54,14 +61,6 @@ class ResNet50FPN(nn.Module):
         self.layer2 = self._make(128, 4, 2)
         self.layer3 = self._make(256, 6, 2)
         self.layer4 = self._make(512, 3, 2)
-        chans = [256, 512, 1024, 2048]
-        self.inner = nn.ModuleList([nn.Conv2d(c, out_channels, 1) for c in chans])
-        self.layer = nn.ModuleList([nn.Conv2d(out_channels, out_channels, 3, padding=1) for _ in chans])
-        for m in self.modules():
-            if isinstance(m, nn.Conv2d):
-                nn.init.kaiming_uniform_(m.weight, a=1)
-                if m.bias is not None:
-                    nn.init.zeros_(m.bias)
 
     def _make(self, planes, blocks, stride):
         down = nn.Sequential(nn.Conv2d(self.inplanes, planes * 4, 1, stride=stride, bias=False),
@@ -74,12 +73,54 @@ class ResNet50FPN(nn.Module):
     def forward(self, x: Tensor):
         x = F.max_pool2d(F.relu(self.bn1(self.conv1(x))), 3, stride=2, padding=1)
         c2 = self.layer1(x); c3 = self.layer2(c2); c4 = self.layer3(c3); c5 = self.layer4(c4)
-        feats = [c2, c3, c4, c5]
-        last = self.inner[3](c5)
-        outs = [self.layer[3](last)]
+        return [c2, c3, c4, c5]
+
+
+class FeaturePyramid(nn.Module):
+    """FPN(256) + LastLevelMaxPool (`backbone.fpn.inner_blocks.N.0.*`, `backbone.fpn.layer_blocks.N.0.*`)"""
+    _version = 2
+
+    def __init__(self, chans, out_channels: int):
+        super().__init__()
+        self.inner_blocks = nn.ModuleList([_ConvBlock(c, out_channels, 1) for c in chans])
+        self.layer_blocks = nn.ModuleList([_ConvBlock(out_channels, out_channels, 3) for _ in chans])
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        # checkpoints written before torchvision 0.13 name the convolutions `inner_blocks.N.weight` (no `.0`)
+        version = local_metadata.get("version", None)
+        if version is None or version < 2:
+            for block in ("inner_blocks", "layer_blocks"):
+                for i in range(len(self.inner_blocks)):
+                    for t in ("weight", "bias"):
+                        old, new = "%s%s.%d.%s" % (prefix, block, i, t), "%s%s.%d.0.%s" % (prefix, block, i, t)
+                        if old in state_dict:
+                            state_dict[new] = state_dict.pop(old)
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
+
+    def forward(self, feats):
+        last = self.inner_blocks[3](feats[3])
+        outs = [self.layer_blocks[3](last)]
         for i in (2, 1, 0):
-            lat = self.inner[i](feats[i])
+            lat = self.inner_blocks[i](feats[i])
             last = lat + F.interpolate(last, size=lat.shape[-2:], mode="nearest")
-            outs.insert(0, self.layer[i](last))
+            outs.insert(0, self.layer_blocks[i](last))
         outs.append(F.max_pool2d(outs[-1], 1, 2, 0))               # LastLevelMaxPool
         return OrderedDict(zip(["0", "1", "2", "3", "pool"], outs))
+
+
+class ResNet50FPN(nn.Module):
+    """`backbone` of the detector with torchvision's BackboneWithFPN key layout (`body.*`, `fpn.*`), so that the reference's
+    checkpoints ({"model": state_dict}, loaded strict=False at train.py:658,674) fill it completely"""
+    def __init__(self, out_channels: int = 256):
+        super().__init__()
+        self.out_channels = out_channels
+        self.body = ResNetBody()
+        self.fpn = FeaturePyramid([256, 512, 1024, 2048], out_channels)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_uniform_(m.weight, a=1)
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+
+    def forward(self, x: Tensor):
+        return self.fpn(self.body(x))

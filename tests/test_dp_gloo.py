@@ -22,7 +22,7 @@ def _make_dets(img_index: int):
             "labels": torch.randint(1, 9, (d,), generator=g)}
 
 
-def _worker(rank, world, port, n_images, q):
+def _worker(rank, world, port, n_images, q, max_det=8):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
     from snn_automotive_object_detection_amd import dp
@@ -55,6 +55,45 @@ def test_all_gather_detections_world2_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res[0] == (0, True, [0, 1]) and res[1] == (1, True, [2, 3])
+
+
+@pytest.mark.parametrize("n_images", [3, 1])
+def test_all_gather_detections_unequal_shards_world2_gloo(n_images):
+    """n_images % world != 0 (and a rank without any image): short ranks pad their block, the padding is dropped after the
+    gather, every rank sees all images in global order (all_gather_into_tensor needs equal shapes)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_images, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res)
+    assert res[0][2] + res[1][2] == list(range(n_images))
+
+
+def test_launch_ranks_runs_world2_and_reports_failures():
+    """dp.launch_ranks (what `python bench.py --gpus N` uses without torchrun): env contract, rank 0's stdout passes
+    through, and a dying rank takes the group down with a non-zero exit code instead of hanging"""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    child = os.path.join(root, "tests", "_dp_child.py")
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from snn_automotive_object_detection_amd import dp\n"
+            "sys.exit(dp.launch_ranks(%r, [sys.argv[1]], 2, timeout_s=90))\n" % (root, child))
+    r = subprocess.run([sys.executable, "-c", code, "ok"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=150)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "LAUNCH_OK world=2" in r.stdout
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-c", code, "die"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=150)
+    assert r.returncode == 7, (r.returncode, r.stderr[-2000:])
+    assert time.time() - t0 < 50                           # rank 0 (sleeping 60 s) was stopped, not waited for
+    assert "rank 1 exited with code 7" in r.stderr
 
 
 def test_shard_range_partitions_everything():

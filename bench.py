@@ -258,7 +258,7 @@ class Leg:
             planes = ops.encode_nchw(f, T, p)
             enc_bits += int(lut[planes.view(torch.uint8).to(torch.int64)].sum())
             enc_n += T * f.numel()
-        _, _, rows, (counts, _, _) = ops.rpn_head_forward(self.feats, C, A, T, p, self.rpn_head._packed_shared(),
+        _, _, rows, (counts, _, _, _) = ops.rpn_head_forward(self.feats, C, A, T, p, self.rpn_head._packed_shared(),
                                                           self.rpn_head._cache_heads.get((self.rpn_head.conv_cls.weight, self.rpn_head.conv_bbox.weight), ops.pack_heads),
                                                           spike_rates=True)
         lif_bits = int(counts[:, :wl["batch"]].sum())

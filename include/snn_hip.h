@@ -156,6 +156,19 @@ int snn_det_head_forward_roialign(const snn_roi_level* levels_host, int n_levels
                                   uint32_t* spk6_count, uint32_t* spk7_count, float* sum_cls, float* sum_bbox,
                                   void* workspace, size_t workspace_bytes, snn_stream_t stream);
 
+/* ---- finished spike-rate tensors of the two spike-rate variants (rpn.py:171-195, faster_rcnn.py:568-618) from the raw side
+ * outputs above: rows (rate, "FLOPs") as float32, what the reference hstacks per layer.
+ *   snn_rpn_rates: rates[n_levels][3][max_N][2]; [l][0] = shared-LIF spikes / (T*C*H*W) with 9*H*W*C*C, [l][1] / [l][2] = mean
+ *   over (A,H,W) / (4A,H,W) of sum_t membrane / T with H*W*C*A*4 / H*W*C*A (the reference's swapped labels, kept).  Two launches.
+ *   snn_det_rates: rates[4][R][2] for lif6, lif7, cls_score, bbox_pred (D*Hd, Hd*Hd, Hd*K, Hd*K*4 or Hd*K when only_one_bbox).
+ * The spike counts themselves come out of the LIF epilogues of the fused kernels (ballot + popcount + integer atomics). */
+size_t snn_rpn_rates_workspace_bytes(int n_levels, int max_N);
+int snn_rpn_rates(const snn_rpn_level* levels_host, int n_levels, int C, int A, int T,
+                  const unsigned long long* spike_counts, const float* sum_logits, const float* sum_bbox,
+                  float* rates, void* workspace, size_t workspace_bytes, snn_stream_t stream);
+int snn_det_rates(int R, int D, int Hd, int K, int K4, int T, int only_one_bbox, const uint32_t* spk6_count,
+                  const uint32_t* spk7_count, const float* sum_cls, const float* sum_bbox, float* rates, snn_stream_t stream);
+
 /* ---- greedy (batched) NMS for the callers either side of the heads (rpn.py:517, roi_heads.py:1160-1161) ----
  * boxes [n][4] already sorted by decreasing score; category (nullable) restricts suppression to equal values
  * (level for the RPN, class for the detector).  keep_out receives up to max_keep indices into the SORTED order,
@@ -166,8 +179,10 @@ int snn_nms_sorted(const float* boxes_sorted, const int* category_sorted, int n,
 
 /* ---- RPN proposal selection (rpn.py:420-499: per-level top-k, box decode, sigmoid, clip, size / score filters,
  * per-level NMS, post_nms_top_n) for the whole batch in six launches, no host synchronisation ----------------
- * Inputs are the head's own position-major outputs.  Candidates are ordered by decreasing score per image (the
- * reference orders them per level); outputs are padded to post_nms_top_n rows, out_counts[N] holds the valid rows. */
+ * Inputs are the head's own position-major outputs.  The K candidates of an image are in the reference's order (level by
+ * level, inside a level by decreasing logit as objectness.topk returns them, equal logits by element index); pre_boxes /
+ * pre_prob report them in that order (rpn.py:493-499).  Equal sigmoid values keep that order in the NMS walk, like the
+ * reference's stable sort.  Outputs are padded to post_nms_top_n rows, out_counts[N] holds the valid rows. */
 typedef struct {
     const float* logits;        /* [N*H*W][A]  objectness logits, rows n*H*W + y*W + x                  */
     const float* deltas;        /* [N*H*W][4A] box regression                                           */

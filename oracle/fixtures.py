@@ -148,6 +148,13 @@ def rpn_post_inputs(spec):
             d = d4.reshape(N, 4 * A, h, w)
         if spec.get("boost_image") is not None:
             o[spec["boost_image"]] += 12.0                               # sigmoid > 0.9999 for this image only
+        t = spec["score_thresh"]
+        if 0.0 < t < 1.0:
+            # keep the candidates off the knife edge of the score threshold: sigmoid implementations differ in the last ulp, so
+            # a logit within ~1e-3 of logit(t) could pass on one side and not on the other (exact hits, sigmoid(0) = 0.5, stay)
+            lt = np.float32(np.log(t / (1.0 - t)))
+            near = (np.abs(o - lt) < 0.25) & (o != lt)
+            o[near] = o[near] + np.where(o[near] >= lt, np.float32(0.25), np.float32(-0.25))
         obj.append(_t(o))
         dl.append(_t(d))
     return obj, dl

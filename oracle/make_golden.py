@@ -119,7 +119,8 @@ class _StoredHead(torch.nn.Module):
 
 def _save_lists(d, key, tensors):
     d[key + "_n"] = np.array([int(t.shape[0]) for t in tensors], dtype=np.int64)
-    d[key] = np_(torch.cat([t.reshape(t.shape[0], -1) for t in tensors], 0)) if tensors else np.zeros((0,))
+    width = max([int(np.prod(t.shape[1:])) for t in tensors] + [1])
+    d[key] = np_(torch.cat([t.reshape(t.shape[0], width) for t in tensors], 0)) if tensors else np.zeros((0, width))
 
 
 def gen_rpn_post(ref_rpn, name, spec, out):

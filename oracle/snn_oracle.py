@@ -39,9 +39,10 @@ def _cells(li_order: str):
 
 def rpn_head_forward(x: Sequence[torch.Tensor], w_shared: torch.Tensor, w_cls: torch.Tensor,
                      w_bbox: torch.Tensor, num_steps: int, li_order: str = "jump_first",
-                     trace: bool = False, spike_rates: bool = False):
+                     trace: bool = False, spike_rates: bool = False, counts_out: Optional[list] = None):
     """rpn.py:84-121.  x: list of [N,C,H,W]; w_shared [C,C,3,3]; w_cls [A,C,1,1]; w_bbox [4A,C,1,1].
-    Returns (logits, bbox_reg[, rates][, traces])."""
+    Returns (logits, bbox_reg[, rates][, traces]).  ``counts_out`` (a list) receives, per level, the exact number of
+    shared-LIF spikes of every image (int64 [N]): what the fp32 rate of rpn.py:172 is the rounded mean of."""
     logits, bbox_reg, traces, all_rates = [], [], [], []
     C = w_shared.shape[0]
     A = w_cls.shape[0]
@@ -51,6 +52,7 @@ def rpn_head_forward(x: Sequence[torch.Tensor], w_shared: torch.Tensor, w_cls: t
         state_shared_lif = state_obj = state_bbox = None              # rpn.py:96
         tr = {"z": [], "cur": [], "spk": [], "v": [], "i": [], "mem_obj": [], "mem_bbox": []}
         l_spk, l_obj, l_bbox = [], [], []
+        n_spk = torch.zeros(feature.shape[0], dtype=torch.int64)
         for step in range(num_steps):                                 # rpn.py:98
             z, v = lif_current_encoder(input_current=feature, voltage=v, p=p_enc, dt=DT)   # :101
             cur = F.conv2d(z, w_shared, None, stride=1, padding=1)    # rpn.py:105
@@ -59,6 +61,8 @@ def rpn_head_forward(x: Sequence[torch.Tensor], w_shared: torch.Tensor, w_cls: t
             mem_obj, state_obj = lif_obj(cur_c, state_obj)            # rpn.py:111
             cur_b = F.conv2d(spk_shared, w_bbox)                      # rpn.py:114
             mem_bbox, state_bbox = lif_bbox(cur_b, state_bbox)        # rpn.py:115
+            if counts_out is not None:
+                n_spk += spk_shared.flatten(start_dim=1).sum(dim=1, dtype=torch.float64).to(torch.int64)
             if trace:
                 tr["z"].append(z); tr["cur"].append(cur); tr["spk"].append(spk_shared)
                 tr["v"].append(state_shared_lif.v); tr["i"].append(state_shared_lif.i)
@@ -67,6 +71,8 @@ def rpn_head_forward(x: Sequence[torch.Tensor], w_shared: torch.Tensor, w_cls: t
                 l_spk.append(spk_shared.flatten(start_dim=1))
                 l_obj.append(mem_obj.flatten(start_dim=1))
                 l_bbox.append(mem_bbox.flatten(start_dim=1))
+        if counts_out is not None:
+            counts_out.append(n_spk)
         logits.append(mem_obj)                                        # rpn.py:118
         bbox_reg.append(mem_bbox)                                     # rpn.py:119
         if trace:
@@ -93,9 +99,11 @@ def rpn_head_forward(x: Sequence[torch.Tensor], w_shared: torch.Tensor, w_cls: t
 
 def det_head_forward(x: torch.Tensor, w6: torch.Tensor, w7: torch.Tensor, w_cls: torch.Tensor,
                      w_bbox: torch.Tensor, num_steps: int, li_order: str = "jump_first",
-                     trace: bool = False, spike_rates: bool = False, only_one_bbox: bool = False):
+                     trace: bool = False, spike_rates: bool = False, only_one_bbox: bool = False,
+                     counts_out: Optional[list] = None):
     """faster_rcnn.py:470-516 (spike_rates=True: 520-618, which returns ONLY the rate list).
-    x [R,C,7,7] (or [R,D]); w6 [Hd,D]; w7 [Hd,Hd]; w_cls [K,Hd]; w_bbox [4K,Hd]."""
+    x [R,C,7,7] (or [R,D]); w6 [Hd,D]; w7 [Hd,Hd]; w_cls [K,Hd]; w_bbox [4K,Hd].
+    ``counts_out`` (a list) receives the exact lif6 / lif7 spike totals per RoI (two int64 [R] tensors)."""
     x = x.flatten(start_dim=1)                                        # faster_rcnn.py:473
     p_enc = LIFParameters(v_th=torch.tensor(V_TH_ENC))
     _, lif6, lif_cls, lif_bbox = _cells(li_order)
@@ -108,6 +116,7 @@ def det_head_forward(x: torch.Tensor, w6: torch.Tensor, w7: torch.Tensor, w_cls:
     if spike_rates:
         c6 = torch.zeros(R, Hd); c7 = torch.zeros(R, Hd)
         cc = torch.zeros(R, K); cb = torch.zeros(R, K4)
+    n6 = torch.zeros(R, dtype=torch.int64); n7 = torch.zeros(R, dtype=torch.int64)
     for step in range(num_steps):                                     # :492
         z, v = lif_current_encoder(input_current=x, voltage=v, p=p_enc, dt=DT)     # :494
         cur6 = F.linear(z, w6)                                        # :498
@@ -122,6 +131,11 @@ def det_head_forward(x: torch.Tensor, w6: torch.Tensor, w7: torch.Tensor, w_cls:
                 tr[k].append(t)
         if spike_rates:                                               # :556-560
             c6 += spk_lif6; c7 += spk_lif7; cc += mem_cls; cb += mem_bbox
+        if counts_out is not None:
+            n6 += spk_lif6.sum(dim=1, dtype=torch.float64).to(torch.int64)
+            n7 += spk_lif7.sum(dim=1, dtype=torch.float64).to(torch.int64)
+    if counts_out is not None:
+        counts_out += [n6, n7]
     if spike_rates:                                                   # :568-618
         D = x.shape[1]
         rates = [(c / num_steps).mean(dim=1, keepdim=True) for c in (c6, c7, cc, cb)]

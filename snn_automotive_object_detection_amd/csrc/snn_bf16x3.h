@@ -78,9 +78,51 @@ struct Gemm3Args {
     int T, pb;
     uint32_t* spk;
     unsigned long long spk_stride;
+    // spike-rate side outputs of the T-in-tile epilogues (nullable; zeroed by the caller): conv: spikes per (level, image) slot
+    // l * max_n + n; linear layers: spikes per row (RoI)
+    unsigned long long* cnt_img;
+    uint32_t* cnt_row;
+    int max_n;
     NeuronP p;
     ConvLevelDev lv[SNN_MAX_LEVELS];
 };
+
+// ---- spike-rate reduction fused into the LIF epilogues (rpn.py:163-172, faster_rcnn.py:556-557: the rates are spike COUNTS / (T * neurons)).
+// The wave ballot of a time step already is the spike word pair, so a position's count is a popcount of words the epilogue
+// holds anyway; the owner wave of a position keeps it in LDS (pos_cnt[pi]) and after the last pass the work-group sends
+// ONE integer atomic per (level, image) slot present in the tile (conv; lanes with equal slots are combined in the wave
+// first) or one per row (linear layers).  Integer atomics: the totals do not depend on the order of arrival.
+#define G3_CNT_BYTES 2048                           // pos_cnt: one uint32 per tile position (pb <= 512)
+template <bool CONV>
+__device__ __forceinline__ void tile_counts_flush(const Gemm3Args& a, const uint32_t* pos_cnt, int m0, int pb, int tid) {
+    const int lane = tid & 63;
+    for (int i = tid; i < ((pb + 63) & ~63); i += (int)blockDim.x) {     // whole waves take a round together
+        const int pos = m0 + i;
+        const bool live = i < pb && pos < a.M;
+        const uint32_t c = live ? pos_cnt[i] : 0u;
+        if (!CONV) {
+            if (live && c) atomicAdd(a.cnt_row + pos, c);
+            continue;
+        }
+        int slot = -1;
+        if (live) {
+            int l = 0;
+            while (l + 1 < a.n_levels && pos >= a.lv[l + 1].pos_base) ++l;
+            slot = l * a.max_n + (pos - a.lv[l].pos_base) / (a.lv[l].H * a.lv[l].W);
+        }
+        unsigned long long rem = __ballot(live);
+        while (rem) {                               // one round per distinct slot among the wave's positions (normally one)
+            const int leader = __ffsll(rem) - 1;
+            const int sl = __shfl(slot, leader);
+            const bool mine = live && slot == sl;
+            uint32_t v = mine ? c : 0u;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+            if (lane == leader && v) atomicAdd(a.cnt_img + sl, (unsigned long long)v);
+            rem &= ~__ballot(mine);
+        }
+    }
+}
 
 __device__ __forceinline__ uint32_t bf16_pair(uint32_t w, int j) {      // bits 2j, 2j+1 -> two bf16 (0 / 1.0)
     const uint32_t t = (w >> (2 * j)) & 3u;
@@ -448,6 +490,8 @@ __global__ __launch_bounds__(512, MODE == G3_CONV_LIF_REG ? 2 : 4) void k_gemm_b
         //                     the even position (low half) and one of the odd position (high half)
         constexpr int CG = G3_TILE_CG(WN), PITCH = CG + 4;
         float* const tile = reinterpret_cast<float*>(smem);
+        uint32_t* const pos_cnt = reinterpret_cast<uint32_t*>(smem + G3_TILE_BYTES(WN));    // behind the tile image
+        const bool counting = args.cnt_img != nullptr || args.cnt_row != nullptr;
         const int pb = args.pb, T = args.T;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // staged-ahead copies of chunks past the end have landed
 #pragma unroll 1
@@ -478,17 +522,20 @@ __global__ __launch_bounds__(512, MODE == G3_CONV_LIF_REG ? 2 : 4) void k_gemm_b
                     float vv = args.p.v_leak, ii = 0.0f;
                     uint32_t my0 = 0, my1 = 0;             // lane t keeps the word pair of time step t
                     const float* src = tile + pi * PITCH + lane;
+                    uint32_t cnt = 0;                      // wave-uniform: spikes of this position in this pass
                     for (int t = 0; t < T; ++t) {
                         const bool z = lif_step(src[(size_t)t * pb * PITCH], vv, ii, args.p);
                         const unsigned long long b = __ballot(z);
                         my0 = lane == t ? (uint32_t)b : my0;
                         my1 = lane == t ? (uint32_t)(b >> 32) : my1;
+                        cnt += __popcll(two ? b : (b & 0xffffffffull));
                     }
                     if (lane < T) {
                         uint32_t* dst = args.spk + (size_t)lane * args.spk_stride + (size_t)pos * (Np >> 5) + word0;
                         dst[0] = my0;
                         if (two) dst[1] = my1;
                     }
+                    if (counting && lane == 0) pos_cnt[pi] = (h == 0 ? 0u : pos_cnt[pi]) + cnt;
                 }
             } else {
                 const int par = lane >> 5, col = lane & 31;
@@ -499,19 +546,31 @@ __global__ __launch_bounds__(512, MODE == G3_CONV_LIF_REG ? 2 : 4) void k_gemm_b
                     float vv = args.p.v_leak, ii = 0.0f;
                     uint32_t my0 = 0, my1 = 0;             // lane t keeps the words of (t, even position), (t, odd position)
                     const float* src = tile + (live ? pi : 2 * pp) * PITCH + col;
+                    uint32_t cnt0 = 0, cnt1 = 0;           // wave-uniform: spikes of the even / odd position in this pass
                     for (int t = 0; t < T; ++t) {
                         const bool z = lif_step(src[(size_t)t * pb * PITCH], vv, ii, args.p);
                         const unsigned long long b = __ballot(z);
                         my0 = lane == t ? (uint32_t)b : my0;
                         my1 = lane == t ? (uint32_t)(b >> 32) : my1;
+                        cnt0 += __popc((uint32_t)b);
+                        cnt1 += __popc((uint32_t)(b >> 32));
                     }
+                    const bool odd_ok = 2 * pp + 1 < pb && m0 + 2 * pp + 1 < M;
                     if (lane < T) {
                         uint32_t* dst = args.spk + (size_t)lane * args.spk_stride + (size_t)(m0 + 2 * pp) * (Np >> 5) + word0;
                         dst[0] = my0;
-                        if (2 * pp + 1 < pb && m0 + 2 * pp + 1 < M) dst[Np >> 5] = my1;
+                        if (odd_ok) dst[Np >> 5] = my1;
+                    }
+                    if (counting && lane == 0) {
+                        pos_cnt[2 * pp] = (h == 0 ? 0u : pos_cnt[2 * pp]) + cnt0;
+                        if (odd_ok) pos_cnt[2 * pp + 1] = (h == 0 ? 0u : pos_cnt[2 * pp + 1]) + cnt1;
                     }
                 }
             }
+        }
+        if (counting) {
+            __syncthreads();
+            tile_counts_flush<CONV>(args, pos_cnt, m0, pb, tid);
         }
         return;
     }

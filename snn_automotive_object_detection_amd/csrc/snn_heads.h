@@ -439,16 +439,78 @@ __global__ __launch_bounds__(256) void k_count_spikes(const uint32_t* __restrict
     if (threadIdx.x == 0) atomicAdd(&counts[blockIdx.x], part[0] + part[1] + part[2] + part[3]);
 }
 
-// spikes per row (RoI) over all T planes: one wave per row  (spike-rate mode of the fused linear layers)
-__global__ __launch_bounds__(256) void k_count_rows(const uint32_t* __restrict__ spk, unsigned long long spk_stride, int T,
-                                                    int R, int words, uint32_t* __restrict__ counts) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (row >= R) return;
-    uint32_t sum = 0;
-    for (int t = 0; t < T; ++t) {
-        const uint32_t* src = spk + (size_t)t * spk_stride + (size_t)row * words;
-        for (int i = lane; i < words; i += 64) sum += __popc(src[i]);
+// ------------------------------------------------------------------------------------------------
+// Finished spike-rate tensors (rpn.py:171-195, faster_rcnn.py:568-618): [.., 2] = (rate, "FLOPs") rows as float32, from the
+// integer spike counts of the LIF epilogues and the time-summed LI membranes of the head kernels.  Rates are formed in double
+// and rounded once; the LI "rates" are means of membrane sums (the reference's quirk), reduced in a
+// fixed order (bitwise repeatable).  The FLOP constants are int64 in the reference and become float32 in its hstack.
+// ------------------------------------------------------------------------------------------------
+#define RATE_CH 32                                   // partial sums per (level, image, head)
+struct RpnRatesArgs {
+    const unsigned long long* counts;                // [n_levels][max_n]
+    const float* sum_l;                              // [P][A]   sum over t of the objectness membranes
+    const float* sum_b;                              // [P][4A]
+    double* part;                                    // [n_levels][max_n][2][RATE_CH]
+    float* rates;                                    // [n_levels][3][max_n][2]
+    int n_levels, max_n, A, T, C;
+    int pos_base[SNN_MAX_LEVELS], N[SNN_MAX_LEVELS], HW[SNN_MAX_LEVELS];
+};
+
+__global__ __launch_bounds__(256) void k_rpn_rate_partials(const RpnRatesArgs a) {
+    const int ch = blockIdx.x, which = blockIdx.y, l = blockIdx.z / a.max_n, n = blockIdx.z % a.max_n;
+    double acc = 0.0;
+    if (n < a.N[l]) {
+        const int width = which == 0 ? a.A : 4 * a.A;
+        const float* src = (which == 0 ? a.sum_l : a.sum_b) + ((size_t)a.pos_base[l] + (size_t)n * a.HW[l]) * width;
+        const size_t len = (size_t)a.HW[l] * width, lo = len * ch / RATE_CH, hi = len * (ch + 1) / RATE_CH;
+        for (size_t i = lo + threadIdx.x; i < hi; i += 256) acc += (double)src[i];
     }
-    for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off);
-    if (lane == 0) counts[row] = sum;
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    __shared__ double wsum[4];
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) a.part[((size_t)blockIdx.z * 2 + which) * RATE_CH + ch] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+
+__global__ void k_rpn_rate_final(const RpnRatesArgs a) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= a.n_levels * 3 * a.max_n) return;
+    const int n = idx % a.max_n, j = (idx / a.max_n) % 3, l = idx / (3 * a.max_n);
+    float rate = 0.0f, flops = 0.0f;
+    if (n < a.N[l]) {
+        const long long HW = a.HW[l];
+        if (j == 0) {                                // shared LIF: spikes / (T * C * H * W); FLOPs 9 * HW * C^2 (rpn.py:177-180)
+            rate = (float)((double)a.counts[l * a.max_n + n] / ((double)a.T * a.C * (double)HW));
+            flops = (float)(9ll * HW * a.C * a.C);
+        } else {                                     // LI heads: mean over (A, H, W) of sum_t membrane / T
+            const double* p = a.part + ((size_t)(l * a.max_n + n) * 2 + (j - 1)) * RATE_CH;
+            double sum = 0.0;
+            for (int c = 0; c < RATE_CH; ++c) sum += p[c];
+            const long long width = j == 1 ? a.A : 4 * a.A;
+            rate = (float)(sum / (double)a.T / (double)(HW * width));
+            // the reference labels these two the other way round (rpn.py:181-188): obj gets A*4, bbox gets A - kept as is
+            flops = (float)(j == 1 ? HW * a.C * a.A * 4 : HW * a.C * a.A);
+        }
+    }
+    float* o = a.rates + ((size_t)(l * 3 + j) * a.max_n + n) * 2;
+    o[0] = rate; o[1] = flops;
+}
+
+// detector: rates[4][R][2] from the per-RoI spike counts of lif6 / lif7 and the time-summed LI membranes
+__global__ void k_det_rates(const uint32_t* __restrict__ c6, const uint32_t* __restrict__ c7, const float* __restrict__ sum_c,
+                            const float* __restrict__ sum_b, int R, long long D, long long Hd, int K, int K4, int T, int one_bbox,
+                            float* __restrict__ rates) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    double sc = 0.0, sb = 0.0;
+    for (int k = 0; k < K; ++k) sc += (double)sum_c[(size_t)r * K + k];
+    for (int k = 0; k < K4; ++k) sb += (double)sum_b[(size_t)r * K4 + k];
+    const float v[4][2] = {{(float)((double)c6[r] / ((double)T * Hd)), (float)(D * Hd)},
+                           {(float)((double)c7[r] / ((double)T * Hd)), (float)(Hd * Hd)},
+                           {(float)(sc / T / K), (float)(Hd * K)},
+                           {(float)(sb / T / K4), (float)(one_bbox ? Hd * K : Hd * K * 4)}};      // faster_rcnn.py:575-593
+    for (int j = 0; j < 4; ++j) {
+        rates[((size_t)j * R + r) * 2] = v[j][0];
+        rates[((size_t)j * R + r) * 2 + 1] = v[j][1];
+    }
 }

@@ -346,7 +346,7 @@ static int launch_gemm3(int mode, int mt, int wn, const Gemm3Args& a, hipStream_
     // LIF_REG owns its CU (256 registers per wave); the others run two work-groups per CU
     const void* kern;
     int lds = G3_LDS(wn == 1 ? G3_NB1 : 3, wn), tiles = cdiv(a.M, G3_BM(wn, mt));
-    const int tile_lds = wn == 2 ? G3_TILE_BYTES(2) : G3_TILE_BYTES(1);       // the LIF_TILE epilogue reuses the ring
+    const int tile_lds = (wn == 2 ? G3_TILE_BYTES(2) : G3_TILE_BYTES(1)) + G3_CNT_BYTES;   // the LIF_TILE epilogue reuses the ring (+ per-position spike counts)
     switch (mode) {
     case G3_FC: kern = g3_kernel<G3_FC>(mt, wn); break;
     case G3_CONV: kern = g3_kernel<G3_CONV>(mt, wn); break;
@@ -354,7 +354,7 @@ static int launch_gemm3(int mode, int mt, int wn, const Gemm3Args& a, hipStream_
     case G3_CONV_LIF_TILE: kern = g3_kernel<G3_CONV_LIF_TILE>(mt, wn); tiles = cdiv(a.M, a.pb); lds = max(lds, tile_lds); break;
     default: kern = g3_kernel<G3_FC_LIF_TILE>(mt, wn); tiles = cdiv(a.M, a.pb); lds = max(lds, tile_lds); break;
     }
-    static_assert(2 * G3_TILE_BYTES(1) <= 160 * 1024 && 2 * G3_LDS(3, 2) <= 160 * 1024, "two work-groups per CU");
+    static_assert(2 * (G3_TILE_BYTES(1) + G3_CNT_BYTES) <= 160 * 1024 && 2 * G3_LDS(3, 2) <= 160 * 1024, "two work-groups per CU");
     hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return fail(-3, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
     if (getenv("SNN_DEBUG_OCC")) {                             // debug: co-resident work-groups per CU
@@ -384,8 +384,9 @@ int snn_spike_gemm_bf16x3(const uint32_t* a_rows, int M, int K, int N, const uin
     return launch_gemm3(G3_FC, mt, wn, a, (hipStream_t)s);
 }
 
-int snn_spike_gemm_lif_bf16x3(const uint32_t* a_planes, int T, int R, int K, int N, const snn_params* p,
-                              const uint16_t* w_packed, uint32_t* spk, size_t spk_stride, snn_stream_t s) {
+// row_counts (nullable, zeroed by the caller): spikes per row over all T steps and N columns, added by the LIF epilogue
+static int spike_gemm_lif_bf16x3_impl(const uint32_t* a_planes, int T, int R, int K, int N, const snn_params* p,
+                                      const uint16_t* w_packed, uint32_t* spk, size_t spk_stride, uint32_t* row_counts, snn_stream_t s) {
     if (!a_planes || !w_packed || !spk || !p || R <= 0 || K <= 0 || N <= 0)
         return fail(-1, "snn_spike_gemm_lif_bf16x3: bad argument");
     if (check_T(T, "snn_spike_gemm_lif_bf16x3")) return -1;
@@ -396,11 +397,16 @@ int snn_spike_gemm_lif_bf16x3(const uint32_t* a_planes, int T, int R, int K, int
     a.plane_elems = (unsigned long long)a.Kc * a.Np * 32;
     const int wn = g3_wn();
     a.n_blocks = cdiv(a.Np, G3_BN(wn));
-    a.T = T; a.spk = spk; a.spk_stride = spk_stride; a.p = make_p(p, p->v_th_lif);
+    a.T = T; a.spk = spk; a.spk_stride = spk_stride; a.p = make_p(p, p->v_th_lif); a.cnt_row = row_counts;
     const int mt = g3_pick_mt([&](int m) { return g3_tile_ok(T, G3_BM(wn, m)) ? (long long)cdiv(R, G3_BM(wn, m) / T) * a.n_blocks : 0ll; });
     if (!mt) return fail(-4, "snn_spike_gemm_lif_bf16x3: T=%d does not fit a row tile (use snn_spike_gemm_bf16x3 + snn_lif_scan)", T);
     a.pb = G3_BM(wn, mt) / T;
     return launch_gemm3(G3_FC_LIF_TILE, mt, wn, a, (hipStream_t)s);
+}
+
+int snn_spike_gemm_lif_bf16x3(const uint32_t* a_planes, int T, int R, int K, int N, const snn_params* p,
+                              const uint16_t* w_packed, uint32_t* spk, size_t spk_stride, snn_stream_t s) {
+    return spike_gemm_lif_bf16x3_impl(a_planes, T, R, K, N, p, w_packed, spk, spk_stride, nullptr, s);
 }
 
 // ---- spike GEMMs on the block-scaled fp4 x fp6 path (snn_mx.h) ------------------------------------
@@ -423,7 +429,7 @@ static int launch_gemm_mx(int mode, MxArgs& a, hipStream_t s) {
     const int mw = mx_mw();
     const void* kern = mw == 8 ? MX_KERNEL_OF(8, mode) : MX_KERNEL_OF(4, mode);
     const bool tile = mode == G3_CONV_LIF_TILE || mode == G3_FC_LIF_TILE;
-    const int lds = tile ? max((int)MX_LDS, (int)G3_TILE_BYTES(1)) : MX_LDS;
+    const int lds = tile ? max((int)MX_LDS, (int)(G3_TILE_BYTES(1) + G3_CNT_BYTES)) : MX_LDS;
     const int tiles = tile ? cdiv(a.g.M, a.g.pb) : cdiv(a.g.M, MX_BM);
     a.g.n_blocks = cdiv(a.g.Np, MX_BN);
     hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -452,8 +458,8 @@ int snn_spike_gemm_mx(const uint32_t* a_rows, int M, int K, int N, const uint32_
     return launch_gemm_mx(G3_FC, a, (hipStream_t)s);
 }
 
-int snn_spike_gemm_lif_mx(const uint32_t* a_planes, int T, int R, int K, int N, const snn_params* p,
-                          const uint32_t* w_packed, uint32_t* spk, size_t spk_stride, snn_stream_t s) {
+static int spike_gemm_lif_mx_impl(const uint32_t* a_planes, int T, int R, int K, int N, const snn_params* p,
+                                  const uint32_t* w_packed, uint32_t* spk, size_t spk_stride, uint32_t* row_counts, snn_stream_t s) {
     if (!a_planes || !w_packed || !spk || !p || R <= 0 || K <= 0 || N <= 0) return fail(-1, "snn_spike_gemm_lif_mx: bad argument");
     if (check_T(T, "snn_spike_gemm_lif_mx")) return -1;
     if (K % 128) return fail(-4, "snn_spike_gemm_lif_mx: K=%d is not a multiple of 128", K);
@@ -463,8 +469,14 @@ int snn_spike_gemm_lif_mx(const uint32_t* a_planes, int T, int R, int K, int N, 
     memset(&a, 0, sizeof(a));
     a.g.A = a_planes; a.g.M = R; a.g.Np = cdiv(N, 32) * 32;
     a.g.T = T; a.g.spk = spk; a.g.spk_stride = spk_stride; a.g.p = make_p(p, p->v_th_lif); a.g.pb = MX_BM / T;
+    a.g.cnt_row = row_counts;
     a.wq = w_packed; a.Kc = K / 128;
     return launch_gemm_mx(G3_FC_LIF_TILE, a, (hipStream_t)s);
+}
+
+int snn_spike_gemm_lif_mx(const uint32_t* a_planes, int T, int R, int K, int N, const snn_params* p,
+                          const uint32_t* w_packed, uint32_t* spk, size_t spk_stride, snn_stream_t s) {
+    return spike_gemm_lif_mx_impl(a_planes, T, R, K, N, p, w_packed, spk, spk_stride, nullptr, s);
 }
 
 static int conv_mx_common(const char* who, const uint32_t* enc, size_t enc_stride, const snn_rpn_level* lv, int n_levels,
@@ -492,9 +504,10 @@ static int conv_mx_common(const char* who, const uint32_t* enc, size_t enc_strid
     return 0;
 }
 
-int snn_conv3x3_lif_mx(const uint32_t* enc, size_t enc_stride, const snn_rpn_level* lv, int n_levels, int C_in, int C_out,
-                       int T, const snn_params* p, const uint32_t* w_packed, uint32_t* spk, size_t spk_stride,
-                       snn_stream_t s) {
+// counts (nullable, zeroed by the caller): shared-LIF spikes per (level, image) slot l * max_n + n, added by the LIF epilogue
+static int conv3x3_lif_mx_impl(const uint32_t* enc, size_t enc_stride, const snn_rpn_level* lv, int n_levels, int C_in, int C_out,
+                               int T, const snn_params* p, const uint32_t* w_packed, uint32_t* spk, size_t spk_stride,
+                               unsigned long long* counts, int max_n, snn_stream_t s) {
     if (!spk || !p) return fail(-1, "snn_conv3x3_lif_mx: bad argument");
     MxArgs a;
     long long P;
@@ -502,7 +515,14 @@ int snn_conv3x3_lif_mx(const uint32_t* enc, size_t enc_stride, const snn_rpn_lev
     if (rc) return rc;
     if (!mx_tile_ok(T)) return fail(-4, "snn_conv3x3_lif_mx: T=%d does not fit a row tile", T);
     a.g.M = (int)P; a.g.T = T; a.g.spk = spk; a.g.spk_stride = spk_stride; a.g.p = make_p(p, p->v_th_lif); a.g.pb = MX_BM / T;
+    a.g.cnt_img = counts; a.g.max_n = max_n;
     return launch_gemm_mx(G3_CONV_LIF_TILE, a, (hipStream_t)s);
+}
+
+int snn_conv3x3_lif_mx(const uint32_t* enc, size_t enc_stride, const snn_rpn_level* lv, int n_levels, int C_in, int C_out,
+                       int T, const snn_params* p, const uint32_t* w_packed, uint32_t* spk, size_t spk_stride,
+                       snn_stream_t s) {
+    return conv3x3_lif_mx_impl(enc, enc_stride, lv, n_levels, C_in, C_out, T, p, w_packed, spk, spk_stride, nullptr, 0, s);
 }
 
 int snn_spike_conv3x3_mx(const uint32_t* enc, size_t enc_stride, const snn_rpn_level* lv, int n_levels, int C_in, int C_out,
@@ -540,9 +560,12 @@ static int conv3_common(const char* who, const uint32_t* enc, size_t enc_stride,
     return 0;
 }
 
-int snn_conv3x3_lif_bf16x3(const uint32_t* enc, size_t enc_stride, const snn_rpn_level* lv, int n_levels, int C_in,
-                           int C_out, int T, const snn_params* p, const uint16_t* w_packed, uint32_t* spk,
-                           size_t spk_stride, snn_stream_t s) {
+static int count_spikes_per_image(const snn_rpn_level* lv, int n_levels, int Cw, int T, const uint32_t* spk, size_t stride,
+                                  unsigned long long* counts, int max_n, hipStream_t s);
+
+static int conv3x3_lif_bf16x3_impl(const uint32_t* enc, size_t enc_stride, const snn_rpn_level* lv, int n_levels, int C_in,
+                                   int C_out, int T, const snn_params* p, const uint16_t* w_packed, uint32_t* spk,
+                                   size_t spk_stride, unsigned long long* counts, int max_n, snn_stream_t s) {
     if (!spk || !p) return fail(-1, "snn_conv3x3_lif_bf16x3: bad argument");
     Gemm3Args a;
     long long P;
@@ -557,12 +580,35 @@ int snn_conv3x3_lif_bf16x3(const uint32_t* enc, size_t enc_stride, const snn_rpn
         a.n_blocks = cdiv(a.Np, G3_BN(wn));
         mt = g3_pick_mt([&](int m) { return g3_tile_ok(T, G3_BM(wn, m)) ? (long long)cdiv(P, G3_BM(wn, m) / T) * a.n_blocks : 0ll; });
     }
-    if (!mt) {
+    if (!mt) {                                     // register-fused fallback: counts from the planes afterwards
         a.n_blocks = cdiv(a.Np, G3_BN(2));
-        return launch_gemm3(G3_CONV_LIF_REG, 4, 2, a, (hipStream_t)s);
+        rc = launch_gemm3(G3_CONV_LIF_REG, 4, 2, a, (hipStream_t)s);
+        if (rc || !counts) return rc;
+        return count_spikes_per_image(lv, n_levels, cdiv(C_out, 32), T, spk, spk_stride, counts, max_n, (hipStream_t)s);
     }
     a.pb = G3_BM(wn, mt) / T;
+    a.cnt_img = counts; a.max_n = max_n;
     return launch_gemm3(G3_CONV_LIF_TILE, mt, wn, a, (hipStream_t)s);
+}
+
+int snn_conv3x3_lif_bf16x3(const uint32_t* enc, size_t enc_stride, const snn_rpn_level* lv, int n_levels, int C_in,
+                           int C_out, int T, const snn_params* p, const uint16_t* w_packed, uint32_t* spk,
+                           size_t spk_stride, snn_stream_t s) {
+    return conv3x3_lif_bf16x3_impl(enc, enc_stride, lv, n_levels, C_in, C_out, T, p, w_packed, spk, spk_stride, nullptr, 0, s);
+}
+
+// spikes per (level, image) from finished planes: one launch per level (fallback of the register-fused conv variant only)
+static int count_spikes_per_image(const snn_rpn_level* lv, int n_levels, int Cw, int T, const uint32_t* spk, size_t stride,
+                                  unsigned long long* counts, int max_n, hipStream_t s) {
+    long long pb = 0;
+    for (int l = 0; l < n_levels; ++l) {
+        const int hw = lv[l].H * lv[l].W;
+        hipLaunchKernelGGL(k_count_spikes, dim3(lv[l].N, max(1, min(256, hw * Cw / 2048))), dim3(256), 0, s, spk + (size_t)pb * Cw,
+                           (unsigned long long)stride, T, hw * Cw, counts + (size_t)l * max_n);
+        SNN_CHECK_LAUNCH("k_count_spikes");
+        pb += (long long)lv[l].N * hw;
+    }
+    return 0;
 }
 
 int snn_spike_conv3x3_bf16x3(const uint32_t* enc, size_t enc_stride, const snn_rpn_level* lv, int n_levels, int C_in,
@@ -930,23 +976,15 @@ int snn_rpn_head_forward_stages(const snn_rpn_level* lv, int n_levels, int C, in
             // conv + LIF fused over T on the bf16 matrix cores (rpn.py:98-106): membrane state in registers, only
             // spike planes written (4.5 ms against 4.2 + 0.5 ms for snn_spike_conv3x3_bf16x3 + snn_lif_scan, which
             // give bit-identical planes)
+            // spike-rate mode: the LIF epilogue popcounts the spike words it ballots and adds them per (level, image)
+            if (spike_counts && hipMemsetAsync(spike_counts, 0, sizeof(unsigned long long) * n_levels * max_n, s) != hipSuccess)
+                return fail(-3, "hipMemsetAsync failed");
             int rc = p->precision == SNN_PRECISION_MXFP6
-                         ? snn_conv3x3_lif_mx(enc, enc_stride, lv, n_levels, C, C, T, p, (const uint32_t*)w_shared_packed, spk, stride, stream)
-                         : snn_conv3x3_lif_bf16x3(enc, stride, lv, n_levels, C, C, T, p, (const uint16_t*)w_shared_packed,
-                                                  spk, stride, stream);
+                         ? conv3x3_lif_mx_impl(enc, enc_stride, lv, n_levels, C, C, T, p, (const uint32_t*)w_shared_packed, spk, stride,
+                                               spike_counts, max_n, stream)
+                         : conv3x3_lif_bf16x3_impl(enc, stride, lv, n_levels, C, C, T, p, (const uint16_t*)w_shared_packed,
+                                                   spk, stride, spike_counts, max_n, stream);
             if (rc) return rc;
-            if (spike_counts) {
-                if (hipMemsetAsync(spike_counts, 0, sizeof(unsigned long long) * n_levels * max_n, s) != hipSuccess)
-                    return fail(-3, "hipMemsetAsync failed");
-                long long pb = 0;
-                for (int l = 0; l < n_levels; ++l) {
-                    const int hw = lv[l].H * lv[l].W;
-                    hipLaunchKernelGGL(k_count_spikes, dim3(lv[l].N, max(1, min(256, hw * Cw / 2048))), dim3(256), 0, s, spk + (size_t)pb * Cw,
-                                       (unsigned long long)stride, T, hw * Cw, spike_counts + (size_t)l * max_n);
-                    SNN_CHECK_LAUNCH("k_count_spikes");
-                    pb += (long long)lv[l].N * hw;
-                }
-            }
         }
     }
     if (!(stage_mask & SNN_STAGE_LI_HEADS)) return 0;
@@ -961,6 +999,47 @@ int snn_rpn_head_forward(const snn_rpn_level* lv, int n_levels, int C, int A, in
     return snn_rpn_head_forward_stages(lv, n_levels, C, A, T, p, w_shared_packed, w_heads_packed, out_logits,
                                        out_bbox, spike_counts, sum_logits, sum_bbox, ws, ws_bytes, SNN_STAGE_ALL,
                                        stream);
+}
+
+// ---- finished spike-rate tensors -------------------------------------------------------------------
+size_t snn_rpn_rates_workspace_bytes(int n_levels, int max_n) {
+    return (n_levels > 0 && max_n > 0) ? (size_t)n_levels * max_n * 2 * RATE_CH * sizeof(double) : 0;
+}
+
+int snn_rpn_rates(const snn_rpn_level* lv, int n_levels, int C, int A, int T, const unsigned long long* spike_counts,
+                  const float* sum_logits, const float* sum_bbox, float* rates, void* ws, size_t ws_bytes, snn_stream_t stream) {
+    if (!lv || !spike_counts || !sum_logits || !sum_bbox || !rates || !ws) return fail(-1, "snn_rpn_rates: null argument");
+    if (n_levels <= 0 || n_levels > SNN_MAX_LEVELS || C <= 0 || A <= 0) return fail(-1, "snn_rpn_rates: bad argument");
+    if (check_T(T, "snn_rpn_rates")) return -1;
+    RpnRatesArgs a;
+    memset(&a, 0, sizeof(a));
+    int max_n = 0;
+    long long pos = 0;
+    for (int l = 0; l < n_levels; ++l) {
+        if (lv[l].N <= 0 || lv[l].H <= 0 || lv[l].W <= 0) return fail(-1, "snn_rpn_rates: bad level %d", l);
+        a.pos_base[l] = (int)pos; a.N[l] = lv[l].N; a.HW[l] = lv[l].H * lv[l].W;
+        pos += (long long)lv[l].N * a.HW[l];
+        max_n = max(max_n, lv[l].N);
+    }
+    if (ws_bytes < snn_rpn_rates_workspace_bytes(n_levels, max_n)) return fail(-2, "snn_rpn_rates: workspace too small");
+    a.counts = spike_counts; a.sum_l = sum_logits; a.sum_b = sum_bbox; a.part = (double*)ws; a.rates = rates;
+    a.n_levels = n_levels; a.max_n = max_n; a.A = A; a.T = T; a.C = C;
+    hipLaunchKernelGGL(k_rpn_rate_partials, dim3(RATE_CH, 2, n_levels * max_n), dim3(256), 0, (hipStream_t)stream, a);
+    SNN_CHECK_LAUNCH("k_rpn_rate_partials");
+    hipLaunchKernelGGL(k_rpn_rate_final, dim3(cdiv(n_levels * 3 * max_n, 64)), dim3(64), 0, (hipStream_t)stream, a);
+    SNN_CHECK_LAUNCH("k_rpn_rate_final");
+    return 0;
+}
+
+int snn_det_rates(int R, int D, int Hd, int K, int K4, int T, int only_one_bbox, const uint32_t* spk6_count,
+                  const uint32_t* spk7_count, const float* sum_cls, const float* sum_bbox, float* rates, snn_stream_t stream) {
+    if (!spk6_count || !spk7_count || !sum_cls || !sum_bbox || !rates) return fail(-1, "snn_det_rates: null argument");
+    if (R <= 0 || D <= 0 || Hd <= 0 || K <= 0 || K4 <= 0) return fail(-1, "snn_det_rates: bad shape");
+    if (check_T(T, "snn_det_rates")) return -1;
+    hipLaunchKernelGGL(k_det_rates, dim3(cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream, spk6_count, spk7_count, sum_cls, sum_bbox,
+                       R, (long long)D, (long long)Hd, K, K4, T, only_one_bbox, rates);
+    SNN_CHECK_LAUNCH("k_det_rates");
+    return 0;
 }
 
 // ---- RPN proposal selection -------------------------------------------------------------------
@@ -1018,9 +1097,10 @@ int snn_rpn_proposals(const snn_rpn_post_level* lv, int n_levels, int N, int A, 
     a.score_thresh = score_thresh; a.min_size = min_size; a.clip = (float)4.135166556742356;     // log(1000/16), boxes.py
     char* w = (char*)ws;
     a.cand_idx = (int*)(w + off[0]); a.cand_logit = (float*)(w + off[1]); a.boxes = (float*)(w + off[2]);
-    a.pre = (float*)(w + off[3]); a.prob = (float*)(w + off[4]); a.skey = (float*)(w + off[5]);
-    a.s_boxes = (float*)(w + off[6]); a.s_pre = pre_boxes ? pre_boxes : (float*)(w + off[7]);
-    a.s_prob = pre_prob ? pre_prob : (float*)(w + off[8]); a.s_cat = (int*)(w + off[9]); a.n_valid = (int*)(w + off[10]);
+    // the pre-NMS report goes straight to the caller's buffers, in candidate order = the reference's order (rpn.py:493-499)
+    a.pre = pre_boxes ? pre_boxes : (float*)(w + off[3]); a.prob = pre_prob ? pre_prob : (float*)(w + off[4]); a.skey = (float*)(w + off[5]);
+    a.s_boxes = (float*)(w + off[6]);
+    a.s_prob = (float*)(w + off[8]); a.s_cat = (int*)(w + off[9]); a.n_valid = (int*)(w + off[10]);
     int* keep = (int*)(w + off[11]);
     int* n_keep = (int*)(w + off[12]);
     unsigned long long* mask = (unsigned long long*)(w + off[13]);
@@ -1165,32 +1245,18 @@ static int det_head_from_planes(int R, int D, int Hd, int K, int K4, int T, cons
     if (mx) {
         if (D % 128 || Hd % 128 || !mx_tile_ok(T))
             return fail(-4, "snn_det_head_forward: the mxfp6 kernels need D, Hd %% 128 == 0 and a T that fits a 512-row tile");
-        if ((rc = snn_spike_gemm_lif_mx(enc, T, R, D, Hd, p, (const uint32_t*)w6_packed, s6, (size_t)R * Hw, stream))) return rc;
-        if ((rc = snn_spike_gemm_lif_mx(s6, T, R, Hd, Hd, p, (const uint32_t*)w7_packed, s7, (size_t)R * Hw, stream))) return rc;
-        if (spk6_count) {
-            hipLaunchKernelGGL(k_count_rows, dim3(cdiv(R, 4)), dim3(256), 0, s, s6, (unsigned long long)R * Hw, T, R, Hw, spk6_count);
-            SNN_CHECK_LAUNCH("k_count_rows");
-        }
-        if (spk7_count) {
-            hipLaunchKernelGGL(k_count_rows, dim3(cdiv(R, 4)), dim3(256), 0, s, s7, (unsigned long long)R * Hw, T, R, Hw, spk7_count);
-            SNN_CHECK_LAUNCH("k_count_rows");
-        }
+        // (spike-rate mode: per-RoI counts come out of the LIF epilogues)
+        if ((rc = spike_gemm_lif_mx_impl(enc, T, R, D, Hd, p, (const uint32_t*)w6_packed, s6, (size_t)R * Hw, spk6_count, stream))) return rc;
+        if ((rc = spike_gemm_lif_mx_impl(s6, T, R, Hd, Hd, p, (const uint32_t*)w7_packed, s7, (size_t)R * Hw, spk7_count, stream))) return rc;
         return snn_li_heads(s7, (size_t)R * Hw, T, R, Hd, w_heads_packed, K, K4, p, out_cls, out_bbox, sum_cls,
                             sum_bbox, stream);
     }
     if (b3 && (g3_tile_ok(T, G3_BM(g3_wn(), 4)) || g3_tile_ok(T, G3_BM(g3_wn(), 3)) || g3_tile_ok(T, G3_BM(g3_wn(), 2)))) {
         // fc6 + LIF and fc7 + LIF, each one launch: a row tile holds all T steps of its RoIs, the currents never
         // leave the chip (faster_rcnn.py:498-501)
-        if ((rc = snn_spike_gemm_lif_bf16x3(enc, T, R, D, Hd, p, (const uint16_t*)w6_packed, s6, (size_t)R * Hw, stream))) return rc;
-        if ((rc = snn_spike_gemm_lif_bf16x3(s6, T, R, Hd, Hd, p, (const uint16_t*)w7_packed, s7, (size_t)R * Hw, stream))) return rc;
-        if (spk6_count) {                                       // spike-rate mode: per-RoI counts from the planes
-            hipLaunchKernelGGL(k_count_rows, dim3(cdiv(R, 4)), dim3(256), 0, s, s6, (unsigned long long)R * Hw, T, R, Hw, spk6_count);
-            SNN_CHECK_LAUNCH("k_count_rows");
-        }
-        if (spk7_count) {
-            hipLaunchKernelGGL(k_count_rows, dim3(cdiv(R, 4)), dim3(256), 0, s, s7, (unsigned long long)R * Hw, T, R, Hw, spk7_count);
-            SNN_CHECK_LAUNCH("k_count_rows");
-        }
+        // (spike-rate mode: per-RoI counts come out of the LIF epilogues)
+        if ((rc = spike_gemm_lif_bf16x3_impl(enc, T, R, D, Hd, p, (const uint16_t*)w6_packed, s6, (size_t)R * Hw, spk6_count, stream))) return rc;
+        if ((rc = spike_gemm_lif_bf16x3_impl(s6, T, R, Hd, Hd, p, (const uint16_t*)w7_packed, s7, (size_t)R * Hw, spk7_count, stream))) return rc;
         return snn_li_heads(s7, (size_t)R * Hw, T, R, Hd, w_heads_packed, K, K4, p, out_cls, out_bbox, sum_cls,
                             sum_bbox, stream);
     }

@@ -481,6 +481,8 @@ __global__ __launch_bounds__(2048 / MW, 16 / MW) void k_gemm_mx(const MxArgs ma)
         // ---- LIF over the T time steps held in this tile (the 8 x 1 epilogue of k_gemm_bf16x3): two passes of 32 columns ----
         constexpr int CG = 32, PITCH = CG + 4;
         float* const tile = reinterpret_cast<float*>(smem);
+        uint32_t* const pos_cnt = reinterpret_cast<uint32_t*>(smem + G3_TILE_BYTES(1));     // behind the tile image
+        const bool counting = args.cnt_img != nullptr || args.cnt_row != nullptr;
         const int pb = args.pb, T = args.T;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll 1
@@ -504,18 +506,30 @@ __global__ __launch_bounds__(2048 / MW, 16 / MW) void k_gemm_mx(const MxArgs ma)
                 float vv = args.p.v_leak, ii = 0.0f;
                 uint32_t my0 = 0, my1 = 0;
                 const float* src = tile + (live ? pi : 2 * pp) * PITCH + col;
+                uint32_t cnt0 = 0, cnt1 = 0;               // wave-uniform: spikes of the even / odd position in this pass
                 for (int t = 0; t < T; ++t) {
                     const bool z = lif_step(src[(size_t)t * pb * PITCH], vv, ii, args.p);
                     const unsigned long long b = __ballot(z);
                     my0 = lane == t ? (uint32_t)b : my0;
                     my1 = lane == t ? (uint32_t)(b >> 32) : my1;
+                    cnt0 += __popc((uint32_t)b);
+                    cnt1 += __popc((uint32_t)(b >> 32));
                 }
+                const bool odd_ok = 2 * pp + 1 < pb && m0 + 2 * pp + 1 < M;
                 if (lane < T) {
                     uint32_t* dst = args.spk + (size_t)lane * args.spk_stride + (size_t)(m0 + 2 * pp) * (Np >> 5) + word0;
                     dst[0] = my0;
-                    if (2 * pp + 1 < pb && m0 + 2 * pp + 1 < M) dst[Np >> 5] = my1;
+                    if (odd_ok) dst[Np >> 5] = my1;
+                }
+                if (counting && lane == 0) {
+                    pos_cnt[2 * pp] = (h == 0 ? 0u : pos_cnt[2 * pp]) + cnt0;
+                    if (odd_ok) pos_cnt[2 * pp + 1] = (h == 0 ? 0u : pos_cnt[2 * pp + 1]) + cnt1;
                 }
             }
+        }
+        if (counting) {
+            __syncthreads();
+            tile_counts_flush<CONV>(args, pos_cnt, m0, pb, tid);
         }
         return;
     }

@@ -109,7 +109,10 @@ __global__ __launch_bounds__(256) void k_nms_scan(const unsigned long long* __re
                 if (!((rc >> b) & 1ull) && count < max_keep) {
                     kept_bits |= 1ull << b;
                     ++count;
-                    rc |= ((unsigned long long)__builtin_amdgcn_readlane(dhi, b) << 32) | __builtin_amdgcn_readlane(dlo, b);
+                    // (readlane returns a signed int: without the uint32_t casts a row whose bit 31 is set sign-extends into
+                    // bits 32..63 and removes the upper half of the chunk - found by the reference-pinned fixtures of round 2)
+                    rc |= ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane(dhi, b) << 32) |
+                          (unsigned long long)(uint32_t)__builtin_amdgcn_readlane(dlo, b);
                 }
             }
             // kept boxes -> keep[] in order: lane b is kept box number base + popcount(kept_bits below b)
@@ -138,9 +141,11 @@ __global__ __launch_bounds__(256) void k_nms_scan(const unsigned long long* __re
 
 // ------------------------------------------------------------------------------------------------
 // RPN proposal selection (rpn.py:420-499 + 262-296 + the box coder), one call for the batch:
-//   k_rpn_topk    per (level, image): the pre_nms_top_n largest logits by a 3-pass radix select (11+11+10 bits)
-//   k_rpn_decode  per candidate: anchor from the level geometry, box decode, sigmoid, clip, size/score filters
-//   k_rpn_sort    per image: bitonic sort of the candidates by decreasing score in LDS, gather into sorted order
+//   k_rpn_topk    per (level, image): the pre_nms_top_n largest logits by a 3-pass radix select (11+11+10 bits), then sorted
+//                 by decreasing logit: candidate slots are in the reference's order (level, rank inside the level)
+//   k_rpn_decode  per candidate: anchor from the level geometry, box decode, sigmoid, clip, size/score filters; the decoded
+//                 un-clipped boxes + probabilities of ALL candidates are the reference's pre-NMS report (rpn.py:493-499)
+//   k_rpn_sort    per image: bitonic sort of the candidates by decreasing score (ties: candidate slot) in LDS, gather
 //   k_nms_mask / k_nms_scan (batched over images, category = level)
 //   k_rpn_output  kept boxes -> [N][post_nms_top_n] padded + counts
 // ------------------------------------------------------------------------------------------------
@@ -165,7 +170,7 @@ struct RpnPostArgs {
     float* pre;                   // [N][Ktot][4] decoded, un-clipped
     float* prob;                  // [N][Ktot]
     float* skey;                  // [N][Ktot] prob, or -1 for filtered candidates
-    float* s_boxes; float* s_pre; float* s_prob; int* s_cat; int* n_valid;     // sorted by decreasing score
+    float* s_boxes; float* s_prob; int* s_cat; int* n_valid;     // sorted by decreasing score
 };
 
 __device__ __forceinline__ uint32_t f2key(float f) {           // monotone: larger float -> larger key
@@ -208,8 +213,16 @@ __global__ __launch_bounds__(1024) void k_rpn_topk(const RpnPostArgs a) {
     }
     // prefix = key of the k-th largest logit; `need` of the keys equal to it are taken: those with the lowest element
     // index (deterministic; an ordered pass with a block scan, run only when there are more ties than needed)
+    // The selected candidates are then put in the reference's order - objectness.topk(k) returns them by decreasing logit
+    // (rpn.py:413), equal logits by increasing element index here - with a bitonic sort of (logit key, ~index) in LDS: the
+    // candidate slot koff + rank IS the position the reference gives the candidate, which later breaks ties between equal
+    // sigmoid values exactly like the reference's stable order (fp32 sigmoid merges many distinct logits).
+    __shared__ unsigned long long sel[RPN_SORT_MAX];
     __shared__ uint32_t s_eq_total;
     if (tid == 0) { s_cnt_gt = 0; s_cnt_eq = 0; s_eq_total = hist[prefix & 1023u]; }
+    int np2 = 1;
+    while (np2 < L.k) np2 <<= 1;
+    for (int i = L.k + tid; i < np2; i += 1024) sel[i] = 0ull;          // padding sorts last
     __syncthreads();
     int* out_idx = a.cand_idx + (size_t)img * a.Ktot + L.koff;
     float* out_logit = a.cand_logit + (size_t)img * a.Ktot + L.koff;
@@ -221,7 +234,7 @@ __global__ __launch_bounds__(1024) void k_rpn_topk(const RpnPostArgs a) {
         int slot = -1;
         if (key > prefix) slot = (int)atomicAdd(&s_cnt_gt, 1u);
         else if (key == prefix && !ordered_ties) slot = (int)(n_gt + atomicAdd(&s_cnt_eq, 1u));
-        if (slot >= 0) { out_idx[slot] = e; out_logit[slot] = x; }
+        if (slot >= 0) sel[slot] = ((unsigned long long)key << 32) | (uint32_t)(~(uint32_t)e);
     }
     if (ordered_ties) {
         __shared__ uint32_t wsum[16];
@@ -236,10 +249,27 @@ __global__ __launch_bounds__(1024) void k_rpn_topk(const RpnPostArgs a) {
             uint32_t before = 0, total = 0;
             for (int w = 0; w < 16; ++w) { if (w < wv) before += wsum[w]; total += wsum[w]; }
             const uint32_t rank = taken + before + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-            if (tie && rank < need) { out_idx[n_gt + rank] = e; out_logit[n_gt + rank] = src[e]; }
+            if (tie && rank < need) sel[n_gt + rank] = ((unsigned long long)prefix << 32) | (uint32_t)(~(uint32_t)e);
             taken += total;
             __syncthreads();
         }
+    }
+    __syncthreads();
+    for (int k = 2; k <= np2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < np2; i += 1024) {
+                const int p = i ^ j;
+                if (p > i) {
+                    const unsigned long long x = sel[i], y = sel[p];
+                    if (((i & k) == 0) ? x < y : x > y) { sel[i] = y; sel[p] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = tid; i < L.k; i += 1024) {
+        const int e = (int)(~(uint32_t)sel[i]);
+        out_idx[i] = e;
+        out_logit[i] = src[e];
     }
 }
 
@@ -277,23 +307,13 @@ __global__ __launch_bounds__(256) void k_rpn_decode(const RpnPostArgs a) {
 
 __global__ __launch_bounds__(1024) void k_rpn_sort(const RpnPostArgs a) {
     __shared__ unsigned long long v[RPN_SORT_MAX];
-    __shared__ uint16_t slot_of[RPN_SORT_MAX];
     const int img = blockIdx.x, tid = threadIdx.x, K = a.Ktot;
     int np2 = 1;
     while (np2 < K) np2 <<= 1;
-    // descending on (score, then level, then lower element index): the candidate's slot rides in the low 13 bits.
-    // (The slots inside a level are filled in atomic order; the element index makes the result run-to-run identical.)
-    for (int i = tid; i < np2; i += 1024) {
-        unsigned long long key = 0ull;
-        if (i < K) {
-            int l = 0;
-            while (l + 1 < a.n_levels && i >= a.lv[l + 1].koff) ++l;
-            const uint32_t ident = ((uint32_t)l << 28) | (uint32_t)a.cand_idx[(size_t)img * K + i];    // e < 2^28
-            key = ((unsigned long long)f2key(a.skey[(size_t)img * K + i]) << 32) | (uint32_t)(~ident);
-        }
-        v[i] = key;
-        slot_of[i] = (uint16_t)i;
-    }
+    // descending on (score, then lower candidate slot).  Slots are in the reference's candidate order (level, then rank by
+    // logit inside the level: k_rpn_topk), so equal scores come out as the reference's stable sort leaves them.
+    for (int i = tid; i < np2; i += 1024)
+        v[i] = i < K ? ((unsigned long long)f2key(a.skey[(size_t)img * K + i]) << 32) | (uint32_t)(~(uint32_t)i) : 0ull;
     __syncthreads();
     for (int k = 2; k <= np2; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
@@ -301,21 +321,16 @@ __global__ __launch_bounds__(1024) void k_rpn_sort(const RpnPostArgs a) {
                 const int p = i ^ j;
                 if (p > i) {
                     const unsigned long long x = v[i], y = v[p];
-                    const bool desc = (i & k) == 0;
-                    if (desc ? x < y : x > y) {
-                        v[i] = y; v[p] = x;
-                        const uint16_t q = slot_of[i]; slot_of[i] = slot_of[p]; slot_of[p] = q;
-                    }
+                    if (((i & k) == 0) ? x < y : x > y) { v[i] = y; v[p] = x; }
                 }
             }
             __syncthreads();
         }
     int valid = 0;
     for (int i = tid; i < K; i += 1024) {
-        const int c = slot_of[i];
+        const int c = (int)(~(uint32_t)v[i]);
         const size_t src = (size_t)img * K + c, dst = (size_t)img * K + i;
         reinterpret_cast<float4*>(a.s_boxes)[dst] = reinterpret_cast<const float4*>(a.boxes)[src];
-        reinterpret_cast<float4*>(a.s_pre)[dst] = reinterpret_cast<const float4*>(a.pre)[src];
         a.s_prob[dst] = a.prob[src];
         int l = 0;
         while (l + 1 < a.n_levels && c >= a.lv[l + 1].koff) ++l;

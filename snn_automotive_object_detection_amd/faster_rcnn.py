@@ -43,7 +43,7 @@ class FastRCNNPredictorSNNFull(nn.Module):
         self._c6 = {"f32": _WeightCache(), "bf16x3": _WeightCache(), "mxfp6": _WeightCache()}
         self._c7 = {"f32": _WeightCache(), "bf16x3": _WeightCache(), "mxfp6": _WeightCache()}
         self._ch = _WeightCache()
-        self._flops_cache = {}
+        self.last_spike_counts = None
 
     def invalidate_packed_weights(self) -> None:
         """drop the packed copies of the weights (needed after in-place edits through ``param.data``, which do not bump the
@@ -103,22 +103,12 @@ class FastRCNNPredictorSNNFull(nn.Module):
         return self._finish(out, rois.shape[0], rois.device)
 
     def _finish(self, out, R, dev):
-        cls, bbox, (c6, c7, s_c, s_b) = out
-        T = int(self.num_steps)
-        Hd, K = self.representation_size, self.num_classes
+        cls, bbox, extras = out
         if not self.spike_rates:
             return cls, bbox                                           # :513-516
-        # faster_rcnn.py:568-618: (count / T).mean(dim=1) and literal "FLOPs" per layer
-        r6 = (c6.to(torch.float64) / float(T * Hd)).to(torch.float32).view(R, 1)
-        r7 = (c7.to(torch.float64) / float(T * Hd)).to(torch.float32).view(R, 1)
-        rc = (s_c / T).mean(dim=1, keepdim=True)
-        rb = (s_b / T).mean(dim=1, keepdim=True)
-        def fl(v):                                                # cached: no host-to-device copy per call
-            key = (int(v), int(R), str(dev))
-            if key not in self._flops_cache:
-                self._flops_cache[key] = torch.tensor([v], device=dev).repeat(R, 1)
-            return self._flops_cache[key]
-        D = self.in_channels
-        return [torch.hstack((r6, fl(D * Hd))), torch.hstack((r7, fl(Hd * Hd))),
-                torch.hstack((rc, fl(Hd * K))),
-                torch.hstack((rb, fl(Hd * K if self.only_one_bbox else Hd * K * 4)))]
+        # faster_rcnn.py:568-618: four [R, 2] = (rate, "FLOPs") tensors - lif6, lif7, cls_score, bbox_pred - finished by
+        # snn_det_rates from the integer spike counts of the LIF epilogues and the time-summed LI membranes (one launch)
+        self.last_spike_counts = (extras[0], extras[1])
+        rates = ops.det_rates(extras, self.in_channels, self.representation_size, self.num_classes,
+                              self.bbox_pred.weight.shape[0], int(self.num_steps), self.only_one_bbox)
+        return [rates[0], rates[1], rates[2], rates[3]]

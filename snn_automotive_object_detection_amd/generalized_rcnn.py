@@ -29,10 +29,10 @@ class GeneralizedRCNN(nn.Module):
         if isinstance(features, torch.Tensor):
             features = OrderedDict([("0", features)])
         head = getattr(self.rpn, "head", None)
-        if getattr(head, "spike_rates", False):                                     # spike-rate path, 98-111
-            _, rpn_rates = self._rpn_spike_rates(images, features)
-            det_rates = self.roi_heads(features, self._last_proposals, images.image_sizes, targets)
-            return rpn_rates + det_rates
+        if getattr(head, "spike_rates", False):                                     # spike-rate path, 98-111: ONE head call;
+            proposals, rpn_rates = self.rpn(images, features, targets)              # the RPN hands the head's rates on (rpn.py:698-701)
+            det_rates = self.roi_heads(features, proposals, images.image_sizes, targets)
+            return list(rpn_rates) + list(det_rates)
         proposals, proposal_extras = self.rpn(images, features, targets)            # :114
         detections, _ = self.roi_heads(features, proposals, images.image_sizes, targets)   # :118
         detections = self.transform.postprocess(detections, images.image_sizes, original_image_sizes)
@@ -42,17 +42,6 @@ class GeneralizedRCNN(nn.Module):
         if detections and "all_boxes" in detections[0]:
             detections = self.postprocess(detections, images.image_sizes, original_image_sizes)
         return detections
-
-    def _rpn_spike_rates(self, images, features):
-        """the rpn.py:608-610 / 698-701 variant: the head returns a third value which replaces `losses`"""
-        feats = list(features.values())
-        objectness, deltas, rates = self.rpn.head(feats)
-        self.rpn.head.spike_rates = False
-        try:
-            self._last_proposals, _ = self.rpn(images, features)
-        finally:
-            self.rpn.head.spike_rates = True
-        return self._last_proposals, rates
 
     def postprocess(self, result: List[Dict[str, Tensor]], image_shapes: List[Tuple[int, int]],
                     original_image_sizes: List[Tuple[int, int]]) -> List[Dict[str, Tensor]]:

@@ -376,6 +376,7 @@ class _Workspace:
 
 
 _WS = _Workspace()
+_WS_RATES = _Workspace()                     # partial sums of snn_rpn_rates (must not alias the heads' workspace)
 
 
 def rpn_head_forward(feats: Sequence[torch.Tensor], C_: int, A: int, T: int, p: snn_params,
@@ -403,7 +404,7 @@ def rpn_head_forward(feats: Sequence[torch.Tensor], C_: int, A: int, T: int, p: 
     ws = _WS.get(dev, ws_bytes)
     out_logits = torch.empty((P, A), dtype=torch.float32, device=dev)
     out_bbox = torch.empty((P, 4 * A), dtype=torch.float32, device=dev)
-    counts = sum_l = sum_b = None
+    counts = sum_l = sum_b = rates = None
     if spike_rates:
         counts = torch.empty((len(feats), max_n), dtype=torch.int64, device=dev)
         sum_l = torch.empty_like(out_logits)
@@ -413,7 +414,13 @@ def rpn_head_forward(feats: Sequence[torch.Tensor], C_: int, A: int, T: int, p: 
                                                _ptr(counts), _ptr(sum_l), _ptr(sum_b), _ptr(ws), ws.numel(),
                                                int(stage_mask), _stream()),
                "snn_rpn_head_forward")
-    return out_logits, out_bbox, rows, (counts, sum_l, sum_b)
+    if spike_rates and stage_mask == 7:
+        # the finished [.., 2] = (rate, FLOPs) rows of rpn.py:171-195: two small launches, no torch arithmetic
+        rates = torch.empty((len(feats), 3, max_n, 2), dtype=torch.float32, device=dev)
+        rws = _WS_RATES.get(dev, lib.snn_rpn_rates_workspace_bytes(len(feats), max_n))
+        _lib.check(lib.snn_rpn_rates(lv, len(feats), C_, A, T, _ptr(counts), _ptr(sum_l), _ptr(sum_b), _ptr(rates), _ptr(rws),
+                                     rws.numel(), _stream()), "snn_rpn_rates")
+    return out_logits, out_bbox, rows, (counts, sum_l, sum_b, rates)
 
 
 def det_head_forward(x: torch.Tensor, Hd: int, K: int, K4: int, T: int, p: snn_params, w6_packed: torch.Tensor,
@@ -440,6 +447,18 @@ def det_head_forward(x: torch.Tensor, Hd: int, K: int, K4: int, T: int, p: snn_p
                                         _ptr(s_c), _ptr(s_b), _ptr(ws), ws.numel(), _stream()),
                "snn_det_head_forward")
     return out_cls, out_bbox, (c6, c7, s_c, s_b)
+
+
+def det_rates(extras, D: int, Hd: int, K: int, K4: int, T: int, only_one_bbox: bool) -> torch.Tensor:
+    """(c6, c7, sum_cls, sum_bbox) of a spike-rate head call -> rates [4, R, 2] = (rate, FLOPs) rows of faster_rcnn.py:568-618"""
+    lib = _lib.load()
+    c6, c7, s_c, s_b = extras
+    R = c6.shape[0]
+    rates = torch.empty((4, R, 2), dtype=torch.float32, device=c6.device)
+    if R:
+        _lib.check(lib.snn_det_rates(R, D, Hd, K, K4, T, int(bool(only_one_bbox)), _ptr(c6), _ptr(c7), _ptr(s_c), _ptr(s_b),
+                                     _ptr(rates), _stream()), "snn_det_rates")
+    return rates
 
 
 # ---------------------------------------------------------------------------------------------

@@ -72,16 +72,7 @@ class RPNHeadSNN(nn.Module):
                 torch.nn.init.normal_(layer.weight, std=0.01)
         self._cache_shared = {"f32": _WeightCache(), "bf16x3": _WeightCache(), "mxfp6": _WeightCache()}
         self._cache_heads = _WeightCache()
-        self._flops_cache = {}
-
-    def _flops_const(self, v: int, N: int, dev) -> Tensor:
-        """[N, 1] int64 tensor holding the FLOP constant v of the spike-rate output (rpn.py:177-188), made once per value"""
-        key = (int(v), int(N), str(dev))
-        t = self._flops_cache.get(key)
-        if t is None:
-            t = torch.tensor([v], device=dev).repeat(N, 1)
-            self._flops_cache[key] = t
-        return t
+        self.last_spike_counts = None
 
     def invalidate_packed_weights(self) -> None:
         """drop the packed (bf16x3 / mxfp6 / f32 fragment-major) copies of the weights; they are rebuilt on the next forward"""
@@ -115,7 +106,7 @@ class RPNHeadSNN(nn.Module):
         C, A, T = self.in_channels, self.num_anchors, int(self.num_steps)
         w_shared = self._packed_shared()
         w_heads = self._cache_heads.get((self.conv_cls.weight, self.conv_bbox.weight), ops.pack_heads)
-        out_l, out_b, rows, (counts, sum_l, sum_b) = ops.rpn_head_forward(
+        out_l, out_b, rows, (counts, sum_l, sum_b, rate_rows) = ops.rpn_head_forward(
             list(x), C, A, T, self._params(), w_shared, w_heads, spike_rates=self.spike_rates)
         logits, bbox_reg, rates = [], [], []
         pos = 0
@@ -126,17 +117,11 @@ class RPNHeadSNN(nn.Module):
             # concat_box_prediction_layers' view/permute/reshape (rpn.py:256-258) copy-free
             logits.append(out_l[pos:pos + n].view(N, H, W, A).permute(0, 3, 1, 2))
             bbox_reg.append(out_b[pos:pos + n].view(N, H, W, 4 * A).permute(0, 3, 1, 2))
-            if self.spike_rates:                                      # rpn.py:171-195
-                dev = f.device
-                r_sh = (counts[l, :N].to(torch.float64) / float(T * C * H * W)).to(torch.float32).view(N, 1)
-                r_ob = (sum_l[pos:pos + n].view(N, -1) / T).mean(dim=1, keepdim=True)
-                r_bb = (sum_b[pos:pos + n].view(N, -1) / T).mean(dim=1, keepdim=True)
-                fl = lambda v: self._flops_const(v, N, dev)           # cached: no host-to-device copy per call
-                rates += [torch.hstack((r_sh, fl(9 * (H * W) * C * C))),
-                          torch.hstack((r_ob, fl(1 * (H * W) * C * A * 4))),   # labels swapped in the
-                          torch.hstack((r_bb, fl(1 * (H * W) * C * A)))]       # reference; kept as is
+            if self.spike_rates:                                      # rpn.py:171-195: three [N, 2] = (rate, FLOPs) tensors per
+                rates += [rate_rows[l, j, :N] for j in range(3)]      # level, finished by snn_rpn_rates (views, no torch math)
             pos += n
         if self.spike_rates:
+            self.last_spike_counts = counts                           # [levels, N] int64: shared-LIF spikes (tests, energy report)
             return logits, bbox_reg, rates
         return logits, bbox_reg
 
@@ -293,9 +278,13 @@ class RegionProposalNetwork(nn.Module):
         if self.training:
             raise NotImplementedError("inference only: training the RPN is out of scope (DESIGN.md §7)")
         feats = list(features.values())
-        objectness, pred_bbox_deltas = self.head(feats)[:2]                           # rpn.py:613
+        head_out = self.head(feats)                                                   # rpn.py:613 (608-610 in spike-rate mode)
+        objectness, pred_bbox_deltas = head_out[:2]
+        # spike-rate mode: the head's third value takes the place of `losses` (rpn.py:698-701, "losses = spike_rates")
+        rates = head_out[2] if len(head_out) == 3 else None
         if objectness[0].is_cuda and self.post == "hip":
-            return self._proposals_hip(objectness, pred_bbox_deltas, images, feats)
+            boxes, pre_nms = self._proposals_hip(objectness, pred_bbox_deltas, images, feats)
+            return boxes, (pre_nms if rates is None else rates)
         anchors = self.anchor_generator(images, feats)
         num_images = len(anchors)
         num_anchors_per_level = [o.shape[1] * o.shape[2] * o.shape[3] for o in objectness]
@@ -307,4 +296,4 @@ class RegionProposalNetwork(nn.Module):
             proposals = self.box_coder.decode(pred_bbox_deltas.detach(), anchors).view(num_images, -1, 4)
             boxes, scores, pre_nms = self.filter_proposals_reference(proposals, objectness, images.image_sizes,
                                                                      num_anchors_per_level)
-        return boxes, pre_nms
+        return boxes, (pre_nms if rates is None else rates)

@@ -52,14 +52,27 @@ def nms(boxes: Tensor, scores: Tensor, iou_threshold: float) -> Tensor:
     return order[keep]
 
 
+HIP_NMS = True     # False: GPU tensors also take the plain-torch NMS (tests: a comparator independent of the HIP kernels)
+
+
 def batched_nms(boxes: Tensor, scores: Tensor, idxs: Tensor, iou_threshold: float) -> Tensor:
-    """NMS per category.  GPU tensors go to the HIP kernels (ops.batched_nms: bit-matrix + in-order scan); CPU
-    tensors use the plain-torch form: shift every category into its own coordinate range, then one NMS."""
+    """NMS per category.  GPU tensors go to the HIP kernels (ops.batched_nms: bit-matrix + in-order scan, IoU on the raw
+    coordinates).  Otherwise torchvision's two strategies with its CPU switch-over (the reference's CPU path is the parity
+    target): more than 4000 coordinates -> one NMS per category on the raw coordinates; else every category is shifted into
+    its own coordinate range and one NMS runs over all of them (the shift rounds the coordinates, so an IoU within ~1e-6 of the
+    threshold can be decided differently by the two)."""
     if boxes.numel() == 0:
         return torch.empty((0,), dtype=torch.int64, device=boxes.device)
-    if boxes.is_cuda and boxes.shape[0] <= 16384:
+    if boxes.is_cuda and boxes.shape[0] <= 16384 and HIP_NMS:
         from .. import ops
         return ops.batched_nms(boxes, scores, idxs, iou_threshold)
+    if boxes.numel() > 4000:
+        keep_mask = torch.zeros_like(scores, dtype=torch.bool)
+        for c in torch.unique(idxs):
+            cur = torch.where(idxs == c)[0]
+            keep_mask[cur[nms(boxes[cur], scores[cur], iou_threshold)]] = True
+        keep = torch.where(keep_mask)[0]
+        return keep[scores[keep].sort(descending=True, stable=True)[1]]
     max_coordinate = boxes.max()
     offsets = idxs.to(boxes) * (max_coordinate + torch.tensor(1).to(boxes))
     return nms(boxes + offsets[:, None], scores, iou_threshold)

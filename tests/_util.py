@@ -33,3 +33,52 @@ def flip_budget(positions: int, channels: int, steps: int) -> float:
     of the same 3x3 convolution disagree on ~7e-8 of the neuron-steps (SURVEY.md §7 risk 1 measured 5 of 7.5e7
     between two oneDNN layouts); a position has channels*steps of them.  Budget = 3.5x that rate + 2."""
     return 2 + 2.5e-7 * channels * steps * positions
+
+
+# ---- post-processing fixtures (tests/golden/post_*.npz; oracle/make_golden.py ran the reference's own bodies) ----
+BOX_ATOL = 1e-3        # pixels: box coordinates reach 1536, where one fp32 ulp is 1.2e-4; decode has ~6 roundings
+SCORE_ATOL = 2e-6      # sigmoid / softmax of identical fp32 logits: library exp() implementations differ in the last ulp
+
+
+def split_rows(flat: np.ndarray, counts) -> list:
+    out, pos = [], 0
+    for c in counts:
+        out.append(flat[pos:pos + int(c)])
+        pos += int(c)
+    return out
+
+
+def assert_same_detections(got_boxes, got_scores, exp_boxes, exp_scores, got_labels=None, exp_labels=None, what=""):
+    """same number of rows, same order (by decreasing score; rows whose scores tie within SCORE_ATOL may be permuted),
+    boxes within BOX_ATOL, scores within SCORE_ATOL, labels equal"""
+    gb, gs = np.asarray(got_boxes, dtype=np.float64).reshape(-1, 4), np.asarray(got_scores, dtype=np.float64).reshape(-1)
+    eb, es = np.asarray(exp_boxes, dtype=np.float64).reshape(-1, 4), np.asarray(exp_scores, dtype=np.float64).reshape(-1)
+    assert gb.shape[0] == eb.shape[0], "%s: %d rows, expected %d" % (what, gb.shape[0], eb.shape[0])
+    if gb.shape[0] == 0:
+        return
+    gl = np.zeros(gs.shape) if got_labels is None else np.asarray(got_labels, dtype=np.float64).reshape(-1)
+    el = np.zeros(es.shape) if exp_labels is None else np.asarray(exp_labels, dtype=np.float64).reshape(-1)
+    assert np.abs(gs - es).max() <= SCORE_ATOL, "%s: scores differ by %g" % (what, np.abs(gs - es).max())
+
+    def canon(b, s, l):                      # order inside groups of (nearly) equal scores by label and coordinates
+        grp = np.concatenate([[0], np.cumsum(np.abs(np.diff(s)) > SCORE_ATOL)])
+        key = np.lexsort((np.round(b[:, 3], 1), np.round(b[:, 2], 1), np.round(b[:, 1], 1), np.round(b[:, 0], 1), l, grp))
+        return b[key], l[key]
+    gb2, gl2 = canon(gb, es, gl)             # group by the EXPECTED scores on both sides
+    eb2, el2 = canon(eb, es, el)
+    assert np.array_equal(gl2, el2), "%s: labels differ" % what
+    assert np.abs(gb2 - eb2).max() <= BOX_ATOL, "%s: boxes differ by %g" % (what, np.abs(gb2 - eb2).max())
+
+
+def record_parity(test: str, **values):
+    """append observed off-tolerance counts to gpurun_out/parity_r2.jsonl (copied into profiles/parity_r2.json after a GPU
+    run): the flip budgets are tightened on this evidence"""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_r2.jsonl")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "a") as f:
+            f.write(json.dumps({"test": test, **values}) + "\n")
+    except OSError:
+        pass

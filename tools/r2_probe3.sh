@@ -1,0 +1,4 @@
+#!/bin/bash
+mkdir -p gpurun_out
+python -m pytest tests/test_gpu_post.py tests/test_gpu_e2e.py tests/test_gpu_nms.py -q -m gpu > gpurun_out/r2_t_post.log 2>&1; echo "rc=$?"
+grep -E "passed|failed|FAILED|Error|assert " gpurun_out/r2_t_post.log | tail -30

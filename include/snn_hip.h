@@ -21,7 +21,9 @@
  *     use, no host<->device copies: every call is hipGraph-capturable;
  *   - return value 0 = success, negative = error (message via snn_last_error(), thread-local);
  *     no exceptions cross the ABI and the library never aborts;
- *   - re-entrant: no global mutable state besides the thread-local error string.
+ *   - re-entrant: no global mutable state besides the thread-local error string.  Two kinds of process-wide constants are
+ *     cached at first use: the debug / A-B knobs (environment variables SNN_*, read ONCE and frozen; snn_debug_reload_knobs()
+ *     re-reads them - test hook, not for concurrent use) and properties of the device (CU count, occupancy of a kernel).
  *
  * Spike tensors never exist as fp32.  A spike train is a set of BIT-PLANES
  *     plane[t][row][w]   (uint32, bit b of word w = spike of channel 32*w+b at time step t)
@@ -72,6 +74,7 @@ typedef struct snn_rpn_level {
 
 int snn_version(void);
 const char* snn_last_error(void);
+void snn_debug_reload_knobs(void);     /* re-read the SNN_* debug knobs from the environment (tests only) */
 
 /* ---- weight packing (call when the weights change; results are plain device buffers) ---------- */
 /* number of floats of a packed GEMM operand with K reduction rows and N output columns */

@@ -40,6 +40,7 @@ class snn_rpn_post_level(C.Structure):
 SYMBOLS = {
     "snn_version": (C.c_int, []),
     "snn_last_error": (C.c_char_p, []),
+    "snn_debug_reload_knobs": (None, []),
     "snn_packed_gemm_elems": (C.c_size_t, [C.c_int, C.c_int]),
     "snn_packed_conv3x3_elems": (C.c_size_t, [C.c_int, C.c_int]),
     "snn_pack_conv3x3_weight": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, c_stream]),
@@ -150,3 +151,9 @@ def check(rc: int, what: str = ""):
     if rc != 0:
         msg = load().snn_last_error()
         raise SnnHipError("%s failed (rc=%d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+
+def reload_knobs():
+    """the SNN_* debug knobs are read from the environment once and frozen; tests that flip them call this afterwards"""
+    if _LIB is not None:
+        _LIB.snn_debug_reload_knobs()

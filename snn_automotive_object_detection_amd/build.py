@@ -67,5 +67,29 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB_PATH
 
 
+ASAN_RUNTIME = "/opt/rocm/lib/llvm/lib/clang/22/lib/linux/libclang_rt.asan-x86_64.so"
+
+
+def asan_runtime() -> str:
+    """the shared AddressSanitizer runtime of the ROCm clang (to LD_PRELOAD into python)"""
+    if os.path.exists(ASAN_RUNTIME):
+        return ASAN_RUNTIME
+    import glob
+    hits = sorted(glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so"))
+    return hits[-1] if hits else ""
+
+
+def build_asan(out_path: str) -> str:
+    """Host-side AddressSanitizer build of the same translation unit (CPU box only: GPU ASan / xnack+ code objects are not
+    available on this pool).  The device code is compiled un-instrumented; what is checked is the host half of the C ABI:
+    argument validation, the level / image tables copied from caller memory, workspace layouts."""
+    cmd = [HIPCC] + [f for f in FLAGS if f != "-O3"] + ["-O1", "-g", "-fsanitize=address", "-fno-gpu-sanitize", "-shared-libsan",
+                                                          "-o", out_path] + [os.path.join(CSRC, s) for s in SOURCES]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc (asan) failed:\n" + r.stdout)
+    return out_path
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))

@@ -108,11 +108,41 @@ __global__ void k_pack_heads(const float* __restrict__ wa, int NA, const float* 
 // ================================================================================================
 // C ABI
 // ================================================================================================
-// encoder fast path: Norse's default rest / reset potentials (SNN_ENC_GENERIC=1 forces the op-for-op kernels: test knob)
-static bool enc_zero_rest(const NeuronP& p) {
-    const char* g = getenv("SNN_ENC_GENERIC");
-    return p.v_leak == 0.0f && p.v_reset == 0.0f && !(g && g[0] == '1');
+// Debug / A-B knobs.  They are read from the environment ONCE (first call into the library, thread-safe static
+// initialisation) and frozen: later setenv() calls change nothing, calls from several threads see one consistent set.
+// snn_debug_reload_knobs() re-reads them (the parity tests compare kernel variants in one process; not for concurrent use).
+struct Knobs {
+    bool enc_generic;        // SNN_ENC_GENERIC=1     op-for-op encoder kernels even for zero rest / reset potentials
+    bool enc_rows_ballot;    // SNN_ENC_ROWS=ballot   element-per-lane row encoder
+    int bf16x3_mt;           // SNN_BF16X3_MT=2|3|4   M-tiles per wave (0: cost model)
+    int bf16x3_wn;           // SNN_BF16X3_WN=1|2     waves along N of the tile (default 2)
+    bool bf16x3_lif_reg;     // SNN_BF16X3_LIF=reg    register-resident conv + LIF fusion instead of T-in-tile
+    int mx_mw;               // SNN_MX_MW=4|8         rows per wave of k_gemm_mx
+    int li_heads;            // SNN_LI_HEADS=valu|mfma|ksplit -> 1 | 2 | 3 (0: by shape)
+    bool debug_occ;          // SNN_DEBUG_OCC         print occupancy of the big kernels
+};
+static Knobs load_knobs() {
+    Knobs k;
+    const char* e;
+    k.enc_generic = (e = getenv("SNN_ENC_GENERIC")) && e[0] == '1';
+    k.enc_rows_ballot = (e = getenv("SNN_ENC_ROWS")) && !strcmp(e, "ballot");
+    k.bf16x3_mt = (e = getenv("SNN_BF16X3_MT")) ? atoi(e) : 0;
+    k.bf16x3_wn = ((e = getenv("SNN_BF16X3_WN")) && e[0] == '1') ? 1 : 2;
+    k.bf16x3_lif_reg = (e = getenv("SNN_BF16X3_LIF")) && !strcmp(e, "reg");
+    e = getenv("SNN_MX_MW");
+    k.mx_mw = (e && e[0] == '8') ? 8 : ((e && e[0] == '4') ? 4 : 0);
+    e = getenv("SNN_LI_HEADS");
+    k.li_heads = !e ? 0 : !strcmp(e, "valu") ? 1 : !strcmp(e, "mfma") ? 2 : !strcmp(e, "ksplit") ? 3 : 4;
+    k.debug_occ = getenv("SNN_DEBUG_OCC") != nullptr;
+    return k;
 }
+static Knobs& knobs() {
+    static Knobs k = load_knobs();
+    return k;
+}
+
+// encoder fast path: Norse's default rest / reset potentials
+static bool enc_zero_rest(const NeuronP& p) { return p.v_leak == 0.0f && p.v_reset == 0.0f && !knobs().enc_generic; }
 
 static int g3_slots() {                       // CUs: two co-resident work-groups share a CU's matrix pipe, so the tail is
                                               // quantised per CU, not per work-group slot (fc6: MT=4 1.03 ms, MT=3 1.07 ms)
@@ -131,11 +161,11 @@ template <typename F>
 static int g3_pick_mt(F tiles_of) {
     int best = 0;
     double best_cost = 0;
-    const char* force = getenv("SNN_BF16X3_MT");              // debug / A-B knob: 2, 3 or 4
+    const int force = knobs().bf16x3_mt;                      // debug / A-B knob: 2, 3 or 4
     for (int mt = 4; mt >= 2; --mt) {
         const long long wgs = tiles_of(mt);
         if (wgs <= 0) continue;
-        if (force && atoi(force) == mt) return mt;
+        if (force == mt) return mt;
         const double cost = (double)((wgs + g3_slots() - 1) / g3_slots()) * (mt + 0.5);
         if (best_cost == 0 || cost < best_cost * 0.97) { best = mt; best_cost = cost; }
     }
@@ -149,10 +179,7 @@ static int g3_pick_mt(F tiles_of) {
 // FLOP, 4-slot ring).  Both run at the same speed (conv+LIF 2.95 / 2.94 ms on one box): the copies are not what the
 // kernel waits for - timing builds without them run faster because MFMAs on all-zero operands draw less power and
 // the chip clocks up, not because the copies cost time.  SNN_BF16X3_WN=1|2 is an A-B / test knob.
-static int g3_wn() {
-    const char* f = getenv("SNN_BF16X3_WN");
-    return (f && f[0] == '1') ? 1 : 2;
-}
+static int g3_wn() { return knobs().bf16x3_wn; }
 
 template <int MODE>
 static const void* g3_kernel(int mt, int wn) {
@@ -247,7 +274,8 @@ __global__ __launch_bounds__(1024) void k_det_payload(const float* __restrict__ 
 
 extern "C" {
 
-int snn_version(void) { return 1; }
+int snn_version(void) { return 2; }
+void snn_debug_reload_knobs(void) { knobs() = load_knobs(); }
 const char* snn_last_error(void) { return g_err; }
 
 size_t snn_packed_gemm_elems(int K_chunks32, int N) { return (size_t)K_chunks32 * cdiv(N, 32) * 1024; }
@@ -357,9 +385,9 @@ static int launch_gemm3(int mode, int mt, int wn, const Gemm3Args& a, hipStream_
     static_assert(2 * (G3_TILE_BYTES(1) + G3_CNT_BYTES) <= 160 * 1024 && 2 * G3_LDS(3, 2) <= 160 * 1024, "two work-groups per CU");
     hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return fail(-3, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-    if (getenv("SNN_DEBUG_OCC")) {                             // debug: co-resident work-groups per CU
+    if (knobs().debug_occ) {                                   // debug: co-resident work-groups per CU
         int v = 0;
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, kern, 512, lds);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, kern, 512, lds);
         fprintf(stderr, "k_gemm_bf16x3 mode %d mt %d wn %d: lds %d B, %d work-groups per CU, grid %d\n", mode, mt, wn, lds, v, tiles * a.n_blocks);
     }
     void* kargs[] = {(void*)&a};
@@ -414,10 +442,7 @@ static bool mx_tile_ok(int T) { return g3_tile_ok(T, MX_BM); }
 
 // rows per wave: 4 M-tiles (8 waves, 128 registers; default) or 8 (4 waves, 256 registers: half the LDS fragment reads
 // per MFMA - measured equal in the loop, slower in the LIF epilogue); SNN_MX_MW=4|8 overrides (debug / A-B switch)
-static int mx_mw() {
-    const char* e = getenv("SNN_MX_MW");
-    return e && e[0] == '8' ? 8 : (e && e[0] == '4' ? 4 : MX_MW_DEFAULT);
-}
+static int mx_mw() { return knobs().mx_mw ? knobs().mx_mw : MX_MW_DEFAULT; }
 
 #define MX_KERNEL_OF(MW, mode)                                                                        \
     ((mode) == G3_FC ? (const void*)k_gemm_mx<G3_FC, MW>                                              \
@@ -434,9 +459,9 @@ static int launch_gemm_mx(int mode, MxArgs& a, hipStream_t s) {
     a.g.n_blocks = cdiv(a.g.Np, MX_BN);
     hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return fail(-3, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-    if (getenv("SNN_DEBUG_OCC")) {
+    if (knobs().debug_occ) {
         int v = 0;
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, kern, 2048 / mw, lds);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, kern, 2048 / mw, lds);
         fprintf(stderr, "k_gemm_mx mode %d mw %d: lds %d B, %d work-groups per CU, grid %d\n", mode, mw, lds, v, tiles * a.g.n_blocks);
     }
     void* kargs[] = {(void*)&a};
@@ -573,10 +598,9 @@ static int conv3x3_lif_bf16x3_impl(const uint32_t* enc, size_t enc_stride, const
     if (rc) return rc;
     a.M = (int)P; a.T = T; a.spk = spk; a.spk_stride = spk_stride; a.p = make_p(p, p->v_th_lif);
     // debug / A-B knob: SNN_BF16X3_LIF=reg forces the register-resident variant (the fallback for T > 64)
-    const char* force = getenv("SNN_BF16X3_LIF");
     const int wn = g3_wn();
     int mt = 0;
-    if (!(force && !strcmp(force, "reg"))) {
+    if (!knobs().bf16x3_lif_reg) {
         a.n_blocks = cdiv(a.Np, G3_BN(wn));
         mt = g3_pick_mt([&](int m) { return g3_tile_ok(T, G3_BM(wn, m)) ? (long long)cdiv(P, G3_BM(wn, m) / T) * a.n_blocks : 0ll; });
     }
@@ -665,8 +689,7 @@ int snn_encode_rows(const float* x, int R, int D, int T, const snn_params* p, ui
     const int Dw = cdiv(D, 32);
     const size_t total = (size_t)R * Dw * 32;
     const NeuronP np = make_p(p, p->v_th_enc);
-    const char* force = getenv("SNN_ENC_ROWS");                // debug / A-B knob: "ballot" forces the element-per-lane kernel
-    if (D % 32 == 0 && ((uintptr_t)x & 15) == 0 && !(force && !strcmp(force, "ballot"))) {
+    if (D % 32 == 0 && ((uintptr_t)x & 15) == 0 && !knobs().enc_rows_ballot) {   // knob: "ballot" forces the element-per-lane kernel
         const size_t n_words = (size_t)R * Dw;
         const dim3 gw((unsigned)((n_words + 255) / 256));
         if (enc_zero_rest(np)) hipLaunchKernelGGL(k_encode_rows_w<true>, gw, dim3(256), 0, (hipStream_t)s, x, n_words, T, np, planes, plane_stride);
@@ -809,12 +832,12 @@ int snn_li_heads(const uint32_t* spk, size_t spk_stride, int T, int M, int K, co
     li_kappa(p, T, &kap);
     const int Kw = cdiv(K, 32), NOp = cdiv(NA + NB, 16) * 16;
     if (NOp > 256) return fail(-1, "snn_li_heads: %d outputs per row not supported", NA + NB);
-    const char* force = getenv("SNN_LI_HEADS");               // debug / A-B knob: "valu" forces the fp32 VALU kernel
+    const int force = knobs().li_heads;                       // debug / A-B knob: 1 "valu" forces the fp32 VALU kernel, 2 "mfma", 3 "ksplit"
     // matrix-core kernel where all of W (as three bf16 planes) stays resident in LDS; the streamed form is latency
     // bound on small row counts (detector heads: 164 us against 88 us for the VALU kernel) and only runs when forced
     const bool fits = (size_t)Kw * 3 * NOp * 64 <= 96 * 1024;
     // W too large for LDS: one work-group per 16 rows, the reduction split over its 4 waves ("ksplit" forces it)
-    if (NOp <= 64 && Kw >= 4 && (force ? !strcmp(force, "ksplit") : !fits)) {
+    if (NOp <= 64 && Kw >= 4 && (force ? force == 3 : !fits)) {
         LiHeadsArgs a;
         memset(&a, 0, sizeof(a));
         a.spk = spk; a.spk_stride = spk_stride; a.wT = w_heads_packed; a.out_a = out_a; a.out_b = out_b;
@@ -829,7 +852,7 @@ int snn_li_heads(const uint32_t* spk, size_t spk_stride, int T, int M, int K, co
         SNN_CHECK_LAUNCH("k_li_heads_ksplit");
         return 0;
     }
-    if (NOp <= 64 && (force ? !strcmp(force, "mfma") : fits)) {
+    if (NOp <= 64 && (force ? force == 2 : fits)) {
         LiHeadsArgs a;
         memset(&a, 0, sizeof(a));
         a.spk = spk; a.spk_stride = spk_stride; a.wT = w_heads_packed; a.out_a = out_a; a.out_b = out_b;

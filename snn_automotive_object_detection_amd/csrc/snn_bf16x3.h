@@ -190,15 +190,20 @@ __global__ __launch_bounds__(512, MODE == G3_CONV_LIF_REG ? 2 : 4) void k_gemm_b
         *reinterpret_cast<uint4*>(lut + tid * 16) = q;
     }
 
-    // ---- A staging role: thread -> row (the first BM threads).  A spike word is addressed as (wave-uniform 64-bit
-    // base in SGPRs) + (32-bit byte offset of the lane's row): no per-chunk 64-bit vector arithmetic ----
+    // ---- A staging: the spike words of a chunk (one per tile row) go straight into the ring slot by LDS-DMA
+    // (global_load_lds_dword: lane L of wave w lands at slot + 256 w + 4 L = row 64 w + L; source = wave-uniform 64-bit base in
+    // SGPRs + the lane's 32-bit byte offset; no VGPR destination, no ds_write, counted on vmcnt with the weight planes).
+    // Convolution rows read encoder planes that carry a ONE-POSITION ZERO HALO around every image (the encoder writes them
+    // that way): every tap of every position is a plain read, there is no border logic in the kernel.
+    // Round 1 fetched the words into registers (global_load_dword under a per-lane tap-validity mask) and stored them with
+    // ds_write; its stream counters lived in vector registers behind exec-mask branches: ~25 vector instructions per wave
+    // and chunk, 12-15 % of the kernel (timing build without the stream: conv+LIF 2.99 -> 2.61 ms, fc6 1.03 -> 0.87 ms).
     const bool a_role = wave * 64 < BM;
     const int xrow = tid & (G3_BM(WN, 4) - 1);
     const int xt = TILE ? xrow / args.pb : 0;       // TILE: time step of the row
     const int xm = TILE ? (xt < args.T ? m0 + xrow % args.pb : M) : m0 + xrow;
     uint32_t a_off = 0;                             // bytes: fc row / conv centre tap, channel word 0
-    int a_pitch = 0;                                // conv: bytes per image row of the lane's pyramid level
-    uint32_t a_valid = 0;                           // conv: 9-bit tap validity
+    uint32_t a_pitch = 0;                           // conv: bytes per (padded) image row of the lane's pyramid level
     if (CONV) {
         if (xm < M) {
             const int t = FUSE ? 0 : (TILE ? xt : xm / args.P_total), p = (FUSE || TILE) ? xm : xm % args.P_total;
@@ -206,64 +211,55 @@ __global__ __launch_bounds__(512, MODE == G3_CONV_LIF_REG ? 2 : 4) void k_gemm_b
             while (l + 1 < args.n_levels && p >= args.lv[l + 1].pos_base) ++l;
             const int H = args.lv[l].H, W = args.lv[l].W;
             const int local = p - args.lv[l].pos_base;
-            const int rem = local % (H * W);
+            const int n = local / (H * W), rem = local % (H * W);
             const int y = rem / W, x = rem % W;
-            a_off = (uint32_t)(((size_t)t * args.enc_stride + (size_t)p * args.Cw) * 4);
-            a_pitch = W * args.Cw * 4;
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
-                a_valid |= (uint32_t)(yy >= 0 && yy < H && xx >= 0 && xx < W) << tap;
-            }
+            const size_t prow = (size_t)args.lv[l].tile_begin + ((size_t)n * (H + 2) + y + 1) * (W + 2) + x + 1;   // padded row
+            a_off = (uint32_t)(((size_t)t * args.enc_stride + prow * args.Cw) * 4);
+            a_pitch = (uint32_t)((W + 2) * args.Cw * 4);
+        } else {                                    // unused tile rows: position (0, 0) of level 0, image 0 - its taps are in range
+            a_off = (uint32_t)((args.lv[0].W + 3) * args.Cw * 4);
+            a_pitch = (uint32_t)((args.lv[0].W + 2) * args.Cw * 4);
         }
     } else if (TILE) {                              // fc rows of the spike planes [T][M][Kc]; unused tile rows read row 0
         a_off = xm < M ? (uint32_t)(((size_t)xt * M + xm) * Kc * 4) : 0u;
     } else {
         a_off = (uint32_t)((size_t)min(xm, M - 1) * Kc * 4);
     }
-    // Spike-word loads are issued as inline asm: hipcc must not see them, or it drains the LDS-DMA queue
-    // (vmcnt(0)) at their first use while weight planes are still in flight.  A word is consumed only after the
-    // s_waitcnt vmcnt(0) that ends the chunk it was issued in.
-    // The fetch stream walks the chunk sequence (t, tap dy, tap dx, channel word) with scalar counters.
-    // (s_nop 4: an SGPR written by SALU / v_readfirstlane needs 5 wait states before a VMEM instruction reads it as
-    // its base address, and hipcc's hazard recogniser does not look into inline asm.)
-    // The stream is a running scalar pointer: within one tap row (dy) the wave-uniform word offset dx*Cw + cc just
-    // increments by one per chunk; every 3*Cw chunks the lanes step one image row down, every Kc chunks one time
-    // step on.  Past the last chunk the stream wraps to the start (staged, never multiplied).
+    // The fetch stream walks the chunk sequence (t, tap dy, tap dx, channel word) as a running scalar pointer: inside a tap
+    // row the wave-uniform word offset dx*Cw + cc just increments; every 3*Cw chunks the lanes step one image row down
+    // (one v_add), every Kc chunks one time step on.  Past the last chunk the stream wraps to the start (staged, never
+    // multiplied).  The counters are wave-uniform: __builtin_amdgcn_readfirstlane says so, or hipcc keeps them in vector
+    // registers and branches on them through the exec mask.
+    // (s_nop 4: an SGPR written by SALU / v_readfirstlane needs 5 wait states before a VMEM instruction reads it as its base
+    // address or M0, and hipcc's hazard recogniser does not look into inline asm.)
     const int n_steps = FUSE ? args.T : 1;
-    const uint32_t* f_tbase = args.A;               // scalar: A + t*enc_stride
-    int f_off = CONV ? -args.Cw : 0;                // scalar: dx*Cw + cc   (fc: kc)
-    uint32_t f_voff = CONV ? a_off - (uint32_t)a_pitch : a_off;     // lane: row offset of tap row dy
-    uint32_t f_mask = 1u;                           // conv: bit of the current tap
-    int f_t = 0, f_kc = 0, f_cc = 0, f_dx = 0;
-    auto fetch_next = [&](uint32_t& w) {
-        w = 0u;
-        const void* sbase = sgpr_ptr(f_tbase + f_off);
-        if (CONV) {
-            if (a_role && (a_valid & f_mask))
-                asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "+v"(w) : "v"(f_voff), "s"(sbase) : "memory");
-        } else {
-            if (a_role) asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "+v"(w) : "v"(f_voff), "s"(sbase) : "memory");
-        }
-        ++f_off;
-        if (CONV && ++f_cc == args.Cw) {
-            f_cc = 0;
-            f_mask <<= 1;
-            if (++f_dx == 3) { f_dx = 0; f_off -= 3 * args.Cw; f_voff += (uint32_t)a_pitch; }
-        }
-        if (++f_kc == Kc) {
-            f_kc = 0; f_cc = 0; f_dx = 0; f_mask = 1u;
-            f_off = CONV ? -args.Cw : 0;
-            if (++f_t == n_steps) f_t = 0;
-            f_tbase = args.A + (FUSE ? (size_t)f_t * args.enc_stride : 0);
-            f_voff = CONV ? a_off - (uint32_t)a_pitch : a_off;
-        }
-    };
-    auto store_w = [&](uint32_t w, uint32_t slot_off) {     // the raw spike word of the thread's row
+    const int row_chunks = __builtin_amdgcn_readfirstlane(3 * args.Cw);
+    const uint32_t* f_ptr = static_cast<const uint32_t*>(sgpr_ptr(args.A + (CONV ? -args.Cw : 0)));
+    uint32_t f_voff = CONV ? a_off - a_pitch : a_off;               // lane: row offset of tap row dy
+    int f_t = 0, f_kc = 0, f_j = 0;
+    const uint32_t a_dst = smem_base + G3_LUT_BYTES + wave * 256;   // + slot offset
+    auto stage_a = [&](uint32_t slot_off) {
+#ifndef SNN_EXP_NO_FETCH                            // (timing only: no spike-word stream at all)
         if (a_role) {
-            uint32_t l;                             // lane id, re-derived (2 VALU) instead of a register held all loop
-            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
-            *reinterpret_cast<uint32_t*>(ring + slot_off + wave * 256 + l * 4) = w;
+            const uint32_t d = __builtin_amdgcn_readfirstlane(a_dst + slot_off);
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dword %0, %1" :: "v"(f_voff), "s"(f_ptr), "s"(d) : "memory", "m0");
+        }
+#endif
+        f_ptr = static_cast<const uint32_t*>(sgpr_ptr(f_ptr + 1));
+        if (CONV) {
+            f_j = __builtin_amdgcn_readfirstlane(f_j + 1);
+            if (f_j == row_chunks) {                // next tap row
+                f_j = 0;
+                f_ptr = static_cast<const uint32_t*>(sgpr_ptr(f_ptr - row_chunks));
+                f_voff += a_pitch;
+            }
+        }
+        f_kc = __builtin_amdgcn_readfirstlane(f_kc + 1);
+        if (f_kc == Kc) {
+            f_kc = 0; f_j = 0;
+            if (FUSE) { f_t = __builtin_amdgcn_readfirstlane(f_t + 1); if (f_t == n_steps) f_t = 0; }
+            f_ptr = static_cast<const uint32_t*>(sgpr_ptr(args.A + (FUSE ? (size_t)f_t * args.enc_stride : 0) + (CONV ? -args.Cw : 0)));
+            f_voff = CONV ? a_off - a_pitch : a_off;
         }
     };
 
@@ -351,25 +347,20 @@ __global__ __launch_bounds__(512, MODE == G3_CONV_LIF_REG ? 2 : 4) void k_gemm_b
     }
     __syncthreads();
 #endif
-    uint32_t w_hold, w_new;
     {
-        uint32_t w0[2];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) fetch_next(w0[j]);  // spike words of chunks 0, 1 -> slots 0, 1
-        fetch_next(w_hold);                             // chunk 2
-#pragma unroll
-        for (int j = 0; j < NB - 1; ++j) stage_next(j * SLOT);      // weight planes of chunks 0 .. NB-2
+        for (int j = 0; j < NB - 1; ++j) { stage_a(j * SLOT); stage_next(j * SLOT); }      // chunks 0 .. NB-2
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            asm volatile("" : "+v"(w0[j]));             // the loaded value is only defined from here on
-            store_w(w0[j], j * SLOT);
-        }
-        asm volatile("" : "+v"(w_hold));
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the table
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     }
+#ifdef SNN_EXP_CLOCK       // diagnostic build: in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz around the main loop
+    unsigned long long clk_c0 = 0, clk_r0 = 0;
+    if (TILE && tid == 0) {
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(clk_c0), "=s"(clk_r0) :: "memory");
+    }
+#endif
     bf16x8 af[2][MT], bq[RING];
     uint32_t wq[MT];
 #pragma unroll
@@ -379,7 +370,7 @@ __global__ __launch_bounds__(512, MODE == G3_CONV_LIF_REG ? 2 : 4) void k_gemm_b
 #pragma unroll
     for (int g = 0; g < PD; ++g) bq[g] = rd_b(0, g);
 
-    // ring slots (byte offsets) of chunks c, c+1, c+2 (receives its spike words now) and c+NB-1 (receives its planes)
+    // ring slots (byte offsets) of chunks c, c+1, (NB = 4: c+2) and c+NB-1 (receives its spike words and weight planes now)
     uint32_t o_cur = 0, o_nxt = SLOT, o_nn = 2 * SLOT, o_wr = (NB - 1) * SLOT;
     int kc = 0, t = 0;
     for (int c0 = 0; c0 < n_total; c0 += 2) {
@@ -395,11 +386,8 @@ __global__ __launch_bounds__(512, MODE == G3_CONV_LIF_REG ? 2 : 4) void k_gemm_b
                     for (int mt = 0; mt < MT; ++mt) wq[mt] = rd_w(o_nxt, mt);
                 }
                 if (g >= 8 && g - 8 < MT) af[u ^ 1][g - 8] = rd_a(wq[g - 8]);
-#ifndef SNN_EXP_NO_STORE_A
-                if (g == 0) store_w(w_hold, o_nn);
-#endif
                 if (g == 2) {
-                    fetch_next(w_new);
+                    stage_a(o_wr);
 #ifndef SNN_EXP_NO_GLDS
                     stage_next(o_wr);
 #endif
@@ -415,17 +403,15 @@ __global__ __launch_bounds__(512, MODE == G3_CONV_LIF_REG ? 2 : 4) void k_gemm_b
             // fragments have arrived; the empty asm statements are compiler fences (neither builtin orders memory
             // accesses for hipcc, which otherwise moves LDS reads across the barrier).
             asm volatile("" ::: "memory");
-            // NB = 4: this chunk's own copies (the youngest vector-memory operations of the wave: 3, or 2 / 1 on the
-            // 8 x 1 wave grid) may stay in flight across the barrier
+            // NB = 4: this chunk's own copies (the youngest vector-memory operations of the wave: its spike-word copy if it
+            // has rows to stage + 3 weight pieces, or 2 / 1 on the 8 x 1 wave grid) may stay in flight across the barrier
             if (NB == 3) __builtin_amdgcn_s_waitcnt(0x0070);        // vmcnt(0) lgkmcnt(0)
-            else if (WN == 2) __builtin_amdgcn_s_waitcnt(0x0073);   // vmcnt(3) lgkmcnt(0)
-            else if (wave + 8 < NPIECE) __builtin_amdgcn_s_waitcnt(0x0072);   // vmcnt(2)
-            else __builtin_amdgcn_s_waitcnt(0x0071);                // vmcnt(1)
+            else if (WN == 2) { if (a_role) __builtin_amdgcn_s_waitcnt(0x0074); else __builtin_amdgcn_s_waitcnt(0x0073); }
+            else if (wave + 8 < NPIECE) { if (a_role) __builtin_amdgcn_s_waitcnt(0x0073); else __builtin_amdgcn_s_waitcnt(0x0072); }
+            else { if (a_role) __builtin_amdgcn_s_waitcnt(0x0072); else __builtin_amdgcn_s_waitcnt(0x0071); }
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
 #endif
-            asm volatile("" : "+v"(w_new));
-            w_hold = w_new;
             if (NB == 3) { const uint32_t o = o_cur; o_cur = o_nxt; o_nxt = o_nn; o_nn = o; o_wr = o; }
             else { const uint32_t o = o_cur; o_cur = o_nxt; o_nxt = o_nn; o_nn = o_wr; o_wr = o; }
             const bool step_done = ++kc == Kc;
@@ -481,6 +467,14 @@ __global__ __launch_bounds__(512, MODE == G3_CONV_LIF_REG ? 2 : 4) void k_gemm_b
         }
     }
     if (FUSE) return;
+#ifdef SNN_EXP_CLOCK
+    if (TILE && tid == 0) {
+        unsigned long long c1, r1;
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c1), "=s"(r1) :: "memory");
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(args.spk + (size_t)args.T * args.spk_stride) + (size_t)blockIdx.x * 2;
+        o[0] = c1 - clk_c0; o[1] = r1 - clk_r0;
+    }
+#endif
     if (TILE) {
         // ---- LIF over the T time steps held in this tile.  The accumulators are the complete input currents
         // cur[t][position][column] of pb positions; in two passes of CG = 32*WN columns they go through LDS (the ring

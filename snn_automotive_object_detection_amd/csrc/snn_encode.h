@@ -75,6 +75,30 @@ __global__ __launch_bounds__(256) void k_encode_levels(const EncLevels lv, int C
                      local / lv.bpi[l], local % lv.bpi[l], blockIdx.y, lv.Wpad[l]);
 }
 
+// zero halo of the padded planes: only the border rows / columns of every image are written (a few hundred KB), not the
+// whole 50-MB plane set.  blockIdx.x = (level, image), blockIdx.y splits its halo words.
+struct HaloLevels {
+    int pos_base[SNN_MAX_LEVELS], H[SNN_MAX_LEVELS], W[SNN_MAX_LEVELS];
+    int blk_base[SNN_MAX_LEVELS + 1];               // first block (= image) of the level
+    int n_levels;
+};
+__global__ __launch_bounds__(256) void k_zero_halo(const HaloLevels lv, int Cw, int T, uint32_t* __restrict__ planes,
+                                                   size_t plane_stride) {
+    int l = 0;
+    while (l + 1 < lv.n_levels && (int)blockIdx.x >= lv.blk_base[l + 1]) ++l;
+    const int n = blockIdx.x - lv.blk_base[l], H = lv.H[l], W = lv.W[l];
+    const int hp = 2 * (W + 2) + 2 * H;             // halo positions of one image
+    for (int idx = blockIdx.y * 256 + threadIdx.x; idx < T * hp * Cw; idx += 256 * gridDim.y) {
+        const int w = idx % Cw, h = (idx / Cw) % hp, t = idx / (Cw * hp);
+        int y, x;
+        if (h < W + 2) { y = 0; x = h; }
+        else if (h < 2 * (W + 2)) { y = H + 1; x = h - (W + 2); }
+        else { const int r = h - 2 * (W + 2); y = 1 + (r >> 1); x = (r & 1) ? W + 1 : 0; }
+        const size_t row = (size_t)lv.pos_base[l] + ((size_t)n * (H + 2) + y) * (W + 2) + x;
+        planes[(size_t)t * plane_stride + row * Cw + w] = 0u;
+    }
+}
+
 // K1b: encoder on row-major x[R][D] -> bit-planes [T][R][Dw]; a wave covers 64 consecutive reduction indices per
 // slot, so one ballot per step IS two plane words.  Each thread runs ENC_U independent elements (64 apart) to keep
 // several loads and scan chains in flight.

@@ -567,15 +567,19 @@ static int conv3_common(const char* who, const uint32_t* enc, size_t enc_stride,
         return fail(-1, "%s: bad argument", who);
     if (check_T(T, who)) return -1;
     memset(&a, 0, sizeof(a));
-    long long P = 0;
+    long long P = 0, Pp = 0;
     for (int l = 0; l < n_levels; ++l) {
         if (lv[l].N <= 0 || lv[l].H <= 0 || lv[l].W <= 0) return fail(-1, "%s: bad level %d", who, l);
         a.lv[l].pos_base = (int)P; a.lv[l].N = lv[l].N; a.lv[l].H = lv[l].H; a.lv[l].W = lv[l].W;
+        a.lv[l].tile_begin = (int)Pp;                  // first row of the level in the padded (zero-halo) encoder planes
         P += (long long)lv[l].N * lv[l].H * lv[l].W;
+        Pp += (long long)lv[l].N * (lv[l].H + 2) * (lv[l].W + 2);
     }
     if ((long long)T * P > 0x7fffffffLL) return fail(-1, "%s: T*P too large", who);
+    if (enc_stride < (size_t)Pp * cdiv(C_in, 32))
+        return fail(-1, "%s: enc_stride %zu < %lld words (planes with a one-position zero halo)", who, enc_stride, Pp * cdiv(C_in, 32));
     // the kernels address a spike word as 64-bit scalar base + 32-bit lane byte offset
-    if (((long long)(T - 1) * (long long)enc_stride + P * cdiv(C_in, 32)) * 4 > 0xffffffffLL)
+    if (((long long)(T - 1) * (long long)enc_stride + Pp * cdiv(C_in, 32)) * 4 > 0xffffffffLL)
         return fail(-1, "%s: encoder planes over 4 GB", who);
     a.A = enc; a.wpk = w_packed; a.enc_stride = enc_stride;
     a.Cw = cdiv(C_in, 32); a.Kc = 9 * a.Cw; a.Np = cdiv(C_out, 32) * 32;
@@ -637,25 +641,12 @@ static int count_spikes_per_image(const snn_rpn_level* lv, int n_levels, int Cw,
 
 int snn_spike_conv3x3_bf16x3(const uint32_t* enc, size_t enc_stride, const snn_rpn_level* lv, int n_levels, int C_in,
                              int C_out, int T, const uint16_t* w_packed, float* cur, int ldo, snn_stream_t s) {
-    if (!enc || !lv || !w_packed || !cur || n_levels <= 0 || n_levels > SNN_MAX_LEVELS || C_in <= 0 || C_out <= 0 ||
-        ldo < C_out)
-        return fail(-1, "snn_spike_conv3x3_bf16x3: bad argument");
-    if (check_T(T, "snn_spike_conv3x3_bf16x3")) return -1;
+    if (!cur || ldo < C_out) return fail(-1, "snn_spike_conv3x3_bf16x3: bad argument");
     Gemm3Args a;
-    memset(&a, 0, sizeof(a));
-    long long P = 0;
-    for (int l = 0; l < n_levels; ++l) {
-        if (lv[l].N <= 0 || lv[l].H <= 0 || lv[l].W <= 0) return fail(-1, "snn_spike_conv3x3_bf16x3: bad level %d", l);
-        a.lv[l].pos_base = (int)P; a.lv[l].N = lv[l].N; a.lv[l].H = lv[l].H; a.lv[l].W = lv[l].W;
-        P += (long long)lv[l].N * lv[l].H * lv[l].W;
-    }
-    if ((long long)T * P > 0x7fffffffLL) return fail(-1, "snn_spike_conv3x3_bf16x3: T*P too large");
-    if (((long long)(T - 1) * (long long)enc_stride + P * cdiv(C_in, 32)) * 4 > 0xffffffffLL)
-        return fail(-1, "snn_spike_conv3x3_bf16x3: encoder planes over 4 GB");
-    a.A = enc; a.wpk = w_packed; a.out = cur; a.enc_stride = enc_stride;
-    a.Cw = cdiv(C_in, 32); a.Kc = 9 * a.Cw; a.Np = cdiv(C_out, 32) * 32; a.ldo = ldo;
-    a.plane_elems = (unsigned long long)a.Kc * a.Np * 32;
-    a.P_total = (int)P; a.n_levels = n_levels; a.M = (int)(T * P);
+    long long P;
+    int rc = conv3_common("snn_spike_conv3x3_bf16x3", enc, enc_stride, lv, n_levels, C_in, C_out, T, w_packed, a, &P);
+    if (rc) return rc;
+    a.out = cur; a.ldo = ldo; a.M = (int)(T * P);
     const int wn = g3_wn();
     a.n_blocks = cdiv(a.Np, G3_BN(wn));
     const int mt = g3_pick_mt([&](int m) { return (long long)cdiv(a.M, G3_BM(wn, m)) * a.n_blocks; });
@@ -931,7 +922,7 @@ size_t snn_rpn_head_workspace_bytes(const snn_rpn_level* lv, int n_levels, int C
     (void)A;
     if (!lv || n_levels <= 0 || n_levels > SNN_MAX_LEVELS || C <= 0 || T < 1) return 0;
     size_t a, b, c, tot;
-    rpn_ws_layout(rpn_positions(lv, n_levels, nullptr), precision == SNN_PRECISION_MXFP6 ? rpn_positions_padded(lv, n_levels) : 0,
+    rpn_ws_layout(rpn_positions(lv, n_levels, nullptr), precision != SNN_PRECISION_F32 ? rpn_positions_padded(lv, n_levels) : 0,
                   C, T, precision, &a, &b, &c, &tot);
     return tot;
 }
@@ -955,7 +946,7 @@ int snn_rpn_head_forward_stages(const snn_rpn_level* lv, int n_levels, int C, in
     int max_n = 0;
     const long long P = rpn_positions(lv, n_levels, &max_n);
     size_t o_spk, o_cur, o_cnt, need;
-    const bool mxp = p->precision == SNN_PRECISION_MXFP6;          // encoder planes with a zero halo (k_gemm_mx)
+    const bool mxp = p->precision != SNN_PRECISION_F32;            // encoder planes with a zero halo (k_gemm_bf16x3, k_gemm_mx)
     const long long Pe = mxp ? rpn_positions_padded(lv, n_levels) : P;
     rpn_ws_layout(P, mxp ? Pe : 0, C, T, p->precision, &o_spk, &o_cur, &o_cnt, &need);
     if (ws_bytes < need) return fail(-2, "snn_rpn_head_forward: workspace %zu < %zu bytes", ws_bytes, need);
@@ -970,7 +961,6 @@ int snn_rpn_head_forward_stages(const snn_rpn_level* lv, int n_levels, int C, in
         memset(&el, 0, sizeof(el));
         long long pos = 0;
         int blocks = 0;
-        if (mxp && hipMemsetAsync(enc, 0, (size_t)T * enc_stride * 4, s) != hipSuccess) return fail(-3, "hipMemsetAsync failed");
         for (int l = 0; l < n_levels; ++l) {
             if (!lv[l].feat) return fail(-1, "snn_rpn_head_forward: level %d has no features", l);
             el.feat[l] = lv[l].feat; el.HW[l] = lv[l].H * lv[l].W; el.bpi[l] = cdiv(el.HW[l], ENC_PB);
@@ -979,6 +969,18 @@ int snn_rpn_head_forward_stages(const snn_rpn_level* lv, int n_levels, int C, in
             pos += mxp ? (long long)lv[l].N * (lv[l].H + 2) * (lv[l].W + 2) : (long long)lv[l].N * el.HW[l];
         }
         el.blk_base[n_levels] = blocks; el.n_levels = n_levels;
+        if (mxp) {                                  // the one-position zero halo around every image (the interior is the encoder's)
+            HaloLevels hl;
+            memset(&hl, 0, sizeof(hl));
+            int images = 0;
+            for (int l = 0; l < n_levels; ++l) {
+                hl.pos_base[l] = el.pos_base[l]; hl.H[l] = lv[l].H; hl.W[l] = lv[l].W; hl.blk_base[l] = images;
+                images += lv[l].N;
+            }
+            hl.blk_base[n_levels] = images; hl.n_levels = n_levels;
+            hipLaunchKernelGGL(k_zero_halo, dim3(images, 32), dim3(256), 0, s, hl, Cw, T, enc, enc_stride);
+            SNN_CHECK_LAUNCH("k_zero_halo");
+        }
         const NeuronP np = make_p(p, p->v_th_enc);
         if (enc_zero_rest(np))
             hipLaunchKernelGGL(k_encode_levels<true>, dim3(blocks, cdiv(Cw, 8)), dim3(256), 0, s, el, C, Cw, T, np, enc, enc_stride);
@@ -1005,7 +1007,7 @@ int snn_rpn_head_forward_stages(const snn_rpn_level* lv, int n_levels, int C, in
             int rc = p->precision == SNN_PRECISION_MXFP6
                          ? conv3x3_lif_mx_impl(enc, enc_stride, lv, n_levels, C, C, T, p, (const uint32_t*)w_shared_packed, spk, stride,
                                                spike_counts, max_n, stream)
-                         : conv3x3_lif_bf16x3_impl(enc, stride, lv, n_levels, C, C, T, p, (const uint16_t*)w_shared_packed,
+                         : conv3x3_lif_bf16x3_impl(enc, enc_stride, lv, n_levels, C, C, T, p, (const uint16_t*)w_shared_packed,
                                                    spk, stride, spike_counts, max_n, stream);
             if (rc) return rc;
         }

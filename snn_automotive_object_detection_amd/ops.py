@@ -229,30 +229,52 @@ def spike_conv3x3_mx(enc: torch.Tensor, shapes, C_in: int, C_out: int, w_packed:
     return cur
 
 
+def pad_planes(planes: torch.Tensor, shapes) -> torch.Tensor:
+    """[T, P, Cw] spike words over levels `shapes` = [(N,H,W), ...] -> [T, Pp, Cw] with a one-position zero halo around every
+    image (Pp = sum N (H+2) (W+2)): the input format of the 3x3 convolution kernels (the head's own encoder writes it directly)"""
+    T, _, Cw = planes.shape
+    out, pos = [], 0
+    for n, h, w in shapes:
+        blk = planes[:, pos:pos + n * h * w].reshape(T, n, h, w, Cw)
+        out.append(torch.nn.functional.pad(blk, (0, 0, 1, 1, 1, 1)).reshape(T, n * (h + 2) * (w + 2), Cw))
+        pos += n * h * w
+    return torch.cat(out, dim=1).contiguous()
+
+
+def _conv_planes(enc: torch.Tensor, shapes):
+    """the conv kernels read zero-halo planes; un-padded planes (what encode_nchw returns) are padded here (stage-level calls only)"""
+    P = sum(n * h * w for n, h, w in shapes)
+    Pp = sum(n * (h + 2) * (w + 2) for n, h, w in shapes)
+    if enc.shape[1] == P and P != Pp:
+        enc = pad_planes(enc, shapes)
+    assert enc.shape[1] == Pp, (enc.shape, P, Pp)
+    return enc.contiguous(), P, Pp
+
+
 def conv3x3_lif_bf16x3(enc: torch.Tensor, shapes, C_in: int, C_out: int, p: snn_params, w_packed: torch.Tensor) -> torch.Tensor:
-    """enc int32 [T, P, Cw] over levels `shapes` = [(N,H,W), ...] -> shared-LIF spike planes int32 [T, P, Nw]"""
+    """enc int32 [T, P or Pp, Cw] over levels `shapes` = [(N,H,W), ...] -> shared-LIF spike planes int32 [T, P, Nw]"""
     _need_gpu(enc, "enc planes")
     lib = _lib.load()
-    T, P, Cw = enc.shape
-    assert P == sum(n * h * w for n, h, w in shapes)
+    enc, P, Pp = _conv_planes(enc, shapes)
+    T, _, Cw = enc.shape
     lv = (snn_rpn_level * len(shapes))(*[snn_rpn_level(None, n, h, w, 0) for n, h, w in shapes])
     Nw = cdiv(C_out, 32)
     spk = torch.empty((T, P, Nw), dtype=torch.int32, device=enc.device)
-    _lib.check(lib.snn_conv3x3_lif_bf16x3(_ptr(enc), P * Cw, lv, len(shapes), C_in, C_out, T, C.byref(p), _ptr(w_packed),
+    _lib.check(lib.snn_conv3x3_lif_bf16x3(_ptr(enc), Pp * Cw, lv, len(shapes), C_in, C_out, T, C.byref(p), _ptr(w_packed),
                                           _ptr(spk), P * Nw, _stream()), "snn_conv3x3_lif_bf16x3")
     return spk
 
 
 def spike_conv3x3_bf16x3(enc: torch.Tensor, shapes, C_in: int, C_out: int, w_packed: torch.Tensor) -> torch.Tensor:
-    """enc int32 [T, P, Cw] over levels `shapes` = [(N,H,W), ...] -> cur fp32 [T, P, Np]"""
+    """enc int32 [T, P or Pp, Cw] over levels `shapes` = [(N,H,W), ...] -> cur fp32 [T, P, Np]"""
     _need_gpu(enc, "enc planes")
     lib = _lib.load()
-    T, P, Cw = enc.shape
-    assert P == sum(n * h * w for n, h, w in shapes)
+    enc, P, Pp = _conv_planes(enc, shapes)
+    T, _, Cw = enc.shape
     lv = (snn_rpn_level * len(shapes))(*[snn_rpn_level(None, n, h, w, 0) for n, h, w in shapes])
     Np = cdiv(C_out, 32) * 32
     cur = torch.empty((T, P, Np), dtype=torch.float32, device=enc.device)
-    _lib.check(lib.snn_spike_conv3x3_bf16x3(_ptr(enc), P * Cw, lv, len(shapes), C_in, C_out, T, _ptr(w_packed), _ptr(cur),
+    _lib.check(lib.snn_spike_conv3x3_bf16x3(_ptr(enc), Pp * Cw, lv, len(shapes), C_in, C_out, T, _ptr(w_packed), _ptr(cur),
                                             Np, _stream()), "snn_spike_conv3x3_bf16x3")
     return cur
 

@@ -37,7 +37,8 @@ def test_size_queries_and_argument_validation_without_gpu():
     lv = (_lib.snn_rpn_level * 1)(_lib.snn_rpn_level(None, 2, 192, 384, 0))
     # 2 plane sets x T x P x Cw x 4 bytes
     assert lib.snn_rpn_head_workspace_bytes(lv, 1, 256, 3, 8, 0) == 2 * 8 * (2 * 192 * 384) * 8 * 4
-    assert lib.snn_rpn_head_workspace_bytes(lv, 1, 256, 3, 8, 1) == 2 * 8 * (2 * 192 * 384) * 8 * 4
+    # (bf16x3 / mxfp6: the encoder planes carry a one-position zero halo around every image)
+    assert lib.snn_rpn_head_workspace_bytes(lv, 1, 256, 3, 8, 1) == 2 * 8 * (2 * 194 * 386) * 8 * 4
     assert lib.snn_det_head_workspace_bytes(2000, 12544, 1024, 9, 36, 12, 1) > 0
     # null / bad arguments are rejected before any device work, with a message
     p = _lib.snn_params(0.1, -0.2, 0, 0, 0.25, 0.1, 0, 0)

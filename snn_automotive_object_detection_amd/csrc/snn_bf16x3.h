@@ -306,8 +306,10 @@ __global__ __launch_bounds__(512, MODE == G3_CONV_LIF_REG ? 2 : 4) void k_gemm_b
     // A fragment: row (wm*64 + mt*16 + lr), k = 8*lg .. 8*lg+7  ->  table[byte lg of the row's spike word]
     const unsigned char* const w_rd = ring + (wm * WROWS + lr) * 4;                          // + slot offset, mt*64
     const int lg8 = 8 * lg;
-    auto rd_w = [&](uint32_t slot_off, int mt) { return *reinterpret_cast<const uint32_t*>(w_rd + slot_off + mt * 64); };
-    auto rd_a = [&](uint32_t w) { return *reinterpret_cast<const bf16x8*>(lut + (__builtin_amdgcn_ubfe(w, lg8, 8) << 4)); };
+    // the lane's byte of the row word is read as a byte (ds_read_u8; the four k-groups of a row hit one dword: no conflict):
+    // fragment address = byte << 4, one shift instead of bfe + shift
+    auto rd_w = [&](uint32_t slot_off, int mt) { return (uint32_t)*reinterpret_cast<const uint8_t*>(w_rd + lg + slot_off + mt * 64); };
+    auto rd_a = [&](uint32_t w) { return *reinterpret_cast<const bf16x8*>(lut + (w << 4)); };
     // B fragment: row (tile*16 + lr), logical unit lg; swz depends on lr only
     const unsigned char* const b_rd = ring + AW_BYTES + (wn * 64 + lr) * G3_ROWB + ((lg ^ G3_SWZ(lr)) << 4);
     // group g of a chunk = (N-tile g/3, plane 2 - g%3): per accumulator the small terms first (lo, mid, hi)
@@ -370,13 +372,17 @@ __global__ __launch_bounds__(512, MODE == G3_CONV_LIF_REG ? 2 : 4) void k_gemm_b
 #pragma unroll
     for (int g = 0; g < PD; ++g) bq[g] = rd_b(0, g);
 
-    // ring slots (byte offsets) of chunks c, c+1, (NB = 4: c+2) and c+NB-1 (receives its spike words and weight planes now)
-    uint32_t o_cur = 0, o_nxt = SLOT, o_nn = 2 * SLOT, o_wr = (NB - 1) * SLOT;
+    // The loop body is unrolled over one full period of the ring (NB slots) and of the fragment double buffer (2): every
+    // LDS address in it is a base register + an immediate, no ring bookkeeping is left at run time.
+    // Slots (byte offsets) of chunk c, of c+1, and of c+NB-1 (which receives its spike words and weight planes now).
+    constexpr int UNR = (NB % 2) ? 2 * NB : NB;
     int kc = 0, t = 0;
-    for (int c0 = 0; c0 < n_total; c0 += 2) {
+    for (int c0 = 0; c0 < n_total; c0 += UNR) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < UNR; ++u) {
             if (c0 + u >= n_total) break;
+            const uint32_t o_cur = (uint32_t)((u % NB) * SLOT), o_nxt = (uint32_t)(((u + 1) % NB) * SLOT),
+                           o_wr = (uint32_t)(((u + NB - 1) % NB) * SLOT);
 #pragma unroll
             for (int g = 0; g < 12; ++g) {
                 const int gp = g + PD;
@@ -385,7 +391,7 @@ __global__ __launch_bounds__(512, MODE == G3_CONV_LIF_REG ? 2 : 4) void k_gemm_b
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) wq[mt] = rd_w(o_nxt, mt);
                 }
-                if (g >= 8 && g - 8 < MT) af[u ^ 1][g - 8] = rd_a(wq[g - 8]);
+                if (g >= 8 && g - 8 < MT) af[(u & 1) ^ 1][g - 8] = rd_a(wq[g - 8]);
                 if (g == 2) {
                     stage_a(o_wr);
 #ifndef SNN_EXP_NO_GLDS
@@ -394,7 +400,7 @@ __global__ __launch_bounds__(512, MODE == G3_CONV_LIF_REG ? 2 : 4) void k_gemm_b
                 }
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
-                    acc[mt][g / 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u][mt], bq[g % RING], acc[mt][g / 3], 0, 0, 0);
+                    acc[mt][g / 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u & 1][mt], bq[g % RING], acc[mt][g / 3], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
 #ifndef SNN_EXP_NO_BARRIER
@@ -412,8 +418,6 @@ __global__ __launch_bounds__(512, MODE == G3_CONV_LIF_REG ? 2 : 4) void k_gemm_b
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
 #endif
-            if (NB == 3) { const uint32_t o = o_cur; o_cur = o_nxt; o_nxt = o_nn; o_nn = o; o_wr = o; }
-            else { const uint32_t o = o_cur; o_cur = o_nxt; o_nxt = o_nn; o_nn = o_wr; o_wr = o; }
             const bool step_done = ++kc == Kc;
             if (step_done) kc = 0;
             if (FUSE && step_done) {

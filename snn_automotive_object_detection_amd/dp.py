@@ -20,7 +20,8 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import torch
 import torch.distributed as dist
 
-DEFAULT_TIMEOUT_S = 120.0           # collective time-out (SNN_DIST_TIMEOUT_S overrides)
+DEFAULT_TIMEOUT_S = 300.0           # collective time-out (SNN_DIST_TIMEOUT_S overrides): ranks of a fresh node differ by the
+                                    # seconds MIOpen / hipcc first-use work takes, never by minutes
 
 
 def dist_timeout_s() -> float:

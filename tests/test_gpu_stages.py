@@ -359,3 +359,75 @@ def test_conv3x3_lif_bf16x3_odd_shapes_equal_unfused_pair(S, gpu_device, C_in, C
         got = cur[:, pos:pos + n * h * wd, :C_out].double().cpu()
         assert (got - exp).abs().max() <= 1e-5
         pos += n * h * wd
+
+
+def _popcount_rows(planes: torch.Tensor) -> torch.Tensor:
+    """int32 [T, M, W] -> int64 [M]: set bits per row over all planes and words"""
+    lut = torch.tensor([bin(i).count("1") for i in range(256)], dtype=torch.int64, device=planes.device)
+    return lut[planes.contiguous().view(torch.uint8).to(torch.int64)].view(planes.shape[0], planes.shape[1], -1).sum(dim=(0, 2))
+
+
+@pytest.mark.parametrize("precision,C", [("bf16x3", 96), ("mxfp6", 128), ("f32", 96)])
+def test_fused_spike_counts_equal_popcount_of_the_planes(gpu_device, monkeypatch, precision, C):
+    """the spike counts that the LIF epilogues add up with ballot / popcount / integer atomics (round 2) against a popcount
+    of the spike planes the same kernels write, per (level, image) and per RoI, over the tile shapes and wave grids - incl.
+    levels of 1 and 6 positions per image, where one tile spans many (level, image) slots"""
+    import snn_automotive_object_detection_amd as pkg
+    from snn_automotive_object_detection_amd import ops
+    g = torch.Generator().manual_seed(31)
+    T = 8
+    shapes = [(3, 9, 14), (3, 2, 3), (3, 1, 1), (3, 5, 7)]
+    feats = [(torch.randn((n, C, h, w), generator=g) * 2).to(gpu_device) for n, h, w in shapes]
+    m = pkg.RPNHeadSNN(C, 3, T).to(gpu_device)
+    with torch.no_grad():
+        m.shared_conv.weight.mul_(6.0)                         # make the shared LIF fire
+    m.precision = precision
+    m.spike_rates = True
+    p = m._params()
+    variants = [("2", "4")] if precision != "bf16x3" else [("2", "4"), ("2", "3"), ("2", "2"), ("1", "4"), ("1", "2")]
+    for wn, mt in variants:
+        monkeypatch.setenv("SNN_BF16X3_WN", wn)
+        monkeypatch.setenv("SNN_BF16X3_MT", mt)
+        m(feats)
+        counts = m.last_spike_counts.cpu()
+        # the same planes through the stage ops, counted on the side
+        encs = torch.cat([ops.encode_nchw(f, T, p) for f in feats], dim=1)
+        if precision == "f32":
+            rows = torch.cat([_popcount_rows(ops.conv3x3_lif(ops.encode_nchw(f, T, p), n, C, C, h, w, p, ops.pack_conv3x3(m.shared_conv.weight)))
+                              for f, (n, h, w) in zip(feats, shapes)])
+        elif precision == "mxfp6":
+            rows = _popcount_rows(ops.conv3x3_lif_mx(ops.pad_planes(encs, shapes), shapes, C, C, p, ops.pack_conv3x3_mx(m.shared_conv.weight)))
+        else:
+            rows = _popcount_rows(ops.conv3x3_lif_bf16x3(encs, shapes, C, C, p, ops.pack_conv3x3_bf16x3(m.shared_conv.weight)))
+        pos = 0
+        for l, (n, h, w) in enumerate(shapes):
+            per_img = rows[pos:pos + n * h * w].view(n, -1).sum(1).cpu()
+            assert torch.equal(counts[l, :n], per_img), (precision, wn, mt, l, counts[l, :n], per_img)
+            assert int(per_img.sum()) > 0 or h * w == 1
+            pos += n * h * w
+    monkeypatch.delenv("SNN_BF16X3_WN")
+    monkeypatch.delenv("SNN_BF16X3_MT")
+    # detector: per-RoI counts of lif6 / lif7
+    D = C * 49 if precision != "mxfp6" else 128 * 49
+    Hd = 128
+    d = pkg.FastRCNNPredictorSNNFull(D, Hd, 5, 12).to(gpu_device)
+    with torch.no_grad():
+        d.fc6.weight.mul_(4.0); d.fc7.weight.mul_(6.0)
+    d.precision = precision
+    d.spike_rates = True
+    x = (torch.randn((37, D // 49, 7, 7), generator=g) * 2).to(gpu_device)
+    d(x)
+    c6, c7 = [c.cpu().to(torch.int64) for c in d.last_spike_counts]
+    pd = d._params()
+    enc = ops.encode_rows(x.flatten(1), 12, pd)
+    if precision == "f32":
+        s6 = ops.lif_scan(ops.spike_gemm(enc.view(12 * 37, -1), D, Hd, ops.pack_linear(d.fc6.weight)).view(12, 37, -1), Hd, pd)
+        s7 = ops.lif_scan(ops.spike_gemm(s6.view(12 * 37, -1), Hd, Hd, ops.pack_linear(d.fc7.weight)).view(12, 37, -1), Hd, pd)
+    elif precision == "mxfp6":
+        s6 = ops.spike_gemm_lif_mx(enc, D, Hd, pd, ops.pack_linear_mx(d.fc6.weight))
+        s7 = ops.spike_gemm_lif_mx(s6, Hd, Hd, pd, ops.pack_linear_mx(d.fc7.weight))
+    else:
+        s6 = ops.spike_gemm_lif_bf16x3(enc, D, Hd, pd, ops.pack_linear_bf16x3(d.fc6.weight))
+        s7 = ops.spike_gemm_lif_bf16x3(s6, Hd, Hd, pd, ops.pack_linear_bf16x3(d.fc7.weight))
+    assert torch.equal(c6, _popcount_rows(s6).cpu()) and torch.equal(c7, _popcount_rows(s7).cpu())
+    assert int(c6.sum()) > 0 and int(c7.sum()) > 0

@@ -153,14 +153,20 @@ enum { G3_FC = 0, G3_CONV = 1, G3_CONV_LIF_REG = 2, G3_CONV_LIF_TILE = 3, G3_FC_
 
 // MT = 16-row M-tiles per wave: the work-group tile is 64*MT rows (256; 192 / 128 only where a small problem spreads
 // better over the CUs that way - per unit of work the smaller tiles are slower: fc6 1.03 / 1.07 / 1.21 ms at MT 4 / 3 / 2).
+// MT = 8 ("fat waves"): the SAME 256 x 128 tile and LDS image as MT = 4 / WN = 2, run by FOUR waves of 128 x 64 (2 x 2,
+// 256 threads, up to 256 registers): every weight fragment read from LDS feeds 8 MFMAs instead of 4 - 37 % fewer LDS read
+// bytes per MFMA, which is energy, i.e. clock, on this power-limited loop (timing build with every second weight-fragment
+// read skipped: conv+LIF -4.3 %, in-kernel clock 1.99 -> 2.05 GHz).  Two such work-groups share a CU (2 waves per SIMD).
 template <int MODE, int NB, int MT, int WN>
-__global__ __launch_bounds__(512, MODE == G3_CONV_LIF_REG ? 2 : 4) void k_gemm_bf16x3(const Gemm3Args args) {
+__global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT == 8) ? 2 : 4) void k_gemm_bf16x3(const Gemm3Args args) {
     constexpr bool CONV = MODE == G3_CONV || MODE == G3_CONV_LIF_REG || MODE == G3_CONV_LIF_TILE;
     constexpr bool FUSE = MODE == G3_CONV_LIF_REG, TILE = MODE == G3_CONV_LIF_TILE || MODE == G3_FC_LIF_TILE;
-    static_assert(MT >= 2 && MT <= 4 && (MT == 4 || !FUSE), "M-tiles per wave");
+    static_assert(((MT >= 2 && MT <= 4) || MT == 8) && (MT == 4 || !FUSE), "M-tiles per wave");
     static_assert(WN == 1 || (WN == 2 && true), "waves along N");
     static_assert(WN == 2 || !FUSE, "the register-fused variant keeps the 4 x 2 wave grid");
-    constexpr int BM = G3_BM(WN, MT), BN = G3_BN(WN), WROWS = 16 * MT;   // rows, columns per work-group; rows per wave
+    static_assert(MT != 8 || (WN == 2 && NB == 3), "fat waves: 2 x 2 wave grid on the 3-slot ring");
+    constexpr int NW = MT == 8 ? 4 : 8;                                   // waves per work-group
+    constexpr int BM = (NW / WN) * 16 * MT, BN = G3_BN(WN), WROWS = 16 * MT;   // rows, columns per work-group; rows per wave
     constexpr int AW_BYTES = G3_AW_BYTES(WN);
     static_assert(NB == 3 || NB == 4, "ring depth");
     constexpr int SLOT = G3_SLOT(WN);
@@ -271,6 +277,9 @@ __global__ __launch_bounds__(512, MODE == G3_CONV_LIF_REG ? 2 : 4) void k_gemm_b
     const int brow = (wave % RBLK) * 16 + (lane >> 2);
     const int bcol = min(nb * BN + brow, Np - 1);               // columns past Np: any valid row (never stored)
     const uint32_t b_off = (uint32_t)(bcol * 64 + (((lane & 3) ^ G3_SWZ(brow)) << 4));     // bytes within a chunk plane
+    // fat waves (4 per work-group): a wave also copies row block wave + 4 (16 rows = 1 KB further; the swizzle, a function of
+    // (row >> 2) & 3, is the same)
+    const uint32_t b_off2 = (uint32_t)(min(nb * BN + brow + 64, Np - 1) * 64 + (((lane & 3) ^ G3_SWZ(brow)) << 4));
     const unsigned long long b_chunk = (unsigned long long)Np * 64, b_plane = args.plane_elems * 2;   // bytes
     unsigned long long s_ptr = (unsigned long long)args.wpk;   // weight stream: plane 0 of the next chunk (scalar)
     int s_kc = 0;
@@ -281,6 +290,10 @@ __global__ __launch_bounds__(512, MODE == G3_CONV_LIF_REG ? 2 : 4) void k_gemm_b
             glds16x3(sgpr_ptr(reinterpret_cast<const void*>(s_ptr)), sgpr_ptr(reinterpret_cast<const void*>(s_ptr + b_plane)),
                      sgpr_ptr(reinterpret_cast<const void*>(s_ptr + 2 * b_plane)), b_off,
                      d, d + BN * G3_ROWB, d + 2 * BN * G3_ROWB);
+            if (NW == 4)
+                glds16x3(sgpr_ptr(reinterpret_cast<const void*>(s_ptr)), sgpr_ptr(reinterpret_cast<const void*>(s_ptr + b_plane)),
+                         sgpr_ptr(reinterpret_cast<const void*>(s_ptr + 2 * b_plane)), b_off2,
+                         d + 4096, d + 4096 + BN * G3_ROWB, d + 4096 + 2 * BN * G3_ROWB);
         } else {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -342,7 +355,7 @@ __global__ __launch_bounds__(512, MODE == G3_CONV_LIF_REG ? 2 : 4) void k_gemm_b
     //   its spike words / table fragments at the end of chunk c (that slot has been complete since the last barrier).
     // One barrier per chunk; s_sched_barrier pins one fragment read + 4 MFMAs per group.
 #ifdef SNN_EXP_FILL_RING           // timing only: random bf16 bits in the whole ring (for the no-copy experiment)
-    for (int i = tid; i < NB * SLOT / 4; i += 512) {
+    for (int i = tid; i < NB * SLOT / 4; i += 64 * NW) {
         uint32_t h = (uint32_t)i * 2654435761u + blockIdx.x * 40503u;
         h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
         reinterpret_cast<uint32_t*>(ring)[i] = (h & 0x3fff3fffu) | 0x38003800u;      // two bf16 of magnitude ~1e-5 .. 1
@@ -386,12 +399,16 @@ __global__ __launch_bounds__(512, MODE == G3_CONV_LIF_REG ? 2 : 4) void k_gemm_b
 #pragma unroll
             for (int g = 0; g < 12; ++g) {
                 const int gp = g + PD;
+#ifdef SNN_EXP_HALF_BREADS                             // timing only: every second weight-fragment read skipped (wrong results)
+                if ((gp & 1) == 0)
+#endif
                 bq[gp % RING] = gp < 12 ? rd_b(o_cur, gp) : rd_b(o_nxt, gp - 12);
-                if (g == 4) {
+                constexpr int AG0 = MT == 8 ? 4 : 8, WG0 = MT == 8 ? 0 : 4;      // groups that read the next chunk's A side
+                if (g == WG0) {
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) wq[mt] = rd_w(o_nxt, mt);
                 }
-                if (g >= 8 && g - 8 < MT) af[(u & 1) ^ 1][g - 8] = rd_a(wq[g - 8]);
+                if (g >= AG0 && g - AG0 < MT) af[(u & 1) ^ 1][g - AG0] = rd_a(wq[g - AG0]);
                 if (g == 2) {
                     stage_a(o_wr);
 #ifndef SNN_EXP_NO_GLDS
@@ -400,7 +417,11 @@ __global__ __launch_bounds__(512, MODE == G3_CONV_LIF_REG ? 2 : 4) void k_gemm_b
                 }
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
+#ifdef SNN_EXP_HALF_BREADS
+                    acc[mt][g / 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u & 1][mt], bq[(g & ~1) % RING], acc[mt][g / 3], 0, 0, 0);
+#else
                     acc[mt][g / 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u & 1][mt], bq[g % RING], acc[mt][g / 3], 0, 0, 0);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
             }
 #ifndef SNN_EXP_NO_BARRIER
@@ -514,7 +535,7 @@ __global__ __launch_bounds__(512, MODE == G3_CONV_LIF_REG ? 2 : 4) void k_gemm_b
             if (word0 * 32 >= Np) continue;                // block-uniform
             if (WN == 2) {
                 const bool two = (word0 + 1) * 32 < Np;
-                for (int pi = wave; pi < pb; pi += 8) {    // wave-uniform
+                for (int pi = wave; pi < pb; pi += NW) {   // wave-uniform
                     const int pos = m0 + pi;
                     if (pos >= M) break;
                     float vv = args.p.v_leak, ii = 0.0f;

@@ -161,7 +161,8 @@ template <typename F>
 static int g3_pick_mt(F tiles_of) {
     int best = 0;
     double best_cost = 0;
-    const int force = knobs().bf16x3_mt;                      // debug / A-B knob: 2, 3 or 4
+    const int force = knobs().bf16x3_mt;                      // debug / A-B knob: 2, 3, 4 or 8 (8: fat waves, 4 x 2 grid only)
+    if (force == 8 && knobs().bf16x3_wn == 2 && tiles_of(8) > 0) return 8;
     for (int mt = 4; mt >= 2; --mt) {
         const long long wgs = tiles_of(mt);
         if (wgs <= 0) continue;
@@ -181,10 +182,14 @@ static int g3_pick_mt(F tiles_of) {
 // the chip clocks up, not because the copies cost time.  SNN_BF16X3_WN=1|2 is an A-B / test knob.
 static int g3_wn() { return knobs().bf16x3_wn; }
 
+// rows of the work-group tile (MT = 8 is the 256 x 128 tile of MT = 4 / WN = 2 run by four fat waves)
+static int g3_bm(int wn, int mt) { return mt == 8 ? 256 : G3_BM(wn, mt); }
+
 template <int MODE>
 static const void* g3_kernel(int mt, int wn) {
     if (wn == 2)
-        return mt == 4 ? (const void*)k_gemm_bf16x3<MODE, 3, 4, 2> : mt == 3 ? (const void*)k_gemm_bf16x3<MODE, 3, 3, 2>
+        return mt == 8 ? (const void*)k_gemm_bf16x3<MODE, 3, 8, 2>
+             : mt == 4 ? (const void*)k_gemm_bf16x3<MODE, 3, 4, 2> : mt == 3 ? (const void*)k_gemm_bf16x3<MODE, 3, 3, 2>
                                                                               : (const void*)k_gemm_bf16x3<MODE, 3, 2, 2>;
     return mt == 4 ? (const void*)k_gemm_bf16x3<MODE, G3_NB1, 4, 1> : mt == 3 ? (const void*)k_gemm_bf16x3<MODE, G3_NB1, 3, 1>
                                                                                 : (const void*)k_gemm_bf16x3<MODE, G3_NB1, 2, 1>;
@@ -373,7 +378,8 @@ static bool g3_tile_ok(int T, int rows) { return T >= 1 && T <= 64 && T <= rows 
 static int launch_gemm3(int mode, int mt, int wn, const Gemm3Args& a, hipStream_t s) {
     // LIF_REG owns its CU (256 registers per wave); the others run two work-groups per CU
     const void* kern;
-    int lds = G3_LDS(wn == 1 ? G3_NB1 : 3, wn), tiles = cdiv(a.M, G3_BM(wn, mt));
+    int lds = G3_LDS(wn == 1 ? G3_NB1 : 3, wn), tiles = cdiv(a.M, g3_bm(wn, mt));
+    const int threads = mt == 8 ? 256 : 512;
     const int tile_lds = (wn == 2 ? G3_TILE_BYTES(2) : G3_TILE_BYTES(1)) + G3_CNT_BYTES;   // the LIF_TILE epilogue reuses the ring (+ per-position spike counts)
     switch (mode) {
     case G3_FC: kern = g3_kernel<G3_FC>(mt, wn); break;
@@ -387,11 +393,11 @@ static int launch_gemm3(int mode, int mt, int wn, const Gemm3Args& a, hipStream_
     if (e != hipSuccess) return fail(-3, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
     if (knobs().debug_occ) {                                   // debug: co-resident work-groups per CU
         int v = 0;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, kern, 512, lds);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, kern, threads, lds);
         fprintf(stderr, "k_gemm_bf16x3 mode %d mt %d wn %d: lds %d B, %d work-groups per CU, grid %d\n", mode, mt, wn, lds, v, tiles * a.n_blocks);
     }
     void* kargs[] = {(void*)&a};
-    e = hipLaunchKernel(kern, dim3(tiles * a.n_blocks), dim3(512), kargs, lds, s);
+    e = hipLaunchKernel(kern, dim3(tiles * a.n_blocks), dim3(threads), kargs, lds, s);
     if (e != hipSuccess) return fail(-3, "k_gemm_bf16x3 launch failed: %s", hipGetErrorString(e));
     SNN_CHECK_LAUNCH("k_gemm_bf16x3");
     return 0;
@@ -408,7 +414,7 @@ int snn_spike_gemm_bf16x3(const uint32_t* a_rows, int M, int K, int N, const uin
     a.plane_elems = (unsigned long long)a.Kc * a.Np * 32;
     const int wn = g3_wn();
     a.n_blocks = cdiv(a.Np, G3_BN(wn));
-    const int mt = g3_pick_mt([&](int m) { return (long long)cdiv(M, G3_BM(wn, m)) * a.n_blocks; });
+    const int mt = g3_pick_mt([&](int m) { return (long long)cdiv(M, g3_bm(wn, m)) * a.n_blocks; });
     return launch_gemm3(G3_FC, mt, wn, a, (hipStream_t)s);
 }
 
@@ -426,9 +432,9 @@ static int spike_gemm_lif_bf16x3_impl(const uint32_t* a_planes, int T, int R, in
     const int wn = g3_wn();
     a.n_blocks = cdiv(a.Np, G3_BN(wn));
     a.T = T; a.spk = spk; a.spk_stride = spk_stride; a.p = make_p(p, p->v_th_lif); a.cnt_row = row_counts;
-    const int mt = g3_pick_mt([&](int m) { return g3_tile_ok(T, G3_BM(wn, m)) ? (long long)cdiv(R, G3_BM(wn, m) / T) * a.n_blocks : 0ll; });
+    const int mt = g3_pick_mt([&](int m) { return g3_tile_ok(T, g3_bm(wn, m)) ? (long long)cdiv(R, g3_bm(wn, m) / T) * a.n_blocks : 0ll; });
     if (!mt) return fail(-4, "snn_spike_gemm_lif_bf16x3: T=%d does not fit a row tile (use snn_spike_gemm_bf16x3 + snn_lif_scan)", T);
-    a.pb = G3_BM(wn, mt) / T;
+    a.pb = g3_bm(wn, mt) / T;
     return launch_gemm3(G3_FC_LIF_TILE, mt, wn, a, (hipStream_t)s);
 }
 
@@ -606,7 +612,7 @@ static int conv3x3_lif_bf16x3_impl(const uint32_t* enc, size_t enc_stride, const
     int mt = 0;
     if (!knobs().bf16x3_lif_reg) {
         a.n_blocks = cdiv(a.Np, G3_BN(wn));
-        mt = g3_pick_mt([&](int m) { return g3_tile_ok(T, G3_BM(wn, m)) ? (long long)cdiv(P, G3_BM(wn, m) / T) * a.n_blocks : 0ll; });
+        mt = g3_pick_mt([&](int m) { return g3_tile_ok(T, g3_bm(wn, m)) ? (long long)cdiv(P, g3_bm(wn, m) / T) * a.n_blocks : 0ll; });
     }
     if (!mt) {                                     // register-fused fallback: counts from the planes afterwards
         a.n_blocks = cdiv(a.Np, G3_BN(2));
@@ -614,7 +620,7 @@ static int conv3x3_lif_bf16x3_impl(const uint32_t* enc, size_t enc_stride, const
         if (rc || !counts) return rc;
         return count_spikes_per_image(lv, n_levels, cdiv(C_out, 32), T, spk, spk_stride, counts, max_n, (hipStream_t)s);
     }
-    a.pb = G3_BM(wn, mt) / T;
+    a.pb = g3_bm(wn, mt) / T;
     a.cnt_img = counts; a.max_n = max_n;
     return launch_gemm3(G3_CONV_LIF_TILE, mt, wn, a, (hipStream_t)s);
 }
@@ -649,7 +655,7 @@ int snn_spike_conv3x3_bf16x3(const uint32_t* enc, size_t enc_stride, const snn_r
     a.out = cur; a.ldo = ldo; a.M = (int)(T * P);
     const int wn = g3_wn();
     a.n_blocks = cdiv(a.Np, G3_BN(wn));
-    const int mt = g3_pick_mt([&](int m) { return (long long)cdiv(a.M, G3_BM(wn, m)) * a.n_blocks; });
+    const int mt = g3_pick_mt([&](int m) { return (long long)cdiv(a.M, g3_bm(wn, m)) * a.n_blocks; });
     return launch_gemm3(G3_CONV, mt, wn, a, (hipStream_t)s);
 }
 

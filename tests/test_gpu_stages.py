@@ -305,6 +305,9 @@ def test_bf16x3_kernel_variants_bit_identical(S, gpu_device, monkeypatch, T):
         for mt in ("2", "3", "4"):
             monkeypatch.setenv("SNN_BF16X3_MT", mt)
             assert torch.equal(S.conv3x3_lif_bf16x3(enc, shapes, C, C, p, wp), base), "WN=%s MT=%s" % (wn, mt)
+    monkeypatch.setenv("SNN_BF16X3_WN", "2")
+    monkeypatch.setenv("SNN_BF16X3_MT", "8")                      # fat waves: 4 waves of 128 x 64 on the same 256 x 128 tile
+    assert torch.equal(S.conv3x3_lif_bf16x3(enc, shapes, C, C, p, wp), base), "fat waves"
     monkeypatch.delenv("SNN_BF16X3_MT")
     monkeypatch.delenv("SNN_BF16X3_WN")
     monkeypatch.setenv("SNN_BF16X3_LIF", "reg")
@@ -324,6 +327,11 @@ def test_bf16x3_kernel_variants_bit_identical(S, gpu_device, monkeypatch, T):
             assert torch.equal(S.spike_gemm_lif_bf16x3(a, K, N, p, wlp), base), "WN=%s MT=%s" % (wn, mt)
             cur = S.spike_gemm_bf16x3(a.view(T * R, -1), K, N, wlp)
             assert torch.equal(S.lif_scan(cur.view(T, R, -1), N, p)[..., :base.shape[-1]], base)
+    monkeypatch.setenv("SNN_BF16X3_WN", "2")
+    monkeypatch.setenv("SNN_BF16X3_MT", "8")
+    assert torch.equal(S.spike_gemm_lif_bf16x3(a, K, N, p, wlp), base), "fat waves"
+    cur = S.spike_gemm_bf16x3(a.view(T * R, -1), K, N, wlp)
+    assert torch.equal(S.lif_scan(cur.view(T, R, -1), N, p)[..., :base.shape[-1]], base)
 
 
 @pytest.mark.parametrize("C_in,C_out,T,shapes", [

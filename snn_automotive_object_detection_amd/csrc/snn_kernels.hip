@@ -1081,18 +1081,21 @@ int snn_rpn_proposals_candidates(const snn_rpn_post_level* lv, int n_levels, int
     return k > 0x7fffffffLL ? -1 : (int)k;
 }
 
-static size_t rpn_post_layout(int N, int K, size_t off[14]) {
+// workspace of snn_rpn_proposals: candidates of the batch + one NMS list per (image, level)
+// (mask_words = mask words per image: sum over the levels of k_l * ceil(k_l / 64) <= K * ceil(K / 64))
+static size_t rpn_post_layout(int N, int K, size_t mask_words, size_t off[9]) {
     const size_t nk = (size_t)N * K;
-    const size_t sz[14] = {nk * 4, nk * 4, nk * 16, nk * 16, nk * 4, nk * 4, nk * 16, nk * 16, nk * 4, nk * 4,
-                           (size_t)N * 4, nk * 4, (size_t)N * 4, nk * cdiv(K, 64) * 8};
+    const size_t sz[9] = {nk * 4, nk * 4, nk * 16, nk * 16, nk * 4, nk * 4, nk * 4, (size_t)N * SNN_MAX_LEVELS * 4,
+                          (size_t)N * mask_words * 8};
     size_t o = 0;
-    for (int i = 0; i < 14; ++i) { off[i] = o; o += align_up(sz[i], 256); }
+    for (int i = 0; i < 9; ++i) { off[i] = o; o += align_up(sz[i], 256); }
     return o;
 }
 
 size_t snn_rpn_proposals_workspace_bytes(int N, int K_candidates) {
-    size_t off[14];
-    return (N > 0 && K_candidates > 0) ? rpn_post_layout(N, K_candidates, off) : 0;
+    size_t off[9];
+    // (the level split is not known here: one list of K candidates per image bounds every split)
+    return (N > 0 && K_candidates > 0) ? rpn_post_layout(N, K_candidates, (size_t)K_candidates * cdiv(K_candidates, 64), off) : 0;
 }
 
 int snn_rpn_proposals(const snn_rpn_post_level* lv, int n_levels, int N, int A, const float* image_hw_host,
@@ -1107,12 +1110,13 @@ int snn_rpn_proposals(const snn_rpn_post_level* lv, int n_levels, int N, int A, 
                     RPN_MAX_IMAGES, RPN_MAX_ANCHORS);
     const int K = snn_rpn_proposals_candidates(lv, n_levels, A, pre_nms_top_n);
     if (K <= 0 || K > RPN_SORT_MAX) return fail(-1, "snn_rpn_proposals: %d candidates per image (max %d)", K, RPN_SORT_MAX);
-    size_t off[14];
-    if (ws_bytes < rpn_post_layout(N, K, off)) return fail(-2, "snn_rpn_proposals: workspace too small");
     hipStream_t s = (hipStream_t)stream;
     RpnPostArgs a;
     memset(&a, 0, sizeof(a));
-    int koff = 0;
+    NmsLists nl;
+    memset(&nl, 0, sizeof(nl));
+    int koff = 0, kmax = 0;
+    size_t mask_words = 0;
     for (int l = 0; l < n_levels; ++l) {
         if (!lv[l].logits || !lv[l].deltas || lv[l].H <= 0 || lv[l].W <= 0) return fail(-1, "snn_rpn_proposals: bad level %d", l);
         if ((long long)lv[l].H * lv[l].W * A * N > 0x7fffffffLL || (long long)lv[l].H * lv[l].W * A >= (1 << 28))
@@ -1122,7 +1126,12 @@ int snn_rpn_proposals(const snn_rpn_post_level* lv, int n_levels, int N, int A, 
         L.n = lv[l].H * lv[l].W * A; L.k = min(pre_nms_top_n, L.n); L.koff = koff; koff += L.k;
         L.sh = lv[l].stride_h; L.sw = lv[l].stride_w;
         memcpy(L.base, lv[l].base_anchors, sizeof(float) * 4 * A);
+        nl.off[l] = L.koff; nl.cap[l] = L.k; nl.moff[l] = (long long)mask_words;
+        mask_words += (size_t)L.k * cdiv(L.k, 64);
+        kmax = max(kmax, L.k);
     }
+    size_t off[9];
+    if (ws_bytes < rpn_post_layout(N, K, mask_words, off)) return fail(-2, "snn_rpn_proposals: workspace too small");
     for (int i = 0; i < N; ++i) { a.img_h[i] = image_hw_host[2 * i]; a.img_w[i] = image_hw_host[2 * i + 1]; }
     a.n_levels = n_levels; a.N = N; a.A = A; a.Ktot = K; a.post_n = post_nms_top_n;
     a.score_thresh = score_thresh; a.min_size = min_size; a.clip = (float)4.135166556742356;     // log(1000/16), boxes.py
@@ -1130,47 +1139,43 @@ int snn_rpn_proposals(const snn_rpn_post_level* lv, int n_levels, int N, int A, 
     a.cand_idx = (int*)(w + off[0]); a.cand_logit = (float*)(w + off[1]); a.boxes = (float*)(w + off[2]);
     // the pre-NMS report goes straight to the caller's buffers, in candidate order = the reference's order (rpn.py:493-499)
     a.pre = pre_boxes ? pre_boxes : (float*)(w + off[3]); a.prob = pre_prob ? pre_prob : (float*)(w + off[4]); a.skey = (float*)(w + off[5]);
-    a.s_boxes = (float*)(w + off[6]);
-    a.s_prob = (float*)(w + off[8]); a.s_cat = (int*)(w + off[9]); a.n_valid = (int*)(w + off[10]);
-    int* keep = (int*)(w + off[11]);
-    int* n_keep = (int*)(w + off[12]);
-    unsigned long long* mask = (unsigned long long*)(w + off[13]);
+    int* keep = (int*)(w + off[6]);
+    int* n_keep = (int*)(w + off[7]);
+    unsigned long long* mask = (unsigned long long*)(w + off[8]);
     hipLaunchKernelGGL(k_rpn_topk, dim3(n_levels, N), dim3(1024), 0, s, a);
     SNN_CHECK_LAUNCH("k_rpn_topk");
     hipLaunchKernelGGL(k_rpn_decode, dim3(cdiv((long long)N * K, 256)), dim3(256), 0, s, a);
     SNN_CHECK_LAUNCH("k_rpn_decode");
-    hipLaunchKernelGGL(k_rpn_sort, dim3(N), dim3(1024), 0, s, a);
-    SNN_CHECK_LAUNCH("k_rpn_sort");
-    const int words = cdiv(K, 64);
-    NmsBatch nb;
-    nb.n_dev = a.n_valid; nb.boxes_stride = (long long)K * 4; nb.cat_stride = K; nb.mask_stride = (long long)K * words;
-    nb.keep_stride = K;
-    hipLaunchKernelGGL(k_nms_mask, dim3(words, words, N), dim3(64), 0, s, a.s_boxes, a.s_cat, K, nms_thresh, mask, words, nb);
-    SNN_CHECK_LAUNCH("k_nms_mask");
-    const int dbl = words <= 156 ? 1 : 0;
-    const size_t lds = (size_t)(1 + dbl) * 64 * words * 8;
-    hipError_t e = hipFuncSetAttribute((const void*)k_nms_scan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    // NMS: one list per (image, level) - the candidates of a level already are in score order (k_rpn_topk), the filtered
+    // ones start out removed
+    nl.boxes = a.boxes; nl.skey = a.skey; nl.n_dev = nullptr; nl.img_stride = K; nl.mask_img = (long long)mask_words; nl.L = n_levels;
+    nl.max_keep0 = nl.max_keep = post_nms_top_n;
+    const int wmax = cdiv(kmax, 64);
+    hipLaunchKernelGGL(k_nms_mask_lists, dim3(wmax, wmax, N * n_levels), dim3(64), 0, s, nl, nms_thresh, mask);
+    SNN_CHECK_LAUNCH("k_nms_mask_lists");
+    const size_t lds = (size_t)2 * 64 * wmax * 8;
+    hipError_t e = hipFuncSetAttribute((const void*)k_nms_scan_lists, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return fail(-3, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(k_nms_scan, dim3(N), dim3(256), lds, s, mask, K, words, post_nms_top_n, dbl, keep, n_keep, nb);
-    SNN_CHECK_LAUNCH("k_nms_scan");
-    hipLaunchKernelGGL(k_rpn_output, dim3(N), dim3(256), 0, s, a, keep, n_keep, out_boxes, out_scores, out_counts);
-    SNN_CHECK_LAUNCH("k_rpn_output");
+    hipLaunchKernelGGL(k_nms_scan_lists, dim3(N * n_levels), dim3(256), lds, s, nl, mask, keep, n_keep);
+    SNN_CHECK_LAUNCH("k_nms_scan_lists");
+    hipLaunchKernelGGL(k_rpn_merge, dim3(N), dim3(1024), 0, s, a, keep, n_keep, out_boxes, out_scores, out_counts);
+    SNN_CHECK_LAUNCH("k_rpn_merge");
     return 0;
 }
 
 // ---- detection post-processing ------------------------------------------------------------------
-static size_t det_post_layout(int N, int Kcap, size_t off[11]) {
-    const size_t L = 2 * (size_t)N, lk = L * Kcap;
-    const size_t sz[11] = {lk * 16, lk * 4, lk * 4, lk * 16, lk * 4, lk * 4, L * 4, lk * 4, L * 4, lk * cdiv(Kcap, 64) * 8, 0};
+static size_t det_post_layout(int N, int K, int Rmax, size_t off[9]) {
+    const size_t lk = (size_t)N * K * Rmax, L = (size_t)N * K;
+    const size_t sz[9] = {lk * 16, lk * 4, lk * 16, lk * 4, lk * 4, L * 4, lk * 4, L * 4, lk * cdiv(Rmax, 64) * 8};
     size_t o = 0;
-    for (int i = 0; i < 11; ++i) { off[i] = o; o += align_up(sz[i], 256); }
+    for (int i = 0; i < 9; ++i) { off[i] = o; o += align_up(sz[i], 256); }
     return o;
 }
 
 size_t snn_det_postprocess_workspace_bytes(int N, int max_rois_per_image, int K) {
-    size_t off[11];
+    size_t off[9];
     if (N <= 0 || max_rois_per_image <= 0 || K < 2) return 0;
-    return det_post_layout(N, max_rois_per_image * (K - 1), off);
+    return det_post_layout(N, K, max_rois_per_image, off);
 }
 
 int snn_det_postprocess(const float* class_logits, const float* box_regression, const float* proposals,
@@ -1181,8 +1186,8 @@ int snn_det_postprocess(const float* class_logits, const float* box_regression, 
     if (!class_logits || !box_regression || !proposals || !rois_per_image_host || !image_hw_host || !box_weights_host || !all_scores ||
         !all_boxes || !out_boxes || !out_scores || !out_labels || !out_counts || !ws)
         return fail(-1, "snn_det_postprocess: null argument");
-    if (N <= 0 || N > RPN_MAX_IMAGES || K < 2 || detections_per_img <= 0)
-        return fail(-1, "snn_det_postprocess: bad argument (images <= %d)", RPN_MAX_IMAGES);
+    if (N <= 0 || N > RPN_MAX_IMAGES || K < 2 || K > NMS_MAX_CAT || detections_per_img <= 0)
+        return fail(-1, "snn_det_postprocess: bad argument (images <= %d, classes <= %d)", RPN_MAX_IMAGES, NMS_MAX_CAT);
     DetPostArgs a;
     memset(&a, 0, sizeof(a));
     int rmax = 0;
@@ -1196,47 +1201,52 @@ int snn_det_postprocess(const float* class_logits, const float* box_regression, 
         if (hipMemsetAsync(out_counts, 0, sizeof(int) * 2 * N, (hipStream_t)stream) != hipSuccess) return fail(-3, "hipMemsetAsync failed");
         return 0;
     }
-    const int Kcap = rmax * (K - 1);
-    if (Kcap > DET_SORT_MAX) return fail(-4, "snn_det_postprocess: %d candidates per image (max %d)", Kcap, DET_SORT_MAX);
+    if (rmax > DET_SORT_MAX) return fail(-4, "snn_det_postprocess: %d RoIs per image (max %d)", rmax, DET_SORT_MAX);
+    if ((long long)(K - 1) * min(detections_per_img, rmax) > DET_MERGE_MAX)
+        return fail(-4, "snn_det_postprocess: (K-1) * detections_per_img = %lld exceeds %d", (long long)(K - 1) * detections_per_img, DET_MERGE_MAX);
     if (out_cap < detections_per_img + rmax) return fail(-1, "snn_det_postprocess: out_cap %d < %d", out_cap, detections_per_img + rmax);
-    size_t off[11];
-    if (ws_bytes < det_post_layout(N, Kcap, off)) return fail(-2, "snn_det_postprocess: workspace too small");
+    size_t off[9];
+    if (ws_bytes < det_post_layout(N, K, rmax, off)) return fail(-2, "snn_det_postprocess: workspace too small");
     hipStream_t s = (hipStream_t)stream;
     a.logits = class_logits; a.deltas = box_regression; a.props = proposals;
-    a.N = N; a.K = K; a.Kcap = Kcap; a.det_per_img = detections_per_img; a.out_cap = out_cap;
+    a.N = N; a.K = K; a.Rmax = rmax; a.det_per_img = detections_per_img; a.out_cap = out_cap;
     a.score_thresh = score_thresh; a.min_size = min_size; a.clip = (float)4.135166556742356;
     a.wx = box_weights_host[0]; a.wy = box_weights_host[1]; a.ww = box_weights_host[2]; a.wh = box_weights_host[3];
     a.all_scores = all_scores; a.all_boxes = all_boxes;
     char* w = (char*)ws;
-    a.boxes = (float*)(w + off[0]); a.skey = (float*)(w + off[1]); a.cat = (int*)(w + off[2]);
-    a.s_boxes = (float*)(w + off[3]); a.s_score = (float*)(w + off[4]); a.s_cat = (int*)(w + off[5]); a.n_valid = (int*)(w + off[6]);
-    int* keep = (int*)(w + off[7]);
-    int* n_keep = (int*)(w + off[8]);
-    unsigned long long* mask = (unsigned long long*)(w + off[9]);
-    const int L = 2 * N;
-    hipLaunchKernelGGL(k_det_candidates, dim3(cdiv(Kcap, 256), L), dim3(256), 0, s, a);
+    a.boxes = (float*)(w + off[0]); a.skey = (float*)(w + off[1]);
+    a.s_boxes = (float*)(w + off[2]); a.s_score = (float*)(w + off[3]); a.s_roi = (int*)(w + off[4]); a.n_valid = (int*)(w + off[5]);
+    int* keep = (int*)(w + off[6]);
+    int* n_keep = (int*)(w + off[7]);
+    unsigned long long* mask = (unsigned long long*)(w + off[8]);
+    const int L = N * K;
+    hipLaunchKernelGGL(k_det_candidates, dim3(cdiv(rmax, 256), L), dim3(256), 0, s, a);
     SNN_CHECK_LAUNCH("k_det_candidates");
     int np2 = 1;
-    while (np2 < Kcap) np2 <<= 1;
-    const size_t sort_lds = (size_t)np2 * 8;
+    while (np2 < rmax) np2 <<= 1;
+    const size_t sort_lds = max((size_t)np2 * 8, (size_t)64);
     hipError_t e = hipFuncSetAttribute((const void*)k_sort_lists, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds);
     if (e != hipSuccess) return fail(-3, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(k_sort_lists, dim3(L), dim3(1024), sort_lds, s, a.skey, a.boxes, a.cat, Kcap, a.s_boxes, a.s_score, a.s_cat, a.n_valid);
+    hipLaunchKernelGGL(k_sort_lists, dim3(L), dim3(1024), sort_lds, s, a.skey, a.boxes, rmax, a.s_boxes, a.s_score, a.s_roi, a.n_valid);
     SNN_CHECK_LAUNCH("k_sort_lists");
-    const int words = cdiv(Kcap, 64);
-    NmsBatch nb;
-    nb.n_dev = a.n_valid; nb.boxes_stride = (long long)Kcap * 4; nb.cat_stride = Kcap; nb.mask_stride = (long long)Kcap * words;
-    nb.keep_stride = Kcap;
-    hipLaunchKernelGGL(k_nms_mask, dim3(words, words, L), dim3(64), 0, s, a.s_boxes, a.s_cat, Kcap, nms_thresh, mask, words, nb);
-    SNN_CHECK_LAUNCH("k_nms_mask");
-    const int dbl = words <= 156 ? 1 : 0;
-    const size_t lds = (size_t)(1 + dbl) * 64 * words * 8;
-    e = hipFuncSetAttribute((const void*)k_nms_scan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    // NMS: one list per (image, class); a foreground class stops after detections_per_img kept boxes, the background list keeps all
+    NmsLists nl;
+    memset(&nl, 0, sizeof(nl));
+    const int wmax = cdiv(rmax, 64);
+    nl.boxes = a.s_boxes; nl.skey = nullptr; nl.n_dev = a.n_valid; nl.img_stride = (long long)K * rmax;
+    nl.mask_img = (long long)K * rmax * wmax; nl.L = K;
+    for (int c = 0; c < K; ++c) { nl.off[c] = c * rmax; nl.cap[c] = rmax; nl.moff[c] = (long long)c * rmax * wmax; }
+    nl.max_keep0 = rmax; nl.max_keep = detections_per_img;
+    hipLaunchKernelGGL(k_nms_mask_lists, dim3(wmax, wmax, L), dim3(64), 0, s, nl, nms_thresh, mask);
+    SNN_CHECK_LAUNCH("k_nms_mask_lists");
+    const size_t lds = (size_t)2 * 64 * wmax * 8;
+    if (lds > 160 * 1024) return fail(-4, "snn_det_postprocess: %d RoIs per image need %zu B of LDS for the NMS walk", rmax, lds);
+    e = hipFuncSetAttribute((const void*)k_nms_scan_lists, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return fail(-3, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(k_nms_scan, dim3(L), dim3(256), lds, s, mask, Kcap, words, Kcap, dbl, keep, n_keep, nb);
-    SNN_CHECK_LAUNCH("k_nms_scan");
-    hipLaunchKernelGGL(k_det_output, dim3(N), dim3(256), 0, s, a, keep, n_keep, out_boxes, out_scores, out_labels, out_counts);
-    SNN_CHECK_LAUNCH("k_det_output");
+    hipLaunchKernelGGL(k_nms_scan_lists, dim3(L), dim3(256), lds, s, nl, mask, keep, n_keep);
+    SNN_CHECK_LAUNCH("k_nms_scan_lists");
+    hipLaunchKernelGGL(k_det_merge, dim3(N), dim3(1024), 0, s, a, keep, n_keep, out_boxes, out_scores, out_labels, out_counts);
+    SNN_CHECK_LAUNCH("k_det_merge");
     return 0;
 }
 

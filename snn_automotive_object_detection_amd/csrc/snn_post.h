@@ -140,14 +140,148 @@ __global__ __launch_bounds__(256) void k_nms_scan(const unsigned long long* __re
 }
 
 // ------------------------------------------------------------------------------------------------
+// List form of the same NMS for the two post-processing pipelines (round 2).  batched_nms only ever suppresses inside a
+// category (pyramid level / class), so every (image, category) pair is its own LIST: candidates already in score order,
+// mask and in-order walk per list, all lists of the batch in one launch each, and a rank-by-binary-search merge of the
+// kept candidates afterwards.  Against one walk over all categories of an image (round 1: 76 chunks of 64 for 4864 RPN
+// candidates, 125 for 8000 detector candidates) a list is 16 chunks, and the lists run side by side.
+// ------------------------------------------------------------------------------------------------
+#define NMS_MAX_CAT 96
+struct NmsLists {
+    const float* boxes;           // candidate boxes of the batch; list (img, c) starts at (img * img_stride + off[c]) * 4
+    const float* skey;            // nullable: candidate i of a list is out of the game when skey[...] < 0 (filtered before NMS)
+    const int* n_dev;             // nullable: candidates per list on the device [N * L]; else n[c]
+    long long img_stride;         // candidates per image (also the stride of keep[])
+    long long mask_img;           // mask words (uint64) per image
+    int L;                        // lists (categories) per image
+    int off[NMS_MAX_CAT];         // first candidate of category c inside the image (boxes, skey, keep[])
+    int cap[NMS_MAX_CAT];         // candidates of category c (capacity; the mask row of the list has ceil(cap / 64) words)
+    long long moff[NMS_MAX_CAT];  // first mask word of category c inside the image
+    int max_keep0, max_keep;      // walk stops after that many kept boxes (category 0 / the others)
+};
+
+__global__ __launch_bounds__(64) void k_nms_mask_lists(const NmsLists nl, float thr, unsigned long long* __restrict__ mask) {
+    const int rb = blockIdx.y, cb = blockIdx.x, z = blockIdx.z, img = z / nl.L, c = z % nl.L;
+    if (cb < rb) return;                                  // only j > i matters
+    const int n = nl.n_dev ? nl.n_dev[z] : nl.cap[c];
+    if (rb * 64 >= n || cb * 64 >= n) return;
+    const float* boxes = nl.boxes + ((size_t)img * nl.img_stride + nl.off[c]) * 4;
+    const int words = (nl.cap[c] + 63) >> 6;
+    mask += (size_t)img * nl.mask_img + nl.moff[c];
+    __shared__ float cbx[64][4];
+    const int t = threadIdx.x;
+    const int j0 = cb * 64;
+    if (j0 + t < n) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cbx[t][q] = boxes[(size_t)(j0 + t) * 4 + q];
+    }
+    __syncthreads();
+    const int i = rb * 64 + t;
+    if (i >= n) return;
+    const float x1 = boxes[(size_t)i * 4], y1 = boxes[(size_t)i * 4 + 1], x2 = boxes[(size_t)i * 4 + 2], y2 = boxes[(size_t)i * 4 + 3];
+    const float area_i = __fmul_rn(__fsub_rn(x2, x1), __fsub_rn(y2, y1));
+    unsigned long long bits = 0;
+    const int jn = min(64, n - j0);
+    for (int jj = (rb == cb ? t + 1 : 0); jj < jn; ++jj) {
+        const float w = fmaxf(__fsub_rn(fminf(x2, cbx[jj][2]), fmaxf(x1, cbx[jj][0])), 0.0f);
+        const float h = fmaxf(__fsub_rn(fminf(y2, cbx[jj][3]), fmaxf(y1, cbx[jj][1])), 0.0f);
+        const float inter = __fmul_rn(w, h);
+        const float area_j = __fmul_rn(__fsub_rn(cbx[jj][2], cbx[jj][0]), __fsub_rn(cbx[jj][3], cbx[jj][1]));
+        const float iou = __fdiv_rn(inter, __fsub_rn(__fadd_rn(area_i, area_j), inter));     // box_iou's formula
+        if (iou > thr) bits |= 1ull << jj;
+    }
+    mask[(size_t)i * words + cb] = bits;
+}
+
+// the walk of k_nms_scan on one list per work-group; candidates flagged by skey < 0 start out removed
+__global__ __launch_bounds__(256) void k_nms_scan_lists(const NmsLists nl, const unsigned long long* __restrict__ mask,
+                                                        int* __restrict__ keep, int* __restrict__ n_keep) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long* rows = reinterpret_cast<unsigned long long*>(smem);     // [2][64][words]
+    const int z = blockIdx.x, img = z / nl.L, c = z % nl.L;
+    const int n = nl.n_dev ? nl.n_dev[z] : nl.cap[c];
+    const int max_keep = c == 0 ? nl.max_keep0 : nl.max_keep;
+    const int words = (nl.cap[c] + 63) >> 6;
+    mask += (size_t)img * nl.mask_img + nl.moff[c];
+    keep += (size_t)img * nl.img_stride + nl.off[c];
+    n_keep += z;
+    if (n <= 0) { if (threadIdx.x == 0) *n_keep = 0; return; }
+    __shared__ unsigned long long removed_cur, kept_cur;
+    __shared__ int count_s;
+    const int t = threadIdx.x;
+    const int n_chunks = (n + 63) / 64;
+    unsigned long long removed = 0;          // thread t (< words): removed bits of boxes [64t, 64t+64)
+    if (nl.skey && t < n_chunks) {
+        const float* sk = nl.skey + (size_t)img * nl.img_stride + nl.off[c] + t * 64;
+        const int m = min(64, n - t * 64);
+        for (int b = 0; b < m; ++b) removed |= (unsigned long long)(sk[b] < 0.0f) << b;
+    }
+    auto copy_chunk = [&](int cc, int first, int step) {      // rows of chunk cc, words [cc, words) -> buffer cc & 1
+        const int rn = min(64, n - cc * 64), wn = n_chunks - cc;
+        unsigned long long* dst = rows + (size_t)(cc & 1) * 64 * words;
+        const unsigned long long* src = mask + (size_t)cc * 64 * words;
+        for (int idx = first; idx < rn * wn; idx += step) {
+            const int r = idx / wn, w = cc + idx % wn;
+            dst[r * words + w] = src[(size_t)r * words + w];
+        }
+    };
+    copy_chunk(0, t, 256);
+    if (t == 0) { count_s = 0; removed_cur = removed; }
+    __syncthreads();
+    for (int cc = 0; cc < n_chunks; ++cc) {
+        const int rn = min(64, n - cc * 64);
+        const unsigned long long* cur = rows + (size_t)(cc & 1) * 64 * words;
+        if (t >= 64) {
+            if (cc + 1 < n_chunks) copy_chunk(cc + 1, t - 64, 192);
+        } else {                              // wave 0: the chunk's own block, resolved in registers
+            const unsigned long long diag = t < rn ? cur[t * words + cc] : 0ull;
+            const uint32_t dlo = (uint32_t)diag, dhi = (uint32_t)(diag >> 32);
+            unsigned long long rc = removed_cur;              // wave-uniform
+            if (rn < 64) rc |= ~0ull << rn;                   // lanes past the end count as removed
+            int count = count_s;
+            const int base = count;
+            unsigned long long kept_bits = 0;
+#pragma unroll
+            for (int b = 0; b < 64; ++b) {
+                if (!((rc >> b) & 1ull) && count < max_keep) {
+                    kept_bits |= 1ull << b;
+                    ++count;
+                    rc |= ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane(dhi, b) << 32) |
+                          (unsigned long long)(uint32_t)__builtin_amdgcn_readlane(dlo, b);
+                }
+            }
+            if ((kept_bits >> t) & 1ull)
+                keep[base + __popcll(kept_bits & ((1ull << t) - 1ull))] = cc * 64 + t;
+            if (t == 0) { count_s = count; kept_cur = kept_bits; }
+        }
+        __syncthreads();
+        const unsigned long long kept = kept_cur;
+        if (t < n_chunks && t > cc) {         // later words: OR the rows of the kept boxes
+            unsigned long long acc = removed, k = kept;
+            while (k) {
+                const int b = __ffsll((long long)k) - 1;
+                k &= k - 1;
+                acc |= cur[b * words + t];
+            }
+            removed = acc;
+        }
+        if (t == cc + 1) removed_cur = removed;
+        const bool done = count_s >= max_keep;
+        __syncthreads();
+        if (done) break;
+    }
+    if (t == 0) *n_keep = count_s;
+}
+
+// ------------------------------------------------------------------------------------------------
 // RPN proposal selection (rpn.py:420-499 + 262-296 + the box coder), one call for the batch:
 //   k_rpn_topk    per (level, image): the pre_nms_top_n largest logits by a 3-pass radix select (11+11+10 bits), then sorted
 //                 by decreasing logit: candidate slots are in the reference's order (level, rank inside the level)
 //   k_rpn_decode  per candidate: anchor from the level geometry, box decode, sigmoid, clip, size/score filters; the decoded
 //                 un-clipped boxes + probabilities of ALL candidates are the reference's pre-NMS report (rpn.py:493-499)
-//   k_rpn_sort    per image: bitonic sort of the candidates by decreasing score (ties: candidate slot) in LDS, gather
-//   k_nms_mask / k_nms_scan (batched over images, category = level)
-//   k_rpn_output  kept boxes -> [N][post_nms_top_n] padded + counts
+//   k_nms_mask_lists / k_nms_scan_lists   one list per (image, level): its candidates already are in score order
+//   k_rpn_merge   kept candidates of the level lists -> the reference's output order by rank computation, first
+//                 post_nms_top_n -> [N][post_nms_top_n] padded + counts
 // ------------------------------------------------------------------------------------------------
 #define RPN_MAX_ANCHORS 16
 #define RPN_MAX_IMAGES 64
@@ -170,7 +304,6 @@ struct RpnPostArgs {
     float* pre;                   // [N][Ktot][4] decoded, un-clipped
     float* prob;                  // [N][Ktot]
     float* skey;                  // [N][Ktot] prob, or -1 for filtered candidates
-    float* s_boxes; float* s_prob; int* s_cat; int* n_valid;     // sorted by decreasing score
 };
 
 __device__ __forceinline__ uint32_t f2key(float f) {           // monotone: larger float -> larger key
@@ -191,9 +324,28 @@ __global__ __launch_bounds__(1024) void k_rpn_topk(const RpnPostArgs a) {
         for (int b = tid; b < 2048; b += 1024) hist[b] = 0;
         __syncthreads();
         const uint32_t bm = (1u << bits[pass]) - 1u;
-        for (int e = tid; e < L.n; e += 1024) {
-            const uint32_t key = f2key(src[e]);
-            if ((key & pmask) == prefix) atomicAdd(&hist[(key >> shifts[pass]) & bm], 1u);
+        // Objectness logits of one level share their high bits (a narrow range of values), so most keys of a pass fall into
+        // a handful of bins: plain LDS atomics serialise on them (0.38 ms for the 221 184 logits of the stride-4 level).
+        // Two rounds of wave aggregation first - the lanes that share the leader's bin send ONE add - then plain atomics
+        // for what is left (spread keys lose two ballots, clustered keys lose 98 % of their atomics).
+        for (int e0 = 0; e0 < L.n; e0 += 1024) {
+            const int e = e0 + tid;
+            const uint32_t key = e < L.n ? f2key(src[e]) : 0u;
+            bool act = e < L.n && (key & pmask) == prefix;
+            const uint32_t bin = (key >> shifts[pass]) & bm;
+            const int lane = tid & 63;
+#pragma unroll
+            for (int round = 0; round < 2; ++round) {
+                const unsigned long long m = __ballot(act);
+                if (m == 0ull) break;
+                const int leader = __ffsll((long long)m) - 1;
+                const uint32_t lb = (uint32_t)__shfl((int)bin, leader);
+                const bool same = act && bin == lb;
+                const unsigned long long sm = __ballot(same);
+                if (lane == leader) atomicAdd(&hist[lb], (uint32_t)__popcll(sm));
+                act = act && !same;
+            }
+            if (act) atomicAdd(&hist[bin], 1u);
         }
         __syncthreads();
         if (tid == 0) {                       // walk the bins from the top until `need` keys are covered
@@ -305,73 +457,69 @@ __global__ __launch_bounds__(256) void k_rpn_decode(const RpnPostArgs a) {
     a.skey[g] = valid ? prob : -1.0f;
 }
 
-__global__ __launch_bounds__(1024) void k_rpn_sort(const RpnPostArgs a) {
-    __shared__ unsigned long long v[RPN_SORT_MAX];
-    const int img = blockIdx.x, tid = threadIdx.x, K = a.Ktot;
-    int np2 = 1;
-    while (np2 < K) np2 <<= 1;
-    // descending on (score, then lower candidate slot).  Slots are in the reference's candidate order (level, then rank by
-    // logit inside the level: k_rpn_topk), so equal scores come out as the reference's stable sort leaves them.
-    for (int i = tid; i < np2; i += 1024)
-        v[i] = i < K ? ((unsigned long long)f2key(a.skey[(size_t)img * K + i]) << 32) | (uint32_t)(~(uint32_t)i) : 0ull;
-    __syncthreads();
-    for (int k = 2; k <= np2; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < np2; i += 1024) {
-                const int p = i ^ j;
-                if (p > i) {
-                    const unsigned long long x = v[i], y = v[p];
-                    if (((i & k) == 0) ? x < y : x > y) { v[i] = y; v[p] = x; }
-                }
-            }
-            __syncthreads();
-        }
-    int valid = 0;
-    for (int i = tid; i < K; i += 1024) {
-        const int c = (int)(~(uint32_t)v[i]);
-        const size_t src = (size_t)img * K + c, dst = (size_t)img * K + i;
-        reinterpret_cast<float4*>(a.s_boxes)[dst] = reinterpret_cast<const float4*>(a.boxes)[src];
-        a.s_prob[dst] = a.prob[src];
-        int l = 0;
-        while (l + 1 < a.n_levels && c >= a.lv[l + 1].koff) ++l;
-        a.s_cat[dst] = l;
-        valid += a.skey[src] >= 0.0f;
-    }
-    __shared__ int s_valid;
-    if (tid == 0) s_valid = 0;
-    __syncthreads();
-    if (valid) atomicAdd(&s_valid, valid);
-    __syncthreads();
-    if (tid == 0) a.n_valid[img] = s_valid;
-}
-
-__global__ __launch_bounds__(256) void k_rpn_output(const RpnPostArgs a, const int* __restrict__ keep, const int* __restrict__ n_keep,
+// Kept candidates of the L level lists of an image -> the reference's output order (decreasing score; equal scores in
+// candidate order = level, then rank inside the level) -> the first post_n of them.  Every list is already in that order, so
+// the position of a kept candidate is its index in its own list + the number of candidates of every other list that precede
+// it (one binary search each, on the kept probabilities gathered in LDS): no sort.
+__global__ __launch_bounds__(1024) void k_rpn_merge(const RpnPostArgs a, const int* __restrict__ keep, const int* __restrict__ n_keep,
                                                     float* __restrict__ out_boxes, float* __restrict__ out_scores,
                                                     int* __restrict__ out_counts) {
-    const int img = blockIdx.x;
-    const int cnt = min(n_keep[img], a.post_n);
-    for (int r = threadIdx.x; r < a.post_n; r += 256) {
-        float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-        float sc = 0.f;
-        if (r < cnt) {
-            const size_t src = (size_t)img * a.Ktot + keep[(size_t)img * a.Ktot + r];
-            b = reinterpret_cast<const float4*>(a.s_boxes)[src];
-            sc = a.s_prob[src];
-        }
-        reinterpret_cast<float4*>(out_boxes)[(size_t)img * a.post_n + r] = b;
-        out_scores[(size_t)img * a.post_n + r] = sc;
+    __shared__ float kp[RPN_SORT_MAX];
+    __shared__ int kbase[SNN_MAX_LEVELS + 1];
+    const int img = blockIdx.x, tid = threadIdx.x, L = a.n_levels;
+    if (tid == 0) {
+        int base = 0;
+        for (int l = 0; l < L; ++l) { kbase[l] = base; base += min(n_keep[img * L + l], a.post_n); }
+        kbase[L] = base;
     }
-    if (threadIdx.x == 0) out_counts[img] = cnt;
+    __syncthreads();
+    const int total = kbase[L];
+    for (int i = tid; i < total; i += 1024) {
+        int l = 0;
+        while (i >= kbase[l + 1]) ++l;
+        const int slot = a.lv[l].koff + keep[(size_t)img * a.Ktot + a.lv[l].koff + (i - kbase[l])];
+        kp[i] = a.prob[(size_t)img * a.Ktot + slot];
+    }
+    __syncthreads();
+    for (int i = tid; i < total; i += 1024) {
+        int l = 0;
+        while (i >= kbase[l + 1]) ++l;
+        const float pr = kp[i];
+        int rank = i - kbase[l];
+        for (int l2 = 0; l2 < L; ++l2) {
+            if (l2 == l) continue;
+            int lo = 0, hi = kbase[l2 + 1] - kbase[l2];
+            const float* q = kp + kbase[l2];
+            while (lo < hi) {                               // first entry of list l2 that does NOT precede (pr, l)
+                const int mid = (lo + hi) >> 1;
+                const bool precedes = q[mid] > pr || (q[mid] == pr && l2 < l);
+                if (precedes) lo = mid + 1; else hi = mid;
+            }
+            rank += lo;
+        }
+        if (rank < a.post_n) {
+            const int slot = a.lv[l].koff + keep[(size_t)img * a.Ktot + a.lv[l].koff + (i - kbase[l])];
+            reinterpret_cast<float4*>(out_boxes)[(size_t)img * a.post_n + rank] = reinterpret_cast<const float4*>(a.boxes)[(size_t)img * a.Ktot + slot];
+            out_scores[(size_t)img * a.post_n + rank] = pr;
+        }
+    }
+    const int cnt = min(total, a.post_n);
+    for (int r = cnt + tid; r < a.post_n; r += 1024) {
+        reinterpret_cast<float4*>(out_boxes)[(size_t)img * a.post_n + r] = make_float4(0.f, 0.f, 0.f, 0.f);
+        out_scores[(size_t)img * a.post_n + r] = 0.f;
+    }
+    if (tid == 0) out_counts[img] = cnt;
 }
 
 // ------------------------------------------------------------------------------------------------
 // Detection post-processing (roi_heads.py:1075-1176, the reference's variant that also reports background boxes),
-// one call for the batch.  Per image two candidate lists: foreground (RoI x class >= 1) and background (RoIs without
-// any class above the score threshold, class-0 box); each list is sorted by decreasing score (ties: lower candidate
-// index, as a stable sort), goes through NMS (category = class) and the kept boxes are written fg first, then bg.
-//   k_det_candidates  per list slot: softmax, BoxCoder(10,10,5,5).decode, clip, score / size filters; also all_scores / all_boxes
-//   k_sort_lists      per list: bitonic sort in LDS (<= 16384 slots), gather into score order
-//   k_nms_mask / k_nms_scan (batched over the 2N lists),  k_det_output
+// one call for the batch.  Per image K candidate lists, one per class (class 0 = background: RoIs without any class above
+// the score threshold, class-0 box), slot = RoI:
+//   k_det_candidates  per (list, RoI): softmax, BoxCoder(10,10,5,5).decode, clip, score / size filters; also all_scores / all_boxes
+//   k_sort_lists      per list: bitonic sort by decreasing score (ties: lower RoI, as the reference's stable sort) in LDS, gather
+//   k_nms_mask_lists / k_nms_scan_lists  (a class list stops after detections_per_img kept boxes: it cannot contribute more)
+//   k_det_merge       kept candidates of the foreground lists -> decreasing score (ties: reference candidate index
+//                     RoI * (K-1) + class - 1) by rank computation, first detections_per_img, then the background list
 // ------------------------------------------------------------------------------------------------
 #define DET_SORT_MAX 16384
 struct DetPostArgs {
@@ -380,21 +528,20 @@ struct DetPostArgs {
     const float* props;           // [R][4]
     int roi_base[RPN_MAX_IMAGES + 1];
     float img_h[RPN_MAX_IMAGES], img_w[RPN_MAX_IMAGES];
-    int N, K, Kcap, det_per_img, out_cap;
+    int N, K, Rmax, det_per_img, out_cap;
     float score_thresh, min_size, clip, wx, wy, ww, wh;
     float* all_scores; float* all_boxes;                       // [R][K], [R][K][4]
-    float* boxes; float* skey; int* cat;                       // [2N][Kcap] candidate lists
-    float* s_boxes; float* s_score; int* s_cat; int* n_valid;   // sorted
+    float* boxes; float* skey;                                 // [N*K][Rmax] candidate lists
+    float* s_boxes; float* s_score; int* s_roi; int* n_valid;   // sorted
 };
 
 __global__ __launch_bounds__(256) void k_det_candidates(const DetPostArgs a) {
-    const int list = blockIdx.y, img = list >> 1, bg = list & 1;
-    const int slot = blockIdx.x * 256 + threadIdx.x;
-    if (slot >= a.Kcap) return;
+    const int list = blockIdx.y, img = list / a.K, k = list % a.K, bg = k == 0;
+    const int rl = blockIdx.x * 256 + threadIdx.x;
+    if (rl >= a.Rmax) return;
     const int Ri = a.roi_base[img + 1] - a.roi_base[img];
-    const int rl = bg ? slot : slot / (a.K - 1), k = bg ? 0 : slot % (a.K - 1) + 1;
-    const size_t o = (size_t)list * a.Kcap + slot;
-    if (rl >= Ri) { a.skey[o] = -1.0f; a.cat[o] = 0; reinterpret_cast<float4*>(a.boxes)[o] = make_float4(0.f, 0.f, 0.f, 0.f); return; }
+    const size_t o = (size_t)list * a.Rmax + rl;
+    if (rl >= Ri) { a.skey[o] = -1.0f; reinterpret_cast<float4*>(a.boxes)[o] = make_float4(0.f, 0.f, 0.f, 0.f); return; }
     const int r = a.roi_base[img] + rl;
     const float* lg = a.logits + (size_t)r * a.K;
     float mx = lg[0];
@@ -423,14 +570,12 @@ __global__ __launch_bounds__(256) void k_det_candidates(const DetPostArgs a) {
     const bool valid = big && (bg ? !has_fg_cand : score > a.score_thresh);
     reinterpret_cast<float4*>(a.boxes)[o] = make_float4(x1, y1, x2, y2);
     a.skey[o] = valid ? score : -1.0f;
-    a.cat[o] = k;
 }
 
 // one block per list: order = decreasing (score, then lower slot); n_valid = candidates with score >= 0
-__global__ __launch_bounds__(1024) void k_sort_lists(const float* __restrict__ skey, const float* __restrict__ boxes,
-                                                     const int* __restrict__ cat, int Kcap, float* __restrict__ s_boxes,
-                                                     float* __restrict__ s_score, int* __restrict__ s_cat,
-                                                     int* __restrict__ n_valid) {
+__global__ __launch_bounds__(1024) void k_sort_lists(const float* __restrict__ skey, const float* __restrict__ boxes, int Kcap,
+                                                     float* __restrict__ s_boxes, float* __restrict__ s_score,
+                                                     int* __restrict__ s_slot, int* __restrict__ n_valid) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long* v = reinterpret_cast<unsigned long long*>(smem);
     const int list = blockIdx.x, tid = threadIdx.x;
@@ -458,7 +603,7 @@ __global__ __launch_bounds__(1024) void k_sort_lists(const float* __restrict__ s
         reinterpret_cast<float4*>(s_boxes)[dst] = reinterpret_cast<const float4*>(boxes)[src];
         const float sc = skey[src];
         s_score[dst] = sc;
-        s_cat[dst] = cat[src];
+        s_slot[dst] = c;
         valid += sc >= 0.0f;
     }
     for (int off = 32; off > 0; off >>= 1) valid += __shfl_down(valid, off);
@@ -473,20 +618,64 @@ __global__ __launch_bounds__(1024) void k_sort_lists(const float* __restrict__ s
     }
 }
 
-__global__ __launch_bounds__(256) void k_det_output(const DetPostArgs a, const int* __restrict__ keep, const int* __restrict__ n_keep,
+#define DET_MERGE_MAX 8192                         // kept foreground candidates of an image that can be ranked ((K-1) * detections_per_img)
+__global__ __launch_bounds__(1024) void k_det_merge(const DetPostArgs a, const int* __restrict__ keep, const int* __restrict__ n_keep,
                                                     float* __restrict__ out_boxes, float* __restrict__ out_scores,
                                                     int* __restrict__ out_labels, int* __restrict__ out_counts) {
-    const int img = blockIdx.x;
-    const int n_fg = min(n_keep[2 * img], a.det_per_img), n_bg = n_keep[2 * img + 1];
-    for (int r = threadIdx.x; r < n_fg + n_bg; r += 256) {
-        const int list = r < n_fg ? 2 * img : 2 * img + 1;
-        const size_t src = (size_t)list * a.Kcap + keep[(size_t)list * a.Kcap + (r < n_fg ? r : r - n_fg)];
-        const size_t dst = (size_t)img * a.out_cap + r;
+    __shared__ float ks[DET_MERGE_MAX];             // score of the kept foreground candidates, class after class
+    __shared__ int ki[DET_MERGE_MAX];               // their reference candidate index: RoI * (K-1) + class - 1
+    __shared__ int kbase[NMS_MAX_CAT + 1];
+    const int img = blockIdx.x, tid = threadIdx.x, K = a.K;
+    if (tid == 0) {
+        int base = 0;
+        for (int c = 1; c < K; ++c) { kbase[c] = base; base += min(n_keep[img * K + c], a.det_per_img); }
+        kbase[K] = base;
+    }
+    __syncthreads();
+    const int total = kbase[K];
+    for (int i = tid; i < total; i += 1024) {
+        int c = 1;
+        while (i >= kbase[c + 1]) ++c;
+        const size_t src = (size_t)(img * K + c) * a.Rmax + keep[(size_t)(img * K + c) * a.Rmax + (i - kbase[c])];
+        ks[i] = a.s_score[src];
+        ki[i] = a.s_roi[src] * (K - 1) + (c - 1);
+    }
+    __syncthreads();
+    for (int i = tid; i < total; i += 1024) {
+        int c = 1;
+        while (i >= kbase[c + 1]) ++c;
+        const float sc = ks[i];
+        const int ci = ki[i];
+        int rank = i - kbase[c];
+        for (int c2 = 1; c2 < K; ++c2) {
+            if (c2 == c) continue;
+            int lo = 0, hi = kbase[c2 + 1] - kbase[c2];
+            const float* q = ks + kbase[c2];
+            const int* qi = ki + kbase[c2];
+            while (lo < hi) {                               // first entry of list c2 that does NOT precede (sc, ci)
+                const int mid = (lo + hi) >> 1;
+                const bool precedes = q[mid] > sc || (q[mid] == sc && qi[mid] < ci);
+                if (precedes) lo = mid + 1; else hi = mid;
+            }
+            rank += lo;
+        }
+        if (rank < a.det_per_img) {
+            const size_t src = (size_t)(img * K + c) * a.Rmax + keep[(size_t)(img * K + c) * a.Rmax + (i - kbase[c])];
+            const size_t dst = (size_t)img * a.out_cap + rank;
+            reinterpret_cast<float4*>(out_boxes)[dst] = reinterpret_cast<const float4*>(a.s_boxes)[src];
+            out_scores[dst] = sc;
+            out_labels[dst] = c;
+        }
+    }
+    const int n_fg = min(total, a.det_per_img), n_bg = n_keep[img * K];
+    for (int r = tid; r < n_bg; r += 1024) {                   // the surviving background boxes, in their own score order
+        const size_t src = (size_t)(img * K) * a.Rmax + keep[(size_t)(img * K) * a.Rmax + r];
+        const size_t dst = (size_t)img * a.out_cap + n_fg + r;
         reinterpret_cast<float4*>(out_boxes)[dst] = reinterpret_cast<const float4*>(a.s_boxes)[src];
         out_scores[dst] = a.s_score[src];
-        out_labels[dst] = a.s_cat[src];
+        out_labels[dst] = 0;
     }
-    if (threadIdx.x == 0) { out_counts[2 * img] = n_fg; out_counts[2 * img + 1] = n_bg; }
+    if (tid == 0) { out_counts[2 * img] = n_fg; out_counts[2 * img + 1] = n_bg; }
 }
 
 // impulse responses of the LI cell (norse leaky_integrator.py: li_feed_forward_step; v_leak = 0)

@@ -50,8 +50,8 @@ class RoIHeadsSNN(nn.Module):
             raise NotImplementedError("postprocess_detections needs %d box outputs per RoI (4 per class), got %d "
                                       "(only_one_bbox heads are not supported past the head, SURVEY.md appendix C.6)"
                                       % (4 * class_logits.shape[-1], box_regression.shape[-1]))
-        if (class_logits.is_cuda and self.post == "hip" and per_image and max(per_image) > 0
-                and max(per_image) * (class_logits.shape[-1] - 1) <= 16384):
+        if (class_logits.is_cuda and self.post == "hip" and per_image and 0 < max(per_image) <= 10000
+                and class_logits.shape[-1] <= 82):            # snn_det_postprocess: RoIs per image / classes it ranks in LDS
             return self._postprocess_hip(class_logits, box_regression, proposals, image_shapes, per_image)
         return self.postprocess_detections_reference(class_logits, box_regression, proposals, image_shapes)
 

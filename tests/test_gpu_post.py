@@ -105,3 +105,27 @@ def test_hip_det_postprocess_full_size_vs_oracle(gpu_device):
         assert np.abs(res[3][i].cpu().numpy() - exp[3][i].numpy()).max() <= 2e-6
         assert np.abs(res[4][i].cpu().numpy() - exp[4][i].numpy()).max() <= 1e-3
     _record("det_post_full", {"fg": 100, "bg": [int(exp[0][i].shape[0]) - 100 for i in range(2)], "min_iou_gap": st.get("min_gap")})
+
+
+def test_hip_det_postprocess_all_background_vs_oracle_and_repeatable(gpu_device):
+    """what a random-init detector produces: no class above the score threshold, all 1000 RoIs of an image go through the
+    background NMS (one list of 16 mask words) - against the oracle, five times over (the walk must be repeatable)"""
+    import snn_automotive_object_detection_amd as S
+    sp = dict(K=9, rois=[1000, 1000], image_shapes=[(768, 1536), (768, 1536)], seed=461, logit_std=0.05, delta_std=0.05)
+    logits, reg, props = FX.det_post_inputs(sp)
+    st = {}
+    exp = PO.det_postprocess(logits, reg, props, list(sp["image_shapes"]), stats=st)
+    heads = S.RoIHeadsSNN(None, None, 0.5, 0.5, 512, 0.25, None, 0.4, 0.5, 100)
+    dl, dr, dp_ = logits.to(gpu_device), reg.to(gpu_device), [p.to(gpu_device) for p in props]
+    first = None
+    for rep in range(5):
+        res = heads.postprocess_detections(dl, dr, dp_, list(sp["image_shapes"]))
+        cur = [(res[0][i].cpu(), res[1][i].cpu(), res[2][i].cpu()) for i in range(2)]
+        if first is None:
+            first = cur
+            for i in range(2):
+                assert int((cur[i][2] > 0).sum()) == 0 and exp[0][i].shape[0] > 200
+                assert_same_detections(cur[i][0].numpy(), cur[i][1].numpy(), exp[0][i].numpy(), exp[1][i].numpy(), what="image %d" % i)
+        else:
+            assert all(torch.equal(a, b) for x, y in zip(first, cur) for a, b in zip(x, y)), "repeat %d differs" % rep
+    _record("det_post_all_background", {"bg": [int(exp[0][i].shape[0]) for i in range(2)], "min_iou_gap": st.get("min_gap")})

@@ -181,7 +181,8 @@ int snn_nms_sorted(const float* boxes_sorted, const int* category_sorted, int n,
                    int* keep_out, int* n_keep_out, void* workspace, size_t workspace_bytes, snn_stream_t stream);
 
 /* ---- RPN proposal selection (rpn.py:420-499: per-level top-k, box decode, sigmoid, clip, size / score filters,
- * per-level NMS, post_nms_top_n) for the whole batch in six launches, no host synchronisation ----------------
+ * per-level NMS, post_nms_top_n) for the whole batch in five launches, no host synchronisation ---------------
+ * (top-k + sort per level, decode, NMS mask and NMS walk with one list per (image, level), rank merge of the kept candidates)
  * Inputs are the head's own position-major outputs.  The K candidates of an image are in the reference's order (level by
  * level, inside a level by decreasing logit as objectness.topk returns them, equal logits by element index); pre_boxes /
  * pre_prob report them in that order (rpn.py:493-499).  Equal sigmoid values keep that order in the NMS walk, like the
@@ -203,11 +204,12 @@ int snn_rpn_proposals(const snn_rpn_post_level* levels, int n_levels, int N, int
                       snn_stream_t stream);
 
 /* ---- detection post-processing (roi_heads.py:1075-1176, incl. the reference's background-box report): softmax,
- * per-class box decode, clip, score / size filters, per-class NMS, detections_per_img - five
+ * per-class box decode, clip, score / size filters, per-class NMS (one list per (image, class)), detections_per_img - five
  * launches for the batch, no host synchronisation.  Rows of image i in out_* [N][out_cap]: out_counts[2i] foreground
  * detections by decreasing score, then out_counts[2i+1] background boxes (RoIs without any class above the score
  * threshold).  all_scores [R][K] / all_boxes [R][K][4] receive the softmax scores and clipped boxes of every class.
- * out_cap >= detections_per_img + max RoIs per image; (K-1) * max RoIs per image <= 16384, else -4. */
+ * out_cap >= detections_per_img + max RoIs per image; max RoIs per image <= 10240, K <= 96 and
+ * (K-1) * detections_per_img <= 8192, else -4. */
 size_t snn_det_postprocess_workspace_bytes(int N, int max_rois_per_image, int K);
 int snn_det_postprocess(const float* class_logits, const float* box_regression, const float* proposals,
                         const int* rois_per_image_host, int N, int K, const float* image_hw_host,

@@ -311,6 +311,8 @@ __device__ __forceinline__ uint32_t f2key(float f) {           // monotone: larg
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
+#define TOPK_U 4                                    // loads in flight per thread (16 measured equal: the kernel is bound by the
+                                                    // vector throughput of the ONE CU a (level, image) block runs on)
 __global__ __launch_bounds__(1024) void k_rpn_topk(const RpnPostArgs a) {
     const RpnPostLevel& L = a.lv[blockIdx.x];
     const int img = blockIdx.y, tid = threadIdx.x;
@@ -328,35 +330,63 @@ __global__ __launch_bounds__(1024) void k_rpn_topk(const RpnPostArgs a) {
         // a handful of bins: plain LDS atomics serialise on them (0.38 ms for the 221 184 logits of the stride-4 level).
         // Two rounds of wave aggregation first - the lanes that share the leader's bin send ONE add - then plain atomics
         // for what is left (spread keys lose two ballots, clustered keys lose 98 % of their atomics).
-        for (int e0 = 0; e0 < L.n; e0 += 1024) {
-            const int e = e0 + tid;
-            const uint32_t key = e < L.n ? f2key(src[e]) : 0u;
-            bool act = e < L.n && (key & pmask) == prefix;
-            const uint32_t bin = (key >> shifts[pass]) & bm;
-            const int lane = tid & 63;
+        // (TOPK_U independent loads per thread in flight: one work-group streams the 221 184 logits of the stride-4 level
+        // four times, one round trip per iteration)
+        for (int e0 = 0; e0 < L.n; e0 += TOPK_U * 1024) {
+            uint32_t keys[TOPK_U];
 #pragma unroll
-            for (int round = 0; round < 2; ++round) {
-                const unsigned long long m = __ballot(act);
-                if (m == 0ull) break;
-                const int leader = __ffsll((long long)m) - 1;
-                const uint32_t lb = (uint32_t)__shfl((int)bin, leader);
-                const bool same = act && bin == lb;
-                const unsigned long long sm = __ballot(same);
-                if (lane == leader) atomicAdd(&hist[lb], (uint32_t)__popcll(sm));
-                act = act && !same;
+            for (int u = 0; u < TOPK_U; ++u) {
+                const int e = e0 + u * 1024 + tid;
+                keys[u] = e < L.n ? f2key(src[e]) : 0u;
             }
-            if (act) atomicAdd(&hist[bin], 1u);
+#pragma unroll
+            for (int u = 0; u < TOPK_U; ++u) {
+                const int e = e0 + u * 1024 + tid;
+                const uint32_t key = keys[u];
+                bool act = e < L.n && (key & pmask) == prefix;
+                const uint32_t bin = (key >> shifts[pass]) & bm;
+                const int lane = tid & 63;
+#ifndef SNN_EXP_TOPK_PLAIN
+#pragma unroll
+                for (int round = 0; round < 2; ++round) {
+                    const unsigned long long m = __ballot(act);
+                    if (m == 0ull) break;
+                    const int leader = __ffsll((long long)m) - 1;
+                    const uint32_t lb = (uint32_t)__shfl((int)bin, leader);
+                    const bool same = act && bin == lb;
+                    const unsigned long long sm = __ballot(same);
+                    if (lane == leader) atomicAdd(&hist[lb], (uint32_t)__popcll(sm));
+                    act = act && !same;
+                }
+#endif
+                if (act) atomicAdd(&hist[bin], 1u);
+            }
         }
         __syncthreads();
-        if (tid == 0) {                       // walk the bins from the top until `need` keys are covered
-            uint32_t cum = 0;
-            int b = (int)bm;
-            for (; b > 0; --b) {
-                if (cum + hist[b] >= need) break;
-                cum += hist[b];
+        // the bin in which the count of keys, taken from the top bin down, reaches `need`: a block-wide scan (thread r counts
+        // bins 2047 - 2r and 2046 - 2r; the first version walked the 2048 bins with one thread: 0.12 ms per pass of dependent
+        // LDS reads, most of this kernel's 0.4 ms)
+        {
+            const int r = tid, b_hi = 2047 - 2 * r, b_lo = 2046 - 2 * r;
+            const uint32_t h_hi = hist[b_hi], h_lo = hist[b_lo];
+            uint32_t v = h_hi + h_lo, inc = v;
+            const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t o = (uint32_t)__shfl_up((int)inc, off);
+                if (lane >= off) inc += o;
             }
-            s_prefix = prefix | ((uint32_t)b << shifts[pass]);
-            s_need = need - cum;              // taken from bin b (all bins above it are taken whole)
+            __shared__ uint32_t wtot[16];
+            if (lane == 63) wtot[wv] = inc;
+            if (tid == 0) { s_prefix = prefix; s_need = need; }          // (fewer than `need` keys match: bin 0, as before)
+            __syncthreads();
+            uint32_t before = inc - v;                                    // keys in the bins above this thread's two
+            for (int w = 0; w < wv; ++w) before += wtot[w];
+            if (before < need && need <= before + h_hi) {
+                s_prefix = prefix | ((uint32_t)b_hi << shifts[pass]); s_need = need - before;
+            } else if (before + h_hi < need && need <= before + v) {
+                s_prefix = prefix | ((uint32_t)b_lo << shifts[pass]); s_need = need - before - h_hi;
+            }
         }
         __syncthreads();
         prefix = s_prefix; need = s_need;
@@ -380,13 +410,22 @@ __global__ __launch_bounds__(1024) void k_rpn_topk(const RpnPostArgs a) {
     float* out_logit = a.cand_logit + (size_t)img * a.Ktot + L.koff;
     const uint32_t n_gt = (uint32_t)L.k - need;
     const bool ordered_ties = s_eq_total > need;
-    for (int e = tid; e < L.n; e += 1024) {
-        const float x = src[e];
-        const uint32_t key = f2key(x);
-        int slot = -1;
-        if (key > prefix) slot = (int)atomicAdd(&s_cnt_gt, 1u);
-        else if (key == prefix && !ordered_ties) slot = (int)(n_gt + atomicAdd(&s_cnt_eq, 1u));
-        if (slot >= 0) sel[slot] = ((unsigned long long)key << 32) | (uint32_t)(~(uint32_t)e);
+    for (int e0 = 0; e0 < L.n; e0 += TOPK_U * 1024) {
+        uint32_t keys[TOPK_U];
+#pragma unroll
+        for (int u = 0; u < TOPK_U; ++u) {
+            const int e = e0 + u * 1024 + tid;
+            keys[u] = e < L.n ? f2key(src[e]) : 0u;                 // (key 0 is below every real key: never selected)
+        }
+#pragma unroll
+        for (int u = 0; u < TOPK_U; ++u) {
+            const int e = e0 + u * 1024 + tid;
+            const uint32_t key = keys[u];
+            int slot = -1;
+            if (e < L.n && key > prefix) slot = (int)atomicAdd(&s_cnt_gt, 1u);
+            else if (e < L.n && key == prefix && !ordered_ties) slot = (int)(n_gt + atomicAdd(&s_cnt_eq, 1u));
+            if (slot >= 0) sel[slot] = ((unsigned long long)key << 32) | (uint32_t)(~(uint32_t)e);
+        }
     }
     if (ordered_ties) {
         __shared__ uint32_t wsum[16];

@@ -181,8 +181,9 @@ int snn_nms_sorted(const float* boxes_sorted, const int* category_sorted, int n,
                    int* keep_out, int* n_keep_out, void* workspace, size_t workspace_bytes, snn_stream_t stream);
 
 /* ---- RPN proposal selection (rpn.py:420-499: per-level top-k, box decode, sigmoid, clip, size / score filters,
- * per-level NMS, post_nms_top_n) for the whole batch in five launches, no host synchronisation ---------------
- * (top-k + sort per level, decode, NMS mask and NMS walk with one list per (image, level), rank merge of the kept candidates)
+ * per-level NMS, post_nms_top_n) for the whole batch, no host synchronisation ---------------
+ * (multi-block radix select + sort per level, decode, NMS mask and NMS walk with one list per (image, level), rank merge of the
+ * kept candidates: 12 small launches)
  * Inputs are the head's own position-major outputs.  The K candidates of an image are in the reference's order (level by
  * level, inside a level by decreasing logit as objectness.topk returns them, equal logits by element index); pre_boxes /
  * pre_prob report them in that order (rpn.py:493-499).  Equal sigmoid values keep that order in the NMS walk, like the

@@ -1083,17 +1083,18 @@ int snn_rpn_proposals_candidates(const snn_rpn_post_level* lv, int n_levels, int
 
 // workspace of snn_rpn_proposals: candidates of the batch + one NMS list per (image, level)
 // (mask_words = mask words per image: sum over the levels of k_l * ceil(k_l / 64) <= K * ceil(K / 64))
-static size_t rpn_post_layout(int N, int K, size_t mask_words, size_t off[9]) {
-    const size_t nk = (size_t)N * K;
-    const size_t sz[9] = {nk * 4, nk * 4, nk * 16, nk * 16, nk * 4, nk * 4, nk * 4, (size_t)N * SNN_MAX_LEVELS * 4,
-                          (size_t)N * mask_words * 8};
+static size_t rpn_post_layout(int N, int K, size_t mask_words, size_t off[13]) {
+    const size_t nk = (size_t)N * K, lists = (size_t)N * SNN_MAX_LEVELS;
+    const size_t sz[13] = {nk * 4, nk * 4, nk * 16, nk * 16, nk * 4, nk * 4, nk * 4, lists * 4,
+                           (size_t)N * mask_words * 8,
+                           lists * sizeof(TopkState), lists * 2048 * 4, lists * TOPK_CH * 1024 * 4, lists * (size_t)K * 8};
     size_t o = 0;
-    for (int i = 0; i < 9; ++i) { off[i] = o; o += align_up(sz[i], 256); }
+    for (int i = 0; i < 13; ++i) { off[i] = o; o += align_up(sz[i], 256); }
     return o;
 }
 
 size_t snn_rpn_proposals_workspace_bytes(int N, int K_candidates) {
-    size_t off[9];
+    size_t off[13];
     // (the level split is not known here: one list of K candidates per image bounds every split)
     return (N > 0 && K_candidates > 0) ? rpn_post_layout(N, K_candidates, (size_t)K_candidates * cdiv(K_candidates, 64), off) : 0;
 }
@@ -1130,7 +1131,7 @@ int snn_rpn_proposals(const snn_rpn_post_level* lv, int n_levels, int N, int A, 
         mask_words += (size_t)L.k * cdiv(L.k, 64);
         kmax = max(kmax, L.k);
     }
-    size_t off[9];
+    size_t off[13];
     if (ws_bytes < rpn_post_layout(N, K, mask_words, off)) return fail(-2, "snn_rpn_proposals: workspace too small");
     for (int i = 0; i < N; ++i) { a.img_h[i] = image_hw_host[2 * i]; a.img_w[i] = image_hw_host[2 * i + 1]; }
     a.n_levels = n_levels; a.N = N; a.A = A; a.Ktot = K; a.post_n = post_nms_top_n;
@@ -1142,8 +1143,24 @@ int snn_rpn_proposals(const snn_rpn_post_level* lv, int n_levels, int N, int A, 
     int* keep = (int*)(w + off[6]);
     int* n_keep = (int*)(w + off[7]);
     unsigned long long* mask = (unsigned long long*)(w + off[8]);
-    hipLaunchKernelGGL(k_rpn_topk, dim3(n_levels, N), dim3(1024), 0, s, a);
-    SNN_CHECK_LAUNCH("k_rpn_topk");
+    {   // top-k per (level, image): three (histogram, pick) rounds, gather, sort
+        TopkState* st = (TopkState*)(w + off[9]);
+        uint32_t* g_hist = (uint32_t*)(w + off[10]);
+        uint32_t* g_hist3 = (uint32_t*)(w + off[11]);
+        unsigned long long* sel = (unsigned long long*)(w + off[12]);
+        const int lists = N * n_levels;
+        if (hipMemsetAsync(g_hist, 0, (size_t)lists * 2048 * 4, s) != hipSuccess) return fail(-3, "hipMemsetAsync failed");
+        for (int pass = 0; pass < 3; ++pass) {
+            hipLaunchKernelGGL(k_topk_hist, dim3(TOPK_CH, n_levels, N), dim3(256), 0, s, a, pass, st, g_hist, g_hist3);
+            SNN_CHECK_LAUNCH("k_topk_hist");
+            hipLaunchKernelGGL(k_topk_pick, dim3(lists), dim3(1024), 0, s, a, pass, st, g_hist);
+            SNN_CHECK_LAUNCH("k_topk_pick");
+        }
+        hipLaunchKernelGGL(k_topk_gather, dim3(TOPK_CH, n_levels, N), dim3(256), 0, s, a, st, g_hist3, sel, K);
+        SNN_CHECK_LAUNCH("k_topk_gather");
+        hipLaunchKernelGGL(k_topk_sort, dim3(n_levels, N), dim3(1024), 0, s, a, sel, K);
+        SNN_CHECK_LAUNCH("k_topk_sort");
+    }
     hipLaunchKernelGGL(k_rpn_decode, dim3(cdiv((long long)N * K, 256)), dim3(256), 0, s, a);
     SNN_CHECK_LAUNCH("k_rpn_decode");
     // NMS: one list per (image, level) - the candidates of a level already are in score order (k_rpn_topk), the filtered

@@ -275,8 +275,9 @@ __global__ __launch_bounds__(256) void k_nms_scan_lists(const NmsLists nl, const
 
 // ------------------------------------------------------------------------------------------------
 // RPN proposal selection (rpn.py:420-499 + 262-296 + the box coder), one call for the batch:
-//   k_rpn_topk    per (level, image): the pre_nms_top_n largest logits by a 3-pass radix select (11+11+10 bits), then sorted
-//                 by decreasing logit: candidate slots are in the reference's order (level, rank inside the level)
+//   k_topk_*      per (level, image): the pre_nms_top_n largest logits by a 3-pass radix select (11+11+10 bits) over
+//                 TOPK_CH work-groups per list, then sorted by decreasing logit: candidate slots are in the reference's
+//                 order (level, rank inside the level)
 //   k_rpn_decode  per candidate: anchor from the level geometry, box decode, sigmoid, clip, size/score filters; the decoded
 //                 un-clipped boxes + probabilities of ALL candidates are the reference's pre-NMS report (rpn.py:493-499)
 //   k_nms_mask_lists / k_nms_scan_lists   one list per (image, level): its candidates already are in score order
@@ -311,154 +312,158 @@ __device__ __forceinline__ uint32_t f2key(float f) {           // monotone: larg
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-#define TOPK_U 4                                    // loads in flight per thread (16 measured equal: the kernel is bound by the
-                                                    // vector throughput of the ONE CU a (level, image) block runs on)
-__global__ __launch_bounds__(1024) void k_rpn_topk(const RpnPostArgs a) {
-    const RpnPostLevel& L = a.lv[blockIdx.x];
-    const int img = blockIdx.y, tid = threadIdx.x;
+// ---- top-k per (level, image): 3-pass radix select (11 + 11 + 10 key bits) spread over TOPK_CH work-groups per list --------
+// Round 1 ran one work-group per list: four sweeps over the 221 184 logits of the stride-4 level on ONE CU (0.3-0.45 ms, the
+// largest kernel of the RPN post-processing).  Now every sweep is its own launch over TOPK_CH chunks per list:
+//   k_topk_hist   chunk histogram of the key bits of this pass in LDS (one round of wave aggregation: objectness logits share
+//                 their high bits, so most keys of a wave fall into one bin), non-empty bins added to the list's histogram
+//   k_topk_pick   the bin in which the count of keys, from the top bin down, reaches `need` (block-wide scan) -> next prefix
+//   k_topk_gather keys above the k-th key take slots by atomic counter; keys EQUAL to it are taken in element order (the
+//                 chunk's first tie rank = ties of the chunks before it, from the per-chunk histograms of the last pass)
+//   k_topk_sort   the k selected (key, ~index) pairs sorted in LDS: candidate slots come out in the reference's order
+//                 (objectness.topk: decreasing logit; equal logits by element index here)
+#define TOPK_CH 32
+struct TopkState { uint32_t prefix, need, cnt_gt, pad; };
+
+__global__ __launch_bounds__(256) void k_topk_hist(const RpnPostArgs a, int pass, const TopkState* __restrict__ state,
+                                                   uint32_t* __restrict__ g_hist, uint32_t* __restrict__ g_hist3) {
+    const RpnPostLevel& L = a.lv[blockIdx.y];
+    const int img = blockIdx.z, list = img * a.n_levels + blockIdx.y, ch = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const float* src = L.logits + (size_t)img * L.n;
+    const int chunk = (L.n + TOPK_CH - 1) / TOPK_CH, lo = ch * chunk, hi = min(L.n, lo + chunk);
+    const int shift = pass == 0 ? 21 : (pass == 1 ? 10 : 0);
+    const uint32_t bm = pass == 2 ? 1023u : 2047u;
+    const uint32_t pmask = pass == 0 ? 0u : (pass == 1 ? 0xFFE00000u : 0xFFFFFC00u);
+    const uint32_t prefix = pass == 0 ? 0u : state[list].prefix;
     __shared__ uint32_t hist[2048];
-    __shared__ uint32_t s_prefix, s_need, s_cnt_gt, s_cnt_eq;
-    uint32_t prefix = 0, pmask = 0;           // bits of the k-th largest key decided so far
-    uint32_t need = (uint32_t)L.k;            // how many are still to be taken among keys matching the prefix
-    const int shifts[3] = {21, 10, 0}, bits[3] = {11, 11, 10};
-    for (int pass = 0; pass < 3; ++pass) {
-        for (int b = tid; b < 2048; b += 1024) hist[b] = 0;
-        __syncthreads();
-        const uint32_t bm = (1u << bits[pass]) - 1u;
-        // Objectness logits of one level share their high bits (a narrow range of values), so most keys of a pass fall into
-        // a handful of bins: plain LDS atomics serialise on them (0.38 ms for the 221 184 logits of the stride-4 level).
-        // Two rounds of wave aggregation first - the lanes that share the leader's bin send ONE add - then plain atomics
-        // for what is left (spread keys lose two ballots, clustered keys lose 98 % of their atomics).
-        // (TOPK_U independent loads per thread in flight: one work-group streams the 221 184 logits of the stride-4 level
-        // four times, one round trip per iteration)
-        for (int e0 = 0; e0 < L.n; e0 += TOPK_U * 1024) {
-            uint32_t keys[TOPK_U];
-#pragma unroll
-            for (int u = 0; u < TOPK_U; ++u) {
-                const int e = e0 + u * 1024 + tid;
-                keys[u] = e < L.n ? f2key(src[e]) : 0u;
-            }
-#pragma unroll
-            for (int u = 0; u < TOPK_U; ++u) {
-                const int e = e0 + u * 1024 + tid;
-                const uint32_t key = keys[u];
-                bool act = e < L.n && (key & pmask) == prefix;
-                const uint32_t bin = (key >> shifts[pass]) & bm;
-                const int lane = tid & 63;
-#ifndef SNN_EXP_TOPK_PLAIN
-#pragma unroll
-                for (int round = 0; round < 2; ++round) {
-                    const unsigned long long m = __ballot(act);
-                    if (m == 0ull) break;
-                    const int leader = __ffsll((long long)m) - 1;
-                    const uint32_t lb = (uint32_t)__shfl((int)bin, leader);
-                    const bool same = act && bin == lb;
-                    const unsigned long long sm = __ballot(same);
-                    if (lane == leader) atomicAdd(&hist[lb], (uint32_t)__popcll(sm));
-                    act = act && !same;
-                }
-#endif
-                if (act) atomicAdd(&hist[bin], 1u);
-            }
-        }
-        __syncthreads();
-        // the bin in which the count of keys, taken from the top bin down, reaches `need`: a block-wide scan (thread r counts
-        // bins 2047 - 2r and 2046 - 2r; the first version walked the 2048 bins with one thread: 0.12 ms per pass of dependent
-        // LDS reads, most of this kernel's 0.4 ms)
-        {
-            const int r = tid, b_hi = 2047 - 2 * r, b_lo = 2046 - 2 * r;
-            const uint32_t h_hi = hist[b_hi], h_lo = hist[b_lo];
-            uint32_t v = h_hi + h_lo, inc = v;
-            const int lane = tid & 63, wv = tid >> 6;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const uint32_t o = (uint32_t)__shfl_up((int)inc, off);
-                if (lane >= off) inc += o;
-            }
-            __shared__ uint32_t wtot[16];
-            if (lane == 63) wtot[wv] = inc;
-            if (tid == 0) { s_prefix = prefix; s_need = need; }          // (fewer than `need` keys match: bin 0, as before)
-            __syncthreads();
-            uint32_t before = inc - v;                                    // keys in the bins above this thread's two
-            for (int w = 0; w < wv; ++w) before += wtot[w];
-            if (before < need && need <= before + h_hi) {
-                s_prefix = prefix | ((uint32_t)b_hi << shifts[pass]); s_need = need - before;
-            } else if (before + h_hi < need && need <= before + v) {
-                s_prefix = prefix | ((uint32_t)b_lo << shifts[pass]); s_need = need - before - h_hi;
-            }
-        }
-        __syncthreads();
-        prefix = s_prefix; need = s_need;
-        pmask |= bm << shifts[pass];
-        __syncthreads();
-    }
-    // prefix = key of the k-th largest logit; `need` of the keys equal to it are taken: those with the lowest element
-    // index (deterministic; an ordered pass with a block scan, run only when there are more ties than needed)
-    // The selected candidates are then put in the reference's order - objectness.topk(k) returns them by decreasing logit
-    // (rpn.py:413), equal logits by increasing element index here - with a bitonic sort of (logit key, ~index) in LDS: the
-    // candidate slot koff + rank IS the position the reference gives the candidate, which later breaks ties between equal
-    // sigmoid values exactly like the reference's stable order (fp32 sigmoid merges many distinct logits).
-    __shared__ unsigned long long sel[RPN_SORT_MAX];
-    __shared__ uint32_t s_eq_total;
-    if (tid == 0) { s_cnt_gt = 0; s_cnt_eq = 0; s_eq_total = hist[prefix & 1023u]; }
-    int np2 = 1;
-    while (np2 < L.k) np2 <<= 1;
-    for (int i = L.k + tid; i < np2; i += 1024) sel[i] = 0ull;          // padding sorts last
+    for (int b = tid; b < 2048; b += 256) hist[b] = 0;
     __syncthreads();
-    int* out_idx = a.cand_idx + (size_t)img * a.Ktot + L.koff;
-    float* out_logit = a.cand_logit + (size_t)img * a.Ktot + L.koff;
-    const uint32_t n_gt = (uint32_t)L.k - need;
-    const bool ordered_ties = s_eq_total > need;
-    for (int e0 = 0; e0 < L.n; e0 += TOPK_U * 1024) {
-        uint32_t keys[TOPK_U];
+    for (int e0 = lo; e0 < hi; e0 += 1024) {
+        uint32_t keys[4];
 #pragma unroll
-        for (int u = 0; u < TOPK_U; ++u) {
-            const int e = e0 + u * 1024 + tid;
-            keys[u] = e < L.n ? f2key(src[e]) : 0u;                 // (key 0 is below every real key: never selected)
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u * 256 + tid;
+            keys[u] = e < hi ? f2key(src[e]) : 0u;
         }
 #pragma unroll
-        for (int u = 0; u < TOPK_U; ++u) {
-            const int e = e0 + u * 1024 + tid;
-            const uint32_t key = keys[u];
-            int slot = -1;
-            if (e < L.n && key > prefix) slot = (int)atomicAdd(&s_cnt_gt, 1u);
-            else if (e < L.n && key == prefix && !ordered_ties) slot = (int)(n_gt + atomicAdd(&s_cnt_eq, 1u));
-            if (slot >= 0) sel[slot] = ((unsigned long long)key << 32) | (uint32_t)(~(uint32_t)e);
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u * 256 + tid;
+            bool act = e < hi && (keys[u] & pmask) == prefix;
+            const uint32_t bin = (keys[u] >> shift) & bm;
+            const unsigned long long m = __ballot(act);
+            if (m != 0ull) {                                     // one round of wave aggregation on the leader's bin
+                const int leader = __ffsll((long long)m) - 1;
+                const uint32_t lb = (uint32_t)__shfl((int)bin, leader);
+                const bool same = act && bin == lb;
+                const unsigned long long sm = __ballot(same);
+                if (lane == leader) atomicAdd(&hist[lb], (uint32_t)__popcll(sm));
+                act = act && !same;
+            }
+            if (act) atomicAdd(&hist[bin], 1u);
         }
     }
-    if (ordered_ties) {
-        __shared__ uint32_t wsum[16];
-        uint32_t taken = 0;                   // block-uniform
-        for (int e0 = 0; e0 < L.n && taken < need; e0 += 1024) {
-            const int e = e0 + tid;
-            const bool tie = e < L.n && f2key(src[e]) == prefix;
+    __syncthreads();
+    for (int b = tid; b < 2048; b += 256) {
+        const uint32_t v = hist[b];
+        if (v) atomicAdd(&g_hist[(size_t)list * 2048 + b], v);
+        if (pass == 2 && b < 1024) g_hist3[((size_t)list * TOPK_CH + ch) * 1024 + b] = v;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_topk_pick(const RpnPostArgs a, int pass, TopkState* __restrict__ state,
+                                                    uint32_t* __restrict__ g_hist) {
+    const int list = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const RpnPostLevel& L = a.lv[list % a.n_levels];
+    const int shift = pass == 0 ? 21 : (pass == 1 ? 10 : 0);
+    const uint32_t prefix = pass == 0 ? 0u : state[list].prefix, need = pass == 0 ? (uint32_t)L.k : state[list].need;
+    uint32_t* h = g_hist + (size_t)list * 2048;
+    // thread r counts bins 2047 - 2r and 2046 - 2r: `before` = keys in the bins above them
+    const int b_hi = 2047 - 2 * tid, b_lo = 2046 - 2 * tid;
+    const uint32_t h_hi = h[b_hi], h_lo = h[b_lo];
+    h[b_hi] = 0; h[b_lo] = 0;                                    // ready for the next pass / the next call
+    uint32_t v = h_hi + h_lo, inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)inc, off);
+        if (lane >= off) inc += o;
+    }
+    __shared__ uint32_t wtot[16];
+    __shared__ uint32_t s_prefix, s_need;
+    if (lane == 63) wtot[wv] = inc;
+    if (tid == 0) { s_prefix = prefix; s_need = need; }          // (fewer than `need` keys match: bin 0)
+    __syncthreads();
+    uint32_t before = inc - v;
+    for (int w = 0; w < wv; ++w) before += wtot[w];
+    if (before < need && need <= before + h_hi) { s_prefix = prefix | ((uint32_t)b_hi << shift); s_need = need - before; }
+    else if (before + h_hi < need && need <= before + v) { s_prefix = prefix | ((uint32_t)b_lo << shift); s_need = need - before - h_hi; }
+    __syncthreads();
+    if (tid == 0) { state[list].prefix = s_prefix; state[list].need = s_need; state[list].cnt_gt = 0; }
+}
+
+__global__ __launch_bounds__(256) void k_topk_gather(const RpnPostArgs a, TopkState* __restrict__ state,
+                                                     const uint32_t* __restrict__ g_hist3, unsigned long long* __restrict__ sel,
+                                                     int kcap) {
+    const RpnPostLevel& L = a.lv[blockIdx.y];
+    const int img = blockIdx.z, list = img * a.n_levels + blockIdx.y, ch = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const float* src = L.logits + (size_t)img * L.n;
+    const int chunk = (L.n + TOPK_CH - 1) / TOPK_CH, lo = ch * chunk, hi = min(L.n, lo + chunk);
+    const uint32_t prefix = state[list].prefix, need = state[list].need, n_gt = (uint32_t)L.k - need;
+    unsigned long long* out = sel + (size_t)list * kcap;
+    // ties of the chunks before this one (element order = chunk order)
+    __shared__ uint32_t s_base;
+    __shared__ uint32_t wsum[4];
+    if (tid < 64) {
+        uint32_t t = 0;
+        for (int c = tid; c < ch; c += 64) t += g_hist3[((size_t)list * TOPK_CH + c) * 1024 + (prefix & 1023u)];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) t += (uint32_t)__shfl_xor((int)t, off);
+        if (tid == 0) s_base = t;
+    }
+    __syncthreads();
+    uint32_t taken = s_base;                                     // block-uniform: tie rank of the next tie of this chunk
+    for (int e0 = lo; e0 < hi; e0 += 256) {
+        const int e = e0 + tid;
+        const uint32_t key = e < hi ? f2key(src[e]) : 0u;
+        if (e < hi && key > prefix) out[atomicAdd(&state[list].cnt_gt, 1u)] = ((unsigned long long)key << 32) | (uint32_t)(~(uint32_t)e);
+        if (taken < need) {                                      // block-uniform
+            const bool tie = e < hi && key == prefix;
             const unsigned long long bal = __ballot(tie);
-            const int lane = tid & 63, wv = tid >> 6;
             if (lane == 0) wsum[wv] = (uint32_t)__popcll(bal);
             __syncthreads();
             uint32_t before = 0, total = 0;
-            for (int w = 0; w < 16; ++w) { if (w < wv) before += wsum[w]; total += wsum[w]; }
+            for (int w = 0; w < 4; ++w) { if (w < wv) before += wsum[w]; total += wsum[w]; }
             const uint32_t rank = taken + before + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-            if (tie && rank < need) sel[n_gt + rank] = ((unsigned long long)prefix << 32) | (uint32_t)(~(uint32_t)e);
+            if (tie && rank < need) out[n_gt + rank] = ((unsigned long long)prefix << 32) | (uint32_t)(~(uint32_t)e);
             taken += total;
             __syncthreads();
         }
     }
+}
+
+__global__ __launch_bounds__(1024) void k_topk_sort(const RpnPostArgs a, const unsigned long long* __restrict__ sel, int kcap) {
+    const RpnPostLevel& L = a.lv[blockIdx.x];
+    const int img = blockIdx.y, list = img * a.n_levels + blockIdx.x, tid = threadIdx.x;
+    const float* src = L.logits + (size_t)img * L.n;
+    __shared__ unsigned long long v[RPN_SORT_MAX];
+    int np2 = 1;
+    while (np2 < L.k) np2 <<= 1;
+    for (int i = tid; i < np2; i += 1024) v[i] = i < L.k ? sel[(size_t)list * kcap + i] : 0ull;     // padding sorts last
     __syncthreads();
     for (int k = 2; k <= np2; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
             for (int i = tid; i < np2; i += 1024) {
                 const int p = i ^ j;
                 if (p > i) {
-                    const unsigned long long x = sel[i], y = sel[p];
-                    if (((i & k) == 0) ? x < y : x > y) { sel[i] = y; sel[p] = x; }
+                    const unsigned long long x = v[i], y = v[p];
+                    if (((i & k) == 0) ? x < y : x > y) { v[i] = y; v[p] = x; }
                 }
             }
             __syncthreads();
         }
+    int* out_idx = a.cand_idx + (size_t)img * a.Ktot + L.koff;
+    float* out_logit = a.cand_logit + (size_t)img * a.Ktot + L.koff;
     for (int i = tid; i < L.k; i += 1024) {
-        const int e = (int)(~(uint32_t)sel[i]);
+        const int e = (int)(~(uint32_t)v[i]);
         out_idx[i] = e;
         out_logit[i] = src[e];
     }

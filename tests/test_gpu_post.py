@@ -129,3 +129,40 @@ def test_hip_det_postprocess_all_background_vs_oracle_and_repeatable(gpu_device)
         else:
             assert all(torch.equal(a, b) for x, y in zip(first, cur) for a, b in zip(x, y)), "repeat %d differs" % rep
     _record("det_post_all_background", {"bg": [int(exp[0][i].shape[0]) for i in range(2)], "min_iou_gap": st.get("min_gap")})
+
+
+@pytest.mark.parametrize("levels", [[(64, 64)], [(40, 56), (3, 5)]])
+def test_rpn_topk_with_many_ties_is_the_stable_order(gpu_device, levels):
+    """the multi-block radix select on logits drawn from a handful of values: far more keys equal to the k-th one than needed,
+    spread over all chunks - the candidates must be the first pre_nms_top_n of a STABLE descending sort (logit, then element
+    index), in that order (objectness.topk leaves the order of equal logits unspecified; this is the documented choice)"""
+    from snn_automotive_object_detection_amd import ops
+    from snn_automotive_object_detection_amd.stock.anchors import AnchorGenerator, ImageList
+    g = torch.Generator().manual_seed(5)
+    N, A, pre = 2, 3, 1000
+    vals = torch.tensor([-1.0, -0.25, 0.0, 0.5, 2.0])
+    logits, deltas, hw, strides = [], [], [], []
+    canvas = (256, 256)
+    for (h, w) in levels:
+        lg = vals[torch.randint(0, 5, (N * h * w, A), generator=g)]
+        lg[:7, 0] = 3.5                                        # a few clear winners
+        logits.append(lg.to(gpu_device))
+        deltas.append(torch.zeros((N * h * w, 4 * A), device=gpu_device))      # proposals = anchors
+        hw.append((h, w)); strides.append((canvas[0] // h, canvas[1] // w))
+    ag = AnchorGenerator(FX.ANCHOR_SIZES[:len(levels)], FX.ASPECT_RATIOS[:len(levels)])
+    boxes, scores, counts, pre_b, pre_p = ops.rpn_proposals(logits, deltas, hw, strides, ag.cell_anchors, [canvas] * N, pre, 50, 0.7, 0.0, 1e-3)
+    feats = [torch.zeros((N, 1, h, w)) for h, w in levels]
+    anchors = ag(ImageList(torch.zeros((N, 3) + canvas), [canvas] * N), feats)[0]      # [sum H*W*A, 4] in (level, y, x, a) order
+    pos = 0
+    koff = 0
+    for l, (h, w) in enumerate(levels):
+        n = h * w * A
+        k = min(pre, n)
+        for i in range(N):
+            lg = logits[l].cpu().view(N, n)[i]
+            order = torch.sort(lg, descending=True, stable=True)[1][:k]
+            assert float((pre_p[i, koff:koff + k].cpu() - torch.sigmoid(lg[order])).abs().max()) <= 2e-6
+            assert torch.equal(pre_b[i, koff:koff + k].cpu(), anchors[pos:pos + n][order]), "level %d image %d" % (l, i)
+        pos += n
+        koff += k
+    assert int(counts.min()) > 0

@@ -129,6 +129,43 @@ DET_POST_SPECS = {
 }
 
 
+# RoI pairs whose IoU sits within ~1e-5 of the NMS threshold: torchvision's coordinate trick (<= 4000 coordinates: every class
+# shifted by label * (max coordinate + 1) before ONE nms) decides some of them differently from the raw coordinates
+DET_POST_SPECS["post_det_trick"] = dict(K=9, rois=[96, 96], image_shapes=[(768, 1536), (768, 1536)], seed=406, pairs=True)
+
+
+def _det_trick_inputs(spec):
+    K, s = spec["K"], spec["seed"]
+    R = sum(spec["rois"])
+    logits = np.zeros((R, K), dtype=np.float32)
+    reg = np.zeros((R, 4 * K), dtype=np.float32)                 # zero deltas: decoded box = proposal (up to an ulp)
+    props, base = [], 0
+    for i, (r, (h, w)) in enumerate(zip(spec["rois"], spec["image_shapes"])):
+        n_pairs = r // 2
+        u = PR.uniform((n_pairs, 6), s * 100 + 10 + i, 0.0, 1.0)
+        cls = 1 + (np.arange(n_pairs) % (K - 1))                 # class of the pair
+        cell = np.arange(n_pairs) // (K - 1)                     # pairs of one class sit in different cells (no interaction)
+        cx0 = 20 + (cell % 8) * 185.0
+        cy0 = 20 + (cell // 8) * 140.0
+        bw = (40 + 100 * u[:, 0]).astype(np.float32)
+        bh = (40 + 70 * u[:, 1]).astype(np.float32)
+        x1 = (cx0 + 10 * u[:, 2]).astype(np.float32)
+        y1 = (cy0 + 10 * u[:, 3]).astype(np.float32)
+        dx = (bw / 3 * (1.0 + (u[:, 4] - 0.5) * 4e-5)).astype(np.float32)      # IoU of the pair = 0.5 +- ~1e-5
+        a = np.stack([x1, y1, x1 + bw, y1 + bh], 1).astype(np.float32)
+        b = a.copy()
+        b[:, 0] += dx
+        b[:, 2] += dx
+        pr = np.empty((2 * n_pairs, 4), dtype=np.float32)
+        pr[0::2], pr[1::2] = a, b
+        props.append(_t(pr))
+        rows = base + np.arange(n_pairs) * 2
+        logits[rows, cls] = 8.5                                  # the first box of a pair scores higher: it is walked first
+        logits[rows + 1, cls] = 8.0
+        base += r
+    return _t(logits), _t(reg), props
+
+
 def rpn_post_inputs(spec):
     """-> (objectness [N,A,H,W] per level, deltas [N,4A,H,W] per level) as the head returns them (NCHW)"""
     N, A, s = len(spec["image_sizes"]), 3, spec["seed"]
@@ -162,6 +199,8 @@ def rpn_post_inputs(spec):
 
 def det_post_inputs(spec):
     """-> (class_logits [R,K], box_regression [R,4K], proposals: list of [R_i,4])"""
+    if spec.get("pairs"):
+        return _det_trick_inputs(spec)
     K, s = spec["K"], spec["seed"]
     R = sum(spec["rois"])
     logits = PR.normalish((R, K), s * 100 + 1, std=spec["logit_std"])

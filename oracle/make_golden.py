@@ -166,11 +166,19 @@ def gen_det_post(ref_roi, name, spec, out):
         for x, y in zip(a, b):
             assert x.dtype == y.dtype and torch.equal(x, y), "oracle != reference postprocess_detections (%s)" % name
     d = {"min_gap": np.array(st.get("min_gap", 1.0))}
+    # how many detections the result would have with IoUs on the raw coordinates (torchvision's > 4000-coordinate strategy)
+    real = TV.batched_nms
+    TV.batched_nms = lambda b, s_, i, t, stats=None: TV._batched_nms_vanilla(b, s_, i, t, stats)
+    try:
+        raw = PO.det_postprocess(logits, reg, props, list(spec["image_shapes"]))
+    finally:
+        TV.batched_nms = real
+    d["n_raw"] = np.array([int(b.shape[0]) for b in raw[0]], dtype=np.int64)
     for key, lst in zip(("boxes", "scores", "labels", "all_scores", "all_boxes"), res):
         _save_lists(d, key, list(lst))
     np.savez_compressed(os.path.join(out, name + ".npz"), **d)
-    print("wrote %-20s detections %s (fg %s), min |IoU - thr| %.2e" % (name, [int(b.shape[0]) for b in res[0]],
-          [int((l > 0).sum()) for l in res[2]], st.get("min_gap", 1.0)))
+    print("wrote %-20s detections %s (fg %s), min |IoU - thr| %.2e, with raw-coordinate IoUs %s" % (name, [int(b.shape[0]) for b in res[0]],
+          [int((l > 0).sum()) for l in res[2]], st.get("min_gap", 1.0), d["n_raw"].tolist()))
 
 
 def _exec_literal_forward(path, first, last):

@@ -1087,7 +1087,7 @@ static size_t rpn_post_layout(int N, int K, size_t mask_words, size_t off[13]) {
     const size_t nk = (size_t)N * K, lists = (size_t)N * SNN_MAX_LEVELS;
     const size_t sz[13] = {nk * 4, nk * 4, nk * 16, nk * 16, nk * 4, nk * 4, nk * 4, lists * 4,
                            (size_t)N * mask_words * 8,
-                           lists * sizeof(TopkState), lists * 2048 * 4, lists * TOPK_CH * 1024 * 4, lists * (size_t)K * 8};
+                           lists * sizeof(TopkState), lists * 2048 * 4 + 2 * lists * 4, lists * TOPK_CH * 1024 * 4, lists * (size_t)K * 8};
     size_t o = 0;
     for (int i = 0; i < 13; ++i) { off[i] = o; o += align_up(sz[i], 256); }
     return o;
@@ -1149,7 +1149,11 @@ int snn_rpn_proposals(const snn_rpn_post_level* lv, int n_levels, int N, int A, 
         uint32_t* g_hist3 = (uint32_t*)(w + off[11]);
         unsigned long long* sel = (unsigned long long*)(w + off[12]);
         const int lists = N * n_levels;
-        if (hipMemsetAsync(g_hist, 0, (size_t)lists * 2048 * 4, s) != hipSuccess) return fail(-3, "hipMemsetAsync failed");
+        // (behind the histograms: per-list count / largest coordinate of the candidates that pass the filters, for the NMS)
+        a.list_cnt = (int*)(g_hist + (size_t)N * SNN_MAX_LEVELS * 2048);
+        a.list_max = (uint32_t*)(a.list_cnt + (size_t)N * SNN_MAX_LEVELS);
+        if (hipMemsetAsync(g_hist, 0, ((size_t)N * SNN_MAX_LEVELS * 2048 + 2 * (size_t)N * SNN_MAX_LEVELS) * 4, s) != hipSuccess)
+            return fail(-3, "hipMemsetAsync failed");
         for (int pass = 0; pass < 3; ++pass) {
             hipLaunchKernelGGL(k_topk_hist, dim3(TOPK_CH, n_levels, N), dim3(256), 0, s, a, pass, st, g_hist, g_hist3);
             SNN_CHECK_LAUNCH("k_topk_hist");
@@ -1167,6 +1171,7 @@ int snn_rpn_proposals(const snn_rpn_post_level* lv, int n_levels, int N, int A, 
     // ones start out removed
     nl.boxes = a.boxes; nl.skey = a.skey; nl.n_dev = nullptr; nl.img_stride = K; nl.mask_img = (long long)mask_words; nl.L = n_levels;
     nl.max_keep0 = nl.max_keep = post_nms_top_n;
+    nl.trick_cnt = a.list_cnt; nl.trick_max = a.list_max; nl.trick_c0 = 0;     // all levels of an image are one batched_nms call
     const int wmax = cdiv(kmax, 64);
     hipLaunchKernelGGL(k_nms_mask_lists, dim3(wmax, wmax, N * n_levels), dim3(64), 0, s, nl, nms_thresh, mask);
     SNN_CHECK_LAUNCH("k_nms_mask_lists");
@@ -1183,7 +1188,7 @@ int snn_rpn_proposals(const snn_rpn_post_level* lv, int n_levels, int N, int A, 
 // ---- detection post-processing ------------------------------------------------------------------
 static size_t det_post_layout(int N, int K, int Rmax, size_t off[9]) {
     const size_t lk = (size_t)N * K * Rmax, L = (size_t)N * K;
-    const size_t sz[9] = {lk * 16, lk * 4, lk * 16, lk * 4, lk * 4, L * 4, lk * 4, L * 4, lk * cdiv(Rmax, 64) * 8};
+    const size_t sz[9] = {lk * 16, lk * 4, lk * 16, lk * 4, lk * 4, 2 * L * 4, lk * 4, L * 4, lk * cdiv(Rmax, 64) * 8};
     size_t o = 0;
     for (int i = 0; i < 9; ++i) { off[i] = o; o += align_up(sz[i], 256); }
     return o;
@@ -1241,10 +1246,11 @@ int snn_det_postprocess(const float* class_logits, const float* box_regression, 
     SNN_CHECK_LAUNCH("k_det_candidates");
     int np2 = 1;
     while (np2 < rmax) np2 <<= 1;
-    const size_t sort_lds = max((size_t)np2 * 8, (size_t)64);
+    const size_t sort_lds = max((size_t)np2 * 8, (size_t)256);
     hipError_t e = hipFuncSetAttribute((const void*)k_sort_lists, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds);
     if (e != hipSuccess) return fail(-3, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(k_sort_lists, dim3(L), dim3(1024), sort_lds, s, a.skey, a.boxes, rmax, a.s_boxes, a.s_score, a.s_roi, a.n_valid);
+    uint32_t* list_max = (uint32_t*)(a.n_valid + L);
+    hipLaunchKernelGGL(k_sort_lists, dim3(L), dim3(1024), sort_lds, s, a.skey, a.boxes, rmax, a.s_boxes, a.s_score, a.s_roi, a.n_valid, list_max);
     SNN_CHECK_LAUNCH("k_sort_lists");
     // NMS: one list per (image, class); a foreground class stops after detections_per_img kept boxes, the background list keeps all
     NmsLists nl;
@@ -1254,6 +1260,7 @@ int snn_det_postprocess(const float* class_logits, const float* box_regression, 
     nl.mask_img = (long long)K * rmax * wmax; nl.L = K;
     for (int c = 0; c < K; ++c) { nl.off[c] = c * rmax; nl.cap[c] = rmax; nl.moff[c] = (long long)c * rmax * wmax; }
     nl.max_keep0 = rmax; nl.max_keep = detections_per_img;
+    nl.trick_cnt = a.n_valid; nl.trick_max = list_max; nl.trick_c0 = 1;    // the foreground classes of an image are one batched_nms call
     hipLaunchKernelGGL(k_nms_mask_lists, dim3(wmax, wmax, L), dim3(64), 0, s, nl, nms_thresh, mask);
     SNN_CHECK_LAUNCH("k_nms_mask_lists");
     const size_t lds = (size_t)2 * 64 * wmax * 8;

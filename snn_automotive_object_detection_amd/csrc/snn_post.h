@@ -158,7 +158,27 @@ struct NmsLists {
     int cap[NMS_MAX_CAT];         // candidates of category c (capacity; the mask row of the list has ceil(cap / 64) words)
     long long moff[NMS_MAX_CAT];  // first mask word of category c inside the image
     int max_keep0, max_keep;      // walk stops after that many kept boxes (category 0 / the others)
+    // torchvision's batched_nms on the CPU (the reference's path) runs ONE nms over all categories of a call when the call has
+    // at most 4000 box coordinates, after shifting category c by c * (max coordinate + 1): the IoUs are then those of the SHIFTED
+    // fp32 coordinates, and one within ~1e-6 of the threshold can be decided differently from the raw coordinates.  Reproduced
+    // here: categories >= trick_c0 of an image form one call; trick_cnt / trick_max give, per list, its number of boxes and its
+    // largest coordinate (as float bits; all coordinates are >= 0).  nullptr: raw coordinates (the > 4000 strategy).
+    const int* trick_cnt;
+    const uint32_t* trick_max;
+    int trick_c0;
 };
+
+__device__ __forceinline__ float nms_trick_offset(const NmsLists& nl, int img, int c) {
+    if (!nl.trick_cnt || c < nl.trick_c0) return 0.0f;
+    int n = 0;
+    uint32_t mx = 0u;
+    for (int q = nl.trick_c0; q < nl.L; ++q) {
+        n += nl.trick_cnt[img * nl.L + q];
+        mx = max(mx, nl.trick_max[img * nl.L + q]);
+    }
+    if (4 * n > 4000) return 0.0f;                                // _batched_nms_vanilla: per category, raw coordinates
+    return __fmul_rn((float)c, __fadd_rn(__uint_as_float(mx), 1.0f));   // idxs.to(boxes) * (max_coordinate + 1)
+}
 
 __global__ __launch_bounds__(64) void k_nms_mask_lists(const NmsLists nl, float thr, unsigned long long* __restrict__ mask) {
     const int rb = blockIdx.y, cb = blockIdx.x, z = blockIdx.z, img = z / nl.L, c = z % nl.L;
@@ -171,14 +191,16 @@ __global__ __launch_bounds__(64) void k_nms_mask_lists(const NmsLists nl, float 
     __shared__ float cbx[64][4];
     const int t = threadIdx.x;
     const int j0 = cb * 64;
+    const float off = nms_trick_offset(nl, img, c);      // 0, or the category's shift of torchvision's coordinate trick
     if (j0 + t < n) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) cbx[t][q] = boxes[(size_t)(j0 + t) * 4 + q];
+        for (int q = 0; q < 4; ++q) cbx[t][q] = __fadd_rn(boxes[(size_t)(j0 + t) * 4 + q], off);
     }
     __syncthreads();
     const int i = rb * 64 + t;
     if (i >= n) return;
-    const float x1 = boxes[(size_t)i * 4], y1 = boxes[(size_t)i * 4 + 1], x2 = boxes[(size_t)i * 4 + 2], y2 = boxes[(size_t)i * 4 + 3];
+    const float x1 = __fadd_rn(boxes[(size_t)i * 4], off), y1 = __fadd_rn(boxes[(size_t)i * 4 + 1], off);
+    const float x2 = __fadd_rn(boxes[(size_t)i * 4 + 2], off), y2 = __fadd_rn(boxes[(size_t)i * 4 + 3], off);
     const float area_i = __fmul_rn(__fsub_rn(x2, x1), __fsub_rn(y2, y1));
     unsigned long long bits = 0;
     const int jn = min(64, n - j0);
@@ -305,6 +327,8 @@ struct RpnPostArgs {
     float* pre;                   // [N][Ktot][4] decoded, un-clipped
     float* prob;                  // [N][Ktot]
     float* skey;                  // [N][Ktot] prob, or -1 for filtered candidates
+    int* list_cnt;                // [N][n_levels] candidates that pass the filters (zeroed by the caller)
+    uint32_t* list_max;           // [N][n_levels] their largest coordinate, as float bits (coordinates are >= 0)
 };
 
 __device__ __forceinline__ uint32_t f2key(float f) {           // monotone: larger float -> larger key
@@ -499,6 +523,10 @@ __global__ __launch_bounds__(256) void k_rpn_decode(const RpnPostArgs a) {
     reinterpret_cast<float4*>(a.boxes)[g] = make_float4(bx1, by1, bx2, by2);
     a.prob[g] = prob;
     a.skey[g] = valid ? prob : -1.0f;
+    if (valid) {                                  // what batched_nms's coordinate trick needs: boxes of the call, largest coordinate
+        atomicAdd(&a.list_cnt[img * a.n_levels + l], 1);
+        atomicMax(&a.list_max[img * a.n_levels + l], __float_as_uint(fmaxf(bx2, by2)));
+    }
 }
 
 // Kept candidates of the L level lists of an image -> the reference's output order (decreasing score; equal scores in
@@ -619,7 +647,7 @@ __global__ __launch_bounds__(256) void k_det_candidates(const DetPostArgs a) {
 // one block per list: order = decreasing (score, then lower slot); n_valid = candidates with score >= 0
 __global__ __launch_bounds__(1024) void k_sort_lists(const float* __restrict__ skey, const float* __restrict__ boxes, int Kcap,
                                                      float* __restrict__ s_boxes, float* __restrict__ s_score,
-                                                     int* __restrict__ s_slot, int* __restrict__ n_valid) {
+                                                     int* __restrict__ s_slot, int* __restrict__ n_valid, uint32_t* __restrict__ list_max) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long* v = reinterpret_cast<unsigned long long*>(smem);
     const int list = blockIdx.x, tid = threadIdx.x;
@@ -641,24 +669,29 @@ __global__ __launch_bounds__(1024) void k_sort_lists(const float* __restrict__ s
             __syncthreads();
         }
     int valid = 0;
+    uint32_t mx = 0u;                                           // largest coordinate of the valid candidates (float bits, >= 0)
     for (int i = tid; i < Kcap; i += 1024) {
         const int c = (int)(~(uint32_t)v[i]);
         const size_t src = (size_t)list * Kcap + c, dst = (size_t)list * Kcap + i;
-        reinterpret_cast<float4*>(s_boxes)[dst] = reinterpret_cast<const float4*>(boxes)[src];
+        const float4 bx = reinterpret_cast<const float4*>(boxes)[src];
+        reinterpret_cast<float4*>(s_boxes)[dst] = bx;
         const float sc = skey[src];
         s_score[dst] = sc;
         s_slot[dst] = c;
         valid += sc >= 0.0f;
+        if (sc >= 0.0f) mx = max(mx, __float_as_uint(fmaxf(bx.z, bx.w)));
     }
-    for (int off = 32; off > 0; off >>= 1) valid += __shfl_down(valid, off);
+    for (int off = 32; off > 0; off >>= 1) { valid += __shfl_down(valid, off); mx = max(mx, (uint32_t)__shfl_down((int)mx, off)); }
     __syncthreads();                                            // v[] is free now
     int* part = reinterpret_cast<int*>(smem);
-    if ((tid & 63) == 0) part[tid >> 6] = valid;
+    if ((tid & 63) == 0) { part[tid >> 6] = valid; part[16 + (tid >> 6)] = (int)mx; }
     __syncthreads();
     if (tid == 0) {
         int t = 0;
-        for (int w = 0; w < 16; ++w) t += part[w];
+        uint32_t m = 0u;
+        for (int w = 0; w < 16; ++w) { t += part[w]; m = max(m, (uint32_t)part[16 + w]); }
         n_valid[list] = t;
+        list_max[list] = m;
     }
 }
 

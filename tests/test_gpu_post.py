@@ -54,6 +54,12 @@ def test_hip_det_postprocess_matches_reference_fixture(gpu_device, name):
     res = heads.postprocess_detections(logits.to(gpu_device), reg.to(gpu_device), [p.to(gpu_device) for p in props],
                                        list(sp["image_shapes"]))
     check_det_against_fixture(name, res)
+    if name == "post_det_trick":
+        # RoI pairs with IoU within 1e-5 of the threshold: the reference (torchvision's coordinate-trick batched_nms, <= 4000
+        # coordinates) keeps a different set than IoUs on the raw coordinates would - the fixture is only matched by reproducing
+        # the shifted fp32 coordinates
+        exp = FX.load_expected(name)
+        assert exp["n_raw"].tolist() != exp["boxes_n"].tolist()
 
 
 def _record(key, value):

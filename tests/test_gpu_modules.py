@@ -265,3 +265,42 @@ def test_f32_conv_rejects_too_many_channels_but_bf16x3_takes_them(pkg, gpu_devic
     m.precision = "bf16x3"
     l, b = m([f])
     assert tuple(l[0].shape) == (1, 3, 8, 8) and torch.isfinite(l[0]).all()
+
+
+def test_two_host_threads_two_streams_bitwise(pkg, gpu_device):
+    """the library is re-entrant (snn_hip.h): two host threads, each on its own HIP stream (workspaces are per stream),
+    run both heads concurrently and reproduce the single-stream results bit for bit"""
+    import threading
+    torch.manual_seed(3)
+    rpn = pkg.RPNHeadSNN(128, 3, 8).to(gpu_device)
+    det = pkg.FastRCNNPredictorSNNFull(32 * 49, 256, 9, 12).to(gpu_device)
+    feats = [[torch.randn(2, 128, 40 + 8 * i, 56, device=gpu_device), torch.randn(2, 128, 20, 28, device=gpu_device)] for i in range(2)]
+    rois = [torch.randn(300 + 50 * i, 32, 7, 7, device=gpu_device) for i in range(2)]
+    with torch.no_grad():
+        ref = [(rpn(feats[i]), det(rois[i])) for i in range(2)]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(gpu_device) for _ in range(2)]
+    bad, errs = [], []
+
+    def worker(i):
+        try:
+            with torch.no_grad(), torch.cuda.stream(streams[i]):
+                fi = [f.clone() for f in feats[i]]
+                ri = rois[i].clone()
+                for it in range(12):
+                    (lg, bb), (c, b) = rpn(fi), det(ri)
+                    (rl, rb), (rc, rbx) = ref[i]
+                    same = all(torch.equal(x, y) for x, y in zip(lg + bb, rl + rb)) and torch.equal(c, rc) and torch.equal(b, rbx)
+                    if not same:
+                        bad.append((i, it))
+                streams[i].synchronize()
+        except Exception as e:                      # surfaced in the main thread
+            errs.append(repr(e))
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    torch.cuda.synchronize()
+    assert not errs, errs
+    assert not bad, bad

@@ -228,6 +228,13 @@ int snn_det_exchange_payload(const float* class_logits /* [N*rois_per_image][K] 
                              const float* box_regression /* [N*rois_per_image][4K] */, int N, int rois_per_image, int K,
                              int max_det, float* payload /* [N][max_det][6] */, int* counts /* [N] */, snn_stream_t stream);
 
+/* ---- helper outside the spiking path: FrozenBatchNorm2d (+ residual) (+ ReLU) of the stock backbone in one pass -----
+ * y[n][c][i] = relu?( (x[n][c][i] * scale[c] + bias[c]) (+ residual[n][c][i]) ), the operations of torchvision's
+ * FrozenBatchNorm2d.forward / Bottleneck.forward (called at faster_rcnn.py:693-694 through resnet_fpn_backbone) in the same
+ * order with separate roundings: bit-identical to the four torch launches it replaces.  residual nullable; y may be x. */
+int snn_affine_act_nchw(const float* x, const float* scale, const float* bias, const float* residual, int N, int C,
+                        int HW, int relu, float* y, snn_stream_t stream);
+
 /* ---- stage-level entry points (parity tests drive the layers one by one, teacher-forced) ----- */
 /* constant-current LIF encoder -> bit-planes.  NCHW feature map -> planes[T][N*H*W][Cw]          */
 int snn_encode_nchw(const float* feat, int N, int C, int H, int W, int T, const snn_params* p_host,

@@ -63,6 +63,7 @@ SYMBOLS = {
     "snn_rpn_rates": (C.c_int, [C.POINTER(snn_rpn_level), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_void_p, C.c_size_t, c_stream]),
     "snn_det_rates": (C.c_int, [C.c_int] * 7 + [C.c_void_p] * 5 + [c_stream]),
+    "snn_affine_act_nchw": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p, c_stream]),
     "snn_encode_nchw": (C.c_int, [C.c_void_p] + [C.c_int] * 5 + [C.POINTER(snn_params), C.c_void_p, C.c_size_t, c_stream]),
     "snn_encode_rows": (C.c_int, [C.c_void_p] + [C.c_int] * 3 + [C.POINTER(snn_params), C.c_void_p, C.c_size_t, c_stream]),
     "snn_conv3x3_lif": (C.c_int, [C.c_void_p, C.c_size_t] + [C.c_int] * 6 + [C.POINTER(snn_params), C.c_void_p,

@@ -105,6 +105,8 @@ __global__ void k_pack_heads(const float* __restrict__ wa, int NA, const float* 
 
 #include "snn_mx.h"
 
+#include "snn_affine.h"
+
 // ================================================================================================
 // C ABI
 // ================================================================================================
@@ -676,6 +678,21 @@ int snn_encode_nchw(const float* feat, int N, int C, int H, int W, int T, const 
     else
         hipLaunchKernelGGL(k_encode_nchw<false>, dim3(cdiv(HW, ENC_PB), cdiv(Cw, 8), N), dim3(256), 0, (hipStream_t)s, feat, C, HW, Cw, T, np, planes, plane_stride);
     SNN_CHECK_LAUNCH("k_encode_nchw");
+    return 0;
+}
+
+int snn_affine_act_nchw(const float* x, const float* scale, const float* bias, const float* residual, int N, int C, int HW,
+                        int relu, float* y, snn_stream_t s) {
+    if (!x || !scale || !bias || !y || N <= 0 || C <= 0 || HW <= 0) return fail(-1, "snn_affine_act_nchw: bad argument");
+    if ((long long)N * C > 0x7fffffffLL / 64) return fail(-1, "snn_affine_act_nchw: too many planes");
+    AffineArgs a;
+    a.x = x; a.scale = scale; a.bias = bias; a.residual = residual; a.y = y; a.C = C; a.HW = HW; a.relu = relu;
+    // ~8 float4 per thread and work-group round; small planes (deep levels) take one work-group each
+    const int per_wg = 256 * 4 * 8;
+    const long long planes = (long long)N * C;
+    a.chunks = (int)max(1LL, min((long long)cdiv(HW, per_wg), max(1LL, (64LL * g3_slots()) / planes)));
+    hipLaunchKernelGGL(k_affine_act, dim3((unsigned)(planes * a.chunks)), dim3(256), 0, (hipStream_t)s, a);
+    SNN_CHECK_LAUNCH("k_affine_act");
     return 0;
 }
 

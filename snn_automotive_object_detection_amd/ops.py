@@ -280,6 +280,27 @@ def spike_conv3x3_bf16x3(enc: torch.Tensor, shapes, C_in: int, C_out: int, w_pac
 
 
 
+def affine_act_nchw(x: torch.Tensor, scale: torch.Tensor, bias: torch.Tensor, residual: Optional[torch.Tensor] = None,
+                    relu: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """relu?((x * scale[c] + bias[c]) (+ residual)) over NCHW in one pass - FrozenBatchNorm2d / Bottleneck tail of the stock
+    backbone, bit-identical to the separate torch launches (snn_hip.h).  ``out`` may be ``x`` (in place)."""
+    _need_gpu(x, "affine input")
+    lib = _lib.load()
+    if x.dtype != torch.float32 or not x.is_contiguous() or x.dim() != 4:
+        raise _lib.SnnHipError("affine_act_nchw: x must be a contiguous fp32 NCHW tensor (got %s, %s)" % (x.dtype, tuple(x.shape)))
+    N, Cc, H, W = x.shape
+    scale, bias = _f32c(scale).reshape(-1), _f32c(bias).reshape(-1)
+    if scale.numel() != Cc or bias.numel() != Cc:
+        raise _lib.SnnHipError("affine_act_nchw: scale / bias need %d channels" % Cc)
+    if residual is not None and (residual.shape != x.shape or residual.dtype != torch.float32 or not residual.is_contiguous()):
+        raise _lib.SnnHipError("affine_act_nchw: residual must match x (contiguous fp32)")
+    y = torch.empty_like(x) if out is None else out
+    if x.numel():
+        _lib.check(lib.snn_affine_act_nchw(_ptr(x), _ptr(scale), _ptr(bias), _ptr(residual), N, Cc, H * W, int(bool(relu)), _ptr(y),
+                                           _stream()), "snn_affine_act_nchw")
+    return y
+
+
 def encode_nchw(feat: torch.Tensor, T: int, p: snn_params) -> torch.Tensor:
     """[N,C,H,W] fp32 -> spike bit-planes uint32 viewed as int32 [T, N*H*W, Cw]"""
     _need_gpu(feat, "feature map")
@@ -668,3 +689,43 @@ def det_postprocess(class_logits: torch.Tensor, box_regression: torch.Tensor, pr
                                        _ptr(boxes), _ptr(scores), _ptr(labels), _ptr(counts), cap, _ptr(ws), ws.numel(),
                                        _stream()), "snn_det_postprocess")
     return boxes, scores, labels, counts, all_scores, all_boxes
+
+
+# ---------------------------------------------------------------------------------------------
+# device guard: every wrapper above launches on "the current stream of the current device"; a caller holding tensors on
+# another GPU of the process (cuda:1 while cuda:0 is current) gets that device made current for the call, as torch's
+# own operators do
+# ---------------------------------------------------------------------------------------------
+def _cuda_device_of(values) -> Optional[torch.device]:
+    for a in values:
+        if isinstance(a, torch.Tensor):
+            if a.is_cuda:
+                return a.device
+        elif isinstance(a, (list, tuple)):
+            d = _cuda_device_of(a)
+            if d is not None:
+                return d
+    return None
+
+
+def _on_tensor_device(fn):
+    import functools
+
+    @functools.wraps(fn)
+    def guarded(*args, **kw):
+        dev = _cuda_device_of(args) or _cuda_device_of(tuple(kw.values()))
+        if dev is None or dev.index == torch.cuda.current_device():
+            return fn(*args, **kw)
+        with torch.cuda.device(dev):
+            return fn(*args, **kw)
+    return guarded
+
+
+for _name in ("pack_conv3x3", "pack_linear", "pack_heads", "pack_conv3x3_bf16x3", "pack_linear_bf16x3", "pack_linear_mx",
+              "pack_conv3x3_mx", "spike_gemm_bf16x3", "spike_gemm_lif_bf16x3", "spike_gemm_mx", "spike_gemm_lif_mx",
+              "conv3x3_lif_mx", "spike_conv3x3_mx", "conv3x3_lif_bf16x3", "spike_conv3x3_bf16x3", "affine_act_nchw", "encode_nchw", "encode_rows",
+              "conv3x3_lif", "spike_gemm", "lif_scan", "det_exchange_payload", "li_heads", "rpn_head_forward", "det_head_forward",
+              "det_rates", "roi_align_encode", "det_head_forward_roialign", "batched_nms", "nms_keep_mask", "rpn_proposals",
+              "det_postprocess"):
+    globals()[_name] = _on_tensor_device(globals()[_name])
+del _name

@@ -155,3 +155,14 @@ def test_postprocess_rejects_one_bbox_outputs_before_touching_the_device():
     m = S.create_model("cityscapes", 9, True, True, 0, False, False, 8, 12, only_one_bbox=True)
     with pytest.raises(NotImplementedError):
         m.roi_heads.postprocess_detections(cls, reg, [props[:3], props[3:]], [(10, 10)] * 2)
+
+
+def test_ops_device_guard_finds_the_tensor_device():
+    """the wrappers run under the device of their first GPU tensor argument (nested lists included); CPU arguments pass
+    through to the wrapper's own loud error"""
+    from snn_automotive_object_detection_amd import ops
+    assert ops._cuda_device_of((1, "x", [torch.zeros(2)], torch.zeros(1))) is None
+    assert ops.rpn_head_forward.__name__ == "rpn_head_forward" and hasattr(ops.rpn_head_forward, "__wrapped__")
+    with pytest.raises(Exception) as e:
+        ops.encode_rows(torch.zeros(4, 32), 4, ops.make_params(ops.LIFParameters(v_th=torch.as_tensor(0.25)), ops.LIFParameters(v_th=torch.as_tensor(0.1))))
+    assert "GPU" in str(e.value) or "gpu" in str(e.value).lower()

@@ -36,14 +36,31 @@ __device__ __forceinline__ const void* sgpr_ptr(const void* p) {
 }
 // Three pieces (the three weight planes of a chunk) per call; s_nop 4 / s_nop 0: SGPR -> VMEM-base and M0 -> LDS-DMA
 // wait states, which hipcc's hazard recogniser does not insert inside inline asm.
+// cache-policy bits of the LDS-DMA copies, A/B switches (0 = default policy): -DSNN_W_AUX_ID=n for the weight planes,
+// -DSNN_A_AUX_ID=n for the spike words; 1 = nt, 2 = sc0, 3 = sc1, 4 = sc0 sc1
+#define SNN_AUX_STR_0 ""
+#define SNN_AUX_STR_1 " nt"
+#define SNN_AUX_STR_2 " sc0"
+#define SNN_AUX_STR_3 " sc1"
+#define SNN_AUX_STR_4 " sc0 sc1"
+#define SNN_AUX_CAT(n) SNN_AUX_STR_##n
+#define SNN_AUX_OF(n) SNN_AUX_CAT(n)
+#ifndef SNN_W_AUX_ID
+#define SNN_W_AUX_ID 0
+#endif
+#ifndef SNN_A_AUX_ID
+#define SNN_A_AUX_ID 0
+#endif
+#define SNN_W_AUX SNN_AUX_OF(SNN_W_AUX_ID)
+#define SNN_A_AUX SNN_AUX_OF(SNN_A_AUX_ID)
 __device__ __forceinline__ void glds16(const void* p0, uint32_t voff, uint32_t d0) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(p0), "s"(d0) : "memory", "m0");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" SNN_W_AUX :: "v"(voff), "s"(p0), "s"(d0) : "memory", "m0");
 }
 __device__ __forceinline__ void glds16x3(const void* p0, const void* p1, const void* p2, uint32_t voff,
                                          uint32_t d0, uint32_t d1, uint32_t d2) {
-    asm volatile("s_mov_b32 m0, %4\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1\n\t"
-                 "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2\n\t"
-                 "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %3"
+    asm volatile("s_mov_b32 m0, %4\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" SNN_W_AUX "\n\t"
+                 "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2" SNN_W_AUX "\n\t"
+                 "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %3" SNN_W_AUX
                  :: "v"(voff), "s"(p0), "s"(p1), "s"(p2), "s"(d0), "s"(d1), "s"(d2) : "memory", "m0");
 }
 
@@ -248,7 +265,7 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
 #ifndef SNN_EXP_NO_FETCH                            // (timing only: no spike-word stream at all)
         if (a_role) {
             const uint32_t d = __builtin_amdgcn_readfirstlane(a_dst + slot_off);
-            asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dword %0, %1" :: "v"(f_voff), "s"(f_ptr), "s"(d) : "memory", "m0");
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dword %0, %1" SNN_A_AUX :: "v"(f_voff), "s"(f_ptr), "s"(d) : "memory", "m0");
         }
 #endif
         f_ptr = static_cast<const uint32_t*>(sgpr_ptr(f_ptr + 1));

@@ -100,6 +100,13 @@ struct Gemm3Args {
     unsigned long long* cnt_img;
     uint32_t* cnt_row;
     int max_n;
+    // word-major operand planes (the heads' internal format): A is [T][word][row] instead of [T][row][word], a_step = rows per
+    // word plane (conv: padded positions of all levels; linear: M).  A chunk's spike words of a tile are then a few contiguous
+    // runs (128 B per time step of a conv tile) instead of one 4-byte piece per row at the row pitch - the 4-bytes-per-line
+    // gather cost 6 % (conv) / 11 % (fc6) of the kernel in clock.  out_wm: the linear-layer LIF epilogue writes
+    // its spike planes word-major as well (fc6 -> fc7).
+    int wm, out_wm;
+    unsigned long long a_step;
     NeuronP p;
     ConvLevelDev lv[SNN_MAX_LEVELS];
 };
@@ -225,6 +232,8 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
     const int xrow = tid & (G3_BM(WN, 4) - 1);
     const int xt = TILE ? xrow / args.pb : 0;       // TILE: time step of the row
     const int xm = TILE ? (xt < args.T ? m0 + xrow % args.pb : M) : m0 + xrow;
+    const bool a_wm = args.wm != 0;                   // word-major planes: a row's consecutive words are a_step words apart
+    const int row_words = a_wm ? 1 : args.Cw;         // conv: words from one (padded) position to the next
     uint32_t a_off = 0;                             // bytes: fc row / conv centre tap, channel word 0
     uint32_t a_pitch = 0;                           // conv: bytes per (padded) image row of the lane's pyramid level
     if (CONV) {
@@ -237,16 +246,16 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
             const int n = local / (H * W), rem = local % (H * W);
             const int y = rem / W, x = rem % W;
             const size_t prow = (size_t)args.lv[l].tile_begin + ((size_t)n * (H + 2) + y + 1) * (W + 2) + x + 1;   // padded row
-            a_off = (uint32_t)(((size_t)t * args.enc_stride + prow * args.Cw) * 4);
-            a_pitch = (uint32_t)((W + 2) * args.Cw * 4);
+            a_off = (uint32_t)(((size_t)t * args.enc_stride + prow * row_words) * 4);
+            a_pitch = (uint32_t)((W + 2) * row_words * 4);
         } else {                                    // unused tile rows: position (0, 0) of level 0, image 0 - its taps are in range
-            a_off = (uint32_t)((args.lv[0].W + 3) * args.Cw * 4);
-            a_pitch = (uint32_t)((args.lv[0].W + 2) * args.Cw * 4);
+            a_off = (uint32_t)((args.lv[0].W + 3) * row_words * 4);
+            a_pitch = (uint32_t)((args.lv[0].W + 2) * row_words * 4);
         }
-    } else if (TILE) {                              // fc rows of the spike planes [T][M][Kc]; unused tile rows read row 0
-        a_off = xm < M ? (uint32_t)(((size_t)xt * M + xm) * Kc * 4) : 0u;
+    } else if (TILE) {                              // fc rows of the spike planes [T][M][Kc] / [T][Kc][M]; unused tile rows read row 0
+        a_off = xm >= M ? 0u : a_wm ? (uint32_t)(((size_t)xt * Kc * M + xm) * 4) : (uint32_t)(((size_t)xt * M + xm) * Kc * 4);
     } else {
-        a_off = (uint32_t)((size_t)min(xm, M - 1) * Kc * 4);
+        a_off = (uint32_t)((size_t)min(xm, M - 1) * (a_wm ? 1 : Kc) * 4);
     }
     // The fetch stream walks the chunk sequence (t, tap dy, tap dx, channel word) as a running scalar pointer: inside a tap
     // row the wave-uniform word offset dx*Cw + cc just increments; every 3*Cw chunks the lanes step one image row down
@@ -257,9 +266,33 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
     // address or M0, and hipcc's hazard recogniser does not look into inline asm.)
     const int n_steps = FUSE ? args.T : 1;
     const int row_chunks = __builtin_amdgcn_readfirstlane(3 * args.Cw);
-    const uint32_t* f_ptr = static_cast<const uint32_t*>(sgpr_ptr(args.A + (CONV ? -args.Cw : 0)));
+    // scalar steps of the stream, in words: to the next channel / K word of the same rows; (conv) at the end of a tap's Cw words
+    // on to the next tap of the row; at the end of a tap row back to its first tap; from the centre tap to tap (-1, -1)'s column
+#if defined(SNN_EXP_A_COMPACT) && SNN_EXP_A_COMPACT == 2 && !defined(SNN_EXP_A_STEP1)
+    const int w_step = 256;
+#else
+    const int w_step = __builtin_amdgcn_readfirstlane(a_wm ? (int)args.a_step : 1);
+#endif
+    const int tap_adj = __builtin_amdgcn_readfirstlane(a_wm ? 1 - args.Cw * (int)args.a_step : 0);
+    const int row_back = __builtin_amdgcn_readfirstlane(a_wm ? 3 : 3 * args.Cw);
+    const int tap_back = __builtin_amdgcn_readfirstlane(CONV ? row_words : 0);
+    const int cw_s = __builtin_amdgcn_readfirstlane(args.Cw);
+    const uint32_t* f_ptr = static_cast<const uint32_t*>(sgpr_ptr(args.A - tap_back));
     uint32_t f_voff = CONV ? a_off - a_pitch : a_off;               // lane: row offset of tap row dy
-    int f_t = 0, f_kc = 0, f_j = 0;
+#ifdef SNN_EXP_A_COMPACT    // timing only: every chunk fetches 1 KB of CONSECUTIVE spike words (wrong rows, same statistics): what
+                            // the 4-bytes-per-row gather of the [row][word] plane layout costs beside a [word][row] layout
+#ifndef SNN_EXP_A_REGIONS
+#define SNN_EXP_A_REGIONS (CONV ? 400 : 64)
+#endif
+#if SNN_EXP_A_COMPACT == 2  // ... a FRESH, aligned 1 KB per chunk (no line is ever fetched twice by a work-group)
+    a_off = (uint32_t)(xrow * 4 + (blockIdx.x % SNN_EXP_A_REGIONS) * (uint32_t)(Kc * 1024) + (CONV ? 4096 : 0));
+#else                       // (1: the same 1 KB + 4 bytes per chunk: the lines stay in the L1)
+    a_off = (uint32_t)(xrow * 4 + (blockIdx.x & 1023) * 1024 + (CONV ? 4096 : 0));
+#endif
+    a_pitch = 0;
+    f_voff = a_off;
+#endif
+    int f_t = 0, f_kc = 0, f_j = 0, f_c = 0;
     const uint32_t a_dst = smem_base + G3_LUT_BYTES + wave * 256;   // + slot offset
     auto stage_a = [&](uint32_t slot_off) {
 #ifndef SNN_EXP_NO_FETCH                            // (timing only: no spike-word stream at all)
@@ -268,20 +301,25 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dword %0, %1" SNN_A_AUX :: "v"(f_voff), "s"(f_ptr), "s"(d) : "memory", "m0");
         }
 #endif
-        f_ptr = static_cast<const uint32_t*>(sgpr_ptr(f_ptr + 1));
+        f_ptr = static_cast<const uint32_t*>(sgpr_ptr(f_ptr + w_step));
         if (CONV) {
+            f_c = __builtin_amdgcn_readfirstlane(f_c + 1);
+            if (f_c == cw_s) {                      // next tap of the row (row-major planes: the words just continue, tap_adj = 0)
+                f_c = 0;
+                f_ptr = static_cast<const uint32_t*>(sgpr_ptr(f_ptr + tap_adj));
+            }
             f_j = __builtin_amdgcn_readfirstlane(f_j + 1);
             if (f_j == row_chunks) {                // next tap row
                 f_j = 0;
-                f_ptr = static_cast<const uint32_t*>(sgpr_ptr(f_ptr - row_chunks));
+                f_ptr = static_cast<const uint32_t*>(sgpr_ptr(f_ptr - row_back));
                 f_voff += a_pitch;
             }
         }
         f_kc = __builtin_amdgcn_readfirstlane(f_kc + 1);
         if (f_kc == Kc) {
-            f_kc = 0; f_j = 0;
+            f_kc = 0; f_j = 0; f_c = 0;
             if (FUSE) { f_t = __builtin_amdgcn_readfirstlane(f_t + 1); if (f_t == n_steps) f_t = 0; }
-            f_ptr = static_cast<const uint32_t*>(sgpr_ptr(args.A + (FUSE ? (size_t)f_t * args.enc_stride : 0) + (CONV ? -args.Cw : 0)));
+            f_ptr = static_cast<const uint32_t*>(sgpr_ptr(args.A + (FUSE ? (size_t)f_t * args.enc_stride : 0) - tap_back));
             f_voff = CONV ? a_off - a_pitch : a_off;
         }
     };
@@ -567,9 +605,15 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
                         cnt += __popcll(two ? b : (b & 0xffffffffull));
                     }
                     if (lane < T) {
-                        uint32_t* dst = args.spk + (size_t)lane * args.spk_stride + (size_t)pos * (Np >> 5) + word0;
-                        dst[0] = my0;
-                        if (two) dst[1] = my1;
+                        if (!CONV && args.out_wm) {                    // word-major planes [T][word][row] (fc6 -> fc7)
+                            uint32_t* dst = args.spk + (size_t)lane * args.spk_stride + (size_t)word0 * M + pos;
+                            dst[0] = my0;
+                            if (two) dst[M] = my1;
+                        } else {
+                            uint32_t* dst = args.spk + (size_t)lane * args.spk_stride + (size_t)pos * (Np >> 5) + word0;
+                            dst[0] = my0;
+                            if (two) dst[1] = my1;
+                        }
                     }
                     if (counting && lane == 0) pos_cnt[pi] = (h == 0 ? 0u : pos_cnt[pi]) + cnt;
                 }
@@ -593,9 +637,15 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
                     }
                     const bool odd_ok = 2 * pp + 1 < pb && m0 + 2 * pp + 1 < M;
                     if (lane < T) {
-                        uint32_t* dst = args.spk + (size_t)lane * args.spk_stride + (size_t)(m0 + 2 * pp) * (Np >> 5) + word0;
-                        dst[0] = my0;
-                        if (odd_ok) dst[Np >> 5] = my1;
+                        if (!CONV && args.out_wm) {
+                            uint32_t* dst = args.spk + (size_t)lane * args.spk_stride + (size_t)word0 * M + (m0 + 2 * pp);
+                            dst[0] = my0;
+                            if (odd_ok) dst[1] = my1;
+                        } else {
+                            uint32_t* dst = args.spk + (size_t)lane * args.spk_stride + (size_t)(m0 + 2 * pp) * (Np >> 5) + word0;
+                            dst[0] = my0;
+                            if (odd_ok) dst[Np >> 5] = my1;
+                        }
                     }
                     if (counting && lane == 0) {
                         pos_cnt[2 * pp] = (h == 0 ? 0u : pos_cnt[2 * pp]) + cnt0;

@@ -16,7 +16,7 @@
 template <bool ZR>
 __device__ __forceinline__ void encode_block(const float* __restrict__ feat, int C, int HW, int Cw, int T, const NeuronP& p,
                                              uint32_t* __restrict__ planes, size_t plane_stride, int n, int bx, int by,
-                                             int Wpad = 0) {
+                                             int Wpad = 0, size_t wm_rows = 0) {
     __shared__ uint32_t wbuf[SNN_MAX_STEPS * ENC_PB * 9];      // [t][position][8 words + 1 pad]
     const int pl = threadIdx.x & 31, cgl = threadIdx.x >> 5;
     const int pos = bx * ENC_PB + pl;
@@ -35,8 +35,10 @@ __device__ __forceinline__ void encode_block(const float* __restrict__ feat, int
         wbuf[(t * ENC_PB + pl) * 9 + cgl] = word;
     }
     __syncthreads();
-    // store: thread -> (position tid >> 3, word tid & 7): consecutive threads write consecutive plane words
-    const int sp = threadIdx.x >> 3, sw = threadIdx.x & 7;
+    // store: thread -> (position tid >> 3, word tid & 7): consecutive threads write consecutive plane words.
+    // wm_rows > 0: word-major planes [T][word][wm_rows rows] (`planes` then points at the level's first ROW of word plane 0):
+    // thread -> (word tid >> 5, position tid & 31), 128-byte runs of 32 positions per (t, word)
+    const int sp = wm_rows ? (threadIdx.x & 31) : (threadIdx.x >> 3), sw = wm_rows ? (threadIdx.x >> 5) : (threadIdx.x & 7);
     const int spos = bx * ENC_PB + sp, scg = by * 8 + sw;
     if (spos < HW && scg < Cw) {
         size_t row = (size_t)n * HW + spos;
@@ -44,7 +46,7 @@ __device__ __forceinline__ void encode_block(const float* __restrict__ feat, int
             const int H = HW / Wpad, y = spos / Wpad, x = spos % Wpad;
             row = ((size_t)n * (H + 2) + y + 1) * (Wpad + 2) + x + 1;
         }
-        uint32_t* out = planes + row * Cw + scg;
+        uint32_t* out = wm_rows ? planes + (size_t)scg * wm_rows + row : planes + row * Cw + scg;
         for (int t = 0; t < T; ++t) out[(size_t)t * plane_stride] = wbuf[(t * ENC_PB + sp) * 9 + sw];
     }
 }
@@ -67,12 +69,12 @@ struct EncLevels {
 };
 template <bool ZR>
 __global__ __launch_bounds__(256) void k_encode_levels(const EncLevels lv, int C, int Cw, int T, NeuronP p,
-                                                       uint32_t* __restrict__ planes, size_t plane_stride) {
+                                                       uint32_t* __restrict__ planes, size_t plane_stride, size_t wm_rows) {
     int l = 0;
     while (l + 1 < lv.n_levels && (int)blockIdx.x >= lv.blk_base[l + 1]) ++l;
     const int local = blockIdx.x - lv.blk_base[l];
-    encode_block<ZR>(lv.feat[l], C, lv.HW[l], Cw, T, p, planes + (size_t)lv.pos_base[l] * Cw, plane_stride,
-                     local / lv.bpi[l], local % lv.bpi[l], blockIdx.y, lv.Wpad[l]);
+    encode_block<ZR>(lv.feat[l], C, lv.HW[l], Cw, T, p, planes + (size_t)lv.pos_base[l] * (wm_rows ? 1 : Cw), plane_stride,
+                     local / lv.bpi[l], local % lv.bpi[l], blockIdx.y, lv.Wpad[l], wm_rows);
 }
 
 // zero halo of the padded planes: only the border rows / columns of every image are written (a few hundred KB), not the
@@ -83,7 +85,7 @@ struct HaloLevels {
     int n_levels;
 };
 __global__ __launch_bounds__(256) void k_zero_halo(const HaloLevels lv, int Cw, int T, uint32_t* __restrict__ planes,
-                                                   size_t plane_stride) {
+                                                   size_t plane_stride, size_t wm_rows) {
     int l = 0;
     while (l + 1 < lv.n_levels && (int)blockIdx.x >= lv.blk_base[l + 1]) ++l;
     const int n = blockIdx.x - lv.blk_base[l], H = lv.H[l], W = lv.W[l];
@@ -95,7 +97,7 @@ __global__ __launch_bounds__(256) void k_zero_halo(const HaloLevels lv, int Cw, 
         else if (h < 2 * (W + 2)) { y = H + 1; x = h - (W + 2); }
         else { const int r = h - 2 * (W + 2); y = 1 + (r >> 1); x = (r & 1) ? W + 1 : 0; }
         const size_t row = (size_t)lv.pos_base[l] + ((size_t)n * (H + 2) + y) * (W + 2) + x;
-        planes[(size_t)t * plane_stride + row * Cw + w] = 0u;
+        planes[(size_t)t * plane_stride + (wm_rows ? (size_t)w * wm_rows + row : row * Cw + w)] = 0u;
     }
 }
 
@@ -174,6 +176,43 @@ __global__ __launch_bounds__(256) void k_encode_rows_w(const float* __restrict__
     }
 }
 
+// K1b'': the same encoder writing WORD-MAJOR planes [T][Dw][R] (what the linear-layer kernels stream best): a work-group takes
+// 32 rows x 8 words (32 x 1 KB of x, 16-byte coalesced loads through LDS), thread = (row tid & 31, word tid >> 5), so the 32
+// lanes of a half-wave store 32 consecutive rows of one word plane: 128-byte runs.  D % 32 == 0, x 16-byte aligned.
+#define ENC_WM_PITCH 260
+template <bool ZR>
+__global__ __launch_bounds__(256) void k_encode_rows_wm(const float* __restrict__ x, int R, int D, int T, NeuronP p,
+                                                        uint32_t* __restrict__ planes, size_t plane_stride) {
+    __shared__ __attribute__((aligned(16))) float tile[32 * ENC_WM_PITCH];
+    const int tid = threadIdx.x;
+    const int r0 = blockIdx.y * 32, w0 = blockIdx.x * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int q = tid + 256 * j;                            // 16-byte piece: row q / 64, floats 4 (q % 64) .. of the 256-float run
+        const int row = q >> 6, col = w0 * 32 + (q & 63) * 4;
+        f32x4 v4 = {0.f, 0.f, 0.f, 0.f};
+        if (r0 + row < R && col < D) v4 = *reinterpret_cast<const f32x4*>(x + (size_t)(r0 + row) * D + col);
+        *reinterpret_cast<f32x4*>(tile + row * ENC_WM_PITCH + (q & 63) * 4) = v4;
+    }
+    __syncthreads();
+    const int row = tid & 31, wd = tid >> 5;
+    if (r0 + row >= R || (w0 + wd) * 32 >= D) return;
+    float xv[32], v[32];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const f32x4 t4 = *reinterpret_cast<const f32x4*>(tile + row * ENC_WM_PITCH + wd * 32 + 4 * q);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { xv[4 * q + r] = t4[r]; v[4 * q + r] = 0.0f; }      // v = 0: faster_rcnn.py:484
+    }
+    uint32_t* dst = planes + (size_t)(w0 + wd) * R + r0 + row;
+    for (int t = 0; t < T; ++t) {
+        uint32_t word = 0;
+#pragma unroll
+        for (int b = 31; b >= 0; --b) enc_step_word<ZR>(xv[b], v[b], p, word);          // bit 31 first
+        dst[(size_t)t * plane_stride] = word;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K1c: MultiScaleRoIAlign (7x7, sampling_ratio 2, aligned=False) fused with the detector's constant-current
 // encoder (roi_heads.py:1217 -> faster_rcnn.py:473,494): the [R,C,7,7] fp32 RoI features (100 MB at R=2000) are
@@ -213,13 +252,11 @@ __device__ __forceinline__ float roi_bilinear(const float* __restrict__ f, int H
     return acc;
 }
 
-__global__ __launch_bounds__(256) void k_roi_align_encode(const RoiArgs a) {
-    const int r = blockIdx.y;
+// pooled value of element d = c*49 + ph*7 + pw of RoI r
+__device__ __forceinline__ float roi_pool_element(const RoiArgs& a, int r, int d) {
     const int D = a.C * 49;
-    const int d = blockIdx.x * 256 + threadIdx.x;
-    const int lane = threadIdx.x & 63;
     float val = 0.0f;
-    if (d < D) {
+    {
         const int c = d / 49, ph = (d % 49) / 7, pw = d % 7;
         const RoiLevel L = a.lv[a.roi_level[r]];
         const float* roi = a.rois + (size_t)r * 4;
@@ -242,6 +279,15 @@ __global__ __launch_bounds__(256) void k_roi_align_encode(const RoiArgs a) {
         val = __fdiv_rn(__fadd_rn(__fadd_rn(__fadd_rn(s[0][0], s[0][1]), s[1][0]), s[1][1]), 4.0f);
         if (a.pooled) a.pooled[(size_t)r * D + d] = val;
     }
+    return val;
+}
+
+__global__ __launch_bounds__(256) void k_roi_align_encode(const RoiArgs a) {
+    const int r = blockIdx.y;
+    const int D = a.C * 49;
+    const int d = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const float val = d < D ? roi_pool_element(a, r, d) : 0.0f;
     // encoder over T steps; the wave's 64 consecutive d are two plane words
     float v = 0.0f;
     const size_t e = (size_t)r * a.Dw * 32 + d;
@@ -251,5 +297,33 @@ __global__ __launch_bounds__(256) void k_roi_align_encode(const RoiArgs a) {
         const unsigned long long m = __ballot(z);
         if ((lane & 31) == 0 && in)
             a.planes[(size_t)t * a.plane_stride + (e >> 5)] = (lane < 32) ? (uint32_t)m : (uint32_t)(m >> 32);
+    }
+}
+
+// K1c': the same with WORD-MAJOR planes [T][Dw][R]: a work-group takes 32 RoIs x 64 elements (two plane words); wave w pools and
+// encodes RoIs 8w .. 8w+7 one after the other (lanes = the 64 elements, the ballot of a step is the RoI's word pair), the words
+// meet in LDS and leave as 128-byte runs of 32 consecutive RoIs per (t, word).  RoI parameters are wave-uniform (scalar loads).
+__global__ __launch_bounds__(256) void k_roi_align_encode_wm(const RoiArgs a) {
+    __shared__ uint32_t wbuf[SNN_MAX_STEPS * 2 * 32];            // [t][word][RoI]
+    const int D = a.C * 49;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r0 = blockIdx.y * 32, d = blockIdx.x * 64 + lane;
+    for (int i = 0; i < 8; ++i) {
+        const int rl = wave * 8 + i, r = r0 + rl;                // wave-uniform
+        if (r >= a.R) break;
+        const float val = d < D ? roi_pool_element(a, r, d) : 0.0f;
+        float v = 0.0f;
+        for (int t = 0; t < a.T; ++t) {
+            const bool z = enc_step(val, v, a.p) && d < D;
+            const unsigned long long m = __ballot(z);
+            if (lane == 0) { wbuf[(t * 2 + 0) * 32 + rl] = (uint32_t)m; wbuf[(t * 2 + 1) * 32 + rl] = (uint32_t)(m >> 32); }
+        }
+    }
+    __syncthreads();
+    const int w0 = blockIdx.x * 2;
+    for (int idx = threadIdx.x; idx < a.T * 64; idx += 256) {
+        const int rl = idx & 31, wd = (idx >> 5) & 1, t = idx >> 6;
+        if (r0 + rl < a.R && w0 + wd < a.Dw)
+            a.planes[(size_t)t * a.plane_stride + (size_t)(w0 + wd) * a.R + r0 + rl] = wbuf[(t * 2 + wd) * 32 + rl];
     }
 }

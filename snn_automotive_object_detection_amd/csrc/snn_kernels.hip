@@ -122,6 +122,10 @@ struct Knobs {
     int mx_mw;               // SNN_MX_MW=4|8         rows per wave of k_gemm_mx
     int li_heads;            // SNN_LI_HEADS=valu|mfma|ksplit -> 1 | 2 | 3 (0: by shape)
     bool debug_occ;          // SNN_DEBUG_OCC         print occupancy of the big kernels
+    bool stage_wm;           // SNN_STAGE_PLANES=wm   A/B harness only: snn_conv3x3_lif_bf16x3 / snn_spike_gemm_lif_bf16x3 take their
+                             //                       INPUT planes word-major ([T][word][row]; tools/ab_conv.py)
+    bool planes_rm;          // SNN_PLANES=rm         the bf16x3 heads keep their internal spike planes row-major [T][row][word]
+                             //                       (default: word-major [T][word][row]; bit-identical results, A/B + test switch)
 };
 static Knobs load_knobs() {
     Knobs k;
@@ -136,6 +140,8 @@ static Knobs load_knobs() {
     e = getenv("SNN_LI_HEADS");
     k.li_heads = !e ? 0 : !strcmp(e, "valu") ? 1 : !strcmp(e, "mfma") ? 2 : !strcmp(e, "ksplit") ? 3 : 4;
     k.debug_occ = getenv("SNN_DEBUG_OCC") != nullptr;
+    k.planes_rm = (e = getenv("SNN_PLANES")) && !strcmp(e, "rm");
+    k.stage_wm = (e = getenv("SNN_STAGE_PLANES")) && !strcmp(e, "wm");
     return k;
 }
 static Knobs& knobs() {
@@ -422,7 +428,8 @@ int snn_spike_gemm_bf16x3(const uint32_t* a_rows, int M, int K, int N, const uin
 
 // row_counts (nullable, zeroed by the caller): spikes per row over all T steps and N columns, added by the LIF epilogue
 static int spike_gemm_lif_bf16x3_impl(const uint32_t* a_planes, int T, int R, int K, int N, const snn_params* p,
-                                      const uint16_t* w_packed, uint32_t* spk, size_t spk_stride, uint32_t* row_counts, snn_stream_t s) {
+                                      const uint16_t* w_packed, uint32_t* spk, size_t spk_stride, uint32_t* row_counts, snn_stream_t s,
+                                      bool wm_in = false, bool wm_out = false) {
     if (!a_planes || !w_packed || !spk || !p || R <= 0 || K <= 0 || N <= 0)
         return fail(-1, "snn_spike_gemm_lif_bf16x3: bad argument");
     if (check_T(T, "snn_spike_gemm_lif_bf16x3")) return -1;
@@ -434,6 +441,7 @@ static int spike_gemm_lif_bf16x3_impl(const uint32_t* a_planes, int T, int R, in
     const int wn = g3_wn();
     a.n_blocks = cdiv(a.Np, G3_BN(wn));
     a.T = T; a.spk = spk; a.spk_stride = spk_stride; a.p = make_p(p, p->v_th_lif); a.cnt_row = row_counts;
+    a.wm = wm_in; a.out_wm = wm_out; a.a_step = (unsigned long long)R;       // word-major planes [T][K/32][R]
     const int mt = g3_pick_mt([&](int m) { return g3_tile_ok(T, g3_bm(wn, m)) ? (long long)cdiv(R, g3_bm(wn, m) / T) * a.n_blocks : 0ll; });
     if (!mt) return fail(-4, "snn_spike_gemm_lif_bf16x3: T=%d does not fit a row tile (use snn_spike_gemm_bf16x3 + snn_lif_scan)", T);
     a.pb = g3_bm(wn, mt) / T;
@@ -442,7 +450,7 @@ static int spike_gemm_lif_bf16x3_impl(const uint32_t* a_planes, int T, int R, in
 
 int snn_spike_gemm_lif_bf16x3(const uint32_t* a_planes, int T, int R, int K, int N, const snn_params* p,
                               const uint16_t* w_packed, uint32_t* spk, size_t spk_stride, snn_stream_t s) {
-    return spike_gemm_lif_bf16x3_impl(a_planes, T, R, K, N, p, w_packed, spk, spk_stride, nullptr, s);
+    return spike_gemm_lif_bf16x3_impl(a_planes, T, R, K, N, p, w_packed, spk, spk_stride, nullptr, s, knobs().stage_wm, false);
 }
 
 // ---- spike GEMMs on the block-scaled fp4 x fp6 path (snn_mx.h) ------------------------------------
@@ -602,12 +610,17 @@ static int count_spikes_per_image(const snn_rpn_level* lv, int n_levels, int Cw,
 
 static int conv3x3_lif_bf16x3_impl(const uint32_t* enc, size_t enc_stride, const snn_rpn_level* lv, int n_levels, int C_in,
                                    int C_out, int T, const snn_params* p, const uint16_t* w_packed, uint32_t* spk,
-                                   size_t spk_stride, unsigned long long* counts, int max_n, snn_stream_t s) {
+                                   size_t spk_stride, unsigned long long* counts, int max_n, snn_stream_t s, bool wm = false) {
     if (!spk || !p) return fail(-1, "snn_conv3x3_lif_bf16x3: bad argument");
     Gemm3Args a;
     long long P;
     int rc = conv3_common("snn_conv3x3_lif_bf16x3", enc, enc_stride, lv, n_levels, C_in, C_out, T, w_packed, a, &P);
     if (rc) return rc;
+    if (wm) {                                      // encoder planes [T][Cw][rows]: enc_stride = Cw * (rows per word plane)
+        if (enc_stride % a.Cw) return fail(-1, "snn_conv3x3_lif_bf16x3: word-major planes need enc_stride %% Cw == 0");
+        a.wm = 1; a.a_step = enc_stride / a.Cw;
+        if (a.a_step * (unsigned long long)a.Cw > 0x7fffffffULL) return fail(-1, "snn_conv3x3_lif_bf16x3: plane too large");
+    }
     a.M = (int)P; a.T = T; a.spk = spk; a.spk_stride = spk_stride; a.p = make_p(p, p->v_th_lif);
     // debug / A-B knob: SNN_BF16X3_LIF=reg forces the register-resident variant (the fallback for T > 64)
     const int wn = g3_wn();
@@ -630,7 +643,8 @@ static int conv3x3_lif_bf16x3_impl(const uint32_t* enc, size_t enc_stride, const
 int snn_conv3x3_lif_bf16x3(const uint32_t* enc, size_t enc_stride, const snn_rpn_level* lv, int n_levels, int C_in,
                            int C_out, int T, const snn_params* p, const uint16_t* w_packed, uint32_t* spk,
                            size_t spk_stride, snn_stream_t s) {
-    return conv3x3_lif_bf16x3_impl(enc, enc_stride, lv, n_levels, C_in, C_out, T, p, w_packed, spk, spk_stride, nullptr, 0, s);
+    return conv3x3_lif_bf16x3_impl(enc, enc_stride, lv, n_levels, C_in, C_out, T, p, w_packed, spk, spk_stride, nullptr, 0, s,
+                                   knobs().stage_wm);
 }
 
 // spikes per (level, image) from finished planes: one launch per level (fallback of the register-fused conv variant only)
@@ -696,13 +710,24 @@ int snn_affine_act_nchw(const float* x, const float* scale, const float* bias, c
     return 0;
 }
 
-int snn_encode_rows(const float* x, int R, int D, int T, const snn_params* p, uint32_t* planes,
-                    size_t plane_stride, snn_stream_t s) {
+// word-major planes [T][Dw][R] need D % 32 == 0 and 16-byte aligned rows (k_encode_rows_wm)
+static bool encode_rows_wm_ok(const float* x, int D) { return D % 32 == 0 && ((uintptr_t)x & 15) == 0; }
+
+static int encode_rows_impl(const float* x, int R, int D, int T, const snn_params* p, uint32_t* planes,
+                            size_t plane_stride, bool wm, snn_stream_t s) {
     if (!x || !planes || !p || R <= 0 || D <= 0) return fail(-1, "snn_encode_rows: bad argument");
     if (check_T(T, "snn_encode_rows")) return -1;
     const int Dw = cdiv(D, 32);
     const size_t total = (size_t)R * Dw * 32;
     const NeuronP np = make_p(p, p->v_th_enc);
+    if (wm) {
+        if (!encode_rows_wm_ok(x, D)) return fail(-1, "snn_encode_rows: word-major planes need D %% 32 == 0 and 16-byte aligned rows");
+        const dim3 g(cdiv(Dw, 8), cdiv(R, 32));
+        if (enc_zero_rest(np)) hipLaunchKernelGGL(k_encode_rows_wm<true>, g, dim3(256), 0, (hipStream_t)s, x, R, D, T, np, planes, plane_stride);
+        else hipLaunchKernelGGL(k_encode_rows_wm<false>, g, dim3(256), 0, (hipStream_t)s, x, R, D, T, np, planes, plane_stride);
+        SNN_CHECK_LAUNCH("k_encode_rows_wm");
+        return 0;
+    }
     if (D % 32 == 0 && ((uintptr_t)x & 15) == 0 && !knobs().enc_rows_ballot) {   // knob: "ballot" forces the element-per-lane kernel
         const size_t n_words = (size_t)R * Dw;
         const dim3 gw((unsigned)((n_words + 255) / 256));
@@ -716,6 +741,11 @@ int snn_encode_rows(const float* x, int R, int D, int T, const snn_params* p, ui
     else hipLaunchKernelGGL(k_encode_rows<false>, grid, dim3(256), 0, (hipStream_t)s, x, R, D, Dw, T, np, planes, plane_stride);
     SNN_CHECK_LAUNCH("k_encode_rows");
     return 0;
+}
+
+int snn_encode_rows(const float* x, int R, int D, int T, const snn_params* p, uint32_t* planes,
+                    size_t plane_stride, snn_stream_t s) {
+    return encode_rows_impl(x, R, D, T, p, planes, plane_stride, false, s);
 }
 
 
@@ -743,9 +773,9 @@ int snn_nms_sorted(const float* boxes_sorted, const int* category_sorted, int n,
     return 0;
 }
 
-int snn_roi_align_encode(const snn_roi_level* levels_host, int n_levels, int C, const float* rois, const int* roi_batch,
-                         const int* roi_level, int R, int T, const snn_params* p, uint32_t* planes,
-                         size_t plane_stride, float* pooled_dbg, snn_stream_t s) {
+static int roi_align_encode_impl(const snn_roi_level* levels_host, int n_levels, int C, const float* rois, const int* roi_batch,
+                                 const int* roi_level, int R, int T, const snn_params* p, uint32_t* planes,
+                                 size_t plane_stride, float* pooled_dbg, bool wm, snn_stream_t s) {
     if (!levels_host || n_levels <= 0 || n_levels > 4 || C <= 0 || !rois || !roi_batch || !roi_level || R <= 0 || !p ||
         !planes)
         return fail(-1, "snn_roi_align_encode: bad argument");
@@ -761,9 +791,17 @@ int snn_roi_align_encode(const snn_roi_level* levels_host, int n_levels, int C, 
     a.rois = rois; a.roi_batch = roi_batch; a.roi_level = roi_level; a.pooled = pooled_dbg; a.planes = planes;
     a.plane_stride = plane_stride; a.R = R; a.C = C; a.T = T; a.Dw = cdiv(C * 49, 32);
     a.p = make_p(p, p->v_th_enc);
-    hipLaunchKernelGGL(k_roi_align_encode, dim3(cdiv(a.Dw * 32, 256), R), dim3(256), 0, (hipStream_t)s, a);
+    if (wm) hipLaunchKernelGGL(k_roi_align_encode_wm, dim3(cdiv(a.Dw, 2), cdiv(R, 32)), dim3(256), 0, (hipStream_t)s, a);
+    else hipLaunchKernelGGL(k_roi_align_encode, dim3(cdiv(a.Dw * 32, 256), R), dim3(256), 0, (hipStream_t)s, a);
     SNN_CHECK_LAUNCH("k_roi_align_encode");
     return 0;
+}
+
+int snn_roi_align_encode(const snn_roi_level* levels_host, int n_levels, int C, const float* rois, const int* roi_batch,
+                         const int* roi_level, int R, int T, const snn_params* p, uint32_t* planes,
+                         size_t plane_stride, float* pooled_dbg, snn_stream_t s) {
+    return roi_align_encode_impl(levels_host, n_levels, C, rois, roi_batch, roi_level, R, T, p, planes, plane_stride, pooled_dbg,
+                                 false, s);
 }
 
 // shared by snn_conv3x3_lif (one level) and snn_rpn_head_forward (all levels in one launch)
@@ -976,6 +1014,8 @@ int snn_rpn_head_forward_stages(const snn_rpn_level* lv, int n_levels, int C, in
     const int Cw = cdiv(C, 32);
     const size_t stride = (size_t)P * Cw;            // words per time plane (spike planes)
     const size_t enc_stride = (size_t)Pe * Cw;       // ... of the encoder planes
+    // bf16x3: encoder planes word-major [T][Cw][Pe] - a conv tile's spike words of a chunk are then 128-byte runs
+    const size_t wm_rows = (p->precision == SNN_PRECISION_BF16X3 && !knobs().planes_rm) ? (size_t)Pe : 0;
     uint32_t* enc = (uint32_t*)ws;
     uint32_t* spk = (uint32_t*)((char*)ws + o_spk);
     hipStream_t s = (hipStream_t)stream;
@@ -1001,14 +1041,14 @@ int snn_rpn_head_forward_stages(const snn_rpn_level* lv, int n_levels, int C, in
                 images += lv[l].N;
             }
             hl.blk_base[n_levels] = images; hl.n_levels = n_levels;
-            hipLaunchKernelGGL(k_zero_halo, dim3(images, 32), dim3(256), 0, s, hl, Cw, T, enc, enc_stride);
+            hipLaunchKernelGGL(k_zero_halo, dim3(images, 32), dim3(256), 0, s, hl, Cw, T, enc, enc_stride, wm_rows);
             SNN_CHECK_LAUNCH("k_zero_halo");
         }
         const NeuronP np = make_p(p, p->v_th_enc);
         if (enc_zero_rest(np))
-            hipLaunchKernelGGL(k_encode_levels<true>, dim3(blocks, cdiv(Cw, 8)), dim3(256), 0, s, el, C, Cw, T, np, enc, enc_stride);
+            hipLaunchKernelGGL(k_encode_levels<true>, dim3(blocks, cdiv(Cw, 8)), dim3(256), 0, s, el, C, Cw, T, np, enc, enc_stride, wm_rows);
         else
-            hipLaunchKernelGGL(k_encode_levels<false>, dim3(blocks, cdiv(Cw, 8)), dim3(256), 0, s, el, C, Cw, T, np, enc, enc_stride);
+            hipLaunchKernelGGL(k_encode_levels<false>, dim3(blocks, cdiv(Cw, 8)), dim3(256), 0, s, el, C, Cw, T, np, enc, enc_stride, wm_rows);
         SNN_CHECK_LAUNCH("k_encode_levels");
     }
     if (stage_mask & SNN_STAGE_CONV_LIF) {
@@ -1031,7 +1071,7 @@ int snn_rpn_head_forward_stages(const snn_rpn_level* lv, int n_levels, int C, in
                          ? conv3x3_lif_mx_impl(enc, enc_stride, lv, n_levels, C, C, T, p, (const uint32_t*)w_shared_packed, spk, stride,
                                                spike_counts, max_n, stream)
                          : conv3x3_lif_bf16x3_impl(enc, enc_stride, lv, n_levels, C, C, T, p, (const uint16_t*)w_shared_packed,
-                                                   spk, stride, spike_counts, max_n, stream);
+                                                   spk, stride, spike_counts, max_n, stream, wm_rows != 0);
             if (rc) return rc;
         }
     }
@@ -1307,10 +1347,18 @@ size_t snn_det_head_workspace_bytes(int R, int D, int Hd, int K, int K4, int T, 
     return tot;
 }
 
+// the detector's bf16x3 path with both linear layers fused with their LIF (one row tile holds all T steps)
+static bool det_b3_tiles(const snn_params* p, int T) {
+    return p->precision == SNN_PRECISION_BF16X3 &&
+           (g3_tile_ok(T, G3_BM(g3_wn(), 4)) || g3_tile_ok(T, G3_BM(g3_wn(), 3)) || g3_tile_ok(T, G3_BM(g3_wn(), 2)));
+}
+// ... which takes its encoder planes word-major [T][D/32][R] (and hands fc6's spikes to fc7 that way)
+static bool det_planes_wm(const snn_params* p, int T) { return det_b3_tiles(p, T) && !knobs().planes_rm; }
+
 static int det_head_from_planes(int R, int D, int Hd, int K, int K4, int T, const snn_params* p, const void* w6_packed,
                                 const void* w7_packed, const float* w_heads_packed, float* out_cls, float* out_bbox,
                                 uint32_t* spk6_count, uint32_t* spk7_count, float* sum_cls, float* sum_bbox, void* ws,
-                                snn_stream_t stream) {
+                                bool enc_wm, snn_stream_t stream) {
     size_t o_enc, o_cur, o_s6, o_s7, need;
     det_ws_layout(R, D, Hd, T, &o_enc, &o_cur, &o_s6, &o_s7, &need);
     hipStream_t s = (hipStream_t)stream;
@@ -1333,12 +1381,14 @@ static int det_head_from_planes(int R, int D, int Hd, int K, int K4, int T, cons
         return snn_li_heads(s7, (size_t)R * Hw, T, R, Hd, w_heads_packed, K, K4, p, out_cls, out_bbox, sum_cls,
                             sum_bbox, stream);
     }
-    if (b3 && (g3_tile_ok(T, G3_BM(g3_wn(), 4)) || g3_tile_ok(T, G3_BM(g3_wn(), 3)) || g3_tile_ok(T, G3_BM(g3_wn(), 2)))) {
+    if (enc_wm && !det_b3_tiles(p, T)) return fail(-1, "snn_det_head_forward: word-major planes without the fused bf16x3 layers");
+    if (det_b3_tiles(p, T)) {
         // fc6 + LIF and fc7 + LIF, each one launch: a row tile holds all T steps of its RoIs, the currents never
         // leave the chip (faster_rcnn.py:498-501)
         // (spike-rate mode: per-RoI counts come out of the LIF epilogues)
-        if ((rc = spike_gemm_lif_bf16x3_impl(enc, T, R, D, Hd, p, (const uint16_t*)w6_packed, s6, (size_t)R * Hw, spk6_count, stream))) return rc;
-        if ((rc = spike_gemm_lif_bf16x3_impl(s6, T, R, Hd, Hd, p, (const uint16_t*)w7_packed, s7, (size_t)R * Hw, spk7_count, stream))) return rc;
+        // (word-major planes between the stages: encoder -> fc6 -> fc7; fc7's spikes feed the LI heads row-major)
+        if ((rc = spike_gemm_lif_bf16x3_impl(enc, T, R, D, Hd, p, (const uint16_t*)w6_packed, s6, (size_t)R * Hw, spk6_count, stream, enc_wm, enc_wm))) return rc;
+        if ((rc = spike_gemm_lif_bf16x3_impl(s6, T, R, Hd, Hd, p, (const uint16_t*)w7_packed, s7, (size_t)R * Hw, spk7_count, stream, enc_wm, false))) return rc;
         return snn_li_heads(s7, (size_t)R * Hw, T, R, Hd, w_heads_packed, K, K4, p, out_cls, out_bbox, sum_cls,
                             sum_bbox, stream);
     }
@@ -1366,10 +1416,11 @@ int snn_det_head_forward(const float* x, int R, int D, int Hd, int K, int K4, in
     size_t o_enc, o_cur, o_s6, o_s7, need;
     det_ws_layout(R, D, Hd, T, &o_enc, &o_cur, &o_s6, &o_s7, &need);
     if (ws_bytes < need) return fail(-2, "snn_det_head_forward: workspace %zu < %zu bytes", ws_bytes, need);
-    int rc = snn_encode_rows(x, R, D, T, p, (uint32_t*)((char*)ws + o_enc), (size_t)R * cdiv(D, 32), stream);
+    const bool wm = det_planes_wm(p, T) && encode_rows_wm_ok(x, D);
+    int rc = encode_rows_impl(x, R, D, T, p, (uint32_t*)((char*)ws + o_enc), (size_t)R * cdiv(D, 32), wm, stream);
     if (rc) return rc;
     return det_head_from_planes(R, D, Hd, K, K4, T, p, w6_packed, w7_packed, w_heads_packed, out_cls, out_bbox,
-                                spk6_count, spk7_count, sum_cls, sum_bbox, ws, stream);
+                                spk6_count, spk7_count, sum_cls, sum_bbox, ws, wm, stream);
 }
 
 int snn_det_head_forward_roialign(const snn_roi_level* levels_host, int n_levels, int C, const float* rois,
@@ -1385,11 +1436,12 @@ int snn_det_head_forward_roialign(const snn_roi_level* levels_host, int n_levels
     size_t o_enc, o_cur, o_s6, o_s7, need;
     det_ws_layout(R, D, Hd, T, &o_enc, &o_cur, &o_s6, &o_s7, &need);
     if (ws_bytes < need) return fail(-2, "snn_det_head_forward_roialign: workspace %zu < %zu bytes", ws_bytes, need);
-    int rc = snn_roi_align_encode(levels_host, n_levels, C, rois, roi_batch, roi_level, R, T, p,
-                                  (uint32_t*)((char*)ws + o_enc), (size_t)R * cdiv(D, 32), nullptr, stream);
+    const bool wm = det_planes_wm(p, T);
+    int rc = roi_align_encode_impl(levels_host, n_levels, C, rois, roi_batch, roi_level, R, T, p,
+                                   (uint32_t*)((char*)ws + o_enc), (size_t)R * cdiv(D, 32), nullptr, wm, stream);
     if (rc) return rc;
     return det_head_from_planes(R, D, Hd, K, K4, T, p, w6_packed, w7_packed, w_heads_packed, out_cls, out_bbox,
-                                spk6_count, spk7_count, sum_cls, sum_bbox, ws, stream);
+                                spk6_count, spk7_count, sum_cls, sum_bbox, ws, wm, stream);
 }
 
 int snn_det_exchange_payload(const float* class_logits, const float* box_regression, int N, int rois_per_image, int K,

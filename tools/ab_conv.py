@@ -35,6 +35,7 @@ while args:
         lib._path = path
         lib._unpadded = name.startswith("R1")            # round-1 builds read un-padded encoder planes
         lib._clock = "CLK" in name                       # -DSNN_EXP_CLOCK build: stamps behind the spike planes
+        lib._wm = env.get("SNN_STAGE_PLANES") == "wm"    # this instance takes its input planes word-major [T][word][row]
         if hasattr(lib, "snn_debug_reload_knobs"):
             lib.snn_debug_reload_knobs()
         for k in env:
@@ -71,14 +72,22 @@ spk6 = spk6_buf[:T6 * R * (Hd // 32)].view(T6, R, Hd // 32)
 st = torch.cuda.current_stream().cuda_stream
 
 
+encs_pad_wm = encs_pad.permute(0, 2, 1).contiguous()
+enc6_wm = None
+
+
 def conv(lib):
-    e, n = (encs, P) if getattr(lib, "_unpadded", False) else (encs_pad, PP)
+    e, n = (encs, P) if getattr(lib, "_unpadded", False) else ((encs_pad_wm, PP) if getattr(lib, "_wm", False) else (encs_pad, PP))
     rc = lib.snn_conv3x3_lif_bf16x3(e.data_ptr(), n * 8, lv, 5, 256, 256, T, C.byref(p), wb.data_ptr(), spk.data_ptr(), P * 8, st)
     assert rc == 0, lib.snn_last_error()
 
 
 def fc6(lib):
-    rc = lib.snn_spike_gemm_lif_bf16x3(enc6.data_ptr(), T6, R, D, Hd, C.byref(p), w6b.data_ptr(), spk6.data_ptr(), R * (Hd // 32), st)
+    global enc6_wm
+    if getattr(lib, "_wm", False) and enc6_wm is None:
+        enc6_wm = enc6.permute(0, 2, 1).contiguous()
+    a = enc6_wm if getattr(lib, "_wm", False) else enc6
+    rc = lib.snn_spike_gemm_lif_bf16x3(a.data_ptr(), T6, R, D, Hd, C.byref(p), w6b.data_ptr(), spk6.data_ptr(), R * (Hd // 32), st)
     assert rc == 0, lib.snn_last_error()
 
 

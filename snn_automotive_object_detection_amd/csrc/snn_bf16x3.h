@@ -604,7 +604,12 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
                         my1 = lane == t ? (uint32_t)(b >> 32) : my1;
                         cnt += __popcll(two ? b : (b & 0xffffffffull));
                     }
-                    if (lane < T) {
+#ifndef SNN_EXP_NO_SPK_STORE                      // (timing only: the spike planes are not written)
+                    if (lane < T)
+#else
+                    if (lane < T && args.T > 1000)
+#endif
+                    {
                         if (!CONV && args.out_wm) {                    // word-major planes [T][word][row] (fc6 -> fc7)
                             uint32_t* dst = args.spk + (size_t)lane * args.spk_stride + (size_t)word0 * M + pos;
                             dst[0] = my0;

@@ -117,7 +117,7 @@ struct Knobs {
     bool enc_generic;        // SNN_ENC_GENERIC=1     op-for-op encoder kernels even for zero rest / reset potentials
     bool enc_rows_ballot;    // SNN_ENC_ROWS=ballot   element-per-lane row encoder
     int bf16x3_mt;           // SNN_BF16X3_MT=2|3|4   M-tiles per wave (0: cost model)
-    int bf16x3_wn;           // SNN_BF16X3_WN=1|2     waves along N of the tile (default 2)
+    int bf16x3_wn;           // SNN_BF16X3_WN=1|2     waves along N of the tile (default 1: 512 x 64 tile)
     bool bf16x3_lif_reg;     // SNN_BF16X3_LIF=reg    register-resident conv + LIF fusion instead of T-in-tile
     int mx_mw;               // SNN_MX_MW=4|8         rows per wave of k_gemm_mx
     int li_heads;            // SNN_LI_HEADS=valu|mfma|ksplit -> 1 | 2 | 3 (0: by shape)
@@ -133,7 +133,7 @@ static Knobs load_knobs() {
     k.enc_generic = (e = getenv("SNN_ENC_GENERIC")) && e[0] == '1';
     k.enc_rows_ballot = (e = getenv("SNN_ENC_ROWS")) && !strcmp(e, "ballot");
     k.bf16x3_mt = (e = getenv("SNN_BF16X3_MT")) ? atoi(e) : 0;
-    k.bf16x3_wn = ((e = getenv("SNN_BF16X3_WN")) && e[0] == '1') ? 1 : 2;
+    k.bf16x3_wn = ((e = getenv("SNN_BF16X3_WN")) && e[0] == '2') ? 2 : 1;
     k.bf16x3_lif_reg = (e = getenv("SNN_BF16X3_LIF")) && !strcmp(e, "reg");
     e = getenv("SNN_MX_MW");
     k.mx_mw = (e && e[0] == '8') ? 8 : ((e && e[0] == '4') ? 4 : 0);
@@ -184,10 +184,10 @@ static int g3_pick_mt(F tiles_of) {
 #ifndef G3_NB1
 #define G3_NB1 4                                    // ring slots of the 8 x 1 wave grid (14 KB each)
 #endif
-// waves along N of the bf16x3 tile: 2 (256 x 128 tile, default) or 1 (512 x 64 tile: half the weight copies per
-// FLOP, 4-slot ring).  Both run at the same speed (conv+LIF 2.95 / 2.94 ms on one box): the copies are not what the
-// kernel waits for - timing builds without them run faster because MFMAs on all-zero operands draw less power and
-// the chip clocks up, not because the copies cost time.  SNN_BF16X3_WN=1|2 is an A-B / test knob.
+// waves along N of the bf16x3 tile: 1 (512 x 64 tile, 4-slot ring; default since the spike planes are word-major) or 2
+// (256 x 128 tile).  The 512 x 64 tile pulls half the weight-plane bytes per MFMA through the L2 -> LDS path, which is what the
+// clock under this kernel pays for (+3.6 % clock); with row-major planes its doubled spike-word gather ate the
+// gain (conv -1.4 %, fc6 +2.9 %), with word-major planes it is conv -1.7 %, detector head -1.5 %.  SNN_BF16X3_WN=1|2: A-B / test knob.
 static int g3_wn() { return knobs().bf16x3_wn; }
 
 // rows of the work-group tile (MT = 8 is the 256 x 128 tile of MT = 4 / WN = 2 run by four fat waves)

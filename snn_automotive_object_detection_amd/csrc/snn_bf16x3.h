@@ -107,6 +107,7 @@ struct Gemm3Args {
     // its spike planes word-major as well (fc6 -> fc7).
     int wm, out_wm;
     unsigned long long a_step;
+    int xcd_classes, n_tiles;    // XCD-aware block order (0: plain row-major order), row tiles of the launch
     NeuronP p;
     ConvLevelDev lv[SNN_MAX_LEVELS];
 };
@@ -209,8 +210,18 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
     // which then stay resident in its 4-MB L2 beside the streaming spike planes.  Both re-orderings tried (each XCD a
     // contiguous eighth of the tiles; both column blocks of a tile on one XCD) put all panels on every XCD and
     // multiplied the L2 fills: FETCH_SIZE 102 -> 323 / 535 MB per launch at unchanged kernel time (profiles/r1_h_*).
-    const int nb = blockIdx.x % args.n_blocks;
-    const int mb = blockIdx.x / args.n_blocks;
+    // xcd_classes > 0 (launch_gemm3, four or more column blocks): work-group b = XCD x = b % 8, j = b / 8 takes column block
+    // 2 (x % groups) + j % 2 of row tile (j / 2) * classes + x / groups - an XCD sees TWO adjacent weight panels (as much L2 as
+    // the one panel of the 256 x 128 tile) and both of them for the same row tiles, so a tile's spike rows come into half as
+    // many L2s.  Tiles past the end (the grid is padded to a multiple of `classes` tiles) leave at once.
+    int nb = blockIdx.x % args.n_blocks;
+    int mb = blockIdx.x / args.n_blocks;
+    if (args.xcd_classes) {
+        const int groups = 8 / args.xcd_classes, x = blockIdx.x & 7, j = blockIdx.x >> 3;
+        nb = 2 * (x % groups) + (j & 1);
+        mb = (j >> 1) * args.xcd_classes + x / groups;
+        if (mb >= args.n_tiles) return;
+    }
     const int m0 = TILE ? mb * args.pb : mb * BM;            // first row (TILE: first position) of the tile
     const int Kc = args.Kc, Np = args.Np, M = args.M;
 

@@ -117,15 +117,17 @@ struct Knobs {
     bool enc_generic;        // SNN_ENC_GENERIC=1     op-for-op encoder kernels even for zero rest / reset potentials
     bool enc_rows_ballot;    // SNN_ENC_ROWS=ballot   element-per-lane row encoder
     int bf16x3_mt;           // SNN_BF16X3_MT=2|3|4   M-tiles per wave (0: cost model)
-    int bf16x3_wn;           // SNN_BF16X3_WN=1|2     waves along N of the tile (default 1: 512 x 64 tile)
+    int bf16x3_wn;           // SNN_BF16X3_WN=1|2     waves along N of the tile (0 = default: linear layers 1 = 512 x 64 tile, conv 2 = 256 x 128)
     bool bf16x3_lif_reg;     // SNN_BF16X3_LIF=reg    register-resident conv + LIF fusion instead of T-in-tile
     int mx_mw;               // SNN_MX_MW=4|8         rows per wave of k_gemm_mx
     int li_heads;            // SNN_LI_HEADS=valu|mfma|ksplit -> 1 | 2 | 3 (0: by shape)
     bool debug_occ;          // SNN_DEBUG_OCC         print occupancy of the big kernels
+    bool bf16x3_xcd;         // SNN_BF16X3_XCD=0      plain block order instead of the XCD-aware one (A/B)
     bool stage_wm;           // SNN_STAGE_PLANES=wm   A/B harness only: snn_conv3x3_lif_bf16x3 / snn_spike_gemm_lif_bf16x3 take their
                              //                       INPUT planes word-major ([T][word][row]; tools/ab_conv.py)
-    bool planes_rm;          // SNN_PLANES=rm         the bf16x3 heads keep their internal spike planes row-major [T][row][word]
-                             //                       (default: word-major [T][word][row]; bit-identical results, A/B + test switch)
+    int planes;              // SNN_PLANES=rm|wm      internal spike planes of the bf16x3 heads: all row-major [T][row][word] / all
+                             //                       word-major [T][word][row] (1 / 2; 0 = default: linear layers word-major, conv
+                             //                       row-major; bit-identical results either way, A/B + test switch)
 };
 static Knobs load_knobs() {
     Knobs k;
@@ -133,14 +135,17 @@ static Knobs load_knobs() {
     k.enc_generic = (e = getenv("SNN_ENC_GENERIC")) && e[0] == '1';
     k.enc_rows_ballot = (e = getenv("SNN_ENC_ROWS")) && !strcmp(e, "ballot");
     k.bf16x3_mt = (e = getenv("SNN_BF16X3_MT")) ? atoi(e) : 0;
-    k.bf16x3_wn = ((e = getenv("SNN_BF16X3_WN")) && e[0] == '2') ? 2 : 1;
+    e = getenv("SNN_BF16X3_WN");
+    k.bf16x3_wn = (e && e[0] == '2') ? 2 : (e && e[0] == '1') ? 1 : 0;
     k.bf16x3_lif_reg = (e = getenv("SNN_BF16X3_LIF")) && !strcmp(e, "reg");
     e = getenv("SNN_MX_MW");
     k.mx_mw = (e && e[0] == '8') ? 8 : ((e && e[0] == '4') ? 4 : 0);
     e = getenv("SNN_LI_HEADS");
     k.li_heads = !e ? 0 : !strcmp(e, "valu") ? 1 : !strcmp(e, "mfma") ? 2 : !strcmp(e, "ksplit") ? 3 : 4;
     k.debug_occ = getenv("SNN_DEBUG_OCC") != nullptr;
-    k.planes_rm = (e = getenv("SNN_PLANES")) && !strcmp(e, "rm");
+    e = getenv("SNN_PLANES");
+    k.planes = !e ? 0 : !strcmp(e, "rm") ? 1 : !strcmp(e, "wm") ? 2 : 0;
+    k.bf16x3_xcd = !((e = getenv("SNN_BF16X3_XCD")) && e[0] == '0');
     k.stage_wm = (e = getenv("SNN_STAGE_PLANES")) && !strcmp(e, "wm");
     return k;
 }
@@ -184,11 +189,13 @@ static int g3_pick_mt(F tiles_of) {
 #ifndef G3_NB1
 #define G3_NB1 4                                    // ring slots of the 8 x 1 wave grid (14 KB each)
 #endif
-// waves along N of the bf16x3 tile: 1 (512 x 64 tile, 4-slot ring; default since the spike planes are word-major) or 2
-// (256 x 128 tile).  The 512 x 64 tile pulls half the weight-plane bytes per MFMA through the L2 -> LDS path, which is what the
-// clock under this kernel pays for (+3.6 % clock); with row-major planes its doubled spike-word gather ate the
-// gain (conv -1.4 %, fc6 +2.9 %), with word-major planes it is conv -1.7 %, detector head -1.5 %.  SNN_BF16X3_WN=1|2: A-B / test knob.
-static int g3_wn() { return knobs().bf16x3_wn; }
+// waves along N of the bf16x3 tile: 1 (512 x 64 tile, 4-slot ring) or 2 (256 x 128 tile).  The 512 x 64 tile pulls half the
+// weight-plane bytes per MFMA through the L2 -> LDS path, which is what the clock under these kernels pays for (DESIGN.md 4.1:
+// +3.6 % clock); with row-major spike planes its doubled spike-word gather ate the gain, with word-major planes it is conv
+// -1.7 %, detector head -1.5 %.  Defaults: the linear layers take it; the 3x3 convolution stays on 256 x 128, because with four
+// column blocks every spike row and every output row passes through twice as many XCDs (FETCH 84 -> 190-206 MB, WRITE 98 ->
+// 98-198 MB per launch) for those 1.7 %.  SNN_BF16X3_WN=1|2 forces one shape everywhere (A-B / test knob).
+static int g3_wn(bool conv = false) { return knobs().bf16x3_wn ? knobs().bf16x3_wn : (conv ? 2 : 1); }
 
 // rows of the work-group tile (MT = 8 is the 256 x 128 tile of MT = 4 / WN = 2 run by four fat waves)
 static int g3_bm(int wn, int mt) { return mt == 8 ? 256 : G3_BM(wn, mt); }
@@ -397,6 +404,16 @@ static int launch_gemm3(int mode, int mt, int wn, const Gemm3Args& a, hipStream_
     default: kern = g3_kernel<G3_FC_LIF_TILE>(mt, wn); tiles = cdiv(a.M, a.pb); lds = max(lds, tile_lds); break;
     }
     static_assert(2 * (G3_TILE_BYTES(1) + G3_CNT_BYTES) <= 160 * 1024 && 2 * G3_LDS(3, 2) <= 160 * 1024, "two work-groups per CU");
+    // XCD-aware order for launches with 4, 8 or 16 column blocks whose weight panels are small enough to stay in an XCD's L2
+    // in pairs (the RPN conv: 2 x 0.9 MB): see k_gemm_bf16x3.  SNN_BF16X3_XCD=0 switches it off (A/B).
+    Gemm3Args ax = a;
+    ax.n_tiles = tiles; ax.xcd_classes = 0;
+    int grid = tiles * a.n_blocks;
+    const size_t pair_bytes = (size_t)2 * G3_BN(wn) * a.Kc * 32 * 2 * 3;
+    if (knobs().bf16x3_xcd && mt != 8 && (a.n_blocks == 4 || a.n_blocks == 8 || a.n_blocks == 16) && pair_bytes <= (size_t)2 << 20) {
+        ax.xcd_classes = 8 / (a.n_blocks / 2);
+        grid = cdiv(tiles, ax.xcd_classes) * ax.xcd_classes * a.n_blocks;
+    }
     hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return fail(-3, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
     if (knobs().debug_occ) {                                   // debug: co-resident work-groups per CU
@@ -404,8 +421,8 @@ static int launch_gemm3(int mode, int mt, int wn, const Gemm3Args& a, hipStream_
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, kern, threads, lds);
         fprintf(stderr, "k_gemm_bf16x3 mode %d mt %d wn %d: lds %d B, %d work-groups per CU, grid %d\n", mode, mt, wn, lds, v, tiles * a.n_blocks);
     }
-    void* kargs[] = {(void*)&a};
-    e = hipLaunchKernel(kern, dim3(tiles * a.n_blocks), dim3(threads), kargs, lds, s);
+    void* kargs[] = {(void*)&ax};
+    e = hipLaunchKernel(kern, dim3(grid), dim3(threads), kargs, lds, s);
     if (e != hipSuccess) return fail(-3, "k_gemm_bf16x3 launch failed: %s", hipGetErrorString(e));
     SNN_CHECK_LAUNCH("k_gemm_bf16x3");
     return 0;
@@ -623,7 +640,7 @@ static int conv3x3_lif_bf16x3_impl(const uint32_t* enc, size_t enc_stride, const
     }
     a.M = (int)P; a.T = T; a.spk = spk; a.spk_stride = spk_stride; a.p = make_p(p, p->v_th_lif);
     // debug / A-B knob: SNN_BF16X3_LIF=reg forces the register-resident variant (the fallback for T > 64)
-    const int wn = g3_wn();
+    const int wn = g3_wn(true);
     int mt = 0;
     if (!knobs().bf16x3_lif_reg) {
         a.n_blocks = cdiv(a.Np, G3_BN(wn));
@@ -669,7 +686,7 @@ int snn_spike_conv3x3_bf16x3(const uint32_t* enc, size_t enc_stride, const snn_r
     int rc = conv3_common("snn_spike_conv3x3_bf16x3", enc, enc_stride, lv, n_levels, C_in, C_out, T, w_packed, a, &P);
     if (rc) return rc;
     a.out = cur; a.ldo = ldo; a.M = (int)(T * P);
-    const int wn = g3_wn();
+    const int wn = g3_wn(true);
     a.n_blocks = cdiv(a.Np, G3_BN(wn));
     const int mt = g3_pick_mt([&](int m) { return (long long)cdiv(a.M, g3_bm(wn, m)) * a.n_blocks; });
     return launch_gemm3(G3_CONV, mt, wn, a, (hipStream_t)s);
@@ -1014,8 +1031,10 @@ int snn_rpn_head_forward_stages(const snn_rpn_level* lv, int n_levels, int C, in
     const int Cw = cdiv(C, 32);
     const size_t stride = (size_t)P * Cw;            // words per time plane (spike planes)
     const size_t enc_stride = (size_t)Pe * Cw;       // ... of the encoder planes
-    // bf16x3: encoder planes word-major [T][Cw][Pe] - a conv tile's spike words of a chunk are then 128-byte runs
-    const size_t wm_rows = (p->precision == SNN_PRECISION_BF16X3 && !knobs().planes_rm) ? (size_t)Pe : 0;
+    // bf16x3, SNN_PLANES=wm: encoder planes word-major [T][Cw][Pe] - a conv tile's spike words of a chunk are then 128-byte
+    // runs.  Not the default for the convolution: -0.7 % of kernel time, but a 128-byte line of a word plane is shared by
+    // horizontally adjacent tiles (on different XCDs), FETCH_SIZE 84 -> 177 MB per launch
+    const size_t wm_rows = (p->precision == SNN_PRECISION_BF16X3 && knobs().planes == 2) ? (size_t)Pe : 0;
     uint32_t* enc = (uint32_t*)ws;
     uint32_t* spk = (uint32_t*)((char*)ws + o_spk);
     hipStream_t s = (hipStream_t)stream;
@@ -1353,7 +1372,7 @@ static bool det_b3_tiles(const snn_params* p, int T) {
            (g3_tile_ok(T, G3_BM(g3_wn(), 4)) || g3_tile_ok(T, G3_BM(g3_wn(), 3)) || g3_tile_ok(T, G3_BM(g3_wn(), 2)));
 }
 // ... which takes its encoder planes word-major [T][D/32][R] (and hands fc6's spikes to fc7 that way)
-static bool det_planes_wm(const snn_params* p, int T) { return det_b3_tiles(p, T) && !knobs().planes_rm; }
+static bool det_planes_wm(const snn_params* p, int T) { return det_b3_tiles(p, T) && knobs().planes != 1; }
 
 static int det_head_from_planes(int R, int D, int Hd, int K, int K4, int T, const snn_params* p, const void* w6_packed,
                                 const void* w7_packed, const float* w_heads_packed, float* out_cls, float* out_bbox,

@@ -1,6 +1,7 @@
-"""Word-major spike planes ([T][word][row], the bf16x3 heads' internal format: csrc/snn_bf16x3.h Gemm3Args.wm, snn_encode.h
-K1a / K1b'' / K1c') against the row-major planes of the stage-level ABI (SNN_PLANES=rm): the layout changes which bytes a
-chunk fetches, not one arithmetic operation - outputs, spike counts and rate tensors must be bit-identical."""
+"""Word-major spike planes ([T][word][row]: csrc/snn_bf16x3.h Gemm3Args.wm, snn_encode.h K1a / K1b'' / K1c'; the default inside
+the bf16x3 detector head, SNN_PLANES=wm also for the RPN convolution) against the row-major planes of the stage-level ABI
+(SNN_PLANES=rm): the layout changes which bytes a chunk fetches, not one arithmetic operation - outputs, spike counts and rate
+tensors must be bit-identical."""
 import pytest
 import torch
 
@@ -10,8 +11,12 @@ pytestmark = pytest.mark.gpu
 def _both(monkeypatch, fn):
     monkeypatch.setenv("SNN_PLANES", "rm")
     rm = fn()
-    monkeypatch.delenv("SNN_PLANES")
+    monkeypatch.setenv("SNN_PLANES", "wm")
     wm = fn()
+    monkeypatch.delenv("SNN_PLANES")
+    default = fn()                          # linear layers word-major, convolution row-major
+    for a, b in zip(rm, default):
+        assert torch.equal(a, b)
     return rm, wm
 
 

@@ -107,6 +107,11 @@ struct Gemm3Args {
     // its spike planes word-major as well (fc6 -> fc7).
     int wm, out_wm;
     unsigned long long a_step;
+    // out_split (conv + LIF tile epilogue): spike planes in blocks of four words, [T][word / 4][position][4] - a work-group's
+    // 128 columns are then ONE 16-byte piece per (t, position) and consecutive positions are adjacent (512-byte runs per time
+    // step and tile) instead of half of every 32-byte row: whole 32-byte sectors leave the L2 (WRITE_SIZE 98 -> 49 MB per
+    // launch at the Cityscapes pyramid).  Read by k_li_heads_mfma (LiHeadsArgs.half_split).
+    int out_split;
     int xcd_classes, n_tiles;    // XCD-aware block order (0: plain row-major order), row tiles of the launch
     NeuronP p;
     ConvLevelDev lv[SNN_MAX_LEVELS];
@@ -625,6 +630,10 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
                             uint32_t* dst = args.spk + (size_t)lane * args.spk_stride + (size_t)word0 * M + pos;
                             dst[0] = my0;
                             if (two) dst[M] = my1;
+                        } else if (CONV && args.out_split) {
+                            uint32_t* dst = args.spk + (size_t)lane * args.spk_stride + ((size_t)(word0 >> 2) * M + pos) * 4 + (word0 & 3);
+                            dst[0] = my0;
+                            if (two) dst[1] = my1;                      // word0 is even: the pair stays inside its block of four
                         } else {
                             uint32_t* dst = args.spk + (size_t)lane * args.spk_stride + (size_t)pos * (Np >> 5) + word0;
                             dst[0] = my0;
@@ -657,6 +666,10 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
                             uint32_t* dst = args.spk + (size_t)lane * args.spk_stride + (size_t)word0 * M + (m0 + 2 * pp);
                             dst[0] = my0;
                             if (odd_ok) dst[1] = my1;
+                        } else if (CONV && args.out_split) {
+                            uint32_t* dst = args.spk + (size_t)lane * args.spk_stride + ((size_t)(word0 >> 2) * M + m0 + 2 * pp) * 4 + (word0 & 3);
+                            dst[0] = my0;
+                            if (odd_ok) dst[4] = my1;
                         } else {
                             uint32_t* dst = args.spk + (size_t)lane * args.spk_stride + (size_t)(m0 + 2 * pp) * (Np >> 5) + word0;
                             dst[0] = my0;

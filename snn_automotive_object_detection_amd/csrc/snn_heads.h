@@ -153,6 +153,7 @@ struct LiHeadsArgs {
     const float* wT;              // [Kp][NOp] fp32 (snn_pack_heads_weight)
     float *out_a, *out_b, *sum_a, *sum_b;
     int T, M, Kw, NOp, NA, NB, n_groups, resident;
+    int half_split;               // k_li_heads_mfma, Kw = 8: planes in blocks of four words [T][2][M][4] (Gemm3Args.out_split)
     Kappa kap;
 };
 
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(256) void k_li_heads_mfma(const LiHeadsArgs a) {
     for (int g = blockIdx.x; g < a.n_groups; g += gridDim.x) {
         const int m0 = (g * 4 + wave) * 16;
         const int mrow = min(m0 + lr, a.M - 1);                 // rows past M: recomputed, never stored
-        const uint32_t* wsrc = a.spk + (size_t)mrow * a.Kw;
+        const uint32_t* wsrc = a.spk + (size_t)mrow * (a.half_split ? 4 : a.Kw);
         f32x4 o_last[NT], o_sum[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) { o_last[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; o_sum[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(256) void k_li_heads_mfma(const LiHeadsArgs a) {
 #pragma unroll
                 for (int t = 0; t < LIH_TG; ++t) {
                     const uint4* q = reinterpret_cast<const uint4*>(wsrc + (size_t)(tg0 + (t < tn ? t : 0)) * a.spk_stride);
-                    wl[t][0] = q[0]; wl[t][1] = q[1];
+                    wl[t][0] = q[0]; wl[t][1] = a.half_split ? q[(size_t)a.M] : q[1];     // second half: M x 16 bytes on
                 }
 #pragma unroll
                 for (int kc = 0; kc < 8; ++kc) {

@@ -122,6 +122,8 @@ struct Knobs {
     int mx_mw;               // SNN_MX_MW=4|8         rows per wave of k_gemm_mx
     int li_heads;            // SNN_LI_HEADS=valu|mfma|ksplit -> 1 | 2 | 3 (0: by shape)
     bool debug_occ;          // SNN_DEBUG_OCC         print occupancy of the big kernels
+    bool spk_rows;           // SNN_SPK_SPLIT=0       the RPN conv writes plain row-major spike planes (A/B; default: blocks of four words
+                             //                       where the LI heads kernel reads them that way)
     bool bf16x3_xcd;         // SNN_BF16X3_XCD=0      plain block order instead of the XCD-aware one (A/B)
     bool stage_wm;           // SNN_STAGE_PLANES=wm   A/B harness only: snn_conv3x3_lif_bf16x3 / snn_spike_gemm_lif_bf16x3 take their
                              //                       INPUT planes word-major ([T][word][row]; tools/ab_conv.py)
@@ -146,6 +148,7 @@ static Knobs load_knobs() {
     e = getenv("SNN_PLANES");
     k.planes = !e ? 0 : !strcmp(e, "rm") ? 1 : !strcmp(e, "wm") ? 2 : 0;
     k.bf16x3_xcd = !((e = getenv("SNN_BF16X3_XCD")) && e[0] == '0');
+    k.spk_rows = (e = getenv("SNN_SPK_SPLIT")) && e[0] == '0';
     k.stage_wm = (e = getenv("SNN_STAGE_PLANES")) && !strcmp(e, "wm");
     return k;
 }
@@ -627,7 +630,11 @@ static int count_spikes_per_image(const snn_rpn_level* lv, int n_levels, int Cw,
 
 static int conv3x3_lif_bf16x3_impl(const uint32_t* enc, size_t enc_stride, const snn_rpn_level* lv, int n_levels, int C_in,
                                    int C_out, int T, const snn_params* p, const uint16_t* w_packed, uint32_t* spk,
-                                   size_t spk_stride, unsigned long long* counts, int max_n, snn_stream_t s, bool wm = false) {
+                                   size_t spk_stride, unsigned long long* counts, int max_n, snn_stream_t s, bool wm = false,
+                                   bool* out_split = nullptr) {
+    // out_split (in: wanted, out: done): spike planes in blocks of four words (Gemm3Args.out_split; T-in-tile kernels only)
+    const bool want_split = out_split && *out_split;
+    if (out_split) *out_split = false;
     if (!spk || !p) return fail(-1, "snn_conv3x3_lif_bf16x3: bad argument");
     Gemm3Args a;
     long long P;
@@ -654,6 +661,7 @@ static int conv3x3_lif_bf16x3_impl(const uint32_t* enc, size_t enc_stride, const
     }
     a.pb = g3_bm(wn, mt) / T;
     a.cnt_img = counts; a.max_n = max_n;
+    if (want_split && a.Np % 128 == 0) { a.out_split = 1; *out_split = true; }
     return launch_gemm3(G3_CONV_LIF_TILE, mt, wn, a, (hipStream_t)s);
 }
 
@@ -890,9 +898,17 @@ int snn_lif_scan(const float* cur, int T, int R, int N, int ldc, const snn_param
     return 0;
 }
 
-int snn_li_heads(const uint32_t* spk, size_t spk_stride, int T, int M, int K, const float* w_heads_packed,
-                 int NA, int NB, const snn_params* p, float* out_a, float* out_b, float* sum_a, float* sum_b,
-                 snn_stream_t s) {
+// the launch of snn_li_heads that can read spike planes in blocks of four words (k_li_heads_mfma with W resident, 8 words per row)
+static bool li_heads_reads_split(int K, int NA, int NB) {
+    const int Kw = cdiv(K, 32), NOp = cdiv(NA + NB, 16) * 16;
+    const int force = knobs().li_heads;
+    return Kw == 8 && NOp <= 64 && (size_t)Kw * 3 * NOp * 64 <= 96 * 1024 && (force == 0 || force == 2);
+}
+
+static int li_heads_impl(const uint32_t* spk, size_t spk_stride, int T, int M, int K, const float* w_heads_packed,
+                         int NA, int NB, const snn_params* p, float* out_a, float* out_b, float* sum_a, float* sum_b,
+                         bool half_split, snn_stream_t s) {
+    if (half_split && !li_heads_reads_split(K, NA, NB)) return fail(-1, "snn_li_heads: split planes need the resident matrix-core kernel");
     if (!spk || !w_heads_packed || !p || !out_a || !out_b || M <= 0 || K <= 0 || NA <= 0 || NB <= 0)
         return fail(-1, "snn_li_heads: bad argument");
     if ((sum_a == nullptr) != (sum_b == nullptr)) return fail(-1, "snn_li_heads: sum_a and sum_b go together");
@@ -927,6 +943,7 @@ int snn_li_heads(const uint32_t* spk, size_t spk_stride, int T, int M, int K, co
         a.spk = spk; a.spk_stride = spk_stride; a.wT = w_heads_packed; a.out_a = out_a; a.out_b = out_b;
         a.sum_a = sum_a; a.sum_b = sum_b; a.T = T; a.M = M; a.Kw = Kw; a.NOp = NOp; a.NA = NA; a.NB = NB; a.kap = kap;
         a.n_groups = cdiv(M, 64);
+        a.half_split = half_split;
         const size_t all = (size_t)Kw * 3 * NOp * 64;
         a.resident = all <= 96 * 1024;
         const size_t lds = G3_LUT_BYTES + (a.resident ? all : (size_t)2 * 3 * NOp * 64);
@@ -967,6 +984,12 @@ int snn_li_heads(const uint32_t* spk, size_t spk_stride, int T, int M, int K, co
                        w_heads_packed, NOp, NA, NB, kap, out_a, out_b, sum_a, sum_b);
     SNN_CHECK_LAUNCH("k_li_heads");
     return 0;
+}
+
+int snn_li_heads(const uint32_t* spk, size_t spk_stride, int T, int M, int K, const float* w_heads_packed,
+                 int NA, int NB, const snn_params* p, float* out_a, float* out_b, float* sum_a, float* sum_b,
+                 snn_stream_t s) {
+    return li_heads_impl(spk, spk_stride, T, M, K, w_heads_packed, NA, NB, p, out_a, out_b, sum_a, sum_b, false, s);
 }
 
 // ---- whole heads ---------------------------------------------------------------------------------
@@ -1031,6 +1054,12 @@ int snn_rpn_head_forward_stages(const snn_rpn_level* lv, int n_levels, int C, in
     const int Cw = cdiv(C, 32);
     const size_t stride = (size_t)P * Cw;            // words per time plane (spike planes)
     const size_t enc_stride = (size_t)Pe * Cw;       // ... of the encoder planes
+    // bf16x3 conv -> LI heads: spike planes in blocks of four words when the heads kernel that will run reads them so (C = 256).
+    // Decided up front, so that a stage-by-stage caller (bench.py's kernel breakdown) sees the same launches; a T that does
+    // not fit a row tile runs the register-fused conv, which writes plain rows: then the heads read plain rows
+    bool split = p->precision == SNN_PRECISION_BF16X3 && !knobs().spk_rows && li_heads_reads_split(C, A, 4 * A) &&
+                 !knobs().bf16x3_lif_reg && cdiv(C, 32) * 32 % 128 == 0 &&
+                 (g3_tile_ok(T, G3_BM(g3_wn(true), 4)) || g3_tile_ok(T, G3_BM(g3_wn(true), 3)) || g3_tile_ok(T, G3_BM(g3_wn(true), 2)));
     // bf16x3, SNN_PLANES=wm: encoder planes word-major [T][Cw][Pe] - a conv tile's spike words of a chunk are then 128-byte
     // runs.  Not the default for the convolution: -0.7 % of kernel time, but a 128-byte line of a word plane is shared by
     // horizontally adjacent tiles (on different XCDs), FETCH_SIZE 84 -> 177 MB per launch
@@ -1090,13 +1119,13 @@ int snn_rpn_head_forward_stages(const snn_rpn_level* lv, int n_levels, int C, in
                          ? conv3x3_lif_mx_impl(enc, enc_stride, lv, n_levels, C, C, T, p, (const uint32_t*)w_shared_packed, spk, stride,
                                                spike_counts, max_n, stream)
                          : conv3x3_lif_bf16x3_impl(enc, enc_stride, lv, n_levels, C, C, T, p, (const uint16_t*)w_shared_packed,
-                                                   spk, stride, spike_counts, max_n, stream, wm_rows != 0);
+                                                   spk, stride, spike_counts, max_n, stream, wm_rows != 0, &split);
             if (rc) return rc;
         }
     }
     if (!(stage_mask & SNN_STAGE_LI_HEADS)) return 0;
-    return snn_li_heads(spk, stride, T, (int)P, C, w_heads_packed, A, 4 * A, p, out_logits, out_bbox, sum_logits,
-                        sum_bbox, stream);
+    return li_heads_impl(spk, stride, T, (int)P, C, w_heads_packed, A, 4 * A, p, out_logits, out_bbox, sum_logits,
+                         sum_bbox, split, stream);
 }
 
 int snn_rpn_head_forward(const snn_rpn_level* lv, int n_levels, int C, int A, int T, const snn_params* p,

@@ -98,3 +98,29 @@ def test_misaligned_or_odd_width_rows_fall_back_to_row_major(gpu_device):
     xs.copy_(x)
     c2, b2 = m(xs)
     assert torch.equal(c, c2) and torch.equal(b, b2)
+
+
+@pytest.mark.parametrize("T", [8, 12, 24])
+@pytest.mark.parametrize("wn", ["1", "2"])
+def test_rpn_spike_planes_in_blocks_of_four_words_equal_plain_rows(gpu_device, monkeypatch, T, wn):
+    """conv -> LI heads hand-over at C = 256: planes [T][word / 4][position][4] (Gemm3Args.out_split, whole 32-byte sectors
+    leave the L2) against plain rows [T][position][8] (SNN_SPK_SPLIT=0): same outputs, spike counts and rates, bit for bit"""
+    import snn_automotive_object_detection_amd as S
+    torch.manual_seed(T)
+    m = S.RPNHeadSNN(256, 3, T).to(gpu_device)
+    with torch.no_grad():
+        m.shared_conv.weight.mul_(5.0)
+    m.spike_rates = True
+    feats = [torch.randn(n, 256, h, w, device=gpu_device) * 1.5 for n, h, w in [(2, 31, 47), (1, 9, 5), (2, 2, 3)]]
+    monkeypatch.setenv("SNN_BF16X3_WN", wn)
+
+    def run():
+        lg, bb, rates = m(feats)
+        return [x.clone() for x in lg + bb + list(rates)] + [m.last_spike_counts.clone()]
+    monkeypatch.setenv("SNN_SPK_SPLIT", "0")
+    plain = run()
+    monkeypatch.delenv("SNN_SPK_SPLIT")
+    split = run()
+    assert int(plain[-1].sum()) > 0
+    for a, b in zip(plain, split):
+        assert torch.equal(a, b)

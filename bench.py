@@ -307,35 +307,15 @@ def e2e_leg(model, dev, iters=5):
     # two batches in flight: one host thread + one HIP stream each (the forward has host syncs on the per-image proposal /
     # detection counts, so a single thread cannot keep two streams fed; workspaces are per stream, ops._Workspace).  The small
     # kernels of one batch (top-k, NMS lists, RoIAlign, transform) then run beside the big contractions of the other.
-    import threading
+    from snn_automotive_object_detection_amd import StreamPipeline
     n_str, per = 2, 12
-    streams = [torch.cuda.Stream(dev) for _ in range(n_str)]
-
-    errs = []
-
-    def worker(i):
-        try:
-            with torch.no_grad(), torch.cuda.stream(streams[i]):
-                for _ in range(per):
-                    model(imgs)
-                streams[i].synchronize()
-        except Exception as e:                      # a thread's exception must not vanish: the leg fails
-            errs.append(repr(e))
-    for i in range(n_str):                          # each stream grows its own allocator pool and workspaces first
-        with torch.no_grad(), torch.cuda.stream(streams[i]):
-            for _ in range(3):
-                model(imgs)
+    pipe = StreamPipeline(model, slots=n_str, device=dev)
+    pipe.map([imgs] * (3 * n_str))                  # each stream grows its own allocator pool and workspaces first
     sync()
     t0 = time.perf_counter()
-    th = [threading.Thread(target=worker, args=(i,)) for i in range(n_str)]
-    for t in th:
-        t.start()
-    for t in th:
-        t.join()
+    pipe.map([imgs] * (n_str * per))
     sync()
     ms2 = (time.perf_counter() - t0) / (n_str * per) * 1e3
-    if errs:
-        raise RuntimeError("two-stream e2e leg failed: " + "; ".join(errs))
     return {"workload": "create_model('cityscapes', 9, T_rpn=8, T_det=12) on 2 x rand(3,1024,2048), random init, fp32 backbone (stock MIOpen)",
             "value": round(2 / (ms * 1e-3), 2), "unit": "images/s", "ms_per_batch": round(ms, 3),
             "two_streams": {"value": round(2 / (ms2 * 1e-3), 2), "unit": "images/s", "ms_per_batch": round(ms2, 3),

@@ -6,3 +6,4 @@ from .rpn import RegionProposalNetwork            # noqa: F401
 from .roi_heads import RoIHeadsSNN                # noqa: F401
 from .generalized_rcnn import GeneralizedRCNN     # noqa: F401
 from .model import create_model                   # noqa: F401
+from .pipeline import StreamPipeline             # noqa: F401

@@ -304,3 +304,23 @@ def test_two_host_threads_two_streams_bitwise(pkg, gpu_device):
     torch.cuda.synchronize()
     assert not errs, errs
     assert not bad, bad
+
+
+def test_stream_pipeline_keeps_order_and_values(pkg, gpu_device):
+    """StreamPipeline: batches in flight on two host threads / HIP streams come back in order with the single-stream values;
+    an exception inside a slot reaches the caller"""
+    torch.manual_seed(4)
+    rpn = pkg.RPNHeadSNN(64, 3, 8).to(gpu_device)
+    batches = [[torch.randn(1, 64, 20 + i, 30, device=gpu_device)] for i in range(7)]
+    with torch.no_grad():
+        ref = [rpn(b) for b in batches]
+    got = pkg.StreamPipeline(rpn, slots=2).map(batches)
+    assert len(got) == len(ref)
+    for (rl, rb), (gl, gb) in zip(ref, got):
+        assert torch.equal(rl[0], gl[0]) and torch.equal(rb[0], gb[0])
+    assert pkg.StreamPipeline(rpn, slots=3).map([]) == []
+
+    def boom(b):
+        raise RuntimeError("slot failure")
+    with pytest.raises(RuntimeError, match="slot failure"):
+        pkg.StreamPipeline(boom, slots=2).map(batches)

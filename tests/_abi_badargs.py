@@ -54,6 +54,10 @@ bad(lib.snn_pack_conv3x3_weight_bf16x3(None, 4, 4, FAKE, None), "pack_conv3x3_bf
 bad(lib.snn_pack_linear_weight_bf16x3(FAKE, 4, -1, FAKE, None), "pack_linear_bf16x3")
 bad(lib.snn_pack_linear_weight_mx(FAKE, 4, 0, FAKE, None), "pack_linear_mx")
 bad(lib.snn_pack_conv3x3_weight_mx(FAKE, 0, 128, FAKE, None), "pack_conv3x3_mx")
+bad(lib.snn_affine_act_nchw(None, FAKE, FAKE, None, 1, 4, 16, 1, FAKE, None), "affine_act x=null")
+bad(lib.snn_affine_act_nchw(FAKE, FAKE, None, None, 1, 4, 16, 1, FAKE, None), "affine_act bias=null")
+bad(lib.snn_affine_act_nchw(FAKE, FAKE, FAKE, None, 1, 0, 16, 0, FAKE, None), "affine_act C=0")
+bad(lib.snn_affine_act_nchw(FAKE, FAKE, FAKE, FAKE, 1 << 20, 1 << 10, 4, 1, FAKE, None), "affine_act too many planes")
 bad(lib.snn_encode_nchw(None, 1, 1, 1, 1, 8, C.byref(P), None, 0, None), "encode_nchw")
 bad(lib.snn_encode_nchw(FAKE, 1, 4, 2, 2, 33, C.byref(P), FAKE, 4, None), "encode_nchw T>32")
 bad(lib.snn_encode_rows(None, 4, 4, 8, C.byref(P), None, 0, None), "encode_rows")

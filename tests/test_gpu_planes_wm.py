@@ -48,12 +48,14 @@ def test_rpn_head_word_major_equals_row_major(gpu_device, monkeypatch, C, T, sha
         assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("R,D_ch,Hd,K,T", [(300, 16, 128, 9, 12), (37, 8, 96, 5, 8), (1, 4, 64, 3, 24), (513, 32, 256, 11, 4)])
+@pytest.mark.parametrize("R,D_ch,Hd,K,T", [(300, 32, 128, 9, 12), (37, 64, 96, 5, 8), (1, 32, 64, 3, 24), (513, 32, 256, 11, 4),
+                                          (2000, 32, 160, 9, 12), (45, 96, 40, 2, 16),
+                                          (300, 16, 128, 9, 12)])      # D = 784, not a multiple of 32: row-major planes either way
 @pytest.mark.parametrize("tile", [("2", "4"), ("2", "3"), ("1", "4")])
 def test_det_head_word_major_equals_row_major(gpu_device, monkeypatch, R, D_ch, Hd, K, T, tile):
     import snn_automotive_object_detection_amd as S
     torch.manual_seed(R + T)
-    m = S.FastRCNNPredictorSNNFull(D_ch * 49 if (D_ch * 49) % 32 == 0 else D_ch * 49, Hd, K, T).to(gpu_device)
+    m = S.FastRCNNPredictorSNNFull(D_ch * 49, Hd, K, T).to(gpu_device)
     x = torch.randn(R, D_ch, 7, 7, device=gpu_device) * 1.5
     monkeypatch.setenv("SNN_BF16X3_WN", tile[0])
     monkeypatch.setenv("SNN_BF16X3_MT", tile[1])

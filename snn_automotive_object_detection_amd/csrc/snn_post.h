@@ -448,7 +448,16 @@ __global__ __launch_bounds__(256) void k_topk_gather(const RpnPostArgs a, TopkSt
     for (int e0 = lo; e0 < hi; e0 += 256) {
         const int e = e0 + tid;
         const uint32_t key = e < hi ? f2key(src[e]) : 0u;
-        if (e < hi && key > prefix) out[atomicAdd(&state[list].cnt_gt, 1u)] = ((unsigned long long)key << 32) | (uint32_t)(~(uint32_t)e);
+        {                                                        // keys above the k-th key: one slot counter bump per wave
+            const bool gt = e < hi && key > prefix;
+            const unsigned long long gm = __ballot(gt);
+            if (gm) {
+                uint32_t base = 0;
+                if (lane == __ffsll(gm) - 1) base = atomicAdd(&state[list].cnt_gt, (uint32_t)__popcll(gm));
+                base = (uint32_t)__shfl((int)base, __ffsll(gm) - 1);
+                if (gt) out[base + (uint32_t)__popcll(gm & ((1ull << lane) - 1ull))] = ((unsigned long long)key << 32) | (uint32_t)(~(uint32_t)e);
+            }
+        }
         if (taken < need) {                                      // block-uniform
             const bool tie = e < hi && key == prefix;
             const unsigned long long bal = __ballot(tie);
@@ -494,8 +503,9 @@ __global__ __launch_bounds__(1024) void k_topk_sort(const RpnPostArgs a, const u
 }
 
 __global__ __launch_bounds__(256) void k_rpn_decode(const RpnPostArgs a) {
-    const int g = blockIdx.x * 256 + threadIdx.x;
-    if (g >= a.N * a.Ktot) return;
+    const int g_raw = blockIdx.x * 256 + threadIdx.x;
+    const bool in = g_raw < a.N * a.Ktot;
+    const int g = in ? g_raw : a.N * a.Ktot - 1;                // lanes past the end recompute the last candidate, store nothing
     const int img = g / a.Ktot, c = g % a.Ktot;
     int l = 0;
     while (l + 1 < a.n_levels && c >= a.lv[l + 1].koff) ++l;
@@ -518,14 +528,33 @@ __global__ __launch_bounds__(256) void k_rpn_decode(const RpnPostArgs a) {
     const float W_ = a.img_w[img], H_ = a.img_h[img];
     const float bx1 = fminf(fmaxf(x1, 0.0f), W_), by1 = fminf(fmaxf(y1, 0.0f), H_);
     const float bx2 = fminf(fmaxf(x2, 0.0f), W_), by2 = fminf(fmaxf(y2, 0.0f), H_);
-    const bool valid = __fsub_rn(bx2, bx1) >= a.min_size && __fsub_rn(by2, by1) >= a.min_size && prob >= a.score_thresh;
-    reinterpret_cast<float4*>(a.pre)[g] = make_float4(x1, y1, x2, y2);
-    reinterpret_cast<float4*>(a.boxes)[g] = make_float4(bx1, by1, bx2, by2);
-    a.prob[g] = prob;
-    a.skey[g] = valid ? prob : -1.0f;
-    if (valid) {                                  // what batched_nms's coordinate trick needs: boxes of the call, largest coordinate
-        atomicAdd(&a.list_cnt[img * a.n_levels + l], 1);
-        atomicMax(&a.list_max[img * a.n_levels + l], __float_as_uint(fmaxf(bx2, by2)));
+    const bool valid = in && __fsub_rn(bx2, bx1) >= a.min_size && __fsub_rn(by2, by1) >= a.min_size && prob >= a.score_thresh;
+    if (in) {
+        reinterpret_cast<float4*>(a.pre)[g] = make_float4(x1, y1, x2, y2);
+        reinterpret_cast<float4*>(a.boxes)[g] = make_float4(bx1, by1, bx2, by2);
+        a.prob[g] = prob;
+        a.skey[g] = valid ? prob : -1.0f;
+    }
+    // what batched_nms's coordinate trick needs per list (image, level): boxes of the call, largest coordinate.  Consecutive
+    // candidates share their list, so a wave combines its lanes first and sends one atomic pair per list it holds (one lane per
+    // candidate on ten addresses serialised ~2 x 970 atomics per address: 0.13 of the kernel's 0.15 ms)
+    const int list = valid ? img * a.n_levels + l : -1;
+    const uint32_t mx = valid ? __float_as_uint(fmaxf(bx2, by2)) : 0u;       // coordinates are >= 0: float order = bit order
+    const int lane = threadIdx.x & 63;
+    unsigned long long rem = __ballot(valid);
+    while (rem) {
+        const int leader = __ffsll(rem) - 1;
+        const int sl = __shfl(list, leader);
+        const bool mine = valid && list == sl;
+        const unsigned long long mm = __ballot(mine);
+        uint32_t v = mine ? mx : 0u;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, off));
+        if (lane == leader) {
+            atomicAdd(&a.list_cnt[sl], (int)__popcll(mm));
+            atomicMax(&a.list_max[sl], v);
+        }
+        rem &= ~mm;
     }
 }
 

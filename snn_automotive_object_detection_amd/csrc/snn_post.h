@@ -122,12 +122,12 @@ __global__ __launch_bounds__(256) void k_nms_scan(const unsigned long long* __re
         }
         __syncthreads();
         const unsigned long long kept = kept_cur;
-        if (t < words && t > c) {             // later words: OR the rows of the kept boxes
-            unsigned long long acc = removed, k = kept;
-            while (k) {
-                const int b = __ffsll((long long)k) - 1;
-                k &= k - 1;
-                acc |= cur[b * words + t];
+        if (t < words && t > c) {             // later words: OR the rows of the kept boxes (all 64 rows read, the others masked:
+            unsigned long long acc = removed; // independent pipelined LDS loads instead of one dependent load per kept box)
+#pragma unroll 16
+            for (int b = 0; b < 64; ++b) {
+                const unsigned long long v = cur[b * words + t];
+                acc |= ((kept >> b) & 1ull) ? v : 0ull;
             }
             removed = acc;
         }
@@ -278,12 +278,12 @@ __global__ __launch_bounds__(256) void k_nms_scan_lists(const NmsLists nl, const
         }
         __syncthreads();
         const unsigned long long kept = kept_cur;
-        if (t < n_chunks && t > cc) {         // later words: OR the rows of the kept boxes
-            unsigned long long acc = removed, k = kept;
-            while (k) {
-                const int b = __ffsll((long long)k) - 1;
-                k &= k - 1;
-                acc |= cur[b * words + t];
+        if (t < n_chunks && t > cc) {         // later words: OR the rows of the kept boxes.  All 64 rows are read (independent,
+            unsigned long long acc = removed; // pipelined LDS loads; rows of boxes that were not kept are masked out) instead of
+#pragma unroll 16                             // one dependent load per kept box
+            for (int b = 0; b < 64; ++b) {
+                const unsigned long long v = cur[b * words + t];
+                acc |= ((kept >> b) & 1ull) ? v : 0ull;
             }
             removed = acc;
         }

@@ -230,3 +230,46 @@ def det_post_inputs(spec):
     if spec.get("spread"):                                              # keep boxes apart so that > 100 survive NMS
         reg *= np.float32(0.2)
     return _t(logits.astype(np.float32)), _t(reg.astype(np.float32)), props
+
+
+# ---------------------------------------------------------------------------------------------
+# box-pooling fixtures.  torchvision is absent from /root/reference and not installed here, so
+# these expected values come from the restatement (oracle/roi_align_oracle.py, pinned by closed-form known answers in
+# tests/test_roi_align_oracle.py), NOT from a run of the reference - the header of that module says "parity unpinned".
+# The pooled features then go through the (reference-pinned) detector-head oracle: expected cls / bbox of the fused
+# RoIAlign + encoder + head path.
+# ---------------------------------------------------------------------------------------------
+ROI_SPECS = {
+    # 4 FPN levels of a 192x320 image at strides 4..32 (+ the unused 'pool' level), 2 images, boxes over all four levels,
+    # three corner cases per image (partly outside, beyond the far edge, degenerate)
+    "roialign_c8": dict(C=8, sizes=[(48, 80), (24, 40), (12, 20), (6, 10)], pool=(3, 5), image_shapes=[(192, 320), (180, 300)],
+                        rois=[60, 45], seed=501, Hd=64, K=5, T=12),
+}
+
+
+def roi_inputs(spec):
+    """-> (features {name: [N,C,H,W]}, boxes per image [k,4], image_shapes)"""
+    C, s = spec["C"], spec["seed"]
+    n_img = len(spec["image_shapes"])
+    feats = {str(i): _t(PR.normalish((n_img, C, h, w), s * 10 + i, std=1.0)) for i, (h, w) in enumerate(spec["sizes"])}
+    feats["pool"] = _t(PR.normalish((n_img, C) + tuple(spec["pool"]), s * 10 + 9, std=1.0))
+    boxes = []
+    for n, (k, (ih, iw)) in enumerate(zip(spec["rois"], spec["image_shapes"])):
+        u = PR.uniform((k, 4), s * 10 + 20 + n, 0.0, 1.0).astype(np.float64)
+        xy = u[:, :2] * np.array([iw * 0.95, ih * 0.95])
+        wh = np.exp(u[:, 2:] * 5.0 + 1.0)                         # 2.7 .. 400 px: all four levels
+        b = np.concatenate([xy, xy + wh], 1).astype(np.float32)
+        b[0] = [-20.0, -10.0, 30.0, 25.0]                         # partly outside
+        b[1] = [iw - 5.0, ih - 5.0, iw + 80.0, ih + 110.0]        # beyond the far edge
+        b[2] = [100.0, 100.0, 100.2, 100.1]                       # degenerate: clamps to one feature pixel
+        boxes.append(_t(b))
+    return feats, boxes, [tuple(sh) for sh in spec["image_shapes"]]
+
+
+def roi_head_weights(spec):
+    """weights of the small detector head behind the pooled features (same distribution as det_inputs)"""
+    C, Hd, K, s = spec["C"], spec["Hd"], spec["K"], spec["seed"]
+    D = C * 49
+    b6, b7 = 1.0 / D ** 0.5, 1.0 / Hd ** 0.5
+    return (_t(PR.uniform((Hd, D), s * 10 + 31, -b6, b6)), _t(PR.uniform((Hd, Hd), s * 10 + 32, -b7, b7)),
+            _t(PR.uniform((K, Hd), s * 10 + 33, -b7, b7)), _t(PR.uniform((4 * K, Hd), s * 10 + 34, -b7, b7)))

@@ -265,6 +265,18 @@ def gen_det(ref_frcnn, name, spec, out):
           float(o_tr["spk6"].mean()), float(o_tr["spk7"].mean())))
 
 
+def gen_roi(name, spec, out):
+    """box pooling: torchvision is absent, so this fixture is written from the RESTATEMENT (oracle/roi_align_oracle.py, pinned by
+    closed-form known answers), then the detector-head oracle on the pooled features"""
+    from oracle import roi_align_oracle as RA
+    feats, boxes, shapes = FX.roi_inputs(spec)
+    pooled = RA.multiscale_roi_align(feats, boxes, shapes)
+    w6, w7, wc, wb = FX.roi_head_weights(spec)
+    cls, bbox = OR.det_head_forward(pooled, w6, w7, wc, wb, spec["T"])
+    np.savez_compressed(os.path.join(out, name + ".npz"), pooled=np_(pooled), cls=np_(cls), bbox=np_(bbox))
+    print("wrote %-20s pooled %s |mean| %.3f" % (name, tuple(pooled.shape), float(pooled.abs().mean())))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=FX.GOLDEN_DIR)
@@ -281,6 +293,8 @@ def main():
         gen_rpn_post(ref_rpn, name, spec, args.out)
     for name, spec in FX.DET_POST_SPECS.items():
         gen_det_post(ref_roi, name, spec, args.out)
+    for name, spec in FX.ROI_SPECS.items():
+        gen_roi(name, spec, args.out)
 
 
 if __name__ == "__main__":

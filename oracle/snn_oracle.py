@@ -39,10 +39,12 @@ def _cells(li_order: str):
 
 def rpn_head_forward(x: Sequence[torch.Tensor], w_shared: torch.Tensor, w_cls: torch.Tensor,
                      w_bbox: torch.Tensor, num_steps: int, li_order: str = "jump_first",
-                     trace: bool = False, spike_rates: bool = False, counts_out: Optional[list] = None):
+                     trace: bool = False, spike_rates: bool = False, counts_out: Optional[list] = None, cur_hook=None):
     """rpn.py:84-121.  x: list of [N,C,H,W]; w_shared [C,C,3,3]; w_cls [A,C,1,1]; w_bbox [4A,C,1,1].
     Returns (logits, bbox_reg[, rates][, traces]).  ``counts_out`` (a list) receives, per level, the exact number of
-    shared-LIF spikes of every image (int64 [N]): what the fp32 rate of rpn.py:172 is the rounded mean of."""
+    shared-LIF spikes of every image (int64 [N]): what the fp32 rate of rpn.py:172 is the rounded mean of.
+    ``cur_hook(name, step, cur) -> cur`` (tests only) may replace the input current of a LIF layer: how the dead-time-step
+    statement of the HIP kernels (csrc/snn_kernels.hip: lif_windows) is checked against this restatement."""
     logits, bbox_reg, traces, all_rates = [], [], [], []
     C = w_shared.shape[0]
     A = w_cls.shape[0]
@@ -56,6 +58,8 @@ def rpn_head_forward(x: Sequence[torch.Tensor], w_shared: torch.Tensor, w_cls: t
         for step in range(num_steps):                                 # rpn.py:98
             z, v = lif_current_encoder(input_current=feature, voltage=v, p=p_enc, dt=DT)   # :101
             cur = F.conv2d(z, w_shared, None, stride=1, padding=1)    # rpn.py:105
+            if cur_hook is not None:
+                cur = cur_hook("shared", step, cur)
             spk_shared, state_shared_lif = shared_lif(cur, state_shared_lif)               # :106
             cur_c = F.conv2d(spk_shared, w_cls)                       # rpn.py:110
             mem_obj, state_obj = lif_obj(cur_c, state_obj)            # rpn.py:111
@@ -100,7 +104,7 @@ def rpn_head_forward(x: Sequence[torch.Tensor], w_shared: torch.Tensor, w_cls: t
 def det_head_forward(x: torch.Tensor, w6: torch.Tensor, w7: torch.Tensor, w_cls: torch.Tensor,
                      w_bbox: torch.Tensor, num_steps: int, li_order: str = "jump_first",
                      trace: bool = False, spike_rates: bool = False, only_one_bbox: bool = False,
-                     counts_out: Optional[list] = None):
+                     counts_out: Optional[list] = None, cur_hook=None):
     """faster_rcnn.py:470-516 (spike_rates=True: 520-618, which returns ONLY the rate list).
     x [R,C,7,7] (or [R,D]); w6 [Hd,D]; w7 [Hd,Hd]; w_cls [K,Hd]; w_bbox [4K,Hd].
     ``counts_out`` (a list) receives the exact lif6 / lif7 spike totals per RoI (two int64 [R] tensors)."""
@@ -120,8 +124,12 @@ def det_head_forward(x: torch.Tensor, w6: torch.Tensor, w7: torch.Tensor, w_cls:
     for step in range(num_steps):                                     # :492
         z, v = lif_current_encoder(input_current=x, voltage=v, p=p_enc, dt=DT)     # :494
         cur6 = F.linear(z, w6)                                        # :498
+        if cur_hook is not None:
+            cur6 = cur_hook("fc6", step, cur6)
         spk_lif6, state_lif6 = lif6(cur6, state_lif6)                 # :499
         cur7 = F.linear(spk_lif6, w7)                                 # :500
+        if cur_hook is not None:
+            cur7 = cur_hook("fc7", step, cur7)
         spk_lif7, state_lif7 = lif7(cur7, state_lif7)                 # :501
         mem_cls, state_cls = lif_cls(F.linear(spk_lif7, w_cls), state_cls)         # :505-506
         mem_bbox, state_bbox = lif_bbox(F.linear(spk_lif7, w_bbox), state_bbox)    # :509-510

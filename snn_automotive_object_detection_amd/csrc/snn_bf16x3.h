@@ -91,8 +91,11 @@ struct Gemm3Args {
     int M, Kc, Np, ldo, n_blocks;
     int Cw, P_total, n_levels;          // conv only
     // conv + LIF: spikes leave as bit-planes.  G3_CONV_LIF_REG: rows are positions, the T loop runs inside;
-    // G3_CONV_LIF_TILE: a 256-row tile = all T time steps of pb = 256/T positions (row = t*pb + position)
-    int T, pb;
+    // G3_CONV_LIF_TILE: a 256-row tile = the Tc time steps t0 .. t0+Tc-1 of pb = 256/Tc positions (row = (t - t0)*pb + position).
+    // The LIF epilogue always runs T steps; the input current of a step outside the window reads as +0 (dead time steps:
+    // lif_feed_forward_step integrates the current of step t AFTER that step's membrane update, so the current of the last
+    // step never reaches a spike - and a layer fed by a LIF layer sees no spike at step 0; launchers: lif_windows)
+    int T, pb, Tc, t0;
     uint32_t* spk;
     unsigned long long spk_stride;
     // spike-rate side outputs of the T-in-tile epilogues (nullable; zeroed by the caller): conv: spikes per (level, image) slot
@@ -247,14 +250,14 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
     const bool a_role = wave * 64 < BM;
     const int xrow = tid & (G3_BM(WN, 4) - 1);
     const int xt = TILE ? xrow / args.pb : 0;       // TILE: time step of the row
-    const int xm = TILE ? (xt < args.T ? m0 + xrow % args.pb : M) : m0 + xrow;
+    const int xm = TILE ? (xt < args.Tc ? m0 + xrow % args.pb : M) : m0 + xrow;
     const bool a_wm = args.wm != 0;                   // word-major planes: a row's consecutive words are a_step words apart
     const int row_words = a_wm ? 1 : args.Cw;         // conv: words from one (padded) position to the next
     uint32_t a_off = 0;                             // bytes: fc row / conv centre tap, channel word 0
     uint32_t a_pitch = 0;                           // conv: bytes per (padded) image row of the lane's pyramid level
     if (CONV) {
         if (xm < M) {
-            const int t = FUSE ? 0 : (TILE ? xt : xm / args.P_total), p = (FUSE || TILE) ? xm : xm % args.P_total;
+            const int t = FUSE ? 0 : (TILE ? xt + args.t0 : xm / args.P_total), p = (FUSE || TILE) ? xm : xm % args.P_total;
             int l = 0;
             while (l + 1 < args.n_levels && p >= args.lv[l + 1].pos_base) ++l;
             const int H = args.lv[l].H, W = args.lv[l].W;
@@ -269,7 +272,7 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
             a_pitch = (uint32_t)((args.lv[0].W + 2) * row_words * 4);
         }
     } else if (TILE) {                              // fc rows of the spike planes [T][M][Kc] / [T][Kc][M]; unused tile rows read row 0
-        a_off = xm >= M ? 0u : a_wm ? (uint32_t)(((size_t)xt * Kc * M + xm) * 4) : (uint32_t)(((size_t)xt * M + xm) * Kc * 4);
+        a_off = xm >= M ? 0u : a_wm ? (uint32_t)(((size_t)(xt + args.t0) * Kc * M + xm) * 4) : (uint32_t)(((size_t)(xt + args.t0) * M + xm) * Kc * 4);
     } else {
         a_off = (uint32_t)((size_t)min(xm, M - 1) * (a_wm ? 1 : Kc) * 4);
     }
@@ -280,7 +283,7 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
     // registers and branches on them through the exec mask.
     // (s_nop 4: an SGPR written by SALU / v_readfirstlane needs 5 wait states before a VMEM instruction reads it as its base
     // address or M0, and hipcc's hazard recogniser does not look into inline asm.)
-    const int n_steps = FUSE ? args.T : 1;
+    const int n_steps = FUSE ? args.Tc : 1;                // (register-fused variant: currents of steps 0 .. Tc-1)
     const int row_chunks = __builtin_amdgcn_readfirstlane(3 * args.Cw);
     // scalar steps of the stream, in words: to the next channel / K word of the same rows; (conv) at the end of a tap's Cw words
     // on to the next tap of the row; at the end of a tap row back to its first tap; from the centre tap to tap (-1, -1)'s column
@@ -418,6 +421,56 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
     }
     const int n_total = n_steps * Kc;
 
+    // ---- LIF step of the register-fused variant on the accumulators (then cleared): called after the K loop of every
+    // current step, and with zero currents for the steps after the last one (dead time steps, Gemm3Args.Tc)
+    auto lif_reg_step = [&](const int t) {
+        // ---- LIF epilogue in registers.  A ballot over accumulator register (mt, nt, reg) holds, for each
+        // of the 4 row groups rg, 16 channel bits of position mt*16 + rg*4 + reg; N-tiles (0,1) and (2,3)
+        // pair up into the two 32-channel words of that position, which lane = position finally stores ----
+        uint32_t my0 = 0, my1 = 0;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int np = 0; np < 2; ++np) {                   // N-tile pair -> word np of the position
+                f32x4 vd[2], d[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int nt = 2 * np + q;
+                    if (mt < 3) {
+                        lif_decay4(acc[mt][nt], v[mt][nt], ci[mt][nt], args.p, vd[q], d[q]);
+                    } else {
+                        f32x4 i3 = ci_lds[nt * 512];
+                        lif_decay4(acc[mt][nt], v[mt][nt], i3, args.p, vd[q], d[q]);
+                        ci_lds[nt * 512] = i3;
+                    }
+                    acc[mt][nt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {                  // two ballots live at a time
+                    const bool z0 = d[0][r] > 0.0f, z1 = d[1][r] > 0.0f;
+                    const unsigned long long b0 = __ballot(z0), b1 = __ballot(z1);
+                    v[mt][2 * np][r] = z0 ? args.p.v_reset : vd[0][r];
+                    v[mt][2 * np + 1][r] = z1 ? args.p.v_reset : vd[1][r];
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) {
+                        const uint32_t w = (uint32_t)((b0 >> (16 * rg)) & 0xffffull) | ((uint32_t)((b1 >> (16 * rg)) & 0xffffull) << 16);
+                        // lane (mt*16 + rg*4 + r) keeps the two words of its position (rows >= M are never stored)
+                        if (np == 0) asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(my0) : "s"(w), "n"(mt * 16 + rg * 4 + r));
+                        else         asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(my1) : "s"(w), "n"(mt * 16 + rg * 4 + r));
+                    }
+                }
+            }
+        {
+            const int row = m0 + wm * 64 + lane;                  // lane = position within the wave's 64 rows
+            const int word0 = (nb * BN + wn * 64) >> 5;
+            uint32_t* dst = args.spk + (size_t)t * args.spk_stride + (size_t)row * (Np >> 5) + word0;
+            if (row < M) {
+                if (word0 * 32 < Np) dst[0] = my0;
+                if ((word0 + 1) * 32 < Np) dst[1] = my1;
+            }
+        }
+    };
+
     // Software pipeline over the chunk sequence c = (t, kc).  During chunk c:
     //   the spike word of chunk c+3 is fetched from global memory (register),
     //   the spike word of chunk c+2 (fetched during chunk c-1) and, by LDS-DMA, the weight planes of chunk c+2 go
@@ -513,56 +566,15 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
             const bool step_done = ++kc == Kc;
             if (step_done) kc = 0;
             if (FUSE && step_done) {
-                // ---- LIF epilogue in registers.  A ballot over accumulator register (mt, nt, reg) holds, for each
-                // of the 4 row groups rg, 16 channel bits of position mt*16 + rg*4 + reg; N-tiles (0,1) and (2,3)
-                // pair up into the two 32-channel words of that position, which lane = position finally stores ----
-                uint32_t my0 = 0, my1 = 0;
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                    for (int np = 0; np < 2; ++np) {                   // N-tile pair -> word np of the position
-                        f32x4 vd[2], d[2];
-#pragma unroll
-                        for (int q = 0; q < 2; ++q) {
-                            const int nt = 2 * np + q;
-                            if (mt < 3) {
-                                lif_decay4(acc[mt][nt], v[mt][nt], ci[mt][nt], args.p, vd[q], d[q]);
-                            } else {
-                                f32x4 i3 = ci_lds[nt * 512];
-                                lif_decay4(acc[mt][nt], v[mt][nt], i3, args.p, vd[q], d[q]);
-                                ci_lds[nt * 512] = i3;
-                            }
-                            acc[mt][nt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-                        }
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {                  // two ballots live at a time
-                            const bool z0 = d[0][r] > 0.0f, z1 = d[1][r] > 0.0f;
-                            const unsigned long long b0 = __ballot(z0), b1 = __ballot(z1);
-                            v[mt][2 * np][r] = z0 ? args.p.v_reset : vd[0][r];
-                            v[mt][2 * np + 1][r] = z1 ? args.p.v_reset : vd[1][r];
-#pragma unroll
-                            for (int rg = 0; rg < 4; ++rg) {
-                                const uint32_t w = (uint32_t)((b0 >> (16 * rg)) & 0xffffull) | ((uint32_t)((b1 >> (16 * rg)) & 0xffffull) << 16);
-                                // lane (mt*16 + rg*4 + r) keeps the two words of its position (rows >= M are never stored)
-                                if (np == 0) asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(my0) : "s"(w), "n"(mt * 16 + rg * 4 + r));
-                                else         asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(my1) : "s"(w), "n"(mt * 16 + rg * 4 + r));
-                            }
-                        }
-                    }
-                {
-                    const int row = m0 + wm * 64 + lane;                  // lane = position within the wave's 64 rows
-                    const int word0 = (nb * BN + wn * 64) >> 5;
-                    uint32_t* dst = args.spk + (size_t)t * args.spk_stride + (size_t)row * (Np >> 5) + word0;
-                    if (row < M) {
-                        if (word0 * 32 < Np) dst[0] = my0;
-                        if ((word0 + 1) * 32 < Np) dst[1] = my1;
-                    }
-                }
+                lif_reg_step(t);
                 ++t;
             }
         }
     }
-    if (FUSE) return;
+    if (FUSE) {
+        for (; t < args.T; ++t) lif_reg_step(t);
+        return;
+    }
 #ifdef SNN_EXP_CLOCK
     if (TILE && tid == 0) {
         unsigned long long c1, r1;
@@ -582,7 +594,7 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
         float* const tile = reinterpret_cast<float*>(smem);
         uint32_t* const pos_cnt = reinterpret_cast<uint32_t*>(smem + G3_TILE_BYTES(WN));    // behind the tile image
         const bool counting = args.cnt_img != nullptr || args.cnt_row != nullptr;
-        const int pb = args.pb, T = args.T;
+        const int pb = args.pb, T = args.T, t0 = args.t0, t1 = args.t0 + args.Tc;      // currents of steps t0 .. t1-1 are in the tile
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // staged-ahead copies of chunks past the end have landed
 #pragma unroll 1
         for (int h = 0; h < 2; ++h) {
@@ -614,7 +626,9 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
                     const float* src = tile + pi * PITCH + lane;
                     uint32_t cnt = 0;                      // wave-uniform: spikes of this position in this pass
                     for (int t = 0; t < T; ++t) {
-                        const bool z = lif_step(src[(size_t)t * pb * PITCH], vv, ii, args.p);
+                        float cur = 0.0f;                  // steps outside the tile's window: no input current
+                        if (t >= t0 && t < t1) cur = src[(size_t)(t - t0) * pb * PITCH];
+                        const bool z = lif_step(cur, vv, ii, args.p);
                         const unsigned long long b = __ballot(z);
                         my0 = lane == t ? (uint32_t)b : my0;
                         my1 = lane == t ? (uint32_t)(b >> 32) : my1;
@@ -653,7 +667,9 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
                     const float* src = tile + (live ? pi : 2 * pp) * PITCH + col;
                     uint32_t cnt0 = 0, cnt1 = 0;           // wave-uniform: spikes of the even / odd position in this pass
                     for (int t = 0; t < T; ++t) {
-                        const bool z = lif_step(src[(size_t)t * pb * PITCH], vv, ii, args.p);
+                        float cur = 0.0f;
+                        if (t >= t0 && t < t1) cur = src[(size_t)(t - t0) * pb * PITCH];
+                        const bool z = lif_step(cur, vv, ii, args.p);
                         const unsigned long long b = __ballot(z);
                         my0 = lane == t ? (uint32_t)b : my0;
                         my1 = lane == t ? (uint32_t)(b >> 32) : my1;

@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void k_encode_rows_wm(const float* __restrict_
 // encoder (roi_heads.py:1217 -> faster_rcnn.py:473,494): the [R,C,7,7] fp32 RoI features (100 MB at R=2000) are
 // never materialised; each thread pools one (RoI, channel, bin) element - 4 samples x 4 bilinear taps - runs its
 // T encoder steps in registers and the wave ballots straight into the bit-planes [T][R][Dw] (flatten order
-// d = c*49 + ph*7 + pw).  Arithmetic follows torchvision's roi_align / the stock-torch stand-in op for op
+// d = c*49 + ph*7 + pw).  Arithmetic follows torchvision 0.13.1's CPU roi_align kernel (restated in oracle/roi_align_oracle.py) op for op
 // (explicit roundings, no fma): sample = (hy*hx)*v1 + (hy*lx)*v2 + (ly*hx)*v3 + (ly*lx)*v4, bin = mean of 4.
 // ------------------------------------------------------------------------------------------------
 struct RoiLevel { const float* feat; int H, W; float scale; };
@@ -265,17 +265,19 @@ __device__ __forceinline__ float roi_pool_element(const RoiArgs& a, int r, int d
         const float rh = fmaxf(__fsub_rn(__fmul_rn(roi[3], L.scale), y1), 1.0f);
         const float bh = __fdiv_rn(rh, 7.0f), bw = __fdiv_rn(rw, 7.0f);
         const float* f = L.feat + ((size_t)a.roi_batch[r] * a.C + c) * (size_t)(L.H * L.W);
-        // sample coordinate: start + (p + (i + .5)/2) * bin   (the stock op's grid form)
+        // sample coordinate, in torchvision's own operation order (roi_align_common.h, pre_calc_for_bilinear_interpolate):
+        //   yy = roi_start_h + ph * bin_size_h + (iy + .5f) * bin_size_h / roi_bin_grid_h     (left to right, fp32, no fma)
+        const float by = __fadd_rn(y1, __fmul_rn((float)ph, bh)), bx = __fadd_rn(x1, __fmul_rn((float)pw, bw));
         float s[2][2];
 #pragma unroll
         for (int iy = 0; iy < 2; ++iy)
 #pragma unroll
             for (int ix = 0; ix < 2; ++ix) {
-                const float gy = __fadd_rn((float)ph, __fdiv_rn((float)iy + 0.5f, 2.0f));
-                const float gx = __fadd_rn((float)pw, __fdiv_rn((float)ix + 0.5f, 2.0f));
-                s[iy][ix] = roi_bilinear(f, L.H, L.W, __fadd_rn(y1, __fmul_rn(gy, bh)), __fadd_rn(x1, __fmul_rn(gx, bw)));
+                const float yy = __fadd_rn(by, __fdiv_rn(__fmul_rn((float)iy + 0.5f, bh), 2.0f));
+                const float xx = __fadd_rn(bx, __fdiv_rn(__fmul_rn((float)ix + 0.5f, bw), 2.0f));
+                s[iy][ix] = roi_bilinear(f, L.H, L.W, yy, xx);
             }
-        // mean over the 2x2 samples (torch .mean(dim=(3,5)): sum in (iy, ix) order, then / 4)
+        // mean over the 2x2 samples (roi_align_kernel.cpp: output_val += sample in (iy, ix) order, then /= count)
         val = __fdiv_rn(__fadd_rn(__fadd_rn(__fadd_rn(s[0][0], s[0][1]), s[1][0]), s[1][1]), 4.0f);
         if (a.pooled) a.pooled[(size_t)r * D + d] = val;
     }

@@ -33,7 +33,9 @@ struct ConvArgs {
     unsigned long long* counts;
     float* dbg_cur;                              // nullable: input currents [T][P][Nw*32] (parity tests)
     unsigned long long enc_stride, spk_stride;   // words per time plane
-    int Cw, Nw, T, n_levels, max_n, pad;
+    int Cw, Nw, T, n_levels, max_n;
+    int Tc;                                      // input currents are formed for steps 0 .. Tc-1; later steps integrate +0 (dead time
+                                                 // steps: the current of step t first moves the membrane at t+1, Gemm3Args.Tc)
     NeuronP p;
     ConvLevelDev lv[SNN_MAX_LEVELS];
 };
@@ -162,15 +164,19 @@ __global__ __launch_bounds__(512) void k_conv3x3_lif(const ConvArgs args) {
     unsigned long long n_spikes = 0;
 
     for (int t = 0; t < args.T; ++t) {
-        __syncthreads();                                   // everyone done reading the previous image
-        expand_halo();
-        if (t + 1 < args.T) fetch_halo(t + 1);             // latency hidden behind this step's MFMAs
-        __syncthreads();                                   // image of step t complete
+        const bool live_t = t < args.Tc;                   // block-uniform: a step whose input current is formed
+        if (live_t) {
+            __syncthreads();                               // everyone done reading the previous image
+            expand_halo();
+            if (t + 1 < args.Tc) fetch_halo(t + 1);        // latency hidden behind this step's MFMAs
+            __syncthreads();                               // image of step t complete
+        }
         if (active) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mt][r] = 0.0f;
+          if (live_t) {
             tapA = 0; ccA = 0;
             load_a_lo(alo);
             // A operands run half a chunk ahead of the MFMAs, B operands one chunk ahead
@@ -195,6 +201,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_lif(const ConvArgs args) {
 #pragma unroll
                 for (int qq = 0; qq < 4; ++qq) b0[qq] = b1[qq];
             }
+          }
             if (DBG) {                         // test-hook instantiation: dump the step's input currents
                 float* d = args.dbg_cur + (size_t)t * (args.spk_stride * 32);
 #pragma unroll

@@ -5,7 +5,8 @@
 // ------------------------------------------------------------------------------------------------
 // K4: LIF scan over T of currents cur[T][R][ldc] -> spike planes [T][R][Nw]  (+ per-row counts)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_lif_scan(const float* __restrict__ cur, int T, int R, int N, int Nw,
+// cur holds the steps t0 .. t0+Tc-1 only (cur[t - t0][R][ldc]); the other steps integrate +0 (dead time steps, Gemm3Args.Tc)
+__global__ __launch_bounds__(256) void k_lif_scan(const float* __restrict__ cur, int T, int t0, int Tc, int R, int N, int Nw,
                                                   int ldc, NeuronP p, uint32_t* __restrict__ spk,
                                                   size_t spk_stride, uint32_t* __restrict__ row_counts) {
     const size_t Np = (size_t)Nw * 32;
@@ -21,7 +22,7 @@ __global__ __launch_bounds__(256) void k_lif_scan(const float* __restrict__ cur,
     const int lane = threadIdx.x & 63;
     uint32_t cnt = 0;
     for (int t = 0; t < T; ++t) {
-        const float x = live ? c[(size_t)t * tstride] : 0.0f;
+        const float x = (live && t >= t0 && t < t0 + Tc) ? c[(size_t)(t - t0) * tstride] : 0.0f;
         const bool z = lif_step(x, v, i, p) && live;
         const unsigned long long m = __ballot(z);
         if ((lane & 31) == 0 && in) {

@@ -127,6 +127,8 @@ struct Knobs {
     bool bf16x3_xcd;         // SNN_BF16X3_XCD=0      plain block order instead of the XCD-aware one (A/B)
     bool stage_wm;           // SNN_STAGE_PLANES=wm   A/B harness only: snn_conv3x3_lif_bf16x3 / snn_spike_gemm_lif_bf16x3 take their
                              //                       INPUT planes word-major ([T][word][row]; tools/ab_conv.py)
+    bool dead_keep;          // SNN_DEAD_STEPS=keep   form the input currents of ALL time steps (A/B + test switch: the default
+                             //                       skips the steps whose currents cannot reach an output, lif_windows)
     int planes;              // SNN_PLANES=rm|wm      internal spike planes of the bf16x3 heads: all row-major [T][row][word] / all
                              //                       word-major [T][word][row] (1 / 2; 0 = default: linear layers word-major, conv
                              //                       row-major; bit-identical results either way, A/B + test switch)
@@ -150,6 +152,7 @@ static Knobs load_knobs() {
     k.bf16x3_xcd = !((e = getenv("SNN_BF16X3_XCD")) && e[0] == '0');
     k.spk_rows = (e = getenv("SNN_SPK_SPLIT")) && e[0] == '0';
     k.stage_wm = (e = getenv("SNN_STAGE_PLANES")) && !strcmp(e, "wm");
+    k.dead_keep = (e = getenv("SNN_DEAD_STEPS")) && !strcmp(e, "keep");
     return k;
 }
 static Knobs& knobs() {
@@ -170,6 +173,37 @@ static int g3_slots() {                       // CUs: two co-resident work-group
         slots = cus;
     }
     return slots;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Dead time steps.  Norse's lif_feed_forward_step (rpn.py:106, faster_rcnn.py:499,501) updates the membrane from the OLD
+// synaptic current and only then adds the step's input:  v_dec = v + ca*((v_leak - v) + i);  z = v_dec > v_th;  i = i_dec + x_t.
+// So x_t first moves a spike at step t+1, and x_{T-1} moves nothing that leaves the layer: a LIF layer whose spikes
+// z_0 .. z_last are consumed needs the currents of steps 0 .. last-1 only.  And a layer FED by a LIF layer sees z_0 = 0 at
+// step 0 (v = v_leak, i = 0: v_dec = v_leak, no spike unless v_leak - v_th > 0), i.e. its current of step 0 is exactly +0.
+// The kernels form currents for a window of steps and integrate +0 elsewhere - bit-identical spikes, counts and outputs
+// (tests/test_gpu_dead_steps.py against SNN_DEAD_STEPS=keep, which forms all T).
+//   RPN (rpn.py:98-119): shared LIF spikes of all T steps feed the LI heads -> conv currents of steps 0 .. T-2.
+//   detector (faster_rcnn.py:492-516): lif7 spikes of all T steps feed the LI heads -> fc7 currents of steps 1 .. T-2
+//   (z6_0 = 0); those read lif6 spikes 1 .. T-2 -> fc6 currents of steps 0 .. T-3 (0 .. T-2 in spike-rate mode, which
+//   counts the lif6 spikes of every step, faster_rcnn.py:556).
+// ------------------------------------------------------------------------------------------------
+struct StepWindow { int t0, n; };                 // currents of steps t0 .. t0+n-1
+static StepWindow lif_window_all(int T) { return StepWindow{0, T}; }
+// the layer's spikes of every step are consumed (stage-level calls, the RPN conv, fc7 with z_in(0) != 0)
+static StepWindow lif_window_full_out(int T) { return knobs().dead_keep ? lif_window_all(T) : StepWindow{0, T > 1 ? T - 1 : 1}; }
+static bool lif_first_spike_is_zero(const snn_params* p) { return !((float)(p->v_leak - p->v_th_lif) > 0.0f); }
+struct DetWindows { StepWindow fc6, fc7; int enc_steps; };
+static DetWindows det_windows(const snn_params* p, int T, bool spike_rates) {
+    DetWindows w;
+    if (knobs().dead_keep) { w.fc6 = w.fc7 = lif_window_all(T); w.enc_steps = T; return w; }
+    w.fc7.t0 = (lif_first_spike_is_zero(p) && T >= 2) ? 1 : 0;
+    w.fc7.n = (T - 1) - w.fc7.t0 > 0 ? (T - 1) - w.fc7.t0 : 1;
+    const int last6 = spike_rates ? T - 1 : w.fc7.t0 + w.fc7.n - 1;          // last lif6 spike plane that is read
+    w.fc6.t0 = 0;
+    w.fc6.n = last6 > 0 ? last6 : 1;
+    w.enc_steps = w.fc6.n;
+    return w;
 }
 
 // M-tiles per wave (work-group rows = 64*MT): fewest rounds of work-groups x (tile work + per-chunk staging overhead)
@@ -449,7 +483,7 @@ int snn_spike_gemm_bf16x3(const uint32_t* a_rows, int M, int K, int N, const uin
 // row_counts (nullable, zeroed by the caller): spikes per row over all T steps and N columns, added by the LIF epilogue
 static int spike_gemm_lif_bf16x3_impl(const uint32_t* a_planes, int T, int R, int K, int N, const snn_params* p,
                                       const uint16_t* w_packed, uint32_t* spk, size_t spk_stride, uint32_t* row_counts, snn_stream_t s,
-                                      bool wm_in = false, bool wm_out = false) {
+                                      bool wm_in = false, bool wm_out = false, const StepWindow* win = nullptr) {
     if (!a_planes || !w_packed || !spk || !p || R <= 0 || K <= 0 || N <= 0)
         return fail(-1, "snn_spike_gemm_lif_bf16x3: bad argument");
     if (check_T(T, "snn_spike_gemm_lif_bf16x3")) return -1;
@@ -462,9 +496,12 @@ static int spike_gemm_lif_bf16x3_impl(const uint32_t* a_planes, int T, int R, in
     a.n_blocks = cdiv(a.Np, G3_BN(wn));
     a.T = T; a.spk = spk; a.spk_stride = spk_stride; a.p = make_p(p, p->v_th_lif); a.cnt_row = row_counts;
     a.wm = wm_in; a.out_wm = wm_out; a.a_step = (unsigned long long)R;       // word-major planes [T][K/32][R]
-    const int mt = g3_pick_mt([&](int m) { return g3_tile_ok(T, g3_bm(wn, m)) ? (long long)cdiv(R, g3_bm(wn, m) / T) * a.n_blocks : 0ll; });
+    const StepWindow w = win ? *win : lif_window_full_out(T);                // time steps whose currents are formed
+    a.t0 = w.t0; a.Tc = w.n;
+    const int Tc = w.n;
+    const int mt = g3_pick_mt([&](int m) { return g3_tile_ok(Tc, g3_bm(wn, m)) ? (long long)cdiv(R, g3_bm(wn, m) / Tc) * a.n_blocks : 0ll; });
     if (!mt) return fail(-4, "snn_spike_gemm_lif_bf16x3: T=%d does not fit a row tile (use snn_spike_gemm_bf16x3 + snn_lif_scan)", T);
-    a.pb = g3_bm(wn, mt) / T;
+    a.pb = g3_bm(wn, mt) / Tc;
     return launch_gemm3(G3_FC_LIF_TILE, mt, wn, a, (hipStream_t)s);
 }
 
@@ -520,16 +557,19 @@ int snn_spike_gemm_mx(const uint32_t* a_rows, int M, int K, int N, const uint32_
 }
 
 static int spike_gemm_lif_mx_impl(const uint32_t* a_planes, int T, int R, int K, int N, const snn_params* p,
-                                  const uint32_t* w_packed, uint32_t* spk, size_t spk_stride, uint32_t* row_counts, snn_stream_t s) {
+                                  const uint32_t* w_packed, uint32_t* spk, size_t spk_stride, uint32_t* row_counts, snn_stream_t s,
+                                  const StepWindow* win = nullptr) {
     if (!a_planes || !w_packed || !spk || !p || R <= 0 || K <= 0 || N <= 0) return fail(-1, "snn_spike_gemm_lif_mx: bad argument");
     if (check_T(T, "snn_spike_gemm_lif_mx")) return -1;
     if (K % 128) return fail(-4, "snn_spike_gemm_lif_mx: K=%d is not a multiple of 128", K);
-    if (!mx_tile_ok(T)) return fail(-4, "snn_spike_gemm_lif_mx: T=%d does not fit a row tile", T);
+    const StepWindow w = win ? *win : lif_window_full_out(T);
+    if (!mx_tile_ok(w.n)) return fail(-4, "snn_spike_gemm_lif_mx: T=%d does not fit a row tile", T);
     if ((long long)T * R * (K / 32) * 4 > 0xffffffffLL) return fail(-1, "snn_spike_gemm_lif_mx: input planes over 4 GB");
     MxArgs a;
     memset(&a, 0, sizeof(a));
     a.g.A = a_planes; a.g.M = R; a.g.Np = cdiv(N, 32) * 32;
-    a.g.T = T; a.g.spk = spk; a.g.spk_stride = spk_stride; a.g.p = make_p(p, p->v_th_lif); a.g.pb = MX_BM / T;
+    a.g.T = T; a.g.spk = spk; a.g.spk_stride = spk_stride; a.g.p = make_p(p, p->v_th_lif); a.g.pb = MX_BM / w.n;
+    a.g.t0 = w.t0; a.g.Tc = w.n;
     a.g.cnt_row = row_counts;
     a.wq = w_packed; a.Kc = K / 128;
     return launch_gemm_mx(G3_FC_LIF_TILE, a, (hipStream_t)s);
@@ -574,8 +614,10 @@ static int conv3x3_lif_mx_impl(const uint32_t* enc, size_t enc_stride, const snn
     long long P;
     int rc = conv_mx_common("snn_conv3x3_lif_mx", enc, enc_stride, lv, n_levels, C_in, C_out, T, w_packed, a, &P);
     if (rc) return rc;
-    if (!mx_tile_ok(T)) return fail(-4, "snn_conv3x3_lif_mx: T=%d does not fit a row tile", T);
-    a.g.M = (int)P; a.g.T = T; a.g.spk = spk; a.g.spk_stride = spk_stride; a.g.p = make_p(p, p->v_th_lif); a.g.pb = MX_BM / T;
+    const StepWindow w = lif_window_full_out(T);
+    if (!mx_tile_ok(w.n)) return fail(-4, "snn_conv3x3_lif_mx: T=%d does not fit a row tile", T);
+    a.g.M = (int)P; a.g.T = T; a.g.spk = spk; a.g.spk_stride = spk_stride; a.g.p = make_p(p, p->v_th_lif); a.g.pb = MX_BM / w.n;
+    a.g.t0 = w.t0; a.g.Tc = w.n;
     a.g.cnt_img = counts; a.g.max_n = max_n;
     return launch_gemm_mx(G3_CONV_LIF_TILE, a, (hipStream_t)s);
 }
@@ -648,10 +690,13 @@ static int conv3x3_lif_bf16x3_impl(const uint32_t* enc, size_t enc_stride, const
     a.M = (int)P; a.T = T; a.spk = spk; a.spk_stride = spk_stride; a.p = make_p(p, p->v_th_lif);
     // debug / A-B knob: SNN_BF16X3_LIF=reg forces the register-resident variant (the fallback for T > 64)
     const int wn = g3_wn(true);
+    const StepWindow w = lif_window_full_out(T);   // the LI heads read the shared LIF's spikes of every step: currents of steps 0 .. T-2
+    a.t0 = w.t0; a.Tc = w.n;
+    const int Tc = w.n;
     int mt = 0;
     if (!knobs().bf16x3_lif_reg) {
         a.n_blocks = cdiv(a.Np, G3_BN(wn));
-        mt = g3_pick_mt([&](int m) { return g3_tile_ok(T, g3_bm(wn, m)) ? (long long)cdiv(P, g3_bm(wn, m) / T) * a.n_blocks : 0ll; });
+        mt = g3_pick_mt([&](int m) { return g3_tile_ok(Tc, g3_bm(wn, m)) ? (long long)cdiv(P, g3_bm(wn, m) / Tc) * a.n_blocks : 0ll; });
     }
     if (!mt) {                                     // register-fused fallback: counts from the planes afterwards
         a.n_blocks = cdiv(a.Np, G3_BN(2));
@@ -659,7 +704,7 @@ static int conv3x3_lif_bf16x3_impl(const uint32_t* enc, size_t enc_stride, const
         if (rc || !counts) return rc;
         return count_spikes_per_image(lv, n_levels, cdiv(C_out, 32), T, spk, spk_stride, counts, max_n, (hipStream_t)s);
     }
-    a.pb = g3_bm(wn, mt) / T;
+    a.pb = g3_bm(wn, mt) / Tc;
     a.cnt_img = counts; a.max_n = max_n;
     if (want_split && a.Np % 128 == 0) { a.out_split = 1; *out_split = true; }
     return launch_gemm3(G3_CONV_LIF_TILE, mt, wn, a, (hipStream_t)s);
@@ -839,6 +884,7 @@ static int launch_conv(const snn_rpn_level* lv, int n_levels, int C_in, int C_ou
     a.enc = enc; a.spk = spk; a.wpk = wpk; a.counts = counts; a.dbg_cur = dbg_cur;
     a.enc_stride = enc_stride; a.spk_stride = spk_stride;
     a.Cw = cdiv(C_in, 32); a.Nw = cdiv(C_out, 32); a.T = T; a.n_levels = n_levels; a.max_n = max_n;
+    a.Tc = dbg_cur ? T : lif_window_full_out(T).n;          // (the test hook dumps the currents of every step)
     a.p = make_p(p, p->v_th_lif);
     int tiles = 0, pos = 0;
     for (int l = 0; l < n_levels; ++l) {
@@ -886,16 +932,22 @@ int snn_spike_gemm(const uint32_t* a_rows, int M, int K, int N, const float* w_p
     return 0;
 }
 
+// cur = the currents of the steps w.t0 .. w.t0+w.n-1, [w.n][R][ldc]
+static int lif_scan_window(const float* cur, int T, StepWindow w, int R, int N, int ldc, const snn_params* p, uint32_t* spk,
+                           size_t spk_stride, uint32_t* row_counts, snn_stream_t s) {
+    const int Nw = cdiv(N, 32);
+    const size_t total = (size_t)R * Nw * 32;
+    hipLaunchKernelGGL(k_lif_scan, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)s, cur, T, w.t0, w.n, R, N,
+                       Nw, ldc, make_p(p, p->v_th_lif), spk, spk_stride, row_counts);
+    SNN_CHECK_LAUNCH("k_lif_scan");
+    return 0;
+}
+
 int snn_lif_scan(const float* cur, int T, int R, int N, int ldc, const snn_params* p, uint32_t* spk,
                  size_t spk_stride, uint32_t* row_counts, snn_stream_t s) {
     if (!cur || !spk || !p || R <= 0 || N <= 0 || ldc < N) return fail(-1, "snn_lif_scan: bad argument");
     if (check_T(T, "snn_lif_scan")) return -1;
-    const int Nw = cdiv(N, 32);
-    const size_t total = (size_t)R * Nw * 32;
-    hipLaunchKernelGGL(k_lif_scan, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)s, cur, T, R, N,
-                       Nw, ldc, make_p(p, p->v_th_lif), spk, spk_stride, row_counts);
-    SNN_CHECK_LAUNCH("k_lif_scan");
-    return 0;
+    return lif_scan_window(cur, T, lif_window_all(T), R, N, ldc, p, spk, spk_stride, row_counts, s);
 }
 
 // the launch of snn_li_heads that can read spike planes in blocks of four words (k_li_heads_mfma with W resident, 8 words per row)
@@ -1038,7 +1090,7 @@ int snn_rpn_head_forward_stages(const snn_rpn_level* lv, int n_levels, int C, in
     if (C <= 0 || A <= 0) return fail(-1, "snn_rpn_head_forward: bad C/A");
     if (p->precision != SNN_PRECISION_F32 && p->precision != SNN_PRECISION_BF16X3 && p->precision != SNN_PRECISION_MXFP6)
         return fail(-1, "snn_rpn_head_forward: unknown precision %d", p->precision);
-    if (p->precision == SNN_PRECISION_MXFP6 && (C % 128 || !mx_tile_ok(T)))
+    if (p->precision == SNN_PRECISION_MXFP6 && (C % 128 || !mx_tile_ok(lif_window_full_out(T).n)))
         return fail(-4, "snn_rpn_head_forward: the mxfp6 kernels need C %% 128 == 0 and a T that fits a 512-row tile (C=%d, T=%d)", C, T);
     if (check_T(T, "snn_rpn_head_forward")) return -1;
     for (int l = 0; l < n_levels; ++l)
@@ -1054,12 +1106,13 @@ int snn_rpn_head_forward_stages(const snn_rpn_level* lv, int n_levels, int C, in
     const int Cw = cdiv(C, 32);
     const size_t stride = (size_t)P * Cw;            // words per time plane (spike planes)
     const size_t enc_stride = (size_t)Pe * Cw;       // ... of the encoder planes
+    const int Tc = lif_window_full_out(T).n;         // encoder planes / conv currents of steps 0 .. Tc-1 (dead time steps: T-1)
     // bf16x3 conv -> LI heads: spike planes in blocks of four words when the heads kernel that will run reads them so (C = 256).
     // Decided up front, so that a stage-by-stage caller (bench.py's kernel breakdown) sees the same launches; a T that does
     // not fit a row tile runs the register-fused conv, which writes plain rows: then the heads read plain rows
     bool split = p->precision == SNN_PRECISION_BF16X3 && !knobs().spk_rows && li_heads_reads_split(C, A, 4 * A) &&
                  !knobs().bf16x3_lif_reg && cdiv(C, 32) * 32 % 128 == 0 &&
-                 (g3_tile_ok(T, G3_BM(g3_wn(true), 4)) || g3_tile_ok(T, G3_BM(g3_wn(true), 3)) || g3_tile_ok(T, G3_BM(g3_wn(true), 2)));
+                 (g3_tile_ok(Tc, G3_BM(g3_wn(true), 4)) || g3_tile_ok(Tc, G3_BM(g3_wn(true), 3)) || g3_tile_ok(Tc, G3_BM(g3_wn(true), 2)));
     // bf16x3, SNN_PLANES=wm: encoder planes word-major [T][Cw][Pe] - a conv tile's spike words of a chunk are then 128-byte
     // runs.  Not the default for the convolution: -0.7 % of kernel time, but a 128-byte line of a word plane is shared by
     // horizontally adjacent tiles (on different XCDs), FETCH_SIZE 84 -> 177 MB per launch
@@ -1089,14 +1142,14 @@ int snn_rpn_head_forward_stages(const snn_rpn_level* lv, int n_levels, int C, in
                 images += lv[l].N;
             }
             hl.blk_base[n_levels] = images; hl.n_levels = n_levels;
-            hipLaunchKernelGGL(k_zero_halo, dim3(images, 32), dim3(256), 0, s, hl, Cw, T, enc, enc_stride, wm_rows);
+            hipLaunchKernelGGL(k_zero_halo, dim3(images, 32), dim3(256), 0, s, hl, Cw, Tc, enc, enc_stride, wm_rows);
             SNN_CHECK_LAUNCH("k_zero_halo");
         }
         const NeuronP np = make_p(p, p->v_th_enc);
         if (enc_zero_rest(np))
-            hipLaunchKernelGGL(k_encode_levels<true>, dim3(blocks, cdiv(Cw, 8)), dim3(256), 0, s, el, C, Cw, T, np, enc, enc_stride, wm_rows);
+            hipLaunchKernelGGL(k_encode_levels<true>, dim3(blocks, cdiv(Cw, 8)), dim3(256), 0, s, el, C, Cw, Tc, np, enc, enc_stride, wm_rows);
         else
-            hipLaunchKernelGGL(k_encode_levels<false>, dim3(blocks, cdiv(Cw, 8)), dim3(256), 0, s, el, C, Cw, T, np, enc, enc_stride, wm_rows);
+            hipLaunchKernelGGL(k_encode_levels<false>, dim3(blocks, cdiv(Cw, 8)), dim3(256), 0, s, el, C, Cw, Tc, np, enc, enc_stride, wm_rows);
         SNN_CHECK_LAUNCH("k_encode_levels");
     }
     if (stage_mask & SNN_STAGE_CONV_LIF) {
@@ -1396,17 +1449,17 @@ size_t snn_det_head_workspace_bytes(int R, int D, int Hd, int K, int K4, int T, 
 }
 
 // the detector's bf16x3 path with both linear layers fused with their LIF (one row tile holds all T steps)
-static bool det_b3_tiles(const snn_params* p, int T) {
-    return p->precision == SNN_PRECISION_BF16X3 &&
-           (g3_tile_ok(T, G3_BM(g3_wn(), 4)) || g3_tile_ok(T, G3_BM(g3_wn(), 3)) || g3_tile_ok(T, G3_BM(g3_wn(), 2)));
+static bool g3_some_tile_ok(int Tc) { return g3_tile_ok(Tc, G3_BM(g3_wn(), 4)) || g3_tile_ok(Tc, G3_BM(g3_wn(), 3)) || g3_tile_ok(Tc, G3_BM(g3_wn(), 2)); }
+static bool det_b3_tiles(const snn_params* p, const DetWindows& w) {
+    return p->precision == SNN_PRECISION_BF16X3 && g3_some_tile_ok(w.fc6.n) && g3_some_tile_ok(w.fc7.n);
 }
 // ... which takes its encoder planes word-major [T][D/32][R] (and hands fc6's spikes to fc7 that way)
-static bool det_planes_wm(const snn_params* p, int T) { return det_b3_tiles(p, T) && knobs().planes != 1; }
+static bool det_planes_wm(const snn_params* p, const DetWindows& w) { return det_b3_tiles(p, w) && knobs().planes != 1; }
 
 static int det_head_from_planes(int R, int D, int Hd, int K, int K4, int T, const snn_params* p, const void* w6_packed,
                                 const void* w7_packed, const float* w_heads_packed, float* out_cls, float* out_bbox,
                                 uint32_t* spk6_count, uint32_t* spk7_count, float* sum_cls, float* sum_bbox, void* ws,
-                                bool enc_wm, snn_stream_t stream) {
+                                bool enc_wm, const DetWindows& win, snn_stream_t stream) {
     size_t o_enc, o_cur, o_s6, o_s7, need;
     det_ws_layout(R, D, Hd, T, &o_enc, &o_cur, &o_s6, &o_s7, &need);
     hipStream_t s = (hipStream_t)stream;
@@ -1421,34 +1474,38 @@ static int det_head_from_planes(int R, int D, int Hd, int K, int K4, int T, cons
     const bool b3 = p->precision == SNN_PRECISION_BF16X3, mx = p->precision == SNN_PRECISION_MXFP6;
     if (p->precision != SNN_PRECISION_F32 && !b3 && !mx) return fail(-1, "snn_det_head_forward: unknown precision %d", p->precision);
     if (mx) {
-        if (D % 128 || Hd % 128 || !mx_tile_ok(T))
-            return fail(-4, "snn_det_head_forward: the mxfp6 kernels need D, Hd %% 128 == 0 and a T that fits a 512-row tile");
+        if (D % 128 || Hd % 128)
+            return fail(-4, "snn_det_head_forward: the mxfp6 kernels need D, Hd %% 128 == 0");
         // (spike-rate mode: per-RoI counts come out of the LIF epilogues)
-        if ((rc = spike_gemm_lif_mx_impl(enc, T, R, D, Hd, p, (const uint32_t*)w6_packed, s6, (size_t)R * Hw, spk6_count, stream))) return rc;
-        if ((rc = spike_gemm_lif_mx_impl(s6, T, R, Hd, Hd, p, (const uint32_t*)w7_packed, s7, (size_t)R * Hw, spk7_count, stream))) return rc;
+        if (!mx_tile_ok(win.fc6.n) || !mx_tile_ok(win.fc7.n)) return fail(-4, "snn_det_head_forward: T=%d does not fit a 512-row tile of the mxfp6 kernels", T);
+        if ((rc = spike_gemm_lif_mx_impl(enc, T, R, D, Hd, p, (const uint32_t*)w6_packed, s6, (size_t)R * Hw, spk6_count, stream, &win.fc6))) return rc;
+        if ((rc = spike_gemm_lif_mx_impl(s6, T, R, Hd, Hd, p, (const uint32_t*)w7_packed, s7, (size_t)R * Hw, spk7_count, stream, &win.fc7))) return rc;
         return snn_li_heads(s7, (size_t)R * Hw, T, R, Hd, w_heads_packed, K, K4, p, out_cls, out_bbox, sum_cls,
                             sum_bbox, stream);
     }
-    if (enc_wm && !det_b3_tiles(p, T)) return fail(-1, "snn_det_head_forward: word-major planes without the fused bf16x3 layers");
-    if (det_b3_tiles(p, T)) {
+    if (enc_wm && !det_b3_tiles(p, win)) return fail(-1, "snn_det_head_forward: word-major planes without the fused bf16x3 layers");
+    if (det_b3_tiles(p, win)) {
         // fc6 + LIF and fc7 + LIF, each one launch: a row tile holds all T steps of its RoIs, the currents never
         // leave the chip (faster_rcnn.py:498-501)
         // (spike-rate mode: per-RoI counts come out of the LIF epilogues)
         // (word-major planes between the stages: encoder -> fc6 -> fc7; fc7's spikes feed the LI heads row-major)
-        if ((rc = spike_gemm_lif_bf16x3_impl(enc, T, R, D, Hd, p, (const uint16_t*)w6_packed, s6, (size_t)R * Hw, spk6_count, stream, enc_wm, enc_wm))) return rc;
-        if ((rc = spike_gemm_lif_bf16x3_impl(s6, T, R, Hd, Hd, p, (const uint16_t*)w7_packed, s7, (size_t)R * Hw, spk7_count, stream, enc_wm, false))) return rc;
+        // (dead time steps, lif_windows: fc6 forms the currents of steps 0 .. T-3, fc7 of steps 1 .. T-2)
+        if ((rc = spike_gemm_lif_bf16x3_impl(enc, T, R, D, Hd, p, (const uint16_t*)w6_packed, s6, (size_t)R * Hw, spk6_count, stream, enc_wm, enc_wm, &win.fc6))) return rc;
+        if ((rc = spike_gemm_lif_bf16x3_impl(s6, T, R, Hd, Hd, p, (const uint16_t*)w7_packed, s7, (size_t)R * Hw, spk7_count, stream, enc_wm, false, &win.fc7))) return rc;
         return snn_li_heads(s7, (size_t)R * Hw, T, R, Hd, w_heads_packed, K, K4, p, out_cls, out_bbox, sum_cls,
                             sum_bbox, stream);
     }
-    // fc6 for all T steps at once: rows m = t*R + r   (faster_rcnn.py:498)
-    rc = b3 ? snn_spike_gemm_bf16x3(enc, T * R, D, Hd, (const uint16_t*)w6_packed, cur, Hp, stream)
-            : snn_spike_gemm(enc, T * R, D, Hd, (const float*)w6_packed, cur, Hp, stream);
+    // fc6 for all (live) time steps at once: rows m = (t - t0)*R + r   (faster_rcnn.py:498)
+    const uint32_t* a6 = enc + (size_t)win.fc6.t0 * R * cdiv(D, 32);
+    rc = b3 ? snn_spike_gemm_bf16x3(a6, win.fc6.n * R, D, Hd, (const uint16_t*)w6_packed, cur, Hp, stream)
+            : snn_spike_gemm(a6, win.fc6.n * R, D, Hd, (const float*)w6_packed, cur, Hp, stream);
     if (rc) return rc;
-    if ((rc = snn_lif_scan(cur, T, R, Hd, Hp, p, s6, (size_t)R * Hw, spk6_count, stream))) return rc;   // :499
-    rc = b3 ? snn_spike_gemm_bf16x3(s6, T * R, Hd, Hd, (const uint16_t*)w7_packed, cur, Hp, stream)
-            : snn_spike_gemm(s6, T * R, Hd, Hd, (const float*)w7_packed, cur, Hp, stream);                       // :500
+    if ((rc = lif_scan_window(cur, T, win.fc6, R, Hd, Hp, p, s6, (size_t)R * Hw, spk6_count, stream))) return rc;   // :499
+    const uint32_t* a7 = s6 + (size_t)win.fc7.t0 * R * Hw;
+    rc = b3 ? snn_spike_gemm_bf16x3(a7, win.fc7.n * R, Hd, Hd, (const uint16_t*)w7_packed, cur, Hp, stream)
+            : snn_spike_gemm(a7, win.fc7.n * R, Hd, Hd, (const float*)w7_packed, cur, Hp, stream);                       // :500
     if (rc) return rc;
-    if ((rc = snn_lif_scan(cur, T, R, Hd, Hp, p, s7, (size_t)R * Hw, spk7_count, stream))) return rc;   // :501
+    if ((rc = lif_scan_window(cur, T, win.fc7, R, Hd, Hp, p, s7, (size_t)R * Hw, spk7_count, stream))) return rc;   // :501
     return snn_li_heads(s7, (size_t)R * Hw, T, R, Hd, w_heads_packed, K, K4, p, out_cls, out_bbox, sum_cls,
                         sum_bbox, stream);                                                               // :505-510
 }
@@ -1464,11 +1521,12 @@ int snn_det_head_forward(const float* x, int R, int D, int Hd, int K, int K4, in
     size_t o_enc, o_cur, o_s6, o_s7, need;
     det_ws_layout(R, D, Hd, T, &o_enc, &o_cur, &o_s6, &o_s7, &need);
     if (ws_bytes < need) return fail(-2, "snn_det_head_forward: workspace %zu < %zu bytes", ws_bytes, need);
-    const bool wm = det_planes_wm(p, T) && encode_rows_wm_ok(x, D);
-    int rc = encode_rows_impl(x, R, D, T, p, (uint32_t*)((char*)ws + o_enc), (size_t)R * cdiv(D, 32), wm, stream);
+    const DetWindows win = det_windows(p, T, spk6_count != nullptr);
+    const bool wm = det_planes_wm(p, win) && encode_rows_wm_ok(x, D);
+    int rc = encode_rows_impl(x, R, D, win.enc_steps, p, (uint32_t*)((char*)ws + o_enc), (size_t)R * cdiv(D, 32), wm, stream);
     if (rc) return rc;
     return det_head_from_planes(R, D, Hd, K, K4, T, p, w6_packed, w7_packed, w_heads_packed, out_cls, out_bbox,
-                                spk6_count, spk7_count, sum_cls, sum_bbox, ws, wm, stream);
+                                spk6_count, spk7_count, sum_cls, sum_bbox, ws, wm, win, stream);
 }
 
 int snn_det_head_forward_roialign(const snn_roi_level* levels_host, int n_levels, int C, const float* rois,
@@ -1484,12 +1542,14 @@ int snn_det_head_forward_roialign(const snn_roi_level* levels_host, int n_levels
     size_t o_enc, o_cur, o_s6, o_s7, need;
     det_ws_layout(R, D, Hd, T, &o_enc, &o_cur, &o_s6, &o_s7, &need);
     if (ws_bytes < need) return fail(-2, "snn_det_head_forward_roialign: workspace %zu < %zu bytes", ws_bytes, need);
-    const bool wm = det_planes_wm(p, T);
-    int rc = roi_align_encode_impl(levels_host, n_levels, C, rois, roi_batch, roi_level, R, T, p,
+    if (check_T(T, "snn_det_head_forward_roialign")) return -1;
+    const DetWindows win = det_windows(p, T, spk6_count != nullptr);
+    const bool wm = det_planes_wm(p, win);
+    int rc = roi_align_encode_impl(levels_host, n_levels, C, rois, roi_batch, roi_level, R, win.enc_steps, p,
                                    (uint32_t*)((char*)ws + o_enc), (size_t)R * cdiv(D, 32), nullptr, wm, stream);
     if (rc) return rc;
     return det_head_from_planes(R, D, Hd, K, K4, T, p, w6_packed, w7_packed, w_heads_packed, out_cls, out_bbox,
-                                spk6_count, spk7_count, sum_cls, sum_bbox, ws, wm, stream);
+                                spk6_count, spk7_count, sum_cls, sum_bbox, ws, wm, win, stream);
 }
 
 int snn_det_exchange_payload(const float* class_logits, const float* box_regression, int N, int rois_per_image, int K,

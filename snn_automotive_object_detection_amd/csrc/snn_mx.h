@@ -207,14 +207,14 @@ __global__ __launch_bounds__(2048 / MW, 16 / MW) void k_gemm_mx(const MxArgs ma)
     for (int i = 0; i < RPT; ++i) {
         const int xrow = wave * WROWS + i * 64 + lane;
         const int xt = TILE ? xrow / args.pb : 0;
-        const int xm = TILE ? (xt < args.T ? m0 + xrow % args.pb : M) : m0 + xrow;
+        const int xm = TILE ? (xt < args.Tc ? m0 + xrow % args.pb : M) : m0 + xrow;
         uint32_t a_off = 0;
         int a_pitch = 0;
         if (CONV) {
             // the encoder planes carry a one-position zero halo around every image: every tap of every position is a plain
             // read (rows past M read the first halo row: zeros)
             if (xm < M) {
-                const int t = TILE ? xt : xm / args.P_total, p = TILE ? xm : xm % args.P_total;
+                const int t = TILE ? xt + args.t0 : xm / args.P_total, p = TILE ? xm : xm % args.P_total;
                 int l = 0;
                 while (l + 1 < args.n_levels && p >= args.lv[l + 1].pos_base) ++l;
                 const int H = args.lv[l].H, W = args.lv[l].W;
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(2048 / MW, 16 / MW) void k_gemm_mx(const MxArgs ma)
             // registers through the MFMA loop
             reinterpret_cast<uint2*>(smem + MX_PARK_OFF)[xrow] = make_uint2(a_off, (uint32_t)a_pitch);
         } else if (TILE) {
-            a_off = xm < M ? (uint32_t)(((size_t)xt * M + xm) * Kw * 4) : 0u;
+            a_off = xm < M ? (uint32_t)(((size_t)(xt + args.t0) * M + xm) * Kw * 4) : 0u;
         } else {
             a_off = (uint32_t)((size_t)min(xm, M - 1) * Kw * 4);
         }
@@ -483,7 +483,7 @@ __global__ __launch_bounds__(2048 / MW, 16 / MW) void k_gemm_mx(const MxArgs ma)
         float* const tile = reinterpret_cast<float*>(smem);
         uint32_t* const pos_cnt = reinterpret_cast<uint32_t*>(smem + G3_TILE_BYTES(1));     // behind the tile image
         const bool counting = args.cnt_img != nullptr || args.cnt_row != nullptr;
-        const int pb = args.pb, T = args.T;
+        const int pb = args.pb, T = args.T, t0 = args.t0, t1 = args.t0 + args.Tc;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll 1
         for (int h = 0; h < 2; ++h) {
@@ -508,7 +508,9 @@ __global__ __launch_bounds__(2048 / MW, 16 / MW) void k_gemm_mx(const MxArgs ma)
                 const float* src = tile + (live ? pi : 2 * pp) * PITCH + col;
                 uint32_t cnt0 = 0, cnt1 = 0;               // wave-uniform: spikes of the even / odd position in this pass
                 for (int t = 0; t < T; ++t) {
-                    const bool z = lif_step(src[(size_t)t * pb * PITCH], vv, ii, args.p);
+                    float cur = 0.0f;                      // steps outside the tile's window: no input current (Gemm3Args.Tc)
+                    if (t >= t0 && t < t1) cur = src[(size_t)(t - t0) * pb * PITCH];
+                    const bool z = lif_step(cur, vv, ii, args.p);
                     const unsigned long long b = __ballot(z);
                     my0 = lane == t ? (uint32_t)b : my0;
                     my1 = lane == t ? (uint32_t)(b >> 32) : my1;

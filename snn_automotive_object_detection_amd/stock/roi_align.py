@@ -40,8 +40,9 @@ def roi_align(feat: Tensor, rois: Tensor, spatial_scale: float, output_size: int
     if K == 0:
         return out
     S, P = sampling_ratio, output_size
-    grid = (torch.arange(P * S, device=feat.device, dtype=feat.dtype) // S) + \
-           ((torch.arange(P * S, device=feat.device, dtype=feat.dtype) % S) + 0.5) / S       # ph + (iy + .5)/S
+    idx = torch.arange(P * S, device=feat.device, dtype=feat.dtype)
+    g_p = torch.div(idx, S, rounding_mode="floor")                                      # ph of sample row / column i
+    g_i = (idx % S) + 0.5                                                               # iy + .5
     for n in range(feat.shape[0]):
         idx = torch.where(rois[:, 0] == n)[0]
         for s in range(0, idx.numel(), chunk):
@@ -50,12 +51,19 @@ def roi_align(feat: Tensor, rois: Tensor, spatial_scale: float, output_size: int
             x1, y1 = r[:, 1] * spatial_scale, r[:, 2] * spatial_scale
             rw = (r[:, 3] * spatial_scale - x1).clamp(min=1.0)
             rh = (r[:, 4] * spatial_scale - y1).clamp(min=1.0)
-            ys = y1[:, None] + grid[None, :] * (rh / P)[:, None]                        # [k, P*S]
-            xs = x1[:, None] + grid[None, :] * (rw / P)[:, None]
+            bh, bw = (rh / P)[:, None], (rw / P)[:, None]
+            # torchvision's operation order (roi_align_common.h): start + ph * bin + (iy + .5) * bin / S, left to right
+            ys = (y1[:, None] + g_p[None, :] * bh) + (g_i[None, :] * bh) / S            # [k, P*S]
+            xs = (x1[:, None] + g_p[None, :] * bw) + (g_i[None, :] * bw) / S
             yy = ys[:, :, None].expand(-1, -1, P * S)
             xx = xs[:, None, :].expand(-1, P * S, -1)
             v = _bilinear(feat[n], yy, xx)                                              # [C, k, PS, PS]
-            v = v.reshape(C, sel.numel(), P, S, P, S).mean(dim=(3, 5))
+            v = v.reshape(C, sel.numel(), P, S, P, S)
+            acc = torch.zeros_like(v[:, :, :, 0, :, 0])
+            for a in range(S):                                                          # output_val += sample, (iy, ix) order
+                for b in range(S):
+                    acc = acc + v[:, :, :, a, :, b]
+            v = acc / float(S * S)
             out[sel] = v.permute(1, 0, 2, 3)
     return out
 

@@ -78,3 +78,47 @@ def test_constants_are_fp32_products():
     b = 0.001 * p.tau_syn_inv
     assert a.dtype == torch.float32 and b.dtype == torch.float32
     assert float(a) == float(np.float32(0.1)) and float(b) == float(np.float32(0.2))
+
+
+def _dead(windows):
+    """cur_hook that zeroes the input current of the steps OUTSIDE each layer's window [t0, t0+n)"""
+    def hook(name, step, cur):
+        t0, n = windows[name]
+        return cur if t0 <= step < t0 + n else torch.zeros_like(cur)
+    return hook
+
+
+def test_dead_time_steps_cannot_reach_an_output():
+    """What the HIP launchers skip (csrc/snn_kernels.hip: lif_windows), stated on the oracle: zeroing the 3x3 conv of the last
+    RPN step, fc6 of the last two detector steps (the last one in spike-rate mode) and fc7 of the first and last step leaves
+    every output, spike plane and rate tensor of the golden fixtures bit-identical (rpn.py:98-119, faster_rcnn.py:492-516:
+    lif_feed_forward_step adds the input of step t after that step's membrane update)."""
+    from oracle import fixtures as FX
+    from oracle import snn_oracle as OR
+    for name in ("rpn_c16_T8", "rpn_c256_T8_odd"):
+        if name not in FX.RPN_SPECS:
+            continue
+        spec = FX.RPN_SPECS[name]
+        feats, w_s, w_c, w_b = FX.rpn_inputs(spec)
+        T = spec["T"]
+        full = OR.rpn_head_forward(feats, w_s, w_c, w_b, T, trace=True, spike_rates=True)
+        cut = OR.rpn_head_forward(feats, w_s, w_c, w_b, T, trace=True, spike_rates=True, cur_hook=_dead({"shared": (0, T - 1)}))
+        for a, b in zip(full[0] + full[1] + full[2], cut[0] + cut[1] + cut[2]):
+            assert torch.equal(a, b)
+        for ta, tb in zip(full[3], cut[3]):
+            assert torch.equal(ta["spk"], tb["spk"]) and bool(ta["spk"].any())
+    for name in sorted(FX.DET_SPECS)[:2]:
+        spec = FX.DET_SPECS[name]
+        x, w6, w7, wc, wb = FX.det_inputs(spec)
+        T = spec["T"]
+        full = OR.det_head_forward(x, w6, w7, wc, wb, T, trace=True)
+        cut = OR.det_head_forward(x, w6, w7, wc, wb, T, trace=True, cur_hook=_dead({"fc6": (0, T - 2), "fc7": (1, T - 2)}))
+        assert torch.equal(full[0], cut[0]) and torch.equal(full[1], cut[1])
+        assert torch.equal(full[2]["spk7"], cut[2]["spk7"]) and bool(full[2]["spk7"].any())
+        r_full = OR.det_head_forward(x, w6, w7, wc, wb, T, spike_rates=True)
+        r_cut = OR.det_head_forward(x, w6, w7, wc, wb, T, spike_rates=True, cur_hook=_dead({"fc6": (0, T - 1), "fc7": (1, T - 2)}))
+        for a, b in zip(r_full, r_cut):
+            assert torch.equal(a, b)
+        # ... and one step more IS visible: the windows are tight
+        one_less = OR.det_head_forward(x, w6, w7, wc, wb, T, trace=True, cur_hook=_dead({"fc6": (0, T - 3), "fc7": (1, T - 2)}))
+        assert not torch.equal(full[2]["spk7"], one_less[2]["spk7"]) or not torch.equal(full[0], one_less[0])

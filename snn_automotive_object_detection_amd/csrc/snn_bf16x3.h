@@ -36,32 +36,21 @@ __device__ __forceinline__ const void* sgpr_ptr(const void* p) {
 }
 // Three pieces (the three weight planes of a chunk) per call; s_nop 4 / s_nop 0: SGPR -> VMEM-base and M0 -> LDS-DMA
 // wait states, which hipcc's hazard recogniser does not insert inside inline asm.
-// cache-policy bits of the LDS-DMA copies, A/B switches (0 = default policy): -DSNN_W_AUX_ID=n for the weight planes,
-// -DSNN_A_AUX_ID=n for the spike words; 1 = nt, 2 = sc0, 3 = sc1, 4 = sc0 sc1
-#define SNN_AUX_STR_0 ""
-#define SNN_AUX_STR_1 " nt"
-#define SNN_AUX_STR_2 " sc0"
-#define SNN_AUX_STR_3 " sc1"
-#define SNN_AUX_STR_4 " sc0 sc1"
-#define SNN_AUX_CAT(n) SNN_AUX_STR_##n
-#define SNN_AUX_OF(n) SNN_AUX_CAT(n)
-#ifndef SNN_W_AUX_ID
-#define SNN_W_AUX_ID 0
-#endif
-#ifndef SNN_A_AUX_ID
-#define SNN_A_AUX_ID 0
-#endif
-#define SNN_W_AUX SNN_AUX_OF(SNN_W_AUX_ID)
-#define SNN_A_AUX SNN_AUX_OF(SNN_A_AUX_ID)
+// M0: every asm statement below writes M0 itself right before the copy that reads it and leaves nothing in it that is used
+// later, so all that is required of the compiler is that IT keeps no value of its own in M0 across these statements.  LLVM
+// reserves M0 on AMDGPU (it is not allocatable, and a clobber entry for it is ignored with a warning - hence none here) and
+// only materialises it immediately in front of its own M0 readers (movrel, sendmsg, GWS, LDS-DMA builtins): none of those
+// exists in this code object.  tests/test_code_object.py disassembles the built library and asserts exactly that: the only
+// instructions that touch M0 are these s_mov_b32, each followed by its global_load_lds within the same asm statement.
 __device__ __forceinline__ void glds16(const void* p0, uint32_t voff, uint32_t d0) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" SNN_W_AUX :: "v"(voff), "s"(p0), "s"(d0) : "memory", "m0");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(p0), "s"(d0) : "memory");
 }
 __device__ __forceinline__ void glds16x3(const void* p0, const void* p1, const void* p2, uint32_t voff,
                                          uint32_t d0, uint32_t d1, uint32_t d2) {
-    asm volatile("s_mov_b32 m0, %4\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" SNN_W_AUX "\n\t"
-                 "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2" SNN_W_AUX "\n\t"
-                 "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %3" SNN_W_AUX
-                 :: "v"(voff), "s"(p0), "s"(p1), "s"(p2), "s"(d0), "s"(d1), "s"(d2) : "memory", "m0");
+    asm volatile("s_mov_b32 m0, %4\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1\n\t"
+                 "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2\n\t"
+                 "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %3"
+                 :: "v"(voff), "s"(p0), "s"(p1), "s"(p2), "s"(d0), "s"(d1), "s"(d2) : "memory");
 }
 
 // Work-group tile: the 8 waves form (8 / WN) x WN; a wave is 16*MT rows x 64 columns.
@@ -116,6 +105,12 @@ struct Gemm3Args {
     // launch at the Cityscapes pyramid).  Read by k_li_heads_mfma (LiHeadsArgs.half_split).
     int out_split;
     int xcd_classes, n_tiles;    // XCD-aware block order (0: plain row-major order), row tiles of the launch
+    // T-in-tile modes: the LAST n_short row-waves of the work-group multiply MT - 1 M-tiles instead of MT ("short" waves: the
+    // last 16 of their rows do not exist), so a tile has 16 n_short fewer rows.  With n_short = half the row-waves every
+    // SIMD hosts one full and one short wave: tile heights between the MT steps (512 / 448 / 384 / 320 / 256 rows on the
+    // 8 x 1 grid), which is what lets a launch of a few hundred work-groups come out at a whole number of rounds per CU
+    // (launchers: g3_pick_tile).  Logical tile row (what t * pb + position counts) = physical row - 16 * (short waves before it).
+    int n_short;
     NeuronP p;
     ConvLevelDev lv[SNN_MAX_LEVELS];
 };
@@ -213,6 +208,9 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
+    constexpr int NWM = NW / WN;                                          // row-waves of the work-group
+    const int first_short = NWM - ((TILE && MT != 8) ? args.n_short : 0);  // row-waves >= first_short are short
+    const bool short_wave = __builtin_amdgcn_readfirstlane((int)(wm >= first_short)) != 0;
     // Plain row-major tile order, column block fastest: work-group b runs on XCD b % 8 (round-robin dispatch), so with
     // 2 (or 4, 8) column blocks every XCD only ever sees ONE weight panel - half of the 3.5 MB of conv weight planes,
     // which then stay resident in its 4-MB L2 beside the streaming spike planes.  Both re-orderings tried (each XCD a
@@ -248,9 +246,13 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
     // ds_write; its stream counters lived in vector registers behind exec-mask branches: ~25 vector instructions per wave
     // and chunk, 12-15 % of the kernel (timing build without the stream: conv+LIF 2.99 -> 2.61 ms, fc6 1.03 -> 0.87 ms).
     const bool a_role = wave * 64 < BM;
-    const int xrow = tid & (G3_BM(WN, 4) - 1);
-    const int xt = TILE ? xrow / args.pb : 0;       // TILE: time step of the row
-    const int xm = TILE ? (xt < args.Tc ? m0 + xrow % args.pb : M) : m0 + xrow;
+    const int xrow = tid & (G3_BM(WN, 4) - 1);      // physical tile row this thread stages
+    // logical row (short waves: their last 16 physical rows are holes)
+    const int xw = xrow / WROWS, xshort = max(0, xw - first_short);
+    const bool xhole = xw >= first_short && xrow % WROWS >= WROWS - 16;
+    const int xl = xrow - 16 * xshort;
+    const int xt = TILE ? xl / args.pb : 0;         // TILE: time step of the row
+    const int xm = TILE ? ((xt < args.Tc && !xhole) ? m0 + xl % args.pb : M) : m0 + xrow;
     const bool a_wm = args.wm != 0;                   // word-major planes: a row's consecutive words are a_step words apart
     const int row_words = a_wm ? 1 : args.Cw;         // conv: words from one (padded) position to the next
     uint32_t a_off = 0;                             // bytes: fc row / conv centre tap, channel word 0
@@ -287,37 +289,20 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
     const int row_chunks = __builtin_amdgcn_readfirstlane(3 * args.Cw);
     // scalar steps of the stream, in words: to the next channel / K word of the same rows; (conv) at the end of a tap's Cw words
     // on to the next tap of the row; at the end of a tap row back to its first tap; from the centre tap to tap (-1, -1)'s column
-#if defined(SNN_EXP_A_COMPACT) && SNN_EXP_A_COMPACT == 2 && !defined(SNN_EXP_A_STEP1)
-    const int w_step = 256;
-#else
     const int w_step = __builtin_amdgcn_readfirstlane(a_wm ? (int)args.a_step : 1);
-#endif
     const int tap_adj = __builtin_amdgcn_readfirstlane(a_wm ? 1 - args.Cw * (int)args.a_step : 0);
     const int row_back = __builtin_amdgcn_readfirstlane(a_wm ? 3 : 3 * args.Cw);
     const int tap_back = __builtin_amdgcn_readfirstlane(CONV ? row_words : 0);
     const int cw_s = __builtin_amdgcn_readfirstlane(args.Cw);
     const uint32_t* f_ptr = static_cast<const uint32_t*>(sgpr_ptr(args.A - tap_back));
     uint32_t f_voff = CONV ? a_off - a_pitch : a_off;               // lane: row offset of tap row dy
-#ifdef SNN_EXP_A_COMPACT    // timing only: every chunk fetches 1 KB of CONSECUTIVE spike words (wrong rows, same statistics): what
-                            // the 4-bytes-per-row gather of the [row][word] plane layout costs beside a [word][row] layout
-#ifndef SNN_EXP_A_REGIONS
-#define SNN_EXP_A_REGIONS (CONV ? 400 : 64)
-#endif
-#if SNN_EXP_A_COMPACT == 2  // ... a FRESH, aligned 1 KB per chunk (no line is ever fetched twice by a work-group)
-    a_off = (uint32_t)(xrow * 4 + (blockIdx.x % SNN_EXP_A_REGIONS) * (uint32_t)(Kc * 1024) + (CONV ? 4096 : 0));
-#else                       // (1: the same 1 KB + 4 bytes per chunk: the lines stay in the L1)
-    a_off = (uint32_t)(xrow * 4 + (blockIdx.x & 1023) * 1024 + (CONV ? 4096 : 0));
-#endif
-    a_pitch = 0;
-    f_voff = a_off;
-#endif
     int f_t = 0, f_kc = 0, f_j = 0, f_c = 0;
     const uint32_t a_dst = smem_base + G3_LUT_BYTES + wave * 256;   // + slot offset
     auto stage_a = [&](uint32_t slot_off) {
 #ifndef SNN_EXP_NO_FETCH                            // (timing only: no spike-word stream at all)
         if (a_role) {
             const uint32_t d = __builtin_amdgcn_readfirstlane(a_dst + slot_off);
-            asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dword %0, %1" SNN_A_AUX :: "v"(f_voff), "s"(f_ptr), "s"(d) : "memory", "m0");
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dword %0, %1" :: "v"(f_voff), "s"(f_ptr), "s"(d) : "memory");
         }
 #endif
         f_ptr = static_cast<const uint32_t*>(sgpr_ptr(f_ptr + w_step));
@@ -423,7 +408,7 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
 
     // ---- LIF step of the register-fused variant on the accumulators (then cleared): called after the K loop of every
     // current step, and with zero currents for the steps after the last one (dead time steps, Gemm3Args.Tc)
-    auto lif_reg_step = [&](const int t) {
+    auto lif_reg_step = [&](const int t) __attribute__((always_inline)) {
         // ---- LIF epilogue in registers.  A ballot over accumulator register (mt, nt, reg) holds, for each
         // of the 4 row groups rg, 16 channel bits of position mt*16 + rg*4 + reg; N-tiles (0,1) and (2,3)
         // pair up into the two 32-channel words of that position, which lane = position finally stores ----
@@ -478,14 +463,6 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
     //   the weight fragments of chunk c are read PD groups ahead of their MFMAs, the first ones of chunk c+1 and
     //   its spike words / table fragments at the end of chunk c (that slot has been complete since the last barrier).
     // One barrier per chunk; s_sched_barrier pins one fragment read + 4 MFMAs per group.
-#ifdef SNN_EXP_FILL_RING           // timing only: random bf16 bits in the whole ring (for the no-copy experiment)
-    for (int i = tid; i < NB * SLOT / 4; i += 64 * NW) {
-        uint32_t h = (uint32_t)i * 2654435761u + blockIdx.x * 40503u;
-        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
-        reinterpret_cast<uint32_t*>(ring)[i] = (h & 0x3fff3fffu) | 0x38003800u;      // two bf16 of magnitude ~1e-5 .. 1
-    }
-    __syncthreads();
-#endif
     {
 #pragma unroll
         for (int j = 0; j < NB - 1; ++j) { stage_a(j * SLOT); stage_next(j * SLOT); }      // chunks 0 .. NB-2
@@ -500,76 +477,80 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
         asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(clk_c0), "=s"(clk_r0) :: "memory");
     }
 #endif
-    bf16x8 af[2][MT], bq[RING];
-    uint32_t wq[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) wq[mt] = rd_w(0, mt);
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) af[0][mt] = rd_a(wq[mt]);
-#pragma unroll
-    for (int g = 0; g < PD; ++g) bq[g] = rd_b(0, g);
-
     // The loop body is unrolled over one full period of the ring (NB slots) and of the fragment double buffer (2): every
     // LDS address in it is a base register + an immediate, no ring bookkeeping is left at run time.
     // Slots (byte offsets) of chunk c, of c+1, and of c+NB-1 (which receives its spike words and weight planes now).
+    // MTA = M-tiles this wave multiplies: MT, or MT - 1 for the "short" waves of a tile with fewer rows (Gemm3Args.short_wm:
+    // the last 16 rows of those waves do not exist; wave-uniform choice between two instances of the same loop, same
+    // number of chunks and barriers in both).
     constexpr int UNR = (NB % 2) ? 2 * NB : NB;
     int kc = 0, t = 0;
-    for (int c0 = 0; c0 < n_total; c0 += UNR) {
+    auto chunk_loop = [&](auto mta_c) __attribute__((always_inline)) {
+        constexpr int MTA = decltype(mta_c)::value;
+        bf16x8 af[2][MTA], bq[RING];
+        uint32_t wq[MTA];
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            if (c0 + u >= n_total) break;
-            const uint32_t o_cur = (uint32_t)((u % NB) * SLOT), o_nxt = (uint32_t)(((u + 1) % NB) * SLOT),
-                           o_wr = (uint32_t)(((u + NB - 1) % NB) * SLOT);
+        for (int mt = 0; mt < MTA; ++mt) wq[mt] = rd_w(0, mt);
 #pragma unroll
-            for (int g = 0; g < 12; ++g) {
-                const int gp = g + PD;
-#ifdef SNN_EXP_HALF_BREADS                             // timing only: every second weight-fragment read skipped (wrong results)
-                if ((gp & 1) == 0)
-#endif
-                bq[gp % RING] = gp < 12 ? rd_b(o_cur, gp) : rd_b(o_nxt, gp - 12);
-                constexpr int AG0 = MT == 8 ? 4 : 8, WG0 = MT == 8 ? 0 : 4;      // groups that read the next chunk's A side
-                if (g == WG0) {
+        for (int mt = 0; mt < MTA; ++mt) af[0][mt] = rd_a(wq[mt]);
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) wq[mt] = rd_w(o_nxt, mt);
-                }
-                if (g >= AG0 && g - AG0 < MT) af[(u & 1) ^ 1][g - AG0] = rd_a(wq[g - AG0]);
-                if (g == 2) {
-                    stage_a(o_wr);
+        for (int g = 0; g < PD; ++g) bq[g] = rd_b(0, g);
+        for (int c0 = 0; c0 < n_total; c0 += UNR) {
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                if (c0 + u >= n_total) break;
+                const uint32_t o_cur = (uint32_t)((u % NB) * SLOT), o_nxt = (uint32_t)(((u + 1) % NB) * SLOT),
+                               o_wr = (uint32_t)(((u + NB - 1) % NB) * SLOT);
+#pragma unroll
+                for (int g = 0; g < 12; ++g) {
+                    const int gp = g + PD;
+                    bq[gp % RING] = gp < 12 ? rd_b(o_cur, gp) : rd_b(o_nxt, gp - 12);
+                    constexpr int AG0 = MT == 8 ? 4 : 8, WG0 = MT == 8 ? 0 : 4;      // groups that read the next chunk's A side
+                    if (g == WG0) {
+#pragma unroll
+                        for (int mt = 0; mt < MTA; ++mt) wq[mt] = rd_w(o_nxt, mt);
+                    }
+                    if (g >= AG0 && g - AG0 < MTA) af[(u & 1) ^ 1][g - AG0] = rd_a(wq[g - AG0]);
+                    if (g == 2) {
+                        stage_a(o_wr);
 #ifndef SNN_EXP_NO_GLDS
-                    stage_next(o_wr);
+                        stage_next(o_wr);
 #endif
-                }
+                    }
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#ifdef SNN_EXP_HALF_BREADS
-                    acc[mt][g / 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u & 1][mt], bq[(g & ~1) % RING], acc[mt][g / 3], 0, 0, 0);
-#else
-                    acc[mt][g / 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u & 1][mt], bq[g % RING], acc[mt][g / 3], 0, 0, 0);
-#endif
-                __builtin_amdgcn_sched_barrier(0);
-            }
+                    for (int mt = 0; mt < MTA; ++mt)
+                        acc[mt][g / 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u & 1][mt], bq[g % RING], acc[mt][g / 3], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
 #ifndef SNN_EXP_NO_BARRIER
-            // weight planes landed (vmcnt), spike words written (lgkmcnt), everyone done reading slot `sl`.
-            // The s_waitcnt builtin (not inline asm) so that hipcc's own wait-count bookkeeping knows the prefetched
-            // fragments have arrived; the empty asm statements are compiler fences (neither builtin orders memory
-            // accesses for hipcc, which otherwise moves LDS reads across the barrier).
-            asm volatile("" ::: "memory");
-            // NB = 4: this chunk's own copies (the youngest vector-memory operations of the wave: its spike-word copy if it
-            // has rows to stage + 3 weight pieces, or 2 / 1 on the 8 x 1 wave grid) may stay in flight across the barrier
-            if (NB == 3) __builtin_amdgcn_s_waitcnt(0x0070);        // vmcnt(0) lgkmcnt(0)
-            else if (WN == 2) { if (a_role) __builtin_amdgcn_s_waitcnt(0x0074); else __builtin_amdgcn_s_waitcnt(0x0073); }
-            else if (wave + 8 < NPIECE) { if (a_role) __builtin_amdgcn_s_waitcnt(0x0073); else __builtin_amdgcn_s_waitcnt(0x0072); }
-            else { if (a_role) __builtin_amdgcn_s_waitcnt(0x0072); else __builtin_amdgcn_s_waitcnt(0x0071); }
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
+                // weight planes landed (vmcnt), spike words written (lgkmcnt), everyone done reading slot `sl`.
+                // The s_waitcnt builtin (not inline asm) so that hipcc's own wait-count bookkeeping knows the prefetched
+                // fragments have arrived; the empty asm statements are compiler fences (neither builtin orders memory
+                // accesses for hipcc, which otherwise moves LDS reads across the barrier).
+                asm volatile("" ::: "memory");
+                // NB = 4: this chunk's own copies (the youngest vector-memory operations of the wave: its spike-word copy if it
+                // has rows to stage + 3 weight pieces, or 2 / 1 on the 8 x 1 wave grid) may stay in flight across the barrier
+                if (NB == 3) __builtin_amdgcn_s_waitcnt(0x0070);        // vmcnt(0) lgkmcnt(0)
+                else if (WN == 2) { if (a_role) __builtin_amdgcn_s_waitcnt(0x0074); else __builtin_amdgcn_s_waitcnt(0x0073); }
+                else if (wave + 8 < NPIECE) { if (a_role) __builtin_amdgcn_s_waitcnt(0x0073); else __builtin_amdgcn_s_waitcnt(0x0072); }
+                else { if (a_role) __builtin_amdgcn_s_waitcnt(0x0072); else __builtin_amdgcn_s_waitcnt(0x0071); }
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
 #endif
-            const bool step_done = ++kc == Kc;
-            if (step_done) kc = 0;
-            if (FUSE && step_done) {
-                lif_reg_step(t);
-                ++t;
+                const bool step_done = ++kc == Kc;
+                if (step_done) kc = 0;
+                if (FUSE && step_done) {
+                    lif_reg_step(t);
+                    ++t;
+                }
             }
         }
+    };
+    if constexpr (TILE && MT != 8) {
+        if (short_wave) chunk_loop(std::integral_constant<int, MT - 1>{});
+        else chunk_loop(std::integral_constant<int, MT>{});
+    } else {
+        chunk_loop(std::integral_constant<int, MT>{});
     }
     if (FUSE) {
         for (; t < args.T; ++t) lif_reg_step(t);
@@ -600,8 +581,10 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
         for (int h = 0; h < 2; ++h) {
             __syncthreads();                               // ring reads done / previous pass consumed
             if (WN == 1 || wn == h) {
+                const int lrow0 = wm * WROWS - 16 * max(0, wm - first_short);    // logical row of the wave's first row
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
+                for (int mt = 0; mt < MT; ++mt) {
+                    if (mt == MT - 1 && short_wave) continue;                   // (rows that do not exist)
 #pragma unroll
                     for (int nq = 0; nq < CG / 16; ++nq) {
 #pragma unroll
@@ -609,9 +592,10 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
                             float val;
                             if (WN == 1) val = h == 0 ? acc[mt][nq][r] : acc[mt][2 + nq][r];
                             else val = acc[mt][nq][r];
-                            tile[(wm * WROWS + mt * 16 + lg * 4 + r) * PITCH + nq * 16 + lr] = val;
+                            tile[(lrow0 + mt * 16 + lg * 4 + r) * PITCH + nq * 16 + lr] = val;
                         }
                     }
+                }
             }
             __syncthreads();
             const int word0 = (nb * BN + h * CG) >> 5;     // first output word of this pass
@@ -634,12 +618,7 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
                         my1 = lane == t ? (uint32_t)(b >> 32) : my1;
                         cnt += __popcll(two ? b : (b & 0xffffffffull));
                     }
-#ifndef SNN_EXP_NO_SPK_STORE                      // (timing only: the spike planes are not written)
-                    if (lane < T)
-#else
-                    if (lane < T && args.T > 1000)
-#endif
-                    {
+                    if (lane < T) {
                         if (!CONV && args.out_wm) {                    // word-major planes [T][word][row] (fc6 -> fc7)
                             uint32_t* dst = args.spk + (size_t)lane * args.spk_stride + (size_t)word0 * M + pos;
                             dst[0] = my0;

@@ -9,6 +9,15 @@
 #include "snn_common.h"
 #include "snn_hip.h"
 
+// Timing-only switches of the A/B harness (tools/ab_build.sh, tools/ab_mx.sh: what does a staging step / barrier cost) give
+// WRONG results by construction.  A build that defines one must say so with -DSNN_EXPERIMENTS; the product build
+// (snn_automotive_object_detection_amd/build.py) never does, and tests/test_code_object.py checks that this guard fires.
+#if !defined(SNN_EXPERIMENTS) && (defined(SNN_EXP_NO_FETCH) || defined(SNN_EXP_NO_GLDS) || defined(SNN_EXP_NO_BARRIER) || \
+    defined(SNN_EXP_CLOCK) || defined(SNN_EXP_MX_NOSTAGE) || defined(SNN_EXP_MX_NOREADB) || defined(SNN_EXP_MX_NOBAR) || \
+    defined(SNN_EXP_MX_NOA) || defined(SNN_EXP_MX_BAR2) || defined(SNN_EXP_MX_RDW_G))
+#error "SNN_EXP_* switches are timing experiments with wrong results: add -DSNN_EXPERIMENTS (never in a product build)"
+#endif
+
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -117,6 +126,7 @@ struct Knobs {
     bool enc_generic;        // SNN_ENC_GENERIC=1     op-for-op encoder kernels even for zero rest / reset potentials
     bool enc_rows_ballot;    // SNN_ENC_ROWS=ballot   element-per-lane row encoder
     int bf16x3_mt;           // SNN_BF16X3_MT=2|3|4   M-tiles per wave (0: cost model)
+    int bf16x3_short;        // SNN_BF16X3_SHORT=0|1  T-in-tile launches: no / half of the row-waves one M-tile short (-1 = by cost)
     int bf16x3_wn;           // SNN_BF16X3_WN=1|2     waves along N of the tile (0 = default: linear layers 1 = 512 x 64 tile, conv 2 = 256 x 128)
     bool bf16x3_lif_reg;     // SNN_BF16X3_LIF=reg    register-resident conv + LIF fusion instead of T-in-tile
     int mx_mw;               // SNN_MX_MW=4|8         rows per wave of k_gemm_mx
@@ -139,6 +149,8 @@ static Knobs load_knobs() {
     k.enc_generic = (e = getenv("SNN_ENC_GENERIC")) && e[0] == '1';
     k.enc_rows_ballot = (e = getenv("SNN_ENC_ROWS")) && !strcmp(e, "ballot");
     k.bf16x3_mt = (e = getenv("SNN_BF16X3_MT")) ? atoi(e) : 0;
+    e = getenv("SNN_BF16X3_SHORT");
+    k.bf16x3_short = (e && e[0] == '1') ? 1 : (e && e[0] == '0') ? 0 : -1;
     e = getenv("SNN_BF16X3_WN");
     k.bf16x3_wn = (e && e[0] == '2') ? 2 : (e && e[0] == '1') ? 1 : 0;
     k.bf16x3_lif_reg = (e = getenv("SNN_BF16X3_LIF")) && !strcmp(e, "reg");
@@ -220,6 +232,31 @@ static int g3_pick_mt(F tiles_of) {
         const double cost = (double)((wgs + g3_slots() - 1) / g3_slots()) * (mt + 0.5);
         if (best_cost == 0 || cost < best_cost * 0.97) { best = mt; best_cost = cost; }
     }
+    return best;
+}
+
+// T-in-tile launches: tile height = 16 * (mt - short / 2) rows per row-wave pair ... i.e. rows = row-waves * 16 * mt - 16 * n_short
+// with n_short = 0 or half the row-waves (every SIMD then hosts one full and one short wave).  `wgs_of(rows)` = work-groups
+// of the launch at that tile height (0: T does not fit).  Cost = rounds of work-groups per CU x (M-tiles per wave + per-chunk
+// staging overhead); ties go to the larger tile.  SNN_BF16X3_MT / SNN_BF16X3_SHORT=0|1 force a shape (A/B, tests).
+struct G3Tile { int mt, n_short, rows; };
+template <typename F>
+static G3Tile g3_pick_tile(int wn, F wgs_of) {
+    G3Tile best = {0, 0, 0};
+    double best_cost = 0;
+    const int force_mt = knobs().bf16x3_mt, force_short = knobs().bf16x3_short;     // -1: by cost
+    const int nwm = 8 / wn;
+    if (force_mt == 8 && knobs().bf16x3_wn == 2 && wgs_of(256) > 0) return G3Tile{8, 0, 256};
+    for (int mt = 4; mt >= 2; --mt)
+        for (int sh = 0; sh < 2; ++sh) {
+            if (force_mt >= 2 && force_mt <= 4 && force_mt != mt) continue;
+            if (force_short >= 0 && force_short != sh) continue;
+            const int n_short = sh ? nwm / 2 : 0, rows = nwm * 16 * mt - 16 * n_short;
+            const long long wgs = wgs_of(rows);
+            if (wgs <= 0) continue;
+            const double cost = (double)((wgs + g3_slots() - 1) / g3_slots()) * (mt - 0.5 * sh + 0.5);
+            if (best_cost == 0 || cost < best_cost * 0.97) { best = G3Tile{mt, n_short, rows}; best_cost = cost; }
+        }
     return best;
 }
 
@@ -426,6 +463,10 @@ int snn_pack_conv3x3_weight_mx(const float* w, int C_out, int C_in, uint32_t* pa
 
 // T-in-tile LIF fusion needs T <= 64 (one lane per time step keeps the spike words) and wastes rows % T rows per tile
 static bool g3_tile_ok(int T, int rows) { return T >= 1 && T <= 64 && T <= rows && T * (rows / T) * 10 >= rows * 9; }
+// some tile height of the bf16x3 family holds Tc time steps
+static bool g3_some_tile_ok(int Tc, bool conv = false) {
+    return g3_pick_tile(g3_wn(conv), [&](int rows) { return g3_tile_ok(Tc, rows) ? 1ll : 0ll; }).mt != 0;
+}
 
 static int launch_gemm3(int mode, int mt, int wn, const Gemm3Args& a, hipStream_t s) {
     // LIF_REG owns its CU (256 registers per wave); the others run two work-groups per CU
@@ -456,7 +497,8 @@ static int launch_gemm3(int mode, int mt, int wn, const Gemm3Args& a, hipStream_
     if (knobs().debug_occ) {                                   // debug: co-resident work-groups per CU
         int v = 0;
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, kern, threads, lds);
-        fprintf(stderr, "k_gemm_bf16x3 mode %d mt %d wn %d: lds %d B, %d work-groups per CU, grid %d\n", mode, mt, wn, lds, v, tiles * a.n_blocks);
+        fprintf(stderr, "k_gemm_bf16x3 mode %d mt %d wn %d short %d: pb %d x Tc %d rows, lds %d B, %d work-groups per CU, grid %d\n", mode, mt, wn,
+                a.n_short, a.pb, a.Tc, lds, v, tiles * a.n_blocks);
     }
     void* kargs[] = {(void*)&ax};
     e = hipLaunchKernel(kern, dim3(grid), dim3(threads), kargs, lds, s);
@@ -499,10 +541,10 @@ static int spike_gemm_lif_bf16x3_impl(const uint32_t* a_planes, int T, int R, in
     const StepWindow w = win ? *win : lif_window_full_out(T);                // time steps whose currents are formed
     a.t0 = w.t0; a.Tc = w.n;
     const int Tc = w.n;
-    const int mt = g3_pick_mt([&](int m) { return g3_tile_ok(Tc, g3_bm(wn, m)) ? (long long)cdiv(R, g3_bm(wn, m) / Tc) * a.n_blocks : 0ll; });
-    if (!mt) return fail(-4, "snn_spike_gemm_lif_bf16x3: T=%d does not fit a row tile (use snn_spike_gemm_bf16x3 + snn_lif_scan)", T);
-    a.pb = g3_bm(wn, mt) / Tc;
-    return launch_gemm3(G3_FC_LIF_TILE, mt, wn, a, (hipStream_t)s);
+    const G3Tile tl = g3_pick_tile(wn, [&](int rows) { return g3_tile_ok(Tc, rows) ? (long long)cdiv(R, rows / Tc) * a.n_blocks : 0ll; });
+    if (!tl.mt) return fail(-4, "snn_spike_gemm_lif_bf16x3: T=%d does not fit a row tile (use snn_spike_gemm_bf16x3 + snn_lif_scan)", T);
+    a.pb = tl.rows / Tc; a.n_short = tl.n_short;
+    return launch_gemm3(G3_FC_LIF_TILE, tl.mt, wn, a, (hipStream_t)s);
 }
 
 int snn_spike_gemm_lif_bf16x3(const uint32_t* a_planes, int T, int R, int K, int N, const snn_params* p,
@@ -693,21 +735,21 @@ static int conv3x3_lif_bf16x3_impl(const uint32_t* enc, size_t enc_stride, const
     const StepWindow w = lif_window_full_out(T);   // the LI heads read the shared LIF's spikes of every step: currents of steps 0 .. T-2
     a.t0 = w.t0; a.Tc = w.n;
     const int Tc = w.n;
-    int mt = 0;
+    G3Tile tl = {0, 0, 0};
     if (!knobs().bf16x3_lif_reg) {
         a.n_blocks = cdiv(a.Np, G3_BN(wn));
-        mt = g3_pick_mt([&](int m) { return g3_tile_ok(Tc, g3_bm(wn, m)) ? (long long)cdiv(P, g3_bm(wn, m) / Tc) * a.n_blocks : 0ll; });
+        tl = g3_pick_tile(wn, [&](int rows) { return g3_tile_ok(Tc, rows) ? (long long)cdiv(P, rows / Tc) * a.n_blocks : 0ll; });
     }
-    if (!mt) {                                     // register-fused fallback: counts from the planes afterwards
+    if (!tl.mt) {                                     // register-fused fallback: counts from the planes afterwards
         a.n_blocks = cdiv(a.Np, G3_BN(2));
         rc = launch_gemm3(G3_CONV_LIF_REG, 4, 2, a, (hipStream_t)s);
         if (rc || !counts) return rc;
         return count_spikes_per_image(lv, n_levels, cdiv(C_out, 32), T, spk, spk_stride, counts, max_n, (hipStream_t)s);
     }
-    a.pb = g3_bm(wn, mt) / Tc;
+    a.pb = tl.rows / Tc; a.n_short = tl.n_short;
     a.cnt_img = counts; a.max_n = max_n;
     if (want_split && a.Np % 128 == 0) { a.out_split = 1; *out_split = true; }
-    return launch_gemm3(G3_CONV_LIF_TILE, mt, wn, a, (hipStream_t)s);
+    return launch_gemm3(G3_CONV_LIF_TILE, tl.mt, wn, a, (hipStream_t)s);
 }
 
 int snn_conv3x3_lif_bf16x3(const uint32_t* enc, size_t enc_stride, const snn_rpn_level* lv, int n_levels, int C_in,
@@ -1112,7 +1154,7 @@ int snn_rpn_head_forward_stages(const snn_rpn_level* lv, int n_levels, int C, in
     // not fit a row tile runs the register-fused conv, which writes plain rows: then the heads read plain rows
     bool split = p->precision == SNN_PRECISION_BF16X3 && !knobs().spk_rows && li_heads_reads_split(C, A, 4 * A) &&
                  !knobs().bf16x3_lif_reg && cdiv(C, 32) * 32 % 128 == 0 &&
-                 (g3_tile_ok(Tc, G3_BM(g3_wn(true), 4)) || g3_tile_ok(Tc, G3_BM(g3_wn(true), 3)) || g3_tile_ok(Tc, G3_BM(g3_wn(true), 2)));
+                 g3_some_tile_ok(Tc, true);
     // bf16x3, SNN_PLANES=wm: encoder planes word-major [T][Cw][Pe] - a conv tile's spike words of a chunk are then 128-byte
     // runs.  Not the default for the convolution: -0.7 % of kernel time, but a 128-byte line of a word plane is shared by
     // horizontally adjacent tiles (on different XCDs), FETCH_SIZE 84 -> 177 MB per launch
@@ -1449,7 +1491,6 @@ size_t snn_det_head_workspace_bytes(int R, int D, int Hd, int K, int K4, int T, 
 }
 
 // the detector's bf16x3 path with both linear layers fused with their LIF (one row tile holds all T steps)
-static bool g3_some_tile_ok(int Tc) { return g3_tile_ok(Tc, G3_BM(g3_wn(), 4)) || g3_tile_ok(Tc, G3_BM(g3_wn(), 3)) || g3_tile_ok(Tc, G3_BM(g3_wn(), 2)); }
 static bool det_b3_tiles(const snn_params* p, const DetWindows& w) {
     return p->precision == SNN_PRECISION_BF16X3 && g3_some_tile_ok(w.fc6.n) && g3_some_tile_ok(w.fc7.n);
 }

@@ -253,7 +253,7 @@ __global__ __launch_bounds__(2048 / MW, 16 / MW) void k_gemm_mx(const MxArgs ma)
 #pragma unroll
         for (int i = 0; i < RPT; ++i) {
             const uint32_t dst = __builtin_amdgcn_readfirstlane(smem_base + MX_LUT_BYTES + par * MX_AW_BYTES + (wave * WROWS + i * 64) * 16);
-            asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(f_voff[i]), "s"(f_ptr), "s"(dst) : "memory", "m0");
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(f_voff[i]), "s"(f_ptr), "s"(dst) : "memory");
         }
         // (the stream position is wave-uniform: say so, or the counters live in vector registers)
         f_ptr = sgpr_u32(f_ptr + 4);
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(2048 / MW, 16 / MW) void k_gemm_mx(const MxArgs ma)
             uint32_t l;                             // lane id, re-derived instead of a register held all loop
             asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
             const uint32_t sc_voff = min(l, (uint32_t)(Np - nb * MX_BN - 1)) * 4u;
-            asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dword %0, %1" :: "v"(sc_voff), "s"(sgpr_ptr(Sg + (size_t)sc_kc * Np)), "s"(sdst) : "memory", "m0");
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dword %0, %1" :: "v"(sc_voff), "s"(sgpr_ptr(Sg + (size_t)sc_kc * Np)), "s"(sdst) : "memory");
         }
         sc_kc = __builtin_amdgcn_readfirstlane(sc_kc + 1);
         if (sc_kc == Kc) sc_kc = 0;

@@ -1,0 +1,95 @@
+"""Checks on the built gfx950 code object (no GPU needed: hipcc cross-compiles, llvm-objdump disassembles).
+
+* M0 hygiene of the LDS-DMA inline asm (csrc/snn_bf16x3.h, snn_mx.h): the asm statements write M0 themselves and LLVM is not
+  told (M0 is reserved; a clobber entry is ignored).  That is sound as long as the COMPILER never keeps a value of its own in
+  M0 across them - asserted here on the disassembly: the only instructions that touch M0 are the asm's own `s_mov_b32 m0, sN`,
+  each one feeding the `global_load_lds_*` of the same statement, and nothing else in the library reads M0 implicitly.
+* the product build carries no timing-only experiment switch, and a build that defines one without -DSNN_EXPERIMENTS fails.
+* the two big kernels keep their register budget (no scratch, <= 128 VGPRs: two work-groups of 8 waves per CU)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+from snn_automotive_object_detection_amd import build as B
+
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+M0_READERS = ("movrel", "s_sendmsg", "ds_gws", "v_interp", "s_ttrace", "ds_ordered_count", "buffer_load", "lds_direct")   # (buffer_load only in its "... lds" form)
+
+
+@pytest.fixture(scope="module")
+def disassembly(tmp_path_factory):
+    if not os.path.exists(OBJDUMP):
+        pytest.skip("no llvm-objdump")
+    lib = B.build(force=False)
+    d = tmp_path_factory.mktemp("codeobj")
+    subprocess.run(["cp", lib, str(d / "lib.so")], check=True)
+    subprocess.run([OBJDUMP, "--offloading", "lib.so"], cwd=str(d), check=True, stdout=subprocess.DEVNULL)
+    objs = [f for f in os.listdir(str(d)) if "gfx950" in f]
+    assert len(objs) == 1, os.listdir(str(d))
+    out = subprocess.run([OBJDUMP, "-d", objs[0]], cwd=str(d), check=True, stdout=subprocess.PIPE, text=True).stdout
+    funcs, cur = {}, None
+    for line in out.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
+        if m:
+            cur = m.group(1)
+            funcs[cur] = []
+        elif cur is not None and line.strip() and not line.startswith("Disassembly"):
+            ins = line.split("//")[0].strip()
+            if ins:
+                funcs[cur].append(ins)
+    return funcs
+
+
+def test_only_the_asm_blocks_touch_m0(disassembly):
+    n_mov = n_dma = 0
+    for name, ins in disassembly.items():
+        for i, x in enumerate(ins):
+            op = x.split()[0]
+            for r in M0_READERS:                      # instructions that read M0 implicitly
+                assert r not in op or (r == "buffer_load" and " lds" not in x), "implicit M0 reader %r in %s" % (x, name)
+            if re.search(r"\bm0\b", x):
+                # the only M0 writers / readers spelled out: s_mov_b32 m0, <sgpr>
+                assert re.match(r"^s_mov_b32 m0, s\d+$", x), "unexpected M0 use %r in %s" % (x, name)
+                n_mov += 1
+                # ... followed, after s_nop wait states only, by the LDS-DMA it feeds
+                j = i + 1
+                while ins[j].startswith("s_nop"):
+                    j += 1
+                assert ins[j].startswith("global_load_lds_dword"), "M0 write not followed by its LDS-DMA in %s: %r" % (name, ins[i:j + 1])
+            if op.startswith("global_load_lds"):
+                n_dma += 1
+                j = i - 1
+                while ins[j].startswith("s_nop"):
+                    j -= 1
+                assert re.match(r"^s_mov_b32 m0, s\d+$", ins[j]), "LDS-DMA without its own M0 write in %s: %r" % (name, ins[j:i + 1])
+    assert n_mov == n_dma and n_dma > 100, (n_mov, n_dma)
+
+
+def test_product_build_has_no_experiment_switch_and_the_guard_fires(tmp_path):
+    assert not any("SNN_EXP" in f for f in B.FLAGS)
+    src = os.path.join(B.CSRC, "snn_kernels.hip")
+    cmd = [B.HIPCC, "--offload-arch=gfx950", "-std=c++17", "-fsyntax-only", "--cuda-host-only", "-I" + os.path.join(B.ROOT, "include"), "-I" + B.CSRC]
+    r = subprocess.run(cmd + ["-DSNN_EXP_NO_GLDS", src], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode != 0 and "SNN_EXPERIMENTS" in r.stdout, r.stdout[-500:]
+
+
+def test_build_is_warning_free_and_the_big_kernels_keep_their_registers(tmp_path):
+    """compiles the device side once more with resource remarks (about 25 s)"""
+    out = str(tmp_path / "x.so")
+    cmd = [B.HIPCC] + B.FLAGS + ["-Rpass-analysis=kernel-resource-usage", "-o", out, os.path.join(B.CSRC, "snn_kernels.hip")]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert "warning:" not in r.stdout, [l for l in r.stdout.splitlines() if "warning:" in l][:5]
+    blocks = re.split(r"remark: [^\n]*Function Name: ", r.stdout)[1:]
+    seen = 0
+    for b in blocks:
+        name = b.split()[0]
+        vg = int(re.search(r"VGPRs: (\d+)", b).group(1))
+        sc = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1))
+        # T-in-tile product kernels: k_gemm_bf16x3<G3_CONV_LIF_TILE = 3 | G3_FC_LIF_TILE = 4, NB, MT <= 4, WN> and k_gemm_mx<.., 4>
+        if re.match(r"_Z13k_gemm_bf16x3ILi[34]ELi[34]ELi[234]E", name) or re.match(r"_Z9k_gemm_mxILi[34]ELi4E", name):
+            seen += 1
+            assert sc == 0 and vg <= 128, (name, vg, sc)
+    assert seen >= 14, seen

@@ -5,6 +5,7 @@
 R=$PWD; mkdir -p tools/_ab
 for spec in "$@"; do
   name=${spec%%:*}; flags=${spec#*:}
+  case "$flags" in *SNN_EXP_*) flags="-DSNN_EXPERIMENTS $flags";; esac      # timing-only switches: wrong results by construction
   ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -w -I$R/include -I$R/snn_automotive_object_detection_amd/csrc $flags \
       -o tools/_ab/lib_$name.so $R/snn_automotive_object_detection_amd/csrc/snn_kernels.hip && echo "built $name [$flags]" ) &
 done

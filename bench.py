@@ -26,6 +26,10 @@ rank 0 at N=1 only) + "extra" (outside the headline timing, N=1 only): a sustain
 end-to-end model (BASELINE config[2]), the BDD per-rank share (config[3]) and the T=16/24 spike-rate stress workload
 (config[4]), each with the launch time and roofline fraction of its own conv+LIF kernel.
 
+N > 1 also runs BASELINE.json's config[3] for real as the `dp_e2e` leg: every rank builds create_model("bdd", 11), takes its
+contiguous shard of 4 x N seeded rand(3,720,1280) images (4 per GPU; train.py:598-601), runs the WHOLE model and the ranks
+all-gather the decoded detections (dp.all_gather_detections: the RCCL counterpart of coco_eval.py:158-177).
+
 --precision bf16x3 (default): both big contractions run on the bf16 matrix cores with an EXACT 3-way bf16
   split of the fp32 weights (spikes are exactly {0,1}; fp32 accumulation; as accurate as the fp32 MFMA chain,
   tools/bf16x3_numerics.hip) - the results are fp32 results, the executed MFMA work is 3x the algorithmic FLOPs.
@@ -72,8 +76,12 @@ def algorithmic_flops(wl):
     return conv, rpn, det
 
 
+def dead_steps_kept():
+    return os.environ.get("SNN_DEAD_STEPS") == "keep"
+
+
 def kernel_of(precision):
-    """(kernel name, matrix-pipe peak TFLOP/s, executed MFMA work / algorithmic FLOPs)"""
+    """(kernel name, matrix-pipe peak TFLOP/s, MFMA work executed per computed time step / algorithmic FLOPs of a step)"""
     if precision == "f32":
         return "k_conv3x3_lif<false>", PEAK_F32_MFMA_TFLOPS, 1.0
     if precision == "mxfp6":
@@ -98,24 +106,20 @@ def cpu_model_name():
     return platform.processor() or "unknown"
 
 
-def cpu_baseline(repeats=3):
-    """the oracle (CPU restatement of the reference loops, un-fused torch ops) on the headline batch: both images
-    (b=2 pyramid, T=8) + the detector head on their 2000 RoIs (T=12); 1 warm-up (levels 1..4 + 256 RoIs: pages the
-    thread pool and allocator in without doubling the cost) + `repeats` timed passes, median reported"""
+def cpu_baseline(leg, repeats=3):
+    """the oracle (CPU restatement of the reference loops, un-fused torch ops) on the SAME tensors as the GPU leg - the leg's
+    backbone-fed pyramid and RoI features and the modules' own weights, copied to the host once: both images (b=2 pyramid, T_rpn)
+    + the detector head on their 2000 RoIs (T_det); 1 warm-up (levels 1..4 + 256 RoIs: pages the thread pool and allocator in
+    without doubling the cost) + `repeats` timed passes, median reported"""
     import torch
     from oracle import snn_oracle as OR
-    wl = WORKLOADS["cityscapes"]
-    g = torch.Generator().manual_seed(0)
-    feats = [torch.randn((wl["batch"], C, h, w), generator=g) for h, w in wl["levels"]]
-    rois = torch.randn((wl["batch"] * ROIS_PER_IMG, C, 7, 7), generator=g)
-    w_s = torch.randn((C, C, 3, 3), generator=g) * 0.01
-    w_c = torch.randn((A, C, 1, 1), generator=g) * 0.01
-    w_b = torch.randn((4 * A, C, 1, 1), generator=g) * 0.01
-    K = wl["K"]
-    w6 = (torch.rand((HD, C * 49), generator=g) * 2 - 1) / (C * 49) ** 0.5
-    w7 = (torch.rand((HD, HD), generator=g) * 2 - 1) / HD ** 0.5
-    wc = (torch.rand((K, HD), generator=g) * 2 - 1) / HD ** 0.5
-    wb = (torch.rand((4 * K, HD), generator=g) * 2 - 1) / HD ** 0.5
+    wl = leg.wl
+    feats = [f.detach().cpu() for f in leg.feats]
+    rois = leg.rois.detach().cpu()
+    r, d = leg.rpn_head, leg.det_head
+    w_s, w_c, w_b = r.shared_conv.weight.detach().cpu(), r.conv_cls.weight.detach().cpu(), r.conv_bbox.weight.detach().cpu()
+    w6, w7 = d.fc6.weight.detach().cpu(), d.fc7.weight.detach().cpu()
+    wc, wb = d.cls_score.weight.detach().cpu(), d.bbox_pred.weight.detach().cpu()
     threads = torch.get_num_threads()
     times = []
     with torch.no_grad():
@@ -129,8 +133,10 @@ def cpu_baseline(repeats=3):
     med = statistics.median(times)
     return {"value": round(wl["batch"] / med, 4), "unit": "images/s", "cores": threads, "kind": "port",
             "cpu": cpu_model_name(), "repeats": repeats, "seconds": [round(t, 2) for t in times],
-            "sample": "b=2: oracle RPN head (5-level pyramid, T=8) + detector head (2000 RoIs, T=12); 1 warm-up + %d repeats, "
-                      "median %.1f s per batch" % (repeats, med)}
+            "inputs": "identical to the GPU leg (copied to the host)",
+            "sample": "b=%d: oracle RPN head (5-level pyramid, T=%d) + detector head (%d RoIs, T=%d) on the GPU leg's own inputs and "
+                      "weights; 1 warm-up + %d repeats, median %.1f s per batch" % (
+                          wl["batch"], wl["T_rpn"], rois.shape[0], wl["T_det"], repeats, med)}
 
 
 # ---------------------------------------------------------------------------------------------
@@ -200,6 +206,16 @@ class Leg:
         payload, counts = ops.det_exchange_payload(cls, deltas, self.wl["batch"], 100)   # top-100 RoIs per image, one launch
         return dp.all_gather_detection_tensors(payload, counts)  # no-op at world == 1
 
+    def step_local(self):
+        """the same step without the collective (side legs that only rank 0 runs)"""
+        from snn_automotive_object_detection_amd import ops
+        rpn_out = self.rpn_head(self.feats)
+        det_out = self.det_head(self.rois)
+        if self.wl["spike_rates"]:
+            return rpn_out, det_out
+        cls, deltas = det_out
+        return ops.det_exchange_payload(cls, deltas, self.wl["batch"], 100)
+
     def exchange_only(self):
         """(payload, counts) of one step, for timing the exchange by itself"""
         from snn_automotive_object_detection_amd import ops
@@ -232,18 +248,21 @@ class Leg:
         det_ms = self.time_ms(lambda: self.det_head(self.rois), iters)
         return {"rpn_head": rpn_ms, "rpn_encode": enc_ms, "rpn_conv3x3_lif": conv_ms, "det_head": det_ms}
 
-    def roofline(self, conv_ms, traffic=None):
+    def roofline(self, conv_ms, traffic=None, traffic_source=None):
         conv_fl, _, _ = algorithmic_flops(self.wl)
-        kernel, peak, exec_factor = kernel_of(self.precision)
-        achieved = conv_fl / (conv_ms * 1e-3) / 1e12            # ALGORITHMIC (dense-equivalent) TFLOP/s
-        # achieved = ALGORITHMIC FLOPs of the launch / its duration.  For bf16x3 the peak is what the bf16 matrix pipe
-        # can deliver of this arithmetic: the dense bf16 MFMA peak / 3 MFMAs per exact fp32 product (the executed
-        # rate against the full 2.5 PF is the same fraction; both are spelled out).
+        kernel, peak, per_step = kernel_of(self.precision)
+        T = self.wl["T_rpn"]
+        # dead time steps: the conv of the last step cannot reach an output and is not executed, so the launch
+        # does (T-1)/T of the dense work SURVEY 8(d) counts.  `achieved` stays the ALGORITHMIC (dense-equivalent) rate =
+        # SURVEY's FLOPs of the launch / its duration; `frac` prices the EXECUTED MFMA work against the matrix-pipe peak.
+        exec_factor = per_step * (1.0 if (dead_steps_kept() or T < 2) else (T - 1) / T)
+        achieved = conv_fl / (conv_ms * 1e-3) / 1e12
         return {"bound": "mfma", "kernel": kernel, "achieved": round(achieved, 2), "peak": round(peak / exec_factor, 1),
-                "unit": "TFLOP/s", "frac": round(achieved * exec_factor / peak, 4), "traffic": traffic,
+                "unit": "TFLOP/s", "frac": round(achieved * exec_factor / peak, 4), "traffic": traffic, "traffic_source": traffic_source,
                 "launch_ms": round(conv_ms, 4), "algorithmic_gflop_per_launch": round(conv_fl / 1e9, 1),
-                "executed_over_algorithmic": exec_factor, "executed_tflops": round(achieved * exec_factor, 2),
-                "mfma_peak_tflops": peak, "algorithmic_frac_of_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4)}
+                "executed_over_algorithmic": round(exec_factor, 4), "executed_tflops": round(achieved * exec_factor, 2),
+                "mfma_peak_tflops": peak, "time_steps_executed": (T if (dead_steps_kept() or T < 2) else T - 1), "time_steps": T,
+                "algorithmic_frac_of_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4)}
 
     def spike_stats(self):
         """measured firing rates of this workload's inputs: encoder planes (popcount) and shared-LIF (the head's counts)"""
@@ -325,6 +344,108 @@ def e2e_leg(model, dev, iters=5):
             "detections": [int(d["boxes"].shape[0]) for d in out], "proposals": [int(p.shape[0]) for p in props]}
 
 
+DP_IMAGES_PER_RANK = 4                                           # BASELINE.json config[3]: b = 32 on 8 GPUs
+
+
+def dp_images(indices, dev):
+    """global image i of the config[3] batch = rand(3,720,1280) from its own seed: the same image whatever the rank count"""
+    import torch
+    out = []
+    for i in indices:
+        g = torch.Generator(device="cpu").manual_seed(9000 + int(i))
+        out.append(torch.rand((3, 720, 1280), generator=g).to(dev))
+    return out
+
+
+def dp_e2e_leg(model, dev, rank, world, fence, iters=3):
+    """BASELINE.json config[3], one rank's share: create_model("bdd", 11) on this rank's contiguous block of the 4 x world
+    images (DistributedSampler(shuffle=False), train.py:598-601; the inference loop train.py:285-297) followed by the path's one
+    exchange: all-gather of the DECODED per-image detections (dp.all_gather_detections; the reference's counterpart is
+    coco_eval.py:158-177).  images/s = all ranks' images / max-over-ranks time, exchange included."""
+    import torch
+    import torch.distributed as dist
+    from snn_automotive_object_detection_amd import dp
+    n_global = DP_IMAGES_PER_RANK * world
+    mine = dp.shard_range(n_global, rank, world)
+    imgs = dp_images(mine, dev)
+
+    def one():
+        dets = model(imgs)
+        return dets, dp.all_gather_detections(dets, max_det=1100, device=dev)
+    for _ in range(2):
+        dets, gathered = one()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        dets, gathered = one()
+    fence()
+    dt = time.perf_counter() - t0
+    xs = []
+    for _ in range(5):                                           # the exchange by itself (pack + collective + unpack)
+        fence()
+        t1 = time.perf_counter()
+        gathered = dp.all_gather_detections(dets, max_det=1100, device=dev)
+        torch.cuda.synchronize()
+        xs.append((time.perf_counter() - t1) * 1e3)
+    if world > 1:
+        t = torch.tensor([dt, statistics.median(xs)], dtype=torch.float64, device=dev if dp.backend_name() != "gloo" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt, x_ms = float(t[0]), float(t[1])
+    else:
+        x_ms = statistics.median(xs)
+    assert len(gathered) == n_global, (len(gathered), n_global)
+    n_det = [int(d["boxes"].shape[0]) for d in gathered]
+    return {"workload": "bdd_720x1280 create_model('bdd', 11, T_rpn=8, T_det=12), %d images per rank, detections all-gathered" % DP_IMAGES_PER_RANK,
+            "value": round(n_global * iters / dt, 3), "unit": "images/s", "ms_per_batch": round(dt / iters * 1e3, 3),
+            "global_batch": n_global, "images_per_rank": len(imgs), "exchange_ms": round(x_ms, 4),
+            "backend": dp.backend_name(), "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+            "rows_gathered": len(gathered), "detections_per_image_min_max": [min(n_det), max(n_det)],
+            "payload_bytes_per_image": 1101 * 6 * 4}
+
+
+def sweep_t_leg(leg, iters=8):
+    """throughput vs T over the paper's grid (metrics_for_different_timesteps.py:30-33,360-361: T_rpn 4..12, T_det 8..16): the two
+    heads are independent, so 9 + 9 timings.  `steps` = time steps whose contractions are executed (dead ones removed),
+    `ms_per_step` relative to the headline T (8 / 12), tile shape and fill as the launcher picks them (snn_debug_tile_shape)."""
+    import ctypes as Ct
+    from snn_automotive_object_detection_amd import _lib
+    lib = _lib.load()
+    out32 = (Ct.c_int32 * 8)()
+    pos = sum(int(f.shape[0] * f.shape[2] * f.shape[3]) for f in leg.feats)
+    R = int(leg.rois.shape[0])
+    t_rpn0, t_det0 = leg.rpn_head.num_steps, leg.det_head.num_steps
+    res = {"rpn": {}, "det": {}}
+    try:
+        for T in range(4, 13):
+            leg.rpn_head.num_steps = T
+            leg.rpn_head(leg.feats)
+            ms = leg.time_ms(lambda: leg.rpn_head(leg.feats), iters)
+            _lib.check(lib.snn_debug_tile_shape(1, pos, C, T, 0, 0, out32), "snn_debug_tile_shape")
+            res["rpn"][T] = {"ms": round(ms, 4), "steps": out32[4], "tile_rows": out32[2], "per_tile": out32[3],
+                             "fill": round(out32[3] * out32[4] / out32[2], 4), "work_groups": out32[5]}
+        for T in range(8, 17):
+            leg.det_head.num_steps = T
+            leg.det_head(leg.rois)
+            ms = leg.time_ms(lambda: leg.det_head(leg.rois), iters)
+            _lib.check(lib.snn_debug_tile_shape(0, R, HD, T, 0, 6, out32), "snn_debug_tile_shape")
+            res["det"][T] = {"ms": round(ms, 4), "steps": out32[4], "tile_rows": out32[2], "per_tile": out32[3],
+                             "fill": round(out32[3] * out32[4] / out32[2], 4), "work_groups": out32[5],
+                             "rounds_per_cu_pair": round(out32[5] / 512.0, 3)}
+    finally:
+        leg.rpn_head.num_steps, leg.det_head.num_steps = t_rpn0, t_det0
+    for head, t_ref in (("rpn", 8), ("det", 12)):
+        ref = res[head][t_ref]["ms"] / res[head][t_ref]["steps"]
+        for T, r in res[head].items():
+            r["ms_per_step_rel"] = round(r["ms"] / r["steps"] / ref, 4)
+    worst = max(r["ms_per_step_rel"] for h in res.values() for r in h.values())
+    res["worst_ms_per_step_rel"] = worst
+    res["images_per_s_grid"] = {"T_rpn x T_det": "b=%d: images/s = b / (rpn ms + det ms)" % leg.wl["batch"],
+                                "min": round(leg.wl["batch"] / ((res["rpn"][12]["ms"] + res["det"][16]["ms"]) * 1e-3), 1),
+                                "headline_T8_T12": round(leg.wl["batch"] / ((res["rpn"][8]["ms"] + res["det"][12]["ms"]) * 1e-3), 1),
+                                "max": round(leg.wl["batch"] / ((res["rpn"][4]["ms"] + res["det"][8]["ms"]) * 1e-3), 1)}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -344,14 +465,15 @@ def main():
     ap.add_argument("--detector-snn", action="store_true", help="accepted for CLI compatibility (always on)")
     ap.add_argument("--cpu-repeats", type=int, default=3)
     ap.add_argument("--sustain-s", type=float, default=2.0)
+    ap.add_argument("--sweep-t", action="store_true", help="only the throughput-vs-T grid (T_rpn 4..12, T_det 8..16) besides the headline")
+    ap.add_argument("--no-dp-e2e", action="store_true", help="skip the whole-model data-parallel leg (config[3])")
     args = ap.parse_args()
 
     # ---- stand-alone multi-rank launch: start the ranks BEFORE anything initialises the GPU in this process ----
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        import torch                                             # device_count() does not initialise the GPU
-        from snn_automotive_object_detection_amd import dp
-        n_dev = torch.cuda.device_count()
-        if n_dev < args.gpus and "SNN_DP_DEVICE" not in os.environ:
+        from snn_automotive_object_detection_amd import dp       # (imports torch, opens neither HIP nor torch.cuda)
+        n_dev = dp.count_gpus_without_hip()                      # asked in a short-lived child; None: unknown, trust --gpus
+        if n_dev is not None and n_dev < args.gpus and "SNN_DP_DEVICE" not in os.environ:
             raise SystemExit("--gpus %d but only %d device(s) visible (a test run of the N-rank path on fewer devices: "
                              "SNN_DIST_BACKEND=gloo SNN_DP_DEVICE=0)" % (args.gpus, n_dev))
         sys.exit(dp.launch_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
@@ -393,6 +515,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def fence_local():                                           # legs that run on one rank only
+        torch.cuda.synchronize()
+
     dt = timed_steps(leg, args.steps, args.warmup, fence)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev if dp.backend_name() != "gloo" else "cpu")
@@ -420,14 +545,18 @@ def main():
     iters = max(3, min(args.steps, 10))
     bd = leg.kernel_breakdown(iters)
     conv_fl, rpn_fl, det_fl = algorithmic_flops(wl)
-    traffic = None                    # HBM bytes per launch of the dominant kernel, from the committed PMC passes
-    for name in ("r2_traffic.json", "r1_traffic.json"):
-        try:
-            with open(os.path.join(ROOT, "profiles", name)) as f:
-                traffic = json.load(f)[args.precision]["hbm_bytes_per_launch"]
-            break
-        except Exception:
-            pass
+    # HBM bytes per launch of the dominant kernel: NOT measured by this run (PMC counters need rocprofv3 around the process) but
+    # read from the committed PMC passes of the same launch (separate --pmc FETCH_SIZE / WRITE_SIZE runs, tools/prof_round.sh)
+    traffic = traffic_source = None
+    if args.workload == "cityscapes" and not args.t_rpn and not dead_steps_kept():
+        for name in ("r3_traffic.json",):
+            try:
+                with open(os.path.join(ROOT, "profiles", name)) as f:
+                    traffic = json.load(f)[args.precision]["hbm_bytes_per_launch"]
+                traffic_source = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this launch, committed; not collected by this run)" % name
+                break
+            except Exception:
+                pass
 
     out = {
         "metric": "images/sec (T_rpn=%d,T_det=%d, %dx%d b=%d) spiking RPN+RoI heads forward" % (
@@ -445,7 +574,7 @@ def main():
                    "global_batch": wl["batch"] * world, "parallelism": "dp%d" % world,
                    "exchange": ("all-gather of per-image detections [100x6] (%s, %d ranks)" % (
                        "RCCL" if exchange["backend"] == "nccl" else exchange["backend"], exchange["ranks"])) if world > 1 else "none"},
-        "roofline": leg.roofline(bd["rpn_conv3x3_lif"], traffic),
+        "roofline": leg.roofline(bd["rpn_conv3x3_lif"], traffic, traffic_source),
         "breakdown_ms": {k: round(v, 3) for k, v in bd.items()},
         "heads_tflops": round((rpn_fl + det_fl) / ((bd["rpn_head"] + bd["det_head"]) * 1e-3) / 1e12, 2),
         "exchange": exchange,
@@ -453,43 +582,58 @@ def main():
     if "SNN_DP_DEVICE" in os.environ and world > 1:
         out["config"]["oversubscribed"] = "%d ranks on device %s (test of the N-rank path, not a scaling measurement)" % (world, os.environ["SNN_DP_DEVICE"])
 
-    if world == 1 and rank == 0 and not args.no_extra:
-        extra = {}
-        def side_leg(name, fn):                       # a failing side leg is reported in place; the headline line still prints
-            try:
-                extra[name] = fn()
-            except Exception as e:
-                extra[name] = {"error": repr(e)[:500]}
-                print("bench.py: side leg %r failed: %r" % (name, e), file=sys.stderr)
-        if not wl["spike_rates"]:
-            side_leg("input_spike_rates", leg.spike_stats)
-        # the same step held for >= sustain_s seconds: the clock the chip sustains, not a burst
-        n, t_acc = 0, 0.0
-        chunk = max(25, args.steps)
-        while t_acc < args.sustain_s:
-            t_acc += timed_steps(leg, chunk, 0, fence)
-            n += chunk
-        extra["sustained"] = {"value": round(wl["batch"] * n / t_acc, 3), "unit": "images/s", "steps": n,
-                              "seconds": round(t_acc, 3), "ms_per_step": round(t_acc / n * 1e3, 4)}
-        if not args.no_alt:
+    extra = {}
+
+    def side_leg(name, fn):                           # a failing side leg is reported in place; the headline line still prints
+        try:
+            extra[name] = fn()
+        except Exception as e:
+            extra[name] = {"error": repr(e)[:500]}
+            print("bench.py: side leg %r failed on rank %d: %r" % (name, rank, e), file=sys.stderr)
+
+    run_extra = not args.no_extra and not args.sweep_t
+    # ---- config[3] for real, every rank takes part: whole model on this rank's image shard + all-gather of the detections
+    if run_extra and not args.no_dp_e2e and not wl["spike_rates"]:
+        side_leg("dp_e2e", lambda: dp_e2e_leg(model_for("bdd", 11), dev, rank, world, fence))   # (same seed: same weights on every rank)
+    if args.sweep_t and rank == 0 and not wl["spike_rates"]:
+        side_leg("t_sweep", lambda: sweep_t_leg(leg))
+    # ---- the other BASELINE.json configurations, outside the headline timing (rank 0; at N > 1 the other ranks wait at the
+    # final barrier meanwhile)
+    if run_extra and rank == 0:
+        if world == 1:
+            if not wl["spike_rates"]:
+                side_leg("input_spike_rates", leg.spike_stats)
+            # the same step held for >= sustain_s seconds: the clock the chip sustains, not a burst
+            n, t_acc = 0, 0.0
+            chunk = max(25, args.steps)
+            while t_acc < args.sustain_s:
+                t_acc += timed_steps(leg, chunk, 0, fence_local)
+                n += chunk
+            extra["sustained"] = {"value": round(wl["batch"] * n / t_acc, 3), "unit": "images/s", "steps": n,
+                                  "seconds": round(t_acc, 3), "ms_per_step": round(t_acc / n * 1e3, 4)}
+            if not wl["spike_rates"]:
+                side_leg("t_sweep", lambda: sweep_t_leg(leg))
+        if world == 1 and not args.no_alt:
             # the same K steps with the other matrix path of the two big contractions: "mxfp6" = fp4 x fp6 block-scaled MFMA
             # on 6 digit planes per weight (passes the same parity tests; weights are rounded at 2^-28 of their block maximum,
-            # so it is NOT the headline; DESIGN.md §4.2)
+            # so it is NOT the headline; DESIGN.md 4.2)
             alt_prec = "bf16x3" if args.precision == "mxfp6" else "mxfp6"
 
             def alt_leg():
                 leg.set_precision(alt_prec)
                 try:
-                    dt_alt = timed_steps(leg, args.steps, max(1, args.warmup), fence)
+                    dt_alt = timed_steps(leg, args.steps, max(1, args.warmup), fence_local)
                 finally:
                     leg.set_precision(args.precision)
                 return {"precision": alt_prec, "value": round(wl["batch"] * args.steps / dt_alt, 3), "unit": "images/s",
                         "ms_per_step": round(dt_alt / args.steps * 1e3, 4)}
             side_leg("alt_precision", alt_leg)
+
         def workload_leg(name):
             w2 = WORKLOADS[name]
             l2 = make_leg(w2, args.precision)
-            dt2 = timed_steps(l2, args.steps, max(1, args.warmup), fence)
+            l2.step = l2.step_local                              # (no collective: the other ranks are not in this leg)
+            dt2 = timed_steps(l2, args.steps, max(1, args.warmup), fence_local)
             bd2 = l2.kernel_breakdown(iters)
             return {"workload": "%s (T_rpn=%d, T_det=%d, b=%d, K=%d%s)" % (w2["name"], w2["T_rpn"], w2["T_det"], w2["batch"], w2["K"],
                                                                     ", spike-rate outputs on" if w2["spike_rates"] else ""),
@@ -500,13 +644,37 @@ def main():
         for name in ("bdd", "stress"):
             if name != args.workload:
                 side_leg(name, lambda: workload_leg(name))
-        if args.workload == "cityscapes":
+        if world == 1 and args.workload == "cityscapes":
             side_leg("e2e", lambda: e2e_leg(model_for("cityscapes", 9), dev))
+    if extra:
         out["extra"] = extra
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.cpu_repeats)
+        out["cpu_baseline"] = cpu_baseline(leg, args.cpu_repeats)
     elif rank == 0:
         out["cpu_baseline"] = None
+    # ---- the side legs' headline numbers once more at the top level and (compact) inside `config`, which the driver keeps
+    other = {}
+    for name, key in (("sustained", "sustained_img_s"), ("bdd", "bdd_heads_img_s"), ("stress", "stress_heads_img_s"),
+                      ("e2e", "e2e_img_s"), ("dp_e2e", "dp_e2e_bdd_img_s"), ("alt_precision", "mxfp6_img_s")):
+        v = extra.get(name, {})
+        if isinstance(v, dict) and "value" in v:
+            other[key] = v["value"]
+            out[key] = v["value"]
+    for name in ("bdd", "stress"):
+        v = extra.get(name, {})
+        if isinstance(v, dict) and "roofline" in v:
+            other[name + "_conv_frac"] = v["roofline"]["frac"]
+            other[name + "_conv_ms"] = v["roofline"]["launch_ms"]
+    if "e2e" in extra and "two_streams" in extra["e2e"]:
+        other["e2e_two_streams_img_s"] = out["e2e_two_streams_img_s"] = extra["e2e"]["two_streams"]["value"]
+    if "dp_e2e" in extra and "exchange_ms" in extra["dp_e2e"]:
+        other["dp_e2e_exchange_ms"] = extra["dp_e2e"]["exchange_ms"]
+        other["dp_e2e_ranks"] = extra["dp_e2e"]["rccl_ranks"]
+        other["dp_e2e_backend"] = extra["dp_e2e"]["backend"]
+    if "t_sweep" in extra and "worst_ms_per_step_rel" in extra["t_sweep"]:
+        other["t_sweep_worst_ms_per_step_rel"] = extra["t_sweep"]["worst_ms_per_step_rel"]
+    if other:
+        out["config"]["other_configs"] = other
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

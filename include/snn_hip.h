@@ -75,6 +75,12 @@ typedef struct snn_rpn_level {
 int snn_version(void);
 const char* snn_last_error(void);
 void snn_debug_reload_knobs(void);     /* re-read the SNN_* debug knobs from the environment (tests only) */
+/* Introspection (bench.py --sweep-t, tests): the row tile a T-in-tile launch of the bf16x3 family would use for `units`
+ * positions (conv = 1: the RPN's shared 3x3 conv, C_out = n_cols) or RoIs (conv = 0: a linear layer with n_cols outputs) and
+ * num_steps LIF steps.  out[0..7] = {M-tiles per wave, short row-waves, tile rows, positions or RoIs per tile, time steps whose
+ * currents are formed (dead time steps removed), work-groups of the launch, column blocks, waves along N}.  Returns 0, or -4
+ * if no tile holds that many steps (the launch then takes the un-fused path). */
+int snn_debug_tile_shape(int conv, long long units, int n_cols, int num_steps, int spike_rates, int layer, int32_t* out);
 
 /* ---- weight packing (call when the weights change; results are plain device buffers) ---------- */
 /* number of floats of a packed GEMM operand with K reduction rows and N output columns */

@@ -1,0 +1,64 @@
+"""Caches of device-side derived data (packed weights, folded FrozenBatchNorm constants, anchors) that stay correct when
+the model is called from several host threads on several HIP streams (pipeline.StreamPipeline).
+
+A cached tensor is produced by kernels enqueued on the stream of whoever fills the cache first.  A second caller on ANOTHER
+stream that finds the entry must not read it before those kernels have run: every entry carries the event recorded behind
+its fill, and a consumer on a different stream waits for that event (a no-op once the fill has completed).  The fill itself
+runs under a lock, so two threads never produce the same entry twice or hand out each other's tensor."""
+import threading
+from typing import Any, Callable, Hashable, Optional
+
+import torch
+
+
+def _stream_id(device: Optional[torch.device]):
+    if device is None or device.type != "cuda" or not torch.cuda.is_available():
+        return None
+    return (device.index, torch.cuda.current_stream(device).cuda_stream)
+
+
+class StreamSafeEntry:
+    """one value keyed on `key`; `make()` enqueues the work that produces it on the current stream of `device`"""
+
+    def __init__(self):
+        self._lock = threading.Lock()
+        self.key: Hashable = None
+        self.val: Any = None
+        self._event = None
+        self._filled_on = None
+
+    def invalidate(self) -> None:
+        with self._lock:
+            self.key = self.val = self._event = self._filled_on = None
+
+    def get(self, key: Hashable, make: Callable[[], Any], device: Optional[torch.device] = None) -> Any:
+        with self._lock:
+            if self.val is None or key != self.key:
+                val = make()
+                ev, sid = None, _stream_id(device)
+                if sid is not None:
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream(device))
+                self.key, self.val, self._event, self._filled_on = key, val, ev, sid
+            val, ev, filled_on = self.val, self._event, self._filled_on
+        if ev is not None and _stream_id(device) != filled_on:
+            torch.cuda.current_stream(device).wait_event(ev)
+        return val
+
+
+class StreamSafeDict:
+    """a few keyed entries (anchors per shape); cleared when it grows past `limit`"""
+
+    def __init__(self, limit: int = 8):
+        self._lock = threading.Lock()
+        self._entries = {}
+        self._limit = limit
+
+    def get(self, key: Hashable, make: Callable[[], Any], device: Optional[torch.device] = None) -> Any:
+        with self._lock:
+            e = self._entries.get(key)
+            if e is None:
+                if len(self._entries) > self._limit:
+                    self._entries.clear()
+                e = self._entries[key] = StreamSafeEntry()
+        return e.get(key, make, device)

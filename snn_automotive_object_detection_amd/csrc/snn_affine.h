@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void k_affine_act(const AffineArgs a) {
         float o = v * s;
         o = o + b;
         if (a.residual) o = o + r;
-        return relu ? fmaxf(o, 0.0f) : o;
+        return relu ? ((o <= 0.0f) ? 0.0f : o) : o;      // torch's relu = threshold(x, 0, 0): NaN stays NaN, -0.0 becomes +0.0 (fmaxf would swallow NaN)
     };
     // planes whose start is 16-B aligned (HW % 4 == 0) go as float4, anything else element by element
     if ((a.HW & 3) == 0) {

@@ -507,6 +507,26 @@ static int launch_gemm3(int mode, int mt, int wn, const Gemm3Args& a, hipStream_
     return 0;
 }
 
+// (declared further down)
+static bool g3_tile_ok(int T, int rows);
+
+int snn_debug_tile_shape(int conv, long long units, int n_cols, int num_steps, int spike_rates, int layer, int32_t* out) {
+    if (!out || units <= 0 || n_cols <= 0 || num_steps < 1 || num_steps > SNN_MAX_STEPS) return fail(-1, "snn_debug_tile_shape: bad argument");
+    snn_params p;
+    memset(&p, 0, sizeof(p));
+    p.v_th_lif = 0.1f;                                          // (only the sign of v_leak - v_th matters for the windows)
+    int Tc;
+    if (conv) Tc = lif_window_full_out(num_steps).n;
+    else { const DetWindows w = det_windows(&p, num_steps, spike_rates != 0); Tc = layer == 7 ? w.fc7.n : w.fc6.n; }
+    const int wn = g3_wn(conv != 0), n_blocks = cdiv(cdiv(n_cols, 32) * 32, G3_BN(wn));
+    const G3Tile tl = g3_pick_tile(wn, [&](int rows) { return g3_tile_ok(Tc, rows) ? (long long)cdiv(units, rows / Tc) * n_blocks : 0ll; });
+    if (!tl.mt) return fail(-4, "snn_debug_tile_shape: %d steps do not fit a row tile", num_steps);
+    const int pb = tl.rows / Tc;
+    out[0] = tl.mt; out[1] = tl.n_short; out[2] = tl.rows; out[3] = pb; out[4] = Tc; out[5] = (int32_t)(cdiv(units, pb) * n_blocks);
+    out[6] = n_blocks; out[7] = wn;
+    return 0;
+}
+
 int snn_spike_gemm_bf16x3(const uint32_t* a_rows, int M, int K, int N, const uint16_t* w_packed, float* cur, int ldo,
                           snn_stream_t s) {
     if (!a_rows || !w_packed || !cur || M <= 0 || K <= 0 || N <= 0 || ldo < N)

@@ -141,6 +141,23 @@ def all_gather_detections(dets: List[Dict[str, torch.Tensor]], max_det: int = 11
 # ---------------------------------------------------------------------------------------------
 # rank launcher: `python bench.py --gpus N` without torchrun (the parent never touches the GPU)
 # ---------------------------------------------------------------------------------------------
+def count_gpus_without_hip() -> Optional[int]:
+    """GPUs visible to this job, counted WITHOUT opening HIP in the calling process: a short-lived child asks torch
+    (``torch.cuda.device_count()``) and exits before any rank is started.  The launcher parent must stay GPU-less - on this
+    pool a process that has initialised the GPU must not start or become another GPU program - and the kernel driver's
+    sysfs topology is no substitute: inside a container it lists every GPU of the node, not the ones this job may open.
+    None if the child fails (the caller then trusts --gpus)."""
+    try:
+        r = subprocess.run([sys.executable, "-c", "import torch; print('SNN_NGPU', torch.cuda.device_count())"],
+                           stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=300)
+        for line in r.stdout.splitlines():
+            if line.startswith("SNN_NGPU "):
+                return int(line.split()[1])
+    except (OSError, ValueError, subprocess.TimeoutExpired):
+        pass
+    return None
+
+
 def _free_port() -> int:
     import socket
     s = socket.socket()

@@ -5,7 +5,10 @@ Python lists, rpn.py:493-499, roi_heads.py:1163-1172), so a single thread cannot
 it waits for one batch's counts nothing of the next batch is enqueued, and the small kernels of the post-processing stages
 leave most of the chip idle.  With two slots the small kernels of one batch run beside the big contractions of the other
 (end to end on 2 x 1024x2048 images: 139 -> 152 images/s; bench.py ``e2e.two_streams``).  Safe because every C-ABI entry point
-enqueues on the stream it is given and the wrappers keep one workspace per (device, stream) (ops._Workspace)."""
+enqueues on the stream it is given, the wrappers keep one workspace per (device, stream) (ops._Workspace), and the model's
+lazily built device-side caches (packed weights, folded FrozenBatchNorm constants, anchors) are filled under a lock and carry
+the event of their fill, which a consumer on another stream waits for (``_cache.StreamSafeEntry``) - a freshly constructed
+model may be handed to ``map`` directly (tests/test_gpu_modules.py::test_stream_pipeline_on_a_cold_model)."""
 import queue
 import threading
 from typing import Any, Callable, Iterable, List

@@ -2,6 +2,7 @@
 901-1347, inference side): box_roi_pool -> **spiking head** (the accelerated call, roi_heads.py:1230) ->
 postprocess_detections (1075-1176) that keeps the surviving background boxes and returns
 ``all_scores`` / ``all_boxes`` for new-object discovery.  Everything except the head call is stock torch."""
+import warnings
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -28,6 +29,7 @@ class RoIHeadsSNN(nn.Module):
         self.detections_per_img = detections_per_img
         self.fuse_roi_align = True        # use the fused RoIAlign+encoder kernel when pool/head support it
         self.post = "hip"                 # "hip": snn_det_postprocess; "reference": the reference's order on stock torch ops
+        self._warned = set()              # fallback reasons already reported
         # training-side hyper-parameters are accepted for signature compatibility only
         self.fg_iou_thresh, self.bg_iou_thresh = fg_iou_thresh, bg_iou_thresh
         self.batch_size_per_image, self.positive_fraction = batch_size_per_image, positive_fraction
@@ -50,10 +52,28 @@ class RoIHeadsSNN(nn.Module):
             raise NotImplementedError("postprocess_detections needs %d box outputs per RoI (4 per class), got %d "
                                       "(only_one_bbox heads are not supported past the head, SURVEY.md appendix C.6)"
                                       % (4 * class_logits.shape[-1], box_regression.shape[-1]))
-        if (class_logits.is_cuda and self.post == "hip" and per_image and 0 < max(per_image) <= 10000
-                and class_logits.shape[-1] <= 82):            # snn_det_postprocess: RoIs per image / classes it ranks in LDS
-            return self._postprocess_hip(class_logits, box_regression, proposals, image_shapes, per_image)
+        if class_logits.is_cuda and self.post == "hip" and per_image and max(per_image) > 0:
+            why = self._hip_postprocess_refusal(len(per_image), max(per_image), class_logits.shape[-1])
+            if why is None:
+                return self._postprocess_hip(class_logits, box_regression, proposals, image_shapes, per_image)
+            if why not in self._warned:                       # loud, once per reason: the stock-torch path is ~4x slower per batch
+                self._warned.add(why)
+                warnings.warn("RoIHeadsSNN: detection post-processing falls back to the stock torch ops (%s)" % why, RuntimeWarning)
         return self.postprocess_detections_reference(class_logits, box_regression, proposals, image_shapes)
+
+    def _hip_postprocess_refusal(self, n_images: int, max_rois: int, n_classes: int):
+        """the limits of snn_det_postprocess (csrc/snn_kernels.hip / snn_post.h), mirrored so that a configuration outside them
+        takes the reference path instead of raising: None if the HIP path can run, else the reason"""
+        if n_images > 64:
+            return "%d images per batch (HIP path: <= 64)" % n_images
+        if n_classes < 2 or n_classes > 96:
+            return "%d classes (HIP path: 2..96)" % n_classes
+        if max_rois > 10240:                                  # 2 x 64 x ceil(R / 64) x 8 B of LDS for the NMS walk (also <= DET_SORT_MAX)
+            return "%d RoIs per image (HIP path: <= 10240)" % max_rois
+        if (n_classes - 1) * min(int(self.detections_per_img), max_rois) > 8192:
+            return "(K-1) x detections_per_img = %d ranked candidates per image (HIP path: <= 8192)" % (
+                (n_classes - 1) * min(int(self.detections_per_img), max_rois))
+        return None
 
     def _postprocess_hip(self, class_logits, box_regression, proposals, image_shapes, per_image):
         """snn_det_postprocess: five launches and one host synchronisation for the batch"""

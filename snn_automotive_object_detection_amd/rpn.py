@@ -5,32 +5,34 @@ Same constructor, same ``forward`` signature and return values, same ``state_dic
 ``RegionProposalNetwork.forward`` (rpn.py:613) can call it unchanged.  The spike-rate variant the
 reference keeps in a string literal (rpn.py:126-200, enabled there by editing the source) is the
 attribute ``spike_rates`` here.  Inference only (no autograd through the kernels)."""
+import warnings
 from typing import List, Tuple
 
 import torch
 from torch import nn, Tensor
 
 from . import ops
+from ._cache import StreamSafeEntry
 
 
 class _WeightCache:
     """packed-weight cache keyed on the parameter's storage and version counter.  In-place writes through ``param.data``
     do not bump the version counter: after such an edit call the module's ``invalidate_packed_weights()`` (``_apply`` -
-    .to() / .half() / .cuda() - and ``load_state_dict`` do it themselves)."""
+    .to() / .half() / .cuda() - and ``load_state_dict`` do it themselves).  Safe across host threads / HIP streams
+    (``_cache.StreamSafeEntry``: filled under a lock, consumers on another stream wait for the packing kernels)."""
     def __init__(self):
-        self.key = None
-        self.val = None
+        self._entry = StreamSafeEntry()
+
+    @property
+    def val(self):
+        return self._entry.val
 
     def invalidate(self):
-        self.key = None
-        self.val = None
+        self._entry.invalidate()
 
     def get(self, tensors, fn):
         key = tuple((t.data_ptr(), t._version, str(t.device)) for t in tensors)
-        if key != self.key:
-            self.val = fn(*tensors)
-            self.key = key
-        return self.val
+        return self._entry.get(key, lambda: fn(*tensors), tensors[0].device)
 
 
 class RPNHeadSNN(nn.Module):
@@ -168,6 +170,7 @@ class RegionProposalNetwork(nn.Module):
         # top-k before decode, "reference" = the reference's per-image order of operations; all three give the same
         # proposals (tests/test_gpu_e2e.py).  CPU tensors always take "reference".
         self.post = "hip"
+        self._warned = set()                                                          # fallback reasons already reported
 
     def pre_nms_top_n(self):
         return self._pre_nms_top_n["training" if self.training else "testing"]
@@ -253,6 +256,21 @@ class RegionProposalNetwork(nn.Module):
         final_scores = list(prob[img_of, pick].split(counts))
         return final_boxes, final_scores, pre_nms
 
+    def _hip_proposals_refusal(self, objectness):
+        """the limits of snn_rpn_proposals (csrc/snn_post.h), mirrored so that a configuration outside them takes the
+        stock-torch path instead of raising: None if the HIP path can run, else the reason"""
+        N, A = objectness[0].shape[0], objectness[0].shape[1]
+        if len(objectness) > 8:
+            return "%d feature levels (HIP path: <= 8)" % len(objectness)
+        if N > 64:
+            return "%d images per batch (HIP path: <= 64)" % N
+        if A > 16:
+            return "%d anchors per location (HIP path: <= 16)" % A
+        k = sum(min(int(self.pre_nms_top_n()), int(o.shape[1] * o.shape[2] * o.shape[3])) for o in objectness)
+        if k > 8192:
+            return "%d pre-NMS candidates per image (HIP path: <= 8192)" % k
+        return None
+
     def _proposals_hip(self, objectness, pred_bbox_deltas, images, feats):
         from . import ops
         N = objectness[0].shape[0]
@@ -283,8 +301,13 @@ class RegionProposalNetwork(nn.Module):
         # spike-rate mode: the head's third value takes the place of `losses` (rpn.py:698-701, "losses = spike_rates")
         rates = head_out[2] if len(head_out) == 3 else None
         if objectness[0].is_cuda and self.post == "hip":
-            boxes, pre_nms = self._proposals_hip(objectness, pred_bbox_deltas, images, feats)
-            return boxes, (pre_nms if rates is None else rates)
+            why = self._hip_proposals_refusal(objectness)
+            if why is None:
+                boxes, pre_nms = self._proposals_hip(objectness, pred_bbox_deltas, images, feats)
+                return boxes, (pre_nms if rates is None else rates)
+            if why not in self._warned:                       # loud, once per reason
+                self._warned.add(why)
+                warnings.warn("RegionProposalNetwork: proposal selection falls back to the stock torch ops (%s)" % why, RuntimeWarning)
         anchors = self.anchor_generator(images, feats)
         num_images = len(anchors)
         num_anchors_per_level = [o.shape[1] * o.shape[2] * o.shape[3] for o in objectness]

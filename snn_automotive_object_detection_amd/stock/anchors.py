@@ -4,6 +4,8 @@ from typing import List, Tuple
 import torch
 from torch import nn, Tensor
 
+from .._cache import StreamSafeDict
+
 
 class ImageList:
     def __init__(self, tensors: Tensor, image_sizes: List[Tuple[int, int]]):
@@ -24,7 +26,7 @@ class AnchorGenerator(nn.Module):
         self.sizes = sizes
         self.aspect_ratios = aspect_ratios
         self.cell_anchors = [self._base(s, a) for s, a in zip(sizes, aspect_ratios)]
-        self._cache = {}                                # (grid sizes, image size, dtype, device) -> anchors
+        self._cache = StreamSafeDict()                  # (grid sizes, image size, dtype, device) -> anchors; safe across threads / streams
 
     @staticmethod
     def _base(scales, ratios, dtype=torch.float32):
@@ -44,20 +46,16 @@ class AnchorGenerator(nn.Module):
         image_size = image_list.tensors.shape[-2:]
         dtype, device = feature_maps[0].dtype, feature_maps[0].device
         key = (tuple(tuple(g) for g in grid_sizes), tuple(image_size), dtype, device)
-        hit = self._cache.get(key)
-        if hit is not None:                             # the anchors depend on the shapes only
-            return [hit for _ in image_list.image_sizes]
-        per_level = []
-        for (gh, gw), base in zip(grid_sizes, self.cell_anchors):
-            sh, sw = image_size[0] // gh, image_size[1] // gw
-            xs = torch.arange(0, gw, dtype=torch.int32, device=device) * sw
-            ys = torch.arange(0, gh, dtype=torch.int32, device=device) * sh
-            yy, xx = torch.meshgrid(ys, xs, indexing="ij")
-            xx, yy = xx.reshape(-1), yy.reshape(-1)
-            shifts = torch.stack((xx, yy, xx, yy), dim=1)
-            per_level.append((shifts.view(-1, 1, 4) + base.to(device=device, dtype=dtype).view(1, -1, 4)).reshape(-1, 4))
-        all_anchors = torch.cat(per_level)
-        if len(self._cache) > 8:
-            self._cache.clear()
-        self._cache[key] = all_anchors
+        def make():                                     # the anchors depend on the shapes only
+            per_level = []
+            for (gh, gw), base in zip(grid_sizes, self.cell_anchors):
+                sh, sw = image_size[0] // gh, image_size[1] // gw
+                xs = torch.arange(0, gw, dtype=torch.int32, device=device) * sw
+                ys = torch.arange(0, gh, dtype=torch.int32, device=device) * sh
+                yy, xx = torch.meshgrid(ys, xs, indexing="ij")
+                xx, yy = xx.reshape(-1), yy.reshape(-1)
+                shifts = torch.stack((xx, yy, xx, yy), dim=1)
+                per_level.append((shifts.view(-1, 1, 4) + base.to(device=device, dtype=dtype).view(1, -1, 4)).reshape(-1, 4))
+            return torch.cat(per_level)
+        all_anchors = self._cache.get(key, make, device)
         return [all_anchors for _ in image_list.image_sizes]

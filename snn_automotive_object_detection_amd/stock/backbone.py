@@ -6,6 +6,8 @@ import torch
 import torch.nn.functional as F
 from torch import nn, Tensor
 
+from .._cache import StreamSafeEntry
+
 
 FUSED_FROZEN_BN = True      # GPU inference: scale/shift (+ residual) (+ ReLU) in one pass (ops.affine_act_nchw, bit-identical to the
                             # separate torch launches below); False = the plain torch sequence everywhere
@@ -19,29 +21,32 @@ class FrozenBatchNorm2d(nn.Module):
         self.register_buffer("bias", torch.zeros(n))
         self.register_buffer("running_mean", torch.zeros(n))
         self.register_buffer("running_var", torch.ones(n))
-        self._folded = None                 # (key, scale, bias): the per-channel constants are frozen, computed once
+        self._folded = StreamSafeEntry()    # (scale, bias): the per-channel constants are frozen, computed once (safe across
+                                            # host threads / HIP streams: pipeline.StreamPipeline)
 
     def _scale_bias(self):
         bufs = (self.weight, self.bias, self.running_mean, self.running_var)
         key = tuple((b.data_ptr(), b._version) for b in bufs)
-        if self._folded is None or self._folded[0] != key:
+
+        def fold():
             scale = self.weight * (self.running_var + self.eps).rsqrt()
-            bias = self.bias - self.running_mean * scale
-            self._folded = (key, scale, bias)
-        return self._folded[1], self._folded[2]
+            return scale, self.bias - self.running_mean * scale
+        return self._folded.get(key, fold, self.weight.device)
 
     def _apply(self, fn, *a, **kw):         # .to() / .cuda(): new storages
-        self._folded = None
+        self._folded.invalidate()
         return super()._apply(fn, *a, **kw)
 
-    def forward(self, x: Tensor, residual: Tensor = None, relu: bool = False) -> Tensor:
+    def forward(self, x: Tensor, residual: Tensor = None, relu: bool = False, inplace: bool = False) -> Tensor:
         """x * scale + bias, then (+ residual), then (ReLU): torchvision's FrozenBatchNorm2d.forward followed by the
-        Bottleneck tail, as separate operations or - same roundings - in one kernel"""
+        Bottleneck tail, as separate operations or - same roundings - in one kernel.  ``inplace=True`` lets the fused kernel
+        overwrite ``x`` (the callers inside this file pass a convolution's fresh output); by default ``x`` is left alone, as
+        torchvision's module leaves it (forward hooks on the convolution, feature extractors)."""
         scale, bias = self._scale_bias()
         if (FUSED_FROZEN_BN and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous() and not x.requires_grad
                 and (residual is None or (residual.is_contiguous() and residual.dtype == torch.float32 and not residual.requires_grad))):
             from .. import ops
-            return ops.affine_act_nchw(x, scale, bias, residual, relu, out=x)      # x is the convolution's fresh output
+            return ops.affine_act_nchw(x, scale, bias, residual, relu, out=x if inplace else None)
         out = x * scale.reshape(1, -1, 1, 1) + bias.reshape(1, -1, 1, 1)
         if residual is not None:
             out = out + residual
@@ -63,9 +68,9 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         idt = x if self.downsample is None else self.downsample(x)
-        out = self.bn1(self.conv1(x), relu=True)
-        out = self.bn2(self.conv2(out), relu=True)
-        return self.bn3(self.conv3(out), residual=idt, relu=True)
+        out = self.bn1(self.conv1(x), relu=True, inplace=True)            # (each convolution output is fresh: overwritten in place)
+        out = self.bn2(self.conv2(out), relu=True, inplace=True)
+        return self.bn3(self.conv3(out), residual=idt, relu=True, inplace=True)
 
 
 class _ConvBlock(nn.Sequential):
@@ -96,7 +101,7 @@ class ResNetBody(nn.Module):
         return nn.Sequential(*layers)
 
     def forward(self, x: Tensor):
-        x = F.max_pool2d(self.bn1(self.conv1(x), relu=True), 3, stride=2, padding=1)
+        x = F.max_pool2d(self.bn1(self.conv1(x), relu=True, inplace=True), 3, stride=2, padding=1)
         c2 = self.layer1(x); c3 = self.layer2(c2); c4 = self.layer3(c3); c5 = self.layer4(c4)
         return [c2, c3, c4, c5]
 

@@ -1,0 +1,57 @@
+"""child of tests/test_gpu_dp.py::test_dp_e2e_gathered_detections_equal_single_process: one rank of BASELINE.json config[3] at a
+reduced image count (2 per rank): create_model("bdd", 11) on this rank's contiguous shard -> dp.all_gather_detections of the
+decoded detections.  Rank 0 then runs every shard itself (same batches, same weights) and prints how the gathered list
+compares with that single-process result, image by image, as one JSON line."""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import torch.distributed as dist
+
+import bench
+import snn_automotive_object_detection_amd as S
+from snn_automotive_object_detection_amd import dp
+
+PER_RANK = int(os.environ.get("DP_E2E_PER_RANK", "2"))
+rank, local, world = dp.init_distributed()
+torch.cuda.set_device(local)
+dev = torch.device("cuda", local)
+torch.manual_seed(4321)
+model = S.create_model("bdd", 11, True, True, 0, False, False, 8, 12).to(dev).eval()
+n_global = PER_RANK * world
+mine = dp.shard_range(n_global, rank, world)
+dets = model(bench.dp_images(mine, dev))
+gathered = dp.all_gather_detections(dets, max_det=1100, device=dev)
+assert len(gathered) == n_global
+# this rank's own block of the gathered list is its own result, bit for bit
+for j, i in enumerate(mine):
+    for k in ("boxes", "scores", "labels"):
+        assert torch.equal(gathered[i][k], dets[j][k][:1100]), (rank, i, k)
+# every rank ends up with the same list
+sig = torch.tensor([float(sum(float(d["boxes"].sum()) + float(d["scores"].sum()) + float(d["labels"].sum()) for d in gathered))], dtype=torch.float64)
+sigs = [torch.zeros_like(sig) for _ in range(world)]
+dist.all_gather(sigs, sig if dist.get_backend() == "gloo" else sig.to(dev))
+assert all(float(x) == float(sig) for x in sigs), [float(x) for x in sigs]
+if rank == 0:
+    report = {"world": world, "images": n_global, "backend": dist.get_backend(), "per_image": []}
+    for r in range(world):                                       # single process: the same batches, one after the other
+        idx = list(dp.shard_range(n_global, r, world))
+        ref = model(bench.dp_images(idx, dev))
+        ref2 = model(bench.dp_images(idx, dev)) if r == 0 else None
+        for j, i in enumerate(idx):
+            g, e = gathered[i], ref[j]
+            n_g, n_e = int(g["boxes"].shape[0]), int(e["boxes"].shape[0])
+            row = {"image": i, "rank": r, "n_gathered": n_g, "n_single": n_e,
+                   "exact": bool(n_g == n_e and all(torch.equal(g[k], e[k]) for k in ("boxes", "scores", "labels")))}
+            if n_g == n_e and n_g:
+                row["max_box_diff"] = float((g["boxes"] - e["boxes"]).abs().max())
+                row["max_score_diff"] = float((g["scores"] - e["scores"]).abs().max())
+                row["labels_equal"] = bool(torch.equal(g["labels"], e["labels"]))
+            if ref2 is not None:
+                row["single_process_repeatable"] = bool(all(torch.equal(ref[j][k], ref2[j][k]) for k in ("boxes", "scores", "labels")))
+            report["per_image"].append(row)
+    print("DP_E2E " + json.dumps(report), flush=True)
+dist.barrier()
+dist.destroy_process_group()

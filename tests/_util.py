@@ -28,11 +28,35 @@ def nchw_to_rows(z: torch.Tensor) -> np.ndarray:
     return z.permute(0, 1, 3, 4, 2).reshape(T, N * H * W, C).numpy()
 
 
-def flip_budget(positions: int, channels: int, steps: int) -> float:
-    """How many positions may hold a hidden spike that differs from the oracle's.  Two fp32 summation orders
-    of the same 3x3 convolution disagree on ~7e-8 of the neuron-steps (SURVEY.md §7 risk 1 measured 5 of 7.5e7
-    between two oneDNN layouts); a position has channels*steps of them.  Budget = 3.5x that rate + 2."""
-    return 2 + 2.5e-7 * channels * steps * positions
+# Spike flips at threshold ties.  Two fp32 summation orders of the same contraction agree to ~1e-7; where the oracle's decayed
+# membrane sits that close to the threshold the spike can fall either way and the position / RoI then leaves the 1e-4 output
+# tolerance (SURVEY.md §7 risk 1).  Budgets = 2 + rate x neuron-steps, with rates set at ~3x what round 2 and 3 OBSERVED
+# (profiles/parity_r2.json, parity_r3.json) - per neuron-step:
+#   RPN on N(0,1) pyramids  : 7 / 12 / 16 of 196 416 positions (bf16x3 / f32 / mxfp6) = 1.7e-8 .. 4e-8 -> rate 8e-8 (mxfp6 x2:
+#                             its digit planes round weights at 2^-29 of the block maximum)
+#   RPN behind the backbone : 35 of 196 416 (firing rates are 3x those of N(0,1) inputs) = 8.7e-8         -> rate 2.5e-7
+#   detector                : 0 - 2 of 2000 RoIs on N(0,1) (bf16x3 / f32), 8 in situ / mxfp6, 9 at T = 24 = 0 .. 1.6e-7 -> 2.5e-7
+# Every full-size test also ATTRIBUTES its flips (first_flip_margins): each first differing spike sits within 2e-5 of the
+# threshold in the oracle's trace, so a regression that flips spikes away from ties fails whatever the count.
+FLIP_RATE = {"rpn_randn": 8e-8, "rpn_in_situ": 2.5e-7, "det": 2.5e-7}
+PRECISION_FACTOR = {"bf16x3": 1.0, "f32": 1.0, "mxfp6": 2.0}
+TIE_MARGIN = 2e-5
+
+
+def flip_budget(positions: int, channels: int, steps: int, kind: str = "rpn_in_situ", precision: str = "bf16x3") -> float:
+    """how many positions / RoIs may hold a hidden spike that differs from the oracle's (see the table above)"""
+    return 2 + FLIP_RATE[kind] * PRECISION_FACTOR[precision] * channels * steps * positions
+
+
+def first_flip_margins(spk_got: np.ndarray, spk_exp: np.ndarray, vdec_exp: np.ndarray, theta: float = 0.1):
+    """spike trains [T, ...]: for every neuron whose train differs from the oracle's, the oracle's |v_dec - theta| at the
+    FIRST differing step (later differences are consequences).  Returns (neurons that differ, their margins, mask of them)."""
+    diff = spk_got != spk_exp
+    any_diff = diff.any(axis=0)
+    first = diff.argmax(axis=0)
+    idx = np.nonzero(any_diff)
+    margins = np.abs(vdec_exp[(first[idx],) + idx] - theta)
+    return int(any_diff.sum()), margins, any_diff
 
 
 # ---- post-processing fixtures (tests/golden/post_*.npz; oracle/make_golden.py ran the reference's own bodies) ----
@@ -71,11 +95,11 @@ def assert_same_detections(got_boxes, got_scores, exp_boxes, exp_scores, got_lab
 
 
 def record_parity(test: str, **values):
-    """append observed off-tolerance counts to gpurun_out/parity_r2.jsonl (copied into profiles/parity_r2.json after a GPU
+    """append observed off-tolerance counts to gpurun_out/parity_r3.jsonl (copied into profiles/parity_r3.json after a GPU
     run): the flip budgets are tightened on this evidence"""
     import json
     import os
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_r2.jsonl")
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_r3.jsonl")
     try:
         os.makedirs(os.path.dirname(path), exist_ok=True)
         with open(path, "a") as f:

@@ -30,6 +30,37 @@ def test_affine_act_bitwise_equals_torch_sequence(gpu_device, shape, residual, r
     assert ops.affine_act_nchw(x2, scale, bias, r, relu, out=x2) is x2 and torch.equal(x2, ref)      # in place
 
 
+@pytest.mark.parametrize("residual", [False, True])
+def test_affine_act_propagates_nan_inf_and_signed_zero_like_torch(gpu_device, residual):
+    """torch's relu is threshold(x, 0, 0) - NaN stays NaN, -0.0 becomes +0.0, +inf stays; the fused kernel must not
+    turn a diverged backbone into clean zeros"""
+    from snn_automotive_object_detection_amd import ops
+    x = torch.tensor([float("nan"), float("inf"), float("-inf"), -0.0, 0.0, -1.0, 1.0, 1e-45], device=gpu_device).reshape(1, 1, 2, 4).repeat(1, 2, 1, 1).contiguous()
+    scale = torch.tensor([1.0, -1.0], device=gpu_device)
+    bias = torch.tensor([0.0, 0.0], device=gpu_device)
+    r = torch.zeros_like(x) if residual else None
+    for relu in (False, True):
+        ref = _plain(x, scale, bias, r, relu)
+        out = ops.affine_act_nchw(x, scale, bias, r, relu)
+        assert torch.equal(torch.isnan(out), torch.isnan(ref)) and bool(torch.isnan(out).any())
+        keep = ~torch.isnan(ref)
+        assert torch.equal(out[keep].view(torch.int32), ref[keep].view(torch.int32))          # bit for bit, signed zeros included
+
+
+def test_frozen_bn_leaves_its_input_alone_unless_told(gpu_device):
+    """the in-place write of the fused path is opt-in (the callers inside stock/backbone.py pass fresh conv outputs)"""
+    from snn_automotive_object_detection_amd.stock import backbone as B
+    bn = B.FrozenBatchNorm2d(8).to(gpu_device)
+    bn.bias.fill_(1.0)
+    x = torch.randn(1, 8, 5, 5, device=gpu_device)
+    x0 = x.clone()
+    with torch.no_grad():
+        y = bn(x, relu=True)
+        assert torch.equal(x, x0) and y.data_ptr() != x.data_ptr()
+        y2 = bn(x, relu=True, inplace=True)
+        assert y2.data_ptr() == x.data_ptr() and torch.equal(y2, y)
+
+
 def test_affine_act_rejects_bad_operands(gpu_device):
     from snn_automotive_object_detection_amd import ops, _lib
     x = torch.randn(1, 4, 3, 3, device=gpu_device)

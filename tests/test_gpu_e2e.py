@@ -19,10 +19,14 @@ def torch_nms_for_the_stock_comparators(monkeypatch):
     monkeypatch.setattr(box_ops, "HIP_NMS", False)
 
 
-@pytest.mark.parametrize("full", [False, True], ids=["canvas384x768", "config2_1024x2048"])
-def test_create_model_end_to_end_and_heads_in_situ(gpu_device, full):
+@pytest.mark.parametrize("full,fused", [(False, False), (True, False), (False, True), (True, True)],
+                         ids=["canvas384x768", "config2_1024x2048", "canvas384x768_fused_roialign", "config2_1024x2048_fused_roialign"])
+def test_create_model_end_to_end_and_heads_in_situ(gpu_device, full, fused):
     """full=True is BASELINE.json config[2]: 2 x rand(3,1024,2048) through create_model at the reference's transform
-    (768x1536 canvas, 5-level pyramid 192x384 .. 12x24, <= 2000 RoIs), heads checked in situ against the oracle"""
+    (768x1536 canvas, 5-level pyramid 192x384 .. 12x24, <= 2000 RoIs), heads checked in situ against the oracle.
+    fused=True is the DEFAULT product path of the RoI stage (RoIHeadsSNN.fuse_roi_align: k_roi_align_encode_wm -> word-major
+    planes -> fc6): what `pool.assign` hands to the fused head is captured and replayed through oracle(RoIAlign restatement on
+    the CPU -> det_head_forward); fused=False observes the head's own forward behind the stock RoIAlign op."""
     import snn_automotive_object_detection_amd as S
     from oracle import snn_oracle as OR
     from tests._util import record_parity
@@ -32,11 +36,24 @@ def test_create_model_end_to_end_and_heads_in_situ(gpu_device, full):
         m.transform.min_size, m.transform.max_size = 384, 768             # 512x1024 images -> 384x768 canvas
     ih, iw = (1024, 2048) if full else (512, 1024)
     m = m.to(gpu_device).eval()
-    m.roi_heads.fuse_roi_align = False      # the hooks below observe the head's own forward (un-fused path)
+    m.roi_heads.fuse_roi_align = fused
     cap = {}
+    if fused:                                # forward hooks do not see forward_roialign: wrap the two calls of the fused path
+        pool, dhead = m.roi_heads.box_roi_pool, m.roi_heads.box_head_and_predictor
+        assign0, fwd0 = pool.assign, dhead.forward_roialign
+
+        def assign(x, boxes, shapes):
+            cap.update(pool_in=({k: v.detach().cpu() for k, v in x.items()}, [b.detach().cpu() for b in boxes], list(shapes)))
+            return assign0(x, boxes, shapes)
+
+        def fwd(*a, **k):
+            out = fwd0(*a, **k)
+            cap.update(det_out=(out[0].cpu(), out[1].cpu()), fused_calls=cap.get("fused_calls", 0) + 1)
+            return out
+        pool.assign, dhead.forward_roialign = assign, fwd
     m.rpn.head.register_forward_hook(lambda mod, inp, out: cap.update(rpn_in=[f.detach().cpu() for f in inp[0]],
                                                                       rpn_out=([t.cpu() for t in out[0]], [t.cpu() for t in out[1]])))
-    m.roi_heads.box_head_and_predictor.register_forward_hook(
+    m.roi_heads.box_head_and_predictor.register_forward_hook(                # (fires on the un-fused path only)
         lambda mod, inp, out: cap.update(det_in=inp[0].detach().cpu(), det_out=(out[0].cpu(), out[1].cpu())))
     # the callers either side of the heads, in situ: what the RPN / RoI heads hand to and get from their post-processing
     m.roi_heads.register_forward_pre_hook(lambda mod, inp: cap.update(props=[p.detach().cpu() for p in inp[1]], shapes=list(inp[2])))
@@ -77,15 +94,21 @@ def test_create_model_end_to_end_and_heads_in_situ(gpu_device, full):
         d = torch.maximum((cap["rpn_out"][0][l] - o_l[l]).abs().amax(1), (cap["rpn_out"][1][l] - o_b[l]).abs().amax(1))
         total += d.numel(); bad += int((d > 1e-4).sum())
     assert bad <= flip_budget(total, 256, 8), (bad, total)
-    record_parity("e2e_rpn_head_in_situ", full=full, positions_off_tolerance=bad, positions=total, budget=flip_budget(total, 256, 8))
+    record_parity("e2e_rpn_head_in_situ", full=full, fused_roialign=fused, positions_off_tolerance=bad, positions=total, budget=flip_budget(total, 256, 8))
     # detector head in situ
     dh = m.roi_heads.box_head_and_predictor
-    o_c, o_d = OR.det_head_forward(cap["det_in"], dh.fc6.weight.cpu(), dh.fc7.weight.cpu(), dh.cls_score.weight.cpu(),
+    if fused:
+        from oracle import roi_align_oracle as RA
+        assert cap["fused_calls"] >= 1 and "det_in" not in cap              # the fused kernel ran, the head's plain forward did not
+        det_in = RA.multiscale_roi_align(*cap["pool_in"])                   # torchvision's CPU kernel restated: [R, 256, 7, 7]
+    else:
+        det_in = cap["det_in"]
+    o_c, o_d = OR.det_head_forward(det_in, dh.fc6.weight.cpu(), dh.fc7.weight.cpu(), dh.cls_score.weight.cpu(),
                                    dh.bbox_pred.weight.cpu(), 12)
     dd = torch.maximum((cap["det_out"][0] - o_c).abs().amax(1), (cap["det_out"][1] - o_d).abs().amax(1))
-    record_parity("e2e_det_head_in_situ", full=full, rois_off_tolerance=int((dd > 1e-4).sum()), rois=dd.numel(),
-                  budget=flip_budget(dd.numel(), 2 * 1024, 12))
-    assert int((dd > 1e-4).sum()) <= flip_budget(dd.numel(), 2 * 1024, 12)
+    record_parity("e2e_det_head_in_situ", full=full, fused_roialign=fused, rois_off_tolerance=int((dd > 1e-4).sum()), rois=dd.numel(),
+                  budget=flip_budget(dd.numel(), 2 * 1024, 12, "det"))
+    assert int((dd > 1e-4).sum()) <= flip_budget(dd.numel(), 2 * 1024, 12, "det")
     # RPN proposal selection in situ (snn_rpn_proposals on the head's own outputs) against the oracle restatement of
     # rpn.py:563-703: same proposals in the same order, up to rows that involve exactly tied logits (a random-init head
     # leaves some logits exactly 0; which of equal logits torch.topk takes first is unspecified)
@@ -258,3 +281,31 @@ def test_det_exchange_payload_equals_torch_selection(gpu_device, N, R, K, max_de
         rows = reg.view(N, R, K, 4)[i][idx[i], li]
         assert torch.equal(payload[i, :n, :4], rows)
         assert float(payload[i, n:].abs().max()) == 0.0 if n < max_det else True
+
+
+def test_det_postprocess_outside_the_hip_limits_warns_once_and_takes_the_reference_path(gpu_device):
+    """VERDICT r2 P-d: (K-1) x detections_per_img > 8192 ranked candidates (K = 40, 300 detections per image) - one
+    RuntimeWarning, then the stock-torch post-processing; same values as post = 'reference'"""
+    import warnings
+    import snn_automotive_object_detection_amd as S
+    torch.manual_seed(2)
+    m = S.create_model("cityscapes", 40, True, True, 0, False, False, num_steps_rpn=4, num_steps_detector=4)
+    rh = m.roi_heads.to(gpu_device).eval()
+    rh.detections_per_img = 300
+    rh.score_thresh = 0.02
+    g = torch.Generator().manual_seed(7)
+    R, K = 400, 40
+    logits = (torch.randn(R, K, generator=g) * 2.0).to(gpu_device)
+    deltas = (torch.randn(R, 4 * K, generator=g) * 1.5).to(gpu_device)
+    xy = torch.rand(R, 2, generator=g) * 250
+    props = [torch.cat([xy, xy + torch.rand(R, 2, generator=g) * 200 + 1], 1).to(gpu_device)]
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        o1 = rh.postprocess_detections(logits, deltas, props, [(384, 768)])
+        o2 = rh.postprocess_detections(logits, deltas, props, [(384, 768)])
+    msgs = [str(x.message) for x in w if issubclass(x.category, RuntimeWarning)]
+    assert len(msgs) == 1 and "ranked candidates" in msgs[0], msgs
+    rh.post = "reference"
+    o3 = rh.postprocess_detections(logits, deltas, props, [(384, 768)])
+    for a, b, c in zip(o1, o2, o3):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[0], c[0])

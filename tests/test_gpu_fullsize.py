@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests._util import flip_budget, record_parity
+from tests._util import TIE_MARGIN, first_flip_margins, flip_budget, nchw_to_rows, planes_to_dense, record_parity
 
 pytestmark = pytest.mark.gpu
 LEVELS = [(192, 384), (96, 192), (48, 96), (24, 48), (12, 24)]
@@ -31,9 +31,34 @@ def test_rpn_head_full_size_vs_oracle(gpu_device, precision):
         bad += int((d > 1e-4).sum())
         assert float(d.max()) < 0.05
     # threshold ties flip ~1e-7 of the spikes between two fp32 summation orders (SURVEY §7 risk 1)
-    record_parity("rpn_head_full_size", precision=precision, positions_off_tolerance=bad, positions=total,
-                  budget=flip_budget(total, 256, 8))
-    assert bad <= flip_budget(total, 256, 8), "positions off-tolerance: %d of %d" % (bad, total)
+    budget = flip_budget(total, 256, 8, "rpn_randn", precision)
+    record_parity("rpn_head_full_size", precision=precision, positions_off_tolerance=bad, positions=total, budget=budget)
+    assert bad <= budget, "positions off-tolerance: %d of %d" % (bad, total)
+    # attribution on one level (96 x 192, b=2): every position off tolerance holds a flipped hidden spike, and every FIRST
+    # flipped spike sits within TIE_MARGIN of the threshold in the oracle's trace (stage-level launch of the same kernels)
+    if precision in ("bf16x3", "f32"):
+        from snn_automotive_object_detection_amd import ops
+        lvl = 1
+        h, w = LEVELS[lvl]
+        with torch.no_grad():
+            _, _, tr = OR.rpn_head_forward([feats[lvl]], m.shared_conv.weight.cpu(), m.conv_cls.weight.cpu(), m.conv_bbox.weight.cpu(), 8, trace=True)
+            _, _, vdec = OR.lif_scan_from_currents(tr[0]["cur"])
+        p = m._params()
+        enc = ops.encode_nchw(feats[lvl].to(gpu_device), 8, p)
+        if precision == "bf16x3":
+            spk = ops.conv3x3_lif_bf16x3(enc, [(2, h, w)], 256, 256, p, m._packed_shared())
+        else:
+            spk = ops.conv3x3_lif(enc, 2, 256, 256, h, w, p, m._packed_shared())
+        n_flip, margins, flipped = first_flip_margins(planes_to_dense(spk, 256), nchw_to_rows(tr[0]["spk"]), nchw_to_rows(vdec))
+        del tr, vdec
+        d_l = torch.maximum((logits[lvl].cpu() - o_l[lvl]).abs().amax(dim=1), (bbox[lvl].cpu() - o_b[lvl]).abs().amax(dim=1)).reshape(-1).numpy()
+        off_pos = np.nonzero(d_l > 1e-4)[0]
+        flipped_pos = flipped.any(axis=1)                                   # [positions]
+        record_parity("rpn_head_full_size_flips", precision=precision, level=lvl, flipped_neurons=n_flip,
+                      worst_margin=float(margins.max()) if n_flip else 0.0, positions_off_tolerance=int(off_pos.size),
+                      positions_with_flip=int(flipped_pos.sum()))
+        assert (margins <= TIE_MARGIN).all(), margins.max()
+        assert flipped_pos[off_pos].all(), "a position is off tolerance without any flipped hidden spike"
     # shared-LIF rates: the integer counts of the LIF epilogues against the oracle's own spike planes, per level and image
     counts = m.last_spike_counts.cpu().numpy()
     worst = 0
@@ -42,7 +67,7 @@ def test_rpn_head_full_size_vs_oracle(gpu_device, precision):
         gold = gold_counts[l].numpy()                                        # exact spike totals per image from the oracle
         diff = np.abs(counts[l, :2] - gold)
         worst = max(worst, int(diff.max()))
-        assert (diff <= 4 * flip_budget(2 * h * w, 256, 8)).all(), (l, counts[l, :2], gold)     # a flipped spike moves a count by a few
+        assert (diff <= 4 * flip_budget(2 * h * w, 256, 8, "rpn_randn", precision)).all(), (l, counts[l, :2], gold)     # a flipped spike moves a count by a few
         r = rates[3 * l][:, 0].cpu().numpy()
         assert np.array_equal(r, (counts[l, :2].astype(np.float64) / n_neur).astype(np.float32))     # rate = count / (T*C*H*W)
     record_parity("rpn_head_full_size_counts", precision=precision, worst_count_difference=worst)
@@ -56,14 +81,37 @@ def test_det_head_full_size_vs_oracle(gpu_device, precision):
     x = torch.randn((2000, 256, 7, 7), generator=g)
     m = S.FastRCNNPredictorSNNFull(12544, 1024, 9, 12)
     with torch.no_grad():
-        o_c, o_b = OR.det_head_forward(x, m.fc6.weight, m.fc7.weight, m.cls_score.weight, m.bbox_pred.weight, 12)
+        o_c, o_b, tr = OR.det_head_forward(x, m.fc6.weight, m.fc7.weight, m.cls_score.weight, m.bbox_pred.weight, 12, trace=True)
+    tr = {k: tr[k] for k in ("cur6", "spk6", "cur7", "spk7")}
     m = m.to(gpu_device)
     m.precision = precision
     cls, bbox = m(x.to(gpu_device))
     d = torch.maximum((cls.cpu() - o_c).abs().amax(dim=1), (bbox.cpu() - o_b).abs().amax(dim=1))
     bad = int((d > 1e-4).sum())                                            # RoIs holding a flipped spike
-    record_parity("det_head_full_size", precision=precision, rois_off_tolerance=bad, rois=2000, budget=flip_budget(2000, 2 * 1024, 12))
-    assert bad <= flip_budget(2000, 2 * 1024, 12), bad                     # two hidden layers of 1024 neurons, 12 steps
+    budget = flip_budget(2000, 2 * 1024, 12, "det", precision)             # two hidden layers of 1024 neurons, 12 steps
+    record_parity("det_head_full_size", precision=precision, rois_off_tolerance=bad, rois=2000, budget=budget)
+    assert bad <= budget, bad
+    if precision == "bf16x3":
+        # attribution (stage-level launches of the same kernels): first flipped lif6 spikes sit on threshold ties; lif7 is
+        # checked on the RoIs whose lif6 trains equal the oracle's (teacher-forced by construction there); every RoI off
+        # tolerance holds a flipped spike
+        from snn_automotive_object_detection_amd import ops
+        p = m._params()
+        w6, w7, _ = m._packed()
+        enc = ops.encode_rows(x.flatten(1).to(gpu_device), 12, p)
+        s6 = ops.spike_gemm_lif_bf16x3(enc, 12544, 1024, p, w6)
+        s7 = ops.spike_gemm_lif_bf16x3(s6, 1024, 1024, p, w7)
+        _, _, vdec6 = OR.lif_scan_from_currents(tr["cur6"])
+        _, _, vdec7 = OR.lif_scan_from_currents(tr["cur7"])
+        n6, marg6, fl6 = first_flip_margins(planes_to_dense(s6, 1024), tr["spk6"].numpy(), vdec6.numpy())
+        roi6 = fl6.any(axis=1)
+        g7, e7 = planes_to_dense(s7, 1024), tr["spk7"].numpy()
+        n7, marg7, fl7 = first_flip_margins(g7[:, ~roi6], e7[:, ~roi6], vdec7.numpy()[:, ~roi6])
+        roi_any = roi6 | (g7 != e7).any(axis=(0, 2))
+        record_parity("det_head_full_size_flips", lif6_flipped_neurons=n6, lif7_flipped_neurons_teacher_forced=n7,
+                      worst_margin=float(max([0.0] + list(marg6) + list(marg7))), rois_off_tolerance=bad, rois_with_flip=int(roi_any.sum()))
+        assert (marg6 <= TIE_MARGIN).all() and (marg7 <= TIE_MARGIN).all(), (marg6, marg7)
+        assert roi_any[(d > 1e-4).numpy()].all(), "a RoI is off tolerance without any flipped hidden spike"
     assert float(d.max()) < 0.1
     assert float(d.median()) < 1e-5
 
@@ -125,8 +173,8 @@ def test_bdd_shape_k11_vs_oracle(gpu_device):
         for l in range(5):
             d = torch.maximum((logits[l].cpu() - o_l[l]).abs().amax(1), (bbox[l].cpu() - o_b[l]).abs().amax(1))
             total += d.numel(); bad += int((d > 1e-4).sum())
-        record_parity("bdd_rpn_head", precision=precision, positions_off_tolerance=bad, positions=total, budget=flip_budget(total, 256, 8))
-        assert bad <= flip_budget(total, 256, 8), (precision, bad, total)
+        record_parity("bdd_rpn_head", precision=precision, positions_off_tolerance=bad, positions=total, budget=flip_budget(total, 256, 8, "rpn_randn", precision))
+        assert bad <= flip_budget(total, 256, 8, "rpn_randn", precision), (precision, bad, total)
     x = torch.randn((300, 256, 7, 7), generator=g)
     d = S.FastRCNNPredictorSNNFull(12544, 1024, 11, 12)
     with torch.no_grad():
@@ -135,8 +183,8 @@ def test_bdd_shape_k11_vs_oracle(gpu_device):
     cls, box = d(x.to(gpu_device))
     assert tuple(cls.shape) == (300, 11) and tuple(box.shape) == (300, 44)
     off = torch.maximum((cls.cpu() - o_c).abs().amax(1), (box.cpu() - o_d).abs().amax(1))
-    record_parity("bdd_det_head_k11", rois_off_tolerance=int((off > 1e-4).sum()), rois=300, budget=flip_budget(300, 2 * 1024, 12))
-    assert int((off > 1e-4).sum()) <= flip_budget(300, 2 * 1024, 12)
+    record_parity("bdd_det_head_k11", rois_off_tolerance=int((off > 1e-4).sum()), rois=300, budget=flip_budget(300, 2 * 1024, 12, "det"))
+    assert int((off > 1e-4).sum()) <= flip_budget(300, 2 * 1024, 12, "det")
 
 
 def test_stress_config_T16_T24_with_spike_rates(gpu_device):
@@ -231,8 +279,8 @@ def test_stress_config_full_canvas_T16_T24(gpu_device):
     for l in range(5):
         d = torch.maximum((logits[l].cpu() - o_l[l]).abs().amax(1), (bbox[l].cpu() - o_b[l]).abs().amax(1))
         total += d.numel(); bad += int((d > 1e-4).sum())
-    record_parity("stress_rpn_full_T16", positions_off_tolerance=bad, positions=total, budget=flip_budget(total, 256, 16))
-    assert bad <= flip_budget(total, 256, 16), (bad, total)
+    record_parity("stress_rpn_full_T16", positions_off_tolerance=bad, positions=total, budget=flip_budget(total, 256, 16, "rpn_randn"))
+    assert bad <= flip_budget(total, 256, 16, "rpn_randn"), (bad, total)
     counts = m.last_spike_counts.cpu().numpy()
     for l, (h, w) in enumerate(LEVELS):
         n_neur = 16 * 256 * h * w
@@ -250,8 +298,8 @@ def test_stress_config_full_canvas_T16_T24(gpu_device):
     cls, box = d(x.to(gpu_device))
     off = torch.maximum((cls.cpu() - o_c).abs().amax(1), (box.cpu() - o_d).abs().amax(1))
     n_off = int((off > 1e-4).sum())
-    record_parity("stress_det_full_T24", rois_off_tolerance=n_off, rois=2000, budget=flip_budget(2000, 2 * 1024, 24))
-    assert n_off <= flip_budget(2000, 2 * 1024, 24), n_off
+    record_parity("stress_det_full_T24", rois_off_tolerance=n_off, rois=2000, budget=flip_budget(2000, 2 * 1024, 24, "det"))
+    assert n_off <= flip_budget(2000, 2 * 1024, 24, "det"), n_off
     d.spike_rates = True
     r = d(x.to(gpu_device))
     c6, c7 = [c.cpu().numpy() for c in d.last_spike_counts]

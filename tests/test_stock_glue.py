@@ -174,3 +174,28 @@ def test_detector_skeleton_end_to_end_on_cpu_with_oracle_heads():
         assert torch.isfinite(d["boxes"]).all()
     with pytest.raises(NotImplementedError):
         m.train()([torch.rand(3, 64, 64)])
+
+
+def test_hip_gates_mirror_the_c_limits():
+    """ADVICE r2 / VERDICT r2 P-d: configurations outside snn_det_postprocess / snn_rpn_proposals limits take the stock path
+    (with a warning on the GPU) instead of raising from the C ABI; the gates are plain functions of the shapes"""
+    import torch
+    import snn_automotive_object_detection_amd as S
+    m = S.create_model("cityscapes", 9, True, True, 0, False, False, 4, 4)
+    rh, rpn = m.roi_heads, m.rpn
+    assert rh._hip_postprocess_refusal(2, 1000, 9) is None
+    assert rh._hip_postprocess_refusal(2, 1000, 82) is None                      # 81 x 100 = 8100 ranked candidates
+    assert "ranked" in rh._hip_postprocess_refusal(2, 1000, 84)                  # 83 x 100 > 8192
+    rh.detections_per_img = 300
+    assert "ranked" in rh._hip_postprocess_refusal(2, 1000, 40)                  # the advisor's example: 39 x 300
+    assert rh._hip_postprocess_refusal(2, 200, 40) is None                       # 39 x min(300, 200) = 7800
+    assert "RoIs" in rh._hip_postprocess_refusal(1, 10241, 9)
+    assert "images" in rh._hip_postprocess_refusal(65, 10, 9)
+    assert "classes" in rh._hip_postprocess_refusal(1, 10, 97)
+    lv = [torch.zeros(2, 3, 48, 80), torch.zeros(2, 3, 24, 40), torch.zeros(2, 3, 12, 20), torch.zeros(2, 3, 6, 10), torch.zeros(2, 3, 3, 5)]
+    assert rpn._hip_proposals_refusal(lv) is None                                # 4 x 1000 + 45 candidates
+    rpn._pre_nms_top_n = {"training": 5000, "testing": 5000}
+    assert "candidates" in rpn._hip_proposals_refusal(lv)                        # 5000 + 2880 + 720 + 180 + 45 > 8192
+    rpn._pre_nms_top_n = {"training": 1000, "testing": 1000}
+    assert "anchors" in rpn._hip_proposals_refusal([torch.zeros(1, 17, 4, 4)])
+    assert "images" in rpn._hip_proposals_refusal([torch.zeros(65, 3, 4, 4)])

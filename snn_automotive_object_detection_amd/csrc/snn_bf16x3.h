@@ -105,6 +105,8 @@ struct Gemm3Args {
     // launch at the Cityscapes pyramid).  Read by k_li_heads_mfma (LiHeadsArgs.half_split).
     int out_split;
     int xcd_classes, n_tiles;    // XCD-aware block order (0: plain row-major order), row tiles of the launch
+    int xcd_contig;              // > 0 (launches with 2 / 4 / 8 column blocks, conv): row tiles per XCD; XCD x = blockIdx % 8 runs column block
+                                 // x % n_blocks on a CONTIGUOUS range of row tiles, see the kernel
     // T-in-tile modes: the LAST n_short row-waves of the work-group multiply MT - 1 M-tiles instead of MT ("short" waves: the
     // last 16 of their rows do not exist), so a tile has 16 n_short fewer rows.  With n_short = half the row-waves every
     // SIMD hosts one full and one short wave: tile heights between the MT steps (512 / 448 / 384 / 320 / 256 rows on the
@@ -227,6 +229,18 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
         nb = 2 * (x % groups) + (j & 1);
         mb = (j >> 1) * args.xcd_classes + x / groups;
         if (mb >= args.n_tiles) return;
+    }
+    // xcd_contig (the 3x3 convolution: 2 column blocks): XCD x still sees ONE weight panel (column block x % n_blocks), but its row
+    // tiles are a contiguous range of the launch (the 8 / n_blocks XCDs of a column block take a quarter each) instead of every
+    // fourth tile.  A tile shares two thirds of its spike rows with the tiles one image row up and down (the 3x3 halo): with
+    // tiles of 32 positions those were 12 tiles away, i.e. on the same XCD by accident of 384 = 12 x 32; with the 36-position
+    // tiles of the 7-step window they landed on other XCDs and every XCD fetched the halo rows again (FETCH_SIZE 83 -> 172 MB per
+    // launch, L2 misses x 1.9: profiles/r3_a_*).  In a contiguous range the neighbours run on the same XCD a few slots apart.
+    if (args.xcd_contig) {
+        const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+        nb = x % args.n_blocks;
+        mb = (x / args.n_blocks) * args.xcd_contig + j;
+        if (j >= args.xcd_contig || mb >= args.n_tiles) return;
     }
     const int m0 = TILE ? mb * args.pb : mb * BM;            // first row (TILE: first position) of the tile
     const int Kc = args.Kc, Np = args.Np, M = args.M;

@@ -491,6 +491,10 @@ static int launch_gemm3(int mode, int mt, int wn, const Gemm3Args& a, hipStream_
     if (knobs().bf16x3_xcd && mt != 8 && (a.n_blocks == 4 || a.n_blocks == 8 || a.n_blocks == 16) && pair_bytes <= (size_t)2 << 20) {
         ax.xcd_classes = 8 / (a.n_blocks / 2);
         grid = cdiv(tiles, ax.xcd_classes) * ax.xcd_classes * a.n_blocks;
+    } else if (knobs().bf16x3_xcd && mt != 8 && a.n_blocks == 2 && (mode == G3_CONV || mode == G3_CONV_LIF_TILE) && tiles >= 64) {
+        // 3x3 convolution with two column blocks: a contiguous quarter of the row tiles per XCD (halo rows stay in one L2)
+        ax.xcd_contig = cdiv(tiles, 8 / a.n_blocks);
+        grid = ax.xcd_contig * 8;
     }
     hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return fail(-3, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));

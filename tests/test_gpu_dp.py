@@ -67,9 +67,6 @@ def test_dp_e2e_gathered_detections_equal_single_process(gpu_device):
     """config[3] for real at 2 ranks x 2 images (both ranks on device 0, gloo standing in for RCCL, which refuses two ranks on
     one device): whole model per rank on its contiguous image shard, all-gather of the decoded detections; the gathered list
     against the same shards run by ONE process, image by image (train.py:285-297, 598-601; coco_eval.py:158-177)."""
-    from snn_automotive_object_detection_amd import dp
-    import io
-    import contextlib
     env = {"SNN_DIST_BACKEND": "gloo", "SNN_DP_DEVICE": "0"}
     r = subprocess.run([sys.executable, "-c",
                         "import sys; sys.path.insert(0, %r)\nfrom snn_automotive_object_detection_amd import dp\n"
@@ -83,9 +80,7 @@ def test_dp_e2e_gathered_detections_equal_single_process(gpu_device):
     from tests._util import record_parity
     record_parity("dp_e2e_gathered_vs_single_process", **rep)
     for row in rep["per_image"]:
-        # the stock MIOpen backbone is not bitwise repeatable run to run on this hardware (tests/test_gpu_e2e.py computes its
-        # features once for that reason), so two runs of the same image may differ in a few threshold-tie spikes: the
-        # detections must agree in number and, where the counts agree, in labels, boxes and scores
-        assert abs(row["n_gathered"] - row["n_single"]) <= max(2, 0.02 * row["n_single"]), row
-        if row["n_gathered"] == row["n_single"] and row["n_single"] and row.get("labels_equal"):
-            assert row["max_score_diff"] < 5e-2, row
+        # (the child runs MIOpen's deterministic convolution solvers: torch.backends.cudnn.deterministic - with the default
+        # ones two passes of the same image differ by ~2e-5 in the pyramid, tools/probe_determinism.py)
+        assert row.get("single_process_repeatable", True), row
+        assert row["exact"], row

@@ -13,6 +13,7 @@ rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc2 -- $P > $OUT/pmc2.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc3 -- $P > $OUT/pmc3.log 2>&1
 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc4 -- $P > $OUT/pmc4.log 2>&1
+rocprofv3 --kernel-trace --pmc TCC_READ_sum TCC_REQ_sum --output-format csv -d $OUT/pmc5 -- $P > $OUT/pmc5.log 2>&1
 python3 tools/prof_summarize.py $OUT > $OUT/summary.txt 2>&1
 find $OUT -name "*.csv" -size +2M -delete
 find $OUT -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv

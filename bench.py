@@ -553,7 +553,8 @@ def main():
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as f:
                     traffic = json.load(f)[args.precision]["hbm_bytes_per_launch"]
-                traffic_source = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this launch, committed; not collected by this run)" % name
+                traffic_source = ("profiles/%s: 2 x FETCH_SIZE (gfx950 tallies 128-B requests at 64 B; calibrated for this access pattern, tools/fetch_calib.hip) "
+                                  "+ WRITE_SIZE, separate rocprofv3 --pmc passes of this launch, committed - NOT collected by this run" % name)
                 break
             except Exception:
                 pass

@@ -80,7 +80,7 @@ def test_dp_e2e_gathered_detections_equal_single_process(gpu_device):
     from tests._util import record_parity
     record_parity("dp_e2e_gathered_vs_single_process", **rep)
     for row in rep["per_image"]:
-        # (the child runs MIOpen's deterministic convolution solvers: torch.backends.cudnn.deterministic - with the default
-        # ones two passes of the same image differ by ~2e-5 in the pyramid, tools/probe_determinism.py)
+        # (the child runs the stock backbone's convolutions on the host: MIOpen's choices are neither repeatable run to run nor
+        # the same in two processes sharing a device - tools/probe_determinism.py; everything behind the backbone is on the GPU)
         assert row.get("single_process_repeatable", True), row
         assert row["exact"], row

@@ -371,7 +371,7 @@ def dp_e2e_leg(model, dev, rank, world, fence, iters=3):
 
     def one():
         dets = model(imgs)
-        return dets, dp.all_gather_detections(dets, max_det=1100, device=dev)
+        return dets, dp.all_gather_detections(dets, max_det=1100, device=dev, images_per_rank=DP_IMAGES_PER_RANK)   # ONE collective per batch
     for _ in range(2):
         dets, gathered = one()
     fence()
@@ -384,7 +384,7 @@ def dp_e2e_leg(model, dev, rank, world, fence, iters=3):
     for _ in range(5):                                           # the exchange by itself (pack + collective + unpack)
         fence()
         t1 = time.perf_counter()
-        gathered = dp.all_gather_detections(dets, max_det=1100, device=dev)
+        gathered = dp.all_gather_detections(dets, max_det=1100, device=dev, images_per_rank=DP_IMAGES_PER_RANK)
         torch.cuda.synchronize()
         xs.append((time.perf_counter() - t1) * 1e3)
     if world > 1:

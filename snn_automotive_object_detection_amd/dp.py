@@ -120,16 +120,23 @@ def all_gather_detection_tensors(payload: torch.Tensor, counts: torch.Tensor,
 
 
 def all_gather_detections(dets: List[Dict[str, torch.Tensor]], max_det: int = 1100,
-                          device: Optional[torch.device] = None) -> List[Dict[str, torch.Tensor]]:
+                          device: Optional[torch.device] = None, images_per_rank: Optional[int] = None) -> List[Dict[str, torch.Tensor]]:
     """every rank returns the detections of ALL images, in global image order (rank-major).  Ranks may pass
-    different numbers of images (also zero): the block size is agreed with one MAX all-reduce first."""
+    different numbers of images (also zero): the block size is agreed with one MAX all-reduce first - unless the caller
+    states it (``images_per_rank`` = the largest image count of any rank, e.g. ceil(batch / world) for ``shard_range``):
+    then the all-gather is the ONLY collective of the batch."""
     if device is None:
         device = dets[0]["boxes"].device if dets else torch.device("cpu")
     payload, counts = pack_detections(dets, max_det, device)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        n_max = torch.tensor([len(dets)], dtype=torch.int64, device=device if dist.get_backend() != "gloo" else "cpu")
-        dist.all_reduce(n_max, op=dist.ReduceOp.MAX)
-        n_max = int(n_max.item())
+        if images_per_rank is not None:
+            if images_per_rank < len(dets):
+                raise ValueError("images_per_rank = %d but this rank holds %d images" % (images_per_rank, len(dets)))
+            n_max = int(images_per_rank)
+        else:
+            n_max = torch.tensor([len(dets)], dtype=torch.int64, device=device if dist.get_backend() != "gloo" else "cpu")
+            dist.all_reduce(n_max, op=dist.ReduceOp.MAX)
+            n_max = int(n_max.item())
         if n_max > len(dets):                              # short rank: pad with rows marked count = -1
             pad = n_max - len(dets)
             payload = torch.cat([payload, payload.new_zeros((pad, max_det, 6))], 0)

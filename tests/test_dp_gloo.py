@@ -31,7 +31,11 @@ def _worker(rank, world, port, n_images, q, max_det=8):
     mine = dp.shard_range(n_images, rank, world)
     dets = [_make_dets(i) for i in mine]
     gathered = dp.all_gather_detections(dets, max_det=8)
-    ok = len(gathered) == n_images
+    # the caller may state the largest shard itself: then the all-gather is the only collective (same result)
+    stated = dp.all_gather_detections(dets, max_det=8, images_per_rank=(n_images + world - 1) // world)
+    ok = len(gathered) == n_images == len(stated)
+    for a, b in zip(gathered, stated):
+        ok &= all(torch.equal(a[k], b[k]) for k in ("boxes", "scores", "labels"))
     for i, d in enumerate(gathered):                      # global image order, truncated to max_det rows
         e = _make_dets(i)
         k = min(e["boxes"].shape[0], 8)

@@ -36,11 +36,11 @@ def nchw_to_rows(z: torch.Tensor) -> np.ndarray:
 #                             its digit planes round weights at 2^-29 of the block maximum)
 #   RPN behind the backbone : 35 of 196 416 (firing rates are 3x those of N(0,1) inputs) = 8.7e-8         -> rate 2.5e-7
 #   detector                : 0 - 2 of 2000 RoIs on N(0,1) (bf16x3 / f32), 8 in situ / mxfp6, 9 at T = 24 = 0 .. 1.6e-7 -> 2.5e-7
-# Every full-size test also ATTRIBUTES its flips (first_flip_margins): each first differing spike sits within 2e-5 of the
+# Every full-size test also ATTRIBUTES its flips (first_flip_margins): each first differing spike sits within TIE_MARGIN of the
 # threshold in the oracle's trace, so a regression that flips spikes away from ties fails whatever the count.
 FLIP_RATE = {"rpn_randn": 8e-8, "rpn_in_situ": 2.5e-7, "det": 2.5e-7}
 PRECISION_FACTOR = {"bf16x3": 1.0, "f32": 1.0, "mxfp6": 2.0}
-TIE_MARGIN = 2e-5
+TIE_MARGIN = 2e-6            # observed: every first flip sits within 5e-8 of the threshold (profiles/parity_r3.json)
 
 
 def flip_budget(positions: int, channels: int, steps: int, kind: str = "rpn_in_situ", precision: str = "bf16x3") -> float:

@@ -120,6 +120,14 @@ bad(lib.snn_rpn_rates(lv_ok, 2, 256, 3, 8, None, FAKE, FAKE, FAKE, FAKE, 1 << 20
 bad(lib.snn_rpn_rates(lv_ok, 2, 256, 3, 8, FAKE, FAKE, FAKE, FAKE, FAKE, 8, None), "rpn_rates small workspace")
 bad(lib.snn_det_rates(4, 64, 32, 3, 12, 8, 0, None, FAKE, FAKE, FAKE, FAKE, None), "det_rates null")
 bad(lib.snn_det_rates(4, 64, 32, 3, 12, 0, 0, FAKE, FAKE, FAKE, FAKE, FAKE, None), "det_rates T=0")
+o8 = (C.c_int32 * 8)()
+bad(lib.snn_debug_tile_shape(1, 1000, 256, 8, 0, 0, None), "tile_shape null out")
+bad(lib.snn_debug_tile_shape(1, 0, 256, 8, 0, 0, o8), "tile_shape no units")
+bad(lib.snn_debug_tile_shape(0, 2000, 1024, 33, 0, 6, o8), "tile_shape T > 32")
+assert lib.snn_debug_tile_shape(1, 196416, 256, 8, 0, 0, o8) == 0 and o8[4] == 7 and o8[2] == 256 and o8[3] == 36       # host-only call: 7 live steps
+assert lib.snn_debug_tile_shape(0, 2000, 1024, 12, 0, 6, o8) == 0 and o8[4] == 10 and o8[3] * o8[4] <= o8[2]
+assert lib.snn_debug_tile_shape(0, 2000, 1024, 12, 1, 6, o8) == 0 and o8[4] == 11                                      # spike-rate mode: fc6 0 .. T-2
+assert lib.snn_debug_tile_shape(0, 2000, 1024, 1, 0, 7, o8) == 0 and o8[4] == 1
 lib.snn_debug_reload_knobs()
 
 # ---- well-formed host tables, no device: the whole host half runs, the first launch (or attribute call) fails with -3 ----

@@ -9,6 +9,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
 // a_rate_256: spike probability of the A operand in 1/256; b_mode 0: zero weights, 1: random sign + 7 mantissa bits, exponent ~[-2,2)
+template <int SWAP>
 __global__ __launch_bounds__(512) void probe(const uint32_t* __restrict__ seed, float* out, unsigned long long* clk, int iters,
                                              int a_rate_256, int b_mode) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -38,7 +39,8 @@ __global__ __launch_bounds__(512) void probe(const uint32_t* __restrict__ seed, 
             bf16x8 b[3];
             for (int pl = 0; pl < 3; ++pl) b[pl] = *reinterpret_cast<const bf16x8*>(Bb + pl * 8192 + nt * 1024);
             for (int mt = 0; mt < 4; ++mt) for (int pl = 0; pl < 3; ++pl)
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b[pl], acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[pl], a[mt], acc[mt][nt], 0, 0, 0)
+                                   : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b[pl], acc[mt][nt], 0, 0, 0);
         }
     }
     float s = 0.f;
@@ -51,9 +53,10 @@ __global__ __launch_bounds__(512) void probe(const uint32_t* __restrict__ seed, 
     }
 }
 
+template <int SWAP>
 static void run(const char* name, int a_rate, int b_mode, const uint32_t* seed, float* out, unsigned long long* clk, double seconds) {
     const int iters = 2000, grid = 512;                  // ~2.6 ms per launch, two work-groups per CU
-    (void)hipFuncSetAttribute((const void*)probe, hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
+    (void)hipFuncSetAttribute((const void*)probe<SWAP>, hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     const double flop = (double)grid * 8 * iters * 64.0 * 64.0 * 32.0 * 2.0 * 3.0;
     auto t0 = std::chrono::steady_clock::now();
@@ -61,7 +64,7 @@ static void run(const char* name, int a_rate, int b_mode, const uint32_t* seed, 
     int round = 0;
     while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds) {
         (void)hipEventRecord(e0);
-        for (int i = 0; i < 50; ++i) hipLaunchKernelGGL(probe, dim3(grid), dim3(512), 81920, 0, seed, out, clk, iters, a_rate, b_mode);
+        for (int i = 0; i < 50; ++i) hipLaunchKernelGGL(probe<SWAP>, dim3(grid), dim3(512), 81920, 0, seed, out, clk, iters, a_rate, b_mode);
         (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
         float ms; (void)hipEventElapsedTime(&ms, e0, e1);
         last = 50 * flop / (ms * 1e-3) / 1e12;
@@ -80,11 +83,16 @@ int main() {
     (void)hipMalloc(&seed, 4096); (void)hipMalloc(&out, 512 * 512 * 4); (void)hipMalloc(&clk, 1024 * 8);
     uint32_t h[1024]; for (int i = 0; i < 1024; ++i) h[i] = i * 747796405u + 2891336453u;
     (void)hipMemcpy(seed, h, 4096, hipMemcpyHostToDevice);
-    run("A = 0, B = 0", 0, 0, seed, out, clk, 3.0);
-    run("A = 0, B random", 0, 1, seed, out, clk, 3.0);
-    run("A spikes 1/3 (the workload), B random", 85, 1, seed, out, clk, 3.0);
-    run("A spikes 1/2, B random", 128, 1, seed, out, clk, 3.0);
-    run("A all ones, B random", 256, 1, seed, out, clk, 3.0);
-    run("A spikes 1/3 (the workload), B random", 85, 1, seed, out, clk, 3.0);
+    run<0>("A = 0, B = 0", 0, 0, seed, out, clk, 3.0);
+    run<0>("A = 0, B random", 0, 1, seed, out, clk, 3.0);
+    run<0>("A spikes 1/3 (the workload), B random", 85, 1, seed, out, clk, 3.0);
+    run<0>("A spikes 1/2, B random", 128, 1, seed, out, clk, 3.0);
+    run<0>("A all ones, B random", 256, 1, seed, out, clk, 3.0);
+    run<0>("A spikes 1/3 (the workload), B random", 85, 1, seed, out, clk, 3.0);
+    // (round 3) the same with the operand roles swapped: weights as the MFMA's first operand, spikes as its second (the accumulator
+    // then holds the transposed tile) - does the multiplier array care which side is the sparse 0 / 1.0 one?
+    run<1>("SWAPPED: A random, B spikes 1/3", 85, 1, seed, out, clk, 3.0);
+    run<0>("A spikes 1/3 (the workload), B random", 85, 1, seed, out, clk, 3.0);
+    run<1>("SWAPPED: A random, B spikes 1/3", 85, 1, seed, out, clk, 3.0);
     return 0;
 }

@@ -105,6 +105,11 @@ struct Gemm3Args {
     // launch at the Cityscapes pyramid).  Read by k_li_heads_mfma (LiHeadsArgs.half_split).
     int out_split;
     int xcd_classes, n_tiles;    // XCD-aware block order (0: plain row-major order), row tiles of the launch
+    // T-in-tile modes, periods != 0 (snn_common.h: PERIOD PLANES): the A planes are the encoder's period planes e_n, row group n - 1 of
+    // a tile accumulates u_n = W e_n, and the LIF epilogue forms the current of step t as the sum of the row groups whose bit is
+    // set in div[t] (n - 1 for every divisor n <= Tc of t + 1), added in ascending n.  t0 = 0 in this mode.
+    int periods;
+    uint32_t div[SNN_MAX_STEPS];
     int xcd_contig;              // > 0 (launches with 2 / 4 / 8 column blocks, conv): row tiles per XCD; XCD x = blockIdx % 8 runs column block
                                  // x % n_blocks on a CONTIGUOUS range of row tiles, see the kernel
     // T-in-tile modes: the LAST n_short row-waves of the work-group multiply MT - 1 M-tiles instead of MT ("short" waves: the
@@ -590,6 +595,32 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
         uint32_t* const pos_cnt = reinterpret_cast<uint32_t*>(smem + G3_TILE_BYTES(WN));    // behind the tile image
         const bool counting = args.cnt_img != nullptr || args.cnt_row != nullptr;
         const int pb = args.pb, T = args.T, t0 = args.t0, t1 = args.t0 + args.Tc;      // currents of steps t0 .. t1-1 are in the tile
+        // input current of step t for the neuron whose tile column starts at src (row group g at src + g * pb * PITCH): +0 outside
+        // the window; the row group of the step, or - period planes - the sum of the row groups of the divisors of t + 1
+        const int group_stride = pb * PITCH;
+        const bool periods = args.periods != 0;
+        // (period planes: u_1 - row group 0 - is a term of every step, u_2 of every second, u_3 of every third: the caller reads the three
+        // once per neuron and passes them in; the larger divisors, one or two steps each, are read where they are needed)
+        auto tile_current = [&](const float* src, const int t, const float u1, const float u2, const float u3) {
+            float cur = 0.0f;
+            if (t >= t0 && t < t1) {
+                if (!periods) {
+                    cur = src[(size_t)(t - t0) * group_stride];
+                } else {
+                    uint32_t m = __builtin_amdgcn_readfirstlane(args.div[t]);        // wave-uniform; divisors in ascending order
+                    cur = u1;
+                    if (m & 2u) cur = __fadd_rn(cur, u2);
+                    if (m & 4u) cur = __fadd_rn(cur, u3);
+                    m &= ~7u;
+                    while (m) {
+                        const int g = __builtin_ctz(m);
+                        m &= m - 1;
+                        cur = __fadd_rn(cur, src[(size_t)g * group_stride]);
+                    }
+                }
+            }
+            return cur;
+        };
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // staged-ahead copies of chunks past the end have landed
 #pragma unroll 1
         for (int h = 0; h < 2; ++h) {
@@ -622,10 +653,11 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
                     float vv = args.p.v_leak, ii = 0.0f;
                     uint32_t my0 = 0, my1 = 0;             // lane t keeps the word pair of time step t
                     const float* src = tile + pi * PITCH + lane;
+                    const float u1 = periods ? src[0] : 0.0f, u2 = (periods && t1 > 1) ? src[group_stride] : 0.0f,
+                                u3 = (periods && t1 > 2) ? src[2 * group_stride] : 0.0f;
                     uint32_t cnt = 0;                      // wave-uniform: spikes of this position in this pass
                     for (int t = 0; t < T; ++t) {
-                        float cur = 0.0f;                  // steps outside the tile's window: no input current
-                        if (t >= t0 && t < t1) cur = src[(size_t)(t - t0) * pb * PITCH];
+                        const float cur = tile_current(src, t, u1, u2, u3);
                         const bool z = lif_step(cur, vv, ii, args.p);
                         const unsigned long long b = __ballot(z);
                         my0 = lane == t ? (uint32_t)b : my0;
@@ -658,10 +690,11 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
                     float vv = args.p.v_leak, ii = 0.0f;
                     uint32_t my0 = 0, my1 = 0;             // lane t keeps the words of (t, even position), (t, odd position)
                     const float* src = tile + (live ? pi : 2 * pp) * PITCH + col;
+                    const float u1 = periods ? src[0] : 0.0f, u2 = (periods && t1 > 1) ? src[group_stride] : 0.0f,
+                                u3 = (periods && t1 > 2) ? src[2 * group_stride] : 0.0f;
                     uint32_t cnt0 = 0, cnt1 = 0;           // wave-uniform: spikes of the even / odd position in this pass
                     for (int t = 0; t < T; ++t) {
-                        float cur = 0.0f;
-                        if (t >= t0 && t < t1) cur = src[(size_t)(t - t0) * pb * PITCH];
+                        const float cur = tile_current(src, t, u1, u2, u3);
                         const bool z = lif_step(cur, vv, ii, args.p);
                         const unsigned long long b = __ballot(z);
                         my0 = lane == t ? (uint32_t)b : my0;

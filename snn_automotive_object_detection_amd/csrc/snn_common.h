@@ -16,7 +16,24 @@ struct NeuronP {
     float v_leak;
     float v_reset;
     float v_th;
+    // encoders with zero rest / reset potentials only: the membrane value after a spike.  +0 = the reference's reset.
+    // ENC_FIRED (a huge negative number) = "period planes": the neuron then never crosses the threshold again, so plane
+    // t holds the neurons whose FIRST spike is at step t (see PERIOD PLANES below).
+    float v_fire;
 };
+#define ENC_FIRED (-1.0e30f)
+
+// PERIOD PLANES.  The constant-current encoder (lif_current_encoder with v = 0 at the start and reset to 0, which is what the
+// reference builds: rpn.py:58,93,101 / faster_rcnn.py:444,484,494) is exactly periodic: after a spike the membrane is +0 again,
+// the same state it started from, so the same fp32 operations repeat - the spike train of a neuron is
+//     z_t = 1  iff  n divides t + 1,      n = (index of its first spike) + 1,
+// and the encoder's spike planes are  z_t = OR over the divisors n of t + 1 of e_n  with DISJOINT planes e_n = (period == n).
+// A bias-free layer is linear, so its input currents are  cur_t = W z_t = sum over n | (t + 1) of u_n,  u_n = W e_n:  the
+// matrix-core kernels multiply the e_n planes (for the bench's features: densities 0.27, 0.09, 0.03, 0.02, ... against
+// 0.27-0.40 for every z_t plane) and the LIF epilogue adds up the u_n of the divisors (Gemm3Args.periods).  Same MFMA count,
+// but the kernels are power-limited and a quarter of the operand switching buys clock: conv+LIF -4 %, fc6+LIF -8 % on the
+// bench's planes (tools/period_probe.py).  The sums are fp32 additions of partial chains - as accurate as one chain
+// (shorter chains, 1-3 extra roundings); against the oracle the results are one more fp32 summation order.
 
 // lif_current_encoder (norse/torch/functional/lif.py; reference rpn.py:101, faster_rcnn.py:494)
 //   dv = dt*tau_mem_inv * ((v_leak - v) + x);  v = v + dv;  z = (v - v_th > 0);  v = v - z*(v - v_reset)
@@ -39,8 +56,9 @@ template <bool ZR>
 __device__ __forceinline__ void enc_step_word(const float x, float& v, const NeuronP& p, uint32_t& word) {
     if (ZR) {
         v = __fadd_rn(v, __fmul_rn(p.ca, __fsub_rn(x, v)));
-        asm("v_cmp_lt_f32 vcc, %2, %1\n\tv_cndmask_b32 %1, %1, 0, vcc\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
-            : "+v"(word), "+v"(v) : "s"(p.v_th) : "vcc");
+        const float fire = p.v_fire;                    // +0 (the reset) or ENC_FIRED (period planes): one loop-invariant register
+        asm("v_cmp_lt_f32 vcc, %2, %1\n\tv_cndmask_b32 %1, %1, %3, vcc\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+            : "+v"(word), "+v"(v) : "s"(p.v_th), "v"(fire) : "vcc");
     } else {
         v = __fadd_rn(v, __fmul_rn(p.ca, __fadd_rn(__fsub_rn(p.v_leak, v), x)));
         const float th = __fsub_rn(v, p.v_th), vr = __fsub_rn(v, __fsub_rn(v, p.v_reset));
@@ -54,7 +72,7 @@ __device__ __forceinline__ bool enc_step_t(const float x, float& v, const Neuron
     if (ZR) {
         v = __fadd_rn(v, __fmul_rn(p.ca, __fsub_rn(x, v)));
         const bool z = v > p.v_th;
-        v = z ? 0.0f : v;
+        v = z ? p.v_fire : v;
         return z;
     }
     return enc_step(x, v, p);

@@ -295,7 +295,9 @@ __global__ __launch_bounds__(256) void k_roi_align_encode(const RoiArgs a) {
     const size_t e = (size_t)r * a.Dw * 32 + d;
     const bool in = d < a.Dw * 32;
     for (int t = 0; t < a.T; ++t) {
-        const bool z = enc_step(val, v, a.p) && d < D;
+        const bool zz = enc_step(val, v, a.p);
+        v = (zz && a.p.v_fire != 0.0f) ? a.p.v_fire : v;         // period planes (zero rest / reset potentials only): never fires again
+        const bool z = zz && d < D;
         const unsigned long long m = __ballot(z);
         if ((lane & 31) == 0 && in)
             a.planes[(size_t)t * a.plane_stride + (e >> 5)] = (lane < 32) ? (uint32_t)m : (uint32_t)(m >> 32);
@@ -316,7 +318,9 @@ __global__ __launch_bounds__(256) void k_roi_align_encode_wm(const RoiArgs a) {
         const float val = d < D ? roi_pool_element(a, r, d) : 0.0f;
         float v = 0.0f;
         for (int t = 0; t < a.T; ++t) {
-            const bool z = enc_step(val, v, a.p) && d < D;
+            const bool zz = enc_step(val, v, a.p);
+            v = (zz && a.p.v_fire != 0.0f) ? a.p.v_fire : v;     // period planes
+            const bool z = zz && d < D;
             const unsigned long long m = __ballot(z);
             if (lane == 0) { wbuf[(t * 2 + 0) * 32 + rl] = (uint32_t)m; wbuf[(t * 2 + 1) * 32 + rl] = (uint32_t)(m >> 32); }
         }

@@ -54,6 +54,7 @@ static NeuronP make_p(const snn_params* p, float v_th) {
     NeuronP q;
     q.ca = p->dt_tau_mem; q.cb = p->neg_dt_tau_syn; q.v_leak = p->v_leak; q.v_reset = p->v_reset;
     q.v_th = v_th;
+    q.v_fire = 0.0f;
     return q;
 }
 
@@ -137,6 +138,10 @@ struct Knobs {
     bool bf16x3_xcd;         // SNN_BF16X3_XCD=0      plain block order instead of the XCD-aware one (A/B)
     bool stage_wm;           // SNN_STAGE_PLANES=wm   A/B harness only: snn_conv3x3_lif_bf16x3 / snn_spike_gemm_lif_bf16x3 take their
                              //                       INPUT planes word-major ([T][word][row]; tools/ab_conv.py)
+    bool periods;            // SNN_PERIOD_PLANES=0   the whole heads multiply the encoder's spike planes z_t instead of its period planes e_n
+                             //                       (snn_common.h; default: period planes on the bf16x3 tile path with zero rest / reset potentials)
+    bool stage_periods;      // SNN_STAGE_PERIODS=1   tests / tools: the STAGE-level encoders emit period planes and the stage-level fused launches
+                             //                       (snn_conv3x3_lif_bf16x3, snn_spike_gemm_lif_bf16x3) take their input planes as such
     bool dead_keep;          // SNN_DEAD_STEPS=keep   form the input currents of ALL time steps (A/B + test switch: the default
                              //                       skips the steps whose currents cannot reach an output, lif_windows)
     int planes;              // SNN_PLANES=rm|wm      internal spike planes of the bf16x3 heads: all row-major [T][row][word] / all
@@ -165,6 +170,8 @@ static Knobs load_knobs() {
     k.spk_rows = (e = getenv("SNN_SPK_SPLIT")) && e[0] == '0';
     k.stage_wm = (e = getenv("SNN_STAGE_PLANES")) && !strcmp(e, "wm");
     k.dead_keep = (e = getenv("SNN_DEAD_STEPS")) && !strcmp(e, "keep");
+    k.periods = !((e = getenv("SNN_PERIOD_PLANES")) && e[0] == '0');
+    k.stage_periods = (e = getenv("SNN_STAGE_PERIODS")) && e[0] == '1';
     return k;
 }
 static Knobs& knobs() {
@@ -174,6 +181,11 @@ static Knobs& knobs() {
 
 // encoder fast path: Norse's default rest / reset potentials
 static bool enc_zero_rest(const NeuronP& p) { return p.v_leak == 0.0f && p.v_reset == 0.0f && !knobs().enc_generic; }
+
+// period planes (snn_common.h): the encoder's spike trains are exactly periodic when it starts from and resets to +0
+static bool periods_possible(const snn_params* p) {
+    return p->precision == SNN_PRECISION_BF16X3 && p->v_leak == 0.0f && p->v_reset == 0.0f && !knobs().enc_generic && !knobs().bf16x3_lif_reg;
+}
 
 static int g3_slots() {                       // CUs: two co-resident work-groups share a CU's matrix pipe, so the tail is
                                               // quantised per CU, not per work-group slot (fc6: MT=4 1.03 ms, MT=3 1.07 ms)
@@ -546,10 +558,23 @@ int snn_spike_gemm_bf16x3(const uint32_t* a_rows, int M, int K, int N, const uin
     return launch_gemm3(G3_FC, mt, wn, a, (hipStream_t)s);
 }
 
+// period planes: row group n - 1 of a tile holds u_n = W e_n; the current of step t < Tc is the sum over the divisors n <= Tc of t + 1
+static int set_periods(Gemm3Args& a, const char* who) {
+    if (a.t0 != 0) return fail(-1, "%s: period planes need a window that starts at step 0", who);
+    a.periods = 1;
+    for (int t = 0; t < SNN_MAX_STEPS; ++t) {
+        a.div[t] = 0;
+        if (t < a.Tc)
+            for (int n = 1; n <= a.Tc; ++n)
+                if ((t + 1) % n == 0) a.div[t] |= 1u << (n - 1);
+    }
+    return 0;
+}
+
 // row_counts (nullable, zeroed by the caller): spikes per row over all T steps and N columns, added by the LIF epilogue
 static int spike_gemm_lif_bf16x3_impl(const uint32_t* a_planes, int T, int R, int K, int N, const snn_params* p,
                                       const uint16_t* w_packed, uint32_t* spk, size_t spk_stride, uint32_t* row_counts, snn_stream_t s,
-                                      bool wm_in = false, bool wm_out = false, const StepWindow* win = nullptr) {
+                                      bool wm_in = false, bool wm_out = false, const StepWindow* win = nullptr, bool periods = false) {
     if (!a_planes || !w_packed || !spk || !p || R <= 0 || K <= 0 || N <= 0)
         return fail(-1, "snn_spike_gemm_lif_bf16x3: bad argument");
     if (check_T(T, "snn_spike_gemm_lif_bf16x3")) return -1;
@@ -568,12 +593,14 @@ static int spike_gemm_lif_bf16x3_impl(const uint32_t* a_planes, int T, int R, in
     const G3Tile tl = g3_pick_tile(wn, [&](int rows) { return g3_tile_ok(Tc, rows) ? (long long)cdiv(R, rows / Tc) * a.n_blocks : 0ll; });
     if (!tl.mt) return fail(-4, "snn_spike_gemm_lif_bf16x3: T=%d does not fit a row tile (use snn_spike_gemm_bf16x3 + snn_lif_scan)", T);
     a.pb = tl.rows / Tc; a.n_short = tl.n_short;
+    if (periods && set_periods(a, "snn_spike_gemm_lif_bf16x3")) return -1;
     return launch_gemm3(G3_FC_LIF_TILE, tl.mt, wn, a, (hipStream_t)s);
 }
 
 int snn_spike_gemm_lif_bf16x3(const uint32_t* a_planes, int T, int R, int K, int N, const snn_params* p,
                               const uint16_t* w_packed, uint32_t* spk, size_t spk_stride, snn_stream_t s) {
-    return spike_gemm_lif_bf16x3_impl(a_planes, T, R, K, N, p, w_packed, spk, spk_stride, nullptr, s, knobs().stage_wm, false);
+    return spike_gemm_lif_bf16x3_impl(a_planes, T, R, K, N, p, w_packed, spk, spk_stride, nullptr, s, knobs().stage_wm, false, nullptr,
+                                      knobs().stage_periods);
 }
 
 // ---- spike GEMMs on the block-scaled fp4 x fp6 path (snn_mx.h) ------------------------------------
@@ -739,7 +766,7 @@ static int count_spikes_per_image(const snn_rpn_level* lv, int n_levels, int Cw,
 static int conv3x3_lif_bf16x3_impl(const uint32_t* enc, size_t enc_stride, const snn_rpn_level* lv, int n_levels, int C_in,
                                    int C_out, int T, const snn_params* p, const uint16_t* w_packed, uint32_t* spk,
                                    size_t spk_stride, unsigned long long* counts, int max_n, snn_stream_t s, bool wm = false,
-                                   bool* out_split = nullptr) {
+                                   bool* out_split = nullptr, bool periods = false) {
     // out_split (in: wanted, out: done): spike planes in blocks of four words (Gemm3Args.out_split; T-in-tile kernels only)
     const bool want_split = out_split && *out_split;
     if (out_split) *out_split = false;
@@ -765,6 +792,7 @@ static int conv3x3_lif_bf16x3_impl(const uint32_t* enc, size_t enc_stride, const
         tl = g3_pick_tile(wn, [&](int rows) { return g3_tile_ok(Tc, rows) ? (long long)cdiv(P, rows / Tc) * a.n_blocks : 0ll; });
     }
     if (!tl.mt) {                                     // register-fused fallback: counts from the planes afterwards
+        if (periods) return fail(-4, "snn_conv3x3_lif_bf16x3: period planes need the T-in-tile kernel (T=%d does not fit a row tile)", T);
         a.n_blocks = cdiv(a.Np, G3_BN(2));
         rc = launch_gemm3(G3_CONV_LIF_REG, 4, 2, a, (hipStream_t)s);
         if (rc || !counts) return rc;
@@ -773,6 +801,7 @@ static int conv3x3_lif_bf16x3_impl(const uint32_t* enc, size_t enc_stride, const
     a.pb = tl.rows / Tc; a.n_short = tl.n_short;
     a.cnt_img = counts; a.max_n = max_n;
     if (want_split && a.Np % 128 == 0) { a.out_split = 1; *out_split = true; }
+    if (periods && set_periods(a, "snn_conv3x3_lif_bf16x3")) return -1;
     return launch_gemm3(G3_CONV_LIF_TILE, tl.mt, wn, a, (hipStream_t)s);
 }
 
@@ -780,7 +809,7 @@ int snn_conv3x3_lif_bf16x3(const uint32_t* enc, size_t enc_stride, const snn_rpn
                            int C_out, int T, const snn_params* p, const uint16_t* w_packed, uint32_t* spk,
                            size_t spk_stride, snn_stream_t s) {
     return conv3x3_lif_bf16x3_impl(enc, enc_stride, lv, n_levels, C_in, C_out, T, p, w_packed, spk, spk_stride, nullptr, 0, s,
-                                   knobs().stage_wm);
+                                   knobs().stage_wm, nullptr, knobs().stage_periods && !knobs().bf16x3_lif_reg);
 }
 
 // spikes per (level, image) from finished planes: one launch per level (fallback of the register-fused conv variant only)
@@ -822,7 +851,8 @@ int snn_encode_nchw(const float* feat, int N, int C, int H, int W, int T, const 
         return fail(-1, "snn_encode_nchw: bad argument");
     if (check_T(T, "snn_encode_nchw")) return -1;
     const int Cw = cdiv(C, 32), HW = H * W;
-    const NeuronP np = make_p(p, p->v_th_enc);
+    NeuronP np = make_p(p, p->v_th_enc);
+    if (knobs().stage_periods && enc_zero_rest(np)) np.v_fire = ENC_FIRED;      // (tests / tools: period planes)
     if (enc_zero_rest(np))
         hipLaunchKernelGGL(k_encode_nchw<true>, dim3(cdiv(HW, ENC_PB), cdiv(Cw, 8), N), dim3(256), 0, (hipStream_t)s, feat, C, HW, Cw, T, np, planes, plane_stride);
     else
@@ -850,12 +880,16 @@ int snn_affine_act_nchw(const float* x, const float* scale, const float* bias, c
 static bool encode_rows_wm_ok(const float* x, int D) { return D % 32 == 0 && ((uintptr_t)x & 15) == 0; }
 
 static int encode_rows_impl(const float* x, int R, int D, int T, const snn_params* p, uint32_t* planes,
-                            size_t plane_stride, bool wm, snn_stream_t s) {
+                            size_t plane_stride, bool wm, snn_stream_t s, bool periods = false) {
     if (!x || !planes || !p || R <= 0 || D <= 0) return fail(-1, "snn_encode_rows: bad argument");
     if (check_T(T, "snn_encode_rows")) return -1;
     const int Dw = cdiv(D, 32);
     const size_t total = (size_t)R * Dw * 32;
-    const NeuronP np = make_p(p, p->v_th_enc);
+    NeuronP np = make_p(p, p->v_th_enc);
+    if (periods) {
+        if (!enc_zero_rest(np)) return fail(-1, "snn_encode_rows: period planes need zero rest / reset potentials");
+        np.v_fire = ENC_FIRED;
+    }
     if (wm) {
         if (!encode_rows_wm_ok(x, D)) return fail(-1, "snn_encode_rows: word-major planes need D %% 32 == 0 and 16-byte aligned rows");
         const dim3 g(cdiv(Dw, 8), cdiv(R, 32));
@@ -881,7 +915,8 @@ static int encode_rows_impl(const float* x, int R, int D, int T, const snn_param
 
 int snn_encode_rows(const float* x, int R, int D, int T, const snn_params* p, uint32_t* planes,
                     size_t plane_stride, snn_stream_t s) {
-    return encode_rows_impl(x, R, D, T, p, planes, plane_stride, false, s);
+    return encode_rows_impl(x, R, D, T, p, planes, plane_stride, false, s,
+                            knobs().stage_periods && p && p->v_leak == 0.0f && p->v_reset == 0.0f && !knobs().enc_generic);
 }
 
 
@@ -911,7 +946,7 @@ int snn_nms_sorted(const float* boxes_sorted, const int* category_sorted, int n,
 
 static int roi_align_encode_impl(const snn_roi_level* levels_host, int n_levels, int C, const float* rois, const int* roi_batch,
                                  const int* roi_level, int R, int T, const snn_params* p, uint32_t* planes,
-                                 size_t plane_stride, float* pooled_dbg, bool wm, snn_stream_t s) {
+                                 size_t plane_stride, float* pooled_dbg, bool wm, snn_stream_t s, bool periods = false) {
     if (!levels_host || n_levels <= 0 || n_levels > 4 || C <= 0 || !rois || !roi_batch || !roi_level || R <= 0 || !p ||
         !planes)
         return fail(-1, "snn_roi_align_encode: bad argument");
@@ -927,6 +962,10 @@ static int roi_align_encode_impl(const snn_roi_level* levels_host, int n_levels,
     a.rois = rois; a.roi_batch = roi_batch; a.roi_level = roi_level; a.pooled = pooled_dbg; a.planes = planes;
     a.plane_stride = plane_stride; a.R = R; a.C = C; a.T = T; a.Dw = cdiv(C * 49, 32);
     a.p = make_p(p, p->v_th_enc);
+    if (periods) {
+        if (a.p.v_leak != 0.0f || a.p.v_reset != 0.0f) return fail(-1, "snn_roi_align_encode: period planes need zero rest / reset potentials");
+        a.p.v_fire = ENC_FIRED;
+    }
     if (wm) hipLaunchKernelGGL(k_roi_align_encode_wm, dim3(cdiv(a.Dw, 2), cdiv(R, 32)), dim3(256), 0, (hipStream_t)s, a);
     else hipLaunchKernelGGL(k_roi_align_encode, dim3(cdiv(a.Dw * 32, 256), R), dim3(256), 0, (hipStream_t)s, a);
     SNN_CHECK_LAUNCH("k_roi_align_encode");
@@ -937,7 +976,7 @@ int snn_roi_align_encode(const snn_roi_level* levels_host, int n_levels, int C, 
                          const int* roi_level, int R, int T, const snn_params* p, uint32_t* planes,
                          size_t plane_stride, float* pooled_dbg, snn_stream_t s) {
     return roi_align_encode_impl(levels_host, n_levels, C, rois, roi_batch, roi_level, R, T, p, planes, plane_stride, pooled_dbg,
-                                 false, s);
+                                 false, s, knobs().stage_periods && p && p->v_leak == 0.0f && p->v_reset == 0.0f);
 }
 
 // shared by snn_conv3x3_lif (one level) and snn_rpn_head_forward (all levels in one launch)
@@ -1173,6 +1212,9 @@ int snn_rpn_head_forward_stages(const snn_rpn_level* lv, int n_levels, int C, in
     const size_t stride = (size_t)P * Cw;            // words per time plane (spike planes)
     const size_t enc_stride = (size_t)Pe * Cw;       // ... of the encoder planes
     const int Tc = lif_window_full_out(T).n;         // encoder planes / conv currents of steps 0 .. Tc-1 (dead time steps: T-1)
+    // period planes (snn_common.h): the encoder writes e_n = (first spike at step n - 1), the conv tile accumulates u_n = W e_n and
+    // its LIF epilogue adds up the divisors' u_n - a quarter of the operand switching in the power-limited matrix-core loop
+    const bool per = knobs().periods && periods_possible(p) && g3_some_tile_ok(Tc, true);
     // bf16x3 conv -> LI heads: spike planes in blocks of four words when the heads kernel that will run reads them so (C = 256).
     // Decided up front, so that a stage-by-stage caller (bench.py's kernel breakdown) sees the same launches; a T that does
     // not fit a row tile runs the register-fused conv, which writes plain rows: then the heads read plain rows
@@ -1211,7 +1253,8 @@ int snn_rpn_head_forward_stages(const snn_rpn_level* lv, int n_levels, int C, in
             hipLaunchKernelGGL(k_zero_halo, dim3(images, 32), dim3(256), 0, s, hl, Cw, Tc, enc, enc_stride, wm_rows);
             SNN_CHECK_LAUNCH("k_zero_halo");
         }
-        const NeuronP np = make_p(p, p->v_th_enc);
+        NeuronP np = make_p(p, p->v_th_enc);
+        if (per) np.v_fire = ENC_FIRED;
         if (enc_zero_rest(np))
             hipLaunchKernelGGL(k_encode_levels<true>, dim3(blocks, cdiv(Cw, 8)), dim3(256), 0, s, el, C, Cw, Tc, np, enc, enc_stride, wm_rows);
         else
@@ -1238,7 +1281,7 @@ int snn_rpn_head_forward_stages(const snn_rpn_level* lv, int n_levels, int C, in
                          ? conv3x3_lif_mx_impl(enc, enc_stride, lv, n_levels, C, C, T, p, (const uint32_t*)w_shared_packed, spk, stride,
                                                spike_counts, max_n, stream)
                          : conv3x3_lif_bf16x3_impl(enc, enc_stride, lv, n_levels, C, C, T, p, (const uint16_t*)w_shared_packed,
-                                                   spk, stride, spike_counts, max_n, stream, wm_rows != 0, &split);
+                                                   spk, stride, spike_counts, max_n, stream, wm_rows != 0, &split, per);
             if (rc) return rc;
         }
     }
@@ -1524,7 +1567,7 @@ static bool det_planes_wm(const snn_params* p, const DetWindows& w) { return det
 static int det_head_from_planes(int R, int D, int Hd, int K, int K4, int T, const snn_params* p, const void* w6_packed,
                                 const void* w7_packed, const float* w_heads_packed, float* out_cls, float* out_bbox,
                                 uint32_t* spk6_count, uint32_t* spk7_count, float* sum_cls, float* sum_bbox, void* ws,
-                                bool enc_wm, const DetWindows& win, snn_stream_t stream) {
+                                bool enc_wm, const DetWindows& win, bool enc_periods, snn_stream_t stream) {
     size_t o_enc, o_cur, o_s6, o_s7, need;
     det_ws_layout(R, D, Hd, T, &o_enc, &o_cur, &o_s6, &o_s7, &need);
     hipStream_t s = (hipStream_t)stream;
@@ -1548,14 +1591,14 @@ static int det_head_from_planes(int R, int D, int Hd, int K, int K4, int T, cons
         return snn_li_heads(s7, (size_t)R * Hw, T, R, Hd, w_heads_packed, K, K4, p, out_cls, out_bbox, sum_cls,
                             sum_bbox, stream);
     }
-    if (enc_wm && !det_b3_tiles(p, win)) return fail(-1, "snn_det_head_forward: word-major planes without the fused bf16x3 layers");
+    if ((enc_wm || enc_periods) && !det_b3_tiles(p, win)) return fail(-1, "snn_det_head_forward: word-major / period planes without the fused bf16x3 layers");
     if (det_b3_tiles(p, win)) {
         // fc6 + LIF and fc7 + LIF, each one launch: a row tile holds all T steps of its RoIs, the currents never
         // leave the chip (faster_rcnn.py:498-501)
         // (spike-rate mode: per-RoI counts come out of the LIF epilogues)
         // (word-major planes between the stages: encoder -> fc6 -> fc7; fc7's spikes feed the LI heads row-major)
         // (dead time steps, lif_windows: fc6 forms the currents of steps 0 .. T-3, fc7 of steps 1 .. T-2)
-        if ((rc = spike_gemm_lif_bf16x3_impl(enc, T, R, D, Hd, p, (const uint16_t*)w6_packed, s6, (size_t)R * Hw, spk6_count, stream, enc_wm, enc_wm, &win.fc6))) return rc;
+        if ((rc = spike_gemm_lif_bf16x3_impl(enc, T, R, D, Hd, p, (const uint16_t*)w6_packed, s6, (size_t)R * Hw, spk6_count, stream, enc_wm, enc_wm, &win.fc6, enc_periods))) return rc;
         if ((rc = spike_gemm_lif_bf16x3_impl(s6, T, R, Hd, Hd, p, (const uint16_t*)w7_packed, s7, (size_t)R * Hw, spk7_count, stream, enc_wm, false, &win.fc7))) return rc;
         return snn_li_heads(s7, (size_t)R * Hw, T, R, Hd, w_heads_packed, K, K4, p, out_cls, out_bbox, sum_cls,
                             sum_bbox, stream);
@@ -1588,10 +1631,11 @@ int snn_det_head_forward(const float* x, int R, int D, int Hd, int K, int K4, in
     if (ws_bytes < need) return fail(-2, "snn_det_head_forward: workspace %zu < %zu bytes", ws_bytes, need);
     const DetWindows win = det_windows(p, T, spk6_count != nullptr);
     const bool wm = det_planes_wm(p, win) && encode_rows_wm_ok(x, D);
-    int rc = encode_rows_impl(x, R, D, win.enc_steps, p, (uint32_t*)((char*)ws + o_enc), (size_t)R * cdiv(D, 32), wm, stream);
+    const bool per = knobs().periods && periods_possible(p) && det_b3_tiles(p, win);      // fc6 on the encoder's period planes (snn_common.h)
+    int rc = encode_rows_impl(x, R, D, win.enc_steps, p, (uint32_t*)((char*)ws + o_enc), (size_t)R * cdiv(D, 32), wm, stream, per);
     if (rc) return rc;
     return det_head_from_planes(R, D, Hd, K, K4, T, p, w6_packed, w7_packed, w_heads_packed, out_cls, out_bbox,
-                                spk6_count, spk7_count, sum_cls, sum_bbox, ws, wm, win, stream);
+                                spk6_count, spk7_count, sum_cls, sum_bbox, ws, wm, win, per, stream);
 }
 
 int snn_det_head_forward_roialign(const snn_roi_level* levels_host, int n_levels, int C, const float* rois,
@@ -1610,11 +1654,12 @@ int snn_det_head_forward_roialign(const snn_roi_level* levels_host, int n_levels
     if (check_T(T, "snn_det_head_forward_roialign")) return -1;
     const DetWindows win = det_windows(p, T, spk6_count != nullptr);
     const bool wm = det_planes_wm(p, win);
+    const bool per = knobs().periods && periods_possible(p) && det_b3_tiles(p, win);
     int rc = roi_align_encode_impl(levels_host, n_levels, C, rois, roi_batch, roi_level, R, win.enc_steps, p,
-                                   (uint32_t*)((char*)ws + o_enc), (size_t)R * cdiv(D, 32), nullptr, wm, stream);
+                                   (uint32_t*)((char*)ws + o_enc), (size_t)R * cdiv(D, 32), nullptr, wm, stream, per);
     if (rc) return rc;
     return det_head_from_planes(R, D, Hd, K, K4, T, p, w6_packed, w7_packed, w_heads_packed, out_cls, out_bbox,
-                                spk6_count, spk7_count, sum_cls, sum_bbox, ws, wm, win, stream);
+                                spk6_count, spk7_count, sum_cls, sum_bbox, ws, wm, win, per, stream);
 }
 
 int snn_det_exchange_payload(const float* class_logits, const float* box_regression, int N, int rois_per_image, int K,

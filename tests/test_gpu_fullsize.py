@@ -231,8 +231,10 @@ def test_stress_config_T16_T24_with_spike_rates(gpu_device):
         assert int((c != gold).sum()) <= flip_budget(64, 1024, 24), (j, int((c != gold).sum()))
         assert np.array_equal(r[j][:, 0].cpu().numpy(), (c.astype(np.float64) / (24 * 1024)).astype(np.float32))
         assert torch.equal(r[j][:, 1].cpu(), o[j][:, 1])
-    for j in (2, 3):                                           # LI "rates": means of membrane sums
-        assert torch.allclose(r[j].cpu(), o[j], rtol=1e-4, atol=2e-5)
+    same = torch.from_numpy((c6 == gd[0].numpy()) & (c7 == gd[1].numpy()))      # RoIs whose hidden spike counts equal the oracle's
+    assert int((~same).sum()) <= flip_budget(64, 2 * 1024, 24, "det")
+    for j in (2, 3):                                           # LI "rates": means of membrane sums (a flipped spike moves them)
+        assert torch.allclose(r[j].cpu()[same], o[j][same], rtol=1e-4, atol=2e-5)
 
 
 def test_heads_are_hipgraph_capturable(gpu_device):

@@ -408,7 +408,7 @@ def sweep_t_leg(leg, iters=8):
     heads are independent, so 9 + 9 timings.  `steps` = time steps whose contractions are executed (dead ones removed),
     `ms_per_step` relative to the headline T (8 / 12), tile shape and fill as the launcher picks them (snn_debug_tile_shape)."""
     import ctypes as Ct
-    from snn_automotive_object_detection_amd import _lib
+    from snn_automotive_object_detection_amd import _lib, ops
     lib = _lib.load()
     out32 = (Ct.c_int32 * 8)()
     pos = sum(int(f.shape[0] * f.shape[2] * f.shape[3]) for f in leg.feats)
@@ -420,8 +420,10 @@ def sweep_t_leg(leg, iters=8):
             leg.rpn_head.num_steps = T
             leg.rpn_head(leg.feats)
             ms = leg.time_ms(lambda: leg.rpn_head(leg.feats), iters)
+            p_, w_sh, w_hd = leg.rpn_head._params(), leg.rpn_head._packed_shared(), leg.rpn_head._cache_heads.val
+            conv_ms = leg.time_ms(lambda: ops.rpn_head_forward(leg.feats, C, A, T, p_, w_sh, w_hd, stage_mask=2), iters)   # the conv+LIF launch alone
             _lib.check(lib.snn_debug_tile_shape(1, pos, C, T, 0, 0, out32), "snn_debug_tile_shape")
-            res["rpn"][T] = {"ms": round(ms, 4), "steps": out32[4], "tile_rows": out32[2], "per_tile": out32[3],
+            res["rpn"][T] = {"ms": round(ms, 4), "conv_lif_ms": round(conv_ms, 4), "steps": out32[4], "tile_rows": out32[2], "per_tile": out32[3],
                              "fill": round(out32[3] * out32[4] / out32[2], 4), "work_groups": out32[5]}
         for T in range(8, 17):
             leg.det_head.num_steps = T
@@ -437,8 +439,14 @@ def sweep_t_leg(leg, iters=8):
         ref = res[head][t_ref]["ms"] / res[head][t_ref]["steps"]
         for T, r in res[head].items():
             r["ms_per_step_rel"] = round(r["ms"] / r["steps"] / ref, 4)
-    worst = max(r["ms_per_step_rel"] for h in res.values() for r in h.values())
+    ref = res["rpn"][8]["conv_lif_ms"] / res["rpn"][8]["steps"]
+    for T, r in res["rpn"].items():
+        r["conv_lif_ms_per_step_rel"] = round(r["conv_lif_ms"] / r["steps"] / ref, 4)
+    worst = max(r["ms_per_step_rel"] for h in ("rpn", "det") for r in res[h].values())
     res["worst_ms_per_step_rel"] = worst
+    res["worst_conv_lif_ms_per_step_rel"] = max(r["conv_lif_ms_per_step_rel"] for r in res["rpn"].values())
+    res["note"] = ("ms = whole head (encoder + contraction(s) + LI heads); the encoder and the LI heads do not shrink with the step count "
+                   "(0.07 + 0.04 ms of the RPN head), which is what a short T pays per step; conv_lif_ms = the matrix-core launch alone")
     res["images_per_s_grid"] = {"T_rpn x T_det": "b=%d: images/s = b / (rpn ms + det ms)" % leg.wl["batch"],
                                 "min": round(leg.wl["batch"] / ((res["rpn"][12]["ms"] + res["det"][16]["ms"]) * 1e-3), 1),
                                 "headline_T8_T12": round(leg.wl["batch"] / ((res["rpn"][8]["ms"] + res["det"][12]["ms"]) * 1e-3), 1),

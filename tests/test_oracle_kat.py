@@ -122,3 +122,21 @@ def test_dead_time_steps_cannot_reach_an_output():
         # ... and one step more IS visible: the windows are tight
         one_less = OR.det_head_forward(x, w6, w7, wc, wb, T, trace=True, cur_hook=_dead({"fc6": (0, T - 3), "fc7": (1, T - 2)}))
         assert not torch.equal(full[2]["spk7"], one_less[2]["spk7"]) or not torch.equal(full[0], one_less[0])
+
+
+def test_encoder_spike_trains_are_exactly_periodic():
+    """What the HIP heads' period planes rest on (csrc/snn_common.h), stated on the oracle: the constant-current encoder starts from
+    and resets to +0 (rpn.py:58,93,101; faster_rcnn.py:444,484,494), so a neuron's train is z_t = 1 iff n | t + 1 with n = (step of its
+    first spike) + 1 - for every input, threshold neighbours included"""
+    from oracle import snn_oracle as OR
+    g = torch.Generator().manual_seed(0)
+    x = torch.cat([torch.randn(20000, generator=g) * 4.0, torch.tensor([2.5, 2.4999998, 2.5000002, 0.25, 0.26, 0.3, 1.0, 1e6, -3.0, 0.0]),
+                   torch.linspace(0.2, 3.0, 5000)])
+    T = 32
+    z = OR.encoder_spikes(x, T).bool()                                       # [T, n]
+    fired = z.any(dim=0)
+    n = torch.where(fired, z.float().argmax(dim=0) + 1, torch.zeros_like(z[0], dtype=torch.int64))
+    t1 = torch.arange(1, T + 1)[:, None]
+    expect = fired[None, :] & ((t1 % n.clamp(min=1)[None, :]) == 0)
+    assert torch.equal(z, expect)
+    assert int(n.max()) >= 20 and int((n == 1).sum()) > 0 and int((~fired).sum()) > 0   # long periods, every-step neurons and silent ones all present

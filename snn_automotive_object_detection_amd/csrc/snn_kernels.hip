@@ -145,8 +145,8 @@ struct Knobs {
     bool dead_keep;          // SNN_DEAD_STEPS=keep   form the input currents of ALL time steps (A/B + test switch: the default
                              //                       skips the steps whose currents cannot reach an output, lif_windows)
     int planes;              // SNN_PLANES=rm|wm      internal spike planes of the bf16x3 heads: all row-major [T][row][word] / all
-                             //                       word-major [T][word][row] (1 / 2; 0 = default: linear layers word-major, conv
-                             //                       row-major; bit-identical results either way, A/B + test switch)
+                             //                       word-major [T][word][row] (1 / 2; 0 = default = word-major since round 3;
+                             //                       bit-identical results either way, A/B + test switch)
 };
 static Knobs load_knobs() {
     Knobs k;
@@ -1221,10 +1221,12 @@ int snn_rpn_head_forward_stages(const snn_rpn_level* lv, int n_levels, int C, in
     bool split = p->precision == SNN_PRECISION_BF16X3 && !knobs().spk_rows && li_heads_reads_split(C, A, 4 * A) &&
                  !knobs().bf16x3_lif_reg && cdiv(C, 32) * 32 % 128 == 0 &&
                  g3_some_tile_ok(Tc, true);
-    // bf16x3, SNN_PLANES=wm: encoder planes word-major [T][Cw][Pe] - a conv tile's spike words of a chunk are then 128-byte
-    // runs.  Not the default for the convolution: -0.7 % of kernel time, but a 128-byte line of a word plane is shared by
-    // horizontally adjacent tiles (on different XCDs), FETCH_SIZE 84 -> 177 MB per launch
-    const size_t wm_rows = (p->precision == SNN_PRECISION_BF16X3 && knobs().planes == 2) ? (size_t)Pe : 0;
+    // bf16x3: encoder planes word-major [T][Cw][Pe] - a conv tile's spike words of a chunk are then 128-byte runs (L2 read
+    // requests of the launch 1.98e8 -> 1.68e8, conv+LIF -1.1 %).  Round 2 kept the convolution on row-major planes because a
+    // 128-byte line of a word plane is shared by horizontally adjacent tiles, which then sat on different XCDs (FETCH_SIZE
+    // x 2); with the XCD-contiguous tile order of round 3 the neighbours share an L2 and the fetch traffic is the same for
+    // both layouts (profiles/r3_word_major_conv.txt).  SNN_PLANES=rm switches back (bit-identical).
+    const size_t wm_rows = (p->precision == SNN_PRECISION_BF16X3 && knobs().planes != 1) ? (size_t)Pe : 0;
     uint32_t* enc = (uint32_t*)ws;
     uint32_t* spk = (uint32_t*)((char*)ws + o_spk);
     hipStream_t s = (hipStream_t)stream;

@@ -80,6 +80,10 @@ void snn_debug_reload_knobs(void);     /* re-read the SNN_* debug knobs from the
  * num_steps LIF steps.  out[0..7] = {M-tiles per wave, short row-waves, tile rows, positions or RoIs per tile, time steps whose
  * currents are formed (dead time steps removed), work-groups of the launch, column blocks, waves along N}.  Returns 0, or -4
  * if no tile holds that many steps (the launch then takes the un-fused path). */
+/* Introspection (tests): the threshold table of the period-plane encoder for these parameters - a neuron's first spike is at or before
+ * step t iff its input is >= th[t] (csrc/snn_common.h: THRESHOLD FORM).  th[0..31] out; returns 1 if the table verified against the
+ * recurrence on the host (the encoders then use it), 0 if not (they keep the recurrence), negative on bad arguments. */
+int snn_debug_encoder_thresholds(const snn_params* p, float* th32);
 int snn_debug_tile_shape(int conv, long long units, int n_cols, int num_steps, int spike_rates, int layer, int32_t* out);
 
 /* ---- weight packing (call when the weights change; results are plain device buffers) ---------- */

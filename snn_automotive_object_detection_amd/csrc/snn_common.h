@@ -66,6 +66,19 @@ __device__ __forceinline__ void enc_step_word(const float x, float& v, const Neu
             : "+v"(word), "+v"(v) : "v"(th), "v"(vr) : "vcc");
     }
 }
+// THRESHOLD FORM of the period-plane encoder.  "First spike at or before step t" is, for the zero-rest encoder, the same as
+// x >= th[t] for a table of fp32 thresholds th[0] > th[1] > ... (the membrane before the first spike is a non-decreasing function of
+// the input): the encoder is a quantiser.  The table is found on the host by bisection over the fp32 bit patterns with the device's
+// exact operation sequence and VERIFIED on every float within 1024 ulps of each threshold (rounding can only matter that close: the
+// accumulated error of t steps is < 1e-5 relative); launchers fall back to the recurrence if the verification ever fails
+// (snn_kernels.hip: enc_thresholds).  Two instructions per neuron-step instead of six: the cumulative plane word
+// C_t = (first spike at or before t), and e_t = C_t & ~C_{t-1}.
+struct EncTh { float th[32]; };
+__device__ __forceinline__ void enc_quant_word(const float x, const float th, uint32_t& word) {     // word = 2 * word + (th <= x)
+    asm("v_cmp_le_f32 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(word) : "v"(x), "s"(th) : "vcc");
+}
+enum { ENC_GENERIC = 0, ENC_ZR = 1, ENC_QUANT = 2 };
+
 // same arithmetic, the spike returned as a predicate (for ballot-based plane words)
 template <bool ZR>
 __device__ __forceinline__ bool enc_step_t(const float x, float& v, const NeuronP& p) {

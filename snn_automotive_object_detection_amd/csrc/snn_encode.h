@@ -13,10 +13,11 @@
 // Wpad > 0: the planes carry a one-position zero halo around every image (row (n, y, x) -> (n*(H+2) + y+1)*(W+2) + x+1,
 // W = Wpad); the halo itself is zeroed by the caller.  The fp4 x fp6 conv kernel reads its 3x3 taps from such planes
 // without any border logic.
-template <bool ZR>
+template <int EM>
 __device__ __forceinline__ void encode_block(const float* __restrict__ feat, int C, int HW, int Cw, int T, const NeuronP& p,
-                                             uint32_t* __restrict__ planes, size_t plane_stride, int n, int bx, int by,
+                                             const EncTh& eth, uint32_t* __restrict__ planes, size_t plane_stride, int n, int bx, int by,
                                              int Wpad = 0, size_t wm_rows = 0) {
+    constexpr bool ZR = EM != ENC_GENERIC;
     __shared__ uint32_t wbuf[SNN_MAX_STEPS * ENC_PB * 9];      // [t][position][8 words + 1 pad]
     const int pl = threadIdx.x & 31, cgl = threadIdx.x >> 5;
     const int pos = bx * ENC_PB + pl;
@@ -28,10 +29,20 @@ __device__ __forceinline__ void encode_block(const float* __restrict__ feat, int
         x[j] = (pos < HW && c < C) ? feat[((size_t)n * C + c) * HW + pos] : 0.0f;
         v[j] = 0.0f;                              // rpn.py:93  v = zeros
     }
+    uint32_t prev = 0;
     for (int t = 0; t < T; ++t) {
         uint32_t word = 0;
+        if (EM == ENC_QUANT) {                      // period planes by thresholds: cumulative word, then the newly fired bits
+            const float th = eth.th[t];
 #pragma unroll
-        for (int j = 31; j >= 0; --j) enc_step_word<ZR>(x[j], v[j], p, word);   // bit 31 first ... bit 0 last
+            for (int j = 31; j >= 0; --j) enc_quant_word(x[j], th, word);
+            const uint32_t cum = word;
+            word = cum & ~prev;
+            prev = cum;
+        } else {
+#pragma unroll
+            for (int j = 31; j >= 0; --j) enc_step_word<ZR>(x[j], v[j], p, word);   // bit 31 first ... bit 0 last
+        }
         wbuf[(t * ENC_PB + pl) * 9 + cgl] = word;
     }
     __syncthreads();
@@ -51,11 +62,11 @@ __device__ __forceinline__ void encode_block(const float* __restrict__ feat, int
     }
 }
 
-template <bool ZR>
+template <int EM>
 __global__ __launch_bounds__(256) void k_encode_nchw(const float* __restrict__ feat, int C, int HW, int Cw,
-                                                     int T, NeuronP p, uint32_t* __restrict__ planes,
+                                                     int T, NeuronP p, const EncTh eth, uint32_t* __restrict__ planes,
                                                      size_t plane_stride) {
-    encode_block<ZR>(feat, C, HW, Cw, T, p, planes, plane_stride, blockIdx.z, blockIdx.x, blockIdx.y);
+    encode_block<EM>(feat, C, HW, Cw, T, p, eth, planes, plane_stride, blockIdx.z, blockIdx.x, blockIdx.y);
 }
 
 // all pyramid levels of the RPN head in one launch (the small levels are launch-latency bound on their own)
@@ -67,13 +78,13 @@ struct EncLevels {
     int Wpad[SNN_MAX_LEVELS];                       // 0, or the level's width when the planes carry a zero halo
     int n_levels;
 };
-template <bool ZR>
-__global__ __launch_bounds__(256) void k_encode_levels(const EncLevels lv, int C, int Cw, int T, NeuronP p,
+template <int EM>
+__global__ __launch_bounds__(256) void k_encode_levels(const EncLevels lv, int C, int Cw, int T, NeuronP p, const EncTh eth,
                                                        uint32_t* __restrict__ planes, size_t plane_stride, size_t wm_rows) {
     int l = 0;
     while (l + 1 < lv.n_levels && (int)blockIdx.x >= lv.blk_base[l + 1]) ++l;
     const int local = blockIdx.x - lv.blk_base[l];
-    encode_block<ZR>(lv.feat[l], C, lv.HW[l], Cw, T, p, planes + (size_t)lv.pos_base[l] * (wm_rows ? 1 : Cw), plane_stride,
+    encode_block<EM>(lv.feat[l], C, lv.HW[l], Cw, T, p, eth, planes + (size_t)lv.pos_base[l] * (wm_rows ? 1 : Cw), plane_stride,
                      local / lv.bpi[l], local % lv.bpi[l], blockIdx.y, lv.Wpad[l], wm_rows);
 }
 
@@ -105,10 +116,11 @@ __global__ __launch_bounds__(256) void k_zero_halo(const HaloLevels lv, int Cw, 
 // slot, so one ballot per step IS two plane words.  Each thread runs ENC_U independent elements (64 apart) to keep
 // several loads and scan chains in flight.
 #define ENC_U 4
-template <bool ZR>
+template <int EM>
 __global__ __launch_bounds__(256) void k_encode_rows(const float* __restrict__ x, int R, int D, int Dw, int T,
-                                                     NeuronP p, uint32_t* __restrict__ planes,
+                                                     NeuronP p, const EncTh eth, uint32_t* __restrict__ planes,
                                                      size_t plane_stride) {
+    constexpr bool ZR = EM != ENC_GENERIC;
     const size_t Dp = (size_t)Dw * 32;
     const size_t total = (size_t)R * Dp;
     const int lane = threadIdx.x & 63;
@@ -128,7 +140,7 @@ __global__ __launch_bounds__(256) void k_encode_rows(const float* __restrict__ x
     for (int t = 0; t < T; ++t) {
 #pragma unroll
         for (int u = 0; u < ENC_U; ++u) {
-            const bool z = enc_step_t<ZR>(xv[u], v[u], p);
+            const bool z = EM == ENC_QUANT ? (xv[u] >= eth.th[t] && !(t > 0 && xv[u] >= eth.th[t - 1])) : enc_step_t<ZR>(xv[u], v[u], p);
             const unsigned long long m = __ballot(z);
             if ((lane & 31) == 0 && e[u] < total)
                 planes[(size_t)t * plane_stride + (e[u] >> 5)] = (lane < 32) ? (uint32_t)m : (uint32_t)(m >> 32);
@@ -143,9 +155,10 @@ __global__ __launch_bounds__(256) void k_encode_rows(const float* __restrict__ x
 // consecutive words per time step.  Against the ballot form: 6 instead of 11 vector instructions per neuron-step and 8
 // times the bytes in flight per thread.
 #define ENC_W_PITCH 36
-template <bool ZR>
-__global__ __launch_bounds__(256) void k_encode_rows_w(const float* __restrict__ x, size_t n_words, int T, NeuronP p,
+template <int EM>
+__global__ __launch_bounds__(256) void k_encode_rows_w(const float* __restrict__ x, size_t n_words, int T, NeuronP p, const EncTh eth,
                                                        uint32_t* __restrict__ planes, size_t plane_stride) {
+    constexpr bool ZR = EM != ENC_GENERIC;
     __shared__ __attribute__((aligned(16))) float tile[256 * ENC_W_PITCH];
     const int tid = threadIdx.x;
     const size_t w0 = (size_t)blockIdx.x * 256;                 // first plane word of the work-group
@@ -168,10 +181,20 @@ __global__ __launch_bounds__(256) void k_encode_rows_w(const float* __restrict__
         for (int r = 0; r < 4; ++r) { xv[4 * q + r] = t4[r]; v[4 * q + r] = 0.0f; }      // v = 0: faster_rcnn.py:484
     }
     uint32_t* dst = planes + w0 + tid;
+    uint32_t prev = 0;
     for (int t = 0; t < T; ++t) {
         uint32_t word = 0;
+        if (EM == ENC_QUANT) {                      // period planes by thresholds (snn_common.h)
+            const float th = eth.th[t];
 #pragma unroll
-        for (int b = 31; b >= 0; --b) enc_step_word<ZR>(xv[b], v[b], p, word);          // bit 31 first
+            for (int b = 31; b >= 0; --b) enc_quant_word(xv[b], th, word);
+            const uint32_t cum = word;
+            word = cum & ~prev;
+            prev = cum;
+        } else {
+#pragma unroll
+            for (int b = 31; b >= 0; --b) enc_step_word<ZR>(xv[b], v[b], p, word);          // bit 31 first
+        }
         dst[(size_t)t * plane_stride] = word;
     }
 }
@@ -180,9 +203,10 @@ __global__ __launch_bounds__(256) void k_encode_rows_w(const float* __restrict__
 // 32 rows x 8 words (32 x 1 KB of x, 16-byte coalesced loads through LDS), thread = (row tid & 31, word tid >> 5), so the 32
 // lanes of a half-wave store 32 consecutive rows of one word plane: 128-byte runs.  D % 32 == 0, x 16-byte aligned.
 #define ENC_WM_PITCH 260
-template <bool ZR>
-__global__ __launch_bounds__(256) void k_encode_rows_wm(const float* __restrict__ x, int R, int D, int T, NeuronP p,
+template <int EM>
+__global__ __launch_bounds__(256) void k_encode_rows_wm(const float* __restrict__ x, int R, int D, int T, NeuronP p, const EncTh eth,
                                                         uint32_t* __restrict__ planes, size_t plane_stride) {
+    constexpr bool ZR = EM != ENC_GENERIC;
     __shared__ __attribute__((aligned(16))) float tile[32 * ENC_WM_PITCH];
     const int tid = threadIdx.x;
     const int r0 = blockIdx.y * 32, w0 = blockIdx.x * 8;
@@ -205,10 +229,20 @@ __global__ __launch_bounds__(256) void k_encode_rows_wm(const float* __restrict_
         for (int r = 0; r < 4; ++r) { xv[4 * q + r] = t4[r]; v[4 * q + r] = 0.0f; }      // v = 0: faster_rcnn.py:484
     }
     uint32_t* dst = planes + (size_t)(w0 + wd) * R + r0 + row;
+    uint32_t prev = 0;
     for (int t = 0; t < T; ++t) {
         uint32_t word = 0;
+        if (EM == ENC_QUANT) {                      // period planes by thresholds (snn_common.h)
+            const float th = eth.th[t];
 #pragma unroll
-        for (int b = 31; b >= 0; --b) enc_step_word<ZR>(xv[b], v[b], p, word);          // bit 31 first
+            for (int b = 31; b >= 0; --b) enc_quant_word(xv[b], th, word);
+            const uint32_t cum = word;
+            word = cum & ~prev;
+            prev = cum;
+        } else {
+#pragma unroll
+            for (int b = 31; b >= 0; --b) enc_step_word<ZR>(xv[b], v[b], p, word);          // bit 31 first
+        }
         dst[(size_t)t * plane_stride] = word;
     }
 }
@@ -231,7 +265,9 @@ struct RoiArgs {
     uint32_t* planes;
     unsigned long long plane_stride;
     int R, C, T, Dw;
+    int quant;                // period planes by thresholds (eth valid): snn_common.h
     NeuronP p;
+    EncTh eth;
 };
 
 __device__ __forceinline__ float roi_bilinear(const float* __restrict__ f, int H, int W, float y, float x) {
@@ -295,8 +331,13 @@ __global__ __launch_bounds__(256) void k_roi_align_encode(const RoiArgs a) {
     const size_t e = (size_t)r * a.Dw * 32 + d;
     const bool in = d < a.Dw * 32;
     for (int t = 0; t < a.T; ++t) {
-        const bool zz = enc_step(val, v, a.p);
-        v = (zz && a.p.v_fire != 0.0f) ? a.p.v_fire : v;         // period planes (zero rest / reset potentials only): never fires again
+        bool zz;
+        if (a.quant) {
+            zz = val >= a.eth.th[t] && !(t > 0 && val >= a.eth.th[t - 1]);
+        } else {
+            zz = enc_step(val, v, a.p);
+            v = (zz && a.p.v_fire != 0.0f) ? a.p.v_fire : v;     // period planes (zero rest / reset potentials only): never fires again
+        }
         const bool z = zz && d < D;
         const unsigned long long m = __ballot(z);
         if ((lane & 31) == 0 && in)
@@ -318,8 +359,13 @@ __global__ __launch_bounds__(256) void k_roi_align_encode_wm(const RoiArgs a) {
         const float val = d < D ? roi_pool_element(a, r, d) : 0.0f;
         float v = 0.0f;
         for (int t = 0; t < a.T; ++t) {
-            const bool zz = enc_step(val, v, a.p);
-            v = (zz && a.p.v_fire != 0.0f) ? a.p.v_fire : v;     // period planes
+            bool zz;
+            if (a.quant) {
+                zz = val >= a.eth.th[t] && !(t > 0 && val >= a.eth.th[t - 1]);
+            } else {
+                zz = enc_step(val, v, a.p);
+                v = (zz && a.p.v_fire != 0.0f) ? a.p.v_fire : v; // period planes
+            }
             const bool z = zz && d < D;
             const unsigned long long m = __ballot(z);
             if (lane == 0) { wbuf[(t * 2 + 0) * 32 + rl] = (uint32_t)m; wbuf[(t * 2 + 1) * 32 + rl] = (uint32_t)(m >> 32); }

@@ -138,6 +138,7 @@ struct Knobs {
     bool bf16x3_xcd;         // SNN_BF16X3_XCD=0      plain block order instead of the XCD-aware one (A/B)
     bool stage_wm;           // SNN_STAGE_PLANES=wm   A/B harness only: snn_conv3x3_lif_bf16x3 / snn_spike_gemm_lif_bf16x3 take their
                              //                       INPUT planes word-major ([T][word][row]; tools/ab_conv.py)
+    bool enc_quant;          // SNN_ENC_QUANT=0       period planes by the encoder's recurrence instead of its threshold table (A/B, tests)
     bool periods;            // SNN_PERIOD_PLANES=0   the whole heads multiply the encoder's spike planes z_t instead of its period planes e_n
                              //                       (snn_common.h; default: period planes on the bf16x3 tile path with zero rest / reset potentials)
     bool stage_periods;      // SNN_STAGE_PERIODS=1   tests / tools: the STAGE-level encoders emit period planes and the stage-level fused launches
@@ -171,6 +172,7 @@ static Knobs load_knobs() {
     k.stage_wm = (e = getenv("SNN_STAGE_PLANES")) && !strcmp(e, "wm");
     k.dead_keep = (e = getenv("SNN_DEAD_STEPS")) && !strcmp(e, "keep");
     k.periods = !((e = getenv("SNN_PERIOD_PLANES")) && e[0] == '0');
+    k.enc_quant = !((e = getenv("SNN_ENC_QUANT")) && e[0] == '0');
     k.stage_periods = (e = getenv("SNN_STAGE_PERIODS")) && e[0] == '1';
     return k;
 }
@@ -181,6 +183,59 @@ static Knobs& knobs() {
 
 // encoder fast path: Norse's default rest / reset potentials
 static bool enc_zero_rest(const NeuronP& p) { return p.v_leak == 0.0f && p.v_reset == 0.0f && !knobs().enc_generic; }
+
+// ---- the period-plane encoder as a quantiser (snn_common.h: THRESHOLD FORM) ----------------------------------------------
+// first spike of the zero-rest encoder at or before step k (0-based), with the device's exact fp32 operation sequence
+// (enc_step_word<true> / enc_step with v_leak = 0; this translation unit is compiled with -ffp-contract=off)
+static bool enc_fires_by(float x, int k, float ca, float v_th) {
+    float v = 0.0f;
+    for (int j = 0; j <= k; ++j) {
+        const float d = x - v;
+        const float m = ca * d;
+        v = v + m;
+        if (v > v_th) return true;
+    }
+    return false;
+}
+struct EncThTable { EncTh t; bool ok; float ca, v_th; };
+// th[k] = the smallest float x with enc_fires_by(x, k): bisection over the bit patterns of the non-negative floats (the predicate is
+// monotone up to rounding), then every float within ENC_TH_WINDOW ulps of the threshold is classified by the recurrence and must
+// agree with the comparison x >= th[k] - beyond that distance the membrane is more than 1e-4 away from the threshold in relative
+// terms, an order of magnitude above the rounding the recurrence can accumulate in 32 steps.  ok = false (any disagreement, a
+// non-positive threshold, ca outside (0, 1)): the launchers keep the recurrence.  Per thread, recomputed when the parameters change.
+#define ENC_TH_WINDOW 1024
+static const EncThTable& enc_thresholds(float ca, float v_th) {
+    static thread_local EncThTable tab = {{{0}}, false, 0.0f, 0.0f};
+    static thread_local bool have = false;
+    if (have && tab.ca == ca && tab.v_th == v_th) return tab;
+    have = true; tab.ca = ca; tab.v_th = v_th; tab.ok = ca > 0.0f && ca < 1.0f && v_th > 0.0f;
+    auto as_float = [](uint32_t b) { float f; memcpy(&f, &b, 4); return f; };
+    for (int k = 0; k < SNN_MAX_STEPS && tab.ok; ++k) {
+        uint32_t lo = 0u, hi = 0x7f800000u;                      // +0 never fires (v stays 0 < v_th), +inf fires at once
+        if (!enc_fires_by(as_float(hi), k, ca, v_th) || enc_fires_by(0.0f, k, ca, v_th)) { tab.ok = false; break; }
+        while (hi - lo > 1) {
+            const uint32_t mid = lo + (hi - lo) / 2;
+            if (enc_fires_by(as_float(mid), k, ca, v_th)) hi = mid; else lo = mid;
+        }
+        tab.t.th[k] = as_float(hi);
+        const uint32_t b0 = hi > ENC_TH_WINDOW ? hi - ENC_TH_WINDOW : 1u, b1 = hi + ENC_TH_WINDOW < 0x7f800000u ? hi + ENC_TH_WINDOW : 0x7f800000u;
+        for (uint32_t b = b0; b <= b1 && tab.ok; ++b)
+            if (enc_fires_by(as_float(b), k, ca, v_th) != (b >= hi)) tab.ok = false;
+        if (k > 0 && !(tab.t.th[k] <= tab.t.th[k - 1])) tab.ok = false;
+    }
+    return tab;
+}
+// encoder mode of a launch: ENC_QUANT for period planes whose threshold table verified, else the recurrence
+static int enc_mode(const NeuronP& np, const EncTh** eth) {
+    static const EncTh none = {{0}};
+    *eth = &none;
+    if (!enc_zero_rest(np)) return ENC_GENERIC;
+    if (np.v_fire != 0.0f && knobs().enc_quant) {
+        const EncThTable& t = enc_thresholds(np.ca, np.v_th);
+        if (t.ok) { *eth = &t.t; return ENC_QUANT; }
+    }
+    return ENC_ZR;
+}
 
 // period planes (snn_common.h): the encoder's spike trains are exactly periodic when it starts from and resets to +0
 static bool periods_possible(const snn_params* p) {
@@ -526,6 +581,14 @@ static int launch_gemm3(int mode, int mt, int wn, const Gemm3Args& a, hipStream_
 // (declared further down)
 static bool g3_tile_ok(int T, int rows);
 
+int snn_debug_encoder_thresholds(const snn_params* p, float* th32) {
+    static_assert(SNN_MAX_STEPS == 32, "EncTh holds 32 thresholds");
+    if (!p || !th32) return fail(-1, "snn_debug_encoder_thresholds: null argument");
+    const EncThTable& t = enc_thresholds(p->dt_tau_mem, p->v_th_enc);
+    memcpy(th32, t.t.th, sizeof(t.t.th));
+    return (t.ok && p->v_leak == 0.0f && p->v_reset == 0.0f) ? 1 : 0;
+}
+
 int snn_debug_tile_shape(int conv, long long units, int n_cols, int num_steps, int spike_rates, int layer, int32_t* out) {
     if (!out || units <= 0 || n_cols <= 0 || num_steps < 1 || num_steps > SNN_MAX_STEPS) return fail(-1, "snn_debug_tile_shape: bad argument");
     snn_params p;
@@ -853,10 +916,12 @@ int snn_encode_nchw(const float* feat, int N, int C, int H, int W, int T, const 
     const int Cw = cdiv(C, 32), HW = H * W;
     NeuronP np = make_p(p, p->v_th_enc);
     if (knobs().stage_periods && enc_zero_rest(np)) np.v_fire = ENC_FIRED;      // (tests / tools: period planes)
-    if (enc_zero_rest(np))
-        hipLaunchKernelGGL(k_encode_nchw<true>, dim3(cdiv(HW, ENC_PB), cdiv(Cw, 8), N), dim3(256), 0, (hipStream_t)s, feat, C, HW, Cw, T, np, planes, plane_stride);
-    else
-        hipLaunchKernelGGL(k_encode_nchw<false>, dim3(cdiv(HW, ENC_PB), cdiv(Cw, 8), N), dim3(256), 0, (hipStream_t)s, feat, C, HW, Cw, T, np, planes, plane_stride);
+    const EncTh* eth;
+    const int em = enc_mode(np, &eth);
+    const dim3 g(cdiv(HW, ENC_PB), cdiv(Cw, 8), N);
+    if (em == ENC_QUANT) hipLaunchKernelGGL(k_encode_nchw<ENC_QUANT>, g, dim3(256), 0, (hipStream_t)s, feat, C, HW, Cw, T, np, *eth, planes, plane_stride);
+    else if (em == ENC_ZR) hipLaunchKernelGGL(k_encode_nchw<ENC_ZR>, g, dim3(256), 0, (hipStream_t)s, feat, C, HW, Cw, T, np, *eth, planes, plane_stride);
+    else hipLaunchKernelGGL(k_encode_nchw<ENC_GENERIC>, g, dim3(256), 0, (hipStream_t)s, feat, C, HW, Cw, T, np, *eth, planes, plane_stride);
     SNN_CHECK_LAUNCH("k_encode_nchw");
     return 0;
 }
@@ -890,25 +955,30 @@ static int encode_rows_impl(const float* x, int R, int D, int T, const snn_param
         if (!enc_zero_rest(np)) return fail(-1, "snn_encode_rows: period planes need zero rest / reset potentials");
         np.v_fire = ENC_FIRED;
     }
+    const EncTh* eth;
+    const int em = enc_mode(np, &eth);
     if (wm) {
         if (!encode_rows_wm_ok(x, D)) return fail(-1, "snn_encode_rows: word-major planes need D %% 32 == 0 and 16-byte aligned rows");
         const dim3 g(cdiv(Dw, 8), cdiv(R, 32));
-        if (enc_zero_rest(np)) hipLaunchKernelGGL(k_encode_rows_wm<true>, g, dim3(256), 0, (hipStream_t)s, x, R, D, T, np, planes, plane_stride);
-        else hipLaunchKernelGGL(k_encode_rows_wm<false>, g, dim3(256), 0, (hipStream_t)s, x, R, D, T, np, planes, plane_stride);
+        if (em == ENC_QUANT) hipLaunchKernelGGL(k_encode_rows_wm<ENC_QUANT>, g, dim3(256), 0, (hipStream_t)s, x, R, D, T, np, *eth, planes, plane_stride);
+        else if (em == ENC_ZR) hipLaunchKernelGGL(k_encode_rows_wm<ENC_ZR>, g, dim3(256), 0, (hipStream_t)s, x, R, D, T, np, *eth, planes, plane_stride);
+        else hipLaunchKernelGGL(k_encode_rows_wm<ENC_GENERIC>, g, dim3(256), 0, (hipStream_t)s, x, R, D, T, np, *eth, planes, plane_stride);
         SNN_CHECK_LAUNCH("k_encode_rows_wm");
         return 0;
     }
     if (D % 32 == 0 && ((uintptr_t)x & 15) == 0 && !knobs().enc_rows_ballot) {   // knob: "ballot" forces the element-per-lane kernel
         const size_t n_words = (size_t)R * Dw;
         const dim3 gw((unsigned)((n_words + 255) / 256));
-        if (enc_zero_rest(np)) hipLaunchKernelGGL(k_encode_rows_w<true>, gw, dim3(256), 0, (hipStream_t)s, x, n_words, T, np, planes, plane_stride);
-        else hipLaunchKernelGGL(k_encode_rows_w<false>, gw, dim3(256), 0, (hipStream_t)s, x, n_words, T, np, planes, plane_stride);
+        if (em == ENC_QUANT) hipLaunchKernelGGL(k_encode_rows_w<ENC_QUANT>, gw, dim3(256), 0, (hipStream_t)s, x, n_words, T, np, *eth, planes, plane_stride);
+        else if (em == ENC_ZR) hipLaunchKernelGGL(k_encode_rows_w<ENC_ZR>, gw, dim3(256), 0, (hipStream_t)s, x, n_words, T, np, *eth, planes, plane_stride);
+        else hipLaunchKernelGGL(k_encode_rows_w<ENC_GENERIC>, gw, dim3(256), 0, (hipStream_t)s, x, n_words, T, np, *eth, planes, plane_stride);
         SNN_CHECK_LAUNCH("k_encode_rows_w");
         return 0;
     }
     const dim3 grid((unsigned)((total + 256 * ENC_U - 1) / (256 * ENC_U)));
-    if (enc_zero_rest(np)) hipLaunchKernelGGL(k_encode_rows<true>, grid, dim3(256), 0, (hipStream_t)s, x, R, D, Dw, T, np, planes, plane_stride);
-    else hipLaunchKernelGGL(k_encode_rows<false>, grid, dim3(256), 0, (hipStream_t)s, x, R, D, Dw, T, np, planes, plane_stride);
+    if (em == ENC_QUANT) hipLaunchKernelGGL(k_encode_rows<ENC_QUANT>, grid, dim3(256), 0, (hipStream_t)s, x, R, D, Dw, T, np, *eth, planes, plane_stride);
+    else if (em == ENC_ZR) hipLaunchKernelGGL(k_encode_rows<ENC_ZR>, grid, dim3(256), 0, (hipStream_t)s, x, R, D, Dw, T, np, *eth, planes, plane_stride);
+    else hipLaunchKernelGGL(k_encode_rows<ENC_GENERIC>, grid, dim3(256), 0, (hipStream_t)s, x, R, D, Dw, T, np, *eth, planes, plane_stride);
     SNN_CHECK_LAUNCH("k_encode_rows");
     return 0;
 }
@@ -965,6 +1035,8 @@ static int roi_align_encode_impl(const snn_roi_level* levels_host, int n_levels,
     if (periods) {
         if (a.p.v_leak != 0.0f || a.p.v_reset != 0.0f) return fail(-1, "snn_roi_align_encode: period planes need zero rest / reset potentials");
         a.p.v_fire = ENC_FIRED;
+        const EncTh* eth;
+        if (enc_mode(a.p, &eth) == ENC_QUANT) { a.quant = 1; a.eth = *eth; }
     }
     if (wm) hipLaunchKernelGGL(k_roi_align_encode_wm, dim3(cdiv(a.Dw, 2), cdiv(R, 32)), dim3(256), 0, (hipStream_t)s, a);
     else hipLaunchKernelGGL(k_roi_align_encode, dim3(cdiv(a.Dw * 32, 256), R), dim3(256), 0, (hipStream_t)s, a);
@@ -1257,10 +1329,12 @@ int snn_rpn_head_forward_stages(const snn_rpn_level* lv, int n_levels, int C, in
         }
         NeuronP np = make_p(p, p->v_th_enc);
         if (per) np.v_fire = ENC_FIRED;
-        if (enc_zero_rest(np))
-            hipLaunchKernelGGL(k_encode_levels<true>, dim3(blocks, cdiv(Cw, 8)), dim3(256), 0, s, el, C, Cw, Tc, np, enc, enc_stride, wm_rows);
-        else
-            hipLaunchKernelGGL(k_encode_levels<false>, dim3(blocks, cdiv(Cw, 8)), dim3(256), 0, s, el, C, Cw, Tc, np, enc, enc_stride, wm_rows);
+        const EncTh* eth;
+        const int em = enc_mode(np, &eth);
+        const dim3 ge(blocks, cdiv(Cw, 8));
+        if (em == ENC_QUANT) hipLaunchKernelGGL(k_encode_levels<ENC_QUANT>, ge, dim3(256), 0, s, el, C, Cw, Tc, np, *eth, enc, enc_stride, wm_rows);
+        else if (em == ENC_ZR) hipLaunchKernelGGL(k_encode_levels<ENC_ZR>, ge, dim3(256), 0, s, el, C, Cw, Tc, np, *eth, enc, enc_stride, wm_rows);
+        else hipLaunchKernelGGL(k_encode_levels<ENC_GENERIC>, ge, dim3(256), 0, s, el, C, Cw, Tc, np, *eth, enc, enc_stride, wm_rows);
         SNN_CHECK_LAUNCH("k_encode_levels");
     }
     if (stage_mask & SNN_STAGE_CONV_LIF) {

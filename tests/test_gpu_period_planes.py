@@ -41,6 +41,15 @@ def test_encoders_emit_disjoint_period_planes_that_reconstruct_the_spike_planes(
     f = (torch.randn(2, 70, 13, 17, generator=g) * 3.0).to(gpu_device)
     x = (torch.randn(37, 320, generator=g) * 3.0).to(gpu_device)
     x[0, :6] = torch.tensor([2.5, 2.4999998, 2.5000002, 0.25, 0.26, 100.0])        # threshold neighbours, a period-1 neuron
+    # every threshold of the encoder's table and its neighbours two ulps either side (csrc/snn_common.h: THRESHOLD FORM)
+    import ctypes as C
+    from snn_automotive_object_detection_amd import _lib
+    th = (C.c_float * 32)()
+    assert _lib.load().snn_debug_encoder_thresholds(C.byref(p), th) == 1
+    bits = np.array(list(th), dtype=np.float32).view(np.uint32)
+    near = np.concatenate([(b + np.arange(-2, 3)).astype(np.uint32).view(np.float32) for b in bits])       # 160 values
+    x[1, :160] = torch.from_numpy(near.copy()).to(gpu_device)
+    f[0, :40, 0, :4] = torch.from_numpy(near.copy()).reshape(40, 4).to(gpu_device)
     feats = {str(i): (torch.randn(2, 8, 24 >> i, 40 >> i, generator=g) * 3).to(gpu_device) for i in range(4)}
     boxes = [torch.tensor([[3.0, 4.0, 60.0, 50.0], [10.0, 10.0, 150.0, 90.0], [0.0, 0.0, 20.0, 12.0]], device=gpu_device)] * 2
     pool = MultiScaleRoIAlign(["0", "1", "2", "3"], 7, 2)
@@ -53,6 +62,10 @@ def test_encoders_emit_disjoint_period_planes_that_reconstruct_the_spike_planes(
     periods = all_planes()
     monkeypatch.setenv("SNN_ENC_ROWS", "ballot")
     periods.append(ops.encode_rows(x, T, p)); direct.append(direct[1])
+    monkeypatch.delenv("SNN_ENC_ROWS")
+    monkeypatch.setenv("SNN_ENC_QUANT", "0")                                        # period planes by the recurrence: the same bits
+    for a, b in zip(all_planes(), periods[:3]):
+        assert torch.equal(a, b)
     for z, e in zip(direct, periods):
         acc = torch.zeros_like(e[0])
         for t in range(T):
@@ -188,3 +201,29 @@ def test_generic_rest_potentials_and_the_other_precisions_take_spike_planes(gpu_
     monkeypatch.setenv("SNN_PERIOD_PLANES", "0")
     b = ops.det_head_forward(x, 64, 5, 20, 6, p, w6, w7, wh)[:2]
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+def test_threshold_encoders_leave_the_heads_bit_identical(gpu_device, monkeypatch):
+    """SNN_ENC_QUANT=0 (period planes from the recurrence) against the default (threshold table): same planes, hence the same bits out
+    of both heads, the fused RoIAlign path included"""
+    import snn_automotive_object_detection_amd as S
+    from tests.test_gpu_roialign import _setup
+    torch.manual_seed(2)
+    r = S.RPNHeadSNN(128, 3, 8).to(gpu_device)
+    d = S.FastRCNNPredictorSNNFull(32 * 49, 128, 9, 12).to(gpu_device)
+    with torch.no_grad():
+        r.shared_conv.weight.mul_(4.0)
+    feats = [torch.randn(2, 128, 21, 30, device=gpu_device) * 3, torch.randn(2, 128, 5, 7, device=gpu_device) * 3]
+    x = torch.randn(150, 32, 7, 7, device=gpu_device) * 3
+    pool, fm, boxes, shapes = _setup(gpu_device, R=60, C=32, seed=4)
+    flist, scales, rois, lvl = pool.assign(fm, boxes, shapes)
+
+    def run():
+        lg, bb = r(feats)
+        c, b = d(x)
+        c2, b2 = d.forward_roialign(flist, scales, rois, lvl)
+        return [t.clone() for t in lg + bb] + [c.clone(), b.clone(), c2.clone(), b2.clone()]
+    a = run()
+    monkeypatch.setenv("SNN_ENC_QUANT", "0")
+    b = run()
+    assert all(torch.equal(p_, q_) for p_, q_ in zip(a, b))

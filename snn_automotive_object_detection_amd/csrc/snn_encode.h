@@ -4,12 +4,14 @@
 
 // ------------------------------------------------------------------------------------------------
 // K1a: constant-current LIF encoder, NCHW fp32 -> bit-planes [T][N*HW][Cw]
-// Block = 32 positions x 8 channel words; thread = one position x 32 channels (reads coalesced along W, two 128-B
-// segments per wave instruction).  The T words of a thread go through LDS so that every plane store of the block is
-// one contiguous run of 32 positions x 8 words (1 KB at C = 256) instead of 4-byte pieces at a 32-byte pitch.
+// Block = 64 positions x 4 channel words; thread = one position x 32 channels, a wave = 64 consecutive positions of one channel
+// word (every load instruction reads one 256-byte run of a channel plane; round 2's 32 x 8 shape read two 128-byte segments of
+// two planes per instruction and topped out at 3.3 TB/s once the threshold form had removed the VALU bound).  The T words of a
+// thread go through LDS so that the plane stores of the block are runs of consecutive positions (word-major planes: 256 bytes).
 // VALU-bound (32 x T encoder steps per thread): packed fp32 arithmetic, see enc_step2_word.
 // ------------------------------------------------------------------------------------------------
-#define ENC_PB 32                                   // positions per block
+#define ENC_PB 64                                   // positions per block (a wave = 64 consecutive positions of one channel: 256-byte runs)
+#define ENC_WB 4                                    // channel words per block
 // Wpad > 0: the planes carry a one-position zero halo around every image (row (n, y, x) -> (n*(H+2) + y+1)*(W+2) + x+1,
 // W = Wpad); the halo itself is zeroed by the caller.  The fp4 x fp6 conv kernel reads its 3x3 taps from such planes
 // without any border logic.
@@ -18,10 +20,10 @@ __device__ __forceinline__ void encode_block(const float* __restrict__ feat, int
                                              const EncTh& eth, uint32_t* __restrict__ planes, size_t plane_stride, int n, int bx, int by,
                                              int Wpad = 0, size_t wm_rows = 0) {
     constexpr bool ZR = EM != ENC_GENERIC;
-    __shared__ uint32_t wbuf[SNN_MAX_STEPS * ENC_PB * 9];      // [t][position][8 words + 1 pad]
-    const int pl = threadIdx.x & 31, cgl = threadIdx.x >> 5;
+    __shared__ uint32_t wbuf[SNN_MAX_STEPS * ENC_PB * (ENC_WB + 1)];      // [t][position][4 words + 1 pad]
+    const int pl = threadIdx.x & (ENC_PB - 1), cgl = threadIdx.x / ENC_PB;
     const int pos = bx * ENC_PB + pl;
-    const int cg = by * 8 + cgl;
+    const int cg = by * ENC_WB + cgl;
     float x[32], v[32];
 #pragma unroll
     for (int j = 0; j < 32; ++j) {
@@ -43,14 +45,14 @@ __device__ __forceinline__ void encode_block(const float* __restrict__ feat, int
 #pragma unroll
             for (int j = 31; j >= 0; --j) enc_step_word<ZR>(x[j], v[j], p, word);   // bit 31 first ... bit 0 last
         }
-        wbuf[(t * ENC_PB + pl) * 9 + cgl] = word;
+        wbuf[(t * ENC_PB + pl) * (ENC_WB + 1) + cgl] = word;
     }
     __syncthreads();
     // store: thread -> (position tid >> 3, word tid & 7): consecutive threads write consecutive plane words.
     // wm_rows > 0: word-major planes [T][word][wm_rows rows] (`planes` then points at the level's first ROW of word plane 0):
     // thread -> (word tid >> 5, position tid & 31), 128-byte runs of 32 positions per (t, word)
-    const int sp = wm_rows ? (threadIdx.x & 31) : (threadIdx.x >> 3), sw = wm_rows ? (threadIdx.x >> 5) : (threadIdx.x & 7);
-    const int spos = bx * ENC_PB + sp, scg = by * 8 + sw;
+    const int sp = wm_rows ? (threadIdx.x & (ENC_PB - 1)) : (threadIdx.x / ENC_WB), sw = wm_rows ? (threadIdx.x / ENC_PB) : (threadIdx.x % ENC_WB);
+    const int spos = bx * ENC_PB + sp, scg = by * ENC_WB + sw;
     if (spos < HW && scg < Cw) {
         size_t row = (size_t)n * HW + spos;
         if (Wpad) {
@@ -58,7 +60,7 @@ __device__ __forceinline__ void encode_block(const float* __restrict__ feat, int
             row = ((size_t)n * (H + 2) + y + 1) * (Wpad + 2) + x + 1;
         }
         uint32_t* out = wm_rows ? planes + (size_t)scg * wm_rows + row : planes + row * Cw + scg;
-        for (int t = 0; t < T; ++t) out[(size_t)t * plane_stride] = wbuf[(t * ENC_PB + sp) * 9 + sw];
+        for (int t = 0; t < T; ++t) out[(size_t)t * plane_stride] = wbuf[(t * ENC_PB + sp) * (ENC_WB + 1) + sw];
     }
 }
 

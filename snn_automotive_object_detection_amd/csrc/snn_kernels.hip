@@ -918,7 +918,7 @@ int snn_encode_nchw(const float* feat, int N, int C, int H, int W, int T, const 
     if (knobs().stage_periods && enc_zero_rest(np)) np.v_fire = ENC_FIRED;      // (tests / tools: period planes)
     const EncTh* eth;
     const int em = enc_mode(np, &eth);
-    const dim3 g(cdiv(HW, ENC_PB), cdiv(Cw, 8), N);
+    const dim3 g(cdiv(HW, ENC_PB), cdiv(Cw, ENC_WB), N);
     if (em == ENC_QUANT) hipLaunchKernelGGL(k_encode_nchw<ENC_QUANT>, g, dim3(256), 0, (hipStream_t)s, feat, C, HW, Cw, T, np, *eth, planes, plane_stride);
     else if (em == ENC_ZR) hipLaunchKernelGGL(k_encode_nchw<ENC_ZR>, g, dim3(256), 0, (hipStream_t)s, feat, C, HW, Cw, T, np, *eth, planes, plane_stride);
     else hipLaunchKernelGGL(k_encode_nchw<ENC_GENERIC>, g, dim3(256), 0, (hipStream_t)s, feat, C, HW, Cw, T, np, *eth, planes, plane_stride);
@@ -1331,7 +1331,7 @@ int snn_rpn_head_forward_stages(const snn_rpn_level* lv, int n_levels, int C, in
         if (per) np.v_fire = ENC_FIRED;
         const EncTh* eth;
         const int em = enc_mode(np, &eth);
-        const dim3 ge(blocks, cdiv(Cw, 8));
+        const dim3 ge(blocks, cdiv(Cw, ENC_WB));
         if (em == ENC_QUANT) hipLaunchKernelGGL(k_encode_levels<ENC_QUANT>, ge, dim3(256), 0, s, el, C, Cw, Tc, np, *eth, enc, enc_stride, wm_rows);
         else if (em == ENC_ZR) hipLaunchKernelGGL(k_encode_levels<ENC_ZR>, ge, dim3(256), 0, s, el, C, Cw, Tc, np, *eth, enc, enc_stride, wm_rows);
         else hipLaunchKernelGGL(k_encode_levels<ENC_GENERIC>, ge, dim3(256), 0, s, el, C, Cw, Tc, np, *eth, enc, enc_stride, wm_rows);

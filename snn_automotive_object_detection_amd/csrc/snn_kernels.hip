@@ -205,10 +205,16 @@ struct EncThTable { EncTh t; bool ok; float ca, v_th; };
 // non-positive threshold, ca outside (0, 1)): the launchers keep the recurrence.  Per thread, recomputed when the parameters change.
 #define ENC_TH_WINDOW 1024
 static const EncThTable& enc_thresholds(float ca, float v_th) {
-    static thread_local EncThTable tab = {{{0}}, false, 0.0f, 0.0f};
-    static thread_local bool have = false;
-    if (have && tab.ca == ca && tab.v_th == v_th) return tab;
-    have = true; tab.ca = ca; tab.v_th = v_th; tab.ok = ca > 0.0f && ca < 1.0f && v_th > 0.0f;
+    // a model has two encoders (RPN head, detector head) whose parameters may differ: a few tables per thread, replaced round-robin
+    constexpr int N_TAB = 4;
+    static thread_local EncThTable tabs[N_TAB];
+    static thread_local int n_tabs = 0, next_tab = 0;
+    for (int j = 0; j < n_tabs; ++j)
+        if (tabs[j].ca == ca && tabs[j].v_th == v_th) return tabs[j];
+    EncThTable& tab = tabs[next_tab];
+    next_tab = (next_tab + 1) % N_TAB;
+    if (n_tabs < N_TAB) ++n_tabs;
+    tab.ca = ca; tab.v_th = v_th; tab.ok = ca > 0.0f && ca < 1.0f && v_th > 0.0f;
     auto as_float = [](uint32_t b) { float f; memcpy(&f, &b, 4); return f; };
     for (int k = 0; k < SNN_MAX_STEPS && tab.ok; ++k) {
         uint32_t lo = 0u, hi = 0x7f800000u;                      // +0 never fires (v stays 0 < v_th), +inf fires at once

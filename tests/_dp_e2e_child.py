@@ -33,6 +33,43 @@ class HostBackbone(torch.nn.Module):
     def forward(self, x):
         from collections import OrderedDict
         return OrderedDict((k, v.to(x.device)) for k, v in self.backbone(x.cpu()).items())
+
+
+class StageTrace:
+    """sha1 of every stage's output (backbone pyramid, RPN head, proposals, detector result) of one model call: when the gathered
+    detections ever differ from the single-process ones, the report names the first stage whose bits differ"""
+    STAGES = ("backbone", "rpn.head", "rpn", "roi_heads")
+
+    def __init__(self, model):
+        self.rows = {}
+        for name in self.STAGES:
+            mod = model
+            for part in name.split("."):
+                mod = getattr(mod, part)
+            mod.register_forward_hook(lambda m, i, o, name=name: self.rows.__setitem__(name, self.digest(o)))
+
+    @classmethod
+    def digest(cls, o):
+        import hashlib
+        h = hashlib.sha1()
+
+        def walk(x):
+            if torch.is_tensor(x):
+                h.update(x.detach().cpu().contiguous().numpy().tobytes())
+            elif isinstance(x, dict):
+                for k in sorted(x):
+                    walk(x[k])
+            elif isinstance(x, (list, tuple)):
+                for y in x:
+                    walk(y)
+        walk(o)
+        return h.hexdigest()[:16]
+
+    def take(self):
+        rows, self.rows = self.rows, {}
+        return rows
+
+
 rank, local, world = dp.init_distributed()
 torch.cuda.set_device(local)
 dev = torch.device("cuda", local)
@@ -41,7 +78,10 @@ model = S.create_model("bdd", 11, True, True, 0, False, False, 8, 12).to(dev).ev
 model.backbone = HostBackbone(model.backbone)
 n_global = PER_RANK * world
 mine = dp.shard_range(n_global, rank, world)
+trace = StageTrace(model)
 dets = model(bench.dp_images(mine, dev))
+stages = [None] * world
+dist.all_gather_object(stages, trace.take())
 gathered = dp.all_gather_detections(dets, max_det=1100, device=dev)
 assert len(gathered) == n_global
 # this rank's own block of the gathered list is its own result, bit for bit
@@ -58,6 +98,9 @@ if rank == 0:
     for r in range(world):                                       # single process: the same batches, one after the other
         idx = list(dp.shard_range(n_global, r, world))
         ref = model(bench.dp_images(idx, dev))
+        single = trace.take()
+        diverged = [k for k in StageTrace.STAGES if stages[r].get(k) != single.get(k)]
+        report.setdefault("first_divergent_stage", {})[str(r)] = diverged[0] if diverged else None
         ref2 = model(bench.dp_images(idx, dev)) if r == 0 else None
         for j, i in enumerate(idx):
             g, e = gathered[i], ref[j]

@@ -83,4 +83,4 @@ def test_dp_e2e_gathered_detections_equal_single_process(gpu_device):
         # (the child runs the stock backbone's convolutions on the host: MIOpen's choices are neither repeatable run to run nor
         # the same in two processes sharing a device - tools/probe_determinism.py; everything behind the backbone is on the GPU)
         assert row.get("single_process_repeatable", True), row
-        assert row["exact"], row
+        assert row["exact"], (row, rep.get("first_divergent_stage"))

@@ -268,6 +268,7 @@ struct RoiArgs {
     unsigned long long plane_stride;
     int R, C, T, Dw;
     int quant;                // period planes by thresholds (eth valid): snn_common.h
+    int E, n_rg, RW;          // k_roi_align_encode_tab: groups of 64 elements per work-group, RoI groups, RoIs per wave (4 waves)
     NeuronP p;
     EncTh eth;
 };
@@ -379,5 +380,132 @@ __global__ __launch_bounds__(256) void k_roi_align_encode_wm(const RoiArgs a) {
         const int rl = idx & 31, wd = (idx >> 5) & 1, t = idx >> 6;
         if (r0 + rl < a.R && w0 + wd < a.Dw)
             a.planes[(size_t)t * a.plane_stride + (size_t)(w0 + wd) * a.R + r0 + rl] = wbuf[(t * 2 + wd) * 32 + rl];
+    }
+}
+
+// K1c'': K1c' with the sample geometry of a RoI computed ONCE per wave instead of once per element.  Everything about a
+// bilinear sample except the feature values is separable and the same for all C channels: 14 sample rows (7 bins x 2) with
+// {y_low * W, y_high * W, ly, hy} and 14 sample columns with {pair base, clamped, lx, hx} (l = -1 outside the map) - 28 x 16 bytes of LDS per wave,
+// built by 28 lanes with exactly the operations of roi_pool_element / roi_bilinear (same roundings, same order), then looked
+// up by bin.  K1c' spent ~200 vector instructions per element on coordinates (six divisions among them) and issued 16
+// 4-byte gathers; here an element costs ~70 instructions and 8 eight-byte gathers: the two taps of a sample row are
+// neighbours (x_high = x_low + 1) except when the column is clamped to the last one, where the pair is read one to the left
+// and both taps take its second half.  A work-group covers 4 RW RoIs (RW per wave, one after the other) x E groups of 64 elements
+// (E x 2 plane words per step; the table is reused E times); the words leave through LDS as runs of 4 RW consecutive RoIs.
+// The kernel is bound by its gathers: ~28 L1 accesses per load instruction (7 bin rows x the row's lines, two channels per
+// wave), and with the plain block order by L2 misses as well - 1.2 GB fetched for 200 MB of feature maps, since every XCD
+// saw every channel plane.  The XCD-aware, channel-major block order below brings that to 0.34 GB (77 % L2 hits).
+// Needs W >= 2 on every level and C*H*W < 2^29 elements per image (32-bit element offsets); the launcher checks.
+struct __attribute__((aligned(16))) RoiTabEntry { int a, b; float l, h; };
+__global__ __launch_bounds__(256) void k_roi_align_encode_tab(const RoiArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t wbuf_dyn[];          // [t][2E words][4 RW RoIs]
+    __shared__ RoiTabEntry tab[4][32];                                           // per wave: 0..13 rows, 16..29 columns
+    const int D = a.C * 49, E = a.E;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // work-group -> (element block, RoI group), XCD-aware and channel-major in time: work-group b runs on XCD b % 8, so XCD x takes
+    // the element blocks x, x + 8, ... and for each of them ALL RoI groups, one block after the other - at any moment an XCD's
+    // work-groups read a handful of channel planes (which its 4-MB L2 holds) instead of all of them (a.n_rg RoI groups)
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    const int eblk = (jj / a.n_rg) * 8 + xcd, rgrp = jj % a.n_rg;
+    if (eblk * E * 2 >= a.Dw) return;
+    const int RW = a.RW, RG = 4 * RW;                          // RoIs per wave / per work-group
+    const int r0 = rgrp * RG;
+    const int d0 = eblk * E * 64;
+    RoiTabEntry* const tb = tab[wave];
+    for (int i = 0; i < RW; ++i) {
+        const int rl = wave * RW + i, r = r0 + rl;               // wave-uniform
+        if (r >= a.R) break;
+        const RoiLevel L = a.lv[a.roi_level[r]];
+        const float* roi = a.rois + (size_t)r * 4;
+        const float* const fimg = L.feat + (size_t)a.roi_batch[r] * a.C * (size_t)(L.H * L.W);
+        const int HW = L.H * L.W;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");                   // the previous RoI's lookups are done
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 32 && (lane & 15) < 14) {
+            // lane 0..13: sample row s = 2 ph + iy;  lane 16..29: sample column s = 2 pw + ix
+            const bool is_x = lane >= 16;
+            const int sidx = lane & 15, pb = sidx >> 1, ii = sidx & 1;
+            const float lo = __fmul_rn(is_x ? roi[0] : roi[1], L.scale);
+            const float ext = fmaxf(__fsub_rn(__fmul_rn(is_x ? roi[2] : roi[3], L.scale), lo), 1.0f);
+            const float bin = __fdiv_rn(ext, 7.0f);
+            const float b0 = __fadd_rn(lo, __fmul_rn((float)pb, bin));
+            float y = __fadd_rn(b0, __fdiv_rn(__fmul_rn((float)ii + 0.5f, bin), 2.0f));
+            const int n = is_x ? L.W : L.H;
+            RoiTabEntry e;
+            if (y < -1.0f || y > (float)n) { e.a = 0; e.b = 0; e.l = -1.0f; e.h = 0.0f; }     // outside the map: l < 0, offsets stay valid
+            else {
+                y = fmaxf(y, 0.0f);
+                int y_low = (int)y, y_high;
+                if (y_low >= n - 1) { y_high = y_low = n - 1; y = (float)y_low; } else y_high = y_low + 1;
+                e.l = __fsub_rn(y, (float)y_low);
+                e.h = __fsub_rn(1.0f, e.l);
+                if (is_x) { e.b = y_high == y_low; e.a = e.b ? y_low - 1 : y_low; }      // pair base, clamped
+                else { e.a = y_low * L.W; e.b = y_high * L.W; }
+            }
+            tb[lane] = e;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int eg = 0; eg < E; ++eg) {
+            const int d = d0 + eg * 64 + lane;
+            float val = 0.0f;
+            if (d < D) {
+                const int c = d / 49, bin = d - 49 * c, ph = bin / 7, pw = bin - 7 * ph;
+                const float* const f = fimg + (unsigned)(c * HW);
+                typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
+                RoiTabEntry ye[2], xe[2];
+                ye[0] = tb[2 * ph]; ye[1] = tb[2 * ph + 1]; xe[0] = tb[16 + 2 * pw]; xe[1] = tb[16 + 2 * pw + 1];
+                // all eight tap pairs are requested before any is used (samples outside the map read row / column 0 and are dropped)
+                f32x2u pt[2][2], qt[2][2];
+#pragma unroll
+                for (int iy = 0; iy < 2; ++iy)
+#pragma unroll
+                    for (int ix = 0; ix < 2; ++ix) {
+                        pt[iy][ix] = *reinterpret_cast<const f32x2u*>(f + (ye[iy].a + xe[ix].a));
+                        qt[iy][ix] = *reinterpret_cast<const f32x2u*>(f + (ye[iy].b + xe[ix].a));
+                    }
+                float s[2][2];
+#pragma unroll
+                for (int iy = 0; iy < 2; ++iy)
+#pragma unroll
+                    for (int ix = 0; ix < 2; ++ix) {
+                        const bool ok = ye[iy].l >= 0.0f && xe[ix].l >= 0.0f;
+                        const f32x2u p2 = pt[iy][ix], q2 = qt[iy][ix];
+                        const float v1 = xe[ix].b ? p2.y : p2.x, v2 = p2.y, v3 = xe[ix].b ? q2.y : q2.x, v4 = q2.y;
+                        float acc = __fmul_rn(__fmul_rn(ye[iy].h, xe[ix].h), v1);
+                        acc = __fadd_rn(acc, __fmul_rn(__fmul_rn(ye[iy].h, xe[ix].l), v2));
+                        acc = __fadd_rn(acc, __fmul_rn(__fmul_rn(ye[iy].l, xe[ix].h), v3));
+                        acc = __fadd_rn(acc, __fmul_rn(__fmul_rn(ye[iy].l, xe[ix].l), v4));
+                        s[iy][ix] = ok ? acc : 0.0f;
+                    }
+                val = __fdiv_rn(__fadd_rn(__fadd_rn(__fadd_rn(s[0][0], s[0][1]), s[1][0]), s[1][1]), 4.0f);
+                if (a.pooled) a.pooled[(size_t)r * D + d] = val;
+            }
+            float v = 0.0f;
+            unsigned long long prev = 0ull;
+            for (int t = 0; t < a.T; ++t) {
+                unsigned long long m;
+                if (a.quant) {
+                    const unsigned long long cum = __ballot(d < D && val >= a.eth.th[t]);     // first spike at or before t
+                    m = cum & ~prev;
+                    prev = cum;
+                } else {
+                    bool zz = enc_step(val, v, a.p);
+                    v = (zz && a.p.v_fire != 0.0f) ? a.p.v_fire : v;                           // period planes
+                    m = __ballot(zz && d < D);
+                }
+                if (lane == 0) {
+                    wbuf_dyn[((t * E + eg) * 2 + 0) * RG + rl] = (uint32_t)m;
+                    wbuf_dyn[((t * E + eg) * 2 + 1) * RG + rl] = (uint32_t)(m >> 32);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int w0 = eblk * E * 2;
+    for (int idx = threadIdx.x; idx < a.T * 2 * E * RG; idx += 256) {
+        const int rl = idx % RG, wd = (idx / RG) % (2 * E), t = idx / (2 * E * RG);
+        if (r0 + rl < a.R && w0 + wd < a.Dw)
+            a.planes[(size_t)t * a.plane_stride + (size_t)(w0 + wd) * a.R + r0 + rl] = wbuf_dyn[(t * 2 * E + wd) * RG + rl];
     }
 }

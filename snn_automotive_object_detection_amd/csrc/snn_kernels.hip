@@ -143,6 +143,8 @@ struct Knobs {
                              //                       (snn_common.h; default: period planes on the bf16x3 tile path with zero rest / reset potentials)
     bool stage_periods;      // SNN_STAGE_PERIODS=1   tests / tools: the STAGE-level encoders emit period planes and the stage-level fused launches
                              //                       (snn_conv3x3_lif_bf16x3, snn_spike_gemm_lif_bf16x3) take their input planes as such
+    int roi_e, roi_rw;       // SNN_ROI_E / SNN_ROI_RW  table-driven RoIAlign kernel: element groups per work-group / RoIs per wave (0 = default 2 / 4)
+    bool roi_tab;            // SNN_ROI_TAB=0         fused RoIAlign + encoder: the per-element kernel instead of the table-driven one (A/B, tests)
     bool dead_keep;          // SNN_DEAD_STEPS=keep   form the input currents of ALL time steps (A/B + test switch: the default
                              //                       skips the steps whose currents cannot reach an output, lif_windows)
     int planes;              // SNN_PLANES=rm|wm      internal spike planes of the bf16x3 heads: all row-major [T][row][word] / all
@@ -174,6 +176,11 @@ static Knobs load_knobs() {
     k.periods = !((e = getenv("SNN_PERIOD_PLANES")) && e[0] == '0');
     k.enc_quant = !((e = getenv("SNN_ENC_QUANT")) && e[0] == '0');
     k.stage_periods = (e = getenv("SNN_STAGE_PERIODS")) && e[0] == '1';
+    k.roi_tab = !((e = getenv("SNN_ROI_TAB")) && e[0] == '0');
+    k.roi_e = (e = getenv("SNN_ROI_E")) ? atoi(e) : 0;
+    k.roi_rw = (e = getenv("SNN_ROI_RW")) ? atoi(e) : 0;
+    if (k.roi_e < 0 || k.roi_e > 16) k.roi_e = 0;
+    if (k.roi_rw < 0 || k.roi_rw > 8) k.roi_rw = 0;
     return k;
 }
 static Knobs& knobs() {
@@ -1044,7 +1051,22 @@ static int roi_align_encode_impl(const snn_roi_level* levels_host, int n_levels,
         const EncTh* eth;
         if (enc_mode(a.p, &eth) == ENC_QUANT) { a.quant = 1; a.eth = *eth; }
     }
-    if (wm) hipLaunchKernelGGL(k_roi_align_encode_wm, dim3(cdiv(a.Dw, 2), cdiv(R, 32)), dim3(256), 0, (hipStream_t)s, a);
+    // word-major planes: the table-driven kernel (sample geometry once per wave and RoI) wherever its 8-byte tap pairs and 32-bit
+    // element offsets are valid; SNN_ROI_TAB=0 keeps the per-element form (bit-identical planes, A/B + test switch)
+    bool tab_ok = wm && knobs().roi_tab;
+    for (int l = 0; l < n_levels && tab_ok; ++l)
+        tab_ok = a.lv[l].W >= 2 && (long long)C * a.lv[l].H * a.lv[l].W < (1ll << 29);
+    if (tab_ok) {
+        // work-group = 16 RoIs (4 per wave) x 2 groups of 64 elements: small blocks keep the channel window of an XCD narrow (its
+        // work-groups sweep the channels in step, snn_encode.h) - 77 % L2 hits against 21 % for 32 RoIs x 7 groups, 0.25 against
+        // 0.30 ms; the per-element kernel: 0.35 ms (tools/time_roi_align.py, profiles/r3_roi_align.txt).  SNN_ROI_E / SNN_ROI_RW: A/B, tests
+        a.E = knobs().roi_e > 0 ? knobs().roi_e : 2;
+        a.RW = knobs().roi_rw > 0 ? knobs().roi_rw : 4;
+        while ((size_t)T * 2 * a.E * 16 * a.RW > 49152 && a.E > 1) --a.E;
+        a.n_rg = cdiv(R, 4 * a.RW);
+        const int n_eblk = cdiv(a.Dw, 2 * a.E);
+        hipLaunchKernelGGL(k_roi_align_encode_tab, dim3(cdiv(n_eblk, 8) * 8 * a.n_rg), dim3(256), (size_t)T * 2 * a.E * 16 * a.RW, (hipStream_t)s, a);
+    } else if (wm) hipLaunchKernelGGL(k_roi_align_encode_wm, dim3(cdiv(a.Dw, 2), cdiv(R, 32)), dim3(256), 0, (hipStream_t)s, a);
     else hipLaunchKernelGGL(k_roi_align_encode, dim3(cdiv(a.Dw * 32, 256), R), dim3(256), 0, (hipStream_t)s, a);
     SNN_CHECK_LAUNCH("k_roi_align_encode");
     return 0;
@@ -1053,8 +1075,9 @@ static int roi_align_encode_impl(const snn_roi_level* levels_host, int n_levels,
 int snn_roi_align_encode(const snn_roi_level* levels_host, int n_levels, int C, const float* rois, const int* roi_batch,
                          const int* roi_level, int R, int T, const snn_params* p, uint32_t* planes,
                          size_t plane_stride, float* pooled_dbg, snn_stream_t s) {
+    // (SNN_STAGE_PLANES=wm, tests / tools: the planes come back word-major [T][Dw][R] - the layout and the kernels the fused head uses)
     return roi_align_encode_impl(levels_host, n_levels, C, rois, roi_batch, roi_level, R, T, p, planes, plane_stride, pooled_dbg,
-                                 false, s, knobs().stage_periods && p && p->v_leak == 0.0f && p->v_reset == 0.0f);
+                                 knobs().stage_wm, s, knobs().stage_periods && p && p->v_leak == 0.0f && p->v_reset == 0.0f);
 }
 
 // shared by snn_conv3x3_lif (one level) and snn_rpn_head_forward (all levels in one launch)

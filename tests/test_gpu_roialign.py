@@ -55,6 +55,53 @@ def test_roi_align_encode_matches_stock_op_and_oracle_encoder(gpu_device):
     assert np.array_equal(planes_to_dense(planes, pooled.shape[1]), z.numpy())
 
 
+@pytest.mark.parametrize("T,periods", [(12, "1"), (12, "0"), (24, "1"), (32, "1"), (5, "0")])
+def test_word_major_kernels_table_driven_and_per_element(gpu_device, monkeypatch, T, periods):
+    """the kernels the fused detector head runs (word-major planes [T][Dw][R]): the table-driven one (sample geometry once per wave
+    and RoI, 8-byte tap pairs; default) and the per-element one (SNN_ROI_TAB=0) - pooled values bit-identical to the restatement of
+    torchvision's kernel, planes identical to the row-major stage kernel's, for spike planes and period planes, at every
+    several work-group shapes (SNN_ROI_E element groups x SNN_ROI_RW RoIs per wave)"""
+    from snn_automotive_object_detection_amd import ops
+    pool, feats, boxes, shapes = _setup(gpu_device, R=333, C=40, seed=5)            # D = 1960: 61.25 plane words (ragged last word)
+    p = ops.make_params(ops.LIFParameters(v_th=torch.tensor(0.25)), ops.LIFParameters(alpha=100, v_th=torch.tensor(0.1)))
+    flist, scales, rois, lvl = pool.assign(feats, boxes, shapes)
+    monkeypatch.setenv("SNN_STAGE_PERIODS", periods)
+    ref_planes, ref_pooled = ops.roi_align_encode(flist, scales, rois[:, 1:5], rois[:, 0], lvl, T, p, want_pooled=True)
+    want = RA.multiscale_roi_align({k: v.cpu() for k, v in feats.items()}, [b.cpu() for b in boxes], shapes).flatten(1)
+    assert np.array_equal(ref_pooled.cpu().numpy(), want.numpy())
+    R, Dw = ref_planes.shape[1], ref_planes.shape[2]
+    monkeypatch.setenv("SNN_STAGE_PLANES", "wm")
+    for tab, e, rw in (("1", "0", "0"), ("0", "0", "0"), ("1", "7", "8"), ("1", "1", "1"), ("1", "3", "5")):
+        monkeypatch.setenv("SNN_ROI_TAB", tab)
+        monkeypatch.setenv("SNN_ROI_E", e)
+        monkeypatch.setenv("SNN_ROI_RW", rw)
+        planes, pooled = ops.roi_align_encode(flist, scales, rois[:, 1:5], rois[:, 0], lvl, T, p, want_pooled=True)
+        assert np.array_equal(pooled.cpu().numpy(), want.numpy()), (tab, e, rw)
+        assert torch.equal(planes.view(T, Dw, R).transpose(1, 2), ref_planes), (tab, e, rw)
+
+
+def test_table_driven_kernel_on_borders_and_tiny_maps(gpu_device, monkeypatch):
+    """clamped columns / rows (the 8-byte tap pair is read one to the left), samples outside the map, 2-pixel-wide levels"""
+    from snn_automotive_object_detection_amd import ops
+    from snn_automotive_object_detection_amd.stock.roi_align import MultiScaleRoIAlign
+    g = torch.Generator().manual_seed(9)
+    sizes = [(16, 16), (8, 8), (4, 4), (2, 2)]
+    feats = {str(i): torch.randn((1, 8, h, w), generator=g).to(gpu_device) for i, (h, w) in enumerate(sizes)}
+    b = torch.tensor([[0.0, 0.0, 64.0, 64.0], [60.0, 60.0, 64.0, 64.0], [63.5, 0.0, 64.0, 64.0], [-30.0, -30.0, 10.0, 10.0],
+                      [0.0, 62.0, 64.0, 66.0], [10.0, 10.0, 500.0, 500.0], [63.9, 63.9, 64.0, 64.0], [0.0, 0.0, 3.0, 3.0]])
+    boxes = [torch.cat([b, torch.rand((40, 4), generator=g) * 32 + torch.tensor([0.0, 0.0, 32.0, 32.0])]).to(gpu_device)]
+    shapes = [(64, 64)]
+    pool = MultiScaleRoIAlign(["0", "1", "2", "3"], 7, 2)
+    flist, scales, rois, lvl = pool.assign(feats, boxes, shapes)
+    p = ops.make_params(ops.LIFParameters(v_th=torch.tensor(0.25)), ops.LIFParameters(alpha=100, v_th=torch.tensor(0.1)))
+    want = RA.multiscale_roi_align({k: v.cpu() for k, v in feats.items()}, [x.cpu() for x in boxes], shapes).flatten(1)
+    monkeypatch.setenv("SNN_STAGE_PLANES", "wm")
+    for tab in ("1", "0"):
+        monkeypatch.setenv("SNN_ROI_TAB", tab)
+        _, pooled = ops.roi_align_encode(flist, scales, rois[:, 1:5], rois[:, 0], lvl, 6, p, want_pooled=True)
+        assert np.array_equal(pooled.cpu().numpy(), want.numpy()), tab
+
+
 @pytest.mark.parametrize("precision", ["bf16x3", "f32"])
 def test_fused_head_equals_two_step_path(gpu_device, precision):
     import snn_automotive_object_detection_amd as S

@@ -621,6 +621,55 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
             }
             return cur;
         };
+        // The first G3_NPRE steps of a neuron run with NO memory access inside the recurrence: the row groups they need are requested
+        // from LDS up front (one latency instead of one per step - the recurrence used to wait for an LDS read and, in period mode, a
+        // scalar load of the divisor mask in every step, ~250 cycles each, while the matrix pipe had only the co-resident work-group's
+        // waves to run), the period sums run over the compile-time divisors of t + 1 in ascending order (the order of tile_current:
+        // bit-identical), and the steps are unrolled behind wave-uniform guards.  Steps from G3_NPRE on (T > 16: outside the paper's
+        // grid) take the step-by-step form - more prefetched steps would not fit beside the accumulators that wait for the second
+        // column pass.  Lane t keeps the ballot of step t.
+        constexpr int NPRE = 16;
+        auto lif_neuron = [&](const float* src, uint32_t& my0, uint32_t& my1, uint32_t& cnt_lo, uint32_t& cnt_hi) __attribute__((always_inline)) {
+            float cs[NPRE];
+            float u1 = 0.0f, u2 = 0.0f, u3 = 0.0f;
+            if (periods) {                                   // (t0 == 0: set_periods)
+                float ug[NPRE];
+#pragma unroll
+                for (int g = 0; g < NPRE; ++g) ug[g] = g < t1 ? src[(size_t)g * group_stride] : 0.0f;
+#pragma unroll
+                for (int t = 0; t < NPRE; ++t) {
+                    float c = ug[0];
+#pragma unroll
+                    for (int n = 2; n <= t + 1; ++n)
+                        if ((t + 1) % n == 0) c = __fadd_rn(c, ug[n - 1]);
+                    cs[t] = t < t1 ? c : 0.0f;
+                }
+                u1 = ug[0]; u2 = ug[1]; u3 = ug[2];
+            } else {
+#pragma unroll
+                for (int t = 0; t < NPRE; ++t) cs[t] = (t >= t0 && t < t1) ? src[(size_t)(t - t0) * group_stride] : 0.0f;
+            }
+            float vv = args.p.v_leak, ii = 0.0f;
+#pragma unroll
+            for (int t = 0; t < NPRE; ++t) {
+                if (t < T) {
+                    const bool z = lif_step(cs[t], vv, ii, args.p);
+                    const unsigned long long b = __ballot(z);
+                    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(my0) : "s"((uint32_t)b), "n"(t));
+                    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(my1) : "s"((uint32_t)(b >> 32)), "n"(t));
+                    cnt_lo += __popc((uint32_t)b);
+                    cnt_hi += __popc((uint32_t)(b >> 32));
+                }
+            }
+            for (int t = NPRE; t < T; ++t) {
+                const bool z = lif_step(tile_current(src, t, u1, u2, u3), vv, ii, args.p);
+                const unsigned long long b = __ballot(z);
+                my0 = lane == t ? (uint32_t)b : my0;
+                my1 = lane == t ? (uint32_t)(b >> 32) : my1;
+                cnt_lo += __popc((uint32_t)b);
+                cnt_hi += __popc((uint32_t)(b >> 32));
+            }
+        };
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // staged-ahead copies of chunks past the end have landed
 #pragma unroll 1
         for (int h = 0; h < 2; ++h) {
@@ -650,12 +699,13 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
                 for (int pi = wave; pi < pb; pi += NW) {   // wave-uniform
                     const int pos = m0 + pi;
                     if (pos >= M) break;
-                    float vv = args.p.v_leak, ii = 0.0f;
                     uint32_t my0 = 0, my1 = 0;             // lane t keeps the word pair of time step t
                     const float* src = tile + pi * PITCH + lane;
+                    uint32_t cnt = 0;                      // wave-uniform: spikes of this position in this pass
+#if defined(SNN_EXPERIMENTS) && defined(SNN_EXP_EPI_SERIAL)
+                    float vv = args.p.v_leak, ii = 0.0f;   // round 2's form (one LDS read / divisor-mask load per step inside the recurrence)
                     const float u1 = periods ? src[0] : 0.0f, u2 = (periods && t1 > 1) ? src[group_stride] : 0.0f,
                                 u3 = (periods && t1 > 2) ? src[2 * group_stride] : 0.0f;
-                    uint32_t cnt = 0;                      // wave-uniform: spikes of this position in this pass
                     for (int t = 0; t < T; ++t) {
                         const float cur = tile_current(src, t, u1, u2, u3);
                         const bool z = lif_step(cur, vv, ii, args.p);
@@ -664,6 +714,11 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
                         my1 = lane == t ? (uint32_t)(b >> 32) : my1;
                         cnt += __popcll(two ? b : (b & 0xffffffffull));
                     }
+#else
+                    uint32_t cnt_hi = 0;
+                    lif_neuron(src, my0, my1, cnt, cnt_hi);
+                    if (two) cnt += cnt_hi;
+#endif
                     if (lane < T) {
                         if (!CONV && args.out_wm) {                    // word-major planes [T][word][row] (fc6 -> fc7)
                             uint32_t* dst = args.spk + (size_t)lane * args.spk_stride + (size_t)word0 * M + pos;
@@ -687,12 +742,13 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
                     const int pi = 2 * pp + par;                       // this half-wave's position
                     const bool live = pi < pb && m0 + pi < M;
                     if (m0 + 2 * pp >= M) break;
-                    float vv = args.p.v_leak, ii = 0.0f;
                     uint32_t my0 = 0, my1 = 0;             // lane t keeps the words of (t, even position), (t, odd position)
                     const float* src = tile + (live ? pi : 2 * pp) * PITCH + col;
+                    uint32_t cnt0 = 0, cnt1 = 0;           // wave-uniform: spikes of the even / odd position in this pass
+#if defined(SNN_EXPERIMENTS) && defined(SNN_EXP_EPI_SERIAL)
+                    float vv = args.p.v_leak, ii = 0.0f;
                     const float u1 = periods ? src[0] : 0.0f, u2 = (periods && t1 > 1) ? src[group_stride] : 0.0f,
                                 u3 = (periods && t1 > 2) ? src[2 * group_stride] : 0.0f;
-                    uint32_t cnt0 = 0, cnt1 = 0;           // wave-uniform: spikes of the even / odd position in this pass
                     for (int t = 0; t < T; ++t) {
                         const float cur = tile_current(src, t, u1, u2, u3);
                         const bool z = lif_step(cur, vv, ii, args.p);
@@ -702,6 +758,9 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
                         cnt0 += __popc((uint32_t)b);
                         cnt1 += __popc((uint32_t)(b >> 32));
                     }
+#else
+                    lif_neuron(src, my0, my1, cnt0, cnt1);
+#endif
                     const bool odd_ok = 2 * pp + 1 < pb && m0 + 2 * pp + 1 < M;
                     if (lane < T) {
                         if (!CONV && args.out_wm) {

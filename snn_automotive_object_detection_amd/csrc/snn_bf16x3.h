@@ -23,6 +23,15 @@
 // ------------------------------------------------------------------------------------------------
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
+// lane `t` (a compile-time constant) of my0 / my1 <- the two halves of a wave ballot.  The ballot is an SGPR pair (often VCC itself)
+// written by the v_cmp right before, and on gfx940 / gfx950 a vector instruction reading an SGPR that a vector instruction wrote needs
+// 2 wait states in between (LLVM: VALUWriteSGPRVALURead) - which the hazard recognizer cannot add inside inline asm: without them the
+// straight-line epilogue stored stale spike words (tests/test_gpu_period_planes.py; tests/test_code_object.py checks the code object).
+// s_nop 2 = 3 wait states.
+#define G3_KEEP_BALLOT(my0, my1, b, t)                                                                          \
+    asm volatile("s_nop 2\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4"                          \
+                 : "+v"(my0), "+v"(my1) : "s"((uint32_t)(b)), "s"((uint32_t)((b) >> 32)), "n"(t))
+
 // LDS-DMA: 16 B per lane straight from global memory (wave-uniform 64-bit base + the lane's 32-bit byte offset)
 // into LDS at (wave-uniform byte address in M0) + 16*lane; no VGPR destination, completion is counted on vmcnt.
 // Issued as inline asm on purpose: once hipcc sees an LDS-DMA in flight it degrades every LDS wait of the loop to
@@ -200,6 +209,10 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
     static_assert(WN == 1 || (WN == 2 && true), "waves along N");
     static_assert(WN == 2 || !FUSE, "the register-fused variant keeps the 4 x 2 wave grid");
     static_assert(MT != 8 || (WN == 2 && NB == 3), "fat waves: 2 x 2 wave grid on the 3-slot ring");
+#ifdef SNN_EXP_TIMELINE     // diagnostic build: wall-clock stamps (s_memrealtime, 100 MHz) of the work-group's phases + where it ran
+    unsigned long long tl_entry = 0, tl_loop0 = 0, tl_loop1 = 0;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_entry) :: "memory");
+#endif
     constexpr int NW = MT == 8 ? 4 : 8;                                   // waves per work-group
     constexpr int BM = (NW / WN) * 16 * MT, BN = G3_BN(WN), WROWS = 16 * MT;   // rows, columns per work-group; rows per wave
     constexpr int AW_BYTES = G3_AW_BYTES(WN);
@@ -490,6 +503,9 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     }
+#ifdef SNN_EXP_TIMELINE
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_loop0) :: "memory");
+#endif
 #ifdef SNN_EXP_CLOCK       // diagnostic build: in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz around the main loop
     unsigned long long clk_c0 = 0, clk_r0 = 0;
     if (TILE && tid == 0) {
@@ -530,7 +546,10 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
                         for (int mt = 0; mt < MTA; ++mt) wq[mt] = rd_w(o_nxt, mt);
                     }
                     if (g >= AG0 && g - AG0 < MTA) af[(u & 1) ^ 1][g - AG0] = rd_a(wq[g - AG0]);
-                    if (g == 2) {
+                    // (3-slot ring: every chunk ends on vmcnt(0), so the copies of the two chunks past the end can simply be left out - 2 of
+                    // 72 weight panels less L2 -> LDS traffic per conv tile and nothing to drain before the epilogue; the 4-slot ring's
+                    // counted waits assume a copy set per chunk, and its linear layers have 392 chunks per tile: left as it is)
+                    if (g == 2 && (NB != 3 || c0 + u + NB - 1 < n_total)) {
                         stage_a(o_wr);
 #ifndef SNN_EXP_NO_GLDS
                         stage_next(o_wr);
@@ -575,6 +594,9 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
         for (; t < args.T; ++t) lif_reg_step(t);
         return;
     }
+#ifdef SNN_EXP_TIMELINE
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_loop1) :: "memory");
+#endif
 #ifdef SNN_EXP_CLOCK
     if (TILE && tid == 0) {
         unsigned long long c1, r1;
@@ -590,6 +612,13 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
         //   WN = 2 (CG = 64): lane = column, wave w takes positions w, w+8, ...; ballot = the word pair of (t, position)
         //   WN = 1 (CG = 32): lane = (position parity, column), wave w takes the position pairs; ballot = one word of
         //                     the even position (low half) and one of the odd position (high half)
+#ifndef SNN_EXP_EPI_NOPRIO
+        // From here on the wave issues no MFMA, while the CU's other work-group is in its K loop and its waves would otherwise win
+        // nearly every vector issue slot: the epilogue took 15 us of a work-group's 109 us lifetime (tools/wg_timeline.py) with the
+        // matrix pipe at the mercy of ONE work-group's waves meanwhile.  At the highest priority the epilogue's (few) vector
+        // instructions issue as soon as they are ready; the MFMAs of the other work-group take the slots in between.
+        __builtin_amdgcn_s_setprio(3);
+#endif
         constexpr int CG = G3_TILE_CG(WN), PITCH = CG + 4;
         float* const tile = reinterpret_cast<float*>(smem);
         uint32_t* const pos_cnt = reinterpret_cast<uint32_t*>(smem + G3_TILE_BYTES(WN));    // behind the tile image
@@ -649,17 +678,44 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
 #pragma unroll
                 for (int t = 0; t < NPRE; ++t) cs[t] = (t >= t0 && t < t1) ? src[(size_t)(t - t0) * group_stride] : 0.0f;
             }
+            // Every vector instruction of the epilogue is matrix-pipe time lost (a SIMD runs either; the epilogue's ~1800 instructions per
+            // wave and tile ARE the kernel's 15 % of idle pipe, tools/wg_timeline.py), so the steps are as short as exactness allows:
+            //  * step 0 starts from v = v_leak, i = 0: v_dec = v_leak + ca*((v_leak - v_leak) + 0) = v_leak and i = (0 + cb*0) + cur_0
+            //    = 0 + cur_0 exactly, no spike unless v_leak - v_th > 0 (wave-uniform; then the general step runs);
+            //  * v_leak == 0 (Norse's default, the reference's): (0 - v) + i == i - v and (v_dec - v_th > 0) == (v_dec > v_th), both
+            //    exact in IEEE arithmetic with gradual underflow (the encoders' identities, snn_common.h) - 8 instead of 10 operations.
             float vv = args.p.v_leak, ii = 0.0f;
+            const bool quiet0 = !(__fsub_rn(args.p.v_leak, args.p.v_th) > 0.0f);
+            const bool zr = args.p.v_leak == 0.0f;
+            auto steps_from = [&](auto zr_c, auto first_c) __attribute__((always_inline)) {
+                constexpr bool ZR = decltype(zr_c)::value;
+                constexpr int FIRST = decltype(first_c)::value;
 #pragma unroll
-            for (int t = 0; t < NPRE; ++t) {
-                if (t < T) {
-                    const bool z = lif_step(cs[t], vv, ii, args.p);
-                    const unsigned long long b = __ballot(z);
-                    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(my0) : "s"((uint32_t)b), "n"(t));
-                    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(my1) : "s"((uint32_t)(b >> 32)), "n"(t));
-                    cnt_lo += __popc((uint32_t)b);
-                    cnt_hi += __popc((uint32_t)(b >> 32));
+                for (int t = FIRST; t < NPRE; ++t) {
+                    if (t < T) {
+                        bool z;
+                        if (ZR) {
+                            const float v_dec = __fadd_rn(vv, __fmul_rn(args.p.ca, __fsub_rn(ii, vv)));
+                            const float i_dec = __fadd_rn(ii, __fmul_rn(args.p.cb, ii));
+                            z = v_dec > args.p.v_th;
+                            vv = z ? args.p.v_reset : v_dec;
+                            ii = __fadd_rn(i_dec, cs[t]);
+                        } else {
+                            z = lif_step(cs[t], vv, ii, args.p);
+                        }
+                        const unsigned long long b = __ballot(z);
+                        G3_KEEP_BALLOT(my0, my1, b, t);
+                        cnt_lo += __popc((uint32_t)b);
+                        cnt_hi += __popc((uint32_t)(b >> 32));
+                    }
                 }
+            };
+            if (quiet0 && T > 0) {
+                ii = __fadd_rn(0.0f, cs[0]);                  // (step 0: no spike, v stays v_leak)
+                if (zr) steps_from(std::true_type{}, std::integral_constant<int, 1>{});
+                else steps_from(std::false_type{}, std::integral_constant<int, 1>{});
+            } else {
+                steps_from(std::false_type{}, std::integral_constant<int, 0>{});
             }
             for (int t = NPRE; t < T; ++t) {
                 const bool z = lif_step(tile_current(src, t, u1, u2, u3), vv, ii, args.p);
@@ -670,10 +726,48 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
                 cnt_hi += __popc((uint32_t)(b >> 32));
             }
         };
+        // The reference's own configurations (T_rpn = 8: 7 period planes; T_det = 12: 10) as straight-line code: no step / row-group
+        // guards, no counters (the general form spends two scalar instructions per guard and four per step on the rate counts, and a
+        // wave issues one instruction - scalar or vector - per four cycles at best).  Period planes, v_leak == 0, no spike at step 0.
+        auto lif_neuron_fixed = [&](const float* src, uint32_t& my0, uint32_t& my1, auto ts_c, auto tcs_c) __attribute__((always_inline)) {
+            constexpr int TS = decltype(ts_c)::value, TCS = decltype(tcs_c)::value;
+            float ug[TCS];
+#pragma unroll
+            for (int g = 0; g < TCS; ++g) ug[g] = src[(size_t)g * group_stride];
+            float vv = 0.0f, ii = 0.0f;
+#pragma unroll
+            for (int t = 0; t < TS; ++t) {
+                float c = 0.0f;
+                if (t < TCS) {
+                    c = ug[0];
+#pragma unroll
+                    for (int n = 2; n <= t + 1; ++n)
+                        if ((t + 1) % n == 0) c = __fadd_rn(c, ug[n - 1]);
+                }
+                if (t == 0) { ii = __fadd_rn(0.0f, c); continue; }
+                const float v_dec = __fadd_rn(vv, __fmul_rn(args.p.ca, __fsub_rn(ii, vv)));
+                const float i_dec = __fadd_rn(ii, __fmul_rn(args.p.cb, ii));
+                const bool z = v_dec > args.p.v_th;
+                vv = z ? args.p.v_reset : v_dec;
+                ii = __fadd_rn(i_dec, c);
+                const unsigned long long b = __ballot(z);
+                G3_KEEP_BALLOT(my0, my1, b, t);
+            }
+        };
+        const bool fixed_ok = periods && !counting && args.p.v_leak == 0.0f && !(__fsub_rn(args.p.v_leak, args.p.v_th) > 0.0f) && t0 == 0;
+        const int fixed_cfg = !fixed_ok ? 0 : (T == 8 && t1 == 7) ? 1 : (T == 12 && t1 == 10) ? 2 : 0;      // block-uniform
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // staged-ahead copies of chunks past the end have landed
+#ifdef SNN_EXP_TIMELINE
+        unsigned long long tl_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define TL_STAMP(i) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_ph[i]) :: "memory")
+        TL_STAMP(0);
+#else
+#define TL_STAMP(i)
+#endif
 #pragma unroll 1
         for (int h = 0; h < 2; ++h) {
             __syncthreads();                               // ring reads done / previous pass consumed
+            if (h == 0) TL_STAMP(1); else TL_STAMP(4);
             if (WN == 1 || wn == h) {
                 const int lrow0 = wm * WROWS - 16 * max(0, wm - first_short);    // logical row of the wave's first row
 #pragma unroll
@@ -692,6 +786,7 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
                 }
             }
             __syncthreads();
+            if (h == 0) TL_STAMP(2); else TL_STAMP(5);
             const int word0 = (nb * BN + h * CG) >> 5;     // first output word of this pass
             if (word0 * 32 >= Np) continue;                // block-uniform
             if (WN == 2) {
@@ -716,7 +811,9 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
                     }
 #else
                     uint32_t cnt_hi = 0;
-                    lif_neuron(src, my0, my1, cnt, cnt_hi);
+                    if (fixed_cfg == 1) lif_neuron_fixed(src, my0, my1, std::integral_constant<int, 8>{}, std::integral_constant<int, 7>{});
+                    else if (fixed_cfg == 2) lif_neuron_fixed(src, my0, my1, std::integral_constant<int, 12>{}, std::integral_constant<int, 10>{});
+                    else lif_neuron(src, my0, my1, cnt, cnt_hi);
                     if (two) cnt += cnt_hi;
 #endif
                     if (lane < T) {
@@ -759,7 +856,9 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
                         cnt1 += __popc((uint32_t)(b >> 32));
                     }
 #else
-                    lif_neuron(src, my0, my1, cnt0, cnt1);
+                    if (fixed_cfg == 1) lif_neuron_fixed(src, my0, my1, std::integral_constant<int, 8>{}, std::integral_constant<int, 7>{});
+                    else if (fixed_cfg == 2) lif_neuron_fixed(src, my0, my1, std::integral_constant<int, 12>{}, std::integral_constant<int, 10>{});
+                    else lif_neuron(src, my0, my1, cnt0, cnt1);
 #endif
                     const bool odd_ok = 2 * pp + 1 < pb && m0 + 2 * pp + 1 < M;
                     if (lane < T) {
@@ -783,11 +882,23 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
                     }
                 }
             }
+            if (h == 0) TL_STAMP(3); else TL_STAMP(6);
         }
         if (counting) {
             __syncthreads();
             tile_counts_flush<CONV>(args, pos_cnt, m0, pb, tid);
         }
+#ifdef SNN_EXP_TIMELINE
+        if (tid == 0) {
+            unsigned long long tl_exit;
+            uint32_t hw, xcc;
+            asm volatile("s_memrealtime %0\n\ts_getreg_b32 %1, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %2, hwreg(HW_REG_XCC_ID)\n\ts_waitcnt lgkmcnt(0)"
+                         : "=s"(tl_exit), "=s"(hw), "=s"(xcc) :: "memory");
+            unsigned long long* o = reinterpret_cast<unsigned long long*>(args.spk + (size_t)args.T * args.spk_stride) + (size_t)blockIdx.x * 16;
+            o[0] = tl_entry; o[1] = tl_loop0; o[2] = tl_loop1; o[3] = tl_exit; o[4] = hw; o[5] = xcc;
+            for (int i = 0; i < 7; ++i) o[8 + i] = tl_ph[i];
+        }
+#endif
         return;
     }
     // ---- store currents: per instruction 4 rows x 16 columns (64-B row segments) ----

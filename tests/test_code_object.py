@@ -67,6 +67,57 @@ def test_only_the_asm_blocks_touch_m0(disassembly):
     assert n_mov == n_dma and n_dma > 100, (n_mov, n_dma)
 
 
+def _sgprs(tok):
+    """SGPR numbers (VCC = 106, 107) named by an operand token"""
+    tok = tok.strip().rstrip(",")
+    if tok == "vcc":
+        return {106, 107}
+    if tok in ("vcc_lo", "vcc_hi"):
+        return {106 if tok == "vcc_lo" else 107}
+    m = re.match(r"^s(\d+)$", tok)
+    if m:
+        return {int(m.group(1))}
+    m = re.match(r"^s\[(\d+):(\d+)\]$", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    return set()
+
+
+def test_writelane_never_reads_a_freshly_compared_sgpr(disassembly):
+    """gfx940 / gfx950: a vector instruction reading an SGPR (or VCC) that another vector instruction wrote needs 2 wait states in
+    between (LLVM's VALUWriteSGPRVALURead rule).  The compiler adds them for its own instructions but cannot look inside inline asm:
+    round 3's straight-line LIF epilogue kept each step's ballot with a v_writelane right behind the v_cmp and stored stale spike
+    words until G3_KEEP_BALLOT got its own s_nop.  Every v_writelane of the code object is checked (compiler spills included)."""
+    n = 0
+    for name, ins in disassembly.items():
+        for i, x in enumerate(ins):
+            if not x.startswith("v_writelane_b32"):
+                continue
+            n += 1
+            src = _sgprs(x.split()[2])
+            if not src:
+                continue
+            wait = 0
+            for y in reversed(ins[max(0, i - 8):i]):
+                if wait >= 2:
+                    break
+                op = y.split()[0]
+                if op == "s_nop":
+                    wait += int(y.split()[1], 0) + 1
+                    continue
+                # vector instructions that write SGPRs: compares (VOPC: vcc; VOP3: first operand), carry-outs, v_readlane / v_readfirstlane
+                dst = set()
+                if op.startswith("v_cmp"):
+                    dst = {106, 107} if op.endswith("_e32") else _sgprs(y.split()[1])
+                elif op.startswith(("v_readlane", "v_readfirstlane")):
+                    dst = _sgprs(y.split()[1])
+                elif "_co_" in op and op.startswith("v_"):
+                    dst = _sgprs(y.split()[2]) if len(y.split()) > 2 else set()
+                assert not (dst & src), "v_writelane reads an SGPR %d wait state(s) after %r wrote it, in %s" % (wait, y, name)
+                wait += 1
+    assert n > 50, n
+
+
 def test_product_build_has_no_experiment_switch_and_the_guard_fires(tmp_path):
     assert not any("SNN_EXP" in f for f in B.FLAGS)
     src = os.path.join(B.CSRC, "snn_kernels.hip")

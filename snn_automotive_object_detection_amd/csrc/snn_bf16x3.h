@@ -658,7 +658,8 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
         // grid) take the step-by-step form - more prefetched steps would not fit beside the accumulators that wait for the second
         // column pass.  Lane t keeps the ballot of step t.
         constexpr int NPRE = 16;
-        auto lif_neuron = [&](const float* src, uint32_t& my0, uint32_t& my1, uint32_t& cnt_lo, uint32_t& cnt_hi) __attribute__((always_inline)) {
+        auto lif_neuron = [&](const float* src, uint32_t& my0, uint32_t& my1, uint32_t& cnt_lo, uint32_t& cnt_hi, auto count_c) __attribute__((always_inline)) {
+            constexpr bool COUNT = decltype(count_c)::value;  // rate counters wanted (four scalar instructions per step otherwise wasted)
             float cs[NPRE];
             float u1 = 0.0f, u2 = 0.0f, u3 = 0.0f;
             if (periods) {                                   // (t0 == 0: set_periods)
@@ -667,11 +668,14 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
                 for (int g = 0; g < NPRE; ++g) ug[g] = g < t1 ? src[(size_t)g * group_stride] : 0.0f;
 #pragma unroll
                 for (int t = 0; t < NPRE; ++t) {
-                    float c = ug[0];
+                    float c = 0.0f;
+                    if (t < t1) {                            // wave-uniform: a scalar branch, not a select per step
+                        c = ug[0];
 #pragma unroll
-                    for (int n = 2; n <= t + 1; ++n)
-                        if ((t + 1) % n == 0) c = __fadd_rn(c, ug[n - 1]);
-                    cs[t] = t < t1 ? c : 0.0f;
+                        for (int n = 2; n <= t + 1; ++n)
+                            if ((t + 1) % n == 0) c = __fadd_rn(c, ug[n - 1]);
+                    }
+                    cs[t] = c;
                 }
                 u1 = ug[0]; u2 = ug[1]; u3 = ug[2];
             } else {
@@ -705,8 +709,10 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
                         }
                         const unsigned long long b = __ballot(z);
                         G3_KEEP_BALLOT(my0, my1, b, t);
-                        cnt_lo += __popc((uint32_t)b);
-                        cnt_hi += __popc((uint32_t)(b >> 32));
+                        if (COUNT) {
+                            cnt_lo += __popc((uint32_t)b);
+                            cnt_hi += __popc((uint32_t)(b >> 32));
+                        }
                     }
                 }
             };
@@ -722,8 +728,10 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
                 const unsigned long long b = __ballot(z);
                 my0 = lane == t ? (uint32_t)b : my0;
                 my1 = lane == t ? (uint32_t)(b >> 32) : my1;
-                cnt_lo += __popc((uint32_t)b);
-                cnt_hi += __popc((uint32_t)(b >> 32));
+                if (COUNT) {
+                    cnt_lo += __popc((uint32_t)b);
+                    cnt_hi += __popc((uint32_t)(b >> 32));
+                }
             }
         };
         // The reference's own configurations (T_rpn = 8: 7 period planes; T_det = 12: 10) as straight-line code: no step / row-group
@@ -813,7 +821,8 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
                     uint32_t cnt_hi = 0;
                     if (fixed_cfg == 1) lif_neuron_fixed(src, my0, my1, std::integral_constant<int, 8>{}, std::integral_constant<int, 7>{});
                     else if (fixed_cfg == 2) lif_neuron_fixed(src, my0, my1, std::integral_constant<int, 12>{}, std::integral_constant<int, 10>{});
-                    else lif_neuron(src, my0, my1, cnt, cnt_hi);
+                    else if (counting) lif_neuron(src, my0, my1, cnt, cnt_hi, std::true_type{});
+                    else lif_neuron(src, my0, my1, cnt, cnt_hi, std::false_type{});
                     if (two) cnt += cnt_hi;
 #endif
                     if (lane < T) {
@@ -858,7 +867,8 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
 #else
                     if (fixed_cfg == 1) lif_neuron_fixed(src, my0, my1, std::integral_constant<int, 8>{}, std::integral_constant<int, 7>{});
                     else if (fixed_cfg == 2) lif_neuron_fixed(src, my0, my1, std::integral_constant<int, 12>{}, std::integral_constant<int, 10>{});
-                    else lif_neuron(src, my0, my1, cnt0, cnt1);
+                    else if (counting) lif_neuron(src, my0, my1, cnt0, cnt1, std::true_type{});
+                    else lif_neuron(src, my0, my1, cnt0, cnt1, std::false_type{});
 #endif
                     const bool odd_ok = 2 * pp + 1 < pb && m0 + 2 * pp + 1 < M;
                     if (lane < T) {

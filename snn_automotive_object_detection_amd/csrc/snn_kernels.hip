@@ -128,7 +128,7 @@ struct Knobs {
     bool enc_rows_ballot;    // SNN_ENC_ROWS=ballot   element-per-lane row encoder
     int bf16x3_mt;           // SNN_BF16X3_MT=2|3|4   M-tiles per wave (0: cost model)
     int bf16x3_short;        // SNN_BF16X3_SHORT=0|1  T-in-tile launches: no / half of the row-waves one M-tile short (-1 = by cost)
-    int bf16x3_wn;           // SNN_BF16X3_WN=1|2     waves along N of the tile (0 = default: linear layers 1 = 512 x 64 tile, conv 2 = 256 x 128)
+    int bf16x3_wn;           // SNN_BF16X3_WN=1|2     waves along N of the tile (0 = default = 1: the 512 x 64 tile; 2 = 256 x 128, the conv's shape until round 3)
     bool bf16x3_lif_reg;     // SNN_BF16X3_LIF=reg    register-resident conv + LIF fusion instead of T-in-tile
     int mx_mw;               // SNN_MX_MW=4|8         rows per wave of k_gemm_mx
     int li_heads;            // SNN_LI_HEADS=valu|mfma|ksplit -> 1 | 2 | 3 (0: by shape)
@@ -349,7 +349,9 @@ static G3Tile g3_pick_tile(int wn, F wgs_of) {
 // -1.7 %, detector head -1.5 %.  Defaults: the linear layers take it; the 3x3 convolution stays on 256 x 128, because with four
 // column blocks every spike row and every output row passes through twice as many XCDs (FETCH 84 -> 190-206 MB, WRITE 98 ->
 // 98-198 MB per launch) for those 1.7 %.  SNN_BF16X3_WN=1|2 forces one shape everywhere (A-B / test knob).
-static int g3_wn(bool conv = false) { return knobs().bf16x3_wn ? knobs().bf16x3_wn : (conv ? 2 : 1); }
+// (the conv ran the 256 x 128 tile until the end of round 3; with the straight-line LIF epilogue the 512 x 64 tile - half the weight bytes
+// per MFMA, 4-slot ring - is 1-2 % faster there too: tools/ab_knobs.py, profiles/r3_h_ab_knobs.txt.  SNN_BF16X3_WN=2 selects the old shape)
+static int g3_wn(bool conv = false) { (void)conv; return knobs().bf16x3_wn ? knobs().bf16x3_wn : 1; }
 
 // rows of the work-group tile (MT = 8 is the 256 x 128 tile of MT = 4 / WN = 2 run by four fat waves)
 static int g3_bm(int wn, int mt) { return mt == 8 ? 256 : G3_BM(wn, mt); }

@@ -119,8 +119,8 @@ struct Gemm3Args {
     // set in div[t] (n - 1 for every divisor n <= Tc of t + 1), added in ascending n.  t0 = 0 in this mode.
     int periods;
     uint32_t div[SNN_MAX_STEPS];
-    int xcd_contig;              // > 0 (launches with 2 / 4 / 8 column blocks, conv): row tiles per XCD; XCD x = blockIdx % 8 runs column block
-                                 // x % n_blocks on a CONTIGUOUS range of row tiles, see the kernel
+    int xcd_contig, xcd_cpx;     // xcd_contig > 0 (conv launches with 2 or 4 column blocks): row tiles per XCD; XCD x = blockIdx % 8 runs xcd_cpx
+                                 // (1 or 2) column blocks on a CONTIGUOUS range of row tiles, see the kernel
     // T-in-tile modes: the LAST n_short row-waves of the work-group multiply MT - 1 M-tiles instead of MT ("short" waves: the
     // last 16 of their rows do not exist), so a tile has 16 n_short fewer rows.  With n_short = half the row-waves every
     // SIMD hosts one full and one short wave: tile heights between the MT steps (512 / 448 / 384 / 320 / 256 rows on the
@@ -254,11 +254,13 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
     // tiles of 32 positions those were 12 tiles away, i.e. on the same XCD by accident of 384 = 12 x 32; with the 36-position
     // tiles of the 7-step window they landed on other XCDs and every XCD fetched the halo rows again (FETCH_SIZE 83 -> 172 MB per
     // launch, L2 misses x 1.9: profiles/r3_a_*).  In a contiguous range the neighbours run on the same XCD a few slots apart.
+    // With 4 column blocks (the 512 x 64 tile) an XCD takes TWO of them (xcd_cpx = 2: work-groups j, j + 1 of the XCD are the two
+    // column blocks of one row tile - 1.77 MB of weight panels in its L2, as before, and every spike row still fetched by 2 XCDs, not 4).
     if (args.xcd_contig) {
-        const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
-        nb = x % args.n_blocks;
-        mb = (x / args.n_blocks) * args.xcd_contig + j;
-        if (j >= args.xcd_contig || mb >= args.n_tiles) return;
+        const int x = blockIdx.x & 7, j = blockIdx.x >> 3, cpx = args.xcd_cpx, groups = args.n_blocks / cpx;
+        nb = (x % groups) * cpx + j % cpx;
+        mb = (x / groups) * args.xcd_contig + j / cpx;
+        if (j / cpx >= args.xcd_contig || mb >= args.n_tiles) return;
     }
     const int m0 = TILE ? mb * args.pb : mb * BM;            // first row (TILE: first position) of the tile
     const int Kc = args.Kc, Np = args.Np, M = args.M;

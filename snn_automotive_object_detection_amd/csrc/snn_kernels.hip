@@ -570,13 +570,16 @@ static int launch_gemm3(int mode, int mt, int wn, const Gemm3Args& a, hipStream_
     ax.n_tiles = tiles; ax.xcd_classes = 0;
     int grid = tiles * a.n_blocks;
     const size_t pair_bytes = (size_t)2 * G3_BN(wn) * a.Kc * 32 * 2 * 3;
-    if (knobs().bf16x3_xcd && mt != 8 && (a.n_blocks == 4 || a.n_blocks == 8 || a.n_blocks == 16) && pair_bytes <= (size_t)2 << 20) {
+    const bool conv_mode = mode == G3_CONV || mode == G3_CONV_LIF_TILE;
+    if (knobs().bf16x3_xcd && mt != 8 && conv_mode && (a.n_blocks == 2 || (a.n_blocks == 4 && pair_bytes <= (size_t)2 << 20)) && tiles >= 64) {
+        // 3x3 convolution with two / four column blocks: half of them and a contiguous quarter of the row tiles per XCD (halo rows stay
+        // in one L2, every spike row is fetched by two XCDs)
+        ax.xcd_cpx = a.n_blocks / 2;
+        ax.xcd_contig = cdiv(tiles, 4);
+        grid = ax.xcd_contig * ax.xcd_cpx * 8;
+    } else if (knobs().bf16x3_xcd && mt != 8 && (a.n_blocks == 4 || a.n_blocks == 8 || a.n_blocks == 16) && pair_bytes <= (size_t)2 << 20) {
         ax.xcd_classes = 8 / (a.n_blocks / 2);
         grid = cdiv(tiles, ax.xcd_classes) * ax.xcd_classes * a.n_blocks;
-    } else if (knobs().bf16x3_xcd && mt != 8 && a.n_blocks == 2 && (mode == G3_CONV || mode == G3_CONV_LIF_TILE) && tiles >= 64) {
-        // 3x3 convolution with two column blocks: a contiguous quarter of the row tiles per XCD (halo rows stay in one L2)
-        ax.xcd_contig = cdiv(tiles, 8 / a.n_blocks);
-        grid = ax.xcd_contig * 8;
     }
     hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return fail(-3, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));

@@ -83,8 +83,10 @@ def build_asan(out_path: str) -> str:
     """Host-side AddressSanitizer build of the same translation unit (CPU box only: GPU ASan / xnack+ code objects are not
     available on this pool).  The device code is compiled un-instrumented; what is checked is the host half of the C ABI:
     argument validation, the level / image tables copied from caller memory, workspace layouts."""
-    cmd = [HIPCC] + [f for f in FLAGS if f != "-O3"] + ["-O1", "-g", "-fsanitize=address", "-fno-gpu-sanitize", "-shared-libsan",
-                                                          "-o", out_path] + [os.path.join(CSRC, s) for s in SOURCES]
+    # host: -O1 -g instrumented; device: the product's -O3 (the LDS-DMA inline asm takes SGPR operands, which only the optimised device
+    # code keeps out of vector registers - and the device half is not what this build is for)
+    cmd = [HIPCC] + [f for f in FLAGS if f != "-O3"] + ["-Xarch_host", "-O1", "-Xarch_device", "-O3", "-g", "-fsanitize=address", "-fno-gpu-sanitize",
+                                                          "-shared-libsan", "-o", out_path] + [os.path.join(CSRC, s) for s in SOURCES]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc (asan) failed:\n" + r.stdout)

@@ -262,6 +262,8 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
         mb = (x / groups) * args.xcd_contig + j / cpx;
         if (j / cpx >= args.xcd_contig || mb >= args.n_tiles) return;
     }
+    nb = __builtin_amdgcn_readfirstlane(nb);     // (block-uniform by construction: said explicitly for the LDS-DMA asm's SGPR operands)
+    mb = __builtin_amdgcn_readfirstlane(mb);
     const int m0 = TILE ? mb * args.pb : mb * BM;            // first row (TILE: first position) of the tile
     const int Kc = args.Kc, Np = args.Np, M = args.M;
 
@@ -332,7 +334,7 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
     uint32_t f_voff = CONV ? a_off - a_pitch : a_off;               // lane: row offset of tap row dy
     int f_t = 0, f_kc = 0, f_j = 0, f_c = 0;
     const uint32_t a_dst = smem_base + G3_LUT_BYTES + wave * 256;   // + slot offset
-    auto stage_a = [&](uint32_t slot_off) {
+    auto stage_a = [&](uint32_t slot_off) __attribute__((always_inline)) {
 #ifndef SNN_EXP_NO_FETCH                            // (timing only: no spike-word stream at all)
         if (a_role) {
             const uint32_t d = __builtin_amdgcn_readfirstlane(a_dst + slot_off);
@@ -377,7 +379,7 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
     unsigned long long s_ptr = (unsigned long long)args.wpk;   // weight stream: plane 0 of the next chunk (scalar)
     int s_kc = 0;
     const uint32_t b_dst = smem_base + G3_LUT_BYTES + AW_BYTES + (wave % RBLK) * 1024;      // + slot offset, plane
-    auto stage_next = [&](uint32_t slot_off) {
+    auto stage_next = [&](uint32_t slot_off) __attribute__((always_inline)) {
         const uint32_t d = __builtin_amdgcn_readfirstlane(b_dst + slot_off);                // wave-uniform LDS address
         if (WN == 2) {
             glds16x3(sgpr_ptr(reinterpret_cast<const void*>(s_ptr)), sgpr_ptr(reinterpret_cast<const void*>(s_ptr + b_plane)),
@@ -414,12 +416,12 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
     const int lg8 = 8 * lg;
     // the lane's byte of the row word is read as a byte (ds_read_u8; the four k-groups of a row hit one dword: no conflict):
     // fragment address = byte << 4, one shift instead of bfe + shift
-    auto rd_w = [&](uint32_t slot_off, int mt) { return (uint32_t)*reinterpret_cast<const uint8_t*>(w_rd + lg + slot_off + mt * 64); };
-    auto rd_a = [&](uint32_t w) { return *reinterpret_cast<const bf16x8*>(lut + (w << 4)); };
+    auto rd_w = [&](uint32_t slot_off, int mt) __attribute__((always_inline)) { return (uint32_t)*reinterpret_cast<const uint8_t*>(w_rd + lg + slot_off + mt * 64); };
+    auto rd_a = [&](uint32_t w) __attribute__((always_inline)) { return *reinterpret_cast<const bf16x8*>(lut + (w << 4)); };
     // B fragment: row (tile*16 + lr), logical unit lg; swz depends on lr only
     const unsigned char* const b_rd = ring + AW_BYTES + (wn * 64 + lr) * G3_ROWB + ((lg ^ G3_SWZ(lr)) << 4);
     // group g of a chunk = (N-tile g/3, plane 2 - g%3): per accumulator the small terms first (lo, mid, hi)
-    auto rd_b = [&](uint32_t slot_off, int g) {
+    auto rd_b = [&](uint32_t slot_off, int g) __attribute__((always_inline)) {
         return *reinterpret_cast<const bf16x8*>(b_rd + slot_off + (2 - g % 3) * (BN * G3_ROWB) + (g / 3) * 16 * G3_ROWB);
     };
 
@@ -548,10 +550,7 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
                         for (int mt = 0; mt < MTA; ++mt) wq[mt] = rd_w(o_nxt, mt);
                     }
                     if (g >= AG0 && g - AG0 < MTA) af[(u & 1) ^ 1][g - AG0] = rd_a(wq[g - AG0]);
-                    // (3-slot ring: every chunk ends on vmcnt(0), so the copies of the two chunks past the end can simply be left out - 2 of
-                    // 72 weight panels less L2 -> LDS traffic per conv tile and nothing to drain before the epilogue; the 4-slot ring's
-                    // counted waits assume a copy set per chunk, and its linear layers have 392 chunks per tile: left as it is)
-                    if (g == 2 && (NB != 3 || c0 + u + NB - 1 < n_total)) {
+                    if (g == 2) {
                         stage_a(o_wr);
 #ifndef SNN_EXP_NO_GLDS
                         stage_next(o_wr);
@@ -632,7 +631,7 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
         const bool periods = args.periods != 0;
         // (period planes: u_1 - row group 0 - is a term of every step, u_2 of every second, u_3 of every third: the caller reads the three
         // once per neuron and passes them in; the larger divisors, one or two steps each, are read where they are needed)
-        auto tile_current = [&](const float* src, const int t, const float u1, const float u2, const float u3) {
+        auto tile_current = [&](const float* src, const int t, const float u1, const float u2, const float u3) __attribute__((always_inline)) {
             float cur = 0.0f;
             if (t >= t0 && t < t1) {
                 if (!periods) {

@@ -124,7 +124,7 @@ o8 = (C.c_int32 * 8)()
 bad(lib.snn_debug_tile_shape(1, 1000, 256, 8, 0, 0, None), "tile_shape null out")
 bad(lib.snn_debug_tile_shape(1, 0, 256, 8, 0, 0, o8), "tile_shape no units")
 bad(lib.snn_debug_tile_shape(0, 2000, 1024, 33, 0, 6, o8), "tile_shape T > 32")
-assert lib.snn_debug_tile_shape(1, 196416, 256, 8, 0, 0, o8) == 0 and o8[4] == 7 and o8[2] == 256 and o8[3] == 36       # host-only call: 7 live steps
+assert lib.snn_debug_tile_shape(1, 196416, 256, 8, 0, 0, o8) == 0 and o8[4] == 7 and o8[2] == 512 and o8[3] == 73       # host-only call: 7 live steps on the 512-row tile
 assert lib.snn_debug_tile_shape(0, 2000, 1024, 12, 0, 6, o8) == 0 and o8[4] == 10 and o8[3] * o8[4] <= o8[2]
 assert lib.snn_debug_tile_shape(0, 2000, 1024, 12, 1, 6, o8) == 0 and o8[4] == 11                                      # spike-rate mode: fc6 0 .. T-2
 assert lib.snn_debug_tile_shape(0, 2000, 1024, 1, 0, 7, o8) == 0 and o8[4] == 1

@@ -735,7 +735,7 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
                 }
             }
         };
-        // The reference's own configurations (T_rpn = 8: 7 period planes; T_det = 12: 10) as straight-line code: no step / row-group
+        // A given (T, window) as straight-line code: no step / row-group
         // guards, no counters (the general form spends two scalar instructions per guard and four per step on the rate counts, and a
         // wave issues one instruction - scalar or vector - per four cycles at best).  Period planes, v_leak == 0, no spike at step 0.
         auto lif_neuron_fixed = [&](const float* src, uint32_t& my0, uint32_t& my1, auto ts_c, auto tcs_c) __attribute__((always_inline)) {
@@ -763,8 +763,20 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
                 G3_KEEP_BALLOT(my0, my1, b, t);
             }
         };
+        // (instantiated for T = 4 ... 16 with the window this kernel's launches use without rate outputs: conv T - 1 steps, fc6 T - 2 -
+        // the paper's grid, metrics_for_different_timesteps.py:30-33; anything else takes the general form)
+        constexpr int FIXED_D = CONV ? 1 : 2;
         const bool fixed_ok = periods && !counting && args.p.v_leak == 0.0f && !(__fsub_rn(args.p.v_leak, args.p.v_th) > 0.0f) && t0 == 0;
-        const int fixed_cfg = !fixed_ok ? 0 : (T == 8 && t1 == 7) ? 1 : (T == 12 && t1 == 10) ? 2 : 0;      // block-uniform
+        const bool fixed_cfg = fixed_ok && T >= 4 && T <= 16 && t1 == T - FIXED_D;                          // block-uniform
+        auto lif_neuron_fixed_T = [&](const float* src, uint32_t& my0, uint32_t& my1) __attribute__((always_inline)) {
+            switch (T) {
+#define G3_FIXED_CASE(n) case n: lif_neuron_fixed(src, my0, my1, std::integral_constant<int, n>{}, std::integral_constant<int, n - FIXED_D>{}); break;
+                G3_FIXED_CASE(4) G3_FIXED_CASE(5) G3_FIXED_CASE(6) G3_FIXED_CASE(7) G3_FIXED_CASE(8) G3_FIXED_CASE(9) G3_FIXED_CASE(10)
+                G3_FIXED_CASE(11) G3_FIXED_CASE(12) G3_FIXED_CASE(13) G3_FIXED_CASE(14) G3_FIXED_CASE(15) G3_FIXED_CASE(16)
+#undef G3_FIXED_CASE
+            default: break;
+            }
+        };
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // staged-ahead copies of chunks past the end have landed
 #ifdef SNN_EXP_TIMELINE
         unsigned long long tl_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -820,8 +832,7 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
                     }
 #else
                     uint32_t cnt_hi = 0;
-                    if (fixed_cfg == 1) lif_neuron_fixed(src, my0, my1, std::integral_constant<int, 8>{}, std::integral_constant<int, 7>{});
-                    else if (fixed_cfg == 2) lif_neuron_fixed(src, my0, my1, std::integral_constant<int, 12>{}, std::integral_constant<int, 10>{});
+                    if (fixed_cfg) lif_neuron_fixed_T(src, my0, my1);
                     else if (counting) lif_neuron(src, my0, my1, cnt, cnt_hi, std::true_type{});
                     else lif_neuron(src, my0, my1, cnt, cnt_hi, std::false_type{});
                     if (two) cnt += cnt_hi;
@@ -866,8 +877,7 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
                         cnt1 += __popc((uint32_t)(b >> 32));
                     }
 #else
-                    if (fixed_cfg == 1) lif_neuron_fixed(src, my0, my1, std::integral_constant<int, 8>{}, std::integral_constant<int, 7>{});
-                    else if (fixed_cfg == 2) lif_neuron_fixed(src, my0, my1, std::integral_constant<int, 12>{}, std::integral_constant<int, 10>{});
+                    if (fixed_cfg) lif_neuron_fixed_T(src, my0, my1);
                     else if (counting) lif_neuron(src, my0, my1, cnt0, cnt1, std::true_type{});
                     else lif_neuron(src, my0, my1, cnt0, cnt1, std::false_type{});
 #endif

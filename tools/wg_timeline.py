@@ -44,6 +44,18 @@ def run():
     assert rc == 0, lib.snn_last_error()
 
 
+if len(sys.argv) > 2 and sys.argv[2] == "fc6":                      # the detector's fc6 + LIF launch instead (2000 RoIs, T = 12)
+    R, D, Hd, T6 = 2000, 12544, 1024, 12
+    x = torch.randn(R, D, device=dev) * 1.7
+    enc6 = ops.encode_rows(x, T6, p).permute(0, 2, 1).contiguous()  # period planes, word-major
+    w6b = ops.pack_linear_bf16x3(torch.randn(Hd, D, device=dev) / D ** 0.5)
+    T, P = T6, R * (Hd // 32) // 8                                   # (so that T * P * 8 = the spike planes' size)
+    buf = torch.zeros((T6 * R * (Hd // 32) + N_WG * 32,), dtype=torch.int32, device=dev)
+
+    def run():
+        rc = lib.snn_spike_gemm_lif_bf16x3(enc6.data_ptr(), T6, R, D, Hd, C.byref(p), w6b.data_ptr(), buf.data_ptr(), R * (Hd // 32), st)
+        assert rc == 0, lib.snn_last_error()
+
 for _ in range(10):
     run()
 torch.cuda.synchronize()

@@ -613,13 +613,6 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
         //   WN = 2 (CG = 64): lane = column, wave w takes positions w, w+8, ...; ballot = the word pair of (t, position)
         //   WN = 1 (CG = 32): lane = (position parity, column), wave w takes the position pairs; ballot = one word of
         //                     the even position (low half) and one of the odd position (high half)
-#ifndef SNN_EXP_EPI_NOPRIO
-        // From here on the wave issues no MFMA, while the CU's other work-group is in its K loop and its waves would otherwise win
-        // nearly every vector issue slot: the epilogue took 15 us of a work-group's 109 us lifetime (tools/wg_timeline.py) with the
-        // matrix pipe at the mercy of ONE work-group's waves meanwhile.  At the highest priority the epilogue's (few) vector
-        // instructions issue as soon as they are ready; the MFMAs of the other work-group take the slots in between.
-        __builtin_amdgcn_s_setprio(3);
-#endif
         constexpr int CG = G3_TILE_CG(WN), PITCH = CG + 4;
         float* const tile = reinterpret_cast<float*>(smem);
         uint32_t* const pos_cnt = reinterpret_cast<uint32_t*>(smem + G3_TILE_BYTES(WN));    // behind the tile image

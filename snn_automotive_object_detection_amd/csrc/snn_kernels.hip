@@ -350,7 +350,7 @@ static G3Tile g3_pick_tile(int wn, F wgs_of) {
 // column blocks every spike row and every output row passes through twice as many XCDs (FETCH 84 -> 190-206 MB, WRITE 98 ->
 // 98-198 MB per launch) for those 1.7 %.  SNN_BF16X3_WN=1|2 forces one shape everywhere (A-B / test knob).
 // (the conv ran the 256 x 128 tile until the end of round 3; with the straight-line LIF epilogue the 512 x 64 tile - half the weight bytes
-// per MFMA, 4-slot ring - is 1-2 % faster there too: tools/ab_knobs.py, profiles/r3_j_ab_knobs.txt.  SNN_BF16X3_WN=2 selects the old shape)
+// per MFMA, 4-slot ring - is 1-2 % faster there too: tools/ab_knobs.py, profiles/r3_k_ab_knobs.txt.  SNN_BF16X3_WN=2 selects the old shape)
 static int g3_wn(bool conv = false) { (void)conv; return knobs().bf16x3_wn ? knobs().bf16x3_wn : 1; }
 
 // rows of the work-group tile (MT = 8 is the 256 x 128 tile of MT = 4 / WN = 2 run by four fat waves)

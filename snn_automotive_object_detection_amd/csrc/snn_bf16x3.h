@@ -119,6 +119,7 @@ struct Gemm3Args {
     // set in div[t] (n - 1 for every divisor n <= Tc of t + 1), added in ascending n.  t0 = 0 in this mode.
     int periods;
     uint32_t div[SNN_MAX_STEPS];
+    int epi_general;             // SNN_EPI_GENERAL=1 (tests): the LIF tile epilogue's general form even where a straight-line instance exists
     int xcd_contig, xcd_cpx;     // xcd_contig > 0 (conv launches with 2 or 4 column blocks): row tiles per XCD; XCD x = blockIdx % 8 runs xcd_cpx
                                  // (1 or 2) column blocks on a CONTIGUOUS range of row tiles, see the kernel
     // T-in-tile modes: the LAST n_short row-waves of the work-group multiply MT - 1 M-tiles instead of MT ("short" waves: the
@@ -760,7 +761,7 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
         // the paper's grid, metrics_for_different_timesteps.py:30-33; anything else takes the general form)
         constexpr int FIXED_D = CONV ? 1 : 2;
         const bool fixed_ok = periods && !counting && args.p.v_leak == 0.0f && !(__fsub_rn(args.p.v_leak, args.p.v_th) > 0.0f) && t0 == 0;
-        const bool fixed_cfg = fixed_ok && T >= 4 && T <= 16 && t1 == T - FIXED_D;                          // block-uniform
+        const bool fixed_cfg = fixed_ok && !args.epi_general && T >= 4 && T <= 16 && t1 == T - FIXED_D;     // block-uniform
         auto lif_neuron_fixed_T = [&](const float* src, uint32_t& my0, uint32_t& my1) __attribute__((always_inline)) {
             switch (T) {
 #define G3_FIXED_CASE(n) case n: lif_neuron_fixed(src, my0, my1, std::integral_constant<int, n>{}, std::integral_constant<int, n - FIXED_D>{}); break;

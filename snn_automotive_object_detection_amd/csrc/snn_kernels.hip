@@ -144,6 +144,7 @@ struct Knobs {
     bool stage_periods;      // SNN_STAGE_PERIODS=1   tests / tools: the STAGE-level encoders emit period planes and the stage-level fused launches
                              //                       (snn_conv3x3_lif_bf16x3, snn_spike_gemm_lif_bf16x3) take their input planes as such
     int roi_e, roi_rw;       // SNN_ROI_E / SNN_ROI_RW  table-driven RoIAlign kernel: element groups per work-group / RoIs per wave (0 = default 2 / 4)
+    bool epi_general;        // SNN_EPI_GENERAL=1     T-in-tile LIF epilogue: the general (guarded) form instead of the straight-line instance of this T (tests)
     bool roi_tab;            // SNN_ROI_TAB=0         fused RoIAlign + encoder: the per-element kernel instead of the table-driven one (A/B, tests)
     bool dead_keep;          // SNN_DEAD_STEPS=keep   form the input currents of ALL time steps (A/B + test switch: the default
                              //                       skips the steps whose currents cannot reach an output, lif_windows)
@@ -176,6 +177,7 @@ static Knobs load_knobs() {
     k.periods = !((e = getenv("SNN_PERIOD_PLANES")) && e[0] == '0');
     k.enc_quant = !((e = getenv("SNN_ENC_QUANT")) && e[0] == '0');
     k.stage_periods = (e = getenv("SNN_STAGE_PERIODS")) && e[0] == '1';
+    k.epi_general = (e = getenv("SNN_EPI_GENERAL")) && e[0] == '1';
     k.roi_tab = !((e = getenv("SNN_ROI_TAB")) && e[0] == '0');
     k.roi_e = (e = getenv("SNN_ROI_E")) ? atoi(e) : 0;
     k.roi_rw = (e = getenv("SNN_ROI_RW")) ? atoi(e) : 0;
@@ -568,6 +570,7 @@ static int launch_gemm3(int mode, int mt, int wn, const Gemm3Args& a, hipStream_
     // in pairs (the RPN conv: 2 x 0.9 MB): see k_gemm_bf16x3.  SNN_BF16X3_XCD=0 switches it off (A/B).
     Gemm3Args ax = a;
     ax.n_tiles = tiles; ax.xcd_classes = 0;
+    ax.epi_general = knobs().epi_general;
     int grid = tiles * a.n_blocks;
     const size_t pair_bytes = (size_t)2 * G3_BN(wn) * a.Kc * 32 * 2 * 3;
     const bool conv_mode = mode == G3_CONV || mode == G3_CONV_LIF_TILE;

@@ -227,3 +227,28 @@ def test_threshold_encoders_leave_the_heads_bit_identical(gpu_device, monkeypatc
     monkeypatch.setenv("SNN_ENC_QUANT", "0")
     b = run()
     assert all(torch.equal(p_, q_) for p_, q_ in zip(a, b))
+
+
+@pytest.mark.parametrize("t_rpn,t_det", [(4, 8), (5, 9), (6, 10), (7, 11), (8, 12), (9, 13), (10, 14), (11, 15), (12, 16), (3, 17)])
+def test_straight_line_epilogue_instances_equal_the_general_form(gpu_device, monkeypatch, t_rpn, t_det):
+    """the T-in-tile LIF epilogue runs straight-line code instantiated per T (4 ... 16: conv window T - 1, fc6 window T - 2) and a
+    guarded general form otherwise (SNN_EPI_GENERAL=1 forces it): the same operations in the same order - bit-identical heads over
+    the paper's grid of time steps (metrics_for_different_timesteps.py:30-33) and one pair outside it"""
+    import snn_automotive_object_detection_amd as S
+    torch.manual_seed(t_rpn)
+    r = S.RPNHeadSNN(128, 3, t_rpn).to(gpu_device)
+    d = S.FastRCNNPredictorSNNFull(32 * 49, 128, 9, t_det).to(gpu_device)
+    with torch.no_grad():
+        r.shared_conv.weight.mul_(4.0)
+    feats = [torch.randn(2, 128, 21, 30, device=gpu_device) * 3, torch.randn(2, 128, 5, 7, device=gpu_device) * 3]
+    x = torch.randn(150, 32, 7, 7, device=gpu_device) * 3
+
+    def run():
+        lg, bb = r(feats)
+        c, b = d(x)
+        return [t.clone() for t in lg + bb] + [c.clone(), b.clone()]
+    a = run()
+    monkeypatch.setenv("SNN_EPI_GENERAL", "1")
+    b = run()
+    assert all(torch.equal(p_, q_) for p_, q_ in zip(a, b))
+    assert any(float(t.abs().max()) > 0 for t in a)

@@ -812,25 +812,11 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
                     uint32_t my0 = 0, my1 = 0;             // lane t keeps the word pair of time step t
                     const float* src = tile + pi * PITCH + lane;
                     uint32_t cnt = 0;                      // wave-uniform: spikes of this position in this pass
-#if defined(SNN_EXPERIMENTS) && defined(SNN_EXP_EPI_SERIAL)
-                    float vv = args.p.v_leak, ii = 0.0f;   // round 2's form (one LDS read / divisor-mask load per step inside the recurrence)
-                    const float u1 = periods ? src[0] : 0.0f, u2 = (periods && t1 > 1) ? src[group_stride] : 0.0f,
-                                u3 = (periods && t1 > 2) ? src[2 * group_stride] : 0.0f;
-                    for (int t = 0; t < T; ++t) {
-                        const float cur = tile_current(src, t, u1, u2, u3);
-                        const bool z = lif_step(cur, vv, ii, args.p);
-                        const unsigned long long b = __ballot(z);
-                        my0 = lane == t ? (uint32_t)b : my0;
-                        my1 = lane == t ? (uint32_t)(b >> 32) : my1;
-                        cnt += __popcll(two ? b : (b & 0xffffffffull));
-                    }
-#else
                     uint32_t cnt_hi = 0;
                     if (fixed_cfg) lif_neuron_fixed_T(src, my0, my1);
                     else if (counting) lif_neuron(src, my0, my1, cnt, cnt_hi, std::true_type{});
                     else lif_neuron(src, my0, my1, cnt, cnt_hi, std::false_type{});
                     if (two) cnt += cnt_hi;
-#endif
                     if (lane < T) {
                         if (!CONV && args.out_wm) {                    // word-major planes [T][word][row] (fc6 -> fc7)
                             uint32_t* dst = args.spk + (size_t)lane * args.spk_stride + (size_t)word0 * M + pos;
@@ -857,24 +843,9 @@ __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT
                     uint32_t my0 = 0, my1 = 0;             // lane t keeps the words of (t, even position), (t, odd position)
                     const float* src = tile + (live ? pi : 2 * pp) * PITCH + col;
                     uint32_t cnt0 = 0, cnt1 = 0;           // wave-uniform: spikes of the even / odd position in this pass
-#if defined(SNN_EXPERIMENTS) && defined(SNN_EXP_EPI_SERIAL)
-                    float vv = args.p.v_leak, ii = 0.0f;
-                    const float u1 = periods ? src[0] : 0.0f, u2 = (periods && t1 > 1) ? src[group_stride] : 0.0f,
-                                u3 = (periods && t1 > 2) ? src[2 * group_stride] : 0.0f;
-                    for (int t = 0; t < T; ++t) {
-                        const float cur = tile_current(src, t, u1, u2, u3);
-                        const bool z = lif_step(cur, vv, ii, args.p);
-                        const unsigned long long b = __ballot(z);
-                        my0 = lane == t ? (uint32_t)b : my0;
-                        my1 = lane == t ? (uint32_t)(b >> 32) : my1;
-                        cnt0 += __popc((uint32_t)b);
-                        cnt1 += __popc((uint32_t)(b >> 32));
-                    }
-#else
                     if (fixed_cfg) lif_neuron_fixed_T(src, my0, my1);
                     else if (counting) lif_neuron(src, my0, my1, cnt0, cnt1, std::true_type{});
                     else lif_neuron(src, my0, my1, cnt0, cnt1, std::false_type{});
-#endif
                     const bool odd_ok = 2 * pp + 1 < pb && m0 + 2 * pp + 1 < M;
                     if (lane < T) {
                         if (!CONV && args.out_wm) {

@@ -66,6 +66,10 @@ typedef struct snn_params {
 #define SNN_PRECISION_BF16X3 1   /* bf16 matrix cores, exact 3-way bf16 split of the fp32 weights; the conv runs
                                     time-batched (currents through HBM) followed by the LIF scan */
 
+#define SNN_PRECISION_F32_STRICT 3 /* SNN_PRECISION_F32 with the LI heads on the fp32 VALU kernel too: no weight is ever split into bf16 planes.
+                                    Where layers go whose weights snn_check_bf16x3_split reports as not exactly splittable (packed
+                                    weights: the SNN_PRECISION_F32 ones) */
+
 typedef struct snn_rpn_level {
     const float* feat;     /* [N][C][H][W] fp32, NCHW contiguous (what the FPN hands over) */
     int32_t N, H, W;
@@ -75,15 +79,20 @@ typedef struct snn_rpn_level {
 int snn_version(void);
 const char* snn_last_error(void);
 void snn_debug_reload_knobs(void);     /* re-read the SNN_* debug knobs from the environment (tests only) */
-/* Introspection (bench.py --sweep-t, tests): the row tile a T-in-tile launch of the bf16x3 family would use for `units`
- * positions (conv = 1: the RPN's shared 3x3 conv, C_out = n_cols) or RoIs (conv = 0: a linear layer with n_cols outputs) and
- * num_steps LIF steps.  out[0..7] = {M-tiles per wave, short row-waves, tile rows, positions or RoIs per tile, time steps whose
- * currents are formed (dead time steps removed), work-groups of the launch, column blocks, waves along N}.  Returns 0, or -4
- * if no tile holds that many steps (the launch then takes the un-fused path). */
 /* Introspection (tests): the threshold table of the period-plane encoder for these parameters - a neuron's first spike is at or before
  * step t iff its input is >= th[t] (csrc/snn_common.h: THRESHOLD FORM).  th[0..31] out; returns 1 if the table verified against the
  * recurrence on the host (the encoders then use it), 0 if not (they keep the recurrence), negative on bad arguments. */
 int snn_debug_encoder_thresholds(const snn_params* p, float* th32);
+/* Introspection (bench.py's t_sweep leg, tests): the row tile a T-in-tile launch of the bf16x3 family would use.
+ *   conv        1: the RPN's shared 3x3 conv (units = positions of the pyramid, n_cols = C_out); 0: a linear layer of the detector
+ *               head (units = RoIs, n_cols = its outputs)
+ *   num_steps   LIF steps T of the head
+ *   spike_rates (conv = 0 only) non-zero: the head runs in spike-rate mode, whose fc6 window is one step longer (the rate counts
+ *               lif6's spikes of every step, faster_rcnn.py:556)
+ *   layer       (conv = 0 only) 6 or 7: fc6's or fc7's window of time steps (any other value reads as 6)
+ * out[0..7] = {M-tiles per wave, short row-waves, tile rows, positions or RoIs per tile, time steps whose currents are formed
+ * (dead time steps removed), work-groups of the launch, column blocks, waves along N}.  Returns 0, or -4 if no tile holds that
+ * many steps (the launch then takes the un-fused path). */
 int snn_debug_tile_shape(int conv, long long units, int n_cols, int num_steps, int spike_rates, int layer, int32_t* out);
 
 /* ---- weight packing (call when the weights change; results are plain device buffers) ---------- */
@@ -101,6 +110,16 @@ int snn_pack_linear_weight(const float* w_nk, int N, int K, float* packed, snn_s
 size_t snn_packed_heads_elems(int NA, int NB, int K);
 int snn_pack_heads_weight(const float* w_a, int NA, const float* w_b, int NB, int K, float* packed,
                           snn_stream_t s);
+
+/* Exactness check of the bf16x3 split (SNN_PRECISION_BF16X3, and the LI heads of every precision but SNN_PRECISION_F32_STRICT, carry
+ * each fp32 weight as hi + mid + lo with three bf16 values).  The split is exact for every finite fp32 weight except magnitudes with
+ * bits below 2^-133 and values within 2^119 of FLT_MAX; this call classifies n weights (any layout) and writes three counters:
+ *   status3[0]  finite weights whose planes do NOT add up to the fp32 value
+ *   status3[1]  non-finite weights (the split of a NaN / infinity is meaningless)
+ *   status3[2]  weights with a plane that is a non-zero bf16 subnormal (exact; informational)
+ * A binding must not run the bf16x3 kernels on a tensor with status3[0] or status3[1] != 0 (the Python modules fall back to
+ * SNN_PRECISION_F32_STRICT with a RuntimeWarning).  status3 is a device buffer, written on `s`. */
+int snn_check_bf16x3_split(const float* w, size_t n, uint32_t* status3, snn_stream_t s);
 
 /* ---- RPN head ------------------------------------------------------------------------------- */
 /* P = sum over levels of N*H*W.  Outputs are position-major ("NHWC"): out_logits[P][A],

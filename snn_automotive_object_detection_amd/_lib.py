@@ -12,7 +12,7 @@ c_stream = C.c_void_p
 
 SNN_MAX_LEVELS = 8
 SNN_MAX_STEPS = 32
-PRECISIONS = {"f32": 0, "bf16x3": 1, "mxfp6": 2}
+PRECISIONS = {"f32": 0, "bf16x3": 1, "mxfp6": 2, "f32_strict": 3}
 
 
 class snn_params(C.Structure):
@@ -99,6 +99,7 @@ SYMBOLS = {
     "snn_pack_conv3x3_weight_bf16x3": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, c_stream]),
     "snn_packed_linear_bf16x3_elems": (C.c_size_t, [C.c_int, C.c_int]),
     "snn_pack_linear_weight_bf16x3": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, c_stream]),
+    "snn_check_bf16x3_split": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, c_stream]),
     "snn_packed_linear_mx_words": (C.c_size_t, [C.c_int, C.c_int]),
     "snn_packed_conv3x3_mx_words": (C.c_size_t, [C.c_int, C.c_int]),
     "snn_pack_linear_weight_mx": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, c_stream]),
@@ -124,6 +125,15 @@ _LIB = None
 
 class SnnHipError(RuntimeError):
     pass
+
+
+class InexactWeightSplit(SnnHipError):
+    """a weight tensor cannot be carried as three bf16 planes exactly (magnitudes with bits below 2^-133, values next to FLT_MAX,
+    NaN / infinity): the bf16x3 kernels must not run on it (ops.check_bf16x3_split; the modules fall back to "f32_strict")"""
+
+    def __init__(self, what: str, inexact: int, nonfinite: int):
+        super().__init__("%s: %d weight(s) are not exactly hi + mid + lo in bf16, %d are non-finite" % (what, inexact, nonfinite))
+        self.inexact, self.nonfinite = inexact, nonfinite
 
 
 def lib_path() -> str:

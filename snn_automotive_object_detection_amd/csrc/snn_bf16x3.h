@@ -910,6 +910,33 @@ __device__ __forceinline__ uint16_t f2bf_rn(float f) {
 }
 __device__ __forceinline__ float bf2f(uint16_t b) { return __uint_as_float((uint32_t)b << 16); }
 
+// Is the three-plane split of w exact, i.e. does (lo + mid) + hi - the order the kernels accumulate the planes in - give back w?
+// It does for every finite fp32 value whose lowest set mantissa bit is >= 2^-133 (the finest bf16 subnormal) and whose high plane
+// does not round up to infinity (|w| < 2^128 - 2^119): 3 x 8 significant bits cover the 24 of an fp32, and each residual is exact
+// (Sterbenz).  What is left: fp32 subnormals / tiny normals with bits below 2^-133 (inexact), values next to FLT_MAX (hi = inf),
+// and non-finite weights (the integer rounding of f2bf_rn turns a NaN into +-inf or 0).  status[0] += inexact finite weights,
+// status[1] += non-finite weights, status[2] += weights with a plane that is a non-zero bf16 SUBNORMAL (exact, but only if the
+// matrix cores keep subnormal operands: tests/test_gpu_stages.py::test_one_hot_spike_gemm_returns_the_weights_bitwise probes that).
+__global__ void k_bf16x3_split_check(const float* __restrict__ w, size_t n, uint32_t* __restrict__ status) {
+    uint32_t inexact = 0, nonfinite = 0, subnormal = 0;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
+        const float x = w[idx];
+        if ((__float_as_uint(x) & 0x7f800000u) == 0x7f800000u) { ++nonfinite; continue; }
+        const uint16_t hi = f2bf_rn(x);
+        const float r1 = __fsub_rn(x, bf2f(hi));
+        const uint16_t mid = f2bf_rn(r1);
+        const float r2 = __fsub_rn(r1, bf2f(mid));
+        const uint16_t lo = f2bf_rn(r2);
+        const float back = __fadd_rn(__fadd_rn(bf2f(lo), bf2f(mid)), bf2f(hi));
+        if (!(back == x)) ++inexact;
+        auto sub = [](uint16_t b) { return (b & 0x7f80u) == 0 && (b & 0x007fu) != 0; };
+        if (sub(hi) || sub(mid) || sub(lo)) ++subnormal;
+    }
+    if (inexact) atomicAdd(status + 0, inexact);
+    if (nonfinite) atomicAdd(status + 1, nonfinite);
+    if (subnormal) atomicAdd(status + 2, subnormal);
+}
+
 __global__ void k_pack_bf16x3(const float* __restrict__ src, uint16_t* __restrict__ dst, int mode, int K, int N,
                               int Kc, int Np, int Cin, int Cp) {
     const size_t plane = (size_t)Kc * Np * 32;

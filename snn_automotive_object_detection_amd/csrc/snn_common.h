@@ -17,11 +17,14 @@ struct NeuronP {
     float v_reset;
     float v_th;
     // encoders with zero rest / reset potentials only: the membrane value after a spike.  +0 = the reference's reset.
-    // ENC_FIRED (a huge negative number) = "period planes": the neuron then never crosses the threshold again, so plane
-    // t holds the neurons whose FIRST spike is at step t (see PERIOD PLANES below).
+    // ENC_FIRED (-infinity) = "period planes": the neuron then never crosses the threshold again, so plane
+    // t holds the neurons whose FIRST spike is at step t (see PERIOD PLANES below).  -inf is a LATCH for every input and every
+    // dt * tau_mem_inv: the next update forms -inf + ca * (x + inf) = NaN (or stays -inf for x = -inf / ca <= 0), and neither
+    // ever compares greater than the threshold.  (Until round 4 the sentinel was -1e30, which decays as (1 - ca)^k and let a
+    // neuron fire again within T for ca >= ~0.9 or inputs >= ~1e31: the e_n planes were then not disjoint.)
     float v_fire;
 };
-#define ENC_FIRED (-1.0e30f)
+#define ENC_FIRED (-__builtin_inff())
 
 // PERIOD PLANES.  The constant-current encoder (lif_current_encoder with v = 0 at the start and reset to 0, which is what the
 // reference builds: rpn.py:58,93,101 / faster_rcnn.py:444,484,494) is exactly periodic: after a spike the membrane is +0 again,

@@ -50,6 +50,10 @@ static int check_launch(const char* name) {
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// SNN_PRECISION_F32_STRICT = the fp32 family with the LI heads on the fp32 VALU kernel as well: no weight is ever split into bf16 planes
+static inline int prec_family(int precision) { return precision == SNN_PRECISION_F32_STRICT ? SNN_PRECISION_F32 : precision; }
+static inline int prec_family(const snn_params* p) { return prec_family(p->precision); }
+
 static NeuronP make_p(const snn_params* p, float v_th) {
     NeuronP q;
     q.ca = p->dt_tau_mem; q.cb = p->neg_dt_tau_syn; q.v_leak = p->v_leak; q.v_reset = p->v_reset;
@@ -254,7 +258,7 @@ static int enc_mode(const NeuronP& np, const EncTh** eth) {
 
 // period planes (snn_common.h): the encoder's spike trains are exactly periodic when it starts from and resets to +0
 static bool periods_possible(const snn_params* p) {
-    return p->precision == SNN_PRECISION_BF16X3 && p->v_leak == 0.0f && p->v_reset == 0.0f && !knobs().enc_generic && !knobs().bf16x3_lif_reg;
+    return prec_family(p) == SNN_PRECISION_BF16X3 && p->v_leak == 0.0f && p->v_reset == 0.0f && !knobs().enc_generic && !knobs().bf16x3_lif_reg;
 }
 
 static int g3_slots() {                       // CUs: two co-resident work-groups share a CU's matrix pipe, so the tail is
@@ -518,6 +522,14 @@ int snn_pack_linear_weight_bf16x3(const float* w, int N, int K, uint16_t* packed
     hipLaunchKernelGGL(k_pack_bf16x3, dim3((unsigned)min((size_t)4096, (total + 255) / 256)), dim3(256), 0,
                        (hipStream_t)s, w, packed, (int)PACK_LINEAR, K, N, Kc, Np, 0, 32);
     SNN_CHECK_LAUNCH("k_pack_bf16x3");
+    return 0;
+}
+
+int snn_check_bf16x3_split(const float* w, size_t n, uint32_t* status3, snn_stream_t s) {
+    if (!w || !status3 || n == 0) return fail(-1, "snn_check_bf16x3_split: bad argument");
+    if (hipMemsetAsync(status3, 0, 3 * sizeof(uint32_t), (hipStream_t)s) != hipSuccess) return fail(-3, "hipMemsetAsync failed");
+    hipLaunchKernelGGL(k_bf16x3_split_check, dim3((unsigned)min((size_t)2048, (n + 255) / 256)), dim3(256), 0, (hipStream_t)s, w, n, status3);
+    SNN_CHECK_LAUNCH("k_bf16x3_split_check");
     return 0;
 }
 
@@ -1186,7 +1198,8 @@ static int li_heads_impl(const uint32_t* spk, size_t spk_stride, int T, int M, i
     li_kappa(p, T, &kap);
     const int Kw = cdiv(K, 32), NOp = cdiv(NA + NB, 16) * 16;
     if (NOp > 256) return fail(-1, "snn_li_heads: %d outputs per row not supported", NA + NB);
-    const int force = knobs().li_heads;                       // debug / A-B knob: 1 "valu" forces the fp32 VALU kernel, 2 "mfma", 3 "ksplit"
+    // debug / A-B knob: 1 "valu" forces the fp32 VALU kernel, 2 "mfma", 3 "ksplit"; SNN_PRECISION_F32_STRICT always takes the VALU kernel
+    const int force = p->precision == SNN_PRECISION_F32_STRICT ? 1 : knobs().li_heads;
     // matrix-core kernel where all of W (as three bf16 planes) stays resident in LDS; the streamed form is latency
     // bound on small row counts (detector heads: 164 us against 88 us for the VALU kernel) and only runs when forced
     const bool fits = (size_t)Kw * 3 * NOp * 64 <= 96 * 1024;
@@ -1292,7 +1305,7 @@ size_t snn_rpn_head_workspace_bytes(const snn_rpn_level* lv, int n_levels, int C
     (void)A;
     if (!lv || n_levels <= 0 || n_levels > SNN_MAX_LEVELS || C <= 0 || T < 1) return 0;
     size_t a, b, c, tot;
-    rpn_ws_layout(rpn_positions(lv, n_levels, nullptr), precision != SNN_PRECISION_F32 ? rpn_positions_padded(lv, n_levels) : 0,
+    rpn_ws_layout(rpn_positions(lv, n_levels, nullptr), prec_family(precision) != SNN_PRECISION_F32 ? rpn_positions_padded(lv, n_levels) : 0,
                   C, T, precision, &a, &b, &c, &tot);
     return tot;
 }
@@ -1305,9 +1318,9 @@ int snn_rpn_head_forward_stages(const snn_rpn_level* lv, int n_levels, int C, in
         return fail(-1, "snn_rpn_head_forward: null argument");
     if (n_levels <= 0 || n_levels > SNN_MAX_LEVELS) return fail(-1, "snn_rpn_head_forward: n_levels=%d", n_levels);
     if (C <= 0 || A <= 0) return fail(-1, "snn_rpn_head_forward: bad C/A");
-    if (p->precision != SNN_PRECISION_F32 && p->precision != SNN_PRECISION_BF16X3 && p->precision != SNN_PRECISION_MXFP6)
+    if (prec_family(p) != SNN_PRECISION_F32 && prec_family(p) != SNN_PRECISION_BF16X3 && prec_family(p) != SNN_PRECISION_MXFP6)
         return fail(-1, "snn_rpn_head_forward: unknown precision %d", p->precision);
-    if (p->precision == SNN_PRECISION_MXFP6 && (C % 128 || !mx_tile_ok(lif_window_full_out(T).n)))
+    if (prec_family(p) == SNN_PRECISION_MXFP6 && (C % 128 || !mx_tile_ok(lif_window_full_out(T).n)))
         return fail(-4, "snn_rpn_head_forward: the mxfp6 kernels need C %% 128 == 0 and a T that fits a 512-row tile (C=%d, T=%d)", C, T);
     if (check_T(T, "snn_rpn_head_forward")) return -1;
     for (int l = 0; l < n_levels; ++l)
@@ -1316,9 +1329,9 @@ int snn_rpn_head_forward_stages(const snn_rpn_level* lv, int n_levels, int C, in
     int max_n = 0;
     const long long P = rpn_positions(lv, n_levels, &max_n);
     size_t o_spk, o_cur, o_cnt, need;
-    const bool mxp = p->precision != SNN_PRECISION_F32;            // encoder planes with a zero halo (k_gemm_bf16x3, k_gemm_mx)
+    const bool mxp = prec_family(p) != SNN_PRECISION_F32;            // encoder planes with a zero halo (k_gemm_bf16x3, k_gemm_mx)
     const long long Pe = mxp ? rpn_positions_padded(lv, n_levels) : P;
-    rpn_ws_layout(P, mxp ? Pe : 0, C, T, p->precision, &o_spk, &o_cur, &o_cnt, &need);
+    rpn_ws_layout(P, mxp ? Pe : 0, C, T, prec_family(p), &o_spk, &o_cur, &o_cnt, &need);
     if (ws_bytes < need) return fail(-2, "snn_rpn_head_forward: workspace %zu < %zu bytes", ws_bytes, need);
     const int Cw = cdiv(C, 32);
     const size_t stride = (size_t)P * Cw;            // words per time plane (spike planes)
@@ -1330,7 +1343,7 @@ int snn_rpn_head_forward_stages(const snn_rpn_level* lv, int n_levels, int C, in
     // bf16x3 conv -> LI heads: spike planes in blocks of four words when the heads kernel that will run reads them so (C = 256).
     // Decided up front, so that a stage-by-stage caller (bench.py's kernel breakdown) sees the same launches; a T that does
     // not fit a row tile runs the register-fused conv, which writes plain rows: then the heads read plain rows
-    bool split = p->precision == SNN_PRECISION_BF16X3 && !knobs().spk_rows && li_heads_reads_split(C, A, 4 * A) &&
+    bool split = prec_family(p) == SNN_PRECISION_BF16X3 && !knobs().spk_rows && li_heads_reads_split(C, A, 4 * A) &&
                  !knobs().bf16x3_lif_reg && cdiv(C, 32) * 32 % 128 == 0 &&
                  g3_some_tile_ok(Tc, true);
     // bf16x3: encoder planes word-major [T][Cw][Pe] - a conv tile's spike words of a chunk are then 128-byte runs (L2 read
@@ -1338,7 +1351,7 @@ int snn_rpn_head_forward_stages(const snn_rpn_level* lv, int n_levels, int C, in
     // 128-byte line of a word plane is shared by horizontally adjacent tiles, which then sat on different XCDs (FETCH_SIZE
     // x 2); with the XCD-contiguous tile order of round 3 the neighbours share an L2 and the fetch traffic is the same for
     // both layouts (profiles/r3_word_major_conv.txt).  SNN_PLANES=rm switches back (bit-identical).
-    const size_t wm_rows = (p->precision == SNN_PRECISION_BF16X3 && knobs().planes != 1) ? (size_t)Pe : 0;
+    const size_t wm_rows = (prec_family(p) == SNN_PRECISION_BF16X3 && knobs().planes != 1) ? (size_t)Pe : 0;
     uint32_t* enc = (uint32_t*)ws;
     uint32_t* spk = (uint32_t*)((char*)ws + o_spk);
     hipStream_t s = (hipStream_t)stream;
@@ -1378,7 +1391,7 @@ int snn_rpn_head_forward_stages(const snn_rpn_level* lv, int n_levels, int C, in
         SNN_CHECK_LAUNCH("k_encode_levels");
     }
     if (stage_mask & SNN_STAGE_CONV_LIF) {
-        if (p->precision == SNN_PRECISION_F32) {
+        if (prec_family(p) == SNN_PRECISION_F32) {
             if (spike_counts) {
                 hipError_t e = hipMemsetAsync(spike_counts, 0, sizeof(unsigned long long) * n_levels * max_n, s);
                 if (e != hipSuccess) return fail(-3, "hipMemsetAsync failed: %s", hipGetErrorString(e));
@@ -1393,7 +1406,7 @@ int snn_rpn_head_forward_stages(const snn_rpn_level* lv, int n_levels, int C, in
             // spike-rate mode: the LIF epilogue popcounts the spike words it ballots and adds them per (level, image)
             if (spike_counts && hipMemsetAsync(spike_counts, 0, sizeof(unsigned long long) * n_levels * max_n, s) != hipSuccess)
                 return fail(-3, "hipMemsetAsync failed");
-            int rc = p->precision == SNN_PRECISION_MXFP6
+            int rc = prec_family(p) == SNN_PRECISION_MXFP6
                          ? conv3x3_lif_mx_impl(enc, enc_stride, lv, n_levels, C, C, T, p, (const uint32_t*)w_shared_packed, spk, stride,
                                                spike_counts, max_n, stream)
                          : conv3x3_lif_bf16x3_impl(enc, enc_stride, lv, n_levels, C, C, T, p, (const uint16_t*)w_shared_packed,
@@ -1675,7 +1688,7 @@ size_t snn_det_head_workspace_bytes(int R, int D, int Hd, int K, int K4, int T, 
 
 // the detector's bf16x3 path with both linear layers fused with their LIF (one row tile holds all T steps)
 static bool det_b3_tiles(const snn_params* p, const DetWindows& w) {
-    return p->precision == SNN_PRECISION_BF16X3 && g3_some_tile_ok(w.fc6.n) && g3_some_tile_ok(w.fc7.n);
+    return prec_family(p) == SNN_PRECISION_BF16X3 && g3_some_tile_ok(w.fc6.n) && g3_some_tile_ok(w.fc7.n);
 }
 // ... which takes its encoder planes word-major [T][D/32][R] (and hands fc6's spikes to fc7 that way)
 static bool det_planes_wm(const snn_params* p, const DetWindows& w) { return det_b3_tiles(p, w) && knobs().planes != 1; }
@@ -1695,8 +1708,8 @@ static int det_head_from_planes(int R, int D, int Hd, int K, int K4, int T, cons
     int rc;
     if (spk6_count) { if (hipMemsetAsync(spk6_count, 0, sizeof(uint32_t) * R, s) != hipSuccess) return fail(-3, "hipMemsetAsync failed"); }
     if (spk7_count) { if (hipMemsetAsync(spk7_count, 0, sizeof(uint32_t) * R, s) != hipSuccess) return fail(-3, "hipMemsetAsync failed"); }
-    const bool b3 = p->precision == SNN_PRECISION_BF16X3, mx = p->precision == SNN_PRECISION_MXFP6;
-    if (p->precision != SNN_PRECISION_F32 && !b3 && !mx) return fail(-1, "snn_det_head_forward: unknown precision %d", p->precision);
+    const bool b3 = prec_family(p) == SNN_PRECISION_BF16X3, mx = prec_family(p) == SNN_PRECISION_MXFP6;
+    if (prec_family(p) != SNN_PRECISION_F32 && !b3 && !mx) return fail(-1, "snn_det_head_forward: unknown precision %d", p->precision);
     if (mx) {
         if (D % 128 || Hd % 128)
             return fail(-4, "snn_det_head_forward: the mxfp6 kernels need D, Hd %% 128 == 0");

@@ -7,7 +7,7 @@ import torch
 from torch import nn
 
 from . import ops
-from .rpn import _WeightCache
+from .rpn import _WeightCache, _pack_heads_unchecked, _strict_if_inexact, _warn_once_box
 
 
 class FastRCNNPredictorSNNFull(nn.Module):
@@ -43,12 +43,13 @@ class FastRCNNPredictorSNNFull(nn.Module):
         self._c6 = {"f32": _WeightCache(), "bf16x3": _WeightCache(), "mxfp6": _WeightCache()}
         self._c7 = {"f32": _WeightCache(), "bf16x3": _WeightCache(), "mxfp6": _WeightCache()}
         self._ch = _WeightCache()
+        self._cache_split = _WeightCache()      # None, or why these weights cannot be carried as three bf16 planes (-> "f32_strict")
         self.last_spike_counts = None
 
     def invalidate_packed_weights(self) -> None:
         """drop the packed copies of the weights (needed after in-place edits through ``param.data``, which do not bump the
         version counter the cache is keyed on); rebuilt on the next forward"""
-        for c in list(self._c6.values()) + list(self._c7.values()) + [self._ch]:
+        for c in list(self._c6.values()) + list(self._c7.values()) + [self._ch, self._cache_split]:
             c.invalidate()
 
     def _apply(self, fn, *args, **kwargs):
@@ -65,15 +66,27 @@ class FastRCNNPredictorSNNFull(nn.Module):
             return "bf16x3"
         return self.precision
 
-    def _params(self):
-        return ops.make_params(self.p_enc, self.p_lif, self.dt, self.li_order, self._eff_precision())
+    def _params(self, precision=None):
+        return ops.make_params(self.p_enc, self.p_lif, self.dt, self.li_order, precision or self._resolve_precision())
 
-    def _packed(self):
+    def _resolve_precision(self) -> str:
+        """see RPNHeadSNN._resolve_precision: "f32_strict" (with a RuntimeWarning) where a weight does not split into three bf16
+        planes exactly"""
         prec = self._eff_precision()
-        pack = {"f32": ops.pack_linear, "bf16x3": ops.pack_linear_bf16x3, "mxfp6": ops.pack_linear_mx}[prec]
-        w6 = self._c6[prec].get((self.fc6.weight,), pack)
-        w7 = self._c7[prec].get((self.fc7.weight,), pack)
-        wh = self._ch.get((self.cls_score.weight, self.bbox_pred.weight), ops.pack_heads)
+        if prec == "f32_strict" or not self.fc6.weight.is_cuda:       # (CPU weights: forward raises anyway - no CPU path)
+            return prec
+        split = (self.cls_score.weight, self.bbox_pred.weight) + ((self.fc6.weight, self.fc7.weight) if prec == "bf16x3" else ())
+        return _strict_if_inexact(self, prec, self._cache_split.get(split, _warn_once_box(ops.split_problem)))
+
+    def _packed(self, prec=None):
+        """packed fc6, fc7, LI heads for `prec` (default: the precision this forward resolves to)"""
+        prec = prec or self._resolve_precision()
+        pack = {"f32": ops.pack_linear, "f32_strict": ops.pack_linear, "bf16x3": lambda w: ops.pack_linear_bf16x3(w, check_split=False),
+                "mxfp6": ops.pack_linear_mx}[prec]
+        slot = "f32" if prec == "f32_strict" else prec
+        w6 = self._c6[slot].get((self.fc6.weight,), pack)
+        w7 = self._c7[slot].get((self.fc7.weight,), pack)
+        wh = self._ch.get((self.cls_score.weight, self.bbox_pred.weight), _pack_heads_unchecked)
         return w6, w7, wh
 
     @torch.no_grad()
@@ -81,11 +94,12 @@ class FastRCNNPredictorSNNFull(nn.Module):
         T = int(self.num_steps)
         Hd, K = self.representation_size, self.num_classes
         K4 = self.bbox_pred.weight.shape[0]
-        w6, w7, wh = self._packed()
+        prec = self._resolve_precision()
+        w6, w7, wh = self._packed(prec)
         x = x.flatten(start_dim=1)                                     # :473
         if x.shape[1] != self.in_channels:
             raise ValueError("expected %d input features, got %d" % (self.in_channels, x.shape[1]))
-        out = ops.det_head_forward(x, Hd, K, K4, T, self._params(), w6, w7, wh, spike_rates=self.spike_rates)
+        out = ops.det_head_forward(x, Hd, K, K4, T, self._params(prec), w6, w7, wh, spike_rates=self.spike_rates)
         return self._finish(out, x.shape[0], x.device)
 
     @torch.no_grad()
@@ -95,11 +109,12 @@ class FastRCNNPredictorSNNFull(nn.Module):
         T = int(self.num_steps)
         Hd, K = self.representation_size, self.num_classes
         K4 = self.bbox_pred.weight.shape[0]
-        w6, w7, wh = self._packed()
+        prec = self._resolve_precision()
+        w6, w7, wh = self._packed(prec)
         if feats[0].shape[1] * 49 != self.in_channels:
             raise ValueError("expected %d input features, got %d x 49" % (self.in_channels, feats[0].shape[1]))
         out = ops.det_head_forward_roialign(feats, scales, rois[:, 1:5], rois[:, 0], roi_level, Hd, K, K4, T,
-                                            self._params(), w6, w7, wh, spike_rates=self.spike_rates)
+                                            self._params(prec), w6, w7, wh, spike_rates=self.spike_rates)
         return self._finish(out, rois.shape[0], rois.device)
 
     def _finish(self, out, R, dev):

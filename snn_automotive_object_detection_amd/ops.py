@@ -94,11 +94,16 @@ def pack_linear(w: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def pack_heads(wa: torch.Tensor, wb: torch.Tensor) -> torch.Tensor:
+def pack_heads(wa: torch.Tensor, wb: torch.Tensor, check_split: bool = True) -> torch.Tensor:
+    """``check_split``: the LI-head kernels of every precision but "f32_strict" split these weights into three bf16 planes on the
+    fly, so the same exactness check applies (InexactWeightSplit)"""
     _need_gpu(wa, "head weight")
     lib = _lib.load()
     wa = _f32c(wa).flatten(1)
     wb = _f32c(wb).flatten(1)
+    if check_split:
+        check_bf16x3_split(wa, "LI head weight %s" % (tuple(wa.shape),))
+        check_bf16x3_split(wb, "LI head weight %s" % (tuple(wb.shape),))
     na, k = wa.shape
     nb = wb.shape[0]
     assert wb.shape[1] == k
@@ -107,20 +112,54 @@ def pack_heads(wa: torch.Tensor, wb: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def pack_conv3x3_bf16x3(w: torch.Tensor) -> torch.Tensor:
+def bf16x3_split_status(w: torch.Tensor) -> Tuple[int, int, int]:
+    """(inexact, non-finite, subnormal-plane) counts of snn_check_bf16x3_split for a weight tensor.  One host synchronisation -
+    weights are packed when they change, not per forward."""
+    _need_gpu(w, "weight")
+    lib = _lib.load()
+    w = _f32c(w)
+    status = torch.empty(3, dtype=torch.int32, device=w.device)
+    _lib.check(lib.snn_check_bf16x3_split(_ptr(w), w.numel(), _ptr(status), _stream()), "snn_check_bf16x3_split")
+    a, b, c = status.tolist()
+    return a, b, c
+
+
+def check_bf16x3_split(w: torch.Tensor, what: str = "weight") -> None:
+    """raise InexactWeightSplit unless every element of w is exactly the sum of its three bf16 planes"""
+    inexact, nonfinite, _ = bf16x3_split_status(w)
+    if inexact or nonfinite:
+        raise _lib.InexactWeightSplit(what, inexact, nonfinite)
+
+
+def split_problem(*weights: torch.Tensor) -> Optional[_lib.InexactWeightSplit]:
+    """None if every tensor splits exactly, else the InexactWeightSplit describing the first one that does not (the modules cache
+    this per weight version and fall back to "f32_strict")"""
+    for w in weights:
+        try:
+            check_bf16x3_split(w, "weight %s" % (tuple(w.shape),))
+        except _lib.InexactWeightSplit as e:
+            return e
+    return None
+
+
+def pack_conv3x3_bf16x3(w: torch.Tensor, check_split: bool = True) -> torch.Tensor:
     _need_gpu(w, "conv weight")
     lib = _lib.load()
     w = _f32c(w)
+    if check_split:
+        check_bf16x3_split(w, "conv weight %s" % (tuple(w.shape),))
     co, ci = w.shape[0], w.shape[1]
     out = torch.empty(lib.snn_packed_conv3x3_bf16x3_elems(co, ci), dtype=torch.int16, device=w.device)
     _lib.check(lib.snn_pack_conv3x3_weight_bf16x3(_ptr(w), co, ci, _ptr(out), _stream()), "snn_pack_conv3x3_weight_bf16x3")
     return out
 
 
-def pack_linear_bf16x3(w: torch.Tensor) -> torch.Tensor:
+def pack_linear_bf16x3(w: torch.Tensor, check_split: bool = True) -> torch.Tensor:
     _need_gpu(w, "linear weight")
     lib = _lib.load()
     w = _f32c(w)
+    if check_split:
+        check_bf16x3_split(w, "linear weight %s" % (tuple(w.shape),))
     n, k = w.shape
     out = torch.empty(lib.snn_packed_linear_bf16x3_elems(n, k), dtype=torch.int16, device=w.device)
     _lib.check(lib.snn_pack_linear_weight_bf16x3(_ptr(w), n, k, _ptr(out), _stream()), "snn_pack_linear_weight_bf16x3")

@@ -10,6 +10,7 @@ import torch.nn.functional as F
 from torch import nn, Tensor
 
 from .stock import boxes as box_ops
+from .rpn import _WARN_LOCK
 
 
 class RoIHeadsSNN(nn.Module):
@@ -56,8 +57,10 @@ class RoIHeadsSNN(nn.Module):
             why = self._hip_postprocess_refusal(len(per_image), max(per_image), class_logits.shape[-1])
             if why is None:
                 return self._postprocess_hip(class_logits, box_regression, proposals, image_shapes, per_image)
-            if why not in self._warned:                       # loud, once per reason: the stock-torch path is ~4x slower per batch
+            with _WARN_LOCK:                                  # loud, once per reason: the stock-torch path is ~4x slower per batch
+                first = why not in self._warned
                 self._warned.add(why)
+            if first:
                 warnings.warn("RoIHeadsSNN: detection post-processing falls back to the stock torch ops (%s)" % why, RuntimeWarning)
         return self.postprocess_detections_reference(class_logits, box_regression, proposals, image_shapes)
 

@@ -5,6 +5,7 @@ Same constructor, same ``forward`` signature and return values, same ``state_dic
 ``RegionProposalNetwork.forward`` (rpn.py:613) can call it unchanged.  The spike-rate variant the
 reference keeps in a string literal (rpn.py:126-200, enabled there by editing the source) is the
 attribute ``spike_rates`` here.  Inference only (no autograd through the kernels)."""
+import threading
 import warnings
 from typing import List, Tuple
 
@@ -13,6 +14,10 @@ from torch import nn, Tensor
 
 from . import ops
 from ._cache import StreamSafeEntry
+
+
+_WARN_LOCK = threading.Lock()       # one-warning-per-reason bookkeeping of the fallback gates (module-level: a lock held by an
+                                    # nn.Module would make the model un-copyable / un-picklable; StreamPipeline calls forward from several threads)
 
 
 class _WeightCache:
@@ -33,6 +38,27 @@ class _WeightCache:
     def get(self, tensors, fn):
         key = tuple((t.data_ptr(), t._version, str(t.device)) for t in tensors)
         return self._entry.get(key, lambda: fn(*tensors), tensors[0].device)
+
+
+def _pack_heads_unchecked(wa, wb):
+    return ops.pack_heads(wa, wb, check_split=False)          # (the modules check the split themselves: _resolve_precision)
+
+
+def _warn_once_box(fn):
+    """cache value = [verdict, warned?] so that the fallback warning is raised once per weight version"""
+    return lambda *tensors: [fn(*tensors), False]
+
+
+def _strict_if_inexact(module, prec: str, box) -> str:
+    problem = box[0]
+    if problem is None:
+        return prec
+    with _WARN_LOCK:
+        first, box[1] = not box[1], True
+    if first:
+        warnings.warn("%s: %s - running precision \"f32_strict\" (fp32 matrix cores, fp32 VALU heads) instead of \"%s\""
+                      % (type(module).__name__, problem, prec), RuntimeWarning)
+    return "f32_strict"
 
 
 class RPNHeadSNN(nn.Module):
@@ -74,11 +100,12 @@ class RPNHeadSNN(nn.Module):
                 torch.nn.init.normal_(layer.weight, std=0.01)
         self._cache_shared = {"f32": _WeightCache(), "bf16x3": _WeightCache(), "mxfp6": _WeightCache()}
         self._cache_heads = _WeightCache()
+        self._cache_split = _WeightCache()      # None, or why these weights cannot be carried as three bf16 planes (-> "f32_strict")
         self.last_spike_counts = None
 
     def invalidate_packed_weights(self) -> None:
         """drop the packed (bf16x3 / mxfp6 / f32 fragment-major) copies of the weights; they are rebuilt on the next forward"""
-        for c in list(self._cache_shared.values()) + [self._cache_heads]:
+        for c in list(self._cache_shared.values()) + [self._cache_heads, self._cache_split]:
             c.invalidate()
 
     def _apply(self, fn, *args, **kwargs):
@@ -95,21 +122,34 @@ class RPNHeadSNN(nn.Module):
             return "bf16x3"
         return self.precision
 
-    def _params(self):
-        return ops.make_params(self.p_enc, self.p_lif, self.dt, self.li_order, self._eff_precision())
+    def _params(self, precision=None):
+        return ops.make_params(self.p_enc, self.p_lif, self.dt, self.li_order, precision or self._resolve_precision())
 
-    def _packed_shared(self):
+    def _resolve_precision(self) -> str:
+        """``_eff_precision()`` unless a weight the kernels of that precision would split into three bf16 planes does not split
+        EXACTLY (ops.check_bf16x3_split: magnitudes with bits below 2^-133, values next to FLT_MAX, NaN / infinity): then
+        "f32_strict" - fp32 matrix cores and fp32 VALU heads, nothing is split - with one RuntimeWarning per weight version.
+        The verdict is cached with the packed weights (one host synchronisation per weight update)."""
         prec = self._eff_precision()
-        pack = {"f32": ops.pack_conv3x3, "bf16x3": ops.pack_conv3x3_bf16x3, "mxfp6": ops.pack_conv3x3_mx}[prec]
-        return self._cache_shared[prec].get((self.shared_conv.weight,), pack)
+        if prec == "f32_strict" or not self.shared_conv.weight.is_cuda:       # (CPU weights: forward raises anyway - no CPU path)
+            return prec
+        split = (self.conv_cls.weight, self.conv_bbox.weight) + ((self.shared_conv.weight,) if prec == "bf16x3" else ())
+        return _strict_if_inexact(self, prec, self._cache_split.get(split, _warn_once_box(ops.split_problem)))
+
+    def _packed_shared(self, prec=None):
+        prec = prec or self._resolve_precision()
+        pack = {"f32": ops.pack_conv3x3, "f32_strict": ops.pack_conv3x3, "bf16x3": lambda w: ops.pack_conv3x3_bf16x3(w, check_split=False),
+                "mxfp6": ops.pack_conv3x3_mx}[prec]
+        return self._cache_shared["f32" if prec == "f32_strict" else prec].get((self.shared_conv.weight,), pack)
 
     @torch.no_grad()
     def forward(self, x: List[Tensor]) -> Tuple[List[Tensor], List[Tensor]]:
         C, A, T = self.in_channels, self.num_anchors, int(self.num_steps)
-        w_shared = self._packed_shared()
-        w_heads = self._cache_heads.get((self.conv_cls.weight, self.conv_bbox.weight), ops.pack_heads)
+        prec = self._resolve_precision()
+        w_shared = self._packed_shared(prec)
+        w_heads = self._cache_heads.get((self.conv_cls.weight, self.conv_bbox.weight), _pack_heads_unchecked)
         out_l, out_b, rows, (counts, sum_l, sum_b, rate_rows) = ops.rpn_head_forward(
-            list(x), C, A, T, self._params(), w_shared, w_heads, spike_rates=self.spike_rates)
+            list(x), C, A, T, self._params(prec), w_shared, w_heads, spike_rates=self.spike_rates)
         logits, bbox_reg, rates = [], [], []
         pos = 0
         for l, f in enumerate(x):
@@ -266,6 +306,10 @@ class RegionProposalNetwork(nn.Module):
             return "%d images per batch (HIP path: <= 64)" % N
         if A > 16:
             return "%d anchors per location (HIP path: <= 16)" % A
+        for l, o in enumerate(objectness):                  # per-level index ranges (32-bit element indices, 28-bit slot keys)
+            per_image = int(o.shape[1] * o.shape[2] * o.shape[3])
+            if per_image * N > 0x7fffffff or per_image >= (1 << 28):
+                return "level %d holds %d anchors per image (HIP path: < 2^28 per image, < 2^31 per batch)" % (l, per_image)
         k = sum(min(int(self.pre_nms_top_n()), int(o.shape[1] * o.shape[2] * o.shape[3])) for o in objectness)
         if k > 8192:
             return "%d pre-NMS candidates per image (HIP path: <= 8192)" % k
@@ -305,8 +349,10 @@ class RegionProposalNetwork(nn.Module):
             if why is None:
                 boxes, pre_nms = self._proposals_hip(objectness, pred_bbox_deltas, images, feats)
                 return boxes, (pre_nms if rates is None else rates)
-            if why not in self._warned:                       # loud, once per reason
+            with _WARN_LOCK:                                 # loud, once per reason
+                first = why not in self._warned
                 self._warned.add(why)
+            if first:
                 warnings.warn("RegionProposalNetwork: proposal selection falls back to the stock torch ops (%s)" % why, RuntimeWarning)
         anchors = self.anchor_generator(images, feats)
         num_images = len(anchors)

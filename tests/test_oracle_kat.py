@@ -162,3 +162,26 @@ def test_encoder_threshold_table_against_the_oracle_encoder():
     fired_by = np.logical_or.accumulate(z, axis=0)                                              # first spike at or before step t
     expect = xs[None, :] >= th[:, None]
     assert np.array_equal(fired_by, expect)
+
+
+def test_encoder_on_non_finite_and_extreme_inputs_kat():
+    """Norse's encoder resets ARITHMETICALLY, v - z * (v - v_reset) (lif_current_encoder; /root/reference/rpn.py:101,
+    faster_rcnn.py:494): a +inf feature spikes ONCE and is NaN ever after; -inf and NaN never spike; huge finite values and FLT_MAX
+    spike every step; -0.0 never.  The HIP encoders reset by selection: they agree on all of these EXCEPT +inf, which they turn into a
+    period-1 neuron (documented in INTEGRATION.md; tests/test_gpu_exactness.py asserts the documented behaviour and that
+    SNN_ENC_GENERIC=1 reproduces this table)."""
+    from oracle import snn_oracle as OR
+    x = torch.tensor([float("inf"), float("-inf"), float("nan"), 3e38, -0.0, 3.4028235e38])
+    z = OR.encoder_spikes(x, 8)
+    assert z[:, 0].tolist() == [1.0, 0, 0, 0, 0, 0, 0, 0]
+    assert float(z[:, 1].sum()) == 0 and float(z[:, 2].sum()) == 0 and float(z[:, 4].sum()) == 0
+    assert z[:, 3].tolist() == [1.0] * 8 and z[:, 5].tolist() == [1.0] * 8
+    # the library's threshold table classifies them the same way except +inf (first spike at step 0 -> period 1)
+    import ctypes as C
+    from snn_automotive_object_detection_amd import _lib, ops
+    p = ops.make_params(ops.LIFParameters(v_th=torch.tensor(0.25)), ops.LIFParameters(alpha=100, v_th=torch.tensor(0.1)))
+    th = (C.c_float * 32)()
+    assert _lib.load().snn_debug_encoder_thresholds(C.byref(p), th) == 1
+    with np.errstate(invalid="ignore"):
+        first_by_0 = x.numpy() >= np.float32(th[0])
+    assert first_by_0.tolist() == [True, False, False, True, False, True]

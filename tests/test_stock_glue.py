@@ -199,3 +199,43 @@ def test_hip_gates_mirror_the_c_limits():
     rpn._pre_nms_top_n = {"training": 1000, "testing": 1000}
     assert "anchors" in rpn._hip_proposals_refusal([torch.zeros(1, 17, 4, 4)])
     assert "images" in rpn._hip_proposals_refusal([torch.zeros(65, 3, 4, 4)])
+
+
+# ---- derived-data caches must not make a model un-copyable (they hold a lock and a HIP event) ----
+def _copy_roundtrips(m):
+    import io
+    import pickle
+    out = [copy.deepcopy(m), pickle.loads(pickle.dumps(m))]
+    buf = io.BytesIO()
+    torch.save(m, buf)
+    buf.seek(0)
+    out.append(torch.load(buf, weights_only=False))
+    return out
+
+
+def test_modules_with_caches_deepcopy_and_pickle():
+    from snn_automotive_object_detection_amd import RPNHeadSNN, FastRCNNPredictorSNNFull
+    from snn_automotive_object_detection_amd.rpn import RegionProposalNetwork
+    from snn_automotive_object_detection_amd.stock.backbone import FrozenBatchNorm2d
+    bn = FrozenBatchNorm2d(8)
+    x = torch.randn(2, 8, 5, 5)
+    y = bn(x)                                             # fills the folded-constant cache
+    for c in _copy_roundtrips(bn):
+        assert torch.equal(c(x), y)
+        assert c._folded is not bn._folded                # a fresh entry, not a shared one
+    ag = AnchorGenerator(((32,),), ((0.5, 1.0, 2.0),))
+    il = ImageList(torch.zeros(1, 3, 64, 64), [(64, 64)])
+    a0 = ag(il, [torch.zeros(1, 4, 8, 8)])[0]
+    for c in _copy_roundtrips(ag):
+        assert torch.equal(c(il, [torch.zeros(1, 4, 8, 8)])[0], a0)
+    head = RPNHeadSNN(32, 3, 8)
+    det = FastRCNNPredictorSNNFull(32 * 49, 64, 5, 4)
+    rpn = RegionProposalNetwork(ag, head, 0.7, 0.3, 256, 0.5, dict(training=2000, testing=1000), dict(training=2000, testing=1000), 0.7)
+    rpn._warned.add("x")
+    for m in (head, det, rpn):
+        for c in _copy_roundtrips(m):
+            sd, sc = m.state_dict(), c.state_dict()
+            assert sd.keys() == sc.keys() and all(torch.equal(sd[k], sc[k]) for k in sd)
+    # EMA-style copy
+    from torch.optim.swa_utils import AveragedModel
+    AveragedModel(head)

@@ -152,6 +152,7 @@ struct Knobs {
     bool roi_tab;            // SNN_ROI_TAB=0         fused RoIAlign + encoder: the per-element kernel instead of the table-driven one (A/B, tests)
     bool dead_keep;          // SNN_DEAD_STEPS=keep   form the input currents of ALL time steps (A/B + test switch: the default
                              //                       skips the steps whose currents cannot reach an output, lif_windows)
+    bool det_pair;           // SNN_DET_PAIR=0        detector head: fc6 + LIF and fc7 + LIF as two launches instead of one (A/B, tests)
     int planes;              // SNN_PLANES=rm|wm      internal spike planes of the bf16x3 heads: all row-major [T][row][word] / all
                              //                       word-major [T][word][row] (1 / 2; 0 = default = word-major since round 3;
                              //                       bit-identical results either way, A/B + test switch)
@@ -183,6 +184,7 @@ static Knobs load_knobs() {
     k.stage_periods = (e = getenv("SNN_STAGE_PERIODS")) && e[0] == '1';
     k.epi_general = (e = getenv("SNN_EPI_GENERAL")) && e[0] == '1';
     k.roi_tab = !((e = getenv("SNN_ROI_TAB")) && e[0] == '0');
+    k.det_pair = !((e = getenv("SNN_DET_PAIR")) && e[0] == '0');
     k.roi_e = (e = getenv("SNN_ROI_E")) ? atoi(e) : 0;
     k.roi_rw = (e = getenv("SNN_ROI_RW")) ? atoi(e) : 0;
     if (k.roi_e < 0 || k.roi_e > 16) k.roi_e = 0;
@@ -564,7 +566,10 @@ static bool g3_some_tile_ok(int Tc, bool conv = false) {
     return g3_pick_tile(g3_wn(conv), [&](int rows) { return g3_tile_ok(Tc, rows) ? 1ll : 0ll; }).mt != 0;
 }
 
-static int launch_gemm3(int mode, int mt, int wn, const Gemm3Args& a, hipStream_t s) {
+struct G3Launch { Gemm3Args ax; int grid, lds, threads; const void* kern; };
+
+// everything of a k_gemm_bf16x3 launch but the launch itself: kernel instance, LDS size, block order, grid
+static int prepare_gemm3(int mode, int mt, int wn, const Gemm3Args& a, G3Launch* L) {
     // LIF_REG owns its CU (256 registers per wave); the others run two work-groups per CU
     const void* kern;
     int lds = G3_LDS(wn == 1 ? G3_NB1 : 3, wn), tiles = cdiv(a.M, g3_bm(wn, mt));
@@ -580,7 +585,8 @@ static int launch_gemm3(int mode, int mt, int wn, const Gemm3Args& a, hipStream_
     static_assert(2 * (G3_TILE_BYTES(1) + G3_CNT_BYTES) <= 160 * 1024 && 2 * G3_LDS(3, 2) <= 160 * 1024, "two work-groups per CU");
     // XCD-aware order for launches with 4, 8 or 16 column blocks whose weight panels are small enough to stay in an XCD's L2
     // in pairs (the RPN conv: 2 x 0.9 MB): see k_gemm_bf16x3.  SNN_BF16X3_XCD=0 switches it off (A/B).
-    Gemm3Args ax = a;
+    Gemm3Args& ax = L->ax;
+    ax = a;
     ax.n_tiles = tiles; ax.xcd_classes = 0;
     ax.epi_general = knobs().epi_general;
     int grid = tiles * a.n_blocks;
@@ -599,18 +605,57 @@ static int launch_gemm3(int mode, int mt, int wn, const Gemm3Args& a, hipStream_
 #ifdef SNN_EXP_ONE_WG_PER_CU                                       // timing experiment: ask for so much LDS that only one work-group fits a CU
     lds = max(lds, 100 * 1024);
 #endif
-    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    L->grid = grid; L->lds = lds; L->threads = threads; L->kern = kern;
+    return 0;
+}
+
+static int launch_gemm3(int mode, int mt, int wn, const Gemm3Args& a, hipStream_t s) {
+    G3Launch L;
+    prepare_gemm3(mode, mt, wn, a, &L);
+    hipError_t e = hipFuncSetAttribute(L.kern, hipFuncAttributeMaxDynamicSharedMemorySize, L.lds);
     if (e != hipSuccess) return fail(-3, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
     if (knobs().debug_occ) {                                   // debug: co-resident work-groups per CU
         int v = 0;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, kern, threads, lds);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, L.kern, L.threads, L.lds);
         fprintf(stderr, "k_gemm_bf16x3 mode %d mt %d wn %d short %d: pb %d x Tc %d rows, lds %d B, %d work-groups per CU, grid %d\n", mode, mt, wn,
-                a.n_short, a.pb, a.Tc, lds, v, tiles * a.n_blocks);
+                a.n_short, a.pb, a.Tc, L.lds, v, L.grid);
     }
-    void* kargs[] = {(void*)&ax};
-    e = hipLaunchKernel(kern, dim3(grid), dim3(threads), kargs, lds, s);
+    void* kargs[] = {(void*)&L.ax};
+    e = hipLaunchKernel(L.kern, dim3(L.grid), dim3(L.threads), kargs, L.lds, s);
     if (e != hipSuccess) return fail(-3, "k_gemm_bf16x3 launch failed: %s", hipGetErrorString(e));
     SNN_CHECK_LAUNCH("k_gemm_bf16x3");
+    return 0;
+}
+
+// fc6 + LIF and fc7 + LIF in one launch (k_gemm_bf16x3_pair): layer b's tiles wait for the row tiles of layer a they read.
+// `sync` = device words [0 .. a's row tiles) counters + one error word behind them, zeroed by the caller on this stream.
+static bool gemm3_pair_ok(int mt_a, int mt_b, int wn, const Gemm3Args& a) {
+    return mt_a == mt_b && mt_a >= 2 && mt_a <= 4 && (cdiv(a.M, a.pb) * a.n_blocks) % 8 == 0 && (wn == 1 || wn == 2);
+}
+static int launch_gemm3_pair(int mt, int wn, const Gemm3Args& a, const Gemm3Args& b, uint32_t* sync, hipStream_t s) {
+    G3Launch la, lb;
+    prepare_gemm3(G3_FC_LIF_TILE, mt, wn, a, &la);
+    prepare_gemm3(G3_FC_LIF_TILE, mt, wn, b, &lb);
+    if (la.ax.xcd_classes || la.ax.xcd_contig || la.grid % 8) return fail(-1, "launch_gemm3_pair: producer layer must run in plain tile order");
+    Gemm3Pair pr;
+    pr.a = la.ax; pr.b = lb.ax; pr.n_a = la.grid;
+    uint32_t* err = sync + la.ax.n_tiles;
+    pr.dep_a = Gemm3Dep{sync, err, 1, 0, 1};
+    pr.dep_b = Gemm3Dep{sync, err, 2, a.n_blocks, a.pb};
+    const void* kern = wn == 2 ? (mt == 4 ? (const void*)k_gemm_bf16x3_pair<3, 4, 2> : mt == 3 ? (const void*)k_gemm_bf16x3_pair<3, 3, 2> : (const void*)k_gemm_bf16x3_pair<3, 2, 2>)
+                               : (mt == 4 ? (const void*)k_gemm_bf16x3_pair<G3_NB1, 4, 1> : mt == 3 ? (const void*)k_gemm_bf16x3_pair<G3_NB1, 3, 1> : (const void*)k_gemm_bf16x3_pair<G3_NB1, 2, 1>);
+    const int lds = max(la.lds, lb.lds);
+    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return fail(-3, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+    if (knobs().debug_occ) {
+        int v = 0;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, kern, 512, lds);
+        fprintf(stderr, "k_gemm_bf16x3_pair mt %d wn %d: grids %d + %d, lds %d B, %d work-groups per CU\n", mt, wn, la.grid, lb.grid, lds, v);
+    }
+    void* kargs[] = {(void*)&pr};
+    e = hipLaunchKernel(kern, dim3(la.grid + lb.grid), dim3(512), kargs, lds, s);
+    if (e != hipSuccess) return fail(-3, "k_gemm_bf16x3_pair launch failed: %s", hipGetErrorString(e));
+    SNN_CHECK_LAUNCH("k_gemm_bf16x3_pair");
     return 0;
 }
 
@@ -671,14 +716,14 @@ static int set_periods(Gemm3Args& a, const char* who) {
 }
 
 // row_counts (nullable, zeroed by the caller): spikes per row over all T steps and N columns, added by the LIF epilogue
-static int spike_gemm_lif_bf16x3_impl(const uint32_t* a_planes, int T, int R, int K, int N, const snn_params* p,
-                                      const uint16_t* w_packed, uint32_t* spk, size_t spk_stride, uint32_t* row_counts, snn_stream_t s,
-                                      bool wm_in = false, bool wm_out = false, const StepWindow* win = nullptr, bool periods = false) {
+static int spike_gemm_lif_bf16x3_args(const uint32_t* a_planes, int T, int R, int K, int N, const snn_params* p,
+                                      const uint16_t* w_packed, uint32_t* spk, size_t spk_stride, uint32_t* row_counts,
+                                      bool wm_in, bool wm_out, const StepWindow* win, bool periods, Gemm3Args* out, G3Tile* tile) {
     if (!a_planes || !w_packed || !spk || !p || R <= 0 || K <= 0 || N <= 0)
         return fail(-1, "snn_spike_gemm_lif_bf16x3: bad argument");
     if (check_T(T, "snn_spike_gemm_lif_bf16x3")) return -1;
     if ((long long)T * R * cdiv(K, 32) * 4 > 0xffffffffLL) return fail(-1, "snn_spike_gemm_lif_bf16x3: input planes over 4 GB");
-    Gemm3Args a;
+    Gemm3Args& a = *out;
     memset(&a, 0, sizeof(a));
     a.A = a_planes; a.wpk = w_packed; a.M = R; a.Kc = cdiv(K, 32); a.Np = cdiv(N, 32) * 32;
     a.plane_elems = (unsigned long long)a.Kc * a.Np * 32;
@@ -693,7 +738,18 @@ static int spike_gemm_lif_bf16x3_impl(const uint32_t* a_planes, int T, int R, in
     if (!tl.mt) return fail(-4, "snn_spike_gemm_lif_bf16x3: T=%d does not fit a row tile (use snn_spike_gemm_bf16x3 + snn_lif_scan)", T);
     a.pb = tl.rows / Tc; a.n_short = tl.n_short;
     if (periods && set_periods(a, "snn_spike_gemm_lif_bf16x3")) return -1;
-    return launch_gemm3(G3_FC_LIF_TILE, tl.mt, wn, a, (hipStream_t)s);
+    *tile = tl;
+    return 0;
+}
+
+static int spike_gemm_lif_bf16x3_impl(const uint32_t* a_planes, int T, int R, int K, int N, const snn_params* p,
+                                      const uint16_t* w_packed, uint32_t* spk, size_t spk_stride, uint32_t* row_counts, snn_stream_t s,
+                                      bool wm_in = false, bool wm_out = false, const StepWindow* win = nullptr, bool periods = false) {
+    Gemm3Args a;
+    G3Tile tl;
+    const int rc = spike_gemm_lif_bf16x3_args(a_planes, T, R, K, N, p, w_packed, spk, spk_stride, row_counts, wm_in, wm_out, win, periods, &a, &tl);
+    if (rc) return rc;
+    return launch_gemm3(G3_FC_LIF_TILE, tl.mt, g3_wn(), a, (hipStream_t)s);
 }
 
 int snn_spike_gemm_lif_bf16x3(const uint32_t* a_planes, int T, int R, int K, int N, const snn_params* p,
@@ -1670,12 +1726,18 @@ int snn_det_postprocess(const float* class_logits, const float* box_regression, 
     return 0;
 }
 
+#define DET_SYNC_BYTES 16384                      // counters of the fc6 row tiles (R / pb of them) + an error word
 static void det_ws_layout(int R, int D, int Hd, int T, size_t* o_enc, size_t* o_cur, size_t* o_s6, size_t* o_s7,
                           size_t* total) {
     const size_t enc = align_up((size_t)T * R * cdiv(D, 32) * 4, 256);
     const size_t cur = align_up((size_t)T * R * cdiv(Hd, 32) * 32 * 4, 256);
     const size_t sp = align_up((size_t)T * R * cdiv(Hd, 32) * 4, 256);
-    *o_enc = 0; *o_cur = enc; *o_s6 = enc + cur; *o_s7 = enc + cur + sp; *total = enc + cur + 2 * sp;
+    *o_enc = 0; *o_cur = enc; *o_s6 = enc + cur; *o_s7 = enc + cur + sp; *total = enc + cur + 2 * sp + DET_SYNC_BYTES;
+}
+static size_t det_ws_sync_offset(int R, int D, int Hd, int T) {        // the fc6 -> fc7 tile counters of the one-launch pair: the last DET_SYNC_BYTES
+    size_t a, b, c, d, tot;
+    det_ws_layout(R, D, Hd, T, &a, &b, &c, &d, &tot);
+    return tot - DET_SYNC_BYTES;
 }
 
 size_t snn_det_head_workspace_bytes(int R, int D, int Hd, int K, int K4, int T, int precision) {
@@ -1699,6 +1761,7 @@ static int det_head_from_planes(int R, int D, int Hd, int K, int K4, int T, cons
                                 bool enc_wm, const DetWindows& win, bool enc_periods, snn_stream_t stream) {
     size_t o_enc, o_cur, o_s6, o_s7, need;
     det_ws_layout(R, D, Hd, T, &o_enc, &o_cur, &o_s6, &o_s7, &need);
+    const size_t o_sync = det_ws_sync_offset(R, D, Hd, T);
     hipStream_t s = (hipStream_t)stream;
     uint32_t* enc = (uint32_t*)((char*)ws + o_enc);
     float* cur = (float*)((char*)ws + o_cur);
@@ -1727,8 +1790,22 @@ static int det_head_from_planes(int R, int D, int Hd, int K, int K4, int T, cons
         // (spike-rate mode: per-RoI counts come out of the LIF epilogues)
         // (word-major planes between the stages: encoder -> fc6 -> fc7; fc7's spikes feed the LI heads row-major)
         // (dead time steps, lif_windows: fc6 forms the currents of steps 0 .. T-3, fc7 of steps 1 .. T-2)
-        if ((rc = spike_gemm_lif_bf16x3_impl(enc, T, R, D, Hd, p, (const uint16_t*)w6_packed, s6, (size_t)R * Hw, spk6_count, stream, enc_wm, enc_wm, &win.fc6, enc_periods))) return rc;
-        if ((rc = spike_gemm_lif_bf16x3_impl(s6, T, R, Hd, Hd, p, (const uint16_t*)w7_packed, s7, (size_t)R * Hw, spk7_count, stream, enc_wm, false, &win.fc7))) return rc;
+        // (round 4: ONE launch for both layers - fc7's tiles wait for the fc6 row tiles they read and fill the slots fc6's last, partial round
+        // of work-groups leaves empty, k_gemm_bf16x3_pair; SNN_DET_PAIR=0 = two launches, bit-identical)
+        Gemm3Args a6, a7;
+        G3Tile t6, t7;
+        if ((rc = spike_gemm_lif_bf16x3_args(enc, T, R, D, Hd, p, (const uint16_t*)w6_packed, s6, (size_t)R * Hw, spk6_count, enc_wm, enc_wm, &win.fc6, enc_periods, &a6, &t6))) return rc;
+        if ((rc = spike_gemm_lif_bf16x3_args(s6, T, R, Hd, Hd, p, (const uint16_t*)w7_packed, s7, (size_t)R * Hw, spk7_count, enc_wm, false, &win.fc7, false, &a7, &t7))) return rc;
+        const int wn = g3_wn();
+        const int n_sync = cdiv(R, a6.pb) + 1;
+        if (knobs().det_pair && gemm3_pair_ok(t6.mt, t7.mt, wn, a6) && (size_t)n_sync * 4 <= DET_SYNC_BYTES) {
+            uint32_t* sync = (uint32_t*)((char*)ws + o_sync);
+            if (hipMemsetAsync(sync, 0, (size_t)n_sync * 4, s) != hipSuccess) return fail(-3, "hipMemsetAsync failed");
+            if ((rc = launch_gemm3_pair(t6.mt, wn, a6, a7, sync, s))) return rc;
+        } else {
+            if ((rc = launch_gemm3(G3_FC_LIF_TILE, t6.mt, wn, a6, s))) return rc;
+            if ((rc = launch_gemm3(G3_FC_LIF_TILE, t7.mt, wn, a7, s))) return rc;
+        }
         return snn_li_heads(s7, (size_t)R * Hw, T, R, Hd, w_heads_packed, K, K4, p, out_cls, out_bbox, sum_cls,
                             sum_bbox, stream);
     }

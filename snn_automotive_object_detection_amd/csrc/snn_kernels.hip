@@ -152,7 +152,8 @@ struct Knobs {
     bool roi_tab;            // SNN_ROI_TAB=0         fused RoIAlign + encoder: the per-element kernel instead of the table-driven one (A/B, tests)
     bool dead_keep;          // SNN_DEAD_STEPS=keep   form the input currents of ALL time steps (A/B + test switch: the default
                              //                       skips the steps whose currents cannot reach an output, lif_windows)
-    bool det_pair;           // SNN_DET_PAIR=0        detector head: fc6 + LIF and fc7 + LIF as two launches instead of one (A/B, tests)
+    bool det_pair;           // SNN_DET_PAIR=1        detector head: fc6 + LIF and fc7 + LIF in ONE launch (k_gemm_bf16x3_pair) instead of two - measured
+                             //                       1 % slower (profiles/r4_det_pair.txt), so off by default; bit-identical (tests/test_gpu_det_pair.py)
     int planes;              // SNN_PLANES=rm|wm      internal spike planes of the bf16x3 heads: all row-major [T][row][word] / all
                              //                       word-major [T][word][row] (1 / 2; 0 = default = word-major since round 3;
                              //                       bit-identical results either way, A/B + test switch)
@@ -184,7 +185,7 @@ static Knobs load_knobs() {
     k.stage_periods = (e = getenv("SNN_STAGE_PERIODS")) && e[0] == '1';
     k.epi_general = (e = getenv("SNN_EPI_GENERAL")) && e[0] == '1';
     k.roi_tab = !((e = getenv("SNN_ROI_TAB")) && e[0] == '0');
-    k.det_pair = !((e = getenv("SNN_DET_PAIR")) && e[0] == '0');
+    k.det_pair = (e = getenv("SNN_DET_PAIR")) && e[0] == '1';
     k.roi_e = (e = getenv("SNN_ROI_E")) ? atoi(e) : 0;
     k.roi_rw = (e = getenv("SNN_ROI_RW")) ? atoi(e) : 0;
     if (k.roi_e < 0 || k.roi_e > 16) k.roi_e = 0;
@@ -630,13 +631,15 @@ static int launch_gemm3(int mode, int mt, int wn, const Gemm3Args& a, hipStream_
 // fc6 + LIF and fc7 + LIF in one launch (k_gemm_bf16x3_pair): layer b's tiles wait for the row tiles of layer a they read.
 // `sync` = device words [0 .. a's row tiles) counters + one error word behind them, zeroed by the caller on this stream.
 static bool gemm3_pair_ok(int mt_a, int mt_b, int wn, const Gemm3Args& a) {
-    return mt_a == mt_b && mt_a >= 2 && mt_a <= 4 && (cdiv(a.M, a.pb) * a.n_blocks) % 8 == 0 && (wn == 1 || wn == 2);
+    return mt_a == mt_b && mt_a >= 2 && mt_a <= 4 && a.n_blocks % 8 == 0 && (wn == 1 || wn == 2);
 }
 static int launch_gemm3_pair(int mt, int wn, const Gemm3Args& a, const Gemm3Args& b, uint32_t* sync, hipStream_t s) {
     G3Launch la, lb;
     prepare_gemm3(G3_FC_LIF_TILE, mt, wn, a, &la);
     prepare_gemm3(G3_FC_LIF_TILE, mt, wn, b, &lb);
-    if (la.ax.xcd_classes || la.ax.xcd_contig || la.grid % 8) return fail(-1, "launch_gemm3_pair: producer layer must run in plain tile order");
+    // (any block order of layer a will do - a tile counts itself in by its row-tile index -, but its grid must be a multiple of 8 so that
+    // layer b's work-groups keep the XCD their block order assumes: XCD = work-group index % 8)
+    if (la.ax.xcd_contig || la.grid % 8) return fail(-1, "launch_gemm3_pair: layer a's grid (%d) must be a multiple of 8", la.grid);
     Gemm3Pair pr;
     pr.a = la.ax; pr.b = lb.ax; pr.n_a = la.grid;
     uint32_t* err = sync + la.ax.n_tiles;
@@ -1790,8 +1793,8 @@ static int det_head_from_planes(int R, int D, int Hd, int K, int K4, int T, cons
         // (spike-rate mode: per-RoI counts come out of the LIF epilogues)
         // (word-major planes between the stages: encoder -> fc6 -> fc7; fc7's spikes feed the LI heads row-major)
         // (dead time steps, lif_windows: fc6 forms the currents of steps 0 .. T-3, fc7 of steps 1 .. T-2)
-        // (round 4: ONE launch for both layers - fc7's tiles wait for the fc6 row tiles they read and fill the slots fc6's last, partial round
-        // of work-groups leaves empty, k_gemm_bf16x3_pair; SNN_DET_PAIR=0 = two launches, bit-identical)
+        // (round 4, SNN_DET_PAIR=1: ONE launch for both layers - fc7's tiles wait for the fc6 row tiles they read and run in the slots fc6's
+        // last, partial round of work-groups leaves empty, k_gemm_bf16x3_pair; bit-identical, but not faster: see the knob)
         Gemm3Args a6, a7;
         G3Tile t6, t7;
         if ((rc = spike_gemm_lif_bf16x3_args(enc, T, R, D, Hd, p, (const uint16_t*)w6_packed, s6, (size_t)R * Hw, spk6_count, enc_wm, enc_wm, &win.fc6, enc_periods, &a6, &t6))) return rc;

@@ -1,5 +1,5 @@
 """fc6 + LIF and fc7 + LIF of the detector head in ONE launch (k_gemm_bf16x3_pair, csrc/snn_bf16x3.h: fc7's row tiles wait for the
-fc6 row tiles they read - faster_rcnn.py:498-501) against the two-launch form (SNN_DET_PAIR=0): the same tiles run the same
+fc6 row tiles they read - faster_rcnn.py:498-501; SNN_DET_PAIR=1) against the default two-launch form: the same tiles run the same
 arithmetic, so logits, deltas, spike counts and rate tensors must be bit-identical - for RoI counts that do and do not fill the
 tiles, in spike-rate mode (whose fc6 window is one step longer than fc7's: the two layers' row tiles then do not coincide), on
 the fused RoIAlign path and when called repeatedly (the tile counters are re-zeroed per call)."""
@@ -25,10 +25,11 @@ def test_pair_launch_equals_two_launches(gpu_device, monkeypatch, R, C, Hd, K, T
     d = _head(gpu_device, C * 49, Hd, K, T, R)
     d.spike_rates = rates
     x = torch.randn(R, C, 7, 7, device=gpu_device) * 2
+    monkeypatch.setenv("SNN_DET_PAIR", "1")
     a = [t.clone() for t in d(x)]
     a2 = [t.clone() for t in d(x)]                 # second call on the same workspace
     cnt_a = [c.clone() for c in d.last_spike_counts] if rates else []
-    monkeypatch.setenv("SNN_DET_PAIR", "0")
+    monkeypatch.delenv("SNN_DET_PAIR")
     b = [t.clone() for t in d(x)]
     cnt_b = [c.clone() for c in d.last_spike_counts] if rates else []
     for p, q, r in zip(a, b, a2):
@@ -44,6 +45,7 @@ def test_pair_launch_under_a_captured_graph_and_two_streams(gpu_device, monkeypa
     d = _head(gpu_device, 32 * 49, 256, 9, 12, 3)
     x = torch.randn(500, 32, 7, 7, device=gpu_device) * 2
     ref = [t.clone() for t in d(x)]
+    monkeypatch.setenv("SNN_DET_PAIR", "1")
     s = torch.cuda.Stream()
     with torch.cuda.stream(s):
         d(x)                                        # warm the stream's workspace outside the capture
@@ -63,7 +65,7 @@ def test_pair_launch_on_the_fused_roialign_path(gpu_device, monkeypatch):
     d = _head(gpu_device, 32 * 49, 128, 9, 12, 9)
     pool, fm, boxes, shapes = _setup(gpu_device, R=700, C=32, seed=4)
     flist, scales, rois, lvl = pool.assign(fm, boxes, shapes)
-    a = [t.clone() for t in d.forward_roialign(flist, scales, rois, lvl)]
-    monkeypatch.setenv("SNN_DET_PAIR", "0")
     b = [t.clone() for t in d.forward_roialign(flist, scales, rois, lvl)]
+    monkeypatch.setenv("SNN_DET_PAIR", "1")
+    a = [t.clone() for t in d.forward_roialign(flist, scales, rois, lvl)]
     assert all(torch.equal(p, q) for p, q in zip(a, b))

@@ -13,8 +13,8 @@
 #define ENC_PB 64                                   // positions per block (a wave = 64 consecutive positions of one channel: 256-byte runs)
 #define ENC_WB 4                                    // channel words per block
 // Wpad > 0: the planes carry a one-position zero halo around every image (row (n, y, x) -> (n*(H+2) + y+1)*(W+2) + x+1,
-// W = Wpad); the halo itself is zeroed by the caller.  The fp4 x fp6 conv kernel reads its 3x3 taps from such planes
-// without any border logic.
+// W = Wpad), written here as well (by the threads of the border positions).  The conv kernels of the bf16x3 and mxfp6 families
+// read their 3x3 taps from such planes without any border logic.
 template <int EM>
 __device__ __forceinline__ void encode_block(const float* __restrict__ feat, int C, int HW, int Cw, int T, const NeuronP& p,
                                              const EncTh& eth, uint32_t* __restrict__ planes, size_t plane_stride, int n, int bx, int by,
@@ -61,6 +61,26 @@ __device__ __forceinline__ void encode_block(const float* __restrict__ feat, int
         }
         uint32_t* out = wm_rows ? planes + (size_t)scg * wm_rows + row : planes + row * Cw + scg;
         for (int t = 0; t < T; ++t) out[(size_t)t * plane_stride] = wbuf[(t * ENC_PB + sp) * (ENC_WB + 1) + sw];
+        if (Wpad) {
+            // the zero halo, written by the threads that own the image's border positions (round 4: a separate k_zero_halo launch
+            // did this before - 5-6 us of a 1.1-ms head at T_rpn = 4): a border position zeroes the padded rows / columns next to it,
+            // corner positions the corners too.  dr = row offset to the neighbour (in padded rows), rs = plane words per padded row
+            const int H = HW / Wpad, y = spos / Wpad, x = spos % Wpad, W2 = Wpad + 2;
+            const size_t rs = wm_rows ? 1 : (size_t)Cw;
+            auto zero = [&](const long long dr) __attribute__((always_inline)) {
+                uint32_t* z = out + dr * (long long)rs;
+                for (int t = 0; t < T; ++t) z[(size_t)t * plane_stride] = 0u;
+            };
+            const bool top = y == 0, bot = y == H - 1, lef = x == 0, rig = x == Wpad - 1;
+            if (top) zero(-W2);
+            if (bot) zero(W2);
+            if (lef) zero(-1);
+            if (rig) zero(1);
+            if (top && lef) zero(-W2 - 1);
+            if (top && rig) zero(-W2 + 1);
+            if (bot && lef) zero(W2 - 1);
+            if (bot && rig) zero(W2 + 1);
+        }
     }
 }
 
@@ -88,30 +108,6 @@ __global__ __launch_bounds__(256) void k_encode_levels(const EncLevels lv, int C
     const int local = blockIdx.x - lv.blk_base[l];
     encode_block<EM>(lv.feat[l], C, lv.HW[l], Cw, T, p, eth, planes + (size_t)lv.pos_base[l] * (wm_rows ? 1 : Cw), plane_stride,
                      local / lv.bpi[l], local % lv.bpi[l], blockIdx.y, lv.Wpad[l], wm_rows);
-}
-
-// zero halo of the padded planes: only the border rows / columns of every image are written (a few hundred KB), not the
-// whole 50-MB plane set.  blockIdx.x = (level, image), blockIdx.y splits its halo words.
-struct HaloLevels {
-    int pos_base[SNN_MAX_LEVELS], H[SNN_MAX_LEVELS], W[SNN_MAX_LEVELS];
-    int blk_base[SNN_MAX_LEVELS + 1];               // first block (= image) of the level
-    int n_levels;
-};
-__global__ __launch_bounds__(256) void k_zero_halo(const HaloLevels lv, int Cw, int T, uint32_t* __restrict__ planes,
-                                                   size_t plane_stride, size_t wm_rows) {
-    int l = 0;
-    while (l + 1 < lv.n_levels && (int)blockIdx.x >= lv.blk_base[l + 1]) ++l;
-    const int n = blockIdx.x - lv.blk_base[l], H = lv.H[l], W = lv.W[l];
-    const int hp = 2 * (W + 2) + 2 * H;             // halo positions of one image
-    for (int idx = blockIdx.y * 256 + threadIdx.x; idx < T * hp * Cw; idx += 256 * gridDim.y) {
-        const int w = idx % Cw, h = (idx / Cw) % hp, t = idx / (Cw * hp);
-        int y, x;
-        if (h < W + 2) { y = 0; x = h; }
-        else if (h < 2 * (W + 2)) { y = H + 1; x = h - (W + 2); }
-        else { const int r = h - 2 * (W + 2); y = 1 + (r >> 1); x = (r & 1) ? W + 1 : 0; }
-        const size_t row = (size_t)lv.pos_base[l] + ((size_t)n * (H + 2) + y) * (W + 2) + x;
-        planes[(size_t)t * plane_stride + (wm_rows ? (size_t)w * wm_rows + row : row * Cw + w)] = 0u;
-    }
 }
 
 // K1b: encoder on row-major x[R][D] -> bit-planes [T][R][Dw]; a wave covers 64 consecutive reduction indices per

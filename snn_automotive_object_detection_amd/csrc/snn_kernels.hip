@@ -1427,18 +1427,7 @@ int snn_rpn_head_forward_stages(const snn_rpn_level* lv, int n_levels, int C, in
             pos += mxp ? (long long)lv[l].N * (lv[l].H + 2) * (lv[l].W + 2) : (long long)lv[l].N * el.HW[l];
         }
         el.blk_base[n_levels] = blocks; el.n_levels = n_levels;
-        if (mxp) {                                  // the one-position zero halo around every image (the interior is the encoder's)
-            HaloLevels hl;
-            memset(&hl, 0, sizeof(hl));
-            int images = 0;
-            for (int l = 0; l < n_levels; ++l) {
-                hl.pos_base[l] = el.pos_base[l]; hl.H[l] = lv[l].H; hl.W[l] = lv[l].W; hl.blk_base[l] = images;
-                images += lv[l].N;
-            }
-            hl.blk_base[n_levels] = images; hl.n_levels = n_levels;
-            hipLaunchKernelGGL(k_zero_halo, dim3(images, 32), dim3(256), 0, s, hl, Cw, Tc, enc, enc_stride, wm_rows);
-            SNN_CHECK_LAUNCH("k_zero_halo");
-        }
+        // (the one-position zero halo around every image is written by the encoder launch itself: encode_block)
         NeuronP np = make_p(p, p->v_th_enc);
         if (per) np.v_fire = ENC_FIRED;
         const EncTh* eth;

@@ -61,8 +61,69 @@ def shard_range(n_items: int, rank: int, world: int) -> range:
     return range(start, start + base + (1 if rank < extra else 0))
 
 
-def pack_detections(dets: List[Dict[str, torch.Tensor]], max_det: int, device) -> Tuple[torch.Tensor, torch.Tensor]:
-    """list of {boxes [D,4], scores [D], labels [D]} -> payload [n, max_det, 6] fp32, counts [n] i32"""
+class ExtrasSpec:
+    """caps of the OPTIONAL per-image fields of the reference's eval dicts: ``all_scores [R, K]``, ``all_boxes [R, K, 4]``
+    (roi_heads.py:1247-1255: what new_object_discovery.py reads) and the RPN's pre-NMS report ``proposals [P, 4]``, ``objectness [P]``
+    (rpn.py:493-499, generalized_rcnn.py:125-132).  Every rank must use the same spec (shapes of a collective).  Defaults: the
+    reference's test-time limits - 1000 RoIs per image (model.py:51-53), 4 x 1000 + 864 pre-NMS candidates."""
+
+    def __init__(self, num_classes: int, rois_max: int = 1000, proposals_max: int = 4864):
+        self.K, self.R, self.P = int(num_classes), int(rois_max), int(proposals_max)
+
+    HEADER = 4                                     # R, K, P of the image + a presence mask
+
+    @property
+    def width(self) -> int:
+        return self.HEADER + self.R * self.K * 5 + self.P * 5
+
+
+def _pack_extras(dets: List[Dict[str, torch.Tensor]], spec: "ExtrasSpec", device) -> torch.Tensor:
+    """[n, spec.width] fp32: header (R, K, P, presence bits), all_scores, all_boxes, proposals, objectness - each padded to its cap"""
+    n = len(dets)
+    out = torch.zeros((n, spec.width), dtype=torch.float32, device=device)
+    o_s, o_b = spec.HEADER, spec.HEADER + spec.R * spec.K
+    o_p = o_b + spec.R * spec.K * 4
+    o_o = o_p + spec.P * 4
+    for i, d in enumerate(dets):
+        present = 0
+        r = k = pn = 0
+        if "all_scores" in d and "all_boxes" in d:
+            sc, bx = d["all_scores"], d["all_boxes"]
+            r, k = int(sc.shape[0]), int(sc.shape[1]) if sc.dim() == 2 else 0
+            if r > spec.R or (r and k != spec.K) or tuple(bx.shape) != (r, k, 4):
+                raise ValueError("image %d: all_scores %s / all_boxes %s do not fit ExtrasSpec(num_classes=%d, rois_max=%d)"
+                                 % (i, tuple(sc.shape), tuple(bx.shape), spec.K, spec.R))
+            out[i, o_s:o_s + r * k] = sc.reshape(-1)
+            out[i, o_b:o_b + r * k * 4] = bx.reshape(-1)
+            present |= 1
+        if "proposals" in d and "objectness" in d:
+            pr, ob = d["proposals"], d["objectness"]
+            pn = int(pr.shape[0])
+            if pn > spec.P or tuple(ob.shape) != (pn,):
+                raise ValueError("image %d: %d proposals do not fit ExtrasSpec(proposals_max=%d)" % (i, pn, spec.P))
+            out[i, o_p:o_p + pn * 4] = pr.reshape(-1)
+            out[i, o_o:o_o + pn] = ob
+            present |= 2
+        out[i, 0], out[i, 1], out[i, 2], out[i, 3] = float(r), float(k), float(pn), float(present)
+    return out
+
+
+def _unpack_extras(extra: torch.Tensor, spec: "ExtrasSpec", row: int, into: Dict[str, torch.Tensor]) -> None:
+    o_s, o_b = spec.HEADER, spec.HEADER + spec.R * spec.K
+    o_p = o_b + spec.R * spec.K * 4
+    o_o = o_p + spec.P * 4
+    r, k, pn, present = (int(v) for v in extra[row, :4].tolist())
+    if present & 1:
+        into["all_scores"] = extra[row, o_s:o_s + r * k].reshape(r, k)
+        into["all_boxes"] = extra[row, o_b:o_b + r * k * 4].reshape(r, k, 4)
+    if present & 2:
+        into["proposals"] = extra[row, o_p:o_p + pn * 4].reshape(pn, 4)
+        into["objectness"] = extra[row, o_o:o_o + pn]
+
+
+def pack_detections(dets: List[Dict[str, torch.Tensor]], max_det: int, device, extras: Optional["ExtrasSpec"] = None):
+    """list of {boxes [D,4], scores [D], labels [D]} -> payload [n, max_det, 6] fp32, counts [n] i32
+    (+ ``extras``: a third tensor [n, extras.width] with the optional fields, see ExtrasSpec)"""
     n = len(dets)
     payload = torch.zeros((n, max_det, 6), dtype=torch.float32, device=device)
     counts = torch.zeros((n,), dtype=torch.int32, device=device)
@@ -73,10 +134,13 @@ def pack_detections(dets: List[Dict[str, torch.Tensor]], max_det: int, device) -
             payload[i, :k, 4] = d["scores"][:k]
             payload[i, :k, 5] = d["labels"][:k].to(torch.float32)
         counts[i] = k
+    if extras is not None:
+        return payload, counts, _pack_extras(dets, extras, device)
     return payload, counts
 
 
-def unpack_detections(payload: torch.Tensor, counts: torch.Tensor) -> List[Dict[str, torch.Tensor]]:
+def unpack_detections(payload: torch.Tensor, counts: torch.Tensor, extra: Optional[torch.Tensor] = None,
+                      extras: Optional["ExtrasSpec"] = None) -> List[Dict[str, torch.Tensor]]:
     """rows with a negative count are padding of a short rank and are dropped"""
     out = []
     cnt = counts.tolist()
@@ -84,8 +148,10 @@ def unpack_detections(payload: torch.Tensor, counts: torch.Tensor) -> List[Dict[
         k = int(cnt[i])
         if k < 0:
             continue
-        out.append({"boxes": payload[i, :k, 0:4], "scores": payload[i, :k, 4],
-                    "labels": payload[i, :k, 5].to(torch.int64)})
+        d = {"boxes": payload[i, :k, 0:4], "scores": payload[i, :k, 4], "labels": payload[i, :k, 5].to(torch.int64)}
+        if extra is not None:
+            _unpack_extras(extra, extras, i, d)
+        out.append(d)
     return out
 
 
@@ -100,34 +166,48 @@ def _collective_all_gather(out: torch.Tensor, inp: torch.Tensor) -> None:
         dist.all_gather_into_tensor(out, inp)
 
 
-def all_gather_detection_tensors(payload: torch.Tensor, counts: torch.Tensor,
-                                 force: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+def all_gather_detection_tensors(payload: torch.Tensor, counts: torch.Tensor, force: bool = False,
+                                 extra: Optional[torch.Tensor] = None):
     """the exchange step proper (device tensors in, device tensors out): ONE collective per batch - the per-image
-    counts travel as an extra payload row (exact in fp32: |counts| < 2^24).  Every rank must pass the same number of
-    images n (all_gather_into_tensor needs equal shapes; ``all_gather_detections`` pads short ranks).
-    ``force``: run the collective even in a one-rank group (exercises RCCL on a single GPU)."""
+    counts travel as an extra payload row (exact in fp32: |counts| < 2^24), and the optional fields (``extra`` [n, E], see
+    ExtrasSpec) behind it in the same buffer.  Every rank must pass the same number of images n (all_gather_into_tensor needs
+    equal shapes; ``all_gather_detections`` pads short ranks).  ``force``: run the collective even in a one-rank group
+    (exercises RCCL on a single GPU).  Returns (payload, counts) or, with ``extra``, (payload, counts, extra)."""
     active = dist.is_available() and dist.is_initialized()
     if not active or (dist.get_world_size() == 1 and not force):
-        return payload, counts
+        return (payload, counts) if extra is None else (payload, counts, extra)
     world = dist.get_world_size()
     n, max_det, width = payload.shape
-    buf = torch.empty((n, max_det + 1, width), dtype=payload.dtype, device=payload.device)
-    buf[:, :max_det] = payload
-    buf[:, max_det] = counts.to(payload.dtype)[:, None]
-    gathered = torch.empty((world * n, max_det + 1, width), dtype=payload.dtype, device=payload.device)
+    base = (max_det + 1) * width
+    e_w = 0 if extra is None else int(extra.shape[1])
+    buf = torch.empty((n, base + e_w), dtype=payload.dtype, device=payload.device)
+    rows = buf[:, :base].view(n, max_det + 1, width)
+    rows[:, :max_det] = payload
+    rows[:, max_det] = counts.to(payload.dtype)[:, None]
+    if extra is not None:
+        buf[:, base:] = extra
+    gathered = torch.empty((world * n, base + e_w), dtype=payload.dtype, device=payload.device)
     _collective_all_gather(gathered, buf)
-    return gathered[:, :max_det], gathered[:, max_det, 0].to(counts.dtype)
+    g_rows = gathered[:, :base].view(world * n, max_det + 1, width)
+    out = (g_rows[:, :max_det], g_rows[:, max_det, 0].to(counts.dtype))
+    return out if extra is None else out + (gathered[:, base:],)
 
 
 def all_gather_detections(dets: List[Dict[str, torch.Tensor]], max_det: int = 1100,
-                          device: Optional[torch.device] = None, images_per_rank: Optional[int] = None) -> List[Dict[str, torch.Tensor]]:
+                          device: Optional[torch.device] = None, images_per_rank: Optional[int] = None,
+                          extras: Optional["ExtrasSpec"] = None) -> List[Dict[str, torch.Tensor]]:
     """every rank returns the detections of ALL images, in global image order (rank-major).  Ranks may pass
     different numbers of images (also zero): the block size is agreed with one MAX all-reduce first - unless the caller
     states it (``images_per_rank`` = the largest image count of any rank, e.g. ceil(batch / world) for ``shard_range``):
-    then the all-gather is the ONLY collective of the batch."""
+    then the all-gather is the ONLY collective of the batch.
+    ``extras`` (an ExtrasSpec, the same on every rank): the gathered dicts also carry ``all_scores`` / ``all_boxes`` /
+    ``proposals`` / ``objectness`` of every image that had them - the reference's full eval dict (roi_heads.py:1247-1255,
+    generalized_rcnn.py:125-132), still in ONE collective.  Without it those fields are NOT exchanged (boxes / scores / labels only)."""
     if device is None:
         device = dets[0]["boxes"].device if dets else torch.device("cpu")
-    payload, counts = pack_detections(dets, max_det, device)
+    packed = pack_detections(dets, max_det, device, extras)
+    payload, counts = packed[0], packed[1]
+    extra = packed[2] if extras is not None else None
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         if images_per_rank is not None:
             if images_per_rank < len(dets):
@@ -141,8 +221,13 @@ def all_gather_detections(dets: List[Dict[str, torch.Tensor]], max_det: int = 11
             pad = n_max - len(dets)
             payload = torch.cat([payload, payload.new_zeros((pad, max_det, 6))], 0)
             counts = torch.cat([counts, counts.new_full((pad,), -1)], 0)
-    g_payload, g_counts = all_gather_detection_tensors(payload, counts)
-    return unpack_detections(g_payload, g_counts)
+            if extra is not None:
+                extra = torch.cat([extra, extra.new_zeros((pad, extra.shape[1]))], 0)
+    if extra is None:
+        g_payload, g_counts = all_gather_detection_tensors(payload, counts)
+        return unpack_detections(g_payload, g_counts)
+    g_payload, g_counts, g_extra = all_gather_detection_tensors(payload, counts, extra=extra)
+    return unpack_detections(g_payload, g_counts, g_extra, extras)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -34,13 +34,13 @@ def nchw_to_rows(z: torch.Tensor) -> np.ndarray:
 # (profiles/parity_r2.json, parity_r3.json) - per neuron-step:
 #   RPN on N(0,1) pyramids  : 7 / 12 / 16 of 196 416 positions (bf16x3 / f32 / mxfp6) = 1.7e-8 .. 4e-8 -> rate 8e-8 (mxfp6 x2:
 #                             its digit planes round weights at 2^-29 of the block maximum)
-#   RPN behind the backbone : 35 of 196 416 (firing rates are 3x those of N(0,1) inputs) = 8.7e-8         -> rate 2.5e-7
+#   RPN behind the backbone : 35 - 43 of 196 416 (firing rates are 3x those of N(0,1) inputs) = 8.7e-8 .. 1.07e-7 -> rate 1.5e-7 (round 4; 2.5e-7 before)
 #   detector                : 0 - 2 of 2000 RoIs on N(0,1) (bf16x3 / f32), 8 in situ / mxfp6, 9 at T = 24 = 0 .. 1.6e-7 -> 2.5e-7
 # Every full-size test also ATTRIBUTES its flips (first_flip_margins): each first differing spike sits within TIE_MARGIN of the
 # threshold in the oracle's trace, so a regression that flips spikes away from ties fails whatever the count.
-FLIP_RATE = {"rpn_randn": 8e-8, "rpn_in_situ": 2.5e-7, "det": 2.5e-7}
+FLIP_RATE = {"rpn_randn": 8e-8, "rpn_in_situ": 1.5e-7, "det": 2.5e-7}
 PRECISION_FACTOR = {"bf16x3": 1.0, "f32": 1.0, "mxfp6": 2.0}
-TIE_MARGIN = 2e-6            # observed: every first flip sits within 5e-8 of the threshold (profiles/parity_r3.json)
+TIE_MARGIN = 5e-7            # observed: every first flip sits within 6e-8 of the threshold (profiles/parity_r3.json, parity_r4.json)
 
 
 def flip_budget(positions: int, channels: int, steps: int, kind: str = "rpn_in_situ", precision: str = "bf16x3") -> float:
@@ -95,11 +95,11 @@ def assert_same_detections(got_boxes, got_scores, exp_boxes, exp_scores, got_lab
 
 
 def record_parity(test: str, **values):
-    """append observed off-tolerance counts to gpurun_out/parity_r3.jsonl (copied into profiles/parity_r3.json after a GPU
+    """append observed off-tolerance counts to gpurun_out/parity_r4.jsonl (copied into profiles/parity_r4.json after a GPU
     run): the flip budgets are tightened on this evidence"""
     import json
     import os
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_r3.jsonl")
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_r4.jsonl")
     try:
         os.makedirs(os.path.dirname(path), exist_ok=True)
         with open(path, "a") as f:

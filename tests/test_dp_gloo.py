@@ -115,3 +115,30 @@ def test_single_process_gather_is_identity():
     dets = [_make_dets(0), _make_dets(2)]
     out = dp.all_gather_detections(dets, max_det=16)
     assert len(out) == 2 and torch.equal(out[0]["boxes"], dets[0]["boxes"]) and out[1]["boxes"].shape == (0, 4)
+
+
+@pytest.mark.parametrize("world,n_images", [(8, 32), (3, 7), (8, 5)])
+def test_launch_ranks_gathers_full_eval_dicts(world, n_images):
+    """pre-flight of the driver's N = 8 run on CPU (gloo): dp.launch_ranks starts `world` ranks, every rank gathers the reference's
+    FULL eval dicts (boxes / scores / labels + all_scores / all_boxes / proposals / objectness: roi_heads.py:1247-1255,
+    generalized_rcnn.py:125-132) of all images in one collective and finds them equal, key by key, to the single-process ones - for
+    even shards (8 x 4: config[3]), uneven ones (3 ranks, 7 images) and ranks without any image (8 ranks, 5 images)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    child = os.path.join(root, "tests", "_dp_gather_child.py")
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from snn_automotive_object_detection_amd import dp\n"
+            "sys.exit(dp.launch_ranks(%r, [sys.argv[1]], %d, timeout_s=150))\n" % (root, child, world))
+    r = subprocess.run([sys.executable, "-c", code, str(n_images)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "GATHER_OK world=%d images=%d" % (world, n_images) in r.stdout
+
+
+def test_extras_refuse_what_does_not_fit():
+    from snn_automotive_object_detection_amd import dp
+    spec = dp.ExtrasSpec(5, rois_max=4, proposals_max=4)
+    d = {"boxes": torch.zeros(0, 4), "scores": torch.zeros(0), "labels": torch.zeros(0, dtype=torch.int64),
+         "all_scores": torch.zeros(5, 5), "all_boxes": torch.zeros(5, 5, 4)}
+    with pytest.raises(ValueError, match="rois_max"):
+        dp.pack_detections([d], 8, torch.device("cpu"), spec)

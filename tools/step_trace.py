@@ -28,7 +28,7 @@ else:
     rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
     idx = max(i for i, r in enumerate(rows) if "FillFunctor" in r["Kernel_Name"])      # the sentinel (no fill inside a step)
     rows = rows[idx + 1:]
-    convs = [i for i, r in enumerate(rows) if "k_zero_halo" in r["Kernel_Name"]]
+    convs = [i for i, r in enumerate(rows) if "k_encode_levels" in r["Kernel_Name"]]
     a, b = convs[3], convs[4]                         # one step in the middle
     t_prev = int(rows[a - 1]["End_Timestamp"])
     busy = gaps = 0

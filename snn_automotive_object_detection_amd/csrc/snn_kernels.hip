@@ -114,6 +114,7 @@ __global__ void k_pack_heads(const float* __restrict__ wa, int NA, const float* 
 #include "snn_encode.h"
 #include "snn_f32.h"
 #include "snn_bf16x3.h"
+#include "snn_sparse.h"
 #include "snn_heads.h"
 #include "snn_post.h"
 
@@ -152,6 +153,8 @@ struct Knobs {
     bool roi_tab;            // SNN_ROI_TAB=0         fused RoIAlign + encoder: the per-element kernel instead of the table-driven one (A/B, tests)
     bool dead_keep;          // SNN_DEAD_STEPS=keep   form the input currents of ALL time steps (A/B + test switch: the default
                              //                       skips the steps whose currents cannot reach an output, lif_windows)
+    bool sparse;             // SNN_SPARSE=0          RPN conv: every period plane on the dense matrix-core instruction (default: planes e_3.. on the
+                             //                       structured-sparse one, snn_sparse.h)
     bool det_pair;           // SNN_DET_PAIR=1        detector head: fc6 + LIF and fc7 + LIF in ONE launch (k_gemm_bf16x3_pair) instead of two - measured
                              //                       1 % slower (profiles/r4_det_pair.txt), so off by default; bit-identical (tests/test_gpu_det_pair.py)
     int planes;              // SNN_PLANES=rm|wm      internal spike planes of the bf16x3 heads: all row-major [T][row][word] / all
@@ -186,6 +189,7 @@ static Knobs load_knobs() {
     k.epi_general = (e = getenv("SNN_EPI_GENERAL")) && e[0] == '1';
     k.roi_tab = !((e = getenv("SNN_ROI_TAB")) && e[0] == '0');
     k.det_pair = (e = getenv("SNN_DET_PAIR")) && e[0] == '1';
+    k.sparse = !((e = getenv("SNN_SPARSE")) && e[0] == '0');
     k.roi_e = (e = getenv("SNN_ROI_E")) ? atoi(e) : 0;
     k.roi_rw = (e = getenv("SNN_ROI_RW")) ? atoi(e) : 0;
     if (k.roi_e < 0 || k.roi_e > 16) k.roi_e = 0;
@@ -921,10 +925,104 @@ static int conv3_common(const char* who, const uint32_t* enc, size_t enc_stride,
 static int count_spikes_per_image(const snn_rpn_level* lv, int n_levels, int Cw, int T, const uint32_t* spk, size_t stride,
                                   unsigned long long* counts, int max_n, hipStream_t s);
 
+static size_t rpn_sparse_bytes(long long P, long long Pe, int C, int T);
+// ---- structured-sparse conv (snn_sparse.h): tile geometry + wave assignment ----
+struct SparsePlan { int q, pb, nd; signed char plane[8][SP_MT]; unsigned char j[8][SP_MT], w_nd[8], w_ns[8]; };
+static bool sparse_plan(int Tc, SparsePlan* sp) {
+    if (Tc < 4 || Tc > 32) return false;
+    const int q = 32 / Tc, nd = 2;
+    if (q < 1 || q > 8) return false;
+    memset(sp, 0, sizeof(*sp));
+    sp->q = q; sp->pb = 16 * q; sp->nd = nd;
+    int used[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double cost[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int w = 0; w < 8; ++w)
+        for (int m = 0; m < SP_MT; ++m) sp->plane[w][m] = -1;
+    int w_rr = 0;
+    for (int t = 0; t < nd; ++t)                           // dense M-tiles: round-robin (at most two per wave: q <= 8)
+        for (int jj = 0; jj < q; ++jj) {
+            const int w = w_rr++ % 8;
+            sp->plane[w][used[w]] = (signed char)t; sp->j[w][used[w]] = (unsigned char)jj;
+            ++used[w]; ++sp->w_nd[w]; cost[w] += 2.0;
+        }
+    for (int t = nd; t < Tc; ++t)                          // sparse M-tiles: to the cheapest wave with a free slot
+        for (int jj = 0; jj < q; ++jj) {
+            int best = -1;
+            for (int w = 0; w < 8; ++w)
+                if (used[w] < SP_MT && (best < 0 || cost[w] < cost[best] - 1e-9)) best = w;
+            if (best < 0) return false;
+            sp->plane[best][used[best]] = (signed char)t; sp->j[best][used[best]] = (unsigned char)jj;
+            ++used[best]; ++sp->w_ns[best]; cost[best] += 1.1;
+        }
+    for (int w = 0; w < 8; ++w)
+        if (sp->w_nd[w] > 2 || sp->w_nd[w] + sp->w_ns[w] > SP_MT) return false;
+    return true;
+}
+
+// the sparse launch pair: compress the planes e_3 .., then the mixed dense / sparse conv + LIF.  `side` = rpn_sparse_bytes() of scratch.
+// Returns 1 if the launches were enqueued (the caller then enqueues the dense launch with Gemm3Args.run_if = *flag_out), 0 if this
+// configuration takes the dense path only, negative on error.
+static int conv3x3_lif_sparse(const Gemm3Args& a, int C_in, void* side, size_t side_bytes, const uint32_t** flag_out, hipStream_t s) {
+    SparsePlan sp;
+    if (!knobs().sparse || !side || !a.wm || !a.periods || a.cnt_img || a.Cw % 2 || a.Np % 64 || a.Kc * 32 > 4096 || a.T < 5 || a.T > 16 ||
+        a.Tc != a.T - 1 || a.t0 != 0 || a.p.v_leak != 0.0f || (float)(a.p.v_leak - a.p.v_th) > 0.0f || !sparse_plan(a.Tc, &sp))
+        return 0;
+    const long long P = a.M, Pe = (long long)a.a_step;
+    if (side_bytes < rpn_sparse_bytes(P, Pe, C_in, a.T)) return 0;
+    char* w = (char*)side;
+    uint32_t* cmp = (uint32_t*)w;
+    w += align_up((size_t)a.T * (a.Cw / 2) * 3 * (size_t)Pe * 4, 256);
+    uint32_t* fix = (uint32_t*)w;
+    w += align_up((size_t)SP_FIX_PER_POS * P * 4 + 4096 * SP_FIX_PER_POS, 256);
+    uint32_t* fix_cnt = (uint32_t*)w;
+    w += align_up(((size_t)P / 16 + 8) * 4, 256);
+    uint32_t* flag = (uint32_t*)w;
+    if ((unsigned long long)((const char*)cmp - (const char*)a.A) + (unsigned long long)a.T * (a.Cw / 2) * 3 * Pe * 4 > 0xffffffffULL) return 0;
+    const int n_tiles = cdiv(P, sp.pb), fix_cap = SP_FIX_PER_POS * sp.pb;
+    if (hipMemsetAsync(fix_cnt, 0, align_up(((size_t)P / 16 + 8) * 4, 256) + 256, s) != hipSuccess) return fail(-3, "hipMemsetAsync failed");
+    CompressArgs ca;
+    memset(&ca, 0, sizeof(ca));
+    ca.enc = a.A; ca.cmp = cmp; ca.fix = fix; ca.fix_cnt = fix_cnt; ca.flag = flag; ca.Pe = (unsigned)Pe; ca.Cw = a.Cw; ca.Tc = a.Tc; ca.nd = sp.nd;
+    ca.pb = sp.pb; ca.fix_cap = fix_cap; ca.Cp = a.Cw * 32; ca.n_levels = a.n_levels;
+    memcpy(ca.lv, a.lv, sizeof(ca.lv));
+    hipLaunchKernelGGL(k_compress_planes, dim3(cdiv(Pe, 256), a.Cw / 2, a.Tc - sp.nd), dim3(256), 0, s, ca);
+    SNN_CHECK_LAUNCH("k_compress_planes");
+    SparseConvArgs sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.enc = a.A; sa.cmp = cmp; sa.wpk = a.wpk; sa.spk = a.spk; sa.fix = fix; sa.fix_cnt = fix_cnt; sa.flag = flag;
+    sa.plane_elems = a.plane_elems; sa.spk_stride = a.spk_stride; sa.Pe = (unsigned)Pe;
+    sa.M = a.M; sa.Kc = a.Kc; sa.Np = a.Np; sa.Cw = a.Cw; sa.n_blocks = a.Np / 64; sa.n_tiles = n_tiles; sa.n_levels = a.n_levels;
+    sa.T = a.T; sa.Tc = a.Tc; sa.nd = sp.nd; sa.pb = sp.pb; sa.q = sp.q; sa.fix_cap = fix_cap; sa.out_split = a.out_split;
+    memcpy(sa.mt_plane, sp.plane, sizeof(sa.mt_plane)); memcpy(sa.mt_j, sp.j, sizeof(sa.mt_j));
+    memcpy(sa.w_nd, sp.w_nd, 8); memcpy(sa.w_ns, sp.w_ns, 8);
+    sa.p = a.p;
+    memcpy(sa.lv, a.lv, sizeof(sa.lv));
+    if (sa.n_blocks % 2 || 8 % (sa.n_blocks / (sa.n_blocks / 2)) ) return 0;
+    sa.xcd_cpx = sa.n_blocks >= 4 ? sa.n_blocks / 2 : 1;                    // column blocks per XCD
+    const int groups = sa.n_blocks / sa.xcd_cpx;                             // XCD groups along N (2)
+    if (8 % groups) return 0;
+    sa.xcd_contig = cdiv(n_tiles, 8 / groups);
+    const int grid = sa.xcd_contig * sa.xcd_cpx * 8;
+    const int lds = max((int)SP_LDS, (int)SP_EPI_BYTES(a.Tc * sp.pb, fix_cap));
+    hipError_t e = hipFuncSetAttribute((const void*)k_conv_lif_sparse, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return fail(-3, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+    if (knobs().debug_occ) {
+        int v = 0;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, (const void*)k_conv_lif_sparse, 512, lds);
+        fprintf(stderr, "k_conv_lif_sparse: pb %d x Tc %d, q %d, lds %d B, %d work-groups per CU, grid %d\n", sp.pb, a.Tc, sp.q, lds, v, grid);
+    }
+    void* kargs[] = {(void*)&sa};
+    e = hipLaunchKernel((const void*)k_conv_lif_sparse, dim3(grid), dim3(512), kargs, lds, s);
+    if (e != hipSuccess) return fail(-3, "k_conv_lif_sparse launch failed: %s", hipGetErrorString(e));
+    SNN_CHECK_LAUNCH("k_conv_lif_sparse");
+    *flag_out = flag;
+    return 1;
+}
+
 static int conv3x3_lif_bf16x3_impl(const uint32_t* enc, size_t enc_stride, const snn_rpn_level* lv, int n_levels, int C_in,
                                    int C_out, int T, const snn_params* p, const uint16_t* w_packed, uint32_t* spk,
                                    size_t spk_stride, unsigned long long* counts, int max_n, snn_stream_t s, bool wm = false,
-                                   bool* out_split = nullptr, bool periods = false) {
+                                   bool* out_split = nullptr, bool periods = false, void* sparse_side = nullptr, size_t sparse_bytes = 0) {
     // out_split (in: wanted, out: done): spike planes in blocks of four words (Gemm3Args.out_split; T-in-tile kernels only)
     const bool want_split = out_split && *out_split;
     if (out_split) *out_split = false;
@@ -960,6 +1058,12 @@ static int conv3x3_lif_bf16x3_impl(const uint32_t* enc, size_t enc_stride, const
     a.cnt_img = counts; a.max_n = max_n;
     if (want_split && a.Np % 128 == 0) { a.out_split = 1; *out_split = true; }
     if (periods && set_periods(a, "snn_conv3x3_lif_bf16x3")) return -1;
+    // round 4: the sparse period planes on the structured-sparse matrix-core instruction (snn_sparse.h); the dense launch stays behind
+    // it as the fallback for inputs whose fix-up lists overflow (it leaves at once otherwise)
+    const uint32_t* flag = nullptr;
+    rc = conv3x3_lif_sparse(a, C_in, sparse_side, sparse_bytes, &flag, (hipStream_t)s);
+    if (rc < 0) return rc;
+    if (rc == 1) a.run_if = flag;
     return launch_gemm3(G3_CONV_LIF_TILE, tl.mt, wn, a, (hipStream_t)s);
 }
 
@@ -1348,13 +1452,18 @@ static long long rpn_positions_padded(const snn_rpn_level* lv, int n_levels) {
 }
 
 // Pe = rows of an encoder plane (positions; with the zero halo for the mxfp6 path)
+// bytes behind the two plane sets for the structured-sparse conv (snn_sparse.h): compressed planes (3 dwords per row and 64 k, at most
+// all T planes), fix-up lists (SP_FIX_PER_POS entries per position), per-tile counters + the overflow flag
+static size_t rpn_sparse_bytes(long long P, long long Pe, int C, int T) {
+    return align_up((size_t)T * cdiv(C, 64) * 3 * (size_t)Pe * 4, 256) + align_up((size_t)SP_FIX_PER_POS * P * 4 + 4096 * SP_FIX_PER_POS, 256) +
+           align_up(((size_t)P / 16 + 8) * 4, 256) + 256;
+}
 static void rpn_ws_layout(long long P, long long Pe, int C, int T, int precision, size_t* o_spk, size_t* o_cur, size_t* o_cnt,
                           size_t* total) {
     const size_t plane = align_up((size_t)T * (Pe > P ? Pe : P) * cdiv(C, 32) * 4, 256);
     *o_spk = plane;
-    *o_cur = 2 * plane;
-    const size_t cur = 0;     // (only the un-fused snn_spike_conv3x3_bf16x3 + snn_lif_scan pair needs currents)
-    (void)precision;
+    *o_cur = 2 * plane;                                   // bf16x3: the sparse conv's side buffers (rpn_sparse_bytes); else unused
+    const size_t cur = precision == SNN_PRECISION_BF16X3 ? rpn_sparse_bytes(P, Pe > P ? Pe : P, C, T) : 0;
     *o_cnt = 2 * plane + cur;
     const size_t cnt = 0;
     *total = 2 * plane + cur + cnt;
@@ -1458,7 +1567,8 @@ int snn_rpn_head_forward_stages(const snn_rpn_level* lv, int n_levels, int C, in
                          ? conv3x3_lif_mx_impl(enc, enc_stride, lv, n_levels, C, C, T, p, (const uint32_t*)w_shared_packed, spk, stride,
                                                spike_counts, max_n, stream)
                          : conv3x3_lif_bf16x3_impl(enc, enc_stride, lv, n_levels, C, C, T, p, (const uint16_t*)w_shared_packed,
-                                                   spk, stride, spike_counts, max_n, stream, wm_rows != 0, &split, per);
+                                                   spk, stride, spike_counts, max_n, stream, wm_rows != 0, &split, per,
+                                                   (char*)ws + o_cur, o_cnt - o_cur);
             if (rc) return rc;
         }
     }

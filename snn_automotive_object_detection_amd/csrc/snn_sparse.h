@@ -1,0 +1,426 @@
+// Structured-sparse matrix cores for the SPARSE period planes of the RPN's shared 3x3 convolution (round 4).  Included by snn_kernels.hip
+// after snn_bf16x3.h (Gemm3-style staging helpers, f2bf / bf2f, G3_SWZ).
+//
+// With period planes (snn_common.h) a conv row tile holds Tc row groups u_n = W e_n, and for n >= 3 the planes are nearly empty
+// (densities 0.039, 0.019, 0.011, 0.007, 0.005 on the bench's pyramid) - yet each costs a full dense MFMA pass.  gfx950's
+// v_smfmac_f32_16x16x64_bf16 multiplies an A operand with at most TWO non-zeros per four consecutive k at 64 k per instruction:
+// 1.82 x the dense rate sustained in this kernel's LDS-fed shape (tools/sparse_probe.hip, profiles/r4_sparse_probe.txt).  So:
+//   * planes e_1, e_2 (densities 0.25 / 0.12: nibbles with three spikes are common) stay on the dense v_mfma_f32_16x16x32_bf16;
+//   * planes e_n, n >= 3, are COMPRESSED (k_compress_planes): per 16 k of a row 8 value slots (occupied or not: the value is 1.0) +
+//     8 two-bit positions.  The A fragment of a lane is table[occupancy byte] - the dense kernels' byte -> 8 bf16 table - plus 16 index
+//     bits; operand layout and encoding were established on the hardware (sparse_probe A1 / A4);
+//   * a nibble with three or four spikes of ONE period (rare: ~0.16 per position over the five sparse planes) keeps its first two in
+//     the compressed plane; each further spike becomes up to nine FIX-UP entries (one per 3x3 tap: output position, plane, k), appended
+//     to the list of the output tile they fall into, and the tile's epilogue adds W[k][:] for them - sorted by (row, k), so the fp32
+//     result does not depend on the order of arrival.  Exactness is unchanged: every product is spike x (hi + mid + lo), fp32 sums.
+//   * a tile whose list overflows (an input with many equal neighbours in a sparse plane) raises a device flag: every work-group of
+//     the sparse launch then leaves at once and the dense launch that follows (Gemm3Args.run_if) does the whole job - no host sync.
+//
+// Row tile = pb positions x Tc planes as M-tiles of 16 rows (plane t, positions 16 j .. 16 j + 15); each of the 8 waves owns up to
+// four M-tiles, dense ones first (table in SparseConvArgs); a wave's loop is instantiated for its (dense, sparse) counts.  The SIMDs
+// see balanced work (waves w and w + 4 share one), which is what matters: a wave waiting at the step barrier leaves its issue slots
+// to the other waves of its SIMD.  K runs in steps of 64 (two 32-deep chunks of the packed weights, whose LDS image is the dense
+// kernels'); ring = two step slots, one barrier per step.
+#pragma once
+
+typedef __bf16 bfv8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bfv16 __attribute__((ext_vector_type(16)));
+
+#define SP_MT 4                                     // M-tile slots per wave
+#define SP_ROWS (8 * SP_MT * 16)                    // physical tile rows (512)
+#define SP_A_BYTES (3 * SP_ROWS * 4)                // three dword arrays per step: dense rows use two (the chunks' spike words), sparse rows
+                                                    // three (occupancy bytes of the four 16-k blocks, index halves 0-1, index halves 2-3)
+#define SP_B_BYTES (2 * 3 * 64 * G3_ROWB)           // two chunks x three weight planes x 64 columns
+#define SP_SLOT (SP_A_BYTES + SP_B_BYTES)           // one 64-k step: 30 KB
+#define SP_LDS (G3_LUT_BYTES + 2 * SP_SLOT)         // 64 KB: two work-groups per CU
+#define SP_PITCH 36                                 // epilogue tile image: 32 columns + 4 floats of padding per row
+#define SP_FIX_PER_POS 8                            // fix-up list capacity of a tile = 8 x its positions
+#define SP_EPI_BYTES(rows, cap) ((rows) * SP_PITCH * 4 + 2 * (cap) * 4)
+
+struct SparseConvArgs {
+    const uint32_t* enc;         // raw period planes, word-major [Tc][Cw][Pe] (zero halo); the dense planes are read from here
+    const uint32_t* cmp;         // compressed planes [Tc - nd][Cw / 2][3][Pe]
+    const uint16_t* wpk;         // [3][Kc][Np][32] bf16
+    uint32_t* spk;               // spike planes out
+    const uint32_t* fix;         // [n_tiles][fix_cap] entries (row << 12 | k), fix_cnt[n_tiles]
+    const uint32_t* fix_cnt;
+    const uint32_t* flag;        // != 0: a list overflowed - leave at once
+    unsigned long long plane_elems, spk_stride;
+    unsigned int Pe;             // padded rows of a word plane
+    int M, Kc, Np, Cw, n_blocks, n_tiles, n_levels;
+    int T, Tc, nd, pb, q, fix_cap, out_split;
+    signed char mt_plane[8][SP_MT];      // plane of the wave's M-tile slot (-1: unused); dense planes (< nd) first
+    unsigned char mt_j[8][SP_MT];        // position block of the slot: local positions 16 j ..
+    unsigned char w_nd[8], w_ns[8];      // dense / sparse M-tiles of the wave
+    int xcd_contig, xcd_cpx;             // block order, as Gemm3Args
+    NeuronP p;
+    ConvLevelDev lv[SNN_MAX_LEVELS];
+};
+
+// nibble -> (two occupancy bits, two 2-bit positions, leftover bits).  bits p0 < p1: slots (1, p0), (1, p1); one bit p < 3: (1, p), (0, 3);
+// p == 3: (0, 0), (1, 3); none: (0, 0), (0, 3): index 0 < index 1 always (tools/sparse_probe.hip A4 ran exactly this encoding).
+__host__ __device__ inline uint32_t sp_nibble_code(uint32_t x) {
+    int p0 = -1, p1 = -1;
+    uint32_t left = 0;
+    for (int b = 0; b < 4; ++b)
+        if (x & (1u << b)) {
+            if (p0 < 0) p0 = b;
+            else if (p1 < 0) p1 = b;
+            else left |= 1u << b;
+        }
+    uint32_t occ, i0, i1;
+    if (p1 >= 0) { occ = 3; i0 = p0; i1 = p1; }
+    else if (p0 >= 0 && p0 < 3) { occ = 1; i0 = p0; i1 = 3; }
+    else if (p0 == 3) { occ = 2; i0 = 0; i1 = 3; }
+    else { occ = 0; i0 = 0; i1 = 3; }
+    return occ | ((i0 | (i1 << 2)) << 2) | (left << 6);       // bits 1:0 occupancy, 5:2 indices, 9:6 leftover
+}
+
+struct CompressArgs {
+    const uint32_t* enc;
+    uint32_t* cmp;
+    uint32_t* fix;
+    uint32_t* fix_cnt;
+    uint32_t* flag;
+    unsigned int Pe;
+    int Cw, Tc, nd, pb, fix_cap, Cp, n_levels;
+    ConvLevelDev lv[SNN_MAX_LEVELS];
+};
+
+// thread = (padded row, 64-k step w2 = blockIdx.y, sparse plane ts = blockIdx.z)
+__global__ __launch_bounds__(256) void k_compress_planes(const CompressArgs a) {
+    __shared__ uint16_t code[16];
+    if (threadIdx.x < 16) code[threadIdx.x] = (uint16_t)sp_nibble_code(threadIdx.x);
+    __syncthreads();
+    const unsigned int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= a.Pe) return;
+    const int w2 = blockIdx.y, ts = blockIdx.z, t = a.nd + ts;
+    const uint32_t wd[2] = {a.enc[((size_t)t * a.Cw + 2 * w2) * a.Pe + row], a.enc[((size_t)t * a.Cw + 2 * w2 + 1) * a.Pe + row]};
+    uint32_t occ = 0, idx[2] = {0, 0}, left[2] = {0, 0};
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int nb = 0; nb < 8; ++nb) {
+            const uint32_t c = code[(wd[h] >> (4 * nb)) & 15u];
+            occ |= (c & 3u) << (16 * h + 2 * nb);
+            idx[h] |= ((c >> 2) & 15u) << (4 * nb);
+            left[h] |= ((c >> 6) & 15u) << (4 * nb);
+        }
+    uint32_t* out = a.cmp + ((size_t)ts * (a.Cw / 2) + w2) * 3 * a.Pe + row;
+    out[0] = occ; out[a.Pe] = idx[0]; out[2 * (size_t)a.Pe] = idx[1];
+    if ((left[0] | left[1]) == 0) return;
+    // (rare) spikes beyond two per nibble: one fix-up entry per 3x3 tap that reads this input position
+    int l = 0;
+    while (l + 1 < a.n_levels && row >= (unsigned)a.lv[l + 1].tile_begin) ++l;
+    const int H = a.lv[l].H, W = a.lv[l].W;
+    const int local = (int)row - a.lv[l].tile_begin;
+    const int n = local / ((H + 2) * (W + 2)), rem = local % ((H + 2) * (W + 2));
+    const int y = rem / (W + 2) - 1, x = rem % (W + 2) - 1;
+    if (y < 0 || y >= H || x < 0 || x >= W) return;            // (halo rows are zero: cannot happen)
+    for (int h = 0; h < 2; ++h) {
+        uint32_t m = left[h];
+        while (m) {
+            const int b = __builtin_ctz(m);
+            m &= m - 1;
+            const int c = (2 * w2 + h) * 32 + b;
+            for (int ky = 0; ky < 3; ++ky)
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int oy = y - (ky - 1), ox = x - (kx - 1);
+                    if (oy < 0 || oy >= H || ox < 0 || ox >= W) continue;
+                    const int p = a.lv[l].pos_base + (n * H + oy) * W + ox;
+                    const int tile = p / a.pb, lp = p % a.pb;
+                    const uint32_t entry = ((uint32_t)(t * a.pb + lp) << 12) | (uint32_t)((ky * 3 + kx) * a.Cp + c);
+                    const uint32_t slot = atomicAdd(a.fix_cnt + tile, 1u);
+                    if (slot < (uint32_t)a.fix_cap) a.fix[(size_t)tile * a.fix_cap + slot] = entry;
+                    else atomicOr(a.flag, 1u);
+                }
+        }
+    }
+}
+
+// LIF over T steps of one neuron from the period sums in the LDS tile image: the straight-line form of k_gemm_bf16x3's epilogue
+// (period planes, v_leak = 0, no spike at step 0, conv window T - 1), same operations in the same order
+template <int TS>
+__device__ __forceinline__ void sp_lif_fixed(const float* src, const int group_stride, const NeuronP& p, uint32_t& my0, uint32_t& my1) {
+    constexpr int TCS = TS - 1;
+    float ug[TCS];
+#pragma unroll
+    for (int g = 0; g < TCS; ++g) ug[g] = src[(size_t)g * group_stride];
+    float vv = 0.0f, ii = 0.0f;
+#pragma unroll
+    for (int t = 0; t < TS; ++t) {
+        float c = 0.0f;
+        if (t < TCS) {
+            c = ug[0];
+#pragma unroll
+            for (int n = 2; n <= t + 1; ++n)
+                if ((t + 1) % n == 0) c = __fadd_rn(c, ug[n - 1]);
+        }
+        if (t == 0) { ii = __fadd_rn(0.0f, c); continue; }
+        const float v_dec = __fadd_rn(vv, __fmul_rn(p.ca, __fsub_rn(ii, vv)));
+        const float i_dec = __fadd_rn(ii, __fmul_rn(p.cb, ii));
+        const bool z = v_dec > p.v_th;
+        vv = z ? p.v_reset : v_dec;
+        ii = __fadd_rn(i_dec, c);
+        const unsigned long long b = __ballot(z);
+        G3_KEEP_BALLOT(my0, my1, b, t);
+    }
+}
+
+__global__ __launch_bounds__(512, 4) void k_conv_lif_sparse(const SparseConvArgs args) {
+    if (*args.flag != 0u) return;                            // a fix-up list overflowed: the dense launch behind this one does the work
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    unsigned char* const lut = smem;
+    unsigned char* const ring = smem + G3_LUT_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, lg = lane >> 4;
+    // block order: XCD x = blockIdx % 8 takes xcd_cpx column blocks on a contiguous range of row tiles (k_gemm_bf16x3: xcd_contig)
+    int nb, mb;
+    {
+        const int x = blockIdx.x & 7, j = blockIdx.x >> 3, cpx = args.xcd_cpx, groups = args.n_blocks / cpx;
+        nb = (x % groups) * cpx + j % cpx;
+        mb = (x / groups) * args.xcd_contig + j / cpx;
+        if (j / cpx >= args.xcd_contig || mb >= args.n_tiles) return;
+    }
+    nb = __builtin_amdgcn_readfirstlane(nb);
+    mb = __builtin_amdgcn_readfirstlane(mb);
+    const int pb = args.pb, M = args.M, Kc = args.Kc, Np = args.Np;
+    const int m0 = mb * pb;
+    if (tid < 256) {
+        uint4 q;
+        q.x = bf16_pair(tid, 0); q.y = bf16_pair(tid, 1); q.z = bf16_pair(tid, 2); q.w = bf16_pair(tid, 3);
+        *reinterpret_cast<uint4*>(lut + tid * 16) = q;
+    }
+    const int nd_w = __builtin_amdgcn_readfirstlane((int)args.w_nd[wave]), ns_w = __builtin_amdgcn_readfirstlane((int)args.w_ns[wave]);
+
+    // ---- A staging: lane L of the wave stages physical row 64 wave + L = slot L >> 4, row L & 15 of that M-tile
+    const int xs = lane >> 4;
+    const int xplane = args.mt_plane[wave][xs];
+    const bool xused = xplane >= 0, xdense = xused && xplane < args.nd;
+    uint32_t voff0, voff1, voff2, inc;                      // byte offsets from args.enc
+    uint32_t tap_fix, row_fix;
+    {
+        const int lp = min(args.mt_j[wave][xs] * 16 + (lane & 15), pb - 1);
+        const int p = min(m0 + (xused ? lp : 0), M - 1);
+        int l = 0;
+        while (l + 1 < args.n_levels && p >= args.lv[l + 1].pos_base) ++l;
+        const int H = args.lv[l].H, W = args.lv[l].W;
+        const int local = p - args.lv[l].pos_base;
+        const int n = local / (H * W), rem = local % (H * W);
+        const int y = rem / W, x = rem % W;
+        const uint32_t row0 = (uint32_t)args.lv[l].tile_begin + (uint32_t)((n * (H + 2) + y) * (W + 2) + x);      // tap (-1, -1)
+        const uint32_t Pe = args.Pe;
+        const int Cw2 = args.Cw / 2;
+        if (xdense || !xused) {
+            const int t = xused ? xplane : 0;
+            voff0 = (uint32_t)(((size_t)t * args.Cw * Pe + row0) * 4);
+            voff1 = voff0 + Pe * 4;
+            voff2 = voff0;
+            inc = 2 * Pe * 4;
+        } else {
+            const uint32_t delta = (uint32_t)((const char*)args.cmp - (const char*)args.enc);
+            voff0 = delta + (uint32_t)(((size_t)(xplane - args.nd) * Cw2 * 3 * Pe + row0) * 4);
+            voff1 = voff0 + Pe * 4;
+            voff2 = voff0 + 2 * Pe * 4;
+            inc = 3 * Pe * 4;
+        }
+        tap_fix = 4u - (uint32_t)Cw2 * inc;                 // next tap of the row: one position on, back to channel word 0
+        row_fix = (uint32_t)((W + 2 - 3) * 4);              // after the third tap of a row: one padded image row down
+    }
+    const uint32_t a_dst = smem_base + G3_LUT_BYTES + wave * 256;
+    const void* const a_base = sgpr_ptr(args.enc);
+    const int cw2_s = __builtin_amdgcn_readfirstlane(args.Cw / 2);
+    int f_c = 0, f_tap = 0;
+    auto stage_a = [&](const uint32_t slot_off) __attribute__((always_inline)) {
+        const uint32_t d = __builtin_amdgcn_readfirstlane(a_dst + slot_off);
+        asm volatile("s_mov_b32 m0, %4\n\ts_nop 4\n\tglobal_load_lds_dword %0, %3\n\t"
+                     "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dword %1, %3\n\t"
+                     "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dword %2, %3"
+                     :: "v"(voff0), "v"(voff1), "v"(voff2), "s"(a_base), "s"(d), "s"(d + SP_ROWS * 4), "s"(d + 2 * SP_ROWS * 4) : "memory");
+        voff0 += inc; voff1 += inc; voff2 += inc;
+        f_c = __builtin_amdgcn_readfirstlane(f_c + 1);
+        if (f_c == cw2_s) {
+            f_c = 0;
+            voff0 += tap_fix; voff1 += tap_fix; voff2 += tap_fix;
+            f_tap = __builtin_amdgcn_readfirstlane(f_tap + 1);
+            if (f_tap == 3) { f_tap = 0; voff0 += row_fix; voff1 += row_fix; voff2 += row_fix; }
+        }
+    };
+
+    // ---- B staging: 24 pieces of 1 KB per step (2 chunks x 3 planes x 4 blocks of 16 columns); wave w copies pieces w, w + 8, w + 16
+    const int brow = (wave & 3) * 16 + (lane >> 2);
+    const uint32_t b_off = (uint32_t)((nb * 64 + brow) * 64 + (((lane & 3) ^ G3_SWZ(brow)) << 4));
+    const unsigned long long b_chunk = (unsigned long long)Np * 64, b_plane = args.plane_elems * 2;
+    unsigned long long s_ptr = (unsigned long long)args.wpk;                  // chunk 2 * step, plane 0
+    const uint32_t b_dst = smem_base + G3_LUT_BYTES + SP_A_BYTES + (wave & 3) * 1024;
+    auto stage_b = [&](const uint32_t slot_off) __attribute__((always_inline)) {
+        const uint32_t d = __builtin_amdgcn_readfirstlane(b_dst + slot_off);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int piece = wave + 8 * i;                                    // wave-uniform
+            const int c2 = piece / 12, pl = (piece % 12) / 4;
+            glds16(sgpr_ptr(reinterpret_cast<const void*>(s_ptr + c2 * b_chunk + pl * b_plane)), b_off, d + c2 * (3 * 64 * G3_ROWB) + pl * (64 * G3_ROWB));
+        }
+        s_ptr += 2 * b_chunk;
+    };
+
+    const unsigned char* const a_rd = ring + (wave * 64 + lr) * 4;                          // + slot offset, M-tile slot * 64
+    const unsigned char* const b_rd = ring + SP_A_BYTES + lr * G3_ROWB + ((lg ^ G3_SWZ(lr)) << 4);
+    f32x4 acc[SP_MT][4];
+#pragma unroll
+    for (int mt = 0; mt < SP_MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    const int n_steps = Kc / 2;
+    stage_a(0); stage_b(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    auto step_loop = [&](auto nd_c, auto ns_c) __attribute__((always_inline)) {
+        constexpr int ND = decltype(nd_c)::value, NS = decltype(ns_c)::value;
+        for (int s = 0; s < n_steps; ++s) {
+            const uint32_t o_cur = (uint32_t)((s & 1) * SP_SLOT), o_nxt = (uint32_t)(((s + 1) & 1) * SP_SLOT);
+            if (s + 1 < n_steps) { stage_a(o_nxt); stage_b(o_nxt); }
+            // A fragments of this step
+            bfv8 ad[ND > 0 ? ND : 1][2], as[NS > 0 ? NS : 1];
+            int ix[NS > 0 ? NS : 1];
+#pragma unroll
+            for (int d = 0; d < ND; ++d)
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2) {
+                    const uint32_t byte = *reinterpret_cast<const uint8_t*>(a_rd + o_cur + c2 * (SP_ROWS * 4) + d * 64 + lg);
+                    ad[d][c2] = *reinterpret_cast<const bfv8*>(lut + (byte << 4));
+                }
+#pragma unroll
+            for (int q = 0; q < NS; ++q) {
+                const unsigned char* r = a_rd + o_cur + (ND + q) * 64;
+                const uint32_t occ = *reinterpret_cast<const uint8_t*>(r + lg);
+                as[q] = *reinterpret_cast<const bfv8*>(lut + (occ << 4));
+                ix[q] = (int)*reinterpret_cast<const uint16_t*>(r + (1 + (lg >> 1)) * (SP_ROWS * 4) + 2 * (lg & 1));
+            }
+            bfv8 b0 = *reinterpret_cast<const bfv8*>(b_rd + o_cur + 2 * (64 * G3_ROWB));
+            bfv8 b1 = *reinterpret_cast<const bfv8*>(b_rd + o_cur + 3 * 64 * G3_ROWB + 2 * (64 * G3_ROWB));
+#pragma unroll
+            for (int g = 0; g < 12; ++g) {                  // group = (N-tile g / 3, plane 2 - g % 3): small terms first
+                bfv8 n0 = b0, n1 = b1;
+                if (g + 1 < 12) {
+                    const int gn = g + 1;
+                    n0 = *reinterpret_cast<const bfv8*>(b_rd + o_cur + (2 - gn % 3) * (64 * G3_ROWB) + (gn / 3) * 16 * G3_ROWB);
+                    n1 = *reinterpret_cast<const bfv8*>(b_rd + o_cur + 3 * 64 * G3_ROWB + (2 - gn % 3) * (64 * G3_ROWB) + (gn / 3) * 16 * G3_ROWB);
+                }
+#pragma unroll
+                for (int d = 0; d < ND; ++d) {
+                    acc[d][g / 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ad[d][0], b0, acc[d][g / 3], 0, 0, 0);
+                    acc[d][g / 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ad[d][1], b1, acc[d][g / 3], 0, 0, 0);
+                }
+                if (NS > 0) {
+                    bfv16 bb;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { bb[i] = b0[i]; bb[8 + i] = b1[i]; }
+#pragma unroll
+                    for (int q = 0; q < NS; ++q)
+                        acc[ND + q][g / 3] = __builtin_amdgcn_smfmac_f32_16x16x64_bf16(as[q], bb, acc[ND + q][g / 3], ix[q], 0, 0);
+                }
+                b0 = n0; b1 = n1;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_waitcnt(0x0070);              // vmcnt(0) lgkmcnt(0): the next step's copies have landed
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+    };
+#define SP_CASE(ND_, NS_) if (nd_w == ND_ && ns_w == NS_) step_loop(std::integral_constant<int, ND_>{}, std::integral_constant<int, NS_>{}); else
+    SP_CASE(1, 3) SP_CASE(1, 2) SP_CASE(2, 2) SP_CASE(0, 4) SP_CASE(0, 3) SP_CASE(1, 1) SP_CASE(2, 1) SP_CASE(0, 2) SP_CASE(0, 1)
+    SP_CASE(2, 0) SP_CASE(1, 0)
+    {   // a wave without M-tiles still stages and keeps the barriers
+        step_loop(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    }
+#undef SP_CASE
+
+    // ---- epilogue: currents -> LDS tile image (two passes of 32 columns), fix-ups, LIF over the T steps, spike words out
+    const int T = args.T, Tc = args.Tc;
+    float* const tile = reinterpret_cast<float*>(smem);
+    const int rows_l = Tc * pb;
+    uint32_t* const fx = reinterpret_cast<uint32_t*>(smem + (size_t)rows_l * SP_PITCH * 4);      // sorted entries, then the unsorted copy
+    const int n_fix = min((int)args.fix_cnt[mb], args.fix_cap);
+    __syncthreads();                                           // ring reads done
+    if (n_fix > 0) {                                           // block-uniform
+        uint32_t* const raw = fx + args.fix_cap;
+        for (int i = tid; i < n_fix; i += 512) raw[i] = args.fix[(size_t)mb * args.fix_cap + i];
+        __syncthreads();
+        for (int i = tid; i < n_fix; i += 512) {
+            const uint32_t key = raw[i];
+            int rank = 0;
+            for (int j = 0; j < n_fix; ++j) rank += raw[j] < key;       // keys are distinct
+            fx[rank] = key;
+        }
+    }
+    const int group_stride = pb * SP_PITCH;
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) {
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < SP_MT; ++mt) {
+            const int plane = args.mt_plane[wave][mt];         // wave-uniform
+            if (plane < 0) continue;
+            const int lp0 = args.mt_j[wave][mt] * 16 + lg * 4;
+#pragma unroll
+            for (int nq = 0; nq < 2; ++nq)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (lp0 + r < pb) tile[(plane * pb + lp0 + r) * SP_PITCH + nq * 16 + lr] = h == 0 ? acc[mt][nq][r] : acc[mt][2 + nq][r];
+        }
+        __syncthreads();
+        if (n_fix > 0) {
+            // entries of one row form a run of the sorted list; the half-wave that owns a run's first entry adds the whole run, in k order
+            const int hw = tid >> 5, c32 = tid & 31;
+            const int col = nb * 64 + h * 32 + c32;
+            for (int e = hw; e < n_fix; e += 16) {
+                const uint32_t row = fx[e] >> 12;
+                if (e > 0 && (fx[e - 1] >> 12) == row) continue;
+                float v = tile[row * SP_PITCH + c32];
+                for (int f = e; f < n_fix && (fx[f] >> 12) == row; ++f) {
+                    const uint32_t k = fx[f] & 0xfffu;
+                    const size_t wi = ((size_t)(k >> 5) * Np + col) * 32 + (k & 31);
+                    const float w = __fadd_rn(__fadd_rn(bf2f(args.wpk[2 * args.plane_elems + wi]), bf2f(args.wpk[args.plane_elems + wi])), bf2f(args.wpk[wi]));
+                    v = __fadd_rn(v, w);
+                }
+                tile[row * SP_PITCH + c32] = v;
+            }
+            __syncthreads();
+        }
+        const int word0 = (nb * 64 + h * 32) >> 5;
+        const int par = lane >> 5, col = lane & 31;
+        for (int pp = wave; 2 * pp < pb; pp += 8) {
+            const int pi = 2 * pp + par;
+            const bool live = pi < pb && m0 + pi < M;
+            if (m0 + 2 * pp >= M) break;
+            uint32_t my0 = 0, my1 = 0;
+            const float* src = tile + (live ? pi : 2 * pp) * SP_PITCH + col;
+            switch (T) {
+#define SP_T(n) case n: sp_lif_fixed<n>(src, group_stride, args.p, my0, my1); break;
+                SP_T(5) SP_T(6) SP_T(7) SP_T(8) SP_T(9) SP_T(10) SP_T(11) SP_T(12) SP_T(13) SP_T(14) SP_T(15) SP_T(16)
+#undef SP_T
+            default: break;
+            }
+            const bool odd_ok = 2 * pp + 1 < pb && m0 + 2 * pp + 1 < M;
+            if (lane < T) {
+                if (args.out_split) {
+                    uint32_t* dst = args.spk + (size_t)lane * args.spk_stride + ((size_t)(word0 >> 2) * M + m0 + 2 * pp) * 4 + (word0 & 3);
+                    dst[0] = my0;
+                    if (odd_ok) dst[4] = my1;
+                } else {
+                    uint32_t* dst = args.spk + (size_t)lane * args.spk_stride + (size_t)(m0 + 2 * pp) * (Np >> 5) + word0;
+                    dst[0] = my0;
+                    if (odd_ok) dst[Np >> 5] = my1;
+                }
+            }
+        }
+    }
+}

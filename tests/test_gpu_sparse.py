@@ -1,0 +1,112 @@
+"""The RPN's shared 3x3 convolution with its sparse period planes e_3 .. on the structured-sparse matrix-core instruction
+(csrc/snn_sparse.h; default) against the all-dense launch (SNN_SPARSE=0) and the oracle (rpn.py:98-119):
+ * same results up to the fp32 summation order: outputs within 1e-4 except at positions where a threshold tie flipped a spike
+   (the usual budget), on pyramids of several T and odd shapes;
+ * nibbles with three and four spikes of one period (more than the instruction can take) go through the fix-up lists: an input
+   built to have them everywhere in a sparse plane still matches the dense launch;
+ * when a tile's list overflows, the dense launch behind the sparse one does the whole job: bit-identical to SNN_SPARSE=0."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import snn_oracle as OR
+from tests._util import flip_budget
+
+pytestmark = pytest.mark.gpu
+
+
+def _head(dev, C, T, seed, gain=4.0):
+    import snn_automotive_object_detection_amd as S
+    torch.manual_seed(seed)
+    m = S.RPNHeadSNN(C, 3, T).to(dev)
+    with torch.no_grad():
+        m.shared_conv.weight.mul_(gain)
+    return m
+
+
+def _run(m, feats):
+    lg, bb = m(feats)
+    return [t.clone() for t in lg + bb]
+
+
+def _off_positions(a, b, tol=1e-4):
+    """positions (n, y, x) where any output channel differs by more than tol, and the largest difference"""
+    bad, mx = 0, 0.0
+    L = len(a) // 2
+    for l in range(L):
+        d = torch.maximum((a[l] - b[l]).abs().amax(1), (a[L + l] - b[L + l]).abs().amax(1))
+        bad += int((d > tol).sum())
+        mx = max(mx, float(d.max()))
+    return bad, mx
+
+
+@pytest.mark.parametrize("T", [5, 6, 8, 9, 12, 16])
+def test_sparse_conv_equals_dense_up_to_ties(gpu_device, monkeypatch, T):
+    m = _head(gpu_device, 256, T, T)
+    g = torch.Generator().manual_seed(T)
+    feats = [(torch.randn(2, 256, h, w, generator=g) * 1.7).to(gpu_device) for h, w in [(37, 53), (19, 27), (7, 9), (1, 3)]]
+    a = _run(m, feats)
+    monkeypatch.setenv("SNN_SPARSE", "0")
+    b = _run(m, feats)
+    pos = sum(2 * f.shape[2] * f.shape[3] for f in feats)
+    bad, mx = _off_positions(a, b)
+    assert bad <= flip_budget(pos, 256, T, "rpn_randn") and mx < 0.05, (bad, mx)
+    assert any(float(t.abs().max()) > 0 for t in a)
+    assert not all(torch.equal(x, y) for x, y in zip(a, b)), "the sparse path did not run (bit-identical to the dense launch)"
+
+
+def test_sparse_conv_vs_oracle(gpu_device):
+    T = 8
+    m = _head(gpu_device, 64, T, 3)
+    g = torch.Generator().manual_seed(5)
+    feats = [torch.randn(2, 64, 23, 31, generator=g) * 1.7, torch.randn(2, 64, 6, 5, generator=g) * 1.7]
+    a = _run(m, [f.to(gpu_device) for f in feats])
+    o_l, o_b = OR.rpn_head_forward(feats, m.shared_conv.weight.detach().cpu(), m.conv_cls.weight.detach().cpu(), m.conv_bbox.weight.detach().cpu(), T)
+    bad, mx = _off_positions([t.cpu() for t in a], list(o_l) + list(o_b))
+    assert bad <= flip_budget(2 * (23 * 31 + 30), 64, T, "rpn_randn") and mx < 0.05, (bad, mx)
+
+
+def _same_period_blocks(C, H, W, period, frac, seed):
+    """features whose channels fire with one period in whole groups of four adjacent channels (3 - 4 spikes per nibble of plane e_period)
+    on a fraction of the positions; the rest N(0, 1.7)"""
+    import ctypes as Ct
+    from snn_automotive_object_detection_amd import _lib, ops
+    p = ops.make_params(ops.LIFParameters(v_th=torch.tensor(0.25)), ops.LIFParameters(alpha=100, v_th=torch.tensor(0.1)))
+    th = (Ct.c_float * 32)()
+    assert _lib.load().snn_debug_encoder_thresholds(Ct.byref(p), th) == 1
+    x_n = 0.5 * (th[period - 1] + th[period - 2])            # first spike at step period - 1  <=>  th[period - 1] <= x < th[period - 2]
+    g = torch.Generator().manual_seed(seed)
+    f = torch.randn(2, C, H, W, generator=g) * 1.7
+    mask = torch.rand(2, 1, H, W, generator=g) < frac
+    grp = (torch.rand(2, C // 4, H, W, generator=g) < 0.5).repeat_interleave(4, dim=1)     # whole nibbles
+    three = torch.rand(2, C, H, W, generator=g) < 0.9                                      # mostly 4, sometimes 3 of a nibble
+    sel = mask & grp & three
+    return torch.where(sel, torch.full_like(f, float(x_n)), f)
+
+
+@pytest.mark.parametrize("period,frac", [(3, 0.02), (5, 0.05), (7, 0.03)])
+def test_fixup_lists_carry_the_spikes_the_instruction_cannot(gpu_device, monkeypatch, period, frac):
+    T = 8
+    m = _head(gpu_device, 128, T, period)
+    feats = [_same_period_blocks(128, 20, 30, period, frac, period).to(gpu_device)]
+    a = _run(m, feats)
+    monkeypatch.setenv("SNN_SPARSE", "0")
+    b = _run(m, feats)
+    bad, mx = _off_positions(a, b)
+    assert bad <= 2 + flip_budget(2 * 600, 128, T, "rpn_randn") and mx < 0.05, (bad, mx)
+    assert not all(torch.equal(x, y) for x, y in zip(a, b))
+    # and repeatable bit for bit (the lists are filled by atomics in any order, the tile sorts them)
+    monkeypatch.delenv("SNN_SPARSE")
+    for _ in range(3):
+        assert all(torch.equal(x, y) for x, y in zip(a, _run(m, feats)))
+
+
+def test_overflowing_lists_fall_back_to_the_dense_launch(gpu_device, monkeypatch):
+    T = 8
+    m = _head(gpu_device, 128, T, 11)
+    feats = [_same_period_blocks(128, 24, 24, 4, 0.9, 2).to(gpu_device)]          # nearly every position: far beyond 8 entries per position
+    a = _run(m, feats)
+    monkeypatch.setenv("SNN_SPARSE", "0")
+    b = _run(m, feats)
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    assert any(float(t.abs().max()) > 0 for t in a)

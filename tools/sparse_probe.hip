@@ -44,6 +44,39 @@ __global__ void layout_probe(float* out, int mode) {
     for (int r = 0; r < 4; ++r) out[((size_t)e * 64 + lane) * 4 + r] = acc[r];
 }
 
+// ---- A4: functional check of the nibble encoding the kernels would use.  A row's 64 spike bits (<= 2 set per nibble) -> per 16-k block
+// 8 value slots (1.0 / 0) + 8 two-bit positions: nibble bits p0 < p1 -> slots (1.0, p0), (1.0, p1); one bit p: p < 3 -> (1.0, p), (0, 3),
+// p == 3 -> (0, 0), (1.0, 3); none -> (0, 0), (0, 3) - always index0 < index1.  B = small integers: the result must equal the host's
+// dot products exactly.  idx_hi: garbage in bits 31:16 of the index register (are they ignored at ABID = 0?).
+__global__ void func_probe(const unsigned long long* __restrict__ rows, const float* __restrict__ bmat, float* out, int idx_hi) {
+    const int lane = threadIdx.x, lr = lane & 15, lg = lane >> 4;
+    const unsigned long long bits = rows[blockIdx.x * 16 + lr];
+    const uint32_t h = (uint32_t)(bits >> (16 * lg)) & 0xffffu;
+    bf16x8 a;
+    int idx = 0;
+    for (int nb = 0; nb < 4; ++nb) {
+        const uint32_t x = (h >> (4 * nb)) & 15u;
+        int p0 = -1, p1 = -1;
+        for (int b = 0; b < 4; ++b) if (x & (1u << b)) { if (p0 < 0) p0 = b; else if (p1 < 0) p1 = b; }
+        float v0, v1; int i0, i1;
+        if (p1 >= 0) { v0 = 1.f; i0 = p0; v1 = 1.f; i1 = p1; }
+        else if (p0 >= 0 && p0 < 3) { v0 = 1.f; i0 = p0; v1 = 0.f; i1 = 3; }
+        else if (p0 == 3) { v0 = 0.f; i0 = 0; v1 = 1.f; i1 = 3; }
+        else { v0 = 0.f; i0 = 0; v1 = 0.f; i1 = 3; }
+        a[2 * nb] = bf(v0); a[2 * nb + 1] = bf(v1);
+        idx |= (i0 | (i1 << 2)) << (4 * nb);
+    }
+    if (idx_hi) idx |= 0x5a5a0000;
+    bf16x16 b;                                                   // element i of lane (g, col): k = 8 g + i (i < 8), 32 + 8 g + i - 8
+    for (int i = 0; i < 16; ++i) {
+        const int k = i < 8 ? 8 * lg + i : 32 + 8 * lg + (i - 8);
+        b[i] = bf(bmat[k * 16 + lr]);
+    }
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    acc = __builtin_amdgcn_smfmac_f32_16x16x64_bf16(a, b, acc, idx, 0, 0);
+    for (int r = 0; r < 4; ++r) out[(blockIdx.x * 16 + 4 * lg + r) * 16 + lr] = acc[r];       // row 4 lg + r, column lr
+}
+
 // ---- A2: instruction rate, everything in registers
 template <int SPARSE>
 __global__ __launch_bounds__(256) void rate_probe(float* out, int iters) {
@@ -224,11 +257,46 @@ int main(int argc, char** argv) {
             // hypothesis: row = l & 15; the value names k = 16 * (l >> 4) + 4 * (j >> 1) + q ... the B element holding that k is element
             // (k % 16) of lane 16 * (k / 16) + column
             const int k_h = 16 * (l >> 4) + 4 * (j >> 1) + q;
-            const bool ok = row == (l & 15) && bi == (k_h & 15) && bl[0] == 16 * (k_h >> 4);
+            // (B: element i < 8 of lane group g holds k = 8 g + i; elements 8 .. 15 hold k = 32 + 8 g + i - 8: two stacked 16x16x32 layouts)
+            const int bg = (k_h & 31) >> 3, be = (k_h & 7) + 8 * (k_h >> 5);
+            const bool ok = row == (l & 15) && bi == be && bl[0] == 16 * bg;
             if (!ok) ++bad;
-            if (e < 40 || (!ok && bad < 40)) printf("  lane %2d slot %d idx %d -> row %2d, B element %2d of lanes %2d.. (hypothesis k = %2d: %s)\n", l, j, q, row, bi, bl[0], k_h, ok ? "ok" : "NO");
+            if (e < 8 || (!ok && bad < 24)) printf("  lane %2d slot %d idx %d -> row %2d, B element %2d of lanes %2d.. (hypothesis k = %2d: %s)\n", l, j, q, row, bi, bl[0], k_h, ok ? "ok" : "NO");
         }
-        printf("A1: %d of 2048 experiments off the hypothesis [row = l & 15; k = 16 (l >> 4) + 4 (j >> 1) + q; B element k %% 16 of lane 16 (k / 16) + column]\n", bad);
+        printf("A1: %d of 2048 experiments off the hypothesis [A: row = l & 15, k = 16 (l >> 4) + 4 (j >> 1) + q;  B: element (k & 7) + 8 (k >> 5) of lane 16 ((k & 31) >> 3) + column]\n", bad);
+    }
+    // ---- A4 functional check
+    {
+        const int NT = 256;
+        std::vector<unsigned long long> rows(NT * 16);
+        std::vector<float> bm(64 * 16);
+        uint32_t x = 12345u;
+        auto rnd = [&]() { x ^= x << 13; x ^= x >> 17; x ^= x << 5; return x; };
+        for (auto& r : rows) {
+            r = 0;
+            for (int nb = 0; nb < 16; ++nb) {
+                const uint32_t c = rnd() % 11;                                  // 0 .. 10: the 11 nibbles with <= 2 bits
+                static const uint32_t pat[11] = {0, 1, 2, 4, 8, 3, 5, 9, 6, 10, 12};
+                r |= (unsigned long long)pat[c] << (4 * nb);
+            }
+        }
+        for (auto& v : bm) v = (float)((int)(rnd() % 17) - 8);
+        unsigned long long* d_rows; float* d_b;
+        CHECK(hipMalloc(&d_rows, rows.size() * 8)); CHECK(hipMalloc(&d_b, bm.size() * 4));
+        CHECK(hipMemcpy(d_rows, rows.data(), rows.size() * 8, hipMemcpyHostToDevice));
+        CHECK(hipMemcpy(d_b, bm.data(), bm.size() * 4, hipMemcpyHostToDevice));
+        for (int hi = 0; hi < 2; ++hi) {
+            hipLaunchKernelGGL(func_probe, dim3(NT), dim3(64), 0, 0, d_rows, d_b, out, hi);
+            std::vector<float> got(NT * 16 * 16);
+            CHECK(hipMemcpy(got.data(), out, got.size() * 4, hipMemcpyDeviceToHost));
+            int bad = 0;
+            for (int t = 0; t < NT * 16; ++t) for (int c = 0; c < 16; ++c) {
+                float e = 0.f;
+                for (int k = 0; k < 64; ++k) if ((rows[t] >> k) & 1ull) e += bm[k * 16 + c];
+                if (got[t * 16 + c] != e) ++bad;
+            }
+            printf("A4: nibble encoding on %d random 2:4-compliant rows x 16 columns, index bits 31:16 %s: %d wrong results\n", NT * 16, hi ? "garbage" : "zero", bad);
+        }
     }
     // ---- A2 rate
     for (int sp = 0; sp < 2; ++sp) {

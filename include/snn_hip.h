@@ -94,6 +94,10 @@ int snn_debug_encoder_thresholds(const snn_params* p, float* th32);
  * (dead time steps removed), work-groups of the launch, column blocks, waves along N}.  Returns 0, or -4 if no tile holds that
  * many steps (the launch then takes the un-fused path). */
 int snn_debug_tile_shape(int conv, long long units, int n_cols, int num_steps, int spike_rates, int layer, int32_t* out);
+/* Introspection (tests, bench.py): 1 if the calling thread's last bf16x3 RPN conv + LIF enqueued the structured-sparse launch pair
+ * (csrc/snn_sparse.h: planes e_3 .. on v_smfmac, the dense launch behind it as the device-side fallback), 0 if it took the dense
+ * launch only (SNN_SPARSE=0, spike-rate mode, T outside 5 .. 16, channel counts that are not multiples of 64, ...). */
+int snn_debug_last_conv_path(void);
 
 /* ---- weight packing (call when the weights change; results are plain device buffers) ---------- */
 /* number of floats of a packed GEMM operand with K reduction rows and N output columns */

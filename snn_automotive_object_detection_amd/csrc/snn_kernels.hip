@@ -27,6 +27,7 @@
 // error plumbing (thread-local; no exceptions, no abort)
 // ------------------------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
+static thread_local int g_last_conv_sparse = 0;    // did this thread's last RPN conv + LIF enqueue the sparse launch pair (snn_debug_last_conv_path)
 
 static int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
 static int fail(int code, const char* fmt, ...) {
@@ -677,6 +678,8 @@ int snn_debug_encoder_thresholds(const snn_params* p, float* th32) {
     return (t.ok && p->v_leak == 0.0f && p->v_reset == 0.0f) ? 1 : 0;
 }
 
+int snn_debug_last_conv_path(void) { return g_last_conv_sparse; }
+
 int snn_debug_tile_shape(int conv, long long units, int n_cols, int num_steps, int spike_rates, int layer, int32_t* out) {
     if (!out || units <= 0 || n_cols <= 0 || num_steps < 1 || num_steps > SNN_MAX_STEPS) return fail(-1, "snn_debug_tile_shape: bad argument");
     snn_params p;
@@ -997,8 +1000,7 @@ static int conv3x3_lif_sparse(const Gemm3Args& a, int C_in, void* side, size_t s
     memcpy(sa.w_nd, sp.w_nd, 8); memcpy(sa.w_ns, sp.w_ns, 8);
     sa.p = a.p;
     memcpy(sa.lv, a.lv, sizeof(sa.lv));
-    if (sa.n_blocks % 2 || 8 % (sa.n_blocks / (sa.n_blocks / 2)) ) return 0;
-    sa.xcd_cpx = sa.n_blocks >= 4 ? sa.n_blocks / 2 : 1;                    // column blocks per XCD
+    sa.xcd_cpx = (sa.n_blocks >= 4 && sa.n_blocks % 2 == 0) ? sa.n_blocks / 2 : 1;     // column blocks per XCD
     const int groups = sa.n_blocks / sa.xcd_cpx;                             // XCD groups along N (2)
     if (8 % groups) return 0;
     sa.xcd_contig = cdiv(n_tiles, 8 / groups);
@@ -1063,6 +1065,7 @@ static int conv3x3_lif_bf16x3_impl(const uint32_t* enc, size_t enc_stride, const
     const uint32_t* flag = nullptr;
     rc = conv3x3_lif_sparse(a, C_in, sparse_side, sparse_bytes, &flag, (hipStream_t)s);
     if (rc < 0) return rc;
+    g_last_conv_sparse = rc;
     if (rc == 1) a.run_if = flag;
     return launch_gemm3(G3_CONV_LIF_TILE, tl.mt, wn, a, (hipStream_t)s);
 }

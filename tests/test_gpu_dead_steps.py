@@ -11,6 +11,9 @@ pytestmark = pytest.mark.gpu
 
 
 def _keep_vs_default(monkeypatch, fn):
+    # (SNN_DEAD_STEPS=keep runs the all-dense conv launch; the default would put the sparse period planes on the structured-sparse
+    # instruction - another fp32 summation order, tests/test_gpu_sparse.py.  The statement here is about the dense kernels' windows.)
+    monkeypatch.setenv("SNN_SPARSE", "0")
     monkeypatch.setenv("SNN_DEAD_STEPS", "keep")
     keep = fn()
     monkeypatch.delenv("SNN_DEAD_STEPS")

@@ -1005,7 +1005,9 @@ static int conv3x3_lif_sparse(const Gemm3Args& a, int C_in, void* side, size_t s
     if (8 % groups) return 0;
     sa.xcd_contig = cdiv(n_tiles, 8 / groups);
     const int grid = sa.xcd_contig * sa.xcd_cpx * 8;
-    const int lds = max((int)SP_LDS, (int)SP_EPI_BYTES(a.Tc * sp.pb, fix_cap));
+    sa.fx_off = max((int)SP_LDS, a.Tc * sp.pb * SP_PITCH * 4);
+    const int lds = sa.fx_off + 2 * fix_cap * 4;
+    if (fix_cap > 1024 || lds > 80 * 1024) return 0;
     hipError_t e = hipFuncSetAttribute((const void*)k_conv_lif_sparse, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return fail(-3, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
     if (knobs().debug_occ) {

@@ -49,6 +49,7 @@ struct SparseConvArgs {
     unsigned int Pe;             // padded rows of a word plane
     int M, Kc, Np, Cw, n_blocks, n_tiles, n_levels;
     int T, Tc, nd, pb, q, fix_cap, out_split;
+    int fx_off;                  // LDS byte offset of the tile's sorted fix-up list (behind the ring and behind the epilogue's tile image)
     signed char mt_plane[8][SP_MT];      // plane of the wave's M-tile slot (-1: unused); dense planes (< nd) first
     unsigned char mt_j[8][SP_MT];        // position block of the slot: local positions 16 j ..
     unsigned char w_nd[8], w_ns[8];      // dense / sparse M-tiles of the wave
@@ -169,6 +170,10 @@ __device__ __forceinline__ void sp_lif_fixed(const float* src, const int group_s
 
 __global__ __launch_bounds__(512, 4) void k_conv_lif_sparse(const SparseConvArgs args) {
     if (*args.flag != 0u) return;                            // a fix-up list overflowed: the dense launch behind this one does the work
+#ifdef SNN_EXP_TIMELINE     // diagnostic build: wall-clock stamps (s_memrealtime, 100 MHz) of the work-group's phases
+    unsigned long long tl_entry = 0, tl_loop0 = 0, tl_loop1 = 0, tl_epi = 0;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_entry) :: "memory");
+#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
     unsigned char* const lut = smem;
@@ -194,6 +199,13 @@ __global__ __launch_bounds__(512, 4) void k_conv_lif_sparse(const SparseConvArgs
         *reinterpret_cast<uint4*>(lut + tid * 16) = q;
     }
     const int nd_w = __builtin_amdgcn_readfirstlane((int)args.w_nd[wave]), ns_w = __builtin_amdgcn_readfirstlane((int)args.w_ns[wave]);
+    // the tile's fix-up list: requested now, sorted in LDS while the first step's operands are on their way (consumed in the epilogue)
+    const int n_fix = min((int)args.fix_cnt[mb], args.fix_cap);
+    uint32_t* const fx = reinterpret_cast<uint32_t*>(smem + args.fx_off);       // sorted entries, then the unsorted copy
+    uint32_t fx_mine[2] = {0xffffffffu, 0xffffffffu};                            // (fix_cap <= 1024: at most two entries per thread)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+        if (tid + 512 * i < n_fix) fx_mine[i] = args.fix[(size_t)mb * args.fix_cap + tid + 512 * i];
 
     // ---- A staging: lane L of the wave stages physical row 64 wave + L = slot L >> 4, row L & 15 of that M-tile
     const int xs = lane >> 4;
@@ -276,11 +288,28 @@ __global__ __launch_bounds__(512, 4) void k_conv_lif_sparse(const SparseConvArgs
 
     const int n_steps = Kc / 2;
     stage_a(0); stage_b(0);
+    if (n_fix > 0) {                                           // block-uniform
+        uint32_t* const raw = fx + args.fix_cap;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            if (tid + 512 * i < n_fix) raw[tid + 512 * i] = fx_mine[i];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            if (tid + 512 * i < n_fix) {
+                int rank = 0;
+                for (int j = 0; j < n_fix; ++j) rank += raw[j] < fx_mine[i];      // keys are distinct
+                fx[rank] = fx_mine[i];
+            }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
+#ifdef SNN_EXP_TIMELINE
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_loop0) :: "memory");
+#endif
     auto step_loop = [&](auto nd_c, auto ns_c) __attribute__((always_inline)) {
         constexpr int ND = decltype(nd_c)::value, NS = decltype(ns_c)::value;
         for (int s = 0; s < n_steps; ++s) {
@@ -343,24 +372,14 @@ __global__ __launch_bounds__(512, 4) void k_conv_lif_sparse(const SparseConvArgs
     }
 #undef SP_CASE
 
+#ifdef SNN_EXP_TIMELINE
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_loop1) :: "memory");
+#endif
     // ---- epilogue: currents -> LDS tile image (two passes of 32 columns), fix-ups, LIF over the T steps, spike words out
     const int T = args.T, Tc = args.Tc;
     float* const tile = reinterpret_cast<float*>(smem);
     const int rows_l = Tc * pb;
-    uint32_t* const fx = reinterpret_cast<uint32_t*>(smem + (size_t)rows_l * SP_PITCH * 4);      // sorted entries, then the unsorted copy
-    const int n_fix = min((int)args.fix_cnt[mb], args.fix_cap);
     __syncthreads();                                           // ring reads done
-    if (n_fix > 0) {                                           // block-uniform
-        uint32_t* const raw = fx + args.fix_cap;
-        for (int i = tid; i < n_fix; i += 512) raw[i] = args.fix[(size_t)mb * args.fix_cap + i];
-        __syncthreads();
-        for (int i = tid; i < n_fix; i += 512) {
-            const uint32_t key = raw[i];
-            int rank = 0;
-            for (int j = 0; j < n_fix; ++j) rank += raw[j] < key;       // keys are distinct
-            fx[rank] = key;
-        }
-    }
     const int group_stride = pb * SP_PITCH;
 #pragma unroll 1
     for (int h = 0; h < 2; ++h) {
@@ -378,20 +397,36 @@ __global__ __launch_bounds__(512, 4) void k_conv_lif_sparse(const SparseConvArgs
         }
         __syncthreads();
         if (n_fix > 0) {
-            // entries of one row form a run of the sorted list; the half-wave that owns a run's first entry adds the whole run, in k order
+            // entries of one row form a run of the sorted list; the half-wave that owns a run's first entry adds the whole run, in k
+            // order.  The weight values of FB entries per half-wave are requested together (one memory latency per batch, not per entry).
+            constexpr int FB = 4;
             const int hw = tid >> 5, c32 = tid & 31;
             const int col = nb * 64 + h * 32 + c32;
-            for (int e = hw; e < n_fix; e += 16) {
-                const uint32_t row = fx[e] >> 12;
-                if (e > 0 && (fx[e - 1] >> 12) == row) continue;
-                float v = tile[row * SP_PITCH + c32];
-                for (int f = e; f < n_fix && (fx[f] >> 12) == row; ++f) {
-                    const uint32_t k = fx[f] & 0xfffu;
+            auto w_of = [&](const uint32_t k) __attribute__((always_inline)) {
+                const size_t wi = ((size_t)(k >> 5) * Np + col) * 32 + (k & 31);
+                return __fadd_rn(__fadd_rn(bf2f(args.wpk[2 * args.plane_elems + wi]), bf2f(args.wpk[args.plane_elems + wi])), bf2f(args.wpk[wi]));
+            };
+            for (int e0 = hw; e0 < n_fix; e0 += 16 * FB) {
+                uint32_t key[FB];
+                bool start[FB];
+                uint16_t w_hi[FB], w_mid[FB], w_lo[FB];
+#pragma unroll
+                for (int b = 0; b < FB; ++b) {
+                    const int e = e0 + 16 * b;
+                    key[b] = e < n_fix ? fx[e] : 0u;
+                    start[b] = e < n_fix && (e == 0 || (fx[e - 1] >> 12) != (key[b] >> 12));
+                    const uint32_t k = key[b] & 0xfffu;
                     const size_t wi = ((size_t)(k >> 5) * Np + col) * 32 + (k & 31);
-                    const float w = __fadd_rn(__fadd_rn(bf2f(args.wpk[2 * args.plane_elems + wi]), bf2f(args.wpk[args.plane_elems + wi])), bf2f(args.wpk[wi]));
-                    v = __fadd_rn(v, w);
+                    w_hi[b] = args.wpk[wi]; w_mid[b] = args.wpk[args.plane_elems + wi]; w_lo[b] = args.wpk[2 * args.plane_elems + wi];
                 }
-                tile[row * SP_PITCH + c32] = v;
+#pragma unroll
+                for (int b = 0; b < FB; ++b) {
+                    if (!start[b]) continue;
+                    const uint32_t row = key[b] >> 12;
+                    float v = __fadd_rn(tile[row * SP_PITCH + c32], __fadd_rn(__fadd_rn(bf2f(w_lo[b]), bf2f(w_mid[b])), bf2f(w_hi[b])));
+                    for (int f = e0 + 16 * b + 1; f < n_fix && (fx[f] >> 12) == row; ++f) v = __fadd_rn(v, w_of(fx[f] & 0xfffu));
+                    tile[row * SP_PITCH + c32] = v;
+                }
             }
             __syncthreads();
         }
@@ -422,5 +457,19 @@ __global__ __launch_bounds__(512, 4) void k_conv_lif_sparse(const SparseConvArgs
                 }
             }
         }
+#ifdef SNN_EXP_TIMELINE
+        if (h == 0) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_epi) :: "memory");
+#endif
     }
+#ifdef SNN_EXP_TIMELINE
+    if (tid == 0) {
+        unsigned long long tl_exit;
+        uint32_t hw, xcc;
+        asm volatile("s_memrealtime %0\n\ts_getreg_b32 %1, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %2, hwreg(HW_REG_XCC_ID)\n\ts_waitcnt lgkmcnt(0)"
+                     : "=s"(tl_exit), "=s"(hw), "=s"(xcc) :: "memory");
+        // (behind the overflow flag = behind everything the head needs of its workspace: tools/sparse_timeline.py allocates more)
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(const_cast<uint32_t*>(args.flag) + 64) + (size_t)blockIdx.x * 8;
+        o[0] = tl_entry; o[1] = tl_loop0; o[2] = tl_loop1; o[3] = tl_epi; o[4] = tl_exit; o[5] = hw; o[6] = xcc; o[7] = 1;
+    }
+#endif
 }

@@ -1,0 +1,48 @@
+"""Per-work-group timeline of k_conv_lif_sparse (a -DSNN_EXP_TIMELINE build: bash tools/ab_build.sh TL:"-DSNN_EXP_TIMELINE", then on the
+GPU box SNN_HIP_LIB=tools/_ab/lib_TL.so python tools/sparse_timeline.py): s_memrealtime stamps at entry / K-loop start / K-loop end /
+end of the first epilogue pass / exit.  Run on the bench's own pyramid."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch                                                     # noqa: E402
+import bench                                                     # noqa: E402
+import snn_automotive_object_detection_amd as S                  # noqa: E402
+from snn_automotive_object_detection_amd import _lib, ops        # noqa: E402
+
+dev = torch.device("cuda:0")
+wl = dict(bench.WORKLOADS["cityscapes"])
+torch.manual_seed(4321)
+model = S.create_model(wl["dataset"], wl["K"], True, True, 0, False, False, 8, 12).to(dev).eval()
+leg = bench.Leg(wl, "bf16x3", dev, 1000, "backbone", model)
+del model
+lib = _lib.load()
+T, C, A = wl["T_rpn"], bench.C, bench.A
+P = sum(f.shape[0] * f.shape[2] * f.shape[3] for f in leg.feats)
+lv = (_lib.snn_rpn_level * len(leg.feats))(*[_lib.snn_rpn_level(f.data_ptr(), f.shape[0], f.shape[2], f.shape[3], 0) for f in leg.feats])
+p = leg.rpn_head._params()
+ws_bytes = lib.snn_rpn_head_workspace_bytes(lv, len(leg.feats), C, A, T, p.precision)
+n_wg = 4 * ((P + 63) // 64) + 64
+ws = ops._WS.get(dev, ws_bytes + n_wg * 64 + (64 << 20))
+off = ws_bytes                                                  # the stamps land behind everything the head needs of its workspace
+w_sh, w_hd = leg.rpn_head._packed_shared(), None
+leg.rpn_head(leg.feats)
+w_hd = leg.rpn_head._cache_heads.val
+for _ in range(5):
+    ops.rpn_head_forward(leg.feats, C, A, T, p, w_sh, w_hd, stage_mask=2)
+torch.cuda.synchronize()
+assert lib.snn_debug_last_conv_path() == 1
+raw = ws[off: off + n_wg * 64].view(torch.int64).view(-1, 8).cpu()
+raw = raw[raw[:, 7] == 1]
+t = raw[:, :5].double() / 100.0                                  # us
+t0 = float(t[:, 0].min())
+print("work-groups stamped: %d; launch span %.1f us" % (raw.shape[0], float(t[:, 4].max()) - t0))
+print("mean us per work-group: before K loop %.2f | K loop %.2f | epilogue pass 0 %.2f | epilogue pass 1 %.2f | whole %.2f" % (
+    float((t[:, 1] - t[:, 0]).mean()), float((t[:, 2] - t[:, 1]).mean()), float((t[:, 3] - t[:, 2]).mean()), float((t[:, 4] - t[:, 3]).mean()),
+    float((t[:, 4] - t[:, 0]).mean())))
+cu = (raw[:, 6] << 16) | (raw[:, 5] & 0x0000ff00) | ((raw[:, 5] >> 13) & 0x7)        # xcc | cu_id / sh / se bits
+ids, counts = torch.unique(cu, return_counts=True)
+print("distinct (XCC, CU) slots seen: %d; work-groups per slot: min %d max %d" % (ids.numel(), int(counts.min()), int(counts.max())))
+busy = float((t[:, 4] - t[:, 0]).sum()) / 512.0
+print("sum of work-group lifetimes / 512 slots = %.1f us (= the span if every slot were always occupied)" % busy)

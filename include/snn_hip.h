@@ -98,6 +98,7 @@ int snn_debug_tile_shape(int conv, long long units, int n_cols, int num_steps, i
  * (csrc/snn_sparse.h: planes e_3 .. on v_smfmac, the dense launch behind it as the device-side fallback), 0 if it took the dense
  * launch only (SNN_SPARSE=0, spike-rate mode, T outside 5 .. 16, channel counts that are not multiples of 64, ...). */
 int snn_debug_last_conv_path(void);
+int snn_debug_last_fc6_path(void);      /* the same for the detector head's fc6 + LIF */
 
 /* ---- weight packing (call when the weights change; results are plain device buffers) ---------- */
 /* number of floats of a packed GEMM operand with K reduction rows and N output columns */

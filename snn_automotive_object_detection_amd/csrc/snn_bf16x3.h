@@ -225,7 +225,7 @@ template <int MODE, int NB, int MT, int WN>
 __device__ __forceinline__ void gemm_bf16x3_body(const Gemm3Args& args, const int bid, const Gemm3Dep dep) {
     constexpr bool CONV = MODE == G3_CONV || MODE == G3_CONV_LIF_REG || MODE == G3_CONV_LIF_TILE;
     constexpr bool FUSE = MODE == G3_CONV_LIF_REG, TILE = MODE == G3_CONV_LIF_TILE || MODE == G3_FC_LIF_TILE;
-    if (MODE == G3_CONV_LIF_TILE && args.run_if != nullptr && *args.run_if == 0u) return;
+    if (TILE && args.run_if != nullptr && *args.run_if == 0u) return;
     static_assert(((MT >= 2 && MT <= 4) || MT == 8) && (MT == 4 || !FUSE), "M-tiles per wave");
     static_assert(WN == 1 || (WN == 2 && true), "waves along N");
     static_assert(WN == 2 || !FUSE, "the register-fused variant keeps the 4 x 2 wave grid");

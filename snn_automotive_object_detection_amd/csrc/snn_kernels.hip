@@ -27,6 +27,7 @@
 // error plumbing (thread-local; no exceptions, no abort)
 // ------------------------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
+static thread_local int g_last_fc_sparse = 0;      // ... the detector's fc6 + LIF
 static thread_local int g_last_conv_sparse = 0;    // did this thread's last RPN conv + LIF enqueue the sparse launch pair (snn_debug_last_conv_path)
 
 static int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
@@ -679,6 +680,7 @@ int snn_debug_encoder_thresholds(const snn_params* p, float* th32) {
 }
 
 int snn_debug_last_conv_path(void) { return g_last_conv_sparse; }
+int snn_debug_last_fc6_path(void) { return g_last_fc_sparse; }
 
 int snn_debug_tile_shape(int conv, long long units, int n_cols, int num_steps, int spike_rates, int layer, int32_t* out) {
     if (!out || units <= 0 || n_cols <= 0 || num_steps < 1 || num_steps > SNN_MAX_STEPS) return fail(-1, "snn_debug_tile_shape: bad argument");
@@ -928,7 +930,7 @@ static int conv3_common(const char* who, const uint32_t* enc, size_t enc_stride,
 static int count_spikes_per_image(const snn_rpn_level* lv, int n_levels, int Cw, int T, const uint32_t* spk, size_t stride,
                                   unsigned long long* counts, int max_n, hipStream_t s);
 
-static size_t rpn_sparse_bytes(long long P, long long Pe, int C, int T);
+static size_t sparse_side_bytes(long long P, long long Pe, int Kw, int T);
 // ---- structured-sparse conv (snn_sparse.h): tile geometry + wave assignment ----
 struct SparsePlan { int q, pb, nd; signed char plane[8][SP_MT]; unsigned char j[8][SP_MT], w_nd[8], w_ns[8]; };
 static bool sparse_plan(int Tc, SparsePlan* sp) {
@@ -962,63 +964,72 @@ static bool sparse_plan(int Tc, SparsePlan* sp) {
     return true;
 }
 
-// the sparse launch pair: compress the planes e_3 .., then the mixed dense / sparse conv + LIF.  `side` = rpn_sparse_bytes() of scratch.
+// the sparse launch pair: compress the planes e_3 .., then the mixed dense / sparse contraction + LIF (conv: the RPN's shared 3x3
+// convolution; !conv: a linear layer on word-major period planes - the detector's fc6).  `side` = sparse_side_bytes() of scratch.
 // Returns 1 if the launches were enqueued (the caller then enqueues the dense launch with Gemm3Args.run_if = *flag_out), 0 if this
 // configuration takes the dense path only, negative on error.
-static int conv3x3_lif_sparse(const Gemm3Args& a, int C_in, void* side, size_t side_bytes, const uint32_t** flag_out, hipStream_t s) {
+static int gemm3_lif_sparse(const Gemm3Args& a, bool conv, void* side, size_t side_bytes, const uint32_t** flag_out, hipStream_t s) {
     SparsePlan sp;
-    if (!knobs().sparse || !side || !a.wm || !a.periods || a.cnt_img || a.Cw % 2 || a.Np % 64 || a.Kc * 32 > 4096 || a.T < 5 || a.T > 16 ||
-        a.Tc != a.T - 1 || a.t0 != 0 || a.p.v_leak != 0.0f || (float)(a.p.v_leak - a.p.v_th) > 0.0f || !sparse_plan(a.Tc, &sp))
+    const int Kw = conv ? a.Cw : a.Kc;                        // plane words per row
+    if (!knobs().sparse || !side || !a.wm || !a.periods || a.cnt_img || a.cnt_row || Kw % 2 || a.Np % 64 || a.Kc * 32 > 65536 || a.T < 5 || a.T > 16 ||
+        a.Tc != a.T - (conv ? 1 : 2) || a.t0 != 0 || a.p.v_leak != 0.0f || (float)(a.p.v_leak - a.p.v_th) > 0.0f || (!conv && !a.out_wm) ||
+        !sparse_plan(a.Tc, &sp))
         return 0;
     const long long P = a.M, Pe = (long long)a.a_step;
-    if (side_bytes < rpn_sparse_bytes(P, Pe, C_in, a.T)) return 0;
+    if (side_bytes < sparse_side_bytes(P, Pe, Kw, a.T)) return 0;
     char* w = (char*)side;
     uint32_t* cmp = (uint32_t*)w;
-    w += align_up((size_t)a.T * (a.Cw / 2) * 3 * (size_t)Pe * 4, 256);
+    w += align_up((size_t)a.T * (Kw / 2) * 3 * (size_t)Pe * 4, 256);
     uint32_t* fix = (uint32_t*)w;
     w += align_up((size_t)SP_FIX_PER_POS * P * 4 + 4096 * SP_FIX_PER_POS, 256);
     uint32_t* fix_cnt = (uint32_t*)w;
     w += align_up(((size_t)P / 16 + 8) * 4, 256);
     uint32_t* flag = (uint32_t*)w;
-    if ((unsigned long long)((const char*)cmp - (const char*)a.A) + (unsigned long long)a.T * (a.Cw / 2) * 3 * Pe * 4 > 0xffffffffULL) return 0;
+    if ((const char*)cmp < (const char*)a.A ||
+        (unsigned long long)((const char*)cmp - (const char*)a.A) + (unsigned long long)a.T * (Kw / 2) * 3 * Pe * 4 > 0xffffffffULL) return 0;
     const int n_tiles = cdiv(P, sp.pb), fix_cap = SP_FIX_PER_POS * sp.pb;
     if (hipMemsetAsync(fix_cnt, 0, align_up(((size_t)P / 16 + 8) * 4, 256) + 256, s) != hipSuccess) return fail(-3, "hipMemsetAsync failed");
     CompressArgs ca;
     memset(&ca, 0, sizeof(ca));
-    ca.enc = a.A; ca.cmp = cmp; ca.fix = fix; ca.fix_cnt = fix_cnt; ca.flag = flag; ca.Pe = (unsigned)Pe; ca.Cw = a.Cw; ca.Tc = a.Tc; ca.nd = sp.nd;
+    ca.enc = a.A; ca.cmp = cmp; ca.fix = fix; ca.fix_cnt = fix_cnt; ca.flag = flag; ca.Pe = (unsigned)Pe; ca.Cw = Kw; ca.Tc = a.Tc; ca.nd = sp.nd;
     ca.pb = sp.pb; ca.fix_cap = fix_cap; ca.Cp = a.Cw * 32; ca.n_levels = a.n_levels;
     memcpy(ca.lv, a.lv, sizeof(ca.lv));
-    hipLaunchKernelGGL(k_compress_planes, dim3(cdiv(Pe, 256), a.Cw / 2, a.Tc - sp.nd), dim3(256), 0, s, ca);
+    if (conv) hipLaunchKernelGGL(k_compress_planes<true>, dim3(cdiv(Pe, 256), Kw / 2, a.Tc - sp.nd), dim3(256), 0, s, ca);
+    else hipLaunchKernelGGL(k_compress_planes<false>, dim3(cdiv(Pe, 256), Kw / 2, a.Tc - sp.nd), dim3(256), 0, s, ca);
     SNN_CHECK_LAUNCH("k_compress_planes");
     SparseConvArgs sa;
     memset(&sa, 0, sizeof(sa));
     sa.enc = a.A; sa.cmp = cmp; sa.wpk = a.wpk; sa.spk = a.spk; sa.fix = fix; sa.fix_cnt = fix_cnt; sa.flag = flag;
     sa.plane_elems = a.plane_elems; sa.spk_stride = a.spk_stride; sa.Pe = (unsigned)Pe;
-    sa.M = a.M; sa.Kc = a.Kc; sa.Np = a.Np; sa.Cw = a.Cw; sa.n_blocks = a.Np / 64; sa.n_tiles = n_tiles; sa.n_levels = a.n_levels;
+    sa.M = a.M; sa.Kc = a.Kc; sa.Np = a.Np; sa.Cw = Kw; sa.n_blocks = a.Np / 64; sa.n_tiles = n_tiles; sa.n_levels = a.n_levels;
     sa.T = a.T; sa.Tc = a.Tc; sa.nd = sp.nd; sa.pb = sp.pb; sa.q = sp.q; sa.fix_cap = fix_cap; sa.out_split = a.out_split;
     memcpy(sa.mt_plane, sp.plane, sizeof(sa.mt_plane)); memcpy(sa.mt_j, sp.j, sizeof(sa.mt_j));
     memcpy(sa.w_nd, sp.w_nd, 8); memcpy(sa.w_ns, sp.w_ns, 8);
     sa.p = a.p;
     memcpy(sa.lv, a.lv, sizeof(sa.lv));
-    sa.xcd_cpx = (sa.n_blocks >= 4 && sa.n_blocks % 2 == 0) ? sa.n_blocks / 2 : 1;     // column blocks per XCD
-    const int groups = sa.n_blocks / sa.xcd_cpx;                             // XCD groups along N (2)
-    if (8 % groups) return 0;
-    sa.xcd_contig = cdiv(n_tiles, 8 / groups);
-    const int grid = sa.xcd_contig * sa.xcd_cpx * 8;
+    int grid = n_tiles * sa.n_blocks;                        // linear layers: plain order
+    if (conv) {
+        sa.xcd_cpx = (sa.n_blocks >= 4 && sa.n_blocks % 2 == 0) ? sa.n_blocks / 2 : 1;     // column blocks per XCD
+        const int groups = sa.n_blocks / sa.xcd_cpx;                             // XCD groups along N (2)
+        if (8 % groups) return 0;
+        sa.xcd_contig = cdiv(n_tiles, 8 / groups);
+        grid = sa.xcd_contig * sa.xcd_cpx * 8;
+    }
     sa.fx_off = max((int)SP_LDS, a.Tc * sp.pb * SP_PITCH * 4);
     const int lds = sa.fx_off + 2 * fix_cap * 4;
     if (fix_cap > 1024 || lds > 80 * 1024) return 0;
-    hipError_t e = hipFuncSetAttribute((const void*)k_conv_lif_sparse, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    const void* kern = conv ? (const void*)k_gemm_lif_sparse<true> : (const void*)k_gemm_lif_sparse<false>;
+    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return fail(-3, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
     if (knobs().debug_occ) {
         int v = 0;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, (const void*)k_conv_lif_sparse, 512, lds);
-        fprintf(stderr, "k_conv_lif_sparse: pb %d x Tc %d, q %d, lds %d B, %d work-groups per CU, grid %d\n", sp.pb, a.Tc, sp.q, lds, v, grid);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, kern, 512, lds);
+        fprintf(stderr, "k_gemm_lif_sparse<%d>: pb %d x Tc %d, q %d, lds %d B, %d work-groups per CU, grid %d\n", (int)conv, sp.pb, a.Tc, sp.q, lds, v, grid);
     }
     void* kargs[] = {(void*)&sa};
-    e = hipLaunchKernel((const void*)k_conv_lif_sparse, dim3(grid), dim3(512), kargs, lds, s);
-    if (e != hipSuccess) return fail(-3, "k_conv_lif_sparse launch failed: %s", hipGetErrorString(e));
-    SNN_CHECK_LAUNCH("k_conv_lif_sparse");
+    e = hipLaunchKernel(kern, dim3(grid), dim3(512), kargs, lds, s);
+    if (e != hipSuccess) return fail(-3, "k_gemm_lif_sparse launch failed: %s", hipGetErrorString(e));
+    SNN_CHECK_LAUNCH("k_gemm_lif_sparse");
     *flag_out = flag;
     return 1;
 }
@@ -1065,7 +1076,7 @@ static int conv3x3_lif_bf16x3_impl(const uint32_t* enc, size_t enc_stride, const
     // round 4: the sparse period planes on the structured-sparse matrix-core instruction (snn_sparse.h); the dense launch stays behind
     // it as the fallback for inputs whose fix-up lists overflow (it leaves at once otherwise)
     const uint32_t* flag = nullptr;
-    rc = conv3x3_lif_sparse(a, C_in, sparse_side, sparse_bytes, &flag, (hipStream_t)s);
+    rc = gemm3_lif_sparse(a, true, sparse_side, sparse_bytes, &flag, (hipStream_t)s);
     if (rc < 0) return rc;
     g_last_conv_sparse = rc;
     if (rc == 1) a.run_if = flag;
@@ -1459,10 +1470,11 @@ static long long rpn_positions_padded(const snn_rpn_level* lv, int n_levels) {
 // Pe = rows of an encoder plane (positions; with the zero halo for the mxfp6 path)
 // bytes behind the two plane sets for the structured-sparse conv (snn_sparse.h): compressed planes (3 dwords per row and 64 k, at most
 // all T planes), fix-up lists (SP_FIX_PER_POS entries per position), per-tile counters + the overflow flag
-static size_t rpn_sparse_bytes(long long P, long long Pe, int C, int T) {
-    return align_up((size_t)T * cdiv(C, 64) * 3 * (size_t)Pe * 4, 256) + align_up((size_t)SP_FIX_PER_POS * P * 4 + 4096 * SP_FIX_PER_POS, 256) +
+static size_t sparse_side_bytes(long long P, long long Pe, int Kw, int T) {     // Kw = 32-bit words per row of a plane
+    return align_up((size_t)T * cdiv(Kw, 2) * 3 * (size_t)Pe * 4, 256) + align_up((size_t)SP_FIX_PER_POS * P * 4 + 4096 * SP_FIX_PER_POS, 256) +
            align_up(((size_t)P / 16 + 8) * 4, 256) + 256;
 }
+static size_t rpn_sparse_bytes(long long P, long long Pe, int C, int T) { return sparse_side_bytes(P, Pe, cdiv(C, 32), T); }
 static void rpn_ws_layout(long long P, long long Pe, int C, int T, int precision, size_t* o_spk, size_t* o_cur, size_t* o_cnt,
                           size_t* total) {
     const size_t plane = align_up((size_t)T * (Pe > P ? Pe : P) * cdiv(C, 32) * 4, 256);
@@ -1904,6 +1916,14 @@ static int det_head_from_planes(int R, int D, int Hd, int K, int K4, int T, cons
         if ((rc = spike_gemm_lif_bf16x3_args(enc, T, R, D, Hd, p, (const uint16_t*)w6_packed, s6, (size_t)R * Hw, spk6_count, enc_wm, enc_wm, &win.fc6, enc_periods, &a6, &t6))) return rc;
         if ((rc = spike_gemm_lif_bf16x3_args(s6, T, R, Hd, Hd, p, (const uint16_t*)w7_packed, s7, (size_t)R * Hw, spk7_count, enc_wm, false, &win.fc7, false, &a7, &t7))) return rc;
         const int wn = g3_wn();
+        // round 4: fc6's sparse period planes e_3 .. on the structured-sparse matrix-core instruction (snn_sparse.h); its side buffers
+        // live in the currents region of the workspace, which the fused layers never write; the dense fc6 launch stays behind it as
+        // the device-side fallback (Gemm3Args.run_if)
+        const uint32_t* flag6 = nullptr;
+        rc = knobs().det_pair ? 0 : gemm3_lif_sparse(a6, false, (char*)ws + o_cur, o_s6 - o_cur, &flag6, s);
+        if (rc < 0) return rc;
+        g_last_fc_sparse = rc;
+        if (rc == 1) a6.run_if = flag6;
         const int n_sync = cdiv(R, a6.pb) + 1;
         if (knobs().det_pair && gemm3_pair_ok(t6.mt, t7.mt, wn, a6) && (size_t)n_sync * 4 <= DET_SYNC_BYTES) {
             uint32_t* sync = (uint32_t*)((char*)ws + o_sync);

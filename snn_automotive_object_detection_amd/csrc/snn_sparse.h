@@ -42,7 +42,7 @@ struct SparseConvArgs {
     const uint32_t* cmp;         // compressed planes [Tc - nd][Cw / 2][3][Pe]
     const uint16_t* wpk;         // [3][Kc][Np][32] bf16
     uint32_t* spk;               // spike planes out
-    const uint32_t* fix;         // [n_tiles][fix_cap] entries (row << 12 | k), fix_cnt[n_tiles]
+    const uint32_t* fix;         // [n_tiles][fix_cap] entries (row << 16 | k), fix_cnt[n_tiles]
     const uint32_t* fix_cnt;
     const uint32_t* flag;        // != 0: a list overflowed - leave at once
     unsigned long long plane_elems, spk_stride;
@@ -88,7 +88,8 @@ struct CompressArgs {
     ConvLevelDev lv[SNN_MAX_LEVELS];
 };
 
-// thread = (padded row, 64-k step w2 = blockIdx.y, sparse plane ts = blockIdx.z)
+// thread = (row, 64-k step w2 = blockIdx.y, sparse plane ts = blockIdx.z); row = padded position (CONV) or RoI (linear layer)
+template <bool CONV>
 __global__ __launch_bounds__(256) void k_compress_planes(const CompressArgs a) {
     __shared__ uint16_t code[16];
     if (threadIdx.x < 16) code[threadIdx.x] = (uint16_t)sp_nibble_code(threadIdx.x);
@@ -110,30 +111,36 @@ __global__ __launch_bounds__(256) void k_compress_planes(const CompressArgs a) {
     uint32_t* out = a.cmp + ((size_t)ts * (a.Cw / 2) + w2) * 3 * a.Pe + row;
     out[0] = occ; out[a.Pe] = idx[0]; out[2 * (size_t)a.Pe] = idx[1];
     if ((left[0] | left[1]) == 0) return;
-    // (rare) spikes beyond two per nibble: one fix-up entry per 3x3 tap that reads this input position
-    int l = 0;
-    while (l + 1 < a.n_levels && row >= (unsigned)a.lv[l + 1].tile_begin) ++l;
-    const int H = a.lv[l].H, W = a.lv[l].W;
-    const int local = (int)row - a.lv[l].tile_begin;
-    const int n = local / ((H + 2) * (W + 2)), rem = local % ((H + 2) * (W + 2));
-    const int y = rem / (W + 2) - 1, x = rem % (W + 2) - 1;
-    if (y < 0 || y >= H || x < 0 || x >= W) return;            // (halo rows are zero: cannot happen)
+    // (rare) spikes beyond two per nibble become fix-up entries of the output tile(s) they belong to
+    auto push = [&](const int p, const uint32_t k) __attribute__((always_inline)) {
+        const int tile = p / a.pb, lp = p % a.pb;
+        const uint32_t entry = ((uint32_t)(t * a.pb + lp) << 16) | k;
+        const uint32_t slot = atomicAdd(a.fix_cnt + tile, 1u);
+        if (slot < (uint32_t)a.fix_cap) a.fix[(size_t)tile * a.fix_cap + slot] = entry;
+        else atomicOr(a.flag, 1u);
+    };
+    int l = 0, H = 0, W = 0, n = 0, y = 0, x = 0;
+    if (CONV) {                                               // one entry per 3x3 tap that reads this input position
+        while (l + 1 < a.n_levels && row >= (unsigned)a.lv[l + 1].tile_begin) ++l;
+        H = a.lv[l].H; W = a.lv[l].W;
+        const int local = (int)row - a.lv[l].tile_begin;
+        n = local / ((H + 2) * (W + 2));
+        const int rem = local % ((H + 2) * (W + 2));
+        y = rem / (W + 2) - 1; x = rem % (W + 2) - 1;
+        if (y < 0 || y >= H || x < 0 || x >= W) return;        // (halo rows are zero: cannot happen)
+    }
     for (int h = 0; h < 2; ++h) {
         uint32_t m = left[h];
         while (m) {
             const int b = __builtin_ctz(m);
             m &= m - 1;
             const int c = (2 * w2 + h) * 32 + b;
+            if (!CONV) { push((int)row, (uint32_t)c); continue; }
             for (int ky = 0; ky < 3; ++ky)
                 for (int kx = 0; kx < 3; ++kx) {
                     const int oy = y - (ky - 1), ox = x - (kx - 1);
                     if (oy < 0 || oy >= H || ox < 0 || ox >= W) continue;
-                    const int p = a.lv[l].pos_base + (n * H + oy) * W + ox;
-                    const int tile = p / a.pb, lp = p % a.pb;
-                    const uint32_t entry = ((uint32_t)(t * a.pb + lp) << 12) | (uint32_t)((ky * 3 + kx) * a.Cp + c);
-                    const uint32_t slot = atomicAdd(a.fix_cnt + tile, 1u);
-                    if (slot < (uint32_t)a.fix_cap) a.fix[(size_t)tile * a.fix_cap + slot] = entry;
-                    else atomicOr(a.flag, 1u);
+                    push(a.lv[l].pos_base + (n * H + oy) * W + ox, (uint32_t)((ky * 3 + kx) * a.Cp + c));
                 }
         }
     }
@@ -141,9 +148,9 @@ __global__ __launch_bounds__(256) void k_compress_planes(const CompressArgs a) {
 
 // LIF over T steps of one neuron from the period sums in the LDS tile image: the straight-line form of k_gemm_bf16x3's epilogue
 // (period planes, v_leak = 0, no spike at step 0, conv window T - 1), same operations in the same order
-template <int TS>
+template <int TS, int D>
 __device__ __forceinline__ void sp_lif_fixed(const float* src, const int group_stride, const NeuronP& p, uint32_t& my0, uint32_t& my1) {
-    constexpr int TCS = TS - 1;
+    constexpr int TCS = TS - D;                          // currents of steps 0 .. T - 1 - D (conv: D = 1; fc6: D = 2 - dead time steps)
     float ug[TCS];
 #pragma unroll
     for (int g = 0; g < TCS; ++g) ug[g] = src[(size_t)g * group_stride];
@@ -168,7 +175,8 @@ __device__ __forceinline__ void sp_lif_fixed(const float* src, const int group_s
     }
 }
 
-__global__ __launch_bounds__(512, 4) void k_conv_lif_sparse(const SparseConvArgs args) {
+template <bool CONV>
+__global__ __launch_bounds__(512, 4) void k_gemm_lif_sparse(const SparseConvArgs args) {
     if (*args.flag != 0u) return;                            // a fix-up list overflowed: the dense launch behind this one does the work
 #ifdef SNN_EXP_TIMELINE     // diagnostic build: wall-clock stamps (s_memrealtime, 100 MHz) of the work-group's phases
     unsigned long long tl_entry = 0, tl_loop0 = 0, tl_loop1 = 0, tl_epi = 0;
@@ -182,8 +190,10 @@ __global__ __launch_bounds__(512, 4) void k_conv_lif_sparse(const SparseConvArgs
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, lg = lane >> 4;
     // block order: XCD x = blockIdx % 8 takes xcd_cpx column blocks on a contiguous range of row tiles (k_gemm_bf16x3: xcd_contig)
-    int nb, mb;
-    {
+    // (xcd_contig == 0 - the linear layers: plain order, column block fastest: an XCD only ever sees two weight panels, and all
+    // work-groups of a panel walk K together)
+    int nb = blockIdx.x % args.n_blocks, mb = blockIdx.x / args.n_blocks;
+    if (args.xcd_contig) {
         const int x = blockIdx.x & 7, j = blockIdx.x >> 3, cpx = args.xcd_cpx, groups = args.n_blocks / cpx;
         nb = (x % groups) * cpx + j % cpx;
         mb = (x / groups) * args.xcd_contig + j / cpx;
@@ -216,13 +226,18 @@ __global__ __launch_bounds__(512, 4) void k_conv_lif_sparse(const SparseConvArgs
     {
         const int lp = min(args.mt_j[wave][xs] * 16 + (lane & 15), pb - 1);
         const int p = min(m0 + (xused ? lp : 0), M - 1);
-        int l = 0;
-        while (l + 1 < args.n_levels && p >= args.lv[l + 1].pos_base) ++l;
-        const int H = args.lv[l].H, W = args.lv[l].W;
-        const int local = p - args.lv[l].pos_base;
-        const int n = local / (H * W), rem = local % (H * W);
-        const int y = rem / W, x = rem % W;
-        const uint32_t row0 = (uint32_t)args.lv[l].tile_begin + (uint32_t)((n * (H + 2) + y) * (W + 2) + x);      // tap (-1, -1)
+        uint32_t row0 = (uint32_t)p;                        // linear layer: the RoI
+        int W = 0;
+        if (CONV) {
+            int l = 0;
+            while (l + 1 < args.n_levels && p >= args.lv[l + 1].pos_base) ++l;
+            const int H = args.lv[l].H;
+            W = args.lv[l].W;
+            const int local = p - args.lv[l].pos_base;
+            const int n = local / (H * W), rem = local % (H * W);
+            const int y = rem / W, x = rem % W;
+            row0 = (uint32_t)args.lv[l].tile_begin + (uint32_t)((n * (H + 2) + y) * (W + 2) + x);      // tap (-1, -1)
+        }
         const uint32_t Pe = args.Pe;
         const int Cw2 = args.Cw / 2;
         if (xdense || !xused) {
@@ -252,6 +267,7 @@ __global__ __launch_bounds__(512, 4) void k_conv_lif_sparse(const SparseConvArgs
                      "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dword %2, %3"
                      :: "v"(voff0), "v"(voff1), "v"(voff2), "s"(a_base), "s"(d), "s"(d + SP_ROWS * 4), "s"(d + 2 * SP_ROWS * 4) : "memory");
         voff0 += inc; voff1 += inc; voff2 += inc;
+        if (!CONV) return;
         f_c = __builtin_amdgcn_readfirstlane(f_c + 1);
         if (f_c == cw2_s) {
             f_c = 0;
@@ -414,17 +430,17 @@ __global__ __launch_bounds__(512, 4) void k_conv_lif_sparse(const SparseConvArgs
                 for (int b = 0; b < FB; ++b) {
                     const int e = e0 + 16 * b;
                     key[b] = e < n_fix ? fx[e] : 0u;
-                    start[b] = e < n_fix && (e == 0 || (fx[e - 1] >> 12) != (key[b] >> 12));
-                    const uint32_t k = key[b] & 0xfffu;
+                    start[b] = e < n_fix && (e == 0 || (fx[e - 1]   >> 16) != (key[b]   >> 16));
+                    const uint32_t k = key[b] & 0xffffu;
                     const size_t wi = ((size_t)(k >> 5) * Np + col) * 32 + (k & 31);
                     w_hi[b] = args.wpk[wi]; w_mid[b] = args.wpk[args.plane_elems + wi]; w_lo[b] = args.wpk[2 * args.plane_elems + wi];
                 }
 #pragma unroll
                 for (int b = 0; b < FB; ++b) {
                     if (!start[b]) continue;
-                    const uint32_t row = key[b] >> 12;
+                    const uint32_t row = key[b]   >> 16;
                     float v = __fadd_rn(tile[row * SP_PITCH + c32], __fadd_rn(__fadd_rn(bf2f(w_lo[b]), bf2f(w_mid[b])), bf2f(w_hi[b])));
-                    for (int f = e0 + 16 * b + 1; f < n_fix && (fx[f] >> 12) == row; ++f) v = __fadd_rn(v, w_of(fx[f] & 0xfffu));
+                    for (int f = e0 + 16 * b + 1; f < n_fix && (fx[f]   >> 16) == row; ++f) v = __fadd_rn(v, w_of(fx[f] & 0xffffu));
                     tile[row * SP_PITCH + c32] = v;
                 }
             }
@@ -439,14 +455,18 @@ __global__ __launch_bounds__(512, 4) void k_conv_lif_sparse(const SparseConvArgs
             uint32_t my0 = 0, my1 = 0;
             const float* src = tile + (live ? pi : 2 * pp) * SP_PITCH + col;
             switch (T) {
-#define SP_T(n) case n: sp_lif_fixed<n>(src, group_stride, args.p, my0, my1); break;
+#define SP_T(n) case n: sp_lif_fixed<n, CONV ? 1 : 2>(src, group_stride, args.p, my0, my1); break;
                 SP_T(5) SP_T(6) SP_T(7) SP_T(8) SP_T(9) SP_T(10) SP_T(11) SP_T(12) SP_T(13) SP_T(14) SP_T(15) SP_T(16)
 #undef SP_T
             default: break;
             }
             const bool odd_ok = 2 * pp + 1 < pb && m0 + 2 * pp + 1 < M;
             if (lane < T) {
-                if (args.out_split) {
+                if (!CONV) {                                               // linear layer: word-major spike planes [T][word][RoI] (fc6 -> fc7)
+                    uint32_t* dst = args.spk + (size_t)lane * args.spk_stride + (size_t)word0 * M + (m0 + 2 * pp);
+                    dst[0] = my0;
+                    if (odd_ok) dst[1] = my1;
+                } else if (args.out_split) {
                     uint32_t* dst = args.spk + (size_t)lane * args.spk_stride + ((size_t)(word0 >> 2) * M + m0 + 2 * pp) * 4 + (word0 & 3);
                     dst[0] = my0;
                     if (odd_ok) dst[4] = my1;

@@ -170,6 +170,21 @@ int snn_det_head_forward(const float* x, int R, int D, int Hd, int K, int K4, in
                          uint32_t* spk6_count, uint32_t* spk7_count, float* sum_cls, float* sum_bbox,
                          void* workspace, size_t workspace_bytes, snn_stream_t stream);
 
+/* The same with fc6's weights packed in a PERMUTED reduction order (snn_pack_linear_weight_bf16x3_perm(w, N, K, inner)): w6_inner =
+ * elements per channel of the flattened input (49 for [C][7][7] RoI features), k' = s * C + c instead of k = c * inner + s; the head
+ * then transposes the encoder's planes to match.  Four consecutive k' are four channels at one bin (independent values) instead of
+ * four neighbouring bins of one channel (correlated: equal firing periods), which is what lets fc6's sparse period planes run on the
+ * structured-sparse matrix-core instruction (csrc/snn_sparse.h).  The contraction is the same sum in another order.  w6_inner = 0:
+ * snn_det_head_forward.  bf16x3 precision, D % 32 == 0, C % 32 == 0; otherwise -4. */
+int snn_pack_linear_weight_bf16x3_perm(const float* w_nk, int N, int K, int inner, uint16_t* packed, snn_stream_t s);
+int snn_det_head_forward_k(const float* x, int R, int D, int Hd, int K, int K4, int T,
+                           const snn_params* p_host,
+                           const void* w6_packed, int w6_inner, const void* w7_packed,
+                           const float* w_heads_packed,
+                           float* out_cls, float* out_bbox,
+                           uint32_t* spk6_count, uint32_t* spk7_count, float* sum_cls, float* sum_bbox,
+                           void* workspace, size_t workspace_bytes, snn_stream_t stream);
+
 /* ---- RoIAlign fused with the detector encoder (the step in front of the head, roi_heads.py:1217) --------
  * MultiScaleRoIAlign(7x7, sampling_ratio 2, aligned=False) + lif_current_encoder in one kernel: the [R,C,7,7]
  * fp32 RoI features are never materialised.  The caller assigns each RoI its FPN level (torchvision's
@@ -192,6 +207,13 @@ int snn_det_head_forward_roialign(const snn_roi_level* levels_host, int n_levels
                                   const float* w_heads_packed, float* out_cls, float* out_bbox,
                                   uint32_t* spk6_count, uint32_t* spk7_count, float* sum_cls, float* sum_bbox,
                                   void* workspace, size_t workspace_bytes, snn_stream_t stream);
+
+int snn_det_head_forward_roialign_k(const snn_roi_level* levels_host, int n_levels, int C, const float* rois,
+                                    const int* roi_batch, const int* roi_level, int R, int Hd, int K, int K4, int T,
+                                    const snn_params* p_host, const void* w6_packed, int w6_inner, const void* w7_packed,
+                                    const float* w_heads_packed, float* out_cls, float* out_bbox,
+                                    uint32_t* spk6_count, uint32_t* spk7_count, float* sum_cls, float* sum_bbox,
+                                    void* workspace, size_t workspace_bytes, snn_stream_t stream);
 
 /* ---- finished spike-rate tensors of the two spike-rate variants (rpn.py:171-195, faster_rcnn.py:568-618) from the raw side
  * outputs above: rows (rate, "FLOPs") as float32, what the reference hstacks per layer.

@@ -102,6 +102,12 @@ SYMBOLS = {
     "snn_packed_linear_bf16x3_elems": (C.c_size_t, [C.c_int, C.c_int]),
     "snn_pack_linear_weight_bf16x3": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, c_stream]),
     "snn_check_bf16x3_split": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, c_stream]),
+    "snn_pack_linear_weight_bf16x3_perm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, c_stream]),
+    "snn_det_head_forward_k": (C.c_int, [C.c_void_p] + [C.c_int] * 6 + [C.POINTER(snn_params), C.c_void_p, C.c_int] +
+                               [C.c_void_p] * 9 + [C.c_size_t, c_stream]),
+    "snn_det_head_forward_roialign_k": (C.c_int, [C.POINTER(snn_roi_level), C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                                  C.c_void_p] + [C.c_int] * 5 + [C.POINTER(snn_params), C.c_void_p, C.c_int] +
+                                        [C.c_void_p] * 9 + [C.c_size_t, c_stream]),
     "snn_packed_linear_mx_words": (C.c_size_t, [C.c_int, C.c_int]),
     "snn_packed_conv3x3_mx_words": (C.c_size_t, [C.c_int, C.c_int]),
     "snn_pack_linear_weight_mx": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, c_stream]),

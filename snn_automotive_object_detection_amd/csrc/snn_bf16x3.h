@@ -1022,6 +1022,8 @@ __global__ void k_pack_bf16x3(const float* __restrict__ src, uint16_t* __restric
             if (mode == PACK_CONV3X3) {
                 const int tap = k / Cp, ci = k % Cp;
                 if (ci < Cin) w = src[((size_t)n * Cin + ci) * 9 + tap];
+            } else if (mode == PACK_LINEAR_PERM) {         // reduction index k' = s * Cp + c  <-  source column c * Cin + s  (Cin = S inner
+                if (k < K) w = src[(size_t)n * K + (size_t)(k % Cp) * Cin + k / Cp];        // elements per channel, Cp = channels)
             } else if (k < K) {
                 w = src[(size_t)n * K + k];
             }

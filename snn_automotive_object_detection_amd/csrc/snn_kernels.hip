@@ -70,7 +70,7 @@ static NeuronP make_p(const snn_params* p, float v_th) {
 // so that one ds_read_b128 per lane yields the B operands of 4 consecutive MFMAs and both the
 // global->LDS copy and the LDS read are perfectly linear (no bank conflicts, no swizzle needed).
 // ------------------------------------------------------------------------------------------------
-enum { PACK_CONV3X3 = 0, PACK_LINEAR = 1 };
+enum { PACK_CONV3X3 = 0, PACK_LINEAR = 1, PACK_LINEAR_PERM = 2 };
 
 __global__ void k_pack_gemm_b(const float* __restrict__ src, float* __restrict__ dst, int mode,
                               int K, int N, int Kc, int Nw, int Cin, int Cp) {
@@ -539,6 +539,16 @@ int snn_check_bf16x3_split(const float* w, size_t n, uint32_t* status3, snn_stre
     if (hipMemsetAsync(status3, 0, 3 * sizeof(uint32_t), (hipStream_t)s) != hipSuccess) return fail(-3, "hipMemsetAsync failed");
     hipLaunchKernelGGL(k_bf16x3_split_check, dim3((unsigned)min((size_t)2048, (n + 255) / 256)), dim3(256), 0, (hipStream_t)s, w, n, status3);
     SNN_CHECK_LAUNCH("k_bf16x3_split_check");
+    return 0;
+}
+
+int snn_pack_linear_weight_bf16x3_perm(const float* w, int N, int K, int inner, uint16_t* packed, snn_stream_t s) {
+    if (!w || !packed || N <= 0 || K <= 0 || inner <= 0 || K % inner) return fail(-1, "snn_pack_linear_weight_bf16x3_perm: bad argument");
+    const int Kc = cdiv(K, 32), Np = cdiv(N, 32) * 32;
+    const size_t total = (size_t)Kc * Np * 32;
+    hipLaunchKernelGGL(k_pack_bf16x3, dim3((unsigned)min((size_t)4096, (total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)s, w, packed, (int)PACK_LINEAR_PERM, K, N, Kc, Np, inner, K / inner);
+    SNN_CHECK_LAUNCH("k_pack_bf16x3");
     return 0;
 }
 
@@ -1849,14 +1859,21 @@ int snn_det_postprocess(const float* class_logits, const float* box_regression, 
 static void det_ws_layout(int R, int D, int Hd, int T, size_t* o_enc, size_t* o_cur, size_t* o_s6, size_t* o_s7,
                           size_t* total) {
     const size_t enc = align_up((size_t)T * R * cdiv(D, 32) * 4, 256);
-    const size_t cur = align_up((size_t)T * R * cdiv(Hd, 32) * 32 * 4, 256);
+    // currents [T R][Hd] of the un-fused paths; in the fused bf16x3 path the region holds the side buffers of the structured-sparse fc6
+    // (snn_sparse.h) instead, so it is at least that large
+    const size_t cur = max(align_up((size_t)T * R * cdiv(Hd, 32) * 32 * 4, 256), align_up(sparse_side_bytes(R, R, cdiv(D, 32), T), 256));
     const size_t sp = align_up((size_t)T * R * cdiv(Hd, 32) * 4, 256);
-    *o_enc = 0; *o_cur = enc; *o_s6 = enc + cur; *o_s7 = enc + cur + sp; *total = enc + cur + 2 * sp + DET_SYNC_BYTES;
+    *o_enc = 0; *o_cur = enc; *o_s6 = enc + cur; *o_s7 = enc + cur + sp; *total = enc + cur + 2 * sp + DET_SYNC_BYTES + enc;
 }
-static size_t det_ws_sync_offset(int R, int D, int Hd, int T) {        // the fc6 -> fc7 tile counters of the one-launch pair: the last DET_SYNC_BYTES
+static size_t det_ws_perm_offset(int R, int D, int Hd, int T) {        // the encoder planes in permuted reduction order (k_permute_planes): the last `enc` bytes
     size_t a, b, c, d, tot;
     det_ws_layout(R, D, Hd, T, &a, &b, &c, &d, &tot);
-    return tot - DET_SYNC_BYTES;
+    return tot - b;                                                   // (b = o_cur = size of the encoder planes)
+}
+static size_t det_ws_sync_offset(int R, int D, int Hd, int T) {        // the fc6 -> fc7 tile counters of the one-launch pair: DET_SYNC_BYTES behind s7
+    size_t a, b, c, d, tot;
+    det_ws_layout(R, D, Hd, T, &a, &b, &c, &d, &tot);
+    return tot - b - DET_SYNC_BYTES;
 }
 
 size_t snn_det_head_workspace_bytes(int R, int D, int Hd, int K, int K4, int T, int precision) {
@@ -1877,7 +1894,7 @@ static bool det_planes_wm(const snn_params* p, const DetWindows& w) { return det
 static int det_head_from_planes(int R, int D, int Hd, int K, int K4, int T, const snn_params* p, const void* w6_packed,
                                 const void* w7_packed, const float* w_heads_packed, float* out_cls, float* out_bbox,
                                 uint32_t* spk6_count, uint32_t* spk7_count, float* sum_cls, float* sum_bbox, void* ws,
-                                bool enc_wm, const DetWindows& win, bool enc_periods, snn_stream_t stream) {
+                                bool enc_wm, const DetWindows& win, bool enc_periods, snn_stream_t stream, int k_inner = 0) {
     size_t o_enc, o_cur, o_s6, o_s7, need;
     det_ws_layout(R, D, Hd, T, &o_enc, &o_cur, &o_s6, &o_s7, &need);
     const size_t o_sync = det_ws_sync_offset(R, D, Hd, T);
@@ -1888,6 +1905,23 @@ static int det_head_from_planes(int R, int D, int Hd, int K, int K4, int T, cons
     uint32_t* s7 = (uint32_t*)((char*)ws + o_s7);
     const int Hw = cdiv(Hd, 32), Hp = Hw * 32;
     int rc;
+    if (k_inner > 1) {
+        // fc6's weights were packed in the permuted reduction order k' = s * C + c (snn_pack_linear_weight_bf16x3_perm): bring the
+        // encoder's planes into the same order (snn_sparse.h: k_permute_planes).  Word-major planes of the fused bf16x3 layers only.
+        const int C = D / k_inner;
+        if (D % k_inner || C % 32 || !enc_wm || !det_b3_tiles(p, win))
+            return fail(-4, "snn_det_head_forward: permuted fc6 weights (inner = %d) need D = C * inner, C %% 32 == 0 and the fused bf16x3 path", k_inner);
+        // (the encoder wrote its planes into the LAST region of the workspace; the permuted ones go to the front, where fc6 reads them -
+        // the sparse kernel addresses its side buffers as 32-bit offsets from the planes, so these must lie in front of them)
+        const uint32_t* enc_raw = (const uint32_t*)((char*)ws + det_ws_perm_offset(R, D, Hd, T));
+        const int Dw = cdiv(D, 32);
+        const size_t lds = (size_t)Dw * 32 * 4;
+        if (lds > 64 * 1024) return fail(-4, "snn_det_head_forward: D = %d too large for the plane transposition", D);
+        hipError_t e = hipFuncSetAttribute((const void*)k_permute_planes, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail(-3, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+        hipLaunchKernelGGL(k_permute_planes, dim3(cdiv(R, 32), win.enc_steps), dim3(512), lds, s, enc_raw, enc, Dw, R, C, k_inner);
+        SNN_CHECK_LAUNCH("k_permute_planes");
+    }
     if (spk6_count) { if (hipMemsetAsync(spk6_count, 0, sizeof(uint32_t) * R, s) != hipSuccess) return fail(-3, "hipMemsetAsync failed"); }
     if (spk7_count) { if (hipMemsetAsync(spk7_count, 0, sizeof(uint32_t) * R, s) != hipSuccess) return fail(-3, "hipMemsetAsync failed"); }
     const bool b3 = prec_family(p) == SNN_PRECISION_BF16X3, mx = prec_family(p) == SNN_PRECISION_MXFP6;
@@ -1955,6 +1989,14 @@ int snn_det_head_forward(const float* x, int R, int D, int Hd, int K, int K4, in
                          const void* w6_packed, const void* w7_packed, const float* w_heads_packed,
                          float* out_cls, float* out_bbox, uint32_t* spk6_count, uint32_t* spk7_count,
                          float* sum_cls, float* sum_bbox, void* ws, size_t ws_bytes, snn_stream_t stream) {
+    return snn_det_head_forward_k(x, R, D, Hd, K, K4, T, p, w6_packed, 0, w7_packed, w_heads_packed, out_cls, out_bbox, spk6_count, spk7_count,
+                                  sum_cls, sum_bbox, ws, ws_bytes, stream);
+}
+
+int snn_det_head_forward_k(const float* x, int R, int D, int Hd, int K, int K4, int T, const snn_params* p,
+                           const void* w6_packed, int w6_inner, const void* w7_packed, const float* w_heads_packed,
+                           float* out_cls, float* out_bbox, uint32_t* spk6_count, uint32_t* spk7_count,
+                           float* sum_cls, float* sum_bbox, void* ws, size_t ws_bytes, snn_stream_t stream) {
     if (!x || !p || !w6_packed || !w7_packed || !w_heads_packed || !out_cls || !out_bbox || !ws)
         return fail(-1, "snn_det_head_forward: null argument");
     if (R <= 0 || D <= 0 || Hd <= 0 || K <= 0 || K4 <= 0) return fail(-1, "snn_det_head_forward: bad shape");
@@ -1965,10 +2007,12 @@ int snn_det_head_forward(const float* x, int R, int D, int Hd, int K, int K4, in
     const DetWindows win = det_windows(p, T, spk6_count != nullptr);
     const bool wm = det_planes_wm(p, win) && encode_rows_wm_ok(x, D);
     const bool per = knobs().periods && periods_possible(p) && det_b3_tiles(p, win);      // fc6 on the encoder's period planes (snn_common.h)
-    int rc = encode_rows_impl(x, R, D, win.enc_steps, p, (uint32_t*)((char*)ws + o_enc), (size_t)R * cdiv(D, 32), wm, stream, per);
+    if (w6_inner > 1 && !wm) return fail(-4, "snn_det_head_forward: permuted fc6 weights need the word-major fused bf16x3 path (D %% 32 == 0, x 16-byte aligned)");
+    uint32_t* enc_dst = (uint32_t*)((char*)ws + (w6_inner > 1 ? det_ws_perm_offset(R, D, Hd, T) : o_enc));
+    int rc = encode_rows_impl(x, R, D, win.enc_steps, p, enc_dst, (size_t)R * cdiv(D, 32), wm, stream, per);
     if (rc) return rc;
     return det_head_from_planes(R, D, Hd, K, K4, T, p, w6_packed, w7_packed, w_heads_packed, out_cls, out_bbox,
-                                spk6_count, spk7_count, sum_cls, sum_bbox, ws, wm, win, per, stream);
+                                spk6_count, spk7_count, sum_cls, sum_bbox, ws, wm, win, per, stream, w6_inner);
 }
 
 int snn_det_head_forward_roialign(const snn_roi_level* levels_host, int n_levels, int C, const float* rois,
@@ -1977,6 +2021,16 @@ int snn_det_head_forward_roialign(const snn_roi_level* levels_host, int n_levels
                                   const float* w_heads_packed, float* out_cls, float* out_bbox, uint32_t* spk6_count,
                                   uint32_t* spk7_count, float* sum_cls, float* sum_bbox, void* ws, size_t ws_bytes,
                                   snn_stream_t stream) {
+    return snn_det_head_forward_roialign_k(levels_host, n_levels, C, rois, roi_batch, roi_level, R, Hd, K, K4, T, p, w6_packed, 0, w7_packed,
+                                           w_heads_packed, out_cls, out_bbox, spk6_count, spk7_count, sum_cls, sum_bbox, ws, ws_bytes, stream);
+}
+
+int snn_det_head_forward_roialign_k(const snn_roi_level* levels_host, int n_levels, int C, const float* rois,
+                                    const int* roi_batch, const int* roi_level, int R, int Hd, int K, int K4, int T,
+                                    const snn_params* p, const void* w6_packed, int w6_inner, const void* w7_packed,
+                                    const float* w_heads_packed, float* out_cls, float* out_bbox, uint32_t* spk6_count,
+                                    uint32_t* spk7_count, float* sum_cls, float* sum_bbox, void* ws, size_t ws_bytes,
+                                    snn_stream_t stream) {
     if (!p || !w6_packed || !w7_packed || !w_heads_packed || !out_cls || !out_bbox || !ws)
         return fail(-1, "snn_det_head_forward_roialign: null argument");
     if (R <= 0 || C <= 0 || Hd <= 0 || K <= 0 || K4 <= 0) return fail(-1, "snn_det_head_forward_roialign: bad shape");
@@ -1988,11 +2042,13 @@ int snn_det_head_forward_roialign(const snn_roi_level* levels_host, int n_levels
     const DetWindows win = det_windows(p, T, spk6_count != nullptr);
     const bool wm = det_planes_wm(p, win);
     const bool per = knobs().periods && periods_possible(p) && det_b3_tiles(p, win);
+    if (w6_inner > 1 && (!wm || w6_inner != 49)) return fail(-4, "snn_det_head_forward_roialign: permuted fc6 weights need inner = 49 and the word-major fused bf16x3 path");
+    uint32_t* enc_dst = (uint32_t*)((char*)ws + (w6_inner > 1 ? det_ws_perm_offset(R, D, Hd, T) : o_enc));
     int rc = roi_align_encode_impl(levels_host, n_levels, C, rois, roi_batch, roi_level, R, win.enc_steps, p,
-                                   (uint32_t*)((char*)ws + o_enc), (size_t)R * cdiv(D, 32), nullptr, wm, stream, per);
+                                   enc_dst, (size_t)R * cdiv(D, 32), nullptr, wm, stream, per);
     if (rc) return rc;
     return det_head_from_planes(R, D, Hd, K, K4, T, p, w6_packed, w7_packed, w_heads_packed, out_cls, out_bbox,
-                                spk6_count, spk7_count, sum_cls, sum_bbox, ws, wm, win, per, stream);
+                                spk6_count, spk7_count, sum_cls, sum_bbox, ws, wm, win, per, stream, w6_inner);
 }
 
 int snn_det_exchange_payload(const float* class_logits, const float* box_regression, int N, int rois_per_image, int K,

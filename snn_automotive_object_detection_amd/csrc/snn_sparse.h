@@ -77,6 +77,32 @@ __host__ __device__ inline uint32_t sp_nibble_code(uint32_t x) {
     return occ | ((i0 | (i1 << 2)) << 2) | (left << 6);       // bits 1:0 occupancy, 5:2 indices, 9:6 leftover
 }
 
+// Reduction-index permutation of a linear layer's period planes (the detector's fc6).  The flattened RoI features run (channel, bin):
+// k = c * S + s, so four consecutive k are four neighbouring BINS of one channel - strongly correlated values, hence often the same
+// period: three or four spikes per nibble would be the rule in the sparse planes, not the exception.  With k' = s * C + c four consecutive
+// k' are four CHANNELS at one bin (independent, as in the RPN's conv, whose reduction index is tap * C + channel).  The encoders keep
+// writing planes in the reference's order; this kernel transposes the bits of every (plane, RoI) row, and fc6's weights are packed in
+// the same order (snn_pack_linear_weight_bf16x3_perm): the contraction is the same sum in another order.
+// Block = (32 RoIs, plane); word-major planes [T][Dw][R] in and out.  thread task = (output word, RoI): 32 bit gathers from LDS.
+__global__ __launch_bounds__(512) void k_permute_planes(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int Dw, int R, int C, int S) {
+    extern __shared__ uint32_t pl[];                          // [Dw][32]
+    const int t = blockIdx.y, r0 = blockIdx.x * 32, rl = threadIdx.x & 31;
+    const bool live = r0 + rl < R;
+    for (int w = threadIdx.x >> 5; w < Dw; w += 16) pl[w * 32 + rl] = live ? in[((size_t)t * Dw + w) * R + r0 + rl] : 0u;
+    __syncthreads();
+    const int cbn = C / 32;                                   // words per bin in the permuted order
+    for (int w = threadIdx.x >> 5; w < Dw; w += 16) {
+        const int s = w / cbn, cb = w % cbn;
+        uint32_t o = 0;
+#pragma unroll 8
+        for (int j = 0; j < 32; ++j) {
+            const int k = (32 * cb + j) * S + s;
+            o |= ((pl[(k >> 5) * 32 + rl] >> (k & 31)) & 1u) << j;
+        }
+        if (live) out[((size_t)t * Dw + w) * R + r0 + rl] = o;
+    }
+}
+
 struct CompressArgs {
     const uint32_t* enc;
     uint32_t* cmp;

@@ -4,6 +4,8 @@ keys (``fc6.weight``, ``fc7.weight``, ``cls_score.weight``, ``bbox_pred.weight``
 ``nn.Linear`` init).  ``RoIHeadsSNN.forward`` (roi_heads.py:1230) can call it unchanged.
 ``spike_rates = True`` gives the faster_rcnn.py:520-618 variant (returns ONLY the rate list)."""
 import torch
+import os
+
 from torch import nn
 
 from . import ops
@@ -43,13 +45,14 @@ class FastRCNNPredictorSNNFull(nn.Module):
         self._c6 = {"f32": _WeightCache(), "bf16x3": _WeightCache(), "mxfp6": _WeightCache()}
         self._c7 = {"f32": _WeightCache(), "bf16x3": _WeightCache(), "mxfp6": _WeightCache()}
         self._ch = _WeightCache()
+        self._c6p = _WeightCache()              # fc6 in the permuted reduction order (fc6_inner)
         self._cache_split = _WeightCache()      # None, or why these weights cannot be carried as three bf16 planes (-> "f32_strict")
         self.last_spike_counts = None
 
     def invalidate_packed_weights(self) -> None:
         """drop the packed copies of the weights (needed after in-place edits through ``param.data``, which do not bump the
         version counter the cache is keyed on); rebuilt on the next forward"""
-        for c in list(self._c6.values()) + list(self._c7.values()) + [self._ch, self._cache_split]:
+        for c in list(self._c6.values()) + list(self._c7.values()) + [self._ch, self._c6p, self._cache_split]:
             c.invalidate()
 
     def _apply(self, fn, *args, **kwargs):
@@ -78,13 +81,27 @@ class FastRCNNPredictorSNNFull(nn.Module):
         split = (self.cls_score.weight, self.bbox_pred.weight) + ((self.fc6.weight, self.fc7.weight) if prec == "bf16x3" else ())
         return _strict_if_inexact(self, prec, self._cache_split.get(split, _warn_once_box(ops.split_problem)))
 
-    def _packed(self, prec=None):
-        """packed fc6, fc7, LI heads for `prec` (default: the precision this forward resolves to)"""
+    def fc6_inner(self, prec=None) -> int:
+        """49 when fc6's weights are packed in the permuted reduction order k' = bin * C + channel (include/snn_hip.h:
+        snn_det_head_forward_k): bf16x3 on [C, 7, 7] inputs with C % 32 == 0 - what lets fc6's sparse period planes run on the
+        structured-sparse matrix-core instruction.  0: the reference's order (SNN_FC6_PERM=0 forces it: A/B, tests)."""
+        prec = prec or self._resolve_precision()
+        if prec != "bf16x3" or os.environ.get("SNN_FC6_PERM") == "0":
+            return 0
+        return 49 if (self.in_channels % 49 == 0 and (self.in_channels // 49) % 32 == 0) else 0
+
+    def _packed(self, prec=None, inner=None):
+        """packed fc6, fc7, LI heads for `prec` (default: the precision this forward resolves to); ``inner`` = 0: fc6 in the
+        reference's reduction order whatever fc6_inner() says (the stage-level ops read un-permuted planes)"""
         prec = prec or self._resolve_precision()
         pack = {"f32": ops.pack_linear, "f32_strict": ops.pack_linear, "bf16x3": lambda w: ops.pack_linear_bf16x3(w, check_split=False),
                 "mxfp6": ops.pack_linear_mx}[prec]
         slot = "f32" if prec == "f32_strict" else prec
-        w6 = self._c6[slot].get((self.fc6.weight,), pack)
+        inner = self.fc6_inner(prec) if inner is None else inner
+        if inner:
+            w6 = self._c6p.get((self.fc6.weight,), lambda w: ops.pack_linear_bf16x3(w, check_split=False, inner=inner))
+        else:
+            w6 = self._c6[slot].get((self.fc6.weight,), pack)
         w7 = self._c7[slot].get((self.fc7.weight,), pack)
         wh = self._ch.get((self.cls_score.weight, self.bbox_pred.weight), _pack_heads_unchecked)
         return w6, w7, wh
@@ -99,7 +116,7 @@ class FastRCNNPredictorSNNFull(nn.Module):
         x = x.flatten(start_dim=1)                                     # :473
         if x.shape[1] != self.in_channels:
             raise ValueError("expected %d input features, got %d" % (self.in_channels, x.shape[1]))
-        out = ops.det_head_forward(x, Hd, K, K4, T, self._params(prec), w6, w7, wh, spike_rates=self.spike_rates)
+        out = ops.det_head_forward(x, Hd, K, K4, T, self._params(prec), w6, w7, wh, spike_rates=self.spike_rates, w6_inner=self.fc6_inner(prec))
         return self._finish(out, x.shape[0], x.device)
 
     @torch.no_grad()
@@ -114,7 +131,7 @@ class FastRCNNPredictorSNNFull(nn.Module):
         if feats[0].shape[1] * 49 != self.in_channels:
             raise ValueError("expected %d input features, got %d x 49" % (self.in_channels, feats[0].shape[1]))
         out = ops.det_head_forward_roialign(feats, scales, rois[:, 1:5], rois[:, 0], roi_level, Hd, K, K4, T,
-                                            self._params(prec), w6, w7, wh, spike_rates=self.spike_rates)
+                                            self._params(prec), w6, w7, wh, spike_rates=self.spike_rates, w6_inner=self.fc6_inner(prec))
         return self._finish(out, rois.shape[0], rois.device)
 
     def _finish(self, out, R, dev):

@@ -154,7 +154,9 @@ def pack_conv3x3_bf16x3(w: torch.Tensor, check_split: bool = True) -> torch.Tens
     return out
 
 
-def pack_linear_bf16x3(w: torch.Tensor, check_split: bool = True) -> torch.Tensor:
+def pack_linear_bf16x3(w: torch.Tensor, check_split: bool = True, inner: int = 0) -> torch.Tensor:
+    """``inner`` > 1: the reduction index is permuted to k' = s * C + c (input column c * inner + s; snn_hip.h:
+    snn_pack_linear_weight_bf16x3_perm) - pass the same value as ``w6_inner`` to the head call"""
     _need_gpu(w, "linear weight")
     lib = _lib.load()
     w = _f32c(w)
@@ -162,7 +164,10 @@ def pack_linear_bf16x3(w: torch.Tensor, check_split: bool = True) -> torch.Tenso
         check_bf16x3_split(w, "linear weight %s" % (tuple(w.shape),))
     n, k = w.shape
     out = torch.empty(lib.snn_packed_linear_bf16x3_elems(n, k), dtype=torch.int16, device=w.device)
-    _lib.check(lib.snn_pack_linear_weight_bf16x3(_ptr(w), n, k, _ptr(out), _stream()), "snn_pack_linear_weight_bf16x3")
+    if inner > 1:
+        _lib.check(lib.snn_pack_linear_weight_bf16x3_perm(_ptr(w), n, k, int(inner), _ptr(out), _stream()), "snn_pack_linear_weight_bf16x3_perm")
+    else:
+        _lib.check(lib.snn_pack_linear_weight_bf16x3(_ptr(w), n, k, _ptr(out), _stream()), "snn_pack_linear_weight_bf16x3")
     return out
 
 
@@ -506,7 +511,7 @@ def rpn_head_forward(feats: Sequence[torch.Tensor], C_: int, A: int, T: int, p: 
 
 
 def det_head_forward(x: torch.Tensor, Hd: int, K: int, K4: int, T: int, p: snn_params, w6_packed: torch.Tensor,
-                     w7_packed: torch.Tensor, w_heads_packed: torch.Tensor, spike_rates: bool = False):
+                     w7_packed: torch.Tensor, w_heads_packed: torch.Tensor, spike_rates: bool = False, w6_inner: int = 0):
     lib = _lib.load()
     _need_gpu(x, "box features")
     x = _f32c(x).flatten(1)
@@ -524,9 +529,9 @@ def det_head_forward(x: torch.Tensor, Hd: int, K: int, K4: int, T: int, p: snn_p
         return out_cls, out_bbox, (c6, c7, s_c, s_b)
     ws_bytes = lib.snn_det_head_workspace_bytes(R, D, Hd, K, K4, T, p.precision)
     ws = _WS.get(dev, ws_bytes)
-    _lib.check(lib.snn_det_head_forward(_ptr(x), R, D, Hd, K, K4, T, C.byref(p), _ptr(w6_packed), _ptr(w7_packed),
-                                        _ptr(w_heads_packed), _ptr(out_cls), _ptr(out_bbox), _ptr(c6), _ptr(c7),
-                                        _ptr(s_c), _ptr(s_b), _ptr(ws), ws.numel(), _stream()),
+    _lib.check(lib.snn_det_head_forward_k(_ptr(x), R, D, Hd, K, K4, T, C.byref(p), _ptr(w6_packed), int(w6_inner), _ptr(w7_packed),
+                                          _ptr(w_heads_packed), _ptr(out_cls), _ptr(out_bbox), _ptr(c6), _ptr(c7),
+                                          _ptr(s_c), _ptr(s_b), _ptr(ws), ws.numel(), _stream()),
                "snn_det_head_forward")
     return out_cls, out_bbox, (c6, c7, s_c, s_b)
 
@@ -577,7 +582,7 @@ def roi_align_encode(feats, scales, rois: torch.Tensor, roi_batch: torch.Tensor,
 
 
 def det_head_forward_roialign(feats, scales, rois, roi_batch, roi_level, Hd: int, K: int, K4: int, T: int, p: snn_params,
-                              w6_packed, w7_packed, w_heads_packed, spike_rates: bool = False):
+                              w6_packed, w7_packed, w_heads_packed, spike_rates: bool = False, w6_inner: int = 0):
     lib = _lib.load()
     lv, keep = _roi_levels(feats, scales)
     Cc = keep[0].shape[1]
@@ -597,10 +602,10 @@ def det_head_forward_roialign(feats, scales, rois, roi_batch, roi_level, Hd: int
         return out_cls, out_bbox, (c6, c7, s_c, s_b)
     ws_bytes = lib.snn_det_head_workspace_bytes(R, Cc * 49, Hd, K, K4, T, p.precision)
     ws = _WS.get(dev, ws_bytes)
-    _lib.check(lib.snn_det_head_forward_roialign(lv, len(keep), Cc, _ptr(rois), _ptr(roi_batch), _ptr(roi_level), R, Hd, K,
-                                                 K4, T, C.byref(p), _ptr(w6_packed), _ptr(w7_packed), _ptr(w_heads_packed),
-                                                 _ptr(out_cls), _ptr(out_bbox), _ptr(c6), _ptr(c7), _ptr(s_c), _ptr(s_b),
-                                                 _ptr(ws), ws.numel(), _stream()), "snn_det_head_forward_roialign")
+    _lib.check(lib.snn_det_head_forward_roialign_k(lv, len(keep), Cc, _ptr(rois), _ptr(roi_batch), _ptr(roi_level), R, Hd, K,
+                                                   K4, T, C.byref(p), _ptr(w6_packed), int(w6_inner), _ptr(w7_packed), _ptr(w_heads_packed),
+                                                   _ptr(out_cls), _ptr(out_bbox), _ptr(c6), _ptr(c7), _ptr(s_c), _ptr(s_b),
+                                                   _ptr(ws), ws.numel(), _stream()), "snn_det_head_forward_roialign")
     return out_cls, out_bbox, (c6, c7, s_c, s_b)
 
 

@@ -148,7 +148,7 @@ def test_det_head_nonzero_rest_potential_keeps_step_zero(gpu_device, monkeypatch
     T = 6
     m = S.FastRCNNPredictorSNNFull(32 * 49, 64, 5, T).to(gpu_device)
     x = torch.randn(40, 32, 7, 7, device=gpu_device)
-    w6, w7, wh = m._packed()
+    w6, w7, wh = m._packed(inner=0)
     for v_leak, fires_at_0 in ((0.2, True), (0.05, False)):
         p = m._params()
         p.v_leak = v_leak                                        # 0.2 > v_th_lif = 0.1: every lif6 neuron fires at step 0

@@ -195,7 +195,7 @@ def test_generic_rest_potentials_and_the_other_precisions_take_spike_planes(gpu_
     p = _params(ops)
     p.v_reset = -0.05                                                               # a reset potential: the detector head through the C ABI wrappers
     d = S.FastRCNNPredictorSNNFull(32 * 49, 64, 5, 6).to(gpu_device)
-    w6, w7, wh = d._packed()
+    w6, w7, wh = d._packed(inner=0)
     x = torch.randn(40, 32, 7, 7, device=gpu_device) * 2
     a = ops.det_head_forward(x, 64, 5, 20, 6, p, w6, w7, wh)[:2]
     monkeypatch.setenv("SNN_PERIOD_PLANES", "0")

@@ -143,6 +143,28 @@ def test_sparse_fc6_equals_dense_up_to_ties(gpu_device, monkeypatch, R, C, Hd, K
     assert float(a[0].abs().max()) > 0
 
 
+def test_fc6_reduction_order_permutation_is_the_same_contraction(gpu_device, monkeypatch):
+    """fc6's weights in the order k' = bin * C + channel, the encoder's planes transposed to match (k_permute_planes): against the
+    reference's order (SNN_FC6_PERM=0) the same sums in another order - on both the dense launch and the fused RoIAlign path"""
+    from tests.test_gpu_roialign import _setup
+    monkeypatch.setenv("SNN_SPARSE", "0")
+    d = _det(gpu_device, 64, 256, 9, 12, 4)
+    assert d.fc6_inner() == 49
+    x = torch.randn(300, 64, 7, 7, device=gpu_device) * 2
+    pool, fm, boxes, shapes = _setup(gpu_device, R=200, C=64, seed=4)
+    flist, scales, rois, lvl = pool.assign(fm, boxes, shapes)
+    a = _run_det(d, x) + tuple(t.clone() for t in d.forward_roialign(flist, scales, rois, lvl))
+    monkeypatch.setenv("SNN_FC6_PERM", "0")
+    d.invalidate_packed_weights()
+    assert d.fc6_inner() == 0
+    b = _run_det(d, x) + tuple(t.clone() for t in d.forward_roialign(flist, scales, rois, lvl))
+    for i in (0, 2):
+        off = ((a[i] - b[i]).abs().amax(1) > 1e-4) | ((a[i + 1] - b[i + 1]).abs().amax(1) > 1e-4)
+        assert int(off.sum()) <= flip_budget(a[i].shape[0], 2 * 256, 12, "det") and float((a[i] - b[i]).abs().max()) < 0.05
+    # a head whose channel count is not a multiple of 32 keeps the reference's order
+    assert _det(gpu_device, 8, 64, 5, 6, 1).fc6_inner() == 0
+
+
 def test_sparse_fc6_vs_oracle(gpu_device):
     T, C, Hd, K, R = 12, 64, 128, 9, 60
     d = _det(gpu_device, C, Hd, K, T, 2)

@@ -61,7 +61,7 @@ pd = leg.det_head._params()
 zd = ops.encode_rows(leg.rois.flatten(1), Td, pd)
 ed = periods(zd)
 print("DET  z_t density", dens(zd), " e_n density", dens(ed))
-w6 = leg.det_head._packed()[0]
+w6 = leg.det_head._packed(inner=0)[0]
 for rnd in range(2):
     print("fc6+LIF on z planes %.4f ms   on e planes %.4f ms" % (tm(lambda: ops.spike_gemm_lif_bf16x3(zd, 12544, 1024, pd, w6)),
                                                                 tm(lambda: ops.spike_gemm_lif_bf16x3(ed, 12544, 1024, pd, w6))), flush=True)

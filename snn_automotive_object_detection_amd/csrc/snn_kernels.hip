@@ -943,10 +943,26 @@ static int count_spikes_per_image(const snn_rpn_level* lv, int n_levels, int Cw,
 static size_t sparse_side_bytes(long long P, long long Pe, int Kw, int T);
 // ---- structured-sparse conv (snn_sparse.h): tile geometry + wave assignment ----
 struct SparsePlan { int q, pb, nd; signed char plane[8][SP_MT]; unsigned char j[8][SP_MT], w_nd[8], w_ns[8]; };
-static bool sparse_plan(int Tc, SparsePlan* sp) {
+// q = M-tiles (16 positions / RoIs each) per plane.  The conv has thousands of tiles and takes the largest one; a linear layer with a few
+// hundred work-groups takes the q with the fewest rounds of work-groups x work per tile (fc6 at 2000 RoIs, 10 planes: q = 3 is 672
+// work-groups = 1.31 rounds of the 512 slots, q = 2 is 1008 = 1.97 rounds of tiles two thirds the size: 687 -> ~520 us)
+static bool sparse_plan(int Tc, SparsePlan* sp, long long units = 0, int n_blocks = 0) {
     if (Tc < 4 || Tc > 32) return false;
-    const int q = 32 / Tc, nd = 2;
-    if (q < 1 || q > 8) return false;
+    int q = 32 / Tc;
+    const int nd = 2;
+    if (q < 1) return false;
+    if (q > 8) q = 8;
+    if (units > 0 && n_blocks > 0) {
+        const int slots = 2 * g3_slots();
+        int best = 0;
+        double best_cost = 0;
+        for (int c = q; c >= 1; --c) {
+            const long long wgs = (long long)cdiv(units, 16 * c) * n_blocks;
+            const double cost = (double)((wgs + slots - 1) / slots) * (c * (2.0 * nd + 1.1 * (Tc - nd)) + 2.0);
+            if (!best || cost < best_cost * 0.97) { best = c; best_cost = cost; }
+        }
+        q = best;
+    }
     memset(sp, 0, sizeof(*sp));
     sp->q = q; sp->pb = 16 * q; sp->nd = nd;
     int used[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -983,7 +999,7 @@ static int gemm3_lif_sparse(const Gemm3Args& a, bool conv, void* side, size_t si
     const int Kw = conv ? a.Cw : a.Kc;                        // plane words per row
     if (!knobs().sparse || !side || !a.wm || !a.periods || a.cnt_img || a.cnt_row || Kw % 2 || a.Np % 64 || a.Kc * 32 > 65536 || a.T < 5 || a.T > 16 ||
         a.Tc != a.T - (conv ? 1 : 2) || a.t0 != 0 || a.p.v_leak != 0.0f || (float)(a.p.v_leak - a.p.v_th) > 0.0f || (!conv && !a.out_wm) ||
-        !sparse_plan(a.Tc, &sp))
+        !sparse_plan(a.Tc, &sp, conv ? 0 : a.M, a.Np / 64))
         return 0;
     const long long P = a.M, Pe = (long long)a.a_step;
     if (side_bytes < sparse_side_bytes(P, Pe, Kw, a.T)) return 0;
@@ -1915,11 +1931,12 @@ static int det_head_from_planes(int R, int D, int Hd, int K, int K4, int T, cons
         // the sparse kernel addresses its side buffers as 32-bit offsets from the planes, so these must lie in front of them)
         const uint32_t* enc_raw = (const uint32_t*)((char*)ws + det_ws_perm_offset(R, D, Hd, T));
         const int Dw = cdiv(D, 32);
-        const size_t lds = (size_t)Dw * 32 * 4;
+        const size_t lds = (size_t)Dw * 33 * 4;
+        if (k_inner != 49) return fail(-4, "snn_det_head_forward: permuted fc6 weights: inner = %d (only 49 = 7 x 7 bins is built)", k_inner);
         if (lds > 64 * 1024) return fail(-4, "snn_det_head_forward: D = %d too large for the plane transposition", D);
-        hipError_t e = hipFuncSetAttribute((const void*)k_permute_planes, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)k_permute_planes<49>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fail(-3, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-        hipLaunchKernelGGL(k_permute_planes, dim3(cdiv(R, 32), win.enc_steps), dim3(512), lds, s, enc_raw, enc, Dw, R, C, k_inner);
+        hipLaunchKernelGGL(k_permute_planes<49>, dim3(cdiv(R, 32), win.enc_steps), dim3(256), lds, s, enc_raw, enc, Dw, R, C);
         SNN_CHECK_LAUNCH("k_permute_planes");
     }
     if (spk6_count) { if (hipMemsetAsync(spk6_count, 0, sizeof(uint32_t) * R, s) != hipSuccess) return fail(-3, "hipMemsetAsync failed"); }

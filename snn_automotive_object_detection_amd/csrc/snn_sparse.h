@@ -365,7 +365,14 @@ __global__ __launch_bounds__(512, 4) void k_gemm_lif_sparse(const SparseConvArgs
         constexpr int ND = decltype(nd_c)::value, NS = decltype(ns_c)::value;
         for (int s = 0; s < n_steps; ++s) {
             const uint32_t o_cur = (uint32_t)((s & 1) * SP_SLOT), o_nxt = (uint32_t)(((s + 1) & 1) * SP_SLOT);
-            if (s + 1 < n_steps) { stage_a(o_nxt); stage_b(o_nxt); }
+            if (s + 1 < n_steps) {
+#ifndef SNN_EXP_SP_NO_A                             // (timing experiments: what do the copies cost - wrong results)
+                stage_a(o_nxt);
+#endif
+#ifndef SNN_EXP_SP_NO_B
+                stage_b(o_nxt);
+#endif
+            }
             // A fragments of this step
             bfv8 ad[ND > 0 ? ND : 1][2], as[NS > 0 ? NS : 1];
             int ix[NS > 0 ? NS : 1];

@@ -53,6 +53,8 @@ ROIS_PER_IMG = 1000
 PEAK_F32_MFMA_TFLOPS = 157.3                                     # MI355X_MICROARCH.md chip table
 PEAK_BF16_MFMA_TFLOPS = 2500.0                                   # dense bf16 (no sparsity)
 PEAK_MX_MFMA_TFLOPS = 10000.0                                    # dense fp6 / fp4 block-scaled (spec, no sparsity)
+PEAK_BF16_SMFMAC_TFLOPS = 5000.0                                 # structured-sparse bf16 (v_smfmac): 2 x the dense peak, dense-equivalent FLOPs
+SPARSE_DENSE_PLANES = 2                                          # period planes e_1, e_2 stay on the dense instruction (csrc/snn_sparse.h)
 
 WORKLOADS = {
     "cityscapes": {"levels": LEVELS_CITY, "image": (1024, 2048), "K": 9, "T_rpn": 8, "T_det": 12, "batch": 2, "spike_rates": False,
@@ -243,6 +245,8 @@ class Leg:
         T = wl["T_rpn"]
         ops.rpn_head_forward(self.feats, C, A, T, p, w_sh, w_hd, stage_mask=7)
         conv_ms = self.time_ms(lambda: ops.rpn_head_forward(self.feats, C, A, T, p, w_sh, w_hd, stage_mask=2), iters)
+        from snn_automotive_object_detection_amd import _lib
+        self.conv_sparse = bool(_lib.load().snn_debug_last_conv_path())      # planes e_3 .. on the structured-sparse instruction?
         enc_ms = self.time_ms(lambda: ops.rpn_head_forward(self.feats, C, A, T, p, w_sh, w_hd, stage_mask=1), iters)
         rpn_ms = self.time_ms(lambda: self.rpn_head(self.feats), iters)
         det_ms = self.time_ms(lambda: self.det_head(self.rois), iters)
@@ -257,6 +261,25 @@ class Leg:
         # SURVEY's FLOPs of the launch / its duration; `frac` prices the EXECUTED MFMA work against the matrix-pipe peak.
         exec_factor = per_step * (1.0 if (dead_steps_kept() or T < 2) else (T - 1) / T)
         achieved = conv_fl / (conv_ms * 1e-3) / 1e12
+        if self.precision == "bf16x3" and getattr(self, "conv_sparse", False):
+            # Round 4: the stage is three launches - k_compress_planes, k_gemm_lif_sparse<true> (the work), the dense k_gemm_bf16x3 that
+            # leaves at once unless a fix-up list overflowed.  Of the T - 1 period planes two run on the dense instruction (peak 2.5 PF)
+            # and T - 3 on the structured-sparse one (v_smfmac_f32_16x16x64_bf16: 64 k per instruction, peak 5 PF dense-equivalent);
+            # frac = (time the executed work takes at those peaks) / (measured time of the whole stage).
+            Tc = T - 1
+            per_plane = conv_fl / T * 3.0                                   # three bf16 weight planes per period plane
+            ex_dense, ex_sparse = per_plane * SPARSE_DENSE_PLANES, per_plane * (Tc - SPARSE_DENSE_PLANES)
+            t_peak = ex_dense / (PEAK_BF16_MFMA_TFLOPS * 1e12) + ex_sparse / (PEAK_BF16_SMFMAC_TFLOPS * 1e12)
+            return {"bound": "mfma", "kernel": "k_gemm_lif_sparse<true>", "achieved": round(achieved, 2),
+                    "peak": round(conv_fl / t_peak / 1e12, 1), "unit": "TFLOP/s", "frac": round(t_peak / (conv_ms * 1e-3), 4),
+                    "traffic": traffic, "traffic_source": traffic_source, "launch_ms": round(conv_ms, 4),
+                    "launches_timed": ["k_compress_planes<true>", "k_gemm_lif_sparse<true>", "k_gemm_bf16x3<3,4,4,1> (device-side fallback: leaves at once)"],
+                    "algorithmic_gflop_per_launch": round(conv_fl / 1e9, 1),
+                    "executed_dense_tflops": round(ex_dense / (conv_ms * 1e-3) / 1e12, 2), "executed_sparse_tflops": round(ex_sparse / (conv_ms * 1e-3) / 1e12, 2),
+                    "mfma_peak_tflops": PEAK_BF16_MFMA_TFLOPS, "smfmac_peak_tflops": PEAK_BF16_SMFMAC_TFLOPS,
+                    "period_planes": {"dense": SPARSE_DENSE_PLANES, "sparse": Tc - SPARSE_DENSE_PLANES}, "time_steps_executed": Tc, "time_steps": T,
+                    "algorithmic_frac_of_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                    "note": "peak = algorithmic FLOPs / (dense planes' work at 2.5 PF + sparse planes' work at 5 PF); the all-dense launch (SNN_SPARSE=0) is the round-3 kernel"}
         return {"bound": "mfma", "kernel": kernel, "achieved": round(achieved, 2), "peak": round(peak / exec_factor, 1),
                 "unit": "TFLOP/s", "frac": round(achieved * exec_factor / peak, 4), "traffic": traffic, "traffic_source": traffic_source,
                 "launch_ms": round(conv_ms, 4), "algorithmic_gflop_per_launch": round(conv_fl / 1e9, 1),
@@ -599,7 +622,7 @@ def main():
     # read from the committed PMC passes of the same launch (separate --pmc FETCH_SIZE / WRITE_SIZE runs, tools/prof_round.sh)
     traffic = traffic_source = None
     if args.workload == "cityscapes" and not args.t_rpn and not dead_steps_kept():
-        for name in ("r3_traffic.json",):
+        for name in ("r4_traffic.json", "r3_traffic.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as f:
                     traffic = json.load(f)[args.precision]["hbm_bytes_per_launch"]

@@ -9,6 +9,15 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _dense_launches_only(monkeypatch):
+    """these tests compare variants of the DENSE matrix-core launches bit for bit; the structured-sparse launches of round 4
+    (csrc/snn_sparse.h: another fp32 summation order, their own tests in tests/test_gpu_sparse.py) and fc6's permuted reduction
+    order (word-major planes only) are switched off"""
+    monkeypatch.setenv("SNN_SPARSE", "0")
+    monkeypatch.setenv("SNN_FC6_PERM", "0")
+
+
 def _head(dev, D, Hd, K, T, seed):
     import snn_automotive_object_detection_amd as S
     torch.manual_seed(seed)

@@ -16,5 +16,5 @@ for d in sorted(glob.glob(os.path.join(root, 'pmc*')) + glob.glob(os.path.join(r
             acc[r['Kernel_Name'][:60]][r['Counter_Name']].append(float(r['Counter_Value']))
     print('== PMC', os.path.basename(d), '(mean per dispatch)')
     for k, cs in acc.items():
-        if any(x in k for x in ('gemm_bf16x3', 'gemm_mx', 'conv3x3', 'lif_scan', 'li_heads', 'encode', 'rate', 'zero_halo', 'det_payload')):
+        if any(x in k for x in ('gemm_bf16x3', 'gemm_lif_sparse', 'compress_planes', 'permute_planes', 'gemm_mx', 'conv3x3', 'lif_scan', 'li_heads', 'encode', 'rate', 'det_payload')):
             print('  %-60s' % k, '  '.join('%s=%.4g (n=%d)' % (c, sum(v) / len(v), len(v)) for c, v in sorted(cs.items())))

@@ -15,3 +15,6 @@ python tools/prof_e2e.py 3 > /dev/null 2>&1
 export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${TAG}_e2e -- python3 tools/prof_e2e.py 20 > gpurun_out/prof_${TAG}_e2e.log 2>&1
 find gpurun_out/prof_${TAG}_e2e -name "*kernel_trace.csv" -delete
+[ -x tools/_ab/sparse_probe ] && timeout 300 tools/_ab/sparse_probe 2>&1 | grep -v "^  lane" > gpurun_out/${TAG}_sparse_probe.txt; tail -12 gpurun_out/${TAG}_sparse_probe.txt
+[ -f tools/_ab/lib_TL.so ] && SNN_HIP_LIB=tools/_ab/lib_TL.so python tools/sparse_timeline.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_sparse_timeline.txt; cat gpurun_out/${TAG}_sparse_timeline.txt
+for l in NOA NOB NOAB; do [ -f tools/_ab/lib_$l.so ] && { echo "== timing build $l (copies skipped: wrong results)"; SNN_HIP_LIB=tools/_ab/lib_$l.so AB_ROUNDS=2 python tools/ab_knobs.py "" 2>&1 | tail -1; }; done > gpurun_out/${TAG}_sparse_staging_cost.txt 2>&1; cat gpurun_out/${TAG}_sparse_staging_cost.txt

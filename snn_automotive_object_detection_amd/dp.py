@@ -46,8 +46,24 @@ def init_distributed(backend: str = None, timeout_s: float = None) -> Tuple[int,
             torch.cuda.set_device(local)
             os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")    # a timed-out collective aborts the rank
         timeout = datetime.timedelta(seconds=dist_timeout_s() if timeout_s is None else timeout_s)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=timeout)
+        with _stdout_to_stderr():        # gloo announces "[Gloo] Rank 0 is connected to ..." on stdout: rank 0's stdout is the JSON line's
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=timeout)
     return rank, local, world
+
+
+class _stdout_to_stderr:
+    """file descriptor 1 -> 2 for the duration (native libraries write to the descriptor, not to sys.stdout)"""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
 
 
 def backend_name() -> str:

@@ -13,7 +13,7 @@
 // WRONG results by construction.  A build that defines one must say so with -DSNN_EXPERIMENTS; the product build
 // (snn_automotive_object_detection_amd/build.py) never does, and tests/test_code_object.py checks that this guard fires.
 #if !defined(SNN_EXPERIMENTS) && (defined(SNN_EXP_NO_FETCH) || defined(SNN_EXP_NO_GLDS) || defined(SNN_EXP_NO_BARRIER) || \
-    defined(SNN_EXP_CLOCK) || defined(SNN_EXP_TIMELINE) || defined(SNN_EXP_SP_NO_A) || defined(SNN_EXP_SP_NO_B) || defined(SNN_EXP_ONE_WG_PER_CU) || defined(SNN_EXP_MX_NOSTAGE) || defined(SNN_EXP_MX_NOREADB) || defined(SNN_EXP_MX_NOBAR) || \
+    defined(SNN_EXP_CLOCK) || defined(SNN_EXP_TIMELINE) || defined(SNN_EXP_SP_NO_A) || defined(SNN_EXP_SP_NO_B) || defined(SNN_EXP_SP_NO_FIX) || defined(SNN_EXP_ONE_WG_PER_CU) || defined(SNN_EXP_MX_NOSTAGE) || defined(SNN_EXP_MX_NOREADB) || defined(SNN_EXP_MX_NOBAR) || \
     defined(SNN_EXP_MX_NOA) || defined(SNN_EXP_MX_BAR2) || defined(SNN_EXP_MX_RDW_G))
 #error "SNN_EXP_* switches are timing experiments with wrong results: add -DSNN_EXPERIMENTS (never in a product build)"
 #endif

@@ -91,7 +91,19 @@ __global__ __launch_bounds__(256) void k_permute_planes(const uint32_t* __restri
     extern __shared__ uint32_t pl[];                          // [Dw][32 + 1]
     const int t = blockIdx.y, r0 = blockIdx.x * 32, rl = threadIdx.x & 31;
     const bool live = r0 + rl < R;
-    for (int w = threadIdx.x >> 5; w < Dw; w += 8) pl[w * 33 + rl] = live ? in[((size_t)t * Dw + w) * R + r0 + rl] : 0u;
+    // (the row's words are requested in batches of 7: one load in flight per thread made this kernel a chain of memory latencies, 82 -> 48 us
+    // even with register bit moves)
+    for (int w0 = threadIdx.x >> 5; w0 < Dw; w0 += 8 * 7) {
+        uint32_t v[7];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            const int w = w0 + 8 * i;
+            v[i] = (live && w < Dw) ? in[((size_t)t * Dw + w) * R + r0 + rl] : 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < 7; ++i)
+            if (w0 + 8 * i < Dw) pl[(w0 + 8 * i) * 33 + rl] = v[i];
+    }
     __syncthreads();
     const int cbn = C / 32;                                   // channel blocks = words per bin in the permuted order
     for (int cb = threadIdx.x >> 5; cb < cbn; cb += 8) {
@@ -245,7 +257,11 @@ __global__ __launch_bounds__(512, 4) void k_gemm_lif_sparse(const SparseConvArgs
     }
     const int nd_w = __builtin_amdgcn_readfirstlane((int)args.w_nd[wave]), ns_w = __builtin_amdgcn_readfirstlane((int)args.w_ns[wave]);
     // the tile's fix-up list: requested now, sorted in LDS while the first step's operands are on their way (consumed in the epilogue)
+#ifdef SNN_EXP_SP_NO_FIX                            // (timing experiment: what do the fix-up phases cost - wrong results)
+    const int n_fix = 0;
+#else
     const int n_fix = min((int)args.fix_cnt[mb], args.fix_cap);
+#endif
     uint32_t* const fx = reinterpret_cast<uint32_t*>(smem + args.fx_off);       // sorted entries, then the unsorted copy
     uint32_t fx_mine[2] = {0xffffffffu, 0xffffffffu};                            // (fix_cap <= 1024: at most two entries per thread)
 #pragma unroll

@@ -942,52 +942,76 @@ static int count_spikes_per_image(const snn_rpn_level* lv, int n_levels, int Cw,
 
 static size_t sparse_side_bytes(long long P, long long Pe, int Kw, int T);
 // ---- structured-sparse conv (snn_sparse.h): tile geometry + wave assignment ----
-struct SparsePlan { int q, pb, nd; signed char plane[8][SP_MT]; unsigned char j[8][SP_MT], w_nd[8], w_ns[8]; };
+struct SparsePlan { int q, pb, nd, wn; signed char plane[8][SP_MTMAX]; unsigned char j[8][SP_MTMAX], w_nd[8], w_ns[8]; };
 // q = M-tiles (16 positions / RoIs each) per plane.  The conv has thousands of tiles and takes the largest one; a linear layer with a few
 // hundred work-groups takes the q with the fewest rounds of work-groups x work per tile (fc6 at 2000 RoIs, 10 planes: q = 3 is 672
 // work-groups = 1.31 rounds of the 512 slots, q = 2 is 1008 = 1.97 rounds of tiles two thirds the size: 687 -> ~520 us)
-static bool sparse_plan(int Tc, SparsePlan* sp, long long units = 0, int n_blocks = 0) {
-    if (Tc < 4 || Tc > 32) return false;
-    int q = 32 / Tc;
-    const int nd = 2;
-    if (q < 1) return false;
-    if (q > 8) q = 8;
-    if (units > 0 && n_blocks > 0) {
-        const int slots = 2 * g3_slots();
-        int best = 0;
-        double best_cost = 0;
-        for (int c = q; c >= 1; --c) {
-            const long long wgs = (long long)cdiv(units, 16 * c) * n_blocks;
-            const double cost = (double)((wgs + slots - 1) / slots) * (c * (2.0 * nd + 1.1 * (Tc - nd)) + 2.0);
-            if (!best || cost < best_cost * 0.97) { best = c; best_cost = cost; }
-        }
-        q = best;
-    }
+static bool sparse_plan_wn(int Tc, int wn, int q, SparsePlan* sp) {
+    const int nd = 2, nwm = 8 / wn, mts = wn == 1 ? SP_MT : SP_MT2;
+    if (q < 1 || Tc * q > nwm * mts) return false;
     memset(sp, 0, sizeof(*sp));
-    sp->q = q; sp->pb = 16 * q; sp->nd = nd;
+    sp->q = q; sp->pb = 16 * q; sp->nd = nd; sp->wn = wn;
     int used[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     double cost[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int w = 0; w < 8; ++w)
-        for (int m = 0; m < SP_MT; ++m) sp->plane[w][m] = -1;
+        for (int m = 0; m < SP_MTMAX; ++m) sp->plane[w][m] = -1;
     int w_rr = 0;
-    for (int t = 0; t < nd; ++t)                           // dense M-tiles: round-robin (at most two per wave: q <= 8)
+    for (int t = 0; t < nd; ++t)                           // dense M-tiles: round-robin over the row-waves
         for (int jj = 0; jj < q; ++jj) {
-            const int w = w_rr++ % 8;
+            const int w = w_rr++ % nwm;
+            if (used[w] >= mts) return false;
             sp->plane[w][used[w]] = (signed char)t; sp->j[w][used[w]] = (unsigned char)jj;
             ++used[w]; ++sp->w_nd[w]; cost[w] += 2.0;
         }
-    for (int t = nd; t < Tc; ++t)                          // sparse M-tiles: to the cheapest wave with a free slot
+    for (int t = nd; t < Tc; ++t)                          // sparse M-tiles: to the cheapest row-wave with a free slot
         for (int jj = 0; jj < q; ++jj) {
             int best = -1;
-            for (int w = 0; w < 8; ++w)
-                if (used[w] < SP_MT && (best < 0 || cost[w] < cost[best] - 1e-9)) best = w;
+            for (int w = 0; w < nwm; ++w)
+                if (used[w] < mts && (best < 0 || cost[w] < cost[best] - 1e-9)) best = w;
             if (best < 0) return false;
             sp->plane[best][used[best]] = (signed char)t; sp->j[best][used[best]] = (unsigned char)jj;
             ++used[best]; ++sp->w_ns[best]; cost[best] += 1.1;
         }
-    for (int w = 0; w < 8; ++w)
-        if (sp->w_nd[w] > 2 || sp->w_nd[w] + sp->w_ns[w] > SP_MT) return false;
+    // loop instances that exist (snn_sparse.h: SP_CASE)
+    static const int inst1[][2] = {{1, 3}, {1, 2}, {2, 2}, {0, 4}, {0, 3}, {1, 1}, {2, 1}, {0, 2}, {0, 1}, {2, 0}, {1, 0}, {0, 0}};
+    static const int inst2[][2] = {{1, 4}, {1, 5}, {2, 4}, {2, 3}, {1, 3}, {0, 6}, {0, 5}, {2, 2}, {0, 4}, {1, 2}, {0, 3}, {0, 0}};
+    for (int w = 0; w < nwm; ++w) {
+        bool ok = false;
+        for (int i = 0; i < 12; ++i) {
+            const int* c = wn == 1 ? inst1[i] : inst2[i];
+            ok |= c[0] == sp->w_nd[w] && c[1] == sp->w_ns[w];
+        }
+        if (!ok) return false;
+    }
     return true;
+}
+
+// q = M-tiles (16 positions / RoIs each) per plane.  The conv has thousands of tiles and takes the largest one on the 8 x 1 wave grid
+// (its K loop is matrix-pipe-bound there).  A linear layer with a few hundred work-groups takes the (wave grid, q) with the fewest
+// rounds of work-groups x work per tile; on the 8 x 1 grid small tiles are LDS-bound (every wave reads the whole weight slot), so the
+// 4 x 2 grid is preferred where its plan exists (fc6 at 2000 RoIs, 10 planes: q = 2 on 4 x 2 = 1008 work-groups = 1.97 rounds).
+static bool sparse_plan(int Tc, SparsePlan* sp, long long units = 0, int n_blocks = 0) {
+    if (Tc < 4 || Tc > 32) return false;
+    if (!(units > 0 && n_blocks > 0)) {
+        int q = 32 / Tc;
+        if (q > 8) q = 8;
+        return sparse_plan_wn(Tc, 1, q, sp);
+    }
+    const int slots = 2 * g3_slots();
+    bool have = false;
+    double best_cost = 0;
+    SparsePlan cand;
+    for (int wn = 2; wn >= 1; --wn)
+        for (int c = (wn == 1 ? 32 : 24) / Tc; c >= 1; --c) {
+            if (!sparse_plan_wn(Tc, wn, c, &cand)) continue;
+            const long long wgs = (long long)cdiv(units, 16 * c) * n_blocks;
+            // per-tile cost: matrix work + a fixed part; on the 8 x 1 grid a step cannot be shorter than its LDS reads (~ the matrix time of 17 units)
+            double work = c * (2.0 * 2 + 1.1 * (Tc - 2));
+            if (wn == 1 && work < 34.0) work = 34.0;
+            const double cost = (double)((wgs + slots - 1) / slots) * (work + 2.0);
+            if (!have || cost < best_cost * 0.97) { *sp = cand; best_cost = cost; have = true; }
+        }
+    return have;
 }
 
 // the sparse launch pair: compress the planes e_3 .., then the mixed dense / sparse contraction + LIF (conv: the RPN's shared 3x3
@@ -1044,13 +1068,13 @@ static int gemm3_lif_sparse(const Gemm3Args& a, bool conv, void* side, size_t si
     sa.fx_off = max((int)SP_LDS, a.Tc * sp.pb * SP_PITCH * 4);
     const int lds = sa.fx_off + 2 * fix_cap * 4;
     if (fix_cap > 1024 || lds > 80 * 1024) return 0;
-    const void* kern = conv ? (const void*)k_gemm_lif_sparse<true> : (const void*)k_gemm_lif_sparse<false>;
+    const void* kern = conv ? (const void*)k_gemm_lif_sparse<true, 1> : sp.wn == 2 ? (const void*)k_gemm_lif_sparse<false, 2> : (const void*)k_gemm_lif_sparse<false, 1>;
     hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return fail(-3, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
     if (knobs().debug_occ) {
         int v = 0;
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, kern, 512, lds);
-        fprintf(stderr, "k_gemm_lif_sparse<%d>: pb %d x Tc %d, q %d, lds %d B, %d work-groups per CU, grid %d\n", (int)conv, sp.pb, a.Tc, sp.q, lds, v, grid);
+        fprintf(stderr, "k_gemm_lif_sparse<%d, %d>: pb %d x Tc %d, q %d, lds %d B, %d work-groups per CU, grid %d\n", (int)conv, sp.wn, sp.pb, a.Tc, sp.q, lds, v, grid);
     }
     void* kargs[] = {(void*)&sa};
     e = hipLaunchKernel(kern, dim3(grid), dim3(512), kargs, lds, s);

@@ -26,8 +26,10 @@
 typedef __bf16 bfv8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bfv16 __attribute__((ext_vector_type(16)));
 
-#define SP_MT 4                                     // M-tile slots per wave
-#define SP_ROWS (8 * SP_MT * 16)                    // physical tile rows (512)
+#define SP_MT 4                                     // M-tile slots per wave on the 8 x 1 wave grid (all waves span the 64 columns)
+#define SP_MT2 6                                    // ... per ROW-wave on the 4 x 2 grid (two waves of 32 columns share a row-wave's slots)
+#define SP_MTMAX 6
+#define SP_ROWS (8 * SP_MT * 16)                    // physical tile rows (512; 4 x 6 x 16 = 384 on the 4 x 2 grid)
 #define SP_A_BYTES (3 * SP_ROWS * 4)                // three dword arrays per step: dense rows use two (the chunks' spike words), sparse rows
                                                     // three (occupancy bytes of the four 16-k blocks, index halves 0-1, index halves 2-3)
 #define SP_B_BYTES (2 * 3 * 64 * G3_ROWB)           // two chunks x three weight planes x 64 columns
@@ -50,9 +52,9 @@ struct SparseConvArgs {
     int M, Kc, Np, Cw, n_blocks, n_tiles, n_levels;
     int T, Tc, nd, pb, q, fix_cap, out_split;
     int fx_off;                  // LDS byte offset of the tile's sorted fix-up list (behind the ring and behind the epilogue's tile image)
-    signed char mt_plane[8][SP_MT];      // plane of the wave's M-tile slot (-1: unused); dense planes (< nd) first
-    unsigned char mt_j[8][SP_MT];        // position block of the slot: local positions 16 j ..
-    unsigned char w_nd[8], w_ns[8];      // dense / sparse M-tiles of the wave
+    signed char mt_plane[8][SP_MTMAX];   // plane of the row-wave's M-tile slot (-1: unused); dense planes (< nd) first
+    unsigned char mt_j[8][SP_MTMAX];     // position block of the slot: local positions 16 j ..
+    unsigned char w_nd[8], w_ns[8];      // dense / sparse M-tiles of the row-wave
     int xcd_contig, xcd_cpx;             // block order, as Gemm3Args
     NeuronP p;
     ConvLevelDev lv[SNN_MAX_LEVELS];
@@ -222,8 +224,12 @@ __device__ __forceinline__ void sp_lif_fixed(const float* src, const int group_s
     }
 }
 
-template <bool CONV>
+// WN = waves along the 64 columns.  1: 8 row-waves x 4 slots, every wave reads the whole weight slot from LDS each step (192 KB per
+// work-group and step).  2: 4 row-waves x 6 slots, a wave covers 32 columns and reads half of the slot (96 KB): the shape for launches whose
+// matrix-pipe time per step is below what those LDS reads take - fc6, whose tiles hold 32 RoIs (tools: profiles/r4_sparse_timeline.txt).
+template <bool CONV, int WN>
 __global__ __launch_bounds__(512, 4) void k_gemm_lif_sparse(const SparseConvArgs args) {
+    constexpr int MTS = WN == 1 ? SP_MT : SP_MT2, NT = 4 / WN;      // slots per (row-)wave, 16-column N-tiles per wave
     if (*args.flag != 0u) return;                            // a fix-up list overflowed: the dense launch behind this one does the work
 #ifdef SNN_EXP_TIMELINE     // diagnostic build: wall-clock stamps (s_memrealtime, 100 MHz) of the work-group's phases
     unsigned long long tl_entry = 0, tl_loop0 = 0, tl_loop1 = 0, tl_epi = 0;
@@ -236,6 +242,7 @@ __global__ __launch_bounds__(512, 4) void k_gemm_lif_sparse(const SparseConvArgs
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, lg = lane >> 4;
+    const int wm = wave / WN, wn = wave % WN;                       // row-wave, column-wave
     // block order: XCD x = blockIdx % 8 takes xcd_cpx column blocks on a contiguous range of row tiles (k_gemm_bf16x3: xcd_contig)
     // (xcd_contig == 0 - the linear layers: plain order, column block fastest: an XCD only ever sees two weight panels, and all
     // work-groups of a panel walk K together)
@@ -255,7 +262,7 @@ __global__ __launch_bounds__(512, 4) void k_gemm_lif_sparse(const SparseConvArgs
         q.x = bf16_pair(tid, 0); q.y = bf16_pair(tid, 1); q.z = bf16_pair(tid, 2); q.w = bf16_pair(tid, 3);
         *reinterpret_cast<uint4*>(lut + tid * 16) = q;
     }
-    const int nd_w = __builtin_amdgcn_readfirstlane((int)args.w_nd[wave]), ns_w = __builtin_amdgcn_readfirstlane((int)args.w_ns[wave]);
+    const int nd_w = __builtin_amdgcn_readfirstlane((int)args.w_nd[wm]), ns_w = __builtin_amdgcn_readfirstlane((int)args.w_ns[wm]);
     // the tile's fix-up list: requested now, sorted in LDS while the first step's operands are on their way (consumed in the epilogue)
 #ifdef SNN_EXP_SP_NO_FIX                            // (timing experiment: what do the fix-up phases cost - wrong results)
     const int n_fix = 0;
@@ -268,14 +275,16 @@ __global__ __launch_bounds__(512, 4) void k_gemm_lif_sparse(const SparseConvArgs
     for (int i = 0; i < 2; ++i)
         if (tid + 512 * i < n_fix) fx_mine[i] = args.fix[(size_t)mb * args.fix_cap + tid + 512 * i];
 
-    // ---- A staging: lane L of the wave stages physical row 64 wave + L = slot L >> 4, row L & 15 of that M-tile
-    const int xs = lane >> 4;
-    const int xplane = args.mt_plane[wave][xs];
+    // ---- A staging: lane L of the wave stages row L & 15 of one M-tile slot of its row-wave.  WN = 1: slot L >> 4 (64 rows per wave);
+    // WN = 2: the two column-waves of a row-wave take three slots each (lanes 0 .. 47)
+    const int xs = WN == 1 ? (lane >> 4) : min(3 * wn + (lane >> 4), MTS - 1);
+    const bool a_lane = WN == 1 || lane < 48;
+    const int xplane = args.mt_plane[wm][xs];
     const bool xused = xplane >= 0, xdense = xused && xplane < args.nd;
     uint32_t voff0, voff1, voff2, inc;                      // byte offsets from args.enc
     uint32_t tap_fix, row_fix;
     {
-        const int lp = min(args.mt_j[wave][xs] * 16 + (lane & 15), pb - 1);
+        const int lp = min(args.mt_j[wm][xs] * 16 + (lane & 15), pb - 1);
         const int p = min(m0 + (xused ? lp : 0), M - 1);
         uint32_t row0 = (uint32_t)p;                        // linear layer: the RoI
         int W = 0;
@@ -307,16 +316,17 @@ __global__ __launch_bounds__(512, 4) void k_gemm_lif_sparse(const SparseConvArgs
         tap_fix = 4u - (uint32_t)Cw2 * inc;                 // next tap of the row: one position on, back to channel word 0
         row_fix = (uint32_t)((W + 2 - 3) * 4);              // after the third tap of a row: one padded image row down
     }
-    const uint32_t a_dst = smem_base + G3_LUT_BYTES + wave * 256;
+    const uint32_t a_dst = smem_base + G3_LUT_BYTES + (WN == 1 ? wave * 256 : (wm * MTS + 3 * wn) * 64);    // physical row (wm MTS + slot) 16 + r
     const void* const a_base = sgpr_ptr(args.enc);
     const int cw2_s = __builtin_amdgcn_readfirstlane(args.Cw / 2);
     int f_c = 0, f_tap = 0;
     auto stage_a = [&](const uint32_t slot_off) __attribute__((always_inline)) {
         const uint32_t d = __builtin_amdgcn_readfirstlane(a_dst + slot_off);
-        asm volatile("s_mov_b32 m0, %4\n\ts_nop 4\n\tglobal_load_lds_dword %0, %3\n\t"
-                     "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dword %1, %3\n\t"
-                     "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dword %2, %3"
-                     :: "v"(voff0), "v"(voff1), "v"(voff2), "s"(a_base), "s"(d), "s"(d + SP_ROWS * 4), "s"(d + 2 * SP_ROWS * 4) : "memory");
+        if (a_lane)
+            asm volatile("s_mov_b32 m0, %4\n\ts_nop 4\n\tglobal_load_lds_dword %0, %3\n\t"
+                         "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dword %1, %3\n\t"
+                         "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dword %2, %3"
+                         :: "v"(voff0), "v"(voff1), "v"(voff2), "s"(a_base), "s"(d), "s"(d + SP_ROWS * 4), "s"(d + 2 * SP_ROWS * 4) : "memory");
         voff0 += inc; voff1 += inc; voff2 += inc;
         if (!CONV) return;
         f_c = __builtin_amdgcn_readfirstlane(f_c + 1);
@@ -345,13 +355,13 @@ __global__ __launch_bounds__(512, 4) void k_gemm_lif_sparse(const SparseConvArgs
         s_ptr += 2 * b_chunk;
     };
 
-    const unsigned char* const a_rd = ring + (wave * 64 + lr) * 4;                          // + slot offset, M-tile slot * 64
-    const unsigned char* const b_rd = ring + SP_A_BYTES + lr * G3_ROWB + ((lg ^ G3_SWZ(lr)) << 4);
-    f32x4 acc[SP_MT][4];
+    const unsigned char* const a_rd = ring + (wm * MTS * 16 + lr) * 4;                      // + slot offset, M-tile slot * 64
+    const unsigned char* const b_rd = ring + SP_A_BYTES + (wn * NT * 16 + lr) * G3_ROWB + ((lg ^ G3_SWZ(lr)) << 4);
+    f32x4 acc[MTS][NT];
 #pragma unroll
-    for (int mt = 0; mt < SP_MT; ++mt)
+    for (int mt = 0; mt < MTS; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
     const int n_steps = Kc / 2;
     stage_a(0); stage_b(0);
@@ -409,9 +419,9 @@ __global__ __launch_bounds__(512, 4) void k_gemm_lif_sparse(const SparseConvArgs
             bfv8 b0 = *reinterpret_cast<const bfv8*>(b_rd + o_cur + 2 * (64 * G3_ROWB));
             bfv8 b1 = *reinterpret_cast<const bfv8*>(b_rd + o_cur + 3 * 64 * G3_ROWB + 2 * (64 * G3_ROWB));
 #pragma unroll
-            for (int g = 0; g < 12; ++g) {                  // group = (N-tile g / 3, plane 2 - g % 3): small terms first
+            for (int g = 0; g < 3 * NT; ++g) {              // group = (N-tile g / 3, plane 2 - g % 3): small terms first
                 bfv8 n0 = b0, n1 = b1;
-                if (g + 1 < 12) {
+                if (g + 1 < 3 * NT) {
                     const int gn = g + 1;
                     n0 = *reinterpret_cast<const bfv8*>(b_rd + o_cur + (2 - gn % 3) * (64 * G3_ROWB) + (gn / 3) * 16 * G3_ROWB);
                     n1 = *reinterpret_cast<const bfv8*>(b_rd + o_cur + 3 * 64 * G3_ROWB + (2 - gn % 3) * (64 * G3_ROWB) + (gn / 3) * 16 * G3_ROWB);
@@ -439,10 +449,18 @@ __global__ __launch_bounds__(512, 4) void k_gemm_lif_sparse(const SparseConvArgs
         }
     };
 #define SP_CASE(ND_, NS_) if (nd_w == ND_ && ns_w == NS_) step_loop(std::integral_constant<int, ND_>{}, std::integral_constant<int, NS_>{}); else
-    SP_CASE(1, 3) SP_CASE(1, 2) SP_CASE(2, 2) SP_CASE(0, 4) SP_CASE(0, 3) SP_CASE(1, 1) SP_CASE(2, 1) SP_CASE(0, 2) SP_CASE(0, 1)
-    SP_CASE(2, 0) SP_CASE(1, 0)
-    {   // a wave without M-tiles still stages and keeps the barriers
-        step_loop(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    if constexpr (WN == 1) {
+        SP_CASE(1, 3) SP_CASE(1, 2) SP_CASE(2, 2) SP_CASE(0, 4) SP_CASE(0, 3) SP_CASE(1, 1) SP_CASE(2, 1) SP_CASE(0, 2) SP_CASE(0, 1)
+        SP_CASE(2, 0) SP_CASE(1, 0)
+        {   // a wave without M-tiles still stages and keeps the barriers
+            step_loop(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        }
+    } else {
+        SP_CASE(1, 4) SP_CASE(1, 5) SP_CASE(2, 4) SP_CASE(2, 3) SP_CASE(1, 3) SP_CASE(0, 6) SP_CASE(0, 5) SP_CASE(2, 2) SP_CASE(0, 4)
+        SP_CASE(1, 2) SP_CASE(0, 3)
+        {
+            step_loop(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        }
     }
 #undef SP_CASE
 
@@ -458,16 +476,22 @@ __global__ __launch_bounds__(512, 4) void k_gemm_lif_sparse(const SparseConvArgs
 #pragma unroll 1
     for (int h = 0; h < 2; ++h) {
         __syncthreads();
+        if (WN == 1 || wn == h) {                              // (4 x 2 grid: the column-wave that holds this pass's 32 columns)
 #pragma unroll
-        for (int mt = 0; mt < SP_MT; ++mt) {
-            const int plane = args.mt_plane[wave][mt];         // wave-uniform
-            if (plane < 0) continue;
-            const int lp0 = args.mt_j[wave][mt] * 16 + lg * 4;
+            for (int mt = 0; mt < MTS; ++mt) {
+                const int plane = args.mt_plane[wm][mt];       // wave-uniform
+                if (plane < 0) continue;
+                const int lp0 = args.mt_j[wm][mt] * 16 + lg * 4;
 #pragma unroll
-            for (int nq = 0; nq < 2; ++nq)
+                for (int nq = 0; nq < 2; ++nq)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (lp0 + r < pb) tile[(plane * pb + lp0 + r) * SP_PITCH + nq * 16 + lr] = h == 0 ? acc[mt][nq][r] : acc[mt][2 + nq][r];
+                    for (int r = 0; r < 4; ++r) {
+                        float val;
+                        if constexpr (WN == 1) val = h == 0 ? acc[mt][nq][r] : acc[mt][2 + nq][r];
+                        else val = acc[mt][nq][r];
+                        if (lp0 + r < pb) tile[(plane * pb + lp0 + r) * SP_PITCH + nq * 16 + lr] = val;
+                    }
+            }
         }
         __syncthreads();
         if (n_fix > 0) {

@@ -35,10 +35,14 @@ def nchw_to_rows(z: torch.Tensor) -> np.ndarray:
 #   RPN on N(0,1) pyramids  : 7 / 12 / 16 of 196 416 positions (bf16x3 / f32 / mxfp6) = 1.7e-8 .. 4e-8 -> rate 8e-8 (mxfp6 x2:
 #                             its digit planes round weights at 2^-29 of the block maximum)
 #   RPN behind the backbone : 35 - 43 of 196 416 (firing rates are 3x those of N(0,1) inputs) = 8.7e-8 .. 1.07e-7 -> rate 1.5e-7 (round 4; 2.5e-7 before)
-#   detector                : 0 - 2 of 2000 RoIs on N(0,1) (bf16x3 / f32), 8 in situ / mxfp6, 9 at T = 24 = 0 .. 1.6e-7 -> 2.5e-7
+#   detector                : 0 - 2 of 2000 RoIs on N(0,1) (bf16x3 / f32), 7 - 8 mxfp6, 9 at T = 24 = 0 .. 1.6e-7 -> 2.5e-7
+#   detector behind the backbone: 7 of 2000 RoIs while fc6 summed in the reference's flatten order (round 3); 9 - 12 since round 4, whose fc6
+#                             runs bin-major (k' = bin * C + c) and on the structured-sparse instruction - an order less like the oracle's
+#                             k-ascending blocks, so the two fp32 errors are less correlated and more exact ties fall differently (same-lease
+#                             A/B: 7, 7 reference order / 9, 11 bin-major dense / 12, 12 bin-major sparse) = 2.4e-7           -> rate 5e-7
 # Every full-size test also ATTRIBUTES its flips (first_flip_margins): each first differing spike sits within TIE_MARGIN of the
 # threshold in the oracle's trace, so a regression that flips spikes away from ties fails whatever the count.
-FLIP_RATE = {"rpn_randn": 8e-8, "rpn_in_situ": 1.5e-7, "det": 2.5e-7}
+FLIP_RATE = {"rpn_randn": 8e-8, "rpn_in_situ": 1.5e-7, "det": 2.5e-7, "det_in_situ": 5e-7}
 PRECISION_FACTOR = {"bf16x3": 1.0, "f32": 1.0, "mxfp6": 2.0}
 TIE_MARGIN = 5e-7            # observed: every first flip sits within 6e-8 of the threshold (profiles/parity_r3.json, parity_r4.json)
 

@@ -107,8 +107,9 @@ def test_create_model_end_to_end_and_heads_in_situ(gpu_device, full, fused):
                                    dh.bbox_pred.weight.cpu(), 12)
     dd = torch.maximum((cap["det_out"][0] - o_c).abs().amax(1), (cap["det_out"][1] - o_d).abs().amax(1))
     record_parity("e2e_det_head_in_situ", full=full, fused_roialign=fused, rois_off_tolerance=int((dd > 1e-4).sum()), rois=dd.numel(),
-                  budget=flip_budget(dd.numel(), 2 * 1024, 12, "det"))
-    assert int((dd > 1e-4).sum()) <= flip_budget(dd.numel(), 2 * 1024, 12, "det")
+                  budget=flip_budget(dd.numel(), 2 * 1024, 12, "det_in_situ"))
+    assert int((dd > 1e-4).sum()) <= flip_budget(dd.numel(), 2 * 1024, 12, "det_in_situ")
+    assert float(dd.max()) < 0.05                                      # a flipped spike moves an output by ~1e-3, never by much
     # RPN proposal selection in situ (snn_rpn_proposals on the head's own outputs) against the oracle restatement of
     # rpn.py:563-703: same proposals in the same order, up to rows that involve exactly tied logits (a random-init head
     # leaves some logits exactly 0; which of equal logits torch.topk takes first is unspecified)

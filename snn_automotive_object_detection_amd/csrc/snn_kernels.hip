@@ -973,7 +973,7 @@ static bool sparse_plan_wn(int Tc, int wn, int q, SparsePlan* sp) {
             ++used[best]; ++sp->w_ns[best]; cost[best] += 1.1;
         }
     // loop instances that exist (snn_sparse.h: SP_CASE)
-    static const int inst1[][2] = {{1, 3}, {1, 2}, {2, 2}, {0, 4}, {0, 3}, {1, 1}, {2, 1}, {0, 2}, {0, 1}, {2, 0}, {1, 0}, {0, 0}, {3, 1}, {3, 0}};
+    static const int inst1[][2] = {{1, 3}, {1, 2}, {2, 2}, {0, 4}, {0, 3}, {1, 1}, {2, 1}, {0, 2}, {0, 1}, {2, 0}, {1, 0}, {0, 0}, {0, 0}, {0, 0}};
     static const int inst2[][2] = {{1, 4}, {1, 5}, {2, 4}, {2, 3}, {1, 3}, {0, 6}, {0, 5}, {2, 2}, {0, 4}, {1, 2}, {0, 3}, {0, 0}, {0, 0}, {0, 0}};
     for (int w = 0; w < nwm; ++w) {
         bool ok = false;
@@ -991,7 +991,7 @@ static bool sparse_plan_wn(int Tc, int wn, int q, SparsePlan* sp) {
 // rounds of work-groups x work per tile; on the 8 x 1 grid small tiles are LDS-bound (every wave reads the whole weight slot), so the
 // 4 x 2 grid is preferred where its plan exists (fc6 at 2000 RoIs, 10 planes: q = 2 on 4 x 2 = 1008 work-groups = 1.97 rounds).
 static bool sparse_plan(int Tc, SparsePlan* sp, long long units = 0, int n_blocks = 0) {
-    if (Tc < 3 || Tc > 32) return false;
+    if (Tc < 4 || Tc > 32) return false;
     if (!(units > 0 && n_blocks > 0)) {
         int q = 32 / Tc;
         if (q > 8) q = 8;
@@ -1021,7 +1021,7 @@ static bool sparse_plan(int Tc, SparsePlan* sp, long long units = 0, int n_block
 static int gemm3_lif_sparse(const Gemm3Args& a, bool conv, void* side, size_t side_bytes, const uint32_t** flag_out, hipStream_t s) {
     SparsePlan sp;
     const int Kw = conv ? a.Cw : a.Kc;                        // plane words per row
-    if (!knobs().sparse || !side || !a.wm || !a.periods || a.cnt_img || a.cnt_row || Kw % 2 || a.Np % 64 || a.Kc * 32 > 65536 || a.T < 4 || a.T > 16 ||
+    if (!knobs().sparse || !side || !a.wm || !a.periods || a.cnt_img || a.cnt_row || Kw % 2 || a.Np % 64 || a.Kc * 32 > 65536 || a.T < 5 || a.T > 16 ||          /* (T = 4: built and measured 2.3 % slower than the dense launch) */
         a.Tc != a.T - (conv ? 1 : 2) || a.t0 != 0 || a.p.v_leak != 0.0f || (float)(a.p.v_leak - a.p.v_th) > 0.0f || (!conv && !a.out_wm) ||
         !sparse_plan(a.Tc, &sp, conv ? 0 : a.M, a.Np / 64))
         return 0;

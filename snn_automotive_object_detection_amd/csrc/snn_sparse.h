@@ -451,7 +451,7 @@ __global__ __launch_bounds__(512, 4) void k_gemm_lif_sparse(const SparseConvArgs
 #define SP_CASE(ND_, NS_) if (nd_w == ND_ && ns_w == NS_) step_loop(std::integral_constant<int, ND_>{}, std::integral_constant<int, NS_>{}); else
     if constexpr (WN == 1) {
         SP_CASE(1, 3) SP_CASE(1, 2) SP_CASE(2, 2) SP_CASE(0, 4) SP_CASE(0, 3) SP_CASE(1, 1) SP_CASE(2, 1) SP_CASE(0, 2) SP_CASE(0, 1)
-        SP_CASE(2, 0) SP_CASE(1, 0) SP_CASE(3, 1) SP_CASE(3, 0)          // (three dense M-tiles: T = 4, whose tile has two dense planes of three)
+        SP_CASE(2, 0) SP_CASE(1, 0)
         {   // a wave without M-tiles still stages and keeps the barriers
             step_loop(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
         }
@@ -538,7 +538,7 @@ __global__ __launch_bounds__(512, 4) void k_gemm_lif_sparse(const SparseConvArgs
             const float* src = tile + (live ? pi : 2 * pp) * SP_PITCH + col;
             switch (T) {
 #define SP_T(n) case n: sp_lif_fixed<n, CONV ? 1 : 2>(src, group_stride, args.p, my0, my1); break;
-                SP_T(4) SP_T(5) SP_T(6) SP_T(7) SP_T(8) SP_T(9) SP_T(10) SP_T(11) SP_T(12) SP_T(13) SP_T(14) SP_T(15) SP_T(16)
+                SP_T(5) SP_T(6) SP_T(7) SP_T(8) SP_T(9) SP_T(10) SP_T(11) SP_T(12) SP_T(13) SP_T(14) SP_T(15) SP_T(16)
 #undef SP_T
             default: break;
             }

@@ -43,7 +43,7 @@ def _off_positions(a, b, tol=1e-4):
     return bad, mx
 
 
-@pytest.mark.parametrize("T", [4, 5, 6, 7, 8, 9, 10, 12, 14, 16])
+@pytest.mark.parametrize("T", [5, 6, 7, 8, 9, 10, 12, 14, 16])
 def test_sparse_conv_equals_dense_up_to_ties(gpu_device, monkeypatch, T):
     m = _head(gpu_device, 256, T, T)
     g = torch.Generator().manual_seed(T)

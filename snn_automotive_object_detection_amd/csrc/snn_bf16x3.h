@@ -128,9 +128,6 @@ struct Gemm3Args {
     // 8 x 1 grid), which is what lets a launch of a few hundred work-groups come out at a whole number of rounds per CU
     // (launchers: g3_pick_tile).  Logical tile row (what t * pb + position counts) = physical row - 16 * (short waves before it).
     int n_short;
-    // nullable: run only if *run_if != 0 (the dense launch behind the structured-sparse conv, snn_sparse.h: it does the work when a
-    // fix-up list of the sparse launch overflowed, and leaves at once otherwise)
-    const uint32_t* run_if;
     NeuronP p;
     ConvLevelDev lv[SNN_MAX_LEVELS];
 };
@@ -225,7 +222,6 @@ template <int MODE, int NB, int MT, int WN>
 __device__ __forceinline__ void gemm_bf16x3_body(const Gemm3Args& args, const int bid, const Gemm3Dep dep) {
     constexpr bool CONV = MODE == G3_CONV || MODE == G3_CONV_LIF_REG || MODE == G3_CONV_LIF_TILE;
     constexpr bool FUSE = MODE == G3_CONV_LIF_REG, TILE = MODE == G3_CONV_LIF_TILE || MODE == G3_FC_LIF_TILE;
-    if (TILE && args.run_if != nullptr && *args.run_if == 0u) return;
     static_assert(((MT >= 2 && MT <= 4) || MT == 8) && (MT == 4 || !FUSE), "M-tiles per wave");
     static_assert(WN == 1 || (WN == 2 && true), "waves along N");
     static_assert(WN == 2 || !FUSE, "the register-fused variant keeps the 4 x 2 wave grid");

@@ -203,14 +203,19 @@ __global__ __launch_bounds__(256) void k_li_heads_mfma(const LiHeadsArgs a) {
         f32x4 o_last[NT], o_sum[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) { o_last[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; o_sum[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        for (int tg0 = 0; tg0 < a.T; tg0 += LIH_TG) {
-            const int tn = min(LIH_TG, a.T - tg0);              // block-uniform
-            f32x4 acc[LIH_TG][NT];
+        // One group of up to LIH_TG time steps.  TN (the steps whose accumulators exist) is a COMPILE-TIME constant: 8, or 4 / 2 / 1 for a
+        // shorter last group; steps past the group's real count tn < TN multiply all-zero spike words (exact: their sums stay 0).
+        // (Until round 4 the loops tested t < tn at run time; the compiler specialised the unrolled chunks on tn itself, and its tn == 2
+        // variant of the Kc == 8 path returned wrong sums in accumulator register 3 - rows 3 mod 4 of every tile, T = 2, 10, 18, 26 at
+        // C = 256; nothing here depends on run-time control flow around the MFMAs any more.  tests/test_gpu_stages.py sweeps T = 1 .. 26.)
+        auto group = [&](auto tn_c, const int tg0, const int tn) __attribute__((always_inline)) {
+            constexpr int TN = decltype(tn_c)::value;
+            f32x4 acc[TN][NT];
 #pragma unroll
-            for (int t = 0; t < LIH_TG; ++t)
+            for (int t = 0; t < TN; ++t)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) acc[t][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            auto chunk = [&](int kc, const uint32_t (&w_cur)[LIH_TG]) {
+            auto chunk = [&](int kc, const uint32_t (&w_cur)[TN]) {
                 const unsigned char* bs = b_rd + (size_t)(a.resident ? kc : (kc & 1)) * slot_bytes;
                 bf16x8 b[3][NT];
 #pragma unroll
@@ -219,48 +224,47 @@ __global__ __launch_bounds__(256) void k_li_heads_mfma(const LiHeadsArgs a) {
                     for (int nt = 0; nt < NT; ++nt)
                         b[pl][nt] = *reinterpret_cast<const bf16x8*>(bs + (pl * NOp + nt * 16) * 64);
 #pragma unroll
-                for (int t = 0; t < LIH_TG; ++t) {
-                    if (t < tn) {
-                        const bf16x8 af = *reinterpret_cast<const bf16x8*>(lut + (__builtin_amdgcn_ubfe(w_cur[t], lg8, 8) << 4));
+                for (int t = 0; t < TN; ++t) {
+                    const bf16x8 af = *reinterpret_cast<const bf16x8*>(lut + (__builtin_amdgcn_ubfe(w_cur[t], lg8, 8) << 4));
 #pragma unroll
-                        for (int pl = 2; pl >= 0; --pl)
+                    for (int pl = 2; pl >= 0; --pl)
 #pragma unroll
-                            for (int nt = 0; nt < NT; ++nt)
-                                acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, b[pl][nt], acc[t][nt], 0, 0, 0);
-                    }
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, b[pl][nt], acc[t][nt], 0, 0, 0);
                 }
             };
             if (a.resident && Kc == 8) {
                 // C = 256: the 8 spike words of a (t, row) are one 32-byte line - all T x 8 words are requested up
                 // front (one memory latency per row tile instead of one per chunk)
-                uint4 wl[LIH_TG][2];
+                uint4 wl[TN][2];
 #pragma unroll
-                for (int t = 0; t < LIH_TG; ++t) {
+                for (int t = 0; t < TN; ++t) {
                     const uint4* q = reinterpret_cast<const uint4*>(wsrc + (size_t)(tg0 + (t < tn ? t : 0)) * a.spk_stride);
                     wl[t][0] = q[0]; wl[t][1] = a.half_split ? q[(size_t)a.M] : q[1];     // second half: M x 16 bytes on
+                    if (t >= tn) { wl[t][0] = uint4{0u, 0u, 0u, 0u}; wl[t][1] = uint4{0u, 0u, 0u, 0u}; }
                 }
 #pragma unroll
                 for (int kc = 0; kc < 8; ++kc) {
-                    uint32_t w_cur[LIH_TG];
+                    uint32_t w_cur[TN];
 #pragma unroll
-                    for (int t = 0; t < LIH_TG; ++t) {
+                    for (int t = 0; t < TN; ++t) {
                         const uint4 v = wl[t][kc >> 2];
                         w_cur[t] = (kc & 3) == 0 ? v.x : (kc & 3) == 1 ? v.y : (kc & 3) == 2 ? v.z : v.w;
                     }
                     chunk(kc, w_cur);
                 }
             } else {
-                uint32_t w_nxt[LIH_TG];
+                uint32_t w_nxt[TN];
 #pragma unroll
-                for (int t = 0; t < LIH_TG; ++t) w_nxt[t] = t < tn ? wsrc[(size_t)(tg0 + t) * a.spk_stride] : 0u;
+                for (int t = 0; t < TN; ++t) w_nxt[t] = t < tn ? wsrc[(size_t)(tg0 + t) * a.spk_stride] : 0u;
                 if (!a.resident) { stage(0, 0); __syncthreads(); }
                 for (int kc = 0; kc < Kc; ++kc) {
-                    uint32_t w_cur[LIH_TG];
+                    uint32_t w_cur[TN];
 #pragma unroll
-                    for (int t = 0; t < LIH_TG; ++t) w_cur[t] = w_nxt[t];
+                    for (int t = 0; t < TN; ++t) w_cur[t] = w_nxt[t];
                     if (kc + 1 < Kc) {
 #pragma unroll
-                        for (int t = 0; t < LIH_TG; ++t) w_nxt[t] = t < tn ? wsrc[(size_t)(tg0 + t) * a.spk_stride + kc + 1] : 0u;
+                        for (int t = 0; t < TN; ++t) w_nxt[t] = t < tn ? wsrc[(size_t)(tg0 + t) * a.spk_stride + kc + 1] : 0u;
                         if (!a.resident) stage(kc + 1, (kc + 1) & 1);
                     }
                     chunk(kc, w_cur);
@@ -268,17 +272,24 @@ __global__ __launch_bounds__(256) void k_li_heads_mfma(const LiHeadsArgs a) {
                 }
             }
 #pragma unroll
-            for (int t = 0; t < LIH_TG; ++t)
-                if (t < tn) {
-                    const float kl = a.kap.last[tg0 + t], ks = a.kap.sum[tg0 + t];
+            for (int t = 0; t < TN; ++t) {
+                const int ti = min(tg0 + t, a.T - 1);           // (steps past tn: their accumulators are zero)
+                const float kl = a.kap.last[ti], ks = a.kap.sum[ti];
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
+                for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            o_last[nt][r] = fmaf(kl, acc[t][nt][r], o_last[nt][r]);
-                            o_sum[nt][r] = fmaf(ks, acc[t][nt][r], o_sum[nt][r]);
-                        }
-                }
+                    for (int r = 0; r < 4; ++r) {
+                        o_last[nt][r] = fmaf(kl, acc[t][nt][r], o_last[nt][r]);
+                        o_sum[nt][r] = fmaf(ks, acc[t][nt][r], o_sum[nt][r]);
+                    }
+            }
+        };
+        for (int tg0 = 0; tg0 < a.T; tg0 += LIH_TG) {
+            const int tn = min(LIH_TG, a.T - tg0);              // block-uniform
+            if (tn > 4) group(std::integral_constant<int, 8>{}, tg0, tn);
+            else if (tn > 2) group(std::integral_constant<int, 4>{}, tg0, tn);
+            else if (tn == 2) group(std::integral_constant<int, 2>{}, tg0, tn);
+            else group(std::integral_constant<int, 1>{}, tg0, tn);
         }
         // lane holds rows lg*4 + r, output column nt*16 + lr
 #pragma unroll

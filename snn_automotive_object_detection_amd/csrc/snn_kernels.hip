@@ -1016,9 +1016,8 @@ static bool sparse_plan(int Tc, SparsePlan* sp, long long units = 0, int n_block
 
 // the sparse launch pair: compress the planes e_3 .., then the mixed dense / sparse contraction + LIF (conv: the RPN's shared 3x3
 // convolution; !conv: a linear layer on word-major period planes - the detector's fc6).  `side` = sparse_side_bytes() of scratch.
-// Returns 1 if the launches were enqueued (the caller then enqueues the dense launch with Gemm3Args.run_if = *flag_out), 0 if this
-// configuration takes the dense path only, negative on error.
-static int gemm3_lif_sparse(const Gemm3Args& a, bool conv, void* side, size_t side_bytes, const uint32_t** flag_out, hipStream_t s) {
+// Returns 1 if the launches were enqueued (the layer is done), 0 if this configuration takes the dense launch, negative on error.
+static int gemm3_lif_sparse(const Gemm3Args& a, bool conv, void* side, size_t side_bytes, hipStream_t s) {
     SparsePlan sp;
     const int Kw = conv ? a.Cw : a.Kc;                        // plane words per row
     if (!knobs().sparse || !side || !a.wm || !a.periods || a.cnt_img || a.cnt_row || Kw % 2 || a.Np % 64 || a.Kc * 32 > 65536 || a.T < 5 || a.T > 16 ||          /* (T = 4: built and measured 2.3 % slower than the dense launch) */
@@ -1027,32 +1026,23 @@ static int gemm3_lif_sparse(const Gemm3Args& a, bool conv, void* side, size_t si
         return 0;
     const long long P = a.M, Pe = (long long)a.a_step;
     if (side_bytes < sparse_side_bytes(P, Pe, Kw, a.T)) return 0;
-    char* w = (char*)side;
-    uint32_t* cmp = (uint32_t*)w;
-    w += align_up((size_t)a.T * (Kw / 2) * 3 * (size_t)Pe * 4, 256);
-    uint32_t* fix = (uint32_t*)w;
-    w += align_up((size_t)SP_FIX_PER_POS * P * 4 + 4096 * SP_FIX_PER_POS, 256);
-    uint32_t* fix_cnt = (uint32_t*)w;
-    w += align_up(((size_t)P / 16 + 8) * 4, 256);
-    uint32_t* flag = (uint32_t*)w;
-    if ((const char*)cmp < (const char*)a.A ||
-        (unsigned long long)((const char*)cmp - (const char*)a.A) + (unsigned long long)a.T * (Kw / 2) * 3 * Pe * 4 > 0xffffffffULL) return 0;
-    const int n_tiles = cdiv(P, sp.pb), fix_cap = SP_FIX_PER_POS * sp.pb;
-    if (hipMemsetAsync(fix_cnt, 0, align_up(((size_t)P / 16 + 8) * 4, 256) + 256, s) != hipSuccess) return fail(-3, "hipMemsetAsync failed");
+    uint32_t* cmp = (uint32_t*)side;
+    const unsigned long long cmp_bytes = (unsigned long long)(a.Tc - sp.nd) * (Kw / 2) * SP_A_ARR * Pe * 4;
+    // (the kernel addresses both the raw and the compressed planes by 32-bit offsets from the raw planes)
+    if ((const char*)cmp < (const char*)a.A || (unsigned long long)((const char*)cmp - (const char*)a.A) + cmp_bytes > 0xffffffffULL) return 0;
+    const int n_tiles = cdiv(P, sp.pb);
     CompressArgs ca;
     memset(&ca, 0, sizeof(ca));
-    ca.enc = a.A; ca.cmp = cmp; ca.fix = fix; ca.fix_cnt = fix_cnt; ca.flag = flag; ca.Pe = (unsigned)Pe; ca.Cw = Kw; ca.Tc = a.Tc; ca.nd = sp.nd;
-    ca.pb = sp.pb; ca.fix_cap = fix_cap; ca.Cp = a.Cw * 32; ca.n_levels = a.n_levels;
-    memcpy(ca.lv, a.lv, sizeof(ca.lv));
-    if (conv) hipLaunchKernelGGL(k_compress_planes<true>, dim3(cdiv(Pe, 256), Kw / 2, a.Tc - sp.nd), dim3(256), 0, s, ca);
-    else hipLaunchKernelGGL(k_compress_planes<false>, dim3(cdiv(Pe, 256), Kw / 2, a.Tc - sp.nd), dim3(256), 0, s, ca);
+    ca.enc = a.A; ca.cmp = cmp; ca.Pe = (unsigned)Pe; ca.Cw = Kw; ca.nd = sp.nd;
+    hipLaunchKernelGGL(k_compress_planes, dim3(cdiv(Pe, 256), Kw / 2, a.Tc - sp.nd), dim3(256), 0, s, ca);
     SNN_CHECK_LAUNCH("k_compress_planes");
     SparseConvArgs sa;
     memset(&sa, 0, sizeof(sa));
-    sa.enc = a.A; sa.cmp = cmp; sa.wpk = a.wpk; sa.spk = a.spk; sa.fix = fix; sa.fix_cnt = fix_cnt; sa.flag = flag;
+    sa.enc = a.A; sa.cmp = cmp; sa.wpk = a.wpk; sa.spk = a.spk;
+    sa.tl = (unsigned long long*)((char*)side + sparse_side_bytes(P, Pe, Kw, a.T));      // (diagnostic builds only: behind the head's workspace)
     sa.plane_elems = a.plane_elems; sa.spk_stride = a.spk_stride; sa.Pe = (unsigned)Pe;
     sa.M = a.M; sa.Kc = a.Kc; sa.Np = a.Np; sa.Cw = Kw; sa.n_blocks = a.Np / 64; sa.n_tiles = n_tiles; sa.n_levels = a.n_levels;
-    sa.T = a.T; sa.Tc = a.Tc; sa.nd = sp.nd; sa.pb = sp.pb; sa.q = sp.q; sa.fix_cap = fix_cap; sa.out_split = a.out_split;
+    sa.T = a.T; sa.Tc = a.Tc; sa.nd = sp.nd; sa.pb = sp.pb; sa.q = sp.q; sa.out_split = a.out_split;
     memcpy(sa.mt_plane, sp.plane, sizeof(sa.mt_plane)); memcpy(sa.mt_j, sp.j, sizeof(sa.mt_j));
     memcpy(sa.w_nd, sp.w_nd, 8); memcpy(sa.w_ns, sp.w_ns, 8);
     sa.p = a.p;
@@ -1065,9 +1055,8 @@ static int gemm3_lif_sparse(const Gemm3Args& a, bool conv, void* side, size_t si
         sa.xcd_contig = cdiv(n_tiles, 8 / groups);
         grid = sa.xcd_contig * sa.xcd_cpx * 8;
     }
-    sa.fx_off = max((int)SP_LDS, a.Tc * sp.pb * SP_PITCH * 4);
-    const int lds = sa.fx_off + 2 * fix_cap * 4;
-    if (fix_cap > 1024 || lds > 80 * 1024) return 0;
+    const int lds = max((int)SP_LDS, a.Tc * sp.pb * SP_PITCH * 4);      // the ring, then the epilogue's tile image in the same bytes
+    if (lds > 80 * 1024) return 0;
     const void* kern = conv ? (const void*)k_gemm_lif_sparse<true, 1> : sp.wn == 2 ? (const void*)k_gemm_lif_sparse<false, 2> : (const void*)k_gemm_lif_sparse<false, 1>;
     hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return fail(-3, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -1080,7 +1069,6 @@ static int gemm3_lif_sparse(const Gemm3Args& a, bool conv, void* side, size_t si
     e = hipLaunchKernel(kern, dim3(grid), dim3(512), kargs, lds, s);
     if (e != hipSuccess) return fail(-3, "k_gemm_lif_sparse launch failed: %s", hipGetErrorString(e));
     SNN_CHECK_LAUNCH("k_gemm_lif_sparse");
-    *flag_out = flag;
     return 1;
 }
 
@@ -1123,13 +1111,11 @@ static int conv3x3_lif_bf16x3_impl(const uint32_t* enc, size_t enc_stride, const
     a.cnt_img = counts; a.max_n = max_n;
     if (want_split && a.Np % 128 == 0) { a.out_split = 1; *out_split = true; }
     if (periods && set_periods(a, "snn_conv3x3_lif_bf16x3")) return -1;
-    // round 4: the sparse period planes on the structured-sparse matrix-core instruction (snn_sparse.h); the dense launch stays behind
-    // it as the fallback for inputs whose fix-up lists overflow (it leaves at once otherwise)
-    const uint32_t* flag = nullptr;
-    rc = gemm3_lif_sparse(a, true, sparse_side, sparse_bytes, &flag, (hipStream_t)s);
+    // round 4: the sparse period planes on the structured-sparse matrix-core instruction (snn_sparse.h) where the configuration allows
+    rc = gemm3_lif_sparse(a, true, sparse_side, sparse_bytes, (hipStream_t)s);
     if (rc < 0) return rc;
     g_last_conv_sparse = rc;
-    if (rc == 1) a.run_if = flag;
+    if (rc == 1) return 0;
     return launch_gemm3(G3_CONV_LIF_TILE, tl.mt, wn, a, (hipStream_t)s);
 }
 
@@ -1518,11 +1504,11 @@ static long long rpn_positions_padded(const snn_rpn_level* lv, int n_levels) {
 }
 
 // Pe = rows of an encoder plane (positions; with the zero halo for the mxfp6 path)
-// bytes behind the two plane sets for the structured-sparse conv (snn_sparse.h): compressed planes (3 dwords per row and 64 k, at most
-// all T planes), fix-up lists (SP_FIX_PER_POS entries per position), per-tile counters + the overflow flag
+// bytes behind the two plane sets for the structured-sparse conv (snn_sparse.h): the compressed planes, primary + secondary (SP_A_ARR
+// dwords per row and 64 k; planes e_3 .. of at most T - 1 current planes)
 static size_t sparse_side_bytes(long long P, long long Pe, int Kw, int T) {     // Kw = 32-bit words per row of a plane
-    return align_up((size_t)T * cdiv(Kw, 2) * 3 * (size_t)Pe * 4, 256) + align_up((size_t)SP_FIX_PER_POS * P * 4 + 4096 * SP_FIX_PER_POS, 256) +
-           align_up(((size_t)P / 16 + 8) * 4, 256) + 256;
+    (void)P;
+    return align_up((size_t)max(T - 3, 1) * cdiv(Kw, 2) * SP_A_ARR * (size_t)Pe * 4, 256) + 256;
 }
 static size_t rpn_sparse_bytes(long long P, long long Pe, int C, int T) { return sparse_side_bytes(P, Pe, cdiv(C, 32), T); }
 static void rpn_ws_layout(long long P, long long Pe, int C, int T, int precision, size_t* o_spk, size_t* o_cur, size_t* o_cnt,
@@ -1992,20 +1978,18 @@ static int det_head_from_planes(int R, int D, int Hd, int K, int K4, int T, cons
         if ((rc = spike_gemm_lif_bf16x3_args(s6, T, R, Hd, Hd, p, (const uint16_t*)w7_packed, s7, (size_t)R * Hw, spk7_count, enc_wm, false, &win.fc7, false, &a7, &t7))) return rc;
         const int wn = g3_wn();
         // round 4: fc6's sparse period planes e_3 .. on the structured-sparse matrix-core instruction (snn_sparse.h); its side buffers
-        // live in the currents region of the workspace, which the fused layers never write; the dense fc6 launch stays behind it as
-        // the device-side fallback (Gemm3Args.run_if)
-        const uint32_t* flag6 = nullptr;
-        rc = knobs().det_pair ? 0 : gemm3_lif_sparse(a6, false, (char*)ws + o_cur, o_s6 - o_cur, &flag6, s);
+        // live in the currents region of the workspace, which the fused layers never write
+        rc = knobs().det_pair ? 0 : gemm3_lif_sparse(a6, false, (char*)ws + o_cur, o_s6 - o_cur, s);
         if (rc < 0) return rc;
+        const bool fc6_done = rc == 1;
         g_last_fc_sparse = rc;
-        if (rc == 1) a6.run_if = flag6;
         const int n_sync = cdiv(R, a6.pb) + 1;
         if (knobs().det_pair && gemm3_pair_ok(t6.mt, t7.mt, wn, a6) && (size_t)n_sync * 4 <= DET_SYNC_BYTES) {
             uint32_t* sync = (uint32_t*)((char*)ws + o_sync);
             if (hipMemsetAsync(sync, 0, (size_t)n_sync * 4, s) != hipSuccess) return fail(-3, "hipMemsetAsync failed");
             if ((rc = launch_gemm3_pair(t6.mt, wn, a6, a7, sync, s))) return rc;
         } else {
-            if ((rc = launch_gemm3(G3_FC_LIF_TILE, t6.mt, wn, a6, s))) return rc;
+            if (!fc6_done && (rc = launch_gemm3(G3_FC_LIF_TILE, t6.mt, wn, a6, s))) return rc;
             if ((rc = launch_gemm3(G3_FC_LIF_TILE, t7.mt, wn, a7, s))) return rc;
         }
         return snn_li_heads(s7, (size_t)R * Hw, T, R, Hd, w_heads_packed, K, K4, p, out_cls, out_bbox, sum_cls,

@@ -10,11 +10,13 @@
 //     8 two-bit positions.  The A fragment of a lane is table[occupancy byte] - the dense kernels' byte -> 8 bf16 table - plus 16 index
 //     bits; operand layout and encoding were established on the hardware (sparse_probe A1 / A4);
 //   * a nibble with three or four spikes of ONE period (rare: ~0.16 per position over the five sparse planes) keeps its first two in
-//     the compressed plane; each further spike becomes up to nine FIX-UP entries (one per 3x3 tap: output position, plane, k), appended
-//     to the list of the output tile they fall into, and the tile's epilogue adds W[k][:] for them - sorted by (row, k), so the fp32
-//     result does not depend on the order of arrival.  Exactness is unchanged: every product is spike x (hi + mid + lo), fp32 sums.
-//   * a tile whose list overflows (an input with many equal neighbours in a sparse plane) raises a device flag: every work-group of
-//     the sparse launch then leaves at once and the dense launch that follows (Gemm3Args.run_if) does the whole job - no host sync.
+//     the compressed plane; the others go into a SECONDARY compressed plane of the same format (two more value slots per nibble: all
+//     four bits of a nibble are covered).  A wave whose 16 rows have an empty secondary block in a 64-k step (the rule: ~98 % of the
+//     (M-tile, step) pairs on the bench's pyramid) skips it; otherwise it issues the structured-sparse instruction a second time for
+//     that M-tile, right behind the step's other products.  Exactness is unchanged: every product is spike x (hi + mid + lo), fp32 sums
+//     in a fixed order.  (Until late in round 4 the third and fourth spikes were per-tile fix-up lists applied in the epilogue, with a
+//     dense fallback launch for inputs that overflowed them: 3.7 % of the conv launch, and a slow path for adversarial inputs.  The
+//     secondary plane needs neither lists nor fallback, and reads its entries through the same 3x3 tap walk as everything else.)
 //
 // Row tile = pb positions x Tc planes as M-tiles of 16 rows (plane t, positions 16 j .. 16 j + 15); each of the 8 waves owns up to
 // four M-tiles, dense ones first (table in SparseConvArgs); a wave's loop is instantiated for its (dense, sparse) counts.  The SIMDs
@@ -30,28 +32,25 @@ typedef __bf16 bfv16 __attribute__((ext_vector_type(16)));
 #define SP_MT2 6                                    // ... per ROW-wave on the 4 x 2 grid (two waves of 32 columns share a row-wave's slots)
 #define SP_MTMAX 6
 #define SP_ROWS (8 * SP_MT * 16)                    // physical tile rows (512; 4 x 6 x 16 = 384 on the 4 x 2 grid)
-#define SP_A_BYTES (3 * SP_ROWS * 4)                // three dword arrays per step: dense rows use two (the chunks' spike words), sparse rows
-                                                    // three (occupancy bytes of the four 16-k blocks, index halves 0-1, index halves 2-3)
+#define SP_A_ARR 6                                  // dword arrays per step: dense rows use two (the chunks' spike words), sparse rows all six:
+                                                    // occupancy bytes of the four 16-k blocks, index halves 0-1, index halves 2-3 of the primary
+                                                    // plane, the same three of the secondary plane
+#define SP_A_BYTES (SP_A_ARR * SP_ROWS * 4)
 #define SP_B_BYTES (2 * 3 * 64 * G3_ROWB)           // two chunks x three weight planes x 64 columns
-#define SP_SLOT (SP_A_BYTES + SP_B_BYTES)           // one 64-k step: 30 KB
-#define SP_LDS (G3_LUT_BYTES + 2 * SP_SLOT)         // 64 KB: two work-groups per CU
+#define SP_SLOT (SP_A_BYTES + SP_B_BYTES)           // one 64-k step: 36 KB
+#define SP_LDS (G3_LUT_BYTES + 2 * SP_SLOT)         // 76 KB: two work-groups per CU
 #define SP_PITCH 36                                 // epilogue tile image: 32 columns + 4 floats of padding per row
-#define SP_FIX_PER_POS 8                            // fix-up list capacity of a tile = 8 x its positions
-#define SP_EPI_BYTES(rows, cap) ((rows) * SP_PITCH * 4 + 2 * (cap) * 4)
 
 struct SparseConvArgs {
     const uint32_t* enc;         // raw period planes, word-major [Tc][Cw][Pe] (zero halo); the dense planes are read from here
-    const uint32_t* cmp;         // compressed planes [Tc - nd][Cw / 2][3][Pe]
+    const uint32_t* cmp;         // compressed planes [Tc - nd][Cw / 2][6][Pe]
     const uint16_t* wpk;         // [3][Kc][Np][32] bf16
     uint32_t* spk;               // spike planes out
-    const uint32_t* fix;         // [n_tiles][fix_cap] entries (row << 16 | k), fix_cnt[n_tiles]
-    const uint32_t* fix_cnt;
-    const uint32_t* flag;        // != 0: a list overflowed - leave at once
+    unsigned long long* tl;      // SNN_EXP_TIMELINE builds: 8 stamps per work-group
     unsigned long long plane_elems, spk_stride;
     unsigned int Pe;             // padded rows of a word plane
     int M, Kc, Np, Cw, n_blocks, n_tiles, n_levels;
-    int T, Tc, nd, pb, q, fix_cap, out_split;
-    int fx_off;                  // LDS byte offset of the tile's sorted fix-up list (behind the ring and behind the epilogue's tile image)
+    int T, Tc, nd, pb, q, out_split;
     signed char mt_plane[8][SP_MTMAX];   // plane of the row-wave's M-tile slot (-1: unused); dense planes (< nd) first
     unsigned char mt_j[8][SP_MTMAX];     // position block of the slot: local positions 16 j ..
     unsigned char w_nd[8], w_ns[8];      // dense / sparse M-tiles of the row-wave
@@ -129,16 +128,13 @@ __global__ __launch_bounds__(256) void k_permute_planes(const uint32_t* __restri
 struct CompressArgs {
     const uint32_t* enc;
     uint32_t* cmp;
-    uint32_t* fix;
-    uint32_t* fix_cnt;
-    uint32_t* flag;
     unsigned int Pe;
-    int Cw, Tc, nd, pb, fix_cap, Cp, n_levels;
-    ConvLevelDev lv[SNN_MAX_LEVELS];
+    int Cw, nd;
 };
 
-// thread = (row, 64-k step w2 = blockIdx.y, sparse plane ts = blockIdx.z); row = padded position (CONV) or RoI (linear layer)
-template <bool CONV>
+// thread = (row, 64-k step w2 = blockIdx.y, sparse plane ts = blockIdx.z); row = padded position (conv) or RoI (linear layer).
+// Out: six dwords per (row, step): primary occupancy / indices 0-1 / indices 2-3, then the secondary plane's (the third and fourth
+// spike of a nibble: zero almost everywhere)
 __global__ __launch_bounds__(256) void k_compress_planes(const CompressArgs a) {
     __shared__ uint16_t code[16];
     if (threadIdx.x < 16) code[threadIdx.x] = (uint16_t)sp_nibble_code(threadIdx.x);
@@ -147,7 +143,7 @@ __global__ __launch_bounds__(256) void k_compress_planes(const CompressArgs a) {
     if (row >= a.Pe) return;
     const int w2 = blockIdx.y, ts = blockIdx.z, t = a.nd + ts;
     const uint32_t wd[2] = {a.enc[((size_t)t * a.Cw + 2 * w2) * a.Pe + row], a.enc[((size_t)t * a.Cw + 2 * w2 + 1) * a.Pe + row]};
-    uint32_t occ = 0, idx[2] = {0, 0}, left[2] = {0, 0};
+    uint32_t occ = 0, idx[2] = {0, 0}, occ2 = 0, idx2[2] = {0, 0};
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -155,44 +151,14 @@ __global__ __launch_bounds__(256) void k_compress_planes(const CompressArgs a) {
             const uint32_t c = code[(wd[h] >> (4 * nb)) & 15u];
             occ |= (c & 3u) << (16 * h + 2 * nb);
             idx[h] |= ((c >> 2) & 15u) << (4 * nb);
-            left[h] |= ((c >> 6) & 15u) << (4 * nb);
+            const uint32_t c2 = code[(c >> 6) & 15u];              // the leftover bits (at most two) through the same table
+            occ2 |= (c2 & 3u) << (16 * h + 2 * nb);
+            idx2[h] |= ((c2 >> 2) & 15u) << (4 * nb);
         }
-    uint32_t* out = a.cmp + ((size_t)ts * (a.Cw / 2) + w2) * 3 * a.Pe + row;
-    out[0] = occ; out[a.Pe] = idx[0]; out[2 * (size_t)a.Pe] = idx[1];
-    if ((left[0] | left[1]) == 0) return;
-    // (rare) spikes beyond two per nibble become fix-up entries of the output tile(s) they belong to
-    auto push = [&](const int p, const uint32_t k) __attribute__((always_inline)) {
-        const int tile = p / a.pb, lp = p % a.pb;
-        const uint32_t entry = ((uint32_t)(t * a.pb + lp) << 16) | k;
-        const uint32_t slot = atomicAdd(a.fix_cnt + tile, 1u);
-        if (slot < (uint32_t)a.fix_cap) a.fix[(size_t)tile * a.fix_cap + slot] = entry;
-        else atomicOr(a.flag, 1u);
-    };
-    int l = 0, H = 0, W = 0, n = 0, y = 0, x = 0;
-    if (CONV) {                                               // one entry per 3x3 tap that reads this input position
-        while (l + 1 < a.n_levels && row >= (unsigned)a.lv[l + 1].tile_begin) ++l;
-        H = a.lv[l].H; W = a.lv[l].W;
-        const int local = (int)row - a.lv[l].tile_begin;
-        n = local / ((H + 2) * (W + 2));
-        const int rem = local % ((H + 2) * (W + 2));
-        y = rem / (W + 2) - 1; x = rem % (W + 2) - 1;
-        if (y < 0 || y >= H || x < 0 || x >= W) return;        // (halo rows are zero: cannot happen)
-    }
-    for (int h = 0; h < 2; ++h) {
-        uint32_t m = left[h];
-        while (m) {
-            const int b = __builtin_ctz(m);
-            m &= m - 1;
-            const int c = (2 * w2 + h) * 32 + b;
-            if (!CONV) { push((int)row, (uint32_t)c); continue; }
-            for (int ky = 0; ky < 3; ++ky)
-                for (int kx = 0; kx < 3; ++kx) {
-                    const int oy = y - (ky - 1), ox = x - (kx - 1);
-                    if (oy < 0 || oy >= H || ox < 0 || ox >= W) continue;
-                    push(a.lv[l].pos_base + (n * H + oy) * W + ox, (uint32_t)((ky * 3 + kx) * a.Cp + c));
-                }
-        }
-    }
+    uint32_t* out = a.cmp + ((size_t)ts * (a.Cw / 2) + w2) * SP_A_ARR * a.Pe + row;
+    const size_t Pe = a.Pe;
+    out[0] = occ; out[Pe] = idx[0]; out[2 * Pe] = idx[1];
+    out[3 * Pe] = occ2; out[4 * Pe] = idx2[0]; out[5 * Pe] = idx2[1];
 }
 
 // LIF over T steps of one neuron from the period sums in the LDS tile image: the straight-line form of k_gemm_bf16x3's epilogue
@@ -230,7 +196,6 @@ __device__ __forceinline__ void sp_lif_fixed(const float* src, const int group_s
 template <bool CONV, int WN>
 __global__ __launch_bounds__(512, 4) void k_gemm_lif_sparse(const SparseConvArgs args) {
     constexpr int MTS = WN == 1 ? SP_MT : SP_MT2, NT = 4 / WN;      // slots per (row-)wave, 16-column N-tiles per wave
-    if (*args.flag != 0u) return;                            // a fix-up list overflowed: the dense launch behind this one does the work
 #ifdef SNN_EXP_TIMELINE     // diagnostic build: wall-clock stamps (s_memrealtime, 100 MHz) of the work-group's phases
     unsigned long long tl_entry = 0, tl_loop0 = 0, tl_loop1 = 0, tl_epi = 0;
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_entry) :: "memory");
@@ -263,25 +228,14 @@ __global__ __launch_bounds__(512, 4) void k_gemm_lif_sparse(const SparseConvArgs
         *reinterpret_cast<uint4*>(lut + tid * 16) = q;
     }
     const int nd_w = __builtin_amdgcn_readfirstlane((int)args.w_nd[wm]), ns_w = __builtin_amdgcn_readfirstlane((int)args.w_ns[wm]);
-    // the tile's fix-up list: requested now, sorted in LDS while the first step's operands are on their way (consumed in the epilogue)
-#ifdef SNN_EXP_SP_NO_FIX                            // (timing experiment: what do the fix-up phases cost - wrong results)
-    const int n_fix = 0;
-#else
-    const int n_fix = min((int)args.fix_cnt[mb], args.fix_cap);
-#endif
-    uint32_t* const fx = reinterpret_cast<uint32_t*>(smem + args.fx_off);       // sorted entries, then the unsorted copy
-    uint32_t fx_mine[2] = {0xffffffffu, 0xffffffffu};                            // (fix_cap <= 1024: at most two entries per thread)
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-        if (tid + 512 * i < n_fix) fx_mine[i] = args.fix[(size_t)mb * args.fix_cap + tid + 512 * i];
-
     // ---- A staging: lane L of the wave stages row L & 15 of one M-tile slot of its row-wave.  WN = 1: slot L >> 4 (64 rows per wave);
     // WN = 2: the two column-waves of a row-wave take three slots each (lanes 0 .. 47)
     const int xs = WN == 1 ? (lane >> 4) : min(3 * wn + (lane >> 4), MTS - 1);
     const bool a_lane = WN == 1 || lane < 48;
     const int xplane = args.mt_plane[wm][xs];
     const bool xused = xplane >= 0, xdense = xused && xplane < args.nd;
-    uint32_t voff0, voff1, voff2, inc;                      // byte offsets from args.enc
+    uint32_t voff, inc;                                     // byte offset from args.enc of the lane's first dword; array j of the step is
+                                                            // j word planes further (dense lanes use two, the rest lands in unused LDS)
     uint32_t tap_fix, row_fix;
     {
         const int lp = min(args.mt_j[wm][xs] * 16 + (lane & 15), pb - 1);
@@ -302,39 +256,42 @@ __global__ __launch_bounds__(512, 4) void k_gemm_lif_sparse(const SparseConvArgs
         const int Cw2 = args.Cw / 2;
         if (xdense || !xused) {
             const int t = xused ? xplane : 0;
-            voff0 = (uint32_t)(((size_t)t * args.Cw * Pe + row0) * 4);
-            voff1 = voff0 + Pe * 4;
-            voff2 = voff0;
+            voff = (uint32_t)(((size_t)t * args.Cw * Pe + row0) * 4);
             inc = 2 * Pe * 4;
         } else {
             const uint32_t delta = (uint32_t)((const char*)args.cmp - (const char*)args.enc);
-            voff0 = delta + (uint32_t)(((size_t)(xplane - args.nd) * Cw2 * 3 * Pe + row0) * 4);
-            voff1 = voff0 + Pe * 4;
-            voff2 = voff0 + 2 * Pe * 4;
-            inc = 3 * Pe * 4;
+            voff = delta + (uint32_t)(((size_t)(xplane - args.nd) * Cw2 * SP_A_ARR * Pe + row0) * 4);
+            inc = SP_A_ARR * Pe * 4;
         }
         tap_fix = 4u - (uint32_t)Cw2 * inc;                 // next tap of the row: one position on, back to channel word 0
         row_fix = (uint32_t)((W + 2 - 3) * 4);              // after the third tap of a row: one padded image row down
     }
     const uint32_t a_dst = smem_base + G3_LUT_BYTES + (WN == 1 ? wave * 256 : (wm * MTS + 3 * wn) * 64);    // physical row (wm MTS + slot) 16 + r
-    const void* const a_base = sgpr_ptr(args.enc);
+    const void* a_base[SP_A_ARR];
+#pragma unroll
+    for (int j = 0; j < SP_A_ARR; ++j) a_base[j] = sgpr_ptr(reinterpret_cast<const char*>(args.enc) + (size_t)j * args.Pe * 4);
     const int cw2_s = __builtin_amdgcn_readfirstlane(args.Cw / 2);
     int f_c = 0, f_tap = 0;
     auto stage_a = [&](const uint32_t slot_off) __attribute__((always_inline)) {
         const uint32_t d = __builtin_amdgcn_readfirstlane(a_dst + slot_off);
-        if (a_lane)
-            asm volatile("s_mov_b32 m0, %4\n\ts_nop 4\n\tglobal_load_lds_dword %0, %3\n\t"
-                         "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dword %1, %3\n\t"
-                         "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dword %2, %3"
-                         :: "v"(voff0), "v"(voff1), "v"(voff2), "s"(a_base), "s"(d), "s"(d + SP_ROWS * 4), "s"(d + 2 * SP_ROWS * 4) : "memory");
-        voff0 += inc; voff1 += inc; voff2 += inc;
+        if (a_lane) {
+            asm volatile("s_mov_b32 m0, %7\n\ts_nop 4\n\tglobal_load_lds_dword %0, %1\n\t"
+                         "s_add_u32 m0, m0, %8\n\ts_nop 0\n\tglobal_load_lds_dword %0, %2\n\t"
+                         "s_add_u32 m0, m0, %8\n\ts_nop 0\n\tglobal_load_lds_dword %0, %3\n\t"
+                         "s_add_u32 m0, m0, %8\n\ts_nop 0\n\tglobal_load_lds_dword %0, %4\n\t"
+                         "s_add_u32 m0, m0, %8\n\ts_nop 0\n\tglobal_load_lds_dword %0, %5\n\t"
+                         "s_add_u32 m0, m0, %8\n\ts_nop 0\n\tglobal_load_lds_dword %0, %6"
+                         :: "v"(voff), "s"(a_base[0]), "s"(a_base[1]), "s"(a_base[2]), "s"(a_base[3]), "s"(a_base[4]), "s"(a_base[5]),
+                            "s"(d), "s"((uint32_t)(SP_ROWS * 4)) : "memory", "scc");
+        }
+        voff += inc;
         if (!CONV) return;
         f_c = __builtin_amdgcn_readfirstlane(f_c + 1);
         if (f_c == cw2_s) {
             f_c = 0;
-            voff0 += tap_fix; voff1 += tap_fix; voff2 += tap_fix;
+            voff += tap_fix;
             f_tap = __builtin_amdgcn_readfirstlane(f_tap + 1);
-            if (f_tap == 3) { f_tap = 0; voff0 += row_fix; voff1 += row_fix; voff2 += row_fix; }
+            if (f_tap == 3) { f_tap = 0; voff += row_fix; }
         }
     };
 
@@ -365,20 +322,6 @@ __global__ __launch_bounds__(512, 4) void k_gemm_lif_sparse(const SparseConvArgs
 
     const int n_steps = Kc / 2;
     stage_a(0); stage_b(0);
-    if (n_fix > 0) {                                           // block-uniform
-        uint32_t* const raw = fx + args.fix_cap;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            if (tid + 512 * i < n_fix) raw[tid + 512 * i] = fx_mine[i];
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            if (tid + 512 * i < n_fix) {
-                int rank = 0;
-                for (int j = 0; j < n_fix; ++j) rank += raw[j] < fx_mine[i];      // keys are distinct
-                fx[rank] = fx_mine[i];
-            }
-    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -402,6 +345,7 @@ __global__ __launch_bounds__(512, 4) void k_gemm_lif_sparse(const SparseConvArgs
             // A fragments of this step
             bfv8 ad[ND > 0 ? ND : 1][2], as[NS > 0 ? NS : 1];
             int ix[NS > 0 ? NS : 1];
+            unsigned long long sec = 0, sec2 = 0;
 #pragma unroll
             for (int d = 0; d < ND; ++d)
 #pragma unroll
@@ -415,6 +359,16 @@ __global__ __launch_bounds__(512, 4) void k_gemm_lif_sparse(const SparseConvArgs
                 const uint32_t occ = *reinterpret_cast<const uint8_t*>(r + lg);
                 as[q] = *reinterpret_cast<const bfv8*>(lut + (occ << 4));
                 ix[q] = (int)*reinterpret_cast<const uint16_t*>(r + (1 + (lg >> 1)) * (SP_ROWS * 4) + 2 * (lg & 1));
+            }
+            // which of the sparse M-tiles hold a third spike of a nibble in this step?  Lane L looks at the secondary occupancy dword of
+            // row L & 15 of sparse slot L >> 4 (6 slots on the 4 x 2 grid: a second look); bits 16 q .. 16 q + 15 of the ballot = slot q
+            if (NS > 0) {
+                const uint32_t o2 = *reinterpret_cast<const uint32_t*>(a_rd + o_cur + 3 * (SP_ROWS * 4) + (ND + lg) * 64);
+                sec = __ballot(o2 != 0u) & (NS >= 4 ? ~0ull : ((1ull << (16 * (NS & 3))) - 1ull));
+                if (NS > 4) {
+                    const uint32_t o3 = *reinterpret_cast<const uint32_t*>(a_rd + o_cur + 3 * (SP_ROWS * 4) + (ND + 4 + lg) * 64);
+                    sec2 = __ballot(o3 != 0u) & ((1ull << (16 * (NS - 4))) - 1ull);
+                }
             }
             bfv8 b0 = *reinterpret_cast<const bfv8*>(b_rd + o_cur + 2 * (64 * G3_ROWB));
             bfv8 b1 = *reinterpret_cast<const bfv8*>(b_rd + o_cur + 3 * 64 * G3_ROWB + 2 * (64 * G3_ROWB));
@@ -442,6 +396,25 @@ __global__ __launch_bounds__(512, 4) void k_gemm_lif_sparse(const SparseConvArgs
                 b0 = n0; b1 = n1;
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if (NS > 0 && (sec | sec2) != 0ull) {            // (rare) the secondary plane of the M-tiles that have one in this step
+#pragma unroll
+                for (int q = 0; q < NS; ++q) {
+                    if ((((q < 4 ? sec : sec2) >> (16 * (q & 3))) & 0xffffull) == 0ull) continue;
+                    const unsigned char* r = a_rd + o_cur + (ND + q) * 64 + 3 * (SP_ROWS * 4);
+                    const uint32_t occ = *reinterpret_cast<const uint8_t*>(r + lg);
+                    const bfv8 a2 = *reinterpret_cast<const bfv8*>(lut + (occ << 4));
+                    const int i2 = (int)*reinterpret_cast<const uint16_t*>(r + (1 + (lg >> 1)) * (SP_ROWS * 4) + 2 * (lg & 1));
+#pragma unroll
+                    for (int g = 0; g < 3 * NT; ++g) {
+                        const bfv8 c0 = *reinterpret_cast<const bfv8*>(b_rd + o_cur + (2 - g % 3) * (64 * G3_ROWB) + (g / 3) * 16 * G3_ROWB);
+                        const bfv8 c1 = *reinterpret_cast<const bfv8*>(b_rd + o_cur + 3 * 64 * G3_ROWB + (2 - g % 3) * (64 * G3_ROWB) + (g / 3) * 16 * G3_ROWB);
+                        bfv16 bb;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) { bb[i] = c0[i]; bb[8 + i] = c1[i]; }
+                        acc[ND + q][g / 3] = __builtin_amdgcn_smfmac_f32_16x16x64_bf16(a2, bb, acc[ND + q][g / 3], i2, 0, 0);
+                    }
+                }
+            }
             asm volatile("" ::: "memory");
             __builtin_amdgcn_s_waitcnt(0x0070);              // vmcnt(0) lgkmcnt(0): the next step's copies have landed
             __builtin_amdgcn_s_barrier();
@@ -467,7 +440,7 @@ __global__ __launch_bounds__(512, 4) void k_gemm_lif_sparse(const SparseConvArgs
 #ifdef SNN_EXP_TIMELINE
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_loop1) :: "memory");
 #endif
-    // ---- epilogue: currents -> LDS tile image (two passes of 32 columns), fix-ups, LIF over the T steps, spike words out
+    // ---- epilogue: currents -> LDS tile image (two passes of 32 columns), LIF over the T steps, spike words out
     const int T = args.T, Tc = args.Tc;
     float* const tile = reinterpret_cast<float*>(smem);
     const int rows_l = Tc * pb;
@@ -494,40 +467,6 @@ __global__ __launch_bounds__(512, 4) void k_gemm_lif_sparse(const SparseConvArgs
             }
         }
         __syncthreads();
-        if (n_fix > 0) {
-            // entries of one row form a run of the sorted list; the half-wave that owns a run's first entry adds the whole run, in k
-            // order.  The weight values of FB entries per half-wave are requested together (one memory latency per batch, not per entry).
-            constexpr int FB = 4;
-            const int hw = tid >> 5, c32 = tid & 31;
-            const int col = nb * 64 + h * 32 + c32;
-            auto w_of = [&](const uint32_t k) __attribute__((always_inline)) {
-                const size_t wi = ((size_t)(k >> 5) * Np + col) * 32 + (k & 31);
-                return __fadd_rn(__fadd_rn(bf2f(args.wpk[2 * args.plane_elems + wi]), bf2f(args.wpk[args.plane_elems + wi])), bf2f(args.wpk[wi]));
-            };
-            for (int e0 = hw; e0 < n_fix; e0 += 16 * FB) {
-                uint32_t key[FB];
-                bool start[FB];
-                uint16_t w_hi[FB], w_mid[FB], w_lo[FB];
-#pragma unroll
-                for (int b = 0; b < FB; ++b) {
-                    const int e = e0 + 16 * b;
-                    key[b] = e < n_fix ? fx[e] : 0u;
-                    start[b] = e < n_fix && (e == 0 || (fx[e - 1]   >> 16) != (key[b]   >> 16));
-                    const uint32_t k = key[b] & 0xffffu;
-                    const size_t wi = ((size_t)(k >> 5) * Np + col) * 32 + (k & 31);
-                    w_hi[b] = args.wpk[wi]; w_mid[b] = args.wpk[args.plane_elems + wi]; w_lo[b] = args.wpk[2 * args.plane_elems + wi];
-                }
-#pragma unroll
-                for (int b = 0; b < FB; ++b) {
-                    if (!start[b]) continue;
-                    const uint32_t row = key[b]   >> 16;
-                    float v = __fadd_rn(tile[row * SP_PITCH + c32], __fadd_rn(__fadd_rn(bf2f(w_lo[b]), bf2f(w_mid[b])), bf2f(w_hi[b])));
-                    for (int f = e0 + 16 * b + 1; f < n_fix && (fx[f]   >> 16) == row; ++f) v = __fadd_rn(v, w_of(fx[f] & 0xffffu));
-                    tile[row * SP_PITCH + c32] = v;
-                }
-            }
-            __syncthreads();
-        }
         const int word0 = (nb * 64 + h * 32) >> 5;
         const int par = lane >> 5, col = lane & 31;
         for (int pp = wave; 2 * pp < pb; pp += 8) {
@@ -569,8 +508,7 @@ __global__ __launch_bounds__(512, 4) void k_gemm_lif_sparse(const SparseConvArgs
         uint32_t hw, xcc;
         asm volatile("s_memrealtime %0\n\ts_getreg_b32 %1, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %2, hwreg(HW_REG_XCC_ID)\n\ts_waitcnt lgkmcnt(0)"
                      : "=s"(tl_exit), "=s"(hw), "=s"(xcc) :: "memory");
-        // (behind the overflow flag = behind everything the head needs of its workspace: tools/sparse_timeline.py allocates more)
-        unsigned long long* o = reinterpret_cast<unsigned long long*>(const_cast<uint32_t*>(args.flag) + 64) + (size_t)blockIdx.x * 8;
+        unsigned long long* o = args.tl + (size_t)blockIdx.x * 8;       // (behind the compressed planes: tools/sparse_timeline.py allocates more)
         o[0] = tl_entry; o[1] = tl_loop0; o[2] = tl_loop1; o[3] = tl_epi; o[4] = tl_exit; o[5] = hw; o[6] = xcc; o[7] = 1;
     }
 #endif

@@ -42,6 +42,9 @@ def disassembly(tmp_path_factory):
     return funcs
 
 
+M0_WRITE = r"^(s_mov_b32 m0, s\d+|s_add_u32 m0, m0, s\d+)$"
+
+
 def test_only_the_asm_blocks_touch_m0(disassembly):
     n_mov = n_dma = 0
     for name, ins in disassembly.items():
@@ -50,8 +53,8 @@ def test_only_the_asm_blocks_touch_m0(disassembly):
             for r in M0_READERS:                      # instructions that read M0 implicitly
                 assert r not in op or (r == "buffer_load" and " lds" not in x), "implicit M0 reader %r in %s" % (x, name)
             if re.search(r"\bm0\b", x):
-                # the only M0 writers / readers spelled out: s_mov_b32 m0, <sgpr>
-                assert re.match(r"^s_mov_b32 m0, s\d+$", x), "unexpected M0 use %r in %s" % (x, name)
+                # the only M0 writers / readers spelled out: s_mov_b32 m0, <sgpr> and (the sparse kernel's six row arrays) s_add_u32 m0, m0, <sgpr>
+                assert re.match(M0_WRITE, x), "unexpected M0 use %r in %s" % (x, name)
                 n_mov += 1
                 # ... followed, after s_nop wait states only, by the LDS-DMA it feeds
                 j = i + 1
@@ -63,7 +66,7 @@ def test_only_the_asm_blocks_touch_m0(disassembly):
                 j = i - 1
                 while ins[j].startswith("s_nop"):
                     j -= 1
-                assert re.match(r"^s_mov_b32 m0, s\d+$", ins[j]), "LDS-DMA without its own M0 write in %s: %r" % (name, ins[j:i + 1])
+                assert re.match(M0_WRITE, ins[j]), "LDS-DMA without its own M0 write in %s: %r" % (name, ins[j:i + 1])
     assert n_mov == n_dma and n_dma > 100, (n_mov, n_dma)
 
 

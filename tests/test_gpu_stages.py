@@ -211,6 +211,36 @@ def test_li_heads_kernel_forms_agree_with_fp64(S, gpu_device, monkeypatch, li_or
     assert float((outs["valu"] - outs["ksplit"]).abs().max()) <= 2 * CUR_TOL
 
 
+@pytest.mark.parametrize("K,NA,NB", [(256, 3, 12), (256, 9, 36), (128, 5, 20), (1024, 9, 36), (512, 2, 8)])
+def test_li_heads_every_number_of_steps(S, gpu_device, monkeypatch, K, NA, NB):
+    """T = 1 .. 26 on every kernel form: the time steps run in groups (8; 16 / 12 on the reduction-split kernel), so every length of
+    the last group is exercised.  (Round 4 found the matrix-core kernel wrong for last groups of exactly two steps - T = 2, 10, 18, 26 -
+    at C = 256: rows 3 mod 4 of every 16-row tile; no other test ran those T.)"""
+    M = 83
+    a, b = float(torch.tensor(0.001) * torch.tensor(100.0)), float(torch.tensor(0.001) * torch.tensor(200.0))
+    g = torch.Generator().manual_seed(K + NA)
+    wa = torch.randn(NA, K, generator=g) / K ** 0.5
+    wb = torch.randn(NB, K, generator=g) / K ** 0.5
+    wh = S.pack_heads(wa.to(gpu_device), wb.to(gpu_device))
+    spk_all = torch.rand(26, M, K, generator=g) < 0.1
+    cur_all = torch.einsum("tmk,nk->tmn", spk_all.double(), torch.cat([wa, wb]).double())
+    for T in range(1, 27):
+        v = torch.zeros(M, NA + NB, dtype=torch.float64)
+        i = torch.zeros_like(v)
+        vsum = torch.zeros_like(v)
+        for t in range(T):
+            i = i + cur_all[t]; v = v + a * (i - v); i = i - b * i
+            vsum = vsum + v
+        planes = dense_to_planes(spk_all[:T].numpy()).to(gpu_device)
+        for form in ("valu", "ksplit", "mfma"):
+            monkeypatch.setenv("SNN_LI_HEADS", form)
+            o_a, o_b, s_a, s_b = S.li_heads(planes, K, wh, NA, NB, _params(S, "jump_first"), want_sums=True)
+            got = torch.cat([o_a, o_b], dim=1).double().cpu()
+            gsum = torch.cat([s_a, s_b], dim=1).double().cpu()
+            assert float((got - v).abs().max()) <= CUR_TOL, (form, T)
+            assert float((gsum - vsum).abs().max()) <= T * CUR_TOL, (form, T)
+
+
 # ---------------------------------------------------------------------------------------------
 # exact bf16x3 contractions (bf16 matrix cores): same teacher-forced bars as the fp32 MFMA kernels
 # ---------------------------------------------------------------------------------------------

@@ -10,9 +10,10 @@
 //     8 two-bit positions.  The A fragment of a lane is table[occupancy byte] - the dense kernels' byte -> 8 bf16 table - plus 16 index
 //     bits; operand layout and encoding were established on the hardware (sparse_probe A1 / A4);
 //   * a nibble with three or four spikes of ONE period (rare: ~0.16 per position over the five sparse planes) keeps its first two in
-//     the compressed plane; the others go into a SECONDARY compressed plane of the same format (two more value slots per nibble: all
-//     four bits of a nibble are covered).  A wave whose 16 rows have an empty secondary block in a 64-k step (the rule: ~98 % of the
-//     (M-tile, step) pairs on the bench's pyramid) skips it; otherwise it issues the structured-sparse instruction a second time for
+//     the compressed plane; the others go into a SECONDARY compressed plane (two more value slots per nibble, at the constant
+//     positions 2 and 3 - where a third / fourth spike can only be: one more dword per row and step, all four bits of a nibble
+//     covered).  A wave whose 16 rows have an empty secondary block in a 64-k step (the rule: ~98 % of the (M-tile, step) pairs on the
+//     bench's pyramid) skips it; otherwise it issues the structured-sparse instruction a second time for
 //     that M-tile, right behind the step's other products.  Exactness is unchanged: every product is spike x (hi + mid + lo), fp32 sums
 //     in a fixed order.  (Until late in round 4 the third and fourth spikes were per-tile fix-up lists applied in the epilogue, with a
 //     dense fallback launch for inputs that overflowed them: 3.7 % of the conv launch, and a slow path for adversarial inputs.  The
@@ -32,18 +33,18 @@ typedef __bf16 bfv16 __attribute__((ext_vector_type(16)));
 #define SP_MT2 6                                    // ... per ROW-wave on the 4 x 2 grid (two waves of 32 columns share a row-wave's slots)
 #define SP_MTMAX 6
 #define SP_ROWS (8 * SP_MT * 16)                    // physical tile rows (512; 4 x 6 x 16 = 384 on the 4 x 2 grid)
-#define SP_A_ARR 6                                  // dword arrays per step: dense rows use two (the chunks' spike words), sparse rows all six:
+#define SP_A_ARR 4                                  // dword arrays per step: dense rows use two (the chunks' spike words), sparse rows all four:
                                                     // occupancy bytes of the four 16-k blocks, index halves 0-1, index halves 2-3 of the primary
-                                                    // plane, the same three of the secondary plane
+                                                    // plane, occupancy bytes of the secondary plane (whose indices are the constant (2, 3))
 #define SP_A_BYTES (SP_A_ARR * SP_ROWS * 4)
 #define SP_B_BYTES (2 * 3 * 64 * G3_ROWB)           // two chunks x three weight planes x 64 columns
-#define SP_SLOT (SP_A_BYTES + SP_B_BYTES)           // one 64-k step: 36 KB
-#define SP_LDS (G3_LUT_BYTES + 2 * SP_SLOT)         // 76 KB: two work-groups per CU
+#define SP_SLOT (SP_A_BYTES + SP_B_BYTES)           // one 64-k step: 32 KB
+#define SP_LDS (G3_LUT_BYTES + 2 * SP_SLOT)         // 68 KB: two work-groups per CU
 #define SP_PITCH 36                                 // epilogue tile image: 32 columns + 4 floats of padding per row
 
 struct SparseConvArgs {
     const uint32_t* enc;         // raw period planes, word-major [Tc][Cw][Pe] (zero halo); the dense planes are read from here
-    const uint32_t* cmp;         // compressed planes [Tc - nd][Cw / 2][6][Pe]
+    const uint32_t* cmp;         // compressed planes [Tc - nd][Cw / 2][4][Pe]
     const uint16_t* wpk;         // [3][Kc][Np][32] bf16
     uint32_t* spk;               // spike planes out
     unsigned long long* tl;      // SNN_EXP_TIMELINE builds: 8 stamps per work-group
@@ -133,8 +134,9 @@ struct CompressArgs {
 };
 
 // thread = (row, 64-k step w2 = blockIdx.y, sparse plane ts = blockIdx.z); row = padded position (conv) or RoI (linear layer).
-// Out: six dwords per (row, step): primary occupancy / indices 0-1 / indices 2-3, then the secondary plane's (the third and fourth
-// spike of a nibble: zero almost everywhere)
+// Out: four dwords per (row, step): primary occupancy / indices 0-1 / indices 2-3, then the secondary plane's occupancy (the third and
+// fourth spike of a nibble: zero almost everywhere).  A third spike can only sit at bit 2 or 3 of its nibble and a fourth at bit 3, so
+// the secondary slots are (value = leftover bit 2, position 2), (value = leftover bit 3, position 3): constant indices, nothing stored.
 __global__ __launch_bounds__(256) void k_compress_planes(const CompressArgs a) {
     __shared__ uint16_t code[16];
     if (threadIdx.x < 16) code[threadIdx.x] = (uint16_t)sp_nibble_code(threadIdx.x);
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(256) void k_compress_planes(const CompressArgs a) {
     if (row >= a.Pe) return;
     const int w2 = blockIdx.y, ts = blockIdx.z, t = a.nd + ts;
     const uint32_t wd[2] = {a.enc[((size_t)t * a.Cw + 2 * w2) * a.Pe + row], a.enc[((size_t)t * a.Cw + 2 * w2 + 1) * a.Pe + row]};
-    uint32_t occ = 0, idx[2] = {0, 0}, occ2 = 0, idx2[2] = {0, 0};
+    uint32_t occ = 0, idx[2] = {0, 0}, occ2 = 0;
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -151,14 +153,12 @@ __global__ __launch_bounds__(256) void k_compress_planes(const CompressArgs a) {
             const uint32_t c = code[(wd[h] >> (4 * nb)) & 15u];
             occ |= (c & 3u) << (16 * h + 2 * nb);
             idx[h] |= ((c >> 2) & 15u) << (4 * nb);
-            const uint32_t c2 = code[(c >> 6) & 15u];              // the leftover bits (at most two) through the same table
-            occ2 |= (c2 & 3u) << (16 * h + 2 * nb);
-            idx2[h] |= ((c2 >> 2) & 15u) << (4 * nb);
+            occ2 |= ((c >> 8) & 3u) << (16 * h + 2 * nb);           // leftover bits 2 and 3 of the nibble
         }
     uint32_t* out = a.cmp + ((size_t)ts * (a.Cw / 2) + w2) * SP_A_ARR * a.Pe + row;
     const size_t Pe = a.Pe;
     out[0] = occ; out[Pe] = idx[0]; out[2 * Pe] = idx[1];
-    out[3 * Pe] = occ2; out[4 * Pe] = idx2[0]; out[5 * Pe] = idx2[1];
+    out[3 * Pe] = occ2;
 }
 
 // LIF over T steps of one neuron from the period sums in the LDS tile image: the straight-line form of k_gemm_bf16x3's epilogue
@@ -275,14 +275,12 @@ __global__ __launch_bounds__(512, 4) void k_gemm_lif_sparse(const SparseConvArgs
     auto stage_a = [&](const uint32_t slot_off) __attribute__((always_inline)) {
         const uint32_t d = __builtin_amdgcn_readfirstlane(a_dst + slot_off);
         if (a_lane) {
-            asm volatile("s_mov_b32 m0, %7\n\ts_nop 4\n\tglobal_load_lds_dword %0, %1\n\t"
-                         "s_add_u32 m0, m0, %8\n\ts_nop 0\n\tglobal_load_lds_dword %0, %2\n\t"
-                         "s_add_u32 m0, m0, %8\n\ts_nop 0\n\tglobal_load_lds_dword %0, %3\n\t"
-                         "s_add_u32 m0, m0, %8\n\ts_nop 0\n\tglobal_load_lds_dword %0, %4\n\t"
-                         "s_add_u32 m0, m0, %8\n\ts_nop 0\n\tglobal_load_lds_dword %0, %5\n\t"
-                         "s_add_u32 m0, m0, %8\n\ts_nop 0\n\tglobal_load_lds_dword %0, %6"
-                         :: "v"(voff), "s"(a_base[0]), "s"(a_base[1]), "s"(a_base[2]), "s"(a_base[3]), "s"(a_base[4]), "s"(a_base[5]),
-                            "s"(d), "s"((uint32_t)(SP_ROWS * 4)) : "memory", "scc");
+            asm volatile("s_mov_b32 m0, %5\n\ts_nop 4\n\tglobal_load_lds_dword %0, %1\n\t"
+                         "s_add_u32 m0, m0, %6\n\ts_nop 0\n\tglobal_load_lds_dword %0, %2\n\t"
+                         "s_add_u32 m0, m0, %6\n\ts_nop 0\n\tglobal_load_lds_dword %0, %3\n\t"
+                         "s_add_u32 m0, m0, %6\n\ts_nop 0\n\tglobal_load_lds_dword %0, %4"
+                         :: "v"(voff), "s"(a_base[0]), "s"(a_base[1]), "s"(a_base[2]), "s"(a_base[3]), "s"(d), "s"((uint32_t)(SP_ROWS * 4))
+                         : "memory", "scc");
         }
         voff += inc;
         if (!CONV) return;
@@ -365,7 +363,7 @@ __global__ __launch_bounds__(512, 4) void k_gemm_lif_sparse(const SparseConvArgs
             if (NS > 0) {
                 const uint32_t o2 = *reinterpret_cast<const uint32_t*>(a_rd + o_cur + 3 * (SP_ROWS * 4) + (ND + lg) * 64);
                 sec = __ballot(o2 != 0u) & (NS >= 4 ? ~0ull : ((1ull << (16 * (NS & 3))) - 1ull));
-                if (NS > 4) {
+                if constexpr (NS > 4) {
                     const uint32_t o3 = *reinterpret_cast<const uint32_t*>(a_rd + o_cur + 3 * (SP_ROWS * 4) + (ND + 4 + lg) * 64);
                     sec2 = __ballot(o3 != 0u) & ((1ull << (16 * (NS - 4))) - 1ull);
                 }
@@ -403,7 +401,7 @@ __global__ __launch_bounds__(512, 4) void k_gemm_lif_sparse(const SparseConvArgs
                     const unsigned char* r = a_rd + o_cur + (ND + q) * 64 + 3 * (SP_ROWS * 4);
                     const uint32_t occ = *reinterpret_cast<const uint8_t*>(r + lg);
                     const bfv8 a2 = *reinterpret_cast<const bfv8*>(lut + (occ << 4));
-                    const int i2 = (int)*reinterpret_cast<const uint16_t*>(r + (1 + (lg >> 1)) * (SP_ROWS * 4) + 2 * (lg & 1));
+                    const int i2 = 0xeeee;                   // every nibble: positions (2, 3)
 #pragma unroll
                     for (int g = 0; g < 3 * NT; ++g) {
                         const bfv8 c0 = *reinterpret_cast<const bfv8*>(b_rd + o_cur + (2 - g % 3) * (64 * G3_ROWB) + (g / 3) * 16 * G3_ROWB);

@@ -49,7 +49,7 @@ struct Kappa { float last[SNN_MAX_STEPS]; float sum[SNN_MAX_STEPS]; };
 #define HEADS_KS 128
 template <int RB>
 __global__ __launch_bounds__(256) void k_li_heads(const uint32_t* __restrict__ spk, size_t spk_stride, int T,
-                                                  int M, int Kw, const float* __restrict__ wT, int NOp, int NA,
+                                                  int M, int Kw, const float* __restrict__ wT, int NOp, int ldw, int col0, int NA,
                                                   int NB, const Kappa kap, float* __restrict__ out_a,
                                                   float* __restrict__ out_b, float* __restrict__ sum_a,
                                                   float* __restrict__ sum_b) {
@@ -71,9 +71,11 @@ __global__ __launch_bounds__(256) void k_li_heads(const uint32_t* __restrict__ s
         const int nw = min(HEADS_KS / 32, Kw - w0);
         // weights of the slab -> LDS (coalesced float4 copy; rows beyond Kp are never touched)
         {
-            const f32x4* src = reinterpret_cast<const f32x4*>(wT + (size_t)w0 * 32 * NOp);
+            // (this launch's NOp columns start at column col0 of the packed matrix, whose rows hold ldw columns: both multiples of 16)
             f32x4* dst = reinterpret_cast<f32x4*>(Wl);
-            for (int i = tid; i < nw * 32 * NOp / 4; i += 256) dst[i] = src[i];
+            const int q4 = NOp / 4;
+            for (int i = tid; i < nw * 32 * q4; i += 256)
+                dst[i] = *reinterpret_cast<const f32x4*>(wT + (size_t)(w0 * 32 + i / q4) * ldw + col0 + 4 * (i % q4));
         }
         // phase 1: item = (row, channel word, byte of the word) - 8 channels each, so that small row blocks (detector
         // heads: RB = 16) still give every thread an item
@@ -131,7 +133,7 @@ __global__ __launch_bounds__(256) void k_li_heads(const uint32_t* __restrict__ s
     if (pact && m < M) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int j = 4 * pjg + r;
+            const int j = col0 + 4 * pjg + r;
             if (j < NA) { out_a[(size_t)m * NA + j] = acc_l[r]; if (want_sum) sum_a[(size_t)m * NA + j] = acc_s[r]; }
             else if (j < NA + NB) {
                 out_b[(size_t)m * NB + (j - NA)] = acc_l[r];
@@ -151,9 +153,10 @@ __global__ __launch_bounds__(256) void k_li_heads(const uint32_t* __restrict__ s
 #define LIH_TG 8
 struct LiHeadsArgs {
     const uint32_t* spk; unsigned long long spk_stride;
-    const float* wT;              // [Kp][NOp] fp32 (snn_pack_heads_weight)
+    const float* wT;              // [Kp][ldw] fp32 (snn_pack_heads_weight)
     float *out_a, *out_b, *sum_a, *sum_b;
     int T, M, Kw, NOp, NA, NB, n_groups, resident;
+    int ldw, col0;                // this launch: columns col0 .. col0 + NOp - 1 of the packed matrix, whose rows hold ldw columns
     int half_split;               // k_li_heads_mfma, Kw = 8: planes in blocks of four words [T][2][M][4] (Gemm3Args.out_split)
     Kappa kap;
 };
@@ -176,11 +179,11 @@ __global__ __launch_bounds__(256) void k_li_heads_mfma(const LiHeadsArgs a) {
         unsigned char* dst = bbase + (size_t)slot * slot_bytes;
         for (int item = tid; item < 16 * NOp; item += 256) {
             const int n = item % NOp, kp = item / NOp;
-            const float* src = a.wT + (size_t)(32 * kc + 2 * kp) * NOp + n;
+            const float* src = a.wT + (size_t)(32 * kc + 2 * kp) * a.ldw + a.col0 + n;
             uint32_t pl[3] = {0u, 0u, 0u};
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const float w = src[(size_t)h * NOp];
+                const float w = src[(size_t)h * a.ldw];
                 const uint16_t hi = f2bf_rn(w);
                 const float r1 = __fsub_rn(w, bf2f(hi));
                 const uint16_t mid = f2bf_rn(r1);
@@ -294,7 +297,7 @@ __global__ __launch_bounds__(256) void k_li_heads_mfma(const LiHeadsArgs a) {
         // lane holds rows lg*4 + r, output column nt*16 + lr
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const int j = nt * 16 + lr;
+            const int j = a.col0 + nt * 16 + lr;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = m0 + lg * 4 + r;
@@ -338,7 +341,7 @@ __global__ __launch_bounds__(256) void k_li_heads_ksplit(const LiHeadsArgs a) {
     const uint32_t* wsrc = a.spk + (size_t)mrow * a.Kw;
     const int c0 = wave * Kc / 4, c1 = (wave + 1) * Kc / 4;    // this wave's chunks
     // element (k = 32 kc + 8 lg + j, n = nt*16 + lr) of W^T: the lane's B fragment is j = 0..7
-    const float* const wlane = a.wT + (size_t)lg8 * NOp + lr;
+    const float* const wlane = a.wT + (size_t)lg8 * a.ldw + a.col0 + lr;
     f32x4 o_last[NT], o_sum[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) { o_last[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; o_sum[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -356,7 +359,7 @@ __global__ __launch_bounds__(256) void k_li_heads_ksplit(const LiHeadsArgs a) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) wf[nt][j] = wlane[(size_t)(32 * kc + j) * NOp + nt * 16];
+            for (int j = 0; j < 8; ++j) wf[nt][j] = wlane[(size_t)(32 * kc + j) * a.ldw + nt * 16];
 #pragma unroll
         for (int t = 0; t < TM; ++t) w_nxt[t] = t < tn ? wsrc[(size_t)(tg0 + t) * a.spk_stride + kc] : 0u;
     };
@@ -420,7 +423,7 @@ __global__ __launch_bounds__(256) void k_li_heads_ksplit(const LiHeadsArgs a) {
             for (int r = 0; r < 4; ++r) { ol[r] = __fadd_rn(ol[r], pl[r]); os[r] = __fadd_rn(os[r], ps[r]); }
         }
         // lane holds rows lg*4 + r, output column nt*16 + lr
-        const int j = nt * 16 + lr;
+        const int j = a.col0 + nt * 16 + lr;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int m = m0 + lg * 4 + r;

@@ -1401,20 +1401,10 @@ static bool li_heads_reads_split(int K, int NA, int NB) {
     return Kw == 8 && NOp <= 64 && (size_t)Kw * 3 * NOp * 64 <= 96 * 1024 && (force == 0 || force == 2);
 }
 
-static int li_heads_impl(const uint32_t* spk, size_t spk_stride, int T, int M, int K, const float* w_heads_packed,
-                         int NA, int NB, const snn_params* p, float* out_a, float* out_b, float* sum_a, float* sum_b,
-                         bool half_split, snn_stream_t s) {
-    if (half_split && !li_heads_reads_split(K, NA, NB)) return fail(-1, "snn_li_heads: split planes need the resident matrix-core kernel");
-    if (!spk || !w_heads_packed || !p || !out_a || !out_b || M <= 0 || K <= 0 || NA <= 0 || NB <= 0)
-        return fail(-1, "snn_li_heads: bad argument");
-    if ((sum_a == nullptr) != (sum_b == nullptr)) return fail(-1, "snn_li_heads: sum_a and sum_b go together");
-    if (check_T(T, "snn_li_heads")) return -1;
-    Kappa kap;
-    li_kappa(p, T, &kap);
-    const int Kw = cdiv(K, 32), NOp = cdiv(NA + NB, 16) * 16;
-    if (NOp > 256) return fail(-1, "snn_li_heads: %d outputs per row not supported", NA + NB);
-    // debug / A-B knob: 1 "valu" forces the fp32 VALU kernel, 2 "mfma", 3 "ksplit"; SNN_PRECISION_F32_STRICT always takes the VALU kernel
-    const int force = p->precision == SNN_PRECISION_F32_STRICT ? 1 : knobs().li_heads;
+// columns col0 .. col0 + NOp - 1 (NOp a multiple of 16, <= 64 for the matrix-core kernels, <= 256 for the VALU kernel) of the heads
+static int li_heads_cols(const uint32_t* spk, size_t spk_stride, int T, int M, int Kw, const float* w_heads_packed, int NA, int NB,
+                         const Kappa& kap, float* out_a, float* out_b, float* sum_a, float* sum_b, bool half_split, int force,
+                         int ldw, int col0, int NOp, hipStream_t s) {
     // matrix-core kernel where all of W (as three bf16 planes) stays resident in LDS; the streamed form is latency
     // bound on small row counts (detector heads: 164 us against 88 us for the VALU kernel) and only runs when forced
     const bool fits = (size_t)Kw * 3 * NOp * 64 <= 96 * 1024;
@@ -1423,13 +1413,13 @@ static int li_heads_impl(const uint32_t* spk, size_t spk_stride, int T, int M, i
         LiHeadsArgs a;
         memset(&a, 0, sizeof(a));
         a.spk = spk; a.spk_stride = spk_stride; a.wT = w_heads_packed; a.out_a = out_a; a.out_b = out_b;
-        a.sum_a = sum_a; a.sum_b = sum_b; a.T = T; a.M = M; a.Kw = Kw; a.NOp = NOp; a.NA = NA; a.NB = NB; a.kap = kap;
+        a.sum_a = sum_a; a.sum_b = sum_b; a.T = T; a.M = M; a.Kw = Kw; a.NOp = NOp; a.NA = NA; a.NB = NB; a.kap = kap; a.ldw = ldw; a.col0 = col0;
         const int nt = NOp / 16;
         const size_t lds = G3_LUT_BYTES + (size_t)4 * 2 * nt * 64 * 16;
         const void* kern = nt == 1 ? (const void*)k_li_heads_ksplit<1> : nt == 2 ? (const void*)k_li_heads_ksplit<2>
                          : nt == 3 ? (const void*)k_li_heads_ksplit<3> : (const void*)k_li_heads_ksplit<4>;
         void* kargs[] = {(void*)&a};
-        hipError_t e = hipLaunchKernel(kern, dim3(cdiv(M, 16)), dim3(256), kargs, lds, (hipStream_t)s);
+        hipError_t e = hipLaunchKernel(kern, dim3(cdiv(M, 16)), dim3(256), kargs, lds, s);
         if (e != hipSuccess) return fail(-3, "k_li_heads_ksplit launch failed: %s", hipGetErrorString(e));
         SNN_CHECK_LAUNCH("k_li_heads_ksplit");
         return 0;
@@ -1438,7 +1428,7 @@ static int li_heads_impl(const uint32_t* spk, size_t spk_stride, int T, int M, i
         LiHeadsArgs a;
         memset(&a, 0, sizeof(a));
         a.spk = spk; a.spk_stride = spk_stride; a.wT = w_heads_packed; a.out_a = out_a; a.out_b = out_b;
-        a.sum_a = sum_a; a.sum_b = sum_b; a.T = T; a.M = M; a.Kw = Kw; a.NOp = NOp; a.NA = NA; a.NB = NB; a.kap = kap;
+        a.sum_a = sum_a; a.sum_b = sum_b; a.T = T; a.M = M; a.Kw = Kw; a.NOp = NOp; a.NA = NA; a.NB = NB; a.kap = kap; a.ldw = ldw; a.col0 = col0;
         a.n_groups = cdiv(M, 64);
         a.half_split = half_split;
         const size_t all = (size_t)Kw * 3 * NOp * 64;
@@ -1462,7 +1452,7 @@ static int li_heads_impl(const uint32_t* spk, size_t spk_stride, int T, int M, i
         const int per_cu = per_cu_cache[nt];
         const int grid = a.resident ? min(a.n_groups, per_cu * g3_slots()) : a.n_groups;
         void* kargs[] = {(void*)&a};
-        e = hipLaunchKernel(kern, dim3(grid), dim3(256), kargs, lds, (hipStream_t)s);
+        e = hipLaunchKernel(kern, dim3(grid), dim3(256), kargs, lds, s);
         if (e != hipSuccess) return fail(-3, "k_li_heads_mfma launch failed: %s", hipGetErrorString(e));
         SNN_CHECK_LAUNCH("k_li_heads_mfma");
         return 0;
@@ -1472,14 +1462,40 @@ static int li_heads_impl(const uint32_t* spk, size_t spk_stride, int T, int M, i
     const int rb = (256 / jg >= 64) ? 64 : (256 / jg >= 32) ? 32 : (256 / jg >= 16) ? 16 : (256 / jg >= 8) ? 8 : 4;
     const size_t lds = ((size_t)(sum_a ? 2 : 1) * rb * (HEADS_KS + 4) + (size_t)HEADS_KS * NOp) * 4;
     if (lds > 160 * 1024) return fail(-1, "snn_li_heads: LDS budget exceeded (NOp=%d)", NOp);
-    void (*kern)(const uint32_t*, size_t, int, int, int, const float*, int, int, int, const Kappa, float*, float*,
+    void (*kern)(const uint32_t*, size_t, int, int, int, const float*, int, int, int, int, int, const Kappa, float*, float*,
                  float*, float*) = rb == 64 ? k_li_heads<64> : rb == 32 ? k_li_heads<32> : rb == 16 ? k_li_heads<16>
                                              : rb == 8 ? k_li_heads<8> : k_li_heads<4>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return fail(-3, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(kern, dim3(cdiv(M, rb)), dim3(256), lds, (hipStream_t)s, spk, spk_stride, T, M, Kw,
-                       w_heads_packed, NOp, NA, NB, kap, out_a, out_b, sum_a, sum_b);
+    hipLaunchKernelGGL(kern, dim3(cdiv(M, rb)), dim3(256), lds, s, spk, spk_stride, T, M, Kw,
+                       w_heads_packed, NOp, ldw, col0, NA, NB, kap, out_a, out_b, sum_a, sum_b);
     SNN_CHECK_LAUNCH("k_li_heads");
+    return 0;
+}
+
+static int li_heads_impl(const uint32_t* spk, size_t spk_stride, int T, int M, int K, const float* w_heads_packed,
+                         int NA, int NB, const snn_params* p, float* out_a, float* out_b, float* sum_a, float* sum_b,
+                         bool half_split, snn_stream_t s) {
+    if (half_split && !li_heads_reads_split(K, NA, NB)) return fail(-1, "snn_li_heads: split planes need the resident matrix-core kernel");
+    if (!spk || !w_heads_packed || !p || !out_a || !out_b || M <= 0 || K <= 0 || NA <= 0 || NB <= 0)
+        return fail(-1, "snn_li_heads: bad argument");
+    if ((sum_a == nullptr) != (sum_b == nullptr)) return fail(-1, "snn_li_heads: sum_a and sum_b go together");
+    if (check_T(T, "snn_li_heads")) return -1;
+    Kappa kap;
+    li_kappa(p, T, &kap);
+    const int Kw = cdiv(K, 32), ldw = cdiv(NA + NB, 16) * 16;       // columns of a row of the packed matrix
+    // debug / A-B knob: 1 "valu" forces the fp32 VALU kernel, 2 "mfma", 3 "ksplit"; SNN_PRECISION_F32_STRICT always takes the VALU kernel
+    const int force = p->precision == SNN_PRECISION_F32_STRICT ? 1 : knobs().li_heads;
+    // More than 64 outputs per row (num_classes >= 13: 5 K outputs - pascal 24, coco 91 of the reference's configs): one launch per
+    // block of 64 columns (matrix-core kernels; the VALU kernel takes 256); every launch reads all spike planes, which is the small
+    // operand here.  (Until round 4: the VALU kernel up to 256 outputs, an error beyond.)
+    const int step = force == 1 ? 256 : 64;
+    if (half_split && ldw > 64) return fail(-1, "snn_li_heads: split planes need the resident matrix-core kernel");
+    for (int col0 = 0; col0 < ldw; col0 += step) {
+        const int rc = li_heads_cols(spk, spk_stride, T, M, Kw, w_heads_packed, NA, NB, kap, out_a, out_b, sum_a, sum_b, half_split, force,
+                                     ldw, col0, min(step, ldw - col0), (hipStream_t)s);
+        if (rc) return rc;
+    }
     return 0;
 }
 

@@ -1,0 +1,64 @@
+"""Every number of time steps, both heads, against the oracle (rpn.py:84-121, faster_rcnn.py:470-516).
+The kernels group, window and tile the time steps (groups of 8 / 12 / 16 in the LI heads, T-in-tile row tiles, dead time steps,
+structured-sparse launches for T = 5 .. 16, register-resident LIF beyond what a tile holds), so a defect can sit at ONE value of T:
+round 4 found the LI heads' matrix-core kernel wrong for T = 2, 10, 18, 26 at 256 channels - values no other test ran.  Here T runs
+2 .. 26 on small inputs with the channel counts that select the special paths (256: resident heads, split spike planes; 64 / 128:
+the general ones), default knobs, all three precisions."""
+import pytest
+import torch
+
+from oracle import snn_oracle as OR
+from tests._util import flip_budget
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("C,precision", [(256, "bf16x3"), (256, "f32"), (256, "mxfp6"), (64, "bf16x3"), (64, "f32")])
+def test_rpn_head_every_T(gpu_device, C, precision):
+    import snn_automotive_object_detection_amd as S
+    shapes = [(11, 14), (5, 6), (1, 2)]
+    g = torch.Generator().manual_seed(C)
+    feats = [torch.randn(2, C, h, w, generator=g) * 1.7 for h, w in shapes]
+    fd = [f.to(gpu_device) for f in feats]
+    pos = sum(2 * h * w for h, w in shapes)
+    worst = {}
+    for T in range(2, 27):
+        torch.manual_seed(100 + T)
+        m = S.RPNHeadSNN(C, 3, T).to(gpu_device)
+        m.precision = precision
+        with torch.no_grad():
+            m.shared_conv.weight.mul_(4.0)
+        lg, bb = m(fd)
+        o_l, o_b = OR.rpn_head_forward(feats, m.shared_conv.weight.detach().cpu(), m.conv_cls.weight.detach().cpu(),
+                                       m.conv_bbox.weight.detach().cpu(), T)
+        bad = 0
+        for l in range(len(shapes)):
+            d = torch.maximum((lg[l].cpu() - o_l[l]).abs().amax(1), (bb[l].cpu() - o_b[l]).abs().amax(1))
+            bad += int((d > 1e-4).sum())
+        worst[T] = bad
+        assert bad <= flip_budget(pos, C, T, "rpn_randn", precision), (T, bad)
+    assert sum(worst.values()) <= 6, worst          # (tie flips are rare at this size: ~0.01 expected per T)
+
+
+@pytest.mark.parametrize("C,Hd,K,precision", [(32, 128, 9, "bf16x3"), (32, 128, 9, "f32"), (64, 1024, 9, "bf16x3"), (64, 1024, 9, "f32"),
+                                              (8, 64, 5, "bf16x3"), (8, 64, 5, "f32"), (128, 256, 9, "mxfp6")])
+def test_det_head_every_T(gpu_device, C, Hd, K, precision):
+    import snn_automotive_object_detection_amd as S
+    R = 37
+    g = torch.Generator().manual_seed(Hd)
+    x = torch.randn(R, C, 7, 7, generator=g) * 2
+    xd = x.to(gpu_device)
+    worst = {}
+    for T in range(2, 27):
+        torch.manual_seed(200 + T)
+        d = S.FastRCNNPredictorSNNFull(C * 49, Hd, K, T).to(gpu_device)
+        d.precision = precision
+        with torch.no_grad():
+            d.fc7.weight.mul_(3.0)
+        c, b = d(xd)
+        o_c, o_d = OR.det_head_forward(x, d.fc6.weight.detach().cpu(), d.fc7.weight.detach().cpu(), d.cls_score.weight.detach().cpu(),
+                                       d.bbox_pred.weight.detach().cpu(), T)
+        off = ((c.cpu() - o_c).abs().amax(1) > 1e-4) | ((b.cpu() - o_d).abs().amax(1) > 1e-4)
+        worst[T] = int(off.sum())
+        assert worst[T] <= flip_budget(R, 2 * Hd, T, "det", precision), (T, worst[T])
+    assert sum(worst.values()) <= 8, worst

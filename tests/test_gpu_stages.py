@@ -177,7 +177,8 @@ def test_li_heads_both_orders(S, gpu_device, li_order):
 
 
 @pytest.mark.parametrize("T,M,K,NA,NB", [(12, 300, 1024, 9, 36), (16, 45, 160, 2, 8), (12, 130, 1024, 11, 44), (5, 17, 2048, 3, 12),
-                                          (24, 70, 1024, 9, 36), (20, 33, 512, 11, 44)])     # the last two: more than one time group
+                                          (24, 70, 1024, 9, 36), (20, 33, 512, 11, 44),      # these two: more than one time group
+                                          (12, 50, 256, 24, 96), (10, 21, 1024, 91, 364)])   # more than 64 outputs: blocks of 64 columns
 @pytest.mark.parametrize("li_order", ["jump_first", "voltage_first"])
 def test_li_heads_kernel_forms_agree_with_fp64(S, gpu_device, monkeypatch, li_order, T, M, K, NA, NB):
     """the three kernels behind snn_li_heads (fp32 VALU, matrix cores with W resident in LDS, matrix cores with the reduction

@@ -33,7 +33,7 @@ def _rpn_case(dev, C, A, T, shapes, N, seed, precision="bf16x3"):
     return bad
 
 
-@pytest.mark.parametrize("C", [32, 64, 96, 128, 160, 192, 224, 256, 320, 384, 512])
+@pytest.mark.parametrize("C", [3, 20, 32, 64, 96, 100, 128, 160, 192, 224, 256, 320, 384, 512])
 def test_rpn_head_channel_counts(gpu_device, C):
     total = 0
     for T, A in [(8, 3), (6, 5), (12, 1)]:
@@ -78,7 +78,7 @@ def _det_case(dev, R, C, Hd, K, T, seed, precision="bf16x3"):
     return int(off.sum())
 
 
-@pytest.mark.parametrize("Hd", [32, 64, 96, 128, 192, 256, 320, 512, 1024])
+@pytest.mark.parametrize("Hd", [8, 32, 40, 64, 96, 100, 128, 192, 256, 320, 512, 1024])
 def test_det_head_hidden_widths(gpu_device, Hd):
     total = 0
     for C, K, T in [(32, 9, 12), (8, 5, 8), (64, 2, 6)]:
@@ -111,3 +111,11 @@ def test_det_head_row_remainders(gpu_device, R):
     for C, Hd, T in [(32, 256, 12), (64, 128, 7)]:
         total += _det_case(gpu_device, R, C, Hd, 9, T, R + Hd)
     assert total <= 2
+
+
+def test_no_rois_and_no_positions(gpu_device):
+    """R = 0 (an image batch without proposals): empty outputs of the right shapes, as the reference's modules give"""
+    import snn_automotive_object_detection_amd as S
+    d = S.FastRCNNPredictorSNNFull(32 * 49, 128, 9, 12).to(gpu_device)
+    c, b = d(torch.zeros(0, 32, 7, 7, device=gpu_device))
+    assert tuple(c.shape) == (0, 9) and tuple(b.shape) == (0, 36)

@@ -161,32 +161,41 @@ __global__ __launch_bounds__(256) void k_compress_planes(const CompressArgs a) {
     out[3 * Pe] = occ2;
 }
 
-// LIF over T steps of one neuron from the period sums in the LDS tile image: the straight-line form of k_gemm_bf16x3's epilogue
-// (period planes, v_leak = 0, no spike at step 0, conv window T - 1), same operations in the same order
-template <int TS, int D>
-__device__ __forceinline__ void sp_lif_fixed(const float* src, const int group_stride, const NeuronP& p, uint32_t& my0, uint32_t& my1) {
+// LIF over T steps of NP independent neurons per lane from the period sums in the LDS tile image: the straight-line form of
+// k_gemm_bf16x3's epilogue (period planes, v_leak = 0, no spike at step 0, conv window T - 1), same operations in the same order per
+// neuron.  NP = 2: the recurrence is one dependent chain of ~6 operations per step; two of them interleaved fill each other's latencies
+// (LIF part of an epilogue pass 3.9 -> see profiles/r4_sparse_timeline.txt).
+template <int TS, int D, int NP>
+__device__ __forceinline__ void sp_lif_fixed(const float* const (&src)[NP], const int group_stride, const NeuronP& p, uint32_t (&my0)[NP], uint32_t (&my1)[NP]) {
     constexpr int TCS = TS - D;                          // currents of steps 0 .. T - 1 - D (conv: D = 1; fc6: D = 2 - dead time steps)
-    float ug[TCS];
+    float ug[NP][TCS];
 #pragma unroll
-    for (int g = 0; g < TCS; ++g) ug[g] = src[(size_t)g * group_stride];
-    float vv = 0.0f, ii = 0.0f;
+    for (int u = 0; u < NP; ++u)
+#pragma unroll
+        for (int g = 0; g < TCS; ++g) ug[u][g] = src[u][(size_t)g * group_stride];
+    float vv[NP], ii[NP];
+#pragma unroll
+    for (int u = 0; u < NP; ++u) { vv[u] = 0.0f; ii[u] = 0.0f; }
 #pragma unroll
     for (int t = 0; t < TS; ++t) {
-        float c = 0.0f;
-        if (t < TCS) {
-            c = ug[0];
 #pragma unroll
-            for (int n = 2; n <= t + 1; ++n)
-                if ((t + 1) % n == 0) c = __fadd_rn(c, ug[n - 1]);
+        for (int u = 0; u < NP; ++u) {
+            float c = 0.0f;
+            if (t < TCS) {
+                c = ug[u][0];
+#pragma unroll
+                for (int n = 2; n <= t + 1; ++n)
+                    if ((t + 1) % n == 0) c = __fadd_rn(c, ug[u][n - 1]);
+            }
+            if (t == 0) { ii[u] = __fadd_rn(0.0f, c); continue; }
+            const float v_dec = __fadd_rn(vv[u], __fmul_rn(p.ca, __fsub_rn(ii[u], vv[u])));
+            const float i_dec = __fadd_rn(ii[u], __fmul_rn(p.cb, ii[u]));
+            const bool z = v_dec > p.v_th;
+            vv[u] = z ? p.v_reset : v_dec;
+            ii[u] = __fadd_rn(i_dec, c);
+            const unsigned long long b = __ballot(z);
+            G3_KEEP_BALLOT(my0[u], my1[u], b, t);
         }
-        if (t == 0) { ii = __fadd_rn(0.0f, c); continue; }
-        const float v_dec = __fadd_rn(vv, __fmul_rn(p.ca, __fsub_rn(ii, vv)));
-        const float i_dec = __fadd_rn(ii, __fmul_rn(p.cb, ii));
-        const bool z = v_dec > p.v_th;
-        vv = z ? p.v_reset : v_dec;
-        ii = __fadd_rn(i_dec, c);
-        const unsigned long long b = __ballot(z);
-        G3_KEEP_BALLOT(my0, my1, b, t);
     }
 }
 
@@ -197,7 +206,7 @@ template <bool CONV, int WN>
 __global__ __launch_bounds__(512, 4) void k_gemm_lif_sparse(const SparseConvArgs args) {
     constexpr int MTS = WN == 1 ? SP_MT : SP_MT2, NT = 4 / WN;      // slots per (row-)wave, 16-column N-tiles per wave
 #ifdef SNN_EXP_TIMELINE     // diagnostic build: wall-clock stamps (s_memrealtime, 100 MHz) of the work-group's phases
-    unsigned long long tl_entry = 0, tl_loop0 = 0, tl_loop1 = 0, tl_epi = 0;
+    unsigned long long tl_entry = 0, tl_loop0 = 0, tl_loop1 = 0, tl_epi = 0, tl_img = 0;
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_entry) :: "memory");
 #endif
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -465,37 +474,57 @@ __global__ __launch_bounds__(512, 4) void k_gemm_lif_sparse(const SparseConvArgs
             }
         }
         __syncthreads();
+#ifdef SNN_EXP_TIMELINE
+        if (h == 0) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_img) :: "memory");
+#endif
         const int word0 = (nb * 64 + h * 32) >> 5;
         const int par = lane >> 5, col = lane & 31;
-        for (int pp = wave; 2 * pp < pb; pp += 8) {
-            const int pi = 2 * pp + par;
-            const bool live = pi < pb && m0 + pi < M;
-            if (m0 + 2 * pp >= M) break;
-            uint32_t my0 = 0, my1 = 0;
-            const float* src = tile + (live ? pi : 2 * pp) * SP_PITCH + col;
-            switch (T) {
-#define SP_T(n) case n: sp_lif_fixed<n, CONV ? 1 : 2>(src, group_stride, args.p, my0, my1); break;
-                SP_T(5) SP_T(6) SP_T(7) SP_T(8) SP_T(9) SP_T(10) SP_T(11) SP_T(12) SP_T(13) SP_T(14) SP_T(15) SP_T(16)
-#undef SP_T
-            default: break;
+        // position pairs per wave and iteration (see sp_lif_fixed): two up to T = 10, one beyond (registers: T - 1 period sums per neuron)
+        auto lif_pass = [&](auto np_c) __attribute__((always_inline)) {
+        constexpr int NP = decltype(np_c)::value;
+        for (int pp0 = wave; 2 * pp0 < pb; pp0 += 8 * NP) {
+            if (m0 + 2 * pp0 >= M) break;
+            uint32_t my0[NP], my1[NP];
+            const float* src[NP];
+#pragma unroll
+            for (int u = 0; u < NP; ++u) {
+                const int pi = 2 * (pp0 + 8 * u) + par;
+                const bool live = pi < pb && m0 + pi < M;
+                my0[u] = 0; my1[u] = 0;
+                src[u] = tile + (live ? pi : 2 * pp0) * SP_PITCH + col;    // (dead lanes / pairs recompute a live row: never stored)
             }
-            const bool odd_ok = 2 * pp + 1 < pb && m0 + 2 * pp + 1 < M;
-            if (lane < T) {
-                if (!CONV) {                                               // linear layer: word-major spike planes [T][word][RoI] (fc6 -> fc7)
-                    uint32_t* dst = args.spk + (size_t)lane * args.spk_stride + (size_t)word0 * M + (m0 + 2 * pp);
-                    dst[0] = my0;
-                    if (odd_ok) dst[1] = my1;
-                } else if (args.out_split) {
-                    uint32_t* dst = args.spk + (size_t)lane * args.spk_stride + ((size_t)(word0 >> 2) * M + m0 + 2 * pp) * 4 + (word0 & 3);
-                    dst[0] = my0;
-                    if (odd_ok) dst[4] = my1;
-                } else {
-                    uint32_t* dst = args.spk + (size_t)lane * args.spk_stride + (size_t)(m0 + 2 * pp) * (Np >> 5) + word0;
-                    dst[0] = my0;
-                    if (odd_ok) dst[Np >> 5] = my1;
+#define SP_T(n) case n: sp_lif_fixed<n, CONV ? 1 : 2, NP>(src, group_stride, args.p, my0, my1); break;
+            if constexpr (NP == 2) {
+                switch (T) { SP_T(5) SP_T(6) SP_T(7) SP_T(8) SP_T(9) SP_T(10) default: break; }
+            } else {
+                switch (T) { SP_T(11) SP_T(12) SP_T(13) SP_T(14) SP_T(15) SP_T(16) default: break; }
+            }
+#undef SP_T
+#pragma unroll
+            for (int u = 0; u < NP; ++u) {
+                const int pp = pp0 + 8 * u;
+                if (2 * pp >= pb || m0 + 2 * pp >= M) continue;
+                const bool odd_ok = 2 * pp + 1 < pb && m0 + 2 * pp + 1 < M;
+                if (lane < T) {
+                    if (!CONV) {                                           // linear layer: word-major spike planes [T][word][RoI] (fc6 -> fc7)
+                        uint32_t* dst = args.spk + (size_t)lane * args.spk_stride + (size_t)word0 * M + (m0 + 2 * pp);
+                        dst[0] = my0[u];
+                        if (odd_ok) dst[1] = my1[u];
+                    } else if (args.out_split) {
+                        uint32_t* dst = args.spk + (size_t)lane * args.spk_stride + ((size_t)(word0 >> 2) * M + m0 + 2 * pp) * 4 + (word0 & 3);
+                        dst[0] = my0[u];
+                        if (odd_ok) dst[4] = my1[u];
+                    } else {
+                        uint32_t* dst = args.spk + (size_t)lane * args.spk_stride + (size_t)(m0 + 2 * pp) * (Np >> 5) + word0;
+                        dst[0] = my0[u];
+                        if (odd_ok) dst[Np >> 5] = my1[u];
+                    }
                 }
             }
         }
+        };
+        if (T <= 10) lif_pass(std::integral_constant<int, 2>{});
+        else lif_pass(std::integral_constant<int, 1>{});
 #ifdef SNN_EXP_TIMELINE
         if (h == 0) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_epi) :: "memory");
 #endif
@@ -507,7 +536,7 @@ __global__ __launch_bounds__(512, 4) void k_gemm_lif_sparse(const SparseConvArgs
         asm volatile("s_memrealtime %0\n\ts_getreg_b32 %1, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %2, hwreg(HW_REG_XCC_ID)\n\ts_waitcnt lgkmcnt(0)"
                      : "=s"(tl_exit), "=s"(hw), "=s"(xcc) :: "memory");
         unsigned long long* o = args.tl + (size_t)blockIdx.x * 8;       // (behind the compressed planes: tools/sparse_timeline.py allocates more)
-        o[0] = tl_entry; o[1] = tl_loop0; o[2] = tl_loop1; o[3] = tl_epi; o[4] = tl_exit; o[5] = hw; o[6] = xcc; o[7] = 1;
+        o[0] = tl_entry; o[1] = tl_loop0; o[2] = tl_loop1; o[3] = tl_epi; o[4] = tl_exit; o[5] = hw; o[6] = xcc; o[7] = tl_img;       // (o[7] != 0 marks the record)
     }
 #endif
 }

@@ -34,13 +34,16 @@ for _ in range(5):
 torch.cuda.synchronize()
 assert lib.snn_debug_last_conv_path() == 1
 raw = ws[off: off + n_wg * 64].view(torch.int64).view(-1, 8).cpu()
-raw = raw[raw[:, 7] == 1]
+raw = raw[raw[:, 7] != 0]
 t = raw[:, :5].double() / 100.0                                  # us
 t0 = float(t[:, 0].min())
 print("work-groups stamped: %d; launch span %.1f us" % (raw.shape[0], float(t[:, 4].max()) - t0))
 print("mean us per work-group: before K loop %.2f | K loop %.2f | epilogue pass 0 %.2f | epilogue pass 1 %.2f | whole %.2f" % (
     float((t[:, 1] - t[:, 0]).mean()), float((t[:, 2] - t[:, 1]).mean()), float((t[:, 3] - t[:, 2]).mean()), float((t[:, 4] - t[:, 3]).mean()),
     float((t[:, 4] - t[:, 0]).mean())))
+img = raw[:, 7].double() / 100.0
+print("epilogue pass 0: accumulators -> tile image (two barriers) %.2f us | LIF recurrence + spike stores %.2f us" % (
+    float((img - t[:, 2]).mean()), float((t[:, 3] - img).mean())))
 cu = (raw[:, 6] << 16) | (raw[:, 5] & 0x0000ff00) | ((raw[:, 5] >> 13) & 0x7)        # xcc | cu_id / sh / se bits
 ids, counts = torch.unique(cu, return_counts=True)
 print("distinct (XCC, CU) slots seen: %d; work-groups per slot: min %d max %d" % (ids.numel(), int(counts.min()), int(counts.max())))

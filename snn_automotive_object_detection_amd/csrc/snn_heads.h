@@ -345,45 +345,46 @@ __global__ __launch_bounds__(256) void k_li_heads_ksplit(const LiHeadsArgs a) {
     f32x4 o_last[NT], o_sum[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) { o_last[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; o_sum[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    // time steps in groups of TM (one group up to T = 16 / 12; T = 24: two passes over this wave's chunks)
-    for (int tg0 = 0; tg0 < T; tg0 += TM) {
-    const int tn = min(TM, T - tg0);                            // block-uniform
-    f32x4 acc[TM][NT];
+    // time steps in groups of TM (one group up to T = 16 / 12; T = 24: two passes over this wave's chunks).  As in k_li_heads_mfma the
+    // number of steps with accumulators, TN, is a compile-time constant (TM, or 8 / 4 / 2 / 1 for a shorter last group); steps past
+    // the group's real count tn multiply all-zero spike words - no run-time control flow around the MFMAs.
+    auto group = [&](auto tn_c, const int tg0, const int tn) __attribute__((always_inline)) {
+        constexpr int TN = decltype(tn_c)::value;
+        f32x4 acc[TN][NT];
 #pragma unroll
-    for (int t = 0; t < TM; ++t)
+        for (int t = 0; t < TN; ++t)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[t][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float wf[NT][8];
-    uint32_t w_nxt[TM];
-    auto request = [&](int kc) {
+            for (int nt = 0; nt < NT; ++nt) acc[t][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float wf[NT][8];
+        uint32_t w_nxt[TN];
+        auto request = [&](int kc) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) wf[nt][j] = wlane[(size_t)(32 * kc + j) * a.ldw + nt * 16];
+                for (int j = 0; j < 8; ++j) wf[nt][j] = wlane[(size_t)(32 * kc + j) * a.ldw + nt * 16];
 #pragma unroll
-        for (int t = 0; t < TM; ++t) w_nxt[t] = t < tn ? wsrc[(size_t)(tg0 + t) * a.spk_stride + kc] : 0u;
-    };
-    if (c0 < c1) request(c0);
-    for (int kc = c0; kc < c1; ++kc) {
-        bf16x8 b[3][NT];
+            for (int t = 0; t < TN; ++t) w_nxt[t] = t < tn ? wsrc[(size_t)(tg0 + t) * a.spk_stride + kc] : 0u;
+        };
+        if (c0 < c1) request(c0);
+        for (int kc = c0; kc < c1; ++kc) {
+            bf16x8 b[3][NT];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float w = wf[nt][j];
-                const uint16_t hi = f2bf_rn(w);
-                const float r1 = __fsub_rn(w, bf2f(hi));
-                const uint16_t mid = f2bf_rn(r1);
-                const uint16_t lo = f2bf_rn(__fsub_rn(r1, bf2f(mid)));
-                b[0][nt][j] = (short)hi; b[1][nt][j] = (short)mid; b[2][nt][j] = (short)lo;
-            }
-        uint32_t w_cur[TM];
+                for (int j = 0; j < 8; ++j) {
+                    const float w = wf[nt][j];
+                    const uint16_t hi = f2bf_rn(w);
+                    const float r1 = __fsub_rn(w, bf2f(hi));
+                    const uint16_t mid = f2bf_rn(r1);
+                    const uint16_t lo = f2bf_rn(__fsub_rn(r1, bf2f(mid)));
+                    b[0][nt][j] = (short)hi; b[1][nt][j] = (short)mid; b[2][nt][j] = (short)lo;
+                }
+            uint32_t w_cur[TN];
 #pragma unroll
-        for (int t = 0; t < TM; ++t) w_cur[t] = w_nxt[t];
-        if (kc + 1 < c1) request(kc + 1);
+            for (int t = 0; t < TN; ++t) w_cur[t] = w_nxt[t];
+            if (kc + 1 < c1) request(kc + 1);
 #pragma unroll
-        for (int t = 0; t < TM; ++t) {
-            if (t < tn) {                                       // block-uniform
+            for (int t = 0; t < TN; ++t) {
                 const bf16x8 af = *reinterpret_cast<const bf16x8*>(lut + (__builtin_amdgcn_ubfe(w_cur[t], lg8, 8) << 4));
 #pragma unroll
                 for (int pl = 2; pl >= 0; --pl)
@@ -392,11 +393,10 @@ __global__ __launch_bounds__(256) void k_li_heads_ksplit(const LiHeadsArgs a) {
                         acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, b[pl][nt], acc[t][nt], 0, 0, 0);
             }
         }
-    }
 #pragma unroll
-    for (int t = 0; t < TM; ++t)
-        if (t < tn) {
-            const float kl = a.kap.last[tg0 + t], ks = a.kap.sum[tg0 + t];
+        for (int t = 0; t < TN; ++t) {
+            const int ti = min(tg0 + t, T - 1);                 // (steps past tn: their accumulators are zero)
+            const float kl = a.kap.last[ti], ks = a.kap.sum[ti];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -405,7 +405,15 @@ __global__ __launch_bounds__(256) void k_li_heads_ksplit(const LiHeadsArgs a) {
                     o_sum[nt][r] = fmaf(ks, acc[t][nt][r], o_sum[nt][r]);
                 }
         }
-    }   // time groups
+    };
+    for (int tg0 = 0; tg0 < T; tg0 += TM) {
+        const int tn = min(TM, T - tg0);                        // block-uniform
+        if (tn > 8) group(std::integral_constant<int, TM>{}, tg0, tn);
+        else if (tn > 4) group(std::integral_constant<int, 8>{}, tg0, tn);
+        else if (tn > 2) group(std::integral_constant<int, 4>{}, tg0, tn);
+        else if (tn == 2) group(std::integral_constant<int, 2>{}, tg0, tn);
+        else group(std::integral_constant<int, 1>{}, tg0, tn);
+    }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         red[((wave * 2 + 0) * NT + nt) * 64 + lane] = o_last[nt];

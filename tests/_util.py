@@ -43,7 +43,7 @@ def nchw_to_rows(z: torch.Tensor) -> np.ndarray:
 # Every full-size test also ATTRIBUTES its flips (first_flip_margins): each first differing spike sits within TIE_MARGIN of the
 # threshold in the oracle's trace, so a regression that flips spikes away from ties fails whatever the count.
 FLIP_RATE = {"rpn_randn": 8e-8, "rpn_in_situ": 1.5e-7, "det": 2.5e-7, "det_in_situ": 5e-7}
-PRECISION_FACTOR = {"bf16x3": 1.0, "f32": 1.0, "mxfp6": 2.0}
+PRECISION_FACTOR = {"bf16x3": 1.0, "f32": 1.0, "f32_strict": 1.0, "mxfp6": 2.0}
 TIE_MARGIN = 5e-7            # observed: every first flip sits within 6e-8 of the threshold (profiles/parity_r3.json, parity_r4.json)
 
 

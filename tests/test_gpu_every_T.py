@@ -13,7 +13,7 @@ from tests._util import flip_budget
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("C,precision", [(256, "bf16x3"), (256, "f32"), (256, "mxfp6"), (64, "bf16x3"), (64, "f32")])
+@pytest.mark.parametrize("C,precision", [(256, "bf16x3"), (256, "f32"), (256, "mxfp6"), (64, "bf16x3"), (64, "f32"), (64, "f32_strict")])
 def test_rpn_head_every_T(gpu_device, C, precision):
     import snn_automotive_object_detection_amd as S
     shapes = [(11, 14), (5, 6), (1, 2)]
@@ -41,7 +41,7 @@ def test_rpn_head_every_T(gpu_device, C, precision):
 
 
 @pytest.mark.parametrize("C,Hd,K,precision", [(32, 128, 9, "bf16x3"), (32, 128, 9, "f32"), (64, 1024, 9, "bf16x3"), (64, 1024, 9, "f32"),
-                                              (8, 64, 5, "bf16x3"), (8, 64, 5, "f32"), (128, 256, 9, "mxfp6")])
+                                              (8, 64, 5, "bf16x3"), (8, 64, 5, "f32"), (128, 256, 9, "mxfp6"), (32, 128, 9, "f32_strict")])
 def test_det_head_every_T(gpu_device, C, Hd, K, precision):
     import snn_automotive_object_detection_amd as S
     R = 37
@@ -62,3 +62,72 @@ def test_det_head_every_T(gpu_device, C, Hd, K, precision):
         worst[T] = int(off.sum())
         assert worst[T] <= flip_budget(R, 2 * Hd, T, "det", precision), (T, worst[T])
     assert sum(worst.values()) <= 8, worst
+
+
+@pytest.mark.parametrize("C", [256, 64])
+def test_rpn_head_spike_rates_every_T(gpu_device, C):
+    """spike-rate mode (rpn.py:172: counting launches, dense kernels, the LI membrane sums) at every T: logits / deltas within tolerance,
+    the shared LIF's spike counts per (level, image) equal to the oracle's as integers, LI rates within tolerance"""
+    import numpy as np
+    import snn_automotive_object_detection_amd as S
+    shapes = [(9, 12), (4, 5)]
+    g = torch.Generator().manual_seed(C + 1)
+    feats = [torch.randn(2, C, h, w, generator=g) * 1.7 for h, w in shapes]
+    fd = [f.to(gpu_device) for f in feats]
+    flips = 0
+    for T in range(2, 27):
+        torch.manual_seed(300 + T)
+        m = S.RPNHeadSNN(C, 3, T)
+        with torch.no_grad():
+            m.shared_conv.weight.mul_(4.0)
+        gc = []
+        o_l, o_b, o_r = OR.rpn_head_forward(feats, m.shared_conv.weight.detach(), m.conv_cls.weight.detach(), m.conv_bbox.weight.detach(), T,
+                                            spike_rates=True, counts_out=gc)
+        m = m.to(gpu_device)
+        m.spike_rates = True
+        lg, bb, rates = m(fd)
+        bad = 0
+        for l in range(len(shapes)):
+            d = torch.maximum((lg[l].cpu() - o_l[l]).abs().amax(1), (bb[l].cpu() - o_b[l]).abs().amax(1))
+            bad += int((d > 1e-4).sum())
+        flips += bad
+        assert bad <= 2, (T, bad)
+        counts = m.last_spike_counts.cpu().numpy()
+        for l in range(len(shapes)):
+            assert (np.abs(counts[l] - gc[l].numpy()) <= 4 * bad).all(), (T, l, counts[l], gc[l])
+            if bad == 0:
+                for j in (1, 2):
+                    assert torch.allclose(rates[3 * l + j].cpu(), o_r[3 * l + j], rtol=1e-4, atol=2e-5), (T, l, j)
+                assert torch.equal(rates[3 * l][:, 1].cpu(), o_r[3 * l][:, 1])
+    assert flips <= 4
+
+
+@pytest.mark.parametrize("C,Hd,K", [(32, 128, 9), (64, 1024, 11)])
+def test_det_head_spike_rates_every_T(gpu_device, C, Hd, K):
+    """faster_rcnn.py:520-618 at every T: the rate list (four [R, 2] tensors) and lif6 / lif7 spike counts per RoI as integers"""
+    import snn_automotive_object_detection_amd as S
+    R = 29
+    g = torch.Generator().manual_seed(Hd + 1)
+    x = torch.randn(R, C, 7, 7, generator=g) * 2
+    xd = x.to(gpu_device)
+    differing = 0
+    for T in range(2, 27):
+        torch.manual_seed(400 + T)
+        d = S.FastRCNNPredictorSNNFull(C * 49, Hd, K, T)
+        with torch.no_grad():
+            d.fc7.weight.mul_(3.0)
+        gd = []
+        o = OR.det_head_forward(x, d.fc6.weight.detach(), d.fc7.weight.detach(), d.cls_score.weight.detach(), d.bbox_pred.weight.detach(), T,
+                                spike_rates=True, counts_out=gd)
+        d = d.to(gpu_device)
+        d.spike_rates = True
+        r = d(xd)
+        assert len(r) == len(o) == 4
+        c6, c7 = [c.cpu() for c in d.last_spike_counts]
+        n_diff = int(((c6 != gd[0]) | (c7 != gd[1])).sum())
+        differing += n_diff
+        assert n_diff <= 1, (T, n_diff)
+        if n_diff == 0:
+            for j in range(4):
+                assert torch.allclose(r[j].cpu(), o[j], rtol=1e-4, atol=2e-5), (T, j)
+    assert differing <= 3

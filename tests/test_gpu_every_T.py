@@ -131,3 +131,27 @@ def test_det_head_spike_rates_every_T(gpu_device, C, Hd, K):
             for j in range(4):
                 assert torch.allclose(r[j].cpu(), o[j], rtol=1e-4, atol=2e-5), (T, j)
     assert differing <= 3
+
+
+@pytest.mark.parametrize("C,Hd", [(32, 128), (16, 64)])
+def test_fused_roialign_head_every_T(gpu_device, C, Hd):
+    """roi_heads.py:1217 + faster_rcnn.py:470-516 in one call (`forward_roialign`: RoIAlign fused with the encoder, then the head) against the
+    two-step path on pooled values of the stock-op restatement, at every T (C = 32: bin-major fc6 order + structured-sparse launch)"""
+    import snn_automotive_object_detection_amd as S
+    from tests.test_gpu_roialign import _setup
+    pool, feats, boxes, shapes = _setup(gpu_device, R=60, C=C, seed=5)
+    box_features = pool({k: v.cpu() for k, v in feats.items()}, [b.cpu() for b in boxes], shapes).to(gpu_device)
+    flist, scales, rois, lvl = pool.assign(feats, boxes, shapes)
+    total = 0
+    for T in range(2, 27):
+        torch.manual_seed(500 + T)
+        head = S.FastRCNNPredictorSNNFull(C * 49, Hd, 9, T).to(gpu_device)
+        with torch.no_grad():
+            head.fc7.weight.mul_(3.0)
+        c_ref, b_ref = head(box_features)
+        c_fused, b_fused = head.forward_roialign(flist, scales, rois, lvl)
+        rows_off = ((c_fused - c_ref).abs().amax(1) > 1e-4) | ((b_fused - b_ref).abs().amax(1) > 1e-4)
+        assert int(rows_off.sum()) <= 2, (T, int(rows_off.sum()))
+        assert float(c_ref.abs().max()) > 0
+        total += int(rows_off.sum())
+    assert total <= 6

@@ -98,6 +98,13 @@ int snn_debug_tile_shape(int conv, long long units, int n_cols, int num_steps, i
  * (csrc/snn_sparse.h: planes e_3 .. on v_smfmac, no dense launch), 0 if it took the dense launch (SNN_SPARSE=0, spike-rate mode, T outside 5 .. 16, channel counts that are not multiples of 64, ...). */
 int snn_debug_last_conv_path(void);
 int snn_debug_last_fc6_path(void);      /* the same for the detector head's fc6 + LIF */
+/* Introspection (parity tests): where the calling thread's last detector-head forward left its hidden spike planes in the caller's
+ * workspace: out3[0] / out3[1] = byte offsets of lif6's / lif7's planes ([T][R][Hd/32] words; lif6's are word-major [T][Hd/32][R] if
+ * out3[2] == 1).  The tests attribute every RoI that is off tolerance to a flipped spike of the launch that actually ran. */
+void snn_debug_last_det_planes(unsigned long long* out3);
+/* The same for the RPN head: out3[0] = byte offset of the shared LIF's spike planes ([T][P][C/32] words over all levels; in blocks of
+ * four words [T][C/128][P][4] if out3[1] == 1), out3[2] = P. */
+void snn_debug_last_rpn_planes(unsigned long long* out3);
 
 /* ---- weight packing (call when the weights change; results are plain device buffers) ---------- */
 /* number of floats of a packed GEMM operand with K reduction rows and N output columns */

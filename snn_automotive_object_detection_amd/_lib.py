@@ -44,6 +44,8 @@ SYMBOLS = {
     "snn_debug_encoder_thresholds": (C.c_int, [C.POINTER(snn_params), C.POINTER(C.c_float)]),
     "snn_debug_last_conv_path": (C.c_int, []),
     "snn_debug_last_fc6_path": (C.c_int, []),
+    "snn_debug_last_det_planes": (None, [C.POINTER(C.c_uint64)]),
+    "snn_debug_last_rpn_planes": (None, [C.POINTER(C.c_uint64)]),
     "snn_debug_tile_shape": (C.c_int, [C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32)]),
     "snn_packed_gemm_elems": (C.c_size_t, [C.c_int, C.c_int]),
     "snn_packed_conv3x3_elems": (C.c_size_t, [C.c_int, C.c_int]),

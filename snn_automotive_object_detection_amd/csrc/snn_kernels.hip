@@ -28,6 +28,8 @@
 // ------------------------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
 static thread_local int g_last_fc_sparse = 0;      // ... the detector's fc6 + LIF
+static thread_local unsigned long long g_last_rpn_planes[3] = {0, 0, 0};      // workspace offset of the shared LIF's spike planes, blocks of four words?, positions
+static thread_local unsigned long long g_last_det_planes[3] = {0, 0, 0};      // workspace offsets of lif6's / lif7's spike planes, lif6 word-major?
 static thread_local int g_last_conv_sparse = 0;    // did this thread's last RPN conv + LIF enqueue the sparse launch pair (snn_debug_last_conv_path)
 
 static int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
@@ -691,6 +693,8 @@ int snn_debug_encoder_thresholds(const snn_params* p, float* th32) {
 
 int snn_debug_last_conv_path(void) { return g_last_conv_sparse; }
 int snn_debug_last_fc6_path(void) { return g_last_fc_sparse; }
+void snn_debug_last_rpn_planes(unsigned long long* out3) { if (out3) for (int i = 0; i < 3; ++i) out3[i] = g_last_rpn_planes[i]; }
+void snn_debug_last_det_planes(unsigned long long* out3) { if (out3) for (int i = 0; i < 3; ++i) out3[i] = g_last_det_planes[i]; }
 
 int snn_debug_tile_shape(int conv, long long units, int n_cols, int num_steps, int spike_rates, int layer, int32_t* out) {
     if (!out || units <= 0 || n_cols <= 0 || num_steps < 1 || num_steps > SNN_MAX_STEPS) return fail(-1, "snn_debug_tile_shape: bad argument");
@@ -1641,6 +1645,7 @@ int snn_rpn_head_forward_stages(const snn_rpn_level* lv, int n_levels, int C, in
             if (rc) return rc;
         }
     }
+    g_last_rpn_planes[0] = o_spk; g_last_rpn_planes[1] = split ? 1 : 0; g_last_rpn_planes[2] = (unsigned long long)P;
     if (!(stage_mask & SNN_STAGE_LI_HEADS)) return 0;
     return li_heads_impl(spk, stride, T, (int)P, C, w_heads_packed, A, 4 * A, p, out_logits, out_bbox, sum_logits,
                          sum_bbox, split, stream);
@@ -1946,6 +1951,7 @@ static int det_head_from_planes(int R, int D, int Hd, int K, int K4, int T, cons
     uint32_t* s6 = (uint32_t*)((char*)ws + o_s6);
     uint32_t* s7 = (uint32_t*)((char*)ws + o_s7);
     const int Hw = cdiv(Hd, 32), Hp = Hw * 32;
+    g_last_det_planes[0] = o_s6; g_last_det_planes[1] = o_s7; g_last_det_planes[2] = enc_wm ? 1 : 0;
     int rc;
     if (k_inner > 1) {
         // fc6's weights were packed in the permuted reduction order k' = s * C + c (snn_pack_linear_weight_bf16x3_perm): bring the

@@ -86,15 +86,33 @@ __host__ __device__ inline uint32_t sp_nibble_code(uint32_t x) {
 // writing planes in the reference's order; this kernel transposes the bits of every (plane, RoI) row, and fc6's weights are packed in
 // the same order (snn_pack_linear_weight_bf16x3_perm): the contraction is the same sum in another order.
 // Block = (32 RoIs, plane); word-major planes [T][Dw][R] in and out.  Thread task = (RoI, block of 32 channels): the channels' 32 x S bits are
-// S words of the row; with S a compile-time constant every bit move is v_bfe + v_lshl_or on registers (S = 49: 3136 operations per task,
-// ~15 us for 2000 RoIs x 10 planes; the first version gathered every bit from LDS: 82 us).  Stores: 32 consecutive RoIs of one word.
+// S words of the row, i.e. a 32 x S bit matrix (row = channel: S consecutive bits at bit offset j S) that leaves as its transpose (S words
+// of 32 channel bits).  With S a compile-time constant: each channel's bits are cut out with two funnel shifts (v_alignbit) into a 32-bit
+// and an (S - 32)-bit part, and the two 32 x 32 bit matrices are transposed in registers by the five-stage butterfly (Hacker's Delight
+// 7-3, LSB-first form): ~1100 operations per task.  (First version: every bit gathered from LDS, 82 us for 2000 RoIs x 10 planes; second:
+// one v_bfe + v_lshl_or per bit, 3136 operations per task, 38 us.)  Stores: 32 consecutive RoIs of one word.
+__device__ __forceinline__ void bit_transpose32(uint32_t (&a)[32]) {          // out[s] bit j = in[j] bit s
+#pragma unroll
+    for (int st = 0; st < 5; ++st) {
+        const int jj = 16 >> st;
+        const uint32_t m = st == 0 ? 0x0000ffffu : st == 1 ? 0x00ff00ffu : st == 2 ? 0x0f0f0f0fu : st == 3 ? 0x33333333u : 0x55555555u;
+#pragma unroll
+        for (int k = 0; k < 32; ++k)
+            if (!(k & jj)) {
+                const uint32_t t = ((a[k] >> jj) ^ a[k + jj]) & m;
+                a[k] ^= t << jj;
+                a[k + jj] ^= t;
+            }
+    }
+}
+
 template <int S>
 __global__ __launch_bounds__(256) void k_permute_planes(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int Dw, int R, int C) {
+    static_assert(S > 32 && S <= 64, "two 32-column parts");
     extern __shared__ uint32_t pl[];                          // [Dw][32 + 1]
     const int t = blockIdx.y, r0 = blockIdx.x * 32, rl = threadIdx.x & 31;
     const bool live = r0 + rl < R;
-    // (the row's words are requested in batches of 7: one load in flight per thread made this kernel a chain of memory latencies, 82 -> 48 us
-    // even with register bit moves)
+    // (the row's words are requested in batches of 7: one load in flight per thread made this kernel a chain of memory latencies)
     for (int w0 = threadIdx.x >> 5; w0 < Dw; w0 += 8 * 7) {
         uint32_t v[7];
 #pragma unroll
@@ -109,19 +127,23 @@ __global__ __launch_bounds__(256) void k_permute_planes(const uint32_t* __restri
     __syncthreads();
     const int cbn = C / 32;                                   // channel blocks = words per bin in the permuted order
     for (int cb = threadIdx.x >> 5; cb < cbn; cb += 8) {
-        uint32_t w[S];
+        uint32_t w[S + 1];
 #pragma unroll
         for (int i = 0; i < S; ++i) w[i] = pl[(cb * S + i) * 33 + rl];          // bits [32 cb S, 32 (cb + 1) S) of the row: channel j at bit j S + s
+        w[S] = 0u;
+        uint32_t lo[32], hi[32];
 #pragma unroll
-        for (int s = 0; s < S; ++s) {
-            uint32_t o = 0;
+        for (int j = 0; j < 32; ++j) {
+            const int o = j * S, i = o >> 5, sh = o & 31;                        // compile-time after unrolling
+            lo[j] = sh ? __builtin_amdgcn_alignbit(w[i + 1], w[i], sh) : w[i];
+            hi[j] = (sh ? __builtin_amdgcn_alignbit(w[i + 2 <= S ? i + 2 : S], w[i + 1], sh) : w[i + 1]) & ((1u << (S - 32)) - 1u);
+        }
+        bit_transpose32(lo);
+        bit_transpose32(hi);
+        if (live) {
 #pragma unroll
-            for (int j = 0; j < 32; ++j) {
-                constexpr int dummy = 0; (void)dummy;
-                const int k = j * S + s;
-                o |= ((w[k >> 5] >> (k & 31)) & 1u) << j;
-            }
-            if (live) out[((size_t)t * Dw + (size_t)s * cbn + cb) * R + r0 + rl] = o;
+            for (int s = 0; s < S; ++s)
+                out[((size_t)t * Dw + (size_t)s * cbn + cb) * R + r0 + rl] = s < 32 ? lo[s] : hi[s - 32];
         }
     }
 }

@@ -12,6 +12,7 @@
 // ------------------------------------------------------------------------------------------------
 #define ENC_PB 64                                   // positions per block (a wave = 64 consecutive positions of one channel: 256-byte runs)
 #define ENC_WB 4                                    // channel words per block
+#define ENC_LDS_BYTES(T) ((size_t)(T) * ENC_PB * (ENC_WB + 1) * 4)
 // Wpad > 0: the planes carry a one-position zero halo around every image (row (n, y, x) -> (n*(H+2) + y+1)*(W+2) + x+1,
 // W = Wpad), written here as well (by the threads of the border positions).  The conv kernels of the bf16x3 and mxfp6 families
 // read their 3x3 taps from such planes without any border logic.
@@ -20,7 +21,9 @@ __device__ __forceinline__ void encode_block(const float* __restrict__ feat, int
                                              const EncTh& eth, uint32_t* __restrict__ planes, size_t plane_stride, int n, int bx, int by,
                                              int Wpad = 0, size_t wm_rows = 0) {
     constexpr bool ZR = EM != ENC_GENERIC;
-    __shared__ uint32_t wbuf[SNN_MAX_STEPS * ENC_PB * (ENC_WB + 1)];      // [t][position][4 words + 1 pad]
+    // dynamic: ENC_LDS_BYTES(T) - sized by the launch's T, not by SNN_MAX_STEPS (40 KB, four blocks per CU: the loads of 16 waves did not
+    // cover the HBM latency; T = 8: 9 KB)
+    extern __shared__ uint32_t wbuf[];                                     // [t][position][4 words + 1 pad]
     const int pl = threadIdx.x & (ENC_PB - 1), cgl = threadIdx.x / ENC_PB;
     const int pos = bx * ENC_PB + pl;
     const int cg = by * ENC_WB + cgl;

@@ -1174,9 +1174,9 @@ int snn_encode_nchw(const float* feat, int N, int C, int H, int W, int T, const 
     const EncTh* eth;
     const int em = enc_mode(np, &eth);
     const dim3 g(cdiv(HW, ENC_PB), cdiv(Cw, ENC_WB), N);
-    if (em == ENC_QUANT) hipLaunchKernelGGL(k_encode_nchw<ENC_QUANT>, g, dim3(256), 0, (hipStream_t)s, feat, C, HW, Cw, T, np, *eth, planes, plane_stride);
-    else if (em == ENC_ZR) hipLaunchKernelGGL(k_encode_nchw<ENC_ZR>, g, dim3(256), 0, (hipStream_t)s, feat, C, HW, Cw, T, np, *eth, planes, plane_stride);
-    else hipLaunchKernelGGL(k_encode_nchw<ENC_GENERIC>, g, dim3(256), 0, (hipStream_t)s, feat, C, HW, Cw, T, np, *eth, planes, plane_stride);
+    if (em == ENC_QUANT) hipLaunchKernelGGL(k_encode_nchw<ENC_QUANT>, g, dim3(256), ENC_LDS_BYTES(T), (hipStream_t)s, feat, C, HW, Cw, T, np, *eth, planes, plane_stride);
+    else if (em == ENC_ZR) hipLaunchKernelGGL(k_encode_nchw<ENC_ZR>, g, dim3(256), ENC_LDS_BYTES(T), (hipStream_t)s, feat, C, HW, Cw, T, np, *eth, planes, plane_stride);
+    else hipLaunchKernelGGL(k_encode_nchw<ENC_GENERIC>, g, dim3(256), ENC_LDS_BYTES(T), (hipStream_t)s, feat, C, HW, Cw, T, np, *eth, planes, plane_stride);
     SNN_CHECK_LAUNCH("k_encode_nchw");
     return 0;
 }
@@ -1615,9 +1615,9 @@ int snn_rpn_head_forward_stages(const snn_rpn_level* lv, int n_levels, int C, in
         const EncTh* eth;
         const int em = enc_mode(np, &eth);
         const dim3 ge(blocks, cdiv(Cw, ENC_WB));
-        if (em == ENC_QUANT) hipLaunchKernelGGL(k_encode_levels<ENC_QUANT>, ge, dim3(256), 0, s, el, C, Cw, Tc, np, *eth, enc, enc_stride, wm_rows);
-        else if (em == ENC_ZR) hipLaunchKernelGGL(k_encode_levels<ENC_ZR>, ge, dim3(256), 0, s, el, C, Cw, Tc, np, *eth, enc, enc_stride, wm_rows);
-        else hipLaunchKernelGGL(k_encode_levels<ENC_GENERIC>, ge, dim3(256), 0, s, el, C, Cw, Tc, np, *eth, enc, enc_stride, wm_rows);
+        if (em == ENC_QUANT) hipLaunchKernelGGL(k_encode_levels<ENC_QUANT>, ge, dim3(256), ENC_LDS_BYTES(Tc), s, el, C, Cw, Tc, np, *eth, enc, enc_stride, wm_rows);
+        else if (em == ENC_ZR) hipLaunchKernelGGL(k_encode_levels<ENC_ZR>, ge, dim3(256), ENC_LDS_BYTES(Tc), s, el, C, Cw, Tc, np, *eth, enc, enc_stride, wm_rows);
+        else hipLaunchKernelGGL(k_encode_levels<ENC_GENERIC>, ge, dim3(256), ENC_LDS_BYTES(Tc), s, el, C, Cw, Tc, np, *eth, enc, enc_stride, wm_rows);
         SNN_CHECK_LAUNCH("k_encode_levels");
     }
     if (stage_mask & SNN_STAGE_CONV_LIF) {

@@ -152,6 +152,6 @@ def test_fused_roialign_head_every_T(gpu_device, C, Hd):
         c_fused, b_fused = head.forward_roialign(flist, scales, rois, lvl)
         rows_off = ((c_fused - c_ref).abs().amax(1) > 1e-4) | ((b_fused - b_ref).abs().amax(1) > 1e-4)
         assert int(rows_off.sum()) <= 2, (T, int(rows_off.sum()))
-        assert float(c_ref.abs().max()) > 0
+        assert T < 12 or float(c_ref.abs().max()) > 0           # (with few steps no spike has reached the LI heads' membranes yet: all-zero outputs)
         total += int(rows_off.sum())
     assert total <= 6

@@ -138,8 +138,8 @@ struct Gemm3Args {
 // ONE integer atomic per (level, image) slot present in the tile (conv; lanes with equal slots are combined in the wave
 // first) or one per row (linear layers).  Integer atomics: the totals do not depend on the order of arrival.
 #define G3_CNT_BYTES 2048                           // pos_cnt: one uint32 per tile position (pb <= 512)
-template <bool CONV>
-__device__ __forceinline__ void tile_counts_flush(const Gemm3Args& a, const uint32_t* pos_cnt, int m0, int pb, int tid) {
+template <bool CONV, class Args>
+__device__ __forceinline__ void tile_counts_flush(const Args& a, const uint32_t* pos_cnt, int m0, int pb, int tid) {
     const int lane = tid & 63;
     for (int i = tid; i < ((pb + 63) & ~63); i += (int)blockDim.x) {     // whole waves take a round together
         const int pos = m0 + i;

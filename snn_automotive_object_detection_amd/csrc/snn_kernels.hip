@@ -1024,7 +1024,7 @@ static bool sparse_plan(int Tc, SparsePlan* sp, long long units = 0, int n_block
 static int gemm3_lif_sparse(const Gemm3Args& a, bool conv, void* side, size_t side_bytes, hipStream_t s) {
     SparsePlan sp;
     const int Kw = conv ? a.Cw : a.Kc;                        // plane words per row
-    if (!knobs().sparse || !side || !a.wm || !a.periods || a.cnt_img || a.cnt_row || Kw % 2 || a.Np % 64 || a.Kc * 32 > 65536 || a.T < 5 || a.T > 16 ||          /* (T = 4: built and measured 2.3 % slower than the dense launch) */
+    if (!knobs().sparse || !side || !a.wm || !a.periods || Kw % 2 || a.Np % 64 || a.Kc * 32 > 65536 || a.T < 5 || a.T > 16 ||          /* (T = 4: built and measured 2.3 % slower than the dense launch) */
         a.Tc != a.T - (conv ? 1 : 2) || a.t0 != 0 || a.p.v_leak != 0.0f || (float)(a.p.v_leak - a.p.v_th) > 0.0f || (!conv && !a.out_wm) ||
         !sparse_plan(a.Tc, &sp, conv ? 0 : a.M, a.Np / 64))
         return 0;
@@ -1060,6 +1060,14 @@ static int gemm3_lif_sparse(const Gemm3Args& a, bool conv, void* side, size_t si
         grid = sa.xcd_contig * sa.xcd_cpx * 8;
     }
     const int lds = max((int)SP_LDS, a.Tc * sp.pb * SP_PITCH * 4);      // the ring, then the epilogue's tile image in the same bytes
+    // spike-rate mode: the LIF epilogue adds its popcounts per row (RoI: straight into the caller's counters; conv: into per-position
+    // counters behind the compressed planes, summed per (level, image) by a small launch afterwards)
+    uint32_t* cnt_pos = nullptr;
+    if (conv && a.cnt_img) {
+        cnt_pos = (uint32_t*)((char*)side + align_up((size_t)cmp_bytes, 256));
+        if (hipMemsetAsync(cnt_pos, 0, (size_t)P * 4, s) != hipSuccess) return fail(-3, "hipMemsetAsync failed");
+    }
+    sa.cnt_row = conv ? cnt_pos : a.cnt_row;
     if (lds > 80 * 1024) return 0;
     const void* kern = conv ? (const void*)k_gemm_lif_sparse<true, 1> : sp.wn == 2 ? (const void*)k_gemm_lif_sparse<false, 2> : (const void*)k_gemm_lif_sparse<false, 1>;
     hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -1073,6 +1081,14 @@ static int gemm3_lif_sparse(const Gemm3Args& a, bool conv, void* side, size_t si
     e = hipLaunchKernel(kern, dim3(grid), dim3(512), kargs, lds, s);
     if (e != hipSuccess) return fail(-3, "k_gemm_lif_sparse launch failed: %s", hipGetErrorString(e));
     SNN_CHECK_LAUNCH("k_gemm_lif_sparse");
+    if (cnt_pos) {
+        PosCountArgs pa;
+        memset(&pa, 0, sizeof(pa));
+        pa.cnt_pos = cnt_pos; pa.cnt_img = a.cnt_img; pa.n_levels = a.n_levels; pa.max_n = a.max_n;
+        memcpy(pa.lv, a.lv, sizeof(pa.lv));
+        hipLaunchKernelGGL(k_sum_pos_counts, dim3(a.n_levels * a.max_n), dim3(256), 0, s, pa);
+        SNN_CHECK_LAUNCH("k_sum_pos_counts");
+    }
     return 1;
 }
 
@@ -1525,10 +1541,10 @@ static long long rpn_positions_padded(const snn_rpn_level* lv, int n_levels) {
 
 // Pe = rows of an encoder plane (positions; with the zero halo for the mxfp6 path)
 // bytes behind the two plane sets for the structured-sparse conv (snn_sparse.h): the compressed planes, primary + secondary (SP_A_ARR
-// dwords per row and 64 k; planes e_3 .. of at most T - 1 current planes)
+// dwords per row and 64 k; planes e_3 .. of at most T - 1 current planes) and the per-position spike counters of spike-rate mode
 static size_t sparse_side_bytes(long long P, long long Pe, int Kw, int T) {     // Kw = 32-bit words per row of a plane
-    (void)P;
-    return align_up((size_t)max(T - 3, 1) * cdiv(Kw, 2) * SP_A_ARR * (size_t)Pe * 4, 256) + 256;
+    // (+ one spike counter per position for the conv's spike-rate mode)
+    return align_up((size_t)max(T - 3, 1) * cdiv(Kw, 2) * SP_A_ARR * (size_t)Pe * 4, 256) + align_up((size_t)P * 4, 256) + 256;
 }
 static size_t rpn_sparse_bytes(long long P, long long Pe, int C, int T) { return sparse_side_bytes(P, Pe, cdiv(C, 32), T); }
 static void rpn_ws_layout(long long P, long long Pe, int C, int T, int precision, size_t* o_spk, size_t* o_cur, size_t* o_cnt,

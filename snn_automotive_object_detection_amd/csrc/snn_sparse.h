@@ -48,6 +48,9 @@ struct SparseConvArgs {
     const uint16_t* wpk;         // [3][Kc][Np][32] bf16
     uint32_t* spk;               // spike planes out
     unsigned long long* tl;      // SNN_EXP_TIMELINE builds: 8 stamps per work-group
+    // spike-rate side output (nullable; zeroed by the caller): spikes per row - RoI, or position (the conv's launcher sums them per
+    // (level, image) afterwards: k_sum_pos_counts).  Integer atomics, one per (row, 32 columns): order-independent.
+    uint32_t* cnt_row;
     unsigned long long plane_elems, spk_stride;
     unsigned int Pe;             // padded rows of a word plane
     int M, Kc, Np, Cw, n_blocks, n_tiles, n_levels;
@@ -187,8 +190,10 @@ __global__ __launch_bounds__(256) void k_compress_planes(const CompressArgs a) {
 // k_gemm_bf16x3's epilogue (period planes, v_leak = 0, no spike at step 0, conv window T - 1), same operations in the same order per
 // neuron.  NP = 2: the recurrence is one dependent chain of ~6 operations per step; two of them interleaved fill each other's latencies
 // (LIF part of an epilogue pass 3.9 -> see profiles/r4_sparse_timeline.txt).
-template <int TS, int D, int NP>
-__device__ __forceinline__ void sp_lif_fixed(const float* const (&src)[NP], const int group_stride, const NeuronP& p, uint32_t (&my0)[NP], uint32_t (&my1)[NP]) {
+// COUNT: also the spikes per position (low / high half of the ballot = even / odd position of the pair): scalar popcounts.
+template <int TS, int D, int NP, bool COUNT>
+__device__ __forceinline__ void sp_lif_fixed(const float* const (&src)[NP], const int group_stride, const NeuronP& p, uint32_t (&my0)[NP], uint32_t (&my1)[NP],
+                                             uint32_t (&cnt_lo)[NP], uint32_t (&cnt_hi)[NP]) {
     constexpr int TCS = TS - D;                          // currents of steps 0 .. T - 1 - D (conv: D = 1; fc6: D = 2 - dead time steps)
     float ug[NP][TCS];
 #pragma unroll
@@ -217,8 +222,27 @@ __device__ __forceinline__ void sp_lif_fixed(const float* const (&src)[NP], cons
             ii[u] = __fadd_rn(i_dec, c);
             const unsigned long long b = __ballot(z);
             G3_KEEP_BALLOT(my0[u], my1[u], b, t);
+            if (COUNT) { cnt_lo[u] += (uint32_t)__builtin_popcount((uint32_t)b); cnt_hi[u] += (uint32_t)__builtin_popcount((uint32_t)(b >> 32)); }
         }
     }
+}
+
+// spike-rate mode of the sparse conv: spikes per (level, image) slot from the per-position counts; block = slot
+struct PosCountArgs { const uint32_t* cnt_pos; unsigned long long* cnt_img; int n_levels, max_n; ConvLevelDev lv[SNN_MAX_LEVELS]; };
+__global__ __launch_bounds__(256) void k_sum_pos_counts(const PosCountArgs a) {
+    __shared__ unsigned long long part[4];
+    const int l = blockIdx.x / a.max_n, n = blockIdx.x % a.max_n;
+    unsigned long long sum = 0;
+    if (n < a.lv[l].N) {
+        const int hw = a.lv[l].H * a.lv[l].W;
+        const uint32_t* src = a.cnt_pos + a.lv[l].pos_base + (size_t)n * hw;
+        for (int i = threadIdx.x; i < hw; i += 256) sum += src[i];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) a.cnt_img[blockIdx.x] += part[0] + part[1] + part[2] + part[3];
 }
 
 // WN = waves along the 64 columns.  1: 8 row-waves x 4 slots, every wave reads the whole weight slot from LDS each step (192 KB per
@@ -475,6 +499,7 @@ __global__ __launch_bounds__(512, 4) void k_gemm_lif_sparse(const SparseConvArgs
     const int rows_l = Tc * pb;
     __syncthreads();                                           // ring reads done
     const int group_stride = pb * SP_PITCH;
+    const bool counting = args.cnt_row != nullptr;
 #pragma unroll 1
     for (int h = 0; h < 2; ++h) {
         __syncthreads();
@@ -502,22 +527,25 @@ __global__ __launch_bounds__(512, 4) void k_gemm_lif_sparse(const SparseConvArgs
         const int word0 = (nb * 64 + h * 32) >> 5;
         const int par = lane >> 5, col = lane & 31;
         // position pairs per wave and iteration (see sp_lif_fixed): two up to T = 10, one beyond (registers: T - 1 period sums per neuron)
-        auto lif_pass = [&](auto np_c) __attribute__((always_inline)) {
+        auto lif_pass = [&](auto np_c, auto count_c) __attribute__((always_inline)) {
         constexpr int NP = decltype(np_c)::value;
+        constexpr bool COUNT = decltype(count_c)::value;
         for (int pp0 = wave; 2 * pp0 < pb; pp0 += 8 * NP) {
             if (m0 + 2 * pp0 >= M) break;
-            uint32_t my0[NP], my1[NP];
+            uint32_t my0[NP], my1[NP], cnt_lo[NP], cnt_hi[NP];
             const float* src[NP];
 #pragma unroll
             for (int u = 0; u < NP; ++u) {
                 const int pi = 2 * (pp0 + 8 * u) + par;
                 const bool live = pi < pb && m0 + pi < M;
-                my0[u] = 0; my1[u] = 0;
+                my0[u] = 0; my1[u] = 0; cnt_lo[u] = 0; cnt_hi[u] = 0;
                 src[u] = tile + (live ? pi : 2 * pp0) * SP_PITCH + col;    // (dead lanes / pairs recompute a live row: never stored)
             }
-#define SP_T(n) case n: sp_lif_fixed<n, CONV ? 1 : 2, NP>(src, group_stride, args.p, my0, my1); break;
+#define SP_T(n) case n: sp_lif_fixed<n, CONV ? 1 : 2, NP, COUNT>(src, group_stride, args.p, my0, my1, cnt_lo, cnt_hi); break;
             if constexpr (NP == 2) {
                 switch (T) { SP_T(5) SP_T(6) SP_T(7) SP_T(8) SP_T(9) SP_T(10) default: break; }
+            } else if constexpr (COUNT) {
+                switch (T) { SP_T(5) SP_T(6) SP_T(7) SP_T(8) SP_T(9) SP_T(10) SP_T(11) SP_T(12) SP_T(13) SP_T(14) SP_T(15) SP_T(16) default: break; }
             } else {
                 switch (T) { SP_T(11) SP_T(12) SP_T(13) SP_T(14) SP_T(15) SP_T(16) default: break; }
             }
@@ -527,6 +555,10 @@ __global__ __launch_bounds__(512, 4) void k_gemm_lif_sparse(const SparseConvArgs
                 const int pp = pp0 + 8 * u;
                 if (2 * pp >= pb || m0 + 2 * pp >= M) continue;
                 const bool odd_ok = 2 * pp + 1 < pb && m0 + 2 * pp + 1 < M;
+                if (COUNT && lane == 0) {                                  // (dead odd rows recompute the even one: not counted)
+                    if (cnt_lo[u]) atomicAdd(args.cnt_row + m0 + 2 * pp, cnt_lo[u]);
+                    if (odd_ok && cnt_hi[u]) atomicAdd(args.cnt_row + m0 + 2 * pp + 1, cnt_hi[u]);
+                }
                 if (lane < T) {
                     if (!CONV) {                                           // linear layer: word-major spike planes [T][word][RoI] (fc6 -> fc7)
                         uint32_t* dst = args.spk + (size_t)lane * args.spk_stride + (size_t)word0 * M + (m0 + 2 * pp);
@@ -545,8 +577,12 @@ __global__ __launch_bounds__(512, 4) void k_gemm_lif_sparse(const SparseConvArgs
             }
         }
         };
-        if (T <= 10) lif_pass(std::integral_constant<int, 2>{});
-        else lif_pass(std::integral_constant<int, 1>{});
+        if (counting) {                                            // (one recurrence per lane: the counters take the registers of the second)
+            lif_pass(std::integral_constant<int, 1>{}, std::true_type{});
+        } else {
+            if (T <= 10) lif_pass(std::integral_constant<int, 2>{}, std::false_type{});
+            else lif_pass(std::integral_constant<int, 1>{}, std::false_type{});
+        }
 #ifdef SNN_EXP_TIMELINE
         if (h == 0) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_epi) :: "memory");
 #endif

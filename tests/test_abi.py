@@ -39,11 +39,11 @@ def test_size_queries_and_argument_validation_without_gpu():
     assert lib.snn_rpn_head_workspace_bytes(lv, 1, 256, 3, 8, 0) == 2 * 8 * (2 * 192 * 384) * 8 * 4
     # (bf16x3 / mxfp6: the encoder planes carry a one-position zero halo around every image)
     # ... plus, for bf16x3, the side buffer of the structured-sparse conv behind the two plane sets: compressed planes e_3 .. e_7, primary +
-    # secondary (3 + 1 dwords per row and 64 k)
+    # secondary (3 + 1 dwords per row and 64 k), and one spike counter per position (spike-rate mode)
     two = 2 * 8 * (2 * 194 * 386) * 8 * 4
     assert lib.snn_rpn_head_workspace_bytes(lv, 1, 256, 3, 8, 2) == two
     side = lib.snn_rpn_head_workspace_bytes(lv, 1, 256, 3, 8, 1) - two
-    assert 5 * 4 * 4 * (2 * 194 * 386) * 4 <= side <= 5 * 4 * 4 * (2 * 194 * 386) * 4 + 1024
+    assert 5 * 4 * 4 * (2 * 194 * 386) * 4 + (2 * 192 * 384) * 4 <= side <= 5 * 4 * 4 * (2 * 194 * 386) * 4 + (2 * 192 * 384) * 4 + 1024
     assert lib.snn_det_head_workspace_bytes(2000, 12544, 1024, 9, 36, 12, 1) > 0
     # null / bad arguments are rejected before any device work, with a message
     p = _lib.snn_params(0.1, -0.2, 0, 0, 0.25, 0.1, 0, 0)

@@ -95,7 +95,7 @@ int snn_debug_encoder_thresholds(const snn_params* p, float* th32);
  * many steps (the launch then takes the un-fused path). */
 int snn_debug_tile_shape(int conv, long long units, int n_cols, int num_steps, int spike_rates, int layer, int32_t* out);
 /* Introspection (tests, bench.py): 1 if the calling thread's last bf16x3 RPN conv + LIF enqueued the structured-sparse launch pair
- * (csrc/snn_sparse.h: planes e_3 .. on v_smfmac, no dense launch), 0 if it took the dense launch (SNN_SPARSE=0, spike-rate mode, T outside 5 .. 16, channel counts that are not multiples of 64, ...). */
+ * (csrc/snn_sparse.h: planes e_3 .. on v_smfmac, no dense launch), 0 if it took the dense launch (SNN_SPARSE=0, T outside 5 .. 16, channel counts that are not multiples of 64, ...). */
 int snn_debug_last_conv_path(void);
 int snn_debug_last_fc6_path(void);      /* the same for the detector head's fc6 + LIF */
 /* Introspection (parity tests): where the calling thread's last detector-head forward left its hidden spike planes in the caller's

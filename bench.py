@@ -474,11 +474,17 @@ def sweep_t_leg(leg, iters=8):
     import ctypes as Ct
     from snn_automotive_object_detection_amd import _lib, ops
     lib = _lib.load()
-    out32 = (Ct.c_int32 * 8)()
+    out32 = (Ct.c_int32 * 12)()
     pos = sum(int(f.shape[0] * f.shape[2] * f.shape[3]) for f in leg.feats)
     R = int(leg.rois.shape[0])
     t_rpn0, t_det0 = leg.rpn_head.num_steps, leg.det_head.num_steps
     res = {"rpn": {}, "det": {}}
+
+    def plan_of(o):                                   # the plan of the launch that runs (structured-sparse or the dense tile)
+        if o[8]:
+            return {"kernel": "k_gemm_lif_sparse", "period_planes": {"dense": o[9], "sparse": o[10]}, "wave_grid": "%d x %d" % (8 // o[7], o[7]),
+                    "fill": round(o[11] / float((8 // o[7]) * o[0]), 4)}          # M-tile slots in use / slots of the wave grid
+        return {"kernel": "k_gemm_bf16x3", "fill": round(o[3] * o[4] / o[2], 4)}
     try:
         for T in range(4, 13):
             leg.rpn_head.num_steps = T
@@ -486,17 +492,18 @@ def sweep_t_leg(leg, iters=8):
             ms = leg.time_ms(lambda: leg.rpn_head(leg.feats), iters)
             p_, w_sh, w_hd = leg.rpn_head._params(), leg.rpn_head._packed_shared(), leg.rpn_head._cache_heads.val
             conv_ms = leg.time_ms(lambda: ops.rpn_head_forward(leg.feats, C, A, T, p_, w_sh, w_hd, stage_mask=2), iters)   # the conv+LIF launch alone
-            _lib.check(lib.snn_debug_tile_shape(1, pos, C, T, 0, 0, out32), "snn_debug_tile_shape")
+            _lib.check(lib.snn_debug_tile_shape(1, pos, C, C, T, 0, 0, out32), "snn_debug_tile_shape")
+            assert bool(out32[8]) == bool(lib.snn_debug_last_conv_path()), "snn_debug_tile_shape disagrees with the launch that ran"
             res["rpn"][T] = {"ms": round(ms, 4), "conv_lif_ms": round(conv_ms, 4), "steps": out32[4], "tile_rows": out32[2], "per_tile": out32[3],
-                             "fill": round(out32[3] * out32[4] / out32[2], 4), "work_groups": out32[5]}
+                             "work_groups": out32[5], **plan_of(out32)}
         for T in range(8, 17):
             leg.det_head.num_steps = T
             leg.det_head(leg.rois)
             ms = leg.time_ms(lambda: leg.det_head(leg.rois), iters)
-            _lib.check(lib.snn_debug_tile_shape(0, R, HD, T, 0, 6, out32), "snn_debug_tile_shape")
+            _lib.check(lib.snn_debug_tile_shape(0, R, C * 49, HD, T, 0, 6, out32), "snn_debug_tile_shape")
+            assert bool(out32[8]) == bool(lib.snn_debug_last_fc6_path()), "snn_debug_tile_shape disagrees with the launch that ran"
             res["det"][T] = {"ms": round(ms, 4), "steps": out32[4], "tile_rows": out32[2], "per_tile": out32[3],
-                             "fill": round(out32[3] * out32[4] / out32[2], 4), "work_groups": out32[5],
-                             "rounds_per_cu_pair": round(out32[5] / 512.0, 3)}
+                             "work_groups": out32[5], "rounds_per_cu_pair": round(out32[5] / 512.0, 3), **plan_of(out32)}
     finally:
         leg.rpn_head.num_steps, leg.det_head.num_steps = t_rpn0, t_det0
     for head, t_ref in (("rpn", 8), ("det", 12)):

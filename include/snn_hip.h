@@ -78,33 +78,6 @@ typedef struct snn_rpn_level {
 
 int snn_version(void);
 const char* snn_last_error(void);
-void snn_debug_reload_knobs(void);     /* re-read the SNN_* debug knobs from the environment (tests only) */
-/* Introspection (tests): the threshold table of the period-plane encoder for these parameters - a neuron's first spike is at or before
- * step t iff its input is >= th[t] (csrc/snn_common.h: THRESHOLD FORM).  th[0..31] out; returns 1 if the table verified against the
- * recurrence on the host (the encoders then use it), 0 if not (they keep the recurrence), negative on bad arguments. */
-int snn_debug_encoder_thresholds(const snn_params* p, float* th32);
-/* Introspection (bench.py's t_sweep leg, tests): the row tile a T-in-tile launch of the bf16x3 family would use.
- *   conv        1: the RPN's shared 3x3 conv (units = positions of the pyramid, n_cols = C_out); 0: a linear layer of the detector
- *               head (units = RoIs, n_cols = its outputs)
- *   num_steps   LIF steps T of the head
- *   spike_rates (conv = 0 only) non-zero: the head runs in spike-rate mode, whose fc6 window is one step longer (the rate counts
- *               lif6's spikes of every step, faster_rcnn.py:556)
- *   layer       (conv = 0 only) 6 or 7: fc6's or fc7's window of time steps (any other value reads as 6)
- * out[0..7] = {M-tiles per wave, short row-waves, tile rows, positions or RoIs per tile, time steps whose currents are formed
- * (dead time steps removed), work-groups of the launch, column blocks, waves along N}.  Returns 0, or -4 if no tile holds that
- * many steps (the launch then takes the un-fused path). */
-int snn_debug_tile_shape(int conv, long long units, int n_cols, int num_steps, int spike_rates, int layer, int32_t* out);
-/* Introspection (tests, bench.py): 1 if the calling thread's last bf16x3 RPN conv + LIF enqueued the structured-sparse launch pair
- * (csrc/snn_sparse.h: planes e_3 .. on v_smfmac, no dense launch), 0 if it took the dense launch (SNN_SPARSE=0, T outside 5 .. 16, channel counts that are not multiples of 64, ...). */
-int snn_debug_last_conv_path(void);
-int snn_debug_last_fc6_path(void);      /* the same for the detector head's fc6 + LIF */
-/* Introspection (parity tests): where the calling thread's last detector-head forward left its hidden spike planes in the caller's
- * workspace: out3[0] / out3[1] = byte offsets of lif6's / lif7's planes ([T][R][Hd/32] words; lif6's are word-major [T][Hd/32][R] if
- * out3[2] == 1).  The tests attribute every RoI that is off tolerance to a flipped spike of the launch that actually ran. */
-void snn_debug_last_det_planes(unsigned long long* out3);
-/* The same for the RPN head: out3[0] = byte offset of the shared LIF's spike planes ([T][P][C/32] words over all levels; in blocks of
- * four words [T][C/128][P][4] if out3[1] == 1), out3[2] = P. */
-void snn_debug_last_rpn_planes(unsigned long long* out3);
 
 /* ---- weight packing (call when the weights change; results are plain device buffers) ---------- */
 /* number of floats of a packed GEMM operand with K reduction rows and N output columns */

@@ -57,7 +57,7 @@ class StreamSafeEntry:
         return new
 
     def __getstate__(self):
-        return {}
+        return {"empty": True}          # (non-empty on purpose: pickle protocols 0 / 1 skip __setstate__ for a falsy state)
 
     def __setstate__(self, state):
         self.__init__()

@@ -202,24 +202,11 @@ enum { G3_FC = 0, G3_CONV = 1, G3_CONV_LIF_REG = 2, G3_CONV_LIF_TILE = 3, G3_FC_
 // 256 threads, up to 256 registers): every weight fragment read from LDS feeds 8 MFMAs instead of 4 - 37 % fewer LDS read
 // bytes per MFMA, which is energy, i.e. clock, on this power-limited loop (timing build with every second weight-fragment
 // read skipped: conv+LIF -4.3 %, in-kernel clock 1.99 -> 2.05 GHz).  Two such work-groups share a CU (2 waves per SIMD).
-// Dependence of a row tile on the row tiles of ANOTHER layer running in the same launch (k_gemm_bf16x3_pair: fc6 + fc7 of the detector
-// head, faster_rcnn.py:498-501).  Producer work-groups (mode 1) count themselves into done[row tile] once their spike planes are
-// visible device-wide; consumer work-groups (mode 2) wait until every producer tile covering their rows has all its column blocks.
-// The consumers come AFTER all producers in the grid and the dispatcher hands out work-groups in index order per XCD, so every
-// producer a consumer can wait for is already resident or finished - the wait cannot deadlock; it is bounded all the same (a
-// consumer that gives up after ~1 s raises *err and traps: a wrong assumption shows as a failed launch, not as a hung GPU or as
-// silently stale spikes).
-struct Gemm3Dep {
-    uint32_t* done;      // one counter per producer row tile (zeroed by the launcher)
-    uint32_t* err;       // != 0 after the launch: a consumer gave up waiting
-    int mode;            // 0: none, 1: producer, 2: consumer
-    int need;            // consumer: column blocks per producer row tile
-    int pb_src;          // consumer: rows (RoIs) per producer row tile
-};
-#define G3_DEP_SPINS (1 << 22)                     // x s_sleep 8 (~0.25 us each): about a second
-
+// (Round 4 also ran fc6 + fc7 as ONE launch with per-row-tile counters and agent-scope release / acquire hand-offs between the two
+// layers' work-groups: bit-identical, 1 % slower - profiles/r4_det_pair.txt.  Removed in round 5: a measured negative, and its
+// bounded-wait failure path could only trap.)
 template <int MODE, int NB, int MT, int WN>
-__device__ __forceinline__ void gemm_bf16x3_body(const Gemm3Args& args, const int bid, const Gemm3Dep dep) {
+__device__ __forceinline__ void gemm_bf16x3_body(const Gemm3Args& args, const int bid) {
     constexpr bool CONV = MODE == G3_CONV || MODE == G3_CONV_LIF_REG || MODE == G3_CONV_LIF_TILE;
     constexpr bool FUSE = MODE == G3_CONV_LIF_REG, TILE = MODE == G3_CONV_LIF_TILE || MODE == G3_FC_LIF_TILE;
     static_assert(((MT >= 2 && MT <= 4) || MT == 8) && (MT == 4 || !FUSE), "M-tiles per wave");
@@ -288,29 +275,6 @@ __device__ __forceinline__ void gemm_bf16x3_body(const Gemm3Args& args, const in
         uint4 q;
         q.x = bf16_pair(tid, 0); q.y = bf16_pair(tid, 1); q.z = bf16_pair(tid, 2); q.w = bf16_pair(tid, 3);
         *reinterpret_cast<uint4*>(lut + tid * 16) = q;
-    }
-
-    if (TILE && dep.mode == 2) {
-        // consumer tile: its A planes are another layer's spikes, written by work-groups of THIS launch (possibly on other XCDs, whose L2s
-        // are not coherent with ours).  One thread waits for the producers' counters (agent-scope atomic loads), then an agent-scope
-        // acquire fence drops the stale lines of this CU's L1 and this XCD's L2 before any wave of the work-group reads the planes.
-        if (tid == 0) {
-            const int r0 = m0 / dep.pb_src, r1 = (min(m0 + args.pb, M) - 1) / dep.pb_src;
-            bool ok = true;
-            for (int r = r0; r <= r1 && ok; ++r) {
-                int spins = 0;
-                while (__hip_atomic_load(dep.done + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)dep.need) {
-                    __builtin_amdgcn_s_sleep(8);
-                    if (++spins > G3_DEP_SPINS) { ok = false; break; }
-                }
-            }
-            if (!ok) {                               // cannot happen while work-groups are dispatched in index order; if it ever does: abort the
-                __hip_atomic_store(dep.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);       // launch (the host sees a failed kernel), never
-                __builtin_trap();                                                                    // continue on planes that are not there
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-        __syncthreads();
     }
 
     // ---- A staging: the spike words of a chunk (one per tile row) go straight into the ring slot by LDS-DMA
@@ -913,15 +877,6 @@ __device__ __forceinline__ void gemm_bf16x3_body(const Gemm3Args& args, const in
             __syncthreads();
             tile_counts_flush<CONV>(args, pos_cnt, m0, pb, tid);
         }
-        if (dep.mode == 1) {
-            // producer tile: every wave's spike-plane stores have reached the L2 (the barrier waits for vmcnt(0)); ONE agent-scope release
-            // fence then writes the XCD's dirty lines back to memory, where the consumers' XCDs will find them, and the tile counts itself in
-            __syncthreads();
-            if (tid == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                __hip_atomic_fetch_add(dep.done + mb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
 #ifdef SNN_EXP_TIMELINE
         if (tid == 0) {
             unsigned long long tl_exit;
@@ -952,21 +907,7 @@ __device__ __forceinline__ void gemm_bf16x3_body(const Gemm3Args& args, const in
 
 template <int MODE, int NB, int MT, int WN>
 __global__ __launch_bounds__(MT == 8 ? 256 : 512, (MODE == G3_CONV_LIF_REG || MT == 8) ? 2 : 4) void k_gemm_bf16x3(const Gemm3Args args) {
-    gemm_bf16x3_body<MODE, NB, MT, WN>(args, (int)blockIdx.x, Gemm3Dep{nullptr, nullptr, 0, 0, 1});
-}
-
-// Two dependent layers in ONE launch (the detector head's fc6 + LIF and fc7 + LIF): work-groups [0, n_a) are layer a's tiles, the rest
-// layer b's, whose A planes are layer a's spike planes.  Layer b's tiles fill the slots that layer a's last, partial round of
-// work-groups leaves empty, and the drain / launch gap between two kernels disappears.  Same tile shape for both layers.
-struct Gemm3Pair {
-    Gemm3Args a, b;
-    int n_a;
-    Gemm3Dep dep_a, dep_b;
-};
-template <int NB, int MT, int WN>
-__global__ __launch_bounds__(512, 4) void k_gemm_bf16x3_pair(const Gemm3Pair p) {
-    if ((int)blockIdx.x < p.n_a) gemm_bf16x3_body<G3_FC_LIF_TILE, NB, MT, WN>(p.a, (int)blockIdx.x, p.dep_a);
-    else gemm_bf16x3_body<G3_FC_LIF_TILE, NB, MT, WN>(p.b, (int)blockIdx.x - p.n_a, p.dep_b);
+    gemm_bf16x3_body<MODE, NB, MT, WN>(args, (int)blockIdx.x);
 }
 
 // fp32 weights -> three bf16 planes [3][Kc][Np][32]  (hi = rn(w), mid = rn(w - hi), lo = rn(w - hi - mid): exact)

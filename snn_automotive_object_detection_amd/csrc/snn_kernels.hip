@@ -8,6 +8,7 @@
 // Reference loops replaced: rpn.py:84-121 (+126-200), faster_rcnn.py:470-516 (+520-618).
 #include "snn_common.h"
 #include "snn_hip.h"
+#include "snn_hip_debug.h"
 
 // Timing-only switches of the A/B harness (tools/ab_build.sh, tools/ab_mx.sh: what does a staging step / barrier cost) give
 // WRONG results by construction.  A build that defines one must say so with -DSNN_EXPERIMENTS; the product build
@@ -159,8 +160,6 @@ struct Knobs {
                              //                       skips the steps whose currents cannot reach an output, lif_windows)
     bool sparse;             // SNN_SPARSE=0          RPN conv: every period plane on the dense matrix-core instruction (default: planes e_3.. on the
                              //                       structured-sparse one, snn_sparse.h)
-    bool det_pair;           // SNN_DET_PAIR=1        detector head: fc6 + LIF and fc7 + LIF in ONE launch (k_gemm_bf16x3_pair) instead of two - measured
-                             //                       1 % slower (profiles/r4_det_pair.txt), so off by default; bit-identical (tests/test_gpu_det_pair.py)
     int planes;              // SNN_PLANES=rm|wm      internal spike planes of the bf16x3 heads: all row-major [T][row][word] / all
                              //                       word-major [T][word][row] (1 / 2; 0 = default = word-major since round 3;
                              //                       bit-identical results either way, A/B + test switch)
@@ -192,7 +191,6 @@ static Knobs load_knobs() {
     k.stage_periods = (e = getenv("SNN_STAGE_PERIODS")) && e[0] == '1';
     k.epi_general = (e = getenv("SNN_EPI_GENERAL")) && e[0] == '1';
     k.roi_tab = !((e = getenv("SNN_ROI_TAB")) && e[0] == '0');
-    k.det_pair = (e = getenv("SNN_DET_PAIR")) && e[0] == '1';
     k.sparse = !((e = getenv("SNN_SPARSE")) && e[0] == '0');
     k.roi_e = (e = getenv("SNN_ROI_E")) ? atoi(e) : 0;
     k.roi_rw = (e = getenv("SNN_ROI_RW")) ? atoi(e) : 0;
@@ -646,40 +644,6 @@ static int launch_gemm3(int mode, int mt, int wn, const Gemm3Args& a, hipStream_
     return 0;
 }
 
-// fc6 + LIF and fc7 + LIF in one launch (k_gemm_bf16x3_pair): layer b's tiles wait for the row tiles of layer a they read.
-// `sync` = device words [0 .. a's row tiles) counters + one error word behind them, zeroed by the caller on this stream.
-static bool gemm3_pair_ok(int mt_a, int mt_b, int wn, const Gemm3Args& a) {
-    return mt_a == mt_b && mt_a >= 2 && mt_a <= 4 && a.n_blocks % 8 == 0 && (wn == 1 || wn == 2);
-}
-static int launch_gemm3_pair(int mt, int wn, const Gemm3Args& a, const Gemm3Args& b, uint32_t* sync, hipStream_t s) {
-    G3Launch la, lb;
-    prepare_gemm3(G3_FC_LIF_TILE, mt, wn, a, &la);
-    prepare_gemm3(G3_FC_LIF_TILE, mt, wn, b, &lb);
-    // (any block order of layer a will do - a tile counts itself in by its row-tile index -, but its grid must be a multiple of 8 so that
-    // layer b's work-groups keep the XCD their block order assumes: XCD = work-group index % 8)
-    if (la.ax.xcd_contig || la.grid % 8) return fail(-1, "launch_gemm3_pair: layer a's grid (%d) must be a multiple of 8", la.grid);
-    Gemm3Pair pr;
-    pr.a = la.ax; pr.b = lb.ax; pr.n_a = la.grid;
-    uint32_t* err = sync + la.ax.n_tiles;
-    pr.dep_a = Gemm3Dep{sync, err, 1, 0, 1};
-    pr.dep_b = Gemm3Dep{sync, err, 2, a.n_blocks, a.pb};
-    const void* kern = wn == 2 ? (mt == 4 ? (const void*)k_gemm_bf16x3_pair<3, 4, 2> : mt == 3 ? (const void*)k_gemm_bf16x3_pair<3, 3, 2> : (const void*)k_gemm_bf16x3_pair<3, 2, 2>)
-                               : (mt == 4 ? (const void*)k_gemm_bf16x3_pair<G3_NB1, 4, 1> : mt == 3 ? (const void*)k_gemm_bf16x3_pair<G3_NB1, 3, 1> : (const void*)k_gemm_bf16x3_pair<G3_NB1, 2, 1>);
-    const int lds = max(la.lds, lb.lds);
-    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return fail(-3, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-    if (knobs().debug_occ) {
-        int v = 0;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, kern, 512, lds);
-        fprintf(stderr, "k_gemm_bf16x3_pair mt %d wn %d: grids %d + %d, lds %d B, %d work-groups per CU\n", mt, wn, la.grid, lb.grid, lds, v);
-    }
-    void* kargs[] = {(void*)&pr};
-    e = hipLaunchKernel(kern, dim3(la.grid + lb.grid), dim3(512), kargs, lds, s);
-    if (e != hipSuccess) return fail(-3, "k_gemm_bf16x3_pair launch failed: %s", hipGetErrorString(e));
-    SNN_CHECK_LAUNCH("k_gemm_bf16x3_pair");
-    return 0;
-}
-
 // (declared further down)
 static bool g3_tile_ok(int T, int rows);
 
@@ -695,23 +659,6 @@ int snn_debug_last_conv_path(void) { return g_last_conv_sparse; }
 int snn_debug_last_fc6_path(void) { return g_last_fc_sparse; }
 void snn_debug_last_rpn_planes(unsigned long long* out3) { if (out3) for (int i = 0; i < 3; ++i) out3[i] = g_last_rpn_planes[i]; }
 void snn_debug_last_det_planes(unsigned long long* out3) { if (out3) for (int i = 0; i < 3; ++i) out3[i] = g_last_det_planes[i]; }
-
-int snn_debug_tile_shape(int conv, long long units, int n_cols, int num_steps, int spike_rates, int layer, int32_t* out) {
-    if (!out || units <= 0 || n_cols <= 0 || num_steps < 1 || num_steps > SNN_MAX_STEPS) return fail(-1, "snn_debug_tile_shape: bad argument");
-    snn_params p;
-    memset(&p, 0, sizeof(p));
-    p.v_th_lif = 0.1f;                                          // (only the sign of v_leak - v_th matters for the windows)
-    int Tc;
-    if (conv) Tc = lif_window_full_out(num_steps).n;
-    else { const DetWindows w = det_windows(&p, num_steps, spike_rates != 0); Tc = layer == 7 ? w.fc7.n : w.fc6.n; }
-    const int wn = g3_wn(conv != 0), n_blocks = cdiv(cdiv(n_cols, 32) * 32, G3_BN(wn));
-    const G3Tile tl = g3_pick_tile(wn, [&](int rows) { return g3_tile_ok(Tc, rows) ? (long long)cdiv(units, rows / Tc) * n_blocks : 0ll; });
-    if (!tl.mt) return fail(-4, "snn_debug_tile_shape: %d steps do not fit a row tile", num_steps);
-    const int pb = tl.rows / Tc;
-    out[0] = tl.mt; out[1] = tl.n_short; out[2] = tl.rows; out[3] = pb; out[4] = Tc; out[5] = (int32_t)(cdiv(units, pb) * n_blocks);
-    out[6] = n_blocks; out[7] = wn;
-    return 0;
-}
 
 int snn_spike_gemm_bf16x3(const uint32_t* a_rows, int M, int K, int N, const uint16_t* w_packed, float* cur, int ldo,
                           snn_stream_t s) {
@@ -1018,23 +965,55 @@ static bool sparse_plan(int Tc, SparsePlan* sp, long long units = 0, int n_block
     return have;
 }
 
+// Shape-only part of the sparse launch's eligibility (shared with snn_debug_tile_shape, so that what bench.py reports is the plan that
+// runs): the knob, channel counts, the (T, window) pairs the LIF epilogue has a form for, a tile plan with existing loop instances, the
+// conv's XCD grouping and the LDS budget.  Kw = plane words per reduction row (conv: C_in / 32; linear: K / 32), Kc = 32-deep chunks.
+// conv: T = 5 .. 16 with the window T - 1 (straight-line LIF instances; T = 4: built and measured 2.3 % slower than the dense launch).
+// linear: any T whose window (T - 2, or T - 1 in spike-rate mode) fits the slot grid - 4 .. 24 planes on the 4 x 2 wave grid - with the
+// general LIF epilogue outside the straight-line grid (round 5: T_det = 17 .. 26 and spike-rate mode used to take the all-dense launch).
+struct SparseShape { SparsePlan sp; int n_tiles, n_blocks, grid, lds, xcd_cpx, xcd_contig, epi_general; };
+static bool sparse_shape(bool conv, long long M, int Kw, int Kc, int Np, int T, int Tc, SparseShape* out) {
+    if (!knobs().sparse || Kw % 2 || Np % 64 || Kc * 32 > 65536 || M <= 0) return false;
+    if (conv ? (T < 5 || T > 16 || Tc != T - 1) : (T < 5 || T > SNN_MAX_STEPS || (Tc != T - 2 && Tc != T - 1))) return false;
+    if (!sparse_plan(Tc, &out->sp, conv ? 0 : M, Np / 64)) return false;
+    const SparsePlan& sp = out->sp;
+    out->n_tiles = cdiv(M, sp.pb);
+    out->n_blocks = Np / 64;
+    out->grid = out->n_tiles * out->n_blocks;                  // linear layers: plain order
+    out->xcd_cpx = out->xcd_contig = 0;
+    if (conv) {
+        out->xcd_cpx = (out->n_blocks >= 4 && out->n_blocks % 2 == 0) ? out->n_blocks / 2 : 1;     // column blocks per XCD
+        const int groups = out->n_blocks / out->xcd_cpx;                                             // XCD groups along N (2)
+        if (8 % groups) return false;
+        out->xcd_contig = cdiv(out->n_tiles, 8 / groups);
+        out->grid = out->xcd_contig * out->xcd_cpx * 8;
+    }
+    out->lds = max((int)SP_LDS, Tc * sp.pb * SP_PITCH * 4);    // the ring, then the epilogue's tile image in the same bytes
+    if (out->lds > 80 * 1024) return false;
+    out->epi_general = !(T >= 5 && T <= 16 && Tc == T - (conv ? 1 : 2));
+    return true;
+}
+
 // the sparse launch pair: compress the planes e_3 .., then the mixed dense / sparse contraction + LIF (conv: the RPN's shared 3x3
 // convolution; !conv: a linear layer on word-major period planes - the detector's fc6).  `side` = sparse_side_bytes() of scratch.
 // Returns 1 if the launches were enqueued (the layer is done), 0 if this configuration takes the dense launch, negative on error.
+// (Every eligibility check comes before the first launch: a configuration that ends on the dense kernel enqueues nothing here.)
 static int gemm3_lif_sparse(const Gemm3Args& a, bool conv, void* side, size_t side_bytes, hipStream_t s) {
-    SparsePlan sp;
+    SparseShape sh;
     const int Kw = conv ? a.Cw : a.Kc;                        // plane words per row
-    if (!knobs().sparse || !side || !a.wm || !a.periods || Kw % 2 || a.Np % 64 || a.Kc * 32 > 65536 || a.T < 5 || a.T > 16 ||          /* (T = 4: built and measured 2.3 % slower than the dense launch) */
-        a.Tc != a.T - (conv ? 1 : 2) || a.t0 != 0 || a.p.v_leak != 0.0f || (float)(a.p.v_leak - a.p.v_th) > 0.0f || (!conv && !a.out_wm) ||
-        !sparse_plan(a.Tc, &sp, conv ? 0 : a.M, a.Np / 64))
+    if (!side || !a.wm || !a.periods || a.t0 != 0 || a.p.v_leak != 0.0f || (float)(a.p.v_leak - a.p.v_th) > 0.0f || (!conv && !a.out_wm) ||
+        !sparse_shape(conv, a.M, Kw, a.Kc, a.Np, a.T, a.Tc, &sh))
         return 0;
+    const SparsePlan& sp = sh.sp;
     const long long P = a.M, Pe = (long long)a.a_step;
     if (side_bytes < sparse_side_bytes(P, Pe, Kw, a.T)) return 0;
     uint32_t* cmp = (uint32_t*)side;
     const unsigned long long cmp_bytes = (unsigned long long)(a.Tc - sp.nd) * (Kw / 2) * SP_A_ARR * Pe * 4;
     // (the kernel addresses both the raw and the compressed planes by 32-bit offsets from the raw planes)
     if ((const char*)cmp < (const char*)a.A || (unsigned long long)((const char*)cmp - (const char*)a.A) + cmp_bytes > 0xffffffffULL) return 0;
-    const int n_tiles = cdiv(P, sp.pb);
+    const void* kern = conv ? (const void*)k_gemm_lif_sparse<true, 1> : sp.wn == 2 ? (const void*)k_gemm_lif_sparse<false, 2> : (const void*)k_gemm_lif_sparse<false, 1>;
+    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, sh.lds);
+    if (e != hipSuccess) return fail(-3, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
     CompressArgs ca;
     memset(&ca, 0, sizeof(ca));
     ca.enc = a.A; ca.cmp = cmp; ca.Pe = (unsigned)Pe; ca.Cw = Kw; ca.nd = sp.nd;
@@ -1045,21 +1024,15 @@ static int gemm3_lif_sparse(const Gemm3Args& a, bool conv, void* side, size_t si
     sa.enc = a.A; sa.cmp = cmp; sa.wpk = a.wpk; sa.spk = a.spk;
     sa.tl = (unsigned long long*)((char*)side + sparse_side_bytes(P, Pe, Kw, a.T));      // (diagnostic builds only: behind the head's workspace)
     sa.plane_elems = a.plane_elems; sa.spk_stride = a.spk_stride; sa.Pe = (unsigned)Pe;
-    sa.M = a.M; sa.Kc = a.Kc; sa.Np = a.Np; sa.Cw = Kw; sa.n_blocks = a.Np / 64; sa.n_tiles = n_tiles; sa.n_levels = a.n_levels;
+    sa.M = a.M; sa.Kc = a.Kc; sa.Np = a.Np; sa.Cw = Kw; sa.n_blocks = sh.n_blocks; sa.n_tiles = sh.n_tiles; sa.n_levels = a.n_levels;
     sa.T = a.T; sa.Tc = a.Tc; sa.nd = sp.nd; sa.pb = sp.pb; sa.q = sp.q; sa.out_split = a.out_split;
     memcpy(sa.mt_plane, sp.plane, sizeof(sa.mt_plane)); memcpy(sa.mt_j, sp.j, sizeof(sa.mt_j));
     memcpy(sa.w_nd, sp.w_nd, 8); memcpy(sa.w_ns, sp.w_ns, 8);
     sa.p = a.p;
+    sa.epi_general = sh.epi_general;
+    memcpy(sa.div, a.div, sizeof(sa.div));
     memcpy(sa.lv, a.lv, sizeof(sa.lv));
-    int grid = n_tiles * sa.n_blocks;                        // linear layers: plain order
-    if (conv) {
-        sa.xcd_cpx = (sa.n_blocks >= 4 && sa.n_blocks % 2 == 0) ? sa.n_blocks / 2 : 1;     // column blocks per XCD
-        const int groups = sa.n_blocks / sa.xcd_cpx;                             // XCD groups along N (2)
-        if (8 % groups) return 0;
-        sa.xcd_contig = cdiv(n_tiles, 8 / groups);
-        grid = sa.xcd_contig * sa.xcd_cpx * 8;
-    }
-    const int lds = max((int)SP_LDS, a.Tc * sp.pb * SP_PITCH * 4);      // the ring, then the epilogue's tile image in the same bytes
+    sa.xcd_cpx = sh.xcd_cpx; sa.xcd_contig = sh.xcd_contig;
     // spike-rate mode: the LIF epilogue adds its popcounts per row (RoI: straight into the caller's counters; conv: into per-position
     // counters behind the compressed planes, summed per (level, image) by a small launch afterwards)
     uint32_t* cnt_pos = nullptr;
@@ -1068,17 +1041,13 @@ static int gemm3_lif_sparse(const Gemm3Args& a, bool conv, void* side, size_t si
         if (hipMemsetAsync(cnt_pos, 0, (size_t)P * 4, s) != hipSuccess) return fail(-3, "hipMemsetAsync failed");
     }
     sa.cnt_row = conv ? cnt_pos : a.cnt_row;
-    if (lds > 80 * 1024) return 0;
-    const void* kern = conv ? (const void*)k_gemm_lif_sparse<true, 1> : sp.wn == 2 ? (const void*)k_gemm_lif_sparse<false, 2> : (const void*)k_gemm_lif_sparse<false, 1>;
-    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return fail(-3, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
     if (knobs().debug_occ) {
         int v = 0;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, kern, 512, lds);
-        fprintf(stderr, "k_gemm_lif_sparse<%d, %d>: pb %d x Tc %d, q %d, lds %d B, %d work-groups per CU, grid %d\n", (int)conv, sp.wn, sp.pb, a.Tc, sp.q, lds, v, grid);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, kern, 512, sh.lds);
+        fprintf(stderr, "k_gemm_lif_sparse<%d, %d>: pb %d x Tc %d, q %d, lds %d B, %d work-groups per CU, grid %d\n", (int)conv, sp.wn, sp.pb, a.Tc, sp.q, sh.lds, v, sh.grid);
     }
     void* kargs[] = {(void*)&sa};
-    e = hipLaunchKernel(kern, dim3(grid), dim3(512), kargs, lds, s);
+    e = hipLaunchKernel(kern, dim3(sh.grid), dim3(512), kargs, sh.lds, s);
     if (e != hipSuccess) return fail(-3, "k_gemm_lif_sparse launch failed: %s", hipGetErrorString(e));
     SNN_CHECK_LAUNCH("k_gemm_lif_sparse");
     if (cnt_pos) {
@@ -1090,6 +1059,35 @@ static int gemm3_lif_sparse(const Gemm3Args& a, bool conv, void* side, size_t si
         SNN_CHECK_LAUNCH("k_sum_pos_counts");
     }
     return 1;
+}
+
+int snn_debug_tile_shape(int conv, long long units, int k_in, int n_cols, int num_steps, int spike_rates, int layer, int32_t* out) {
+    if (!out || units <= 0 || k_in <= 0 || n_cols <= 0 || num_steps < 1 || num_steps > SNN_MAX_STEPS) return fail(-1, "snn_debug_tile_shape: bad argument");
+    snn_params p;
+    memset(&p, 0, sizeof(p));
+    p.v_th_lif = 0.1f;                                          // (only the sign of v_leak - v_th matters for the windows)
+    int Tc;
+    if (conv) Tc = lif_window_full_out(num_steps).n;
+    else { const DetWindows w = det_windows(&p, num_steps, spike_rates != 0); Tc = layer == 7 ? w.fc7.n : w.fc6.n; }
+    memset(out, 0, 12 * sizeof(int32_t));
+    // the structured-sparse plan, where the launchers take it (period planes of the default parameters: conv, fc6)
+    SparseShape sh;
+    const int Kw = cdiv(k_in, 32), Np = cdiv(n_cols, 32) * 32;
+    if (knobs().periods && (conv || layer != 7) && sparse_shape(conv != 0, units, Kw, conv ? 9 * Kw : Kw, Np, num_steps, Tc, &sh)) {
+        const SparsePlan& sp = sh.sp;
+        int slots = 0;
+        for (int w = 0; w < 8 / sp.wn; ++w) slots += sp.w_nd[w] + sp.w_ns[w];
+        out[0] = sp.wn == 1 ? SP_MT : SP_MT2; out[1] = 0; out[2] = Tc * sp.pb; out[3] = sp.pb; out[4] = Tc; out[5] = sh.n_tiles * sh.n_blocks;
+        out[6] = sh.n_blocks; out[7] = sp.wn; out[8] = 1; out[9] = sp.nd; out[10] = Tc - sp.nd; out[11] = slots;
+        return 0;
+    }
+    const int wn = g3_wn(conv != 0), n_blocks = cdiv(Np, G3_BN(wn));
+    const G3Tile tl = g3_pick_tile(wn, [&](int rows) { return g3_tile_ok(Tc, rows) ? (long long)cdiv(units, rows / Tc) * n_blocks : 0ll; });
+    if (!tl.mt) return fail(-4, "snn_debug_tile_shape: %d steps do not fit a row tile", num_steps);
+    const int pb = tl.rows / Tc;
+    out[0] = tl.mt; out[1] = tl.n_short; out[2] = tl.rows; out[3] = pb; out[4] = Tc; out[5] = (int32_t)(cdiv(units, pb) * n_blocks);
+    out[6] = n_blocks; out[7] = wn; out[8] = 0; out[9] = Tc; out[10] = 0; out[11] = 0;
+    return 0;
 }
 
 static int conv3x3_lif_bf16x3_impl(const uint32_t* enc, size_t enc_stride, const snn_rpn_level* lv, int n_levels, int C_in,
@@ -1918,7 +1916,7 @@ int snn_det_postprocess(const float* class_logits, const float* box_regression, 
     return 0;
 }
 
-#define DET_SYNC_BYTES 16384                      // counters of the fc6 row tiles (R / pb of them) + an error word
+#define DET_SYNC_BYTES 16384                      // (a guard gap between the spike planes and the raw encoder planes; round 4 kept tile counters here)
 static void det_ws_layout(int R, int D, int Hd, int T, size_t* o_enc, size_t* o_cur, size_t* o_s6, size_t* o_s7,
                           size_t* total) {
     const size_t enc = align_up((size_t)T * R * cdiv(D, 32) * 4, 256);
@@ -1932,11 +1930,6 @@ static size_t det_ws_perm_offset(int R, int D, int Hd, int T) {        // the en
     size_t a, b, c, d, tot;
     det_ws_layout(R, D, Hd, T, &a, &b, &c, &d, &tot);
     return tot - b;                                                   // (b = o_cur = size of the encoder planes)
-}
-static size_t det_ws_sync_offset(int R, int D, int Hd, int T) {        // the fc6 -> fc7 tile counters of the one-launch pair: DET_SYNC_BYTES behind s7
-    size_t a, b, c, d, tot;
-    det_ws_layout(R, D, Hd, T, &a, &b, &c, &d, &tot);
-    return tot - b - DET_SYNC_BYTES;
 }
 
 size_t snn_det_head_workspace_bytes(int R, int D, int Hd, int K, int K4, int T, int precision) {
@@ -1960,7 +1953,6 @@ static int det_head_from_planes(int R, int D, int Hd, int K, int K4, int T, cons
                                 bool enc_wm, const DetWindows& win, bool enc_periods, snn_stream_t stream, int k_inner = 0) {
     size_t o_enc, o_cur, o_s6, o_s7, need;
     det_ws_layout(R, D, Hd, T, &o_enc, &o_cur, &o_s6, &o_s7, &need);
-    const size_t o_sync = det_ws_sync_offset(R, D, Hd, T);
     hipStream_t s = (hipStream_t)stream;
     uint32_t* enc = (uint32_t*)((char*)ws + o_enc);
     float* cur = (float*)((char*)ws + o_cur);
@@ -1979,12 +1971,8 @@ static int det_head_from_planes(int R, int D, int Hd, int K, int K4, int T, cons
         // the sparse kernel addresses its side buffers as 32-bit offsets from the planes, so these must lie in front of them)
         const uint32_t* enc_raw = (const uint32_t*)((char*)ws + det_ws_perm_offset(R, D, Hd, T));
         const int Dw = cdiv(D, 32);
-        const size_t lds = (size_t)Dw * 33 * 4;
         if (k_inner != 49) return fail(-4, "snn_det_head_forward: permuted fc6 weights: inner = %d (only 49 = 7 x 7 bins is built)", k_inner);
-        if (lds > 64 * 1024) return fail(-4, "snn_det_head_forward: D = %d too large for the plane transposition", D);
-        hipError_t e = hipFuncSetAttribute((const void*)k_permute_planes<49>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return fail(-3, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-        hipLaunchKernelGGL(k_permute_planes<49>, dim3(cdiv(R, 32), win.enc_steps), dim3(256), lds, s, enc_raw, enc, Dw, R, C);
+        hipLaunchKernelGGL(k_permute_planes<49>, dim3(cdiv(R, 32), win.enc_steps), dim3(256), 0, s, enc_raw, enc, Dw, R, C);
         SNN_CHECK_LAUNCH("k_permute_planes");
     }
     if (spk6_count) { if (hipMemsetAsync(spk6_count, 0, sizeof(uint32_t) * R, s) != hipSuccess) return fail(-3, "hipMemsetAsync failed"); }
@@ -2008,8 +1996,6 @@ static int det_head_from_planes(int R, int D, int Hd, int K, int K4, int T, cons
         // (spike-rate mode: per-RoI counts come out of the LIF epilogues)
         // (word-major planes between the stages: encoder -> fc6 -> fc7; fc7's spikes feed the LI heads row-major)
         // (dead time steps, lif_windows: fc6 forms the currents of steps 0 .. T-3, fc7 of steps 1 .. T-2)
-        // (round 4, SNN_DET_PAIR=1: ONE launch for both layers - fc7's tiles wait for the fc6 row tiles they read and run in the slots fc6's
-        // last, partial round of work-groups leaves empty, k_gemm_bf16x3_pair; bit-identical, but not faster: see the knob)
         Gemm3Args a6, a7;
         G3Tile t6, t7;
         if ((rc = spike_gemm_lif_bf16x3_args(enc, T, R, D, Hd, p, (const uint16_t*)w6_packed, s6, (size_t)R * Hw, spk6_count, enc_wm, enc_wm, &win.fc6, enc_periods, &a6, &t6))) return rc;
@@ -2017,19 +2003,11 @@ static int det_head_from_planes(int R, int D, int Hd, int K, int K4, int T, cons
         const int wn = g3_wn();
         // round 4: fc6's sparse period planes e_3 .. on the structured-sparse matrix-core instruction (snn_sparse.h); its side buffers
         // live in the currents region of the workspace, which the fused layers never write
-        rc = knobs().det_pair ? 0 : gemm3_lif_sparse(a6, false, (char*)ws + o_cur, o_s6 - o_cur, s);
+        rc = gemm3_lif_sparse(a6, false, (char*)ws + o_cur, o_s6 - o_cur, s);
         if (rc < 0) return rc;
-        const bool fc6_done = rc == 1;
         g_last_fc_sparse = rc;
-        const int n_sync = cdiv(R, a6.pb) + 1;
-        if (knobs().det_pair && gemm3_pair_ok(t6.mt, t7.mt, wn, a6) && (size_t)n_sync * 4 <= DET_SYNC_BYTES) {
-            uint32_t* sync = (uint32_t*)((char*)ws + o_sync);
-            if (hipMemsetAsync(sync, 0, (size_t)n_sync * 4, s) != hipSuccess) return fail(-3, "hipMemsetAsync failed");
-            if ((rc = launch_gemm3_pair(t6.mt, wn, a6, a7, sync, s))) return rc;
-        } else {
-            if (!fc6_done && (rc = launch_gemm3(G3_FC_LIF_TILE, t6.mt, wn, a6, s))) return rc;
-            if ((rc = launch_gemm3(G3_FC_LIF_TILE, t7.mt, wn, a7, s))) return rc;
-        }
+        if (rc == 0 && (rc = launch_gemm3(G3_FC_LIF_TILE, t6.mt, wn, a6, s))) return rc;
+        if ((rc = launch_gemm3(G3_FC_LIF_TILE, t7.mt, wn, a7, s))) return rc;
         return snn_li_heads(s7, (size_t)R * Hw, T, R, Hd, w_heads_packed, K, K4, p, out_cls, out_bbox, sum_cls,
                             sum_bbox, stream);
     }

@@ -59,6 +59,10 @@ struct SparseConvArgs {
     unsigned char mt_j[8][SP_MTMAX];     // position block of the slot: local positions 16 j ..
     unsigned char w_nd[8], w_ns[8];      // dense / sparse M-tiles of the row-wave
     int xcd_contig, xcd_cpx;             // block order, as Gemm3Args
+    // epi_general != 0: the LIF epilogue's general form (run-time T and window: the current of step t < Tc is the sum of the row groups in
+    // div[t], ascending) - every (T, window) without a straight-line instance: linear layers at T > 16 and in spike-rate mode (window T - 1)
+    int epi_general;
+    uint32_t div[SNN_MAX_STEPS];
     NeuronP p;
     ConvLevelDev lv[SNN_MAX_LEVELS];
 };
@@ -109,30 +113,36 @@ __device__ __forceinline__ void bit_transpose32(uint32_t (&a)[32]) {          //
     }
 }
 
+#define PERM_CB 8                                   // channel blocks (of 32 channels) per pass: one per wave; LDS = PERM_CB * S * 33 words (51.7 KB at S = 49)
 template <int S>
 __global__ __launch_bounds__(256) void k_permute_planes(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int Dw, int R, int C) {
     static_assert(S > 32 && S <= 64, "two 32-column parts");
-    extern __shared__ uint32_t pl[];                          // [Dw][32 + 1]
+    __shared__ uint32_t pl[PERM_CB * S * 33];                 // [word of the pass][32 RoIs + 1]
     const int t = blockIdx.y, r0 = blockIdx.x * 32, rl = threadIdx.x & 31;
     const bool live = r0 + rl < R;
-    // (the row's words are requested in batches of 7: one load in flight per thread made this kernel a chain of memory latencies)
-    for (int w0 = threadIdx.x >> 5; w0 < Dw; w0 += 8 * 7) {
-        uint32_t v[7];
-#pragma unroll
-        for (int i = 0; i < 7; ++i) {
-            const int w = w0 + 8 * i;
-            v[i] = (live && w < Dw) ? in[((size_t)t * Dw + w) * R + r0 + rl] : 0u;
-        }
-#pragma unroll
-        for (int i = 0; i < 7; ++i)
-            if (w0 + 8 * i < Dw) pl[(w0 + 8 * i) * 33 + rl] = v[i];
-    }
-    __syncthreads();
     const int cbn = C / 32;                                   // channel blocks = words per bin in the permuted order
-    for (int cb = threadIdx.x >> 5; cb < cbn; cb += 8) {
+    // passes of PERM_CB channel blocks (any channel count: round 5 - the whole row in LDS capped C at 320)
+    for (int cb0 = 0; cb0 < cbn; cb0 += PERM_CB) {
+        const int nw = min(PERM_CB, cbn - cb0) * S, wbase = cb0 * S;       // words [wbase, wbase + nw) of the row
+        if (cb0) __syncthreads();
+        // (the row's words are requested in batches of 7: one load in flight per thread made this kernel a chain of memory latencies)
+        for (int w0 = threadIdx.x >> 5; w0 < nw; w0 += 8 * 7) {
+            uint32_t v[7];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) {
+                const int w = w0 + 8 * i;
+                v[i] = (live && w < nw) ? in[((size_t)t * Dw + wbase + w) * R + r0 + rl] : 0u;
+            }
+#pragma unroll
+            for (int i = 0; i < 7; ++i)
+                if (w0 + 8 * i < nw) pl[(w0 + 8 * i) * 33 + rl] = v[i];
+        }
+        __syncthreads();
+        const int cl = threadIdx.x >> 5, cb = cb0 + cl;       // one channel block per wave-half
+        if (cb >= cbn) continue;
         uint32_t w[S + 1];
 #pragma unroll
-        for (int i = 0; i < S; ++i) w[i] = pl[(cb * S + i) * 33 + rl];          // bits [32 cb S, 32 (cb + 1) S) of the row: channel j at bit j S + s
+        for (int i = 0; i < S; ++i) w[i] = pl[(cl * S + i) * 33 + rl];          // bits [32 cb S, 32 (cb + 1) S) of the row: channel j at bit j S + s
         w[S] = 0u;
         uint32_t lo[32], hi[32];
 #pragma unroll
@@ -224,6 +234,44 @@ __device__ __forceinline__ void sp_lif_fixed(const float* const (&src)[NP], cons
             G3_KEEP_BALLOT(my0[u], my1[u], b, t);
             if (COUNT) { cnt_lo[u] += (uint32_t)__builtin_popcount((uint32_t)b); cnt_hi[u] += (uint32_t)__builtin_popcount((uint32_t)(b >> 32)); }
         }
+    }
+}
+
+// The same recurrence with T and the window at run time (one neuron per lane): u_1 .. u_3 are read once (terms of every / every second /
+// every third step), the larger divisors where a step needs them - the order of k_gemm_bf16x3's tile_current (ascending n), so the sums
+// are those of the straight-line instances bit for bit.  For the (T, window) pairs outside sp_lif_fixed's grid: a linear layer's tile
+// then holds 16 or 32 RoIs, i.e. one or two of these per wave and column pass behind a 196-step K loop.
+template <bool COUNT>
+__device__ __forceinline__ void sp_lif_general(const float* src, const int group_stride, const NeuronP& p, const int T, const int Tcs, const uint32_t* div,
+                                               const int lane, uint32_t& my0, uint32_t& my1, uint32_t& cnt_lo, uint32_t& cnt_hi) {
+    const float u1 = src[0];
+    const float u2 = Tcs > 1 ? src[(size_t)group_stride] : 0.0f;
+    const float u3 = Tcs > 2 ? src[(size_t)2 * group_stride] : 0.0f;
+    float vv = 0.0f, ii = 0.0f;
+    for (int t = 0; t < T; ++t) {
+        float c = 0.0f;
+        if (t < Tcs) {
+            uint32_t m = __builtin_amdgcn_readfirstlane(div[t]);                   // wave-uniform; divisors in ascending order
+            c = u1;
+            if (m & 2u) c = __fadd_rn(c, u2);
+            if (m & 4u) c = __fadd_rn(c, u3);
+            m &= ~7u;
+            while (m) {
+                const int g = __builtin_ctz(m);
+                m &= m - 1;
+                c = __fadd_rn(c, src[(size_t)g * group_stride]);
+            }
+        }
+        if (t == 0) { ii = __fadd_rn(0.0f, c); continue; }
+        const float v_dec = __fadd_rn(vv, __fmul_rn(p.ca, __fsub_rn(ii, vv)));
+        const float i_dec = __fadd_rn(ii, __fmul_rn(p.cb, ii));
+        const bool z = v_dec > p.v_th;
+        vv = z ? p.v_reset : v_dec;
+        ii = __fadd_rn(i_dec, c);
+        const unsigned long long b = __ballot(z);
+        my0 = lane == t ? (uint32_t)b : my0;
+        my1 = lane == t ? (uint32_t)(b >> 32) : my1;
+        if (COUNT) { cnt_lo += (uint32_t)__builtin_popcount((uint32_t)b); cnt_hi += (uint32_t)__builtin_popcount((uint32_t)(b >> 32)); }
     }
 }
 
@@ -542,7 +590,9 @@ __global__ __launch_bounds__(512, 4) void k_gemm_lif_sparse(const SparseConvArgs
                 src[u] = tile + (live ? pi : 2 * pp0) * SP_PITCH + col;    // (dead lanes / pairs recompute a live row: never stored)
             }
 #define SP_T(n) case n: sp_lif_fixed<n, CONV ? 1 : 2, NP, COUNT>(src, group_stride, args.p, my0, my1, cnt_lo, cnt_hi); break;
-            if constexpr (NP == 2) {
+            if (NP == 1 && !CONV && args.epi_general) {               // (block-uniform; linear layers only: the conv's launcher keeps to the fixed grid)
+                if constexpr (NP == 1 && !CONV) sp_lif_general<COUNT>(src[0], group_stride, args.p, T, Tc, args.div, lane, my0[0], my1[0], cnt_lo[0], cnt_hi[0]);
+            } else if constexpr (NP == 2) {
                 switch (T) { SP_T(5) SP_T(6) SP_T(7) SP_T(8) SP_T(9) SP_T(10) default: break; }
             } else if constexpr (COUNT) {
                 switch (T) { SP_T(5) SP_T(6) SP_T(7) SP_T(8) SP_T(9) SP_T(10) SP_T(11) SP_T(12) SP_T(13) SP_T(14) SP_T(15) SP_T(16) default: break; }
@@ -580,7 +630,7 @@ __global__ __launch_bounds__(512, 4) void k_gemm_lif_sparse(const SparseConvArgs
         if (counting) {                                            // (one recurrence per lane: the counters take the registers of the second)
             lif_pass(std::integral_constant<int, 1>{}, std::true_type{});
         } else {
-            if (T <= 10) lif_pass(std::integral_constant<int, 2>{}, std::false_type{});
+            if (T <= 10 && !args.epi_general) lif_pass(std::integral_constant<int, 2>{}, std::false_type{});
             else lif_pass(std::integral_constant<int, 1>{}, std::false_type{});
         }
 #ifdef SNN_EXP_TIMELINE

@@ -86,7 +86,9 @@ class FastRCNNPredictorSNNFull(nn.Module):
         snn_det_head_forward_k): bf16x3 on [C, 7, 7] inputs with C % 32 == 0 - what lets fc6's sparse period planes run on the
         structured-sparse matrix-core instruction.  0: the reference's order (SNN_FC6_PERM=0 forces it: A/B, tests)."""
         prec = prec or self._resolve_precision()
-        if prec != "bf16x3" or os.environ.get("SNN_FC6_PERM") == "0":
+        # (mirrors the C side's gates: the permuted order needs the word-major fused bf16x3 layers - SNN_PLANES=rm, an A/B knob, switches
+        # them off; any channel count that is a multiple of 32 is fine since round 5: k_permute_planes works in passes of 8 channel blocks)
+        if prec != "bf16x3" or os.environ.get("SNN_FC6_PERM") == "0" or os.environ.get("SNN_PLANES") == "rm":
             return 0
         return 49 if (self.in_channels % 49 == 0 and (self.in_channels // 49) % 32 == 0) else 0
 

@@ -515,6 +515,8 @@ def det_head_forward(x: torch.Tensor, Hd: int, K: int, K4: int, T: int, p: snn_p
     lib = _lib.load()
     _need_gpu(x, "box features")
     x = _f32c(x).flatten(1)
+    if x.data_ptr() % 16:                                        # (a view at an odd offset: the word-major encoder loads 16-byte pieces)
+        x = x.clone()
     R, D = x.shape
     dev = x.device
     out_cls = torch.empty((R, K), dtype=torch.float32, device=dev)

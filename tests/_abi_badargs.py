@@ -120,14 +120,27 @@ bad(lib.snn_rpn_rates(lv_ok, 2, 256, 3, 8, None, FAKE, FAKE, FAKE, FAKE, 1 << 20
 bad(lib.snn_rpn_rates(lv_ok, 2, 256, 3, 8, FAKE, FAKE, FAKE, FAKE, FAKE, 8, None), "rpn_rates small workspace")
 bad(lib.snn_det_rates(4, 64, 32, 3, 12, 8, 0, None, FAKE, FAKE, FAKE, FAKE, None), "det_rates null")
 bad(lib.snn_det_rates(4, 64, 32, 3, 12, 0, 0, FAKE, FAKE, FAKE, FAKE, FAKE, None), "det_rates T=0")
-o8 = (C.c_int32 * 8)()
-bad(lib.snn_debug_tile_shape(1, 1000, 256, 8, 0, 0, None), "tile_shape null out")
-bad(lib.snn_debug_tile_shape(1, 0, 256, 8, 0, 0, o8), "tile_shape no units")
-bad(lib.snn_debug_tile_shape(0, 2000, 1024, 33, 0, 6, o8), "tile_shape T > 32")
-assert lib.snn_debug_tile_shape(1, 196416, 256, 8, 0, 0, o8) == 0 and o8[4] == 7 and o8[2] == 512 and o8[3] == 73       # host-only call: 7 live steps on the 512-row tile
-assert lib.snn_debug_tile_shape(0, 2000, 1024, 12, 0, 6, o8) == 0 and o8[4] == 10 and o8[3] * o8[4] <= o8[2]
-assert lib.snn_debug_tile_shape(0, 2000, 1024, 12, 1, 6, o8) == 0 and o8[4] == 11                                      # spike-rate mode: fc6 0 .. T-2
-assert lib.snn_debug_tile_shape(0, 2000, 1024, 1, 0, 7, o8) == 0 and o8[4] == 1
+o12 = (C.c_int32 * 12)()
+bad(lib.snn_debug_tile_shape(1, 1000, 256, 256, 8, 0, 0, None), "tile_shape null out")
+bad(lib.snn_debug_tile_shape(1, 0, 256, 256, 8, 0, 0, o12), "tile_shape no units")
+bad(lib.snn_debug_tile_shape(0, 2000, 12544, 1024, 33, 0, 6, o12), "tile_shape T > 32")
+# host-only calls.  Default knobs: the structured-sparse plans (csrc/snn_sparse.h) - conv T = 8: 7 live steps = 2 dense + 5 sparse period
+# planes on tiles of 64 positions; fc6 T = 12: 10 planes on tiles of 32 RoIs, 4 x 2 wave grid; spike-rate mode one step more; T = 24: 22 planes, 16 RoIs
+assert lib.snn_debug_tile_shape(1, 196416, 256, 256, 8, 0, 0, o12) == 0 and list(o12[2:11]) == [448, 64, 7, 4 * 3069, 4, 1, 1, 2, 5], list(o12)
+assert lib.snn_debug_tile_shape(0, 2000, 12544, 1024, 12, 0, 6, o12) == 0 and list(o12[2:11]) == [320, 32, 10, 63 * 16, 16, 2, 1, 2, 8], list(o12)
+assert lib.snn_debug_tile_shape(0, 2000, 12544, 1024, 12, 1, 6, o12) == 0 and o12[4] == 11 and o12[8] == 1, list(o12)                  # spike-rate mode: fc6 0 .. T-2
+assert lib.snn_debug_tile_shape(0, 2000, 12544, 1024, 24, 0, 6, o12) == 0 and list(o12[2:5]) == [352, 16, 22] and o12[8] == 1 and o12[11] == 22, list(o12)
+assert lib.snn_debug_tile_shape(0, 2000, 12544, 1024, 24, 1, 6, o12) == 0 and o12[4] == 23 and o12[8] == 1, list(o12)                  # config[4]: T_det = 24, rates on
+for T in range(6, 27):                                                                # every T_det of the reference's range has a sparse plan
+    assert lib.snn_debug_tile_shape(0, 2000, 12544, 1024, T, 0, 6, o12) == 0 and o12[8] == 1 and o12[4] == T - 2 and o12[11] == o12[4] * (o12[3] // 16), (T, list(o12))
+assert lib.snn_debug_tile_shape(1, 196416, 256, 256, 4, 0, 0, o12) == 0 and o12[8] == 0 and o12[4] == 3                               # T_rpn = 4: the dense tile
+assert lib.snn_debug_tile_shape(1, 196416, 192, 192, 8, 0, 0, o12) == 0 and o12[8] == 0                                                # 3 column blocks: no XCD grouping
+assert lib.snn_debug_tile_shape(0, 2000, 1024, 1024, 12, 0, 7, o12) == 0 and o12[8] == 0 and o12[4] == 10 and o12[3] * o12[4] <= o12[2]  # fc7: dense tile
+assert lib.snn_debug_tile_shape(0, 2000, 1024, 1024, 1, 0, 7, o12) == 0 and o12[4] == 1
+os.environ["SNN_SPARSE"] = "0"
+lib.snn_debug_reload_knobs()
+assert lib.snn_debug_tile_shape(1, 196416, 256, 256, 8, 0, 0, o12) == 0 and o12[4] == 7 and o12[2] == 512 and o12[3] == 73 and o12[8] == 0   # the round-3 dense tile
+del os.environ["SNN_SPARSE"]
 lib.snn_debug_reload_knobs()
 
 # ---- well-formed host tables, no device: the whole host half runs, the first launch (or attribute call) fails with -3 ----

@@ -30,26 +30,36 @@ def nchw_to_rows(z: torch.Tensor) -> np.ndarray:
 
 # Spike flips at threshold ties.  Two fp32 summation orders of the same contraction agree to ~1e-7; where the oracle's decayed
 # membrane sits that close to the threshold the spike can fall either way and the position / RoI then leaves the 1e-4 output
-# tolerance (SURVEY.md §7 risk 1).  Budgets = 2 + rate x neuron-steps, with rates set at ~3x what round 2 and 3 OBSERVED
-# (profiles/parity_r2.json, parity_r3.json) - per neuron-step:
-#   RPN on N(0,1) pyramids  : 7 / 12 / 16 of 196 416 positions (bf16x3 / f32 / mxfp6) = 1.7e-8 .. 4e-8 -> rate 8e-8 (mxfp6 x2:
-#                             its digit planes round weights at 2^-29 of the block maximum)
-#   RPN behind the backbone : 35 - 43 of 196 416 (firing rates are 3x those of N(0,1) inputs) = 8.7e-8 .. 1.07e-7 -> rate 1.5e-7 (round 4; 2.5e-7 before)
-#   detector                : 0 - 2 of 2000 RoIs on N(0,1) (bf16x3 / f32), 7 - 8 mxfp6, 9 at T = 24 = 0 .. 1.6e-7 -> 2.5e-7
-#   detector behind the backbone: 7 of 2000 RoIs while fc6 summed in the reference's flatten order (round 3); 9 - 12 since round 4, whose fc6
-#                             runs bin-major (k' = bin * C + c) and on the structured-sparse instruction - an order less like the oracle's
-#                             k-ascending blocks, so the two fp32 errors are less correlated and more exact ties fall differently (same-lease
-#                             A/B: 7, 7 reference order / 9, 11 bin-major dense / 12, 12 bin-major sparse) = 2.4e-7           -> rate 5e-7
+# tolerance (SURVEY.md §7 risk 1).  The number of such positions is Poisson-like, so the budget carries a variance term (round 5;
+# VERDICT r4 P-b: `2 + 3 x rate x N` sat within one sigma of the observation at 14 / 17):
+#       budget = lambda + 4 sqrt(lambda) + 2,     lambda = rate x neuron-steps x max(1, T / 8)
+# with the rates at what rounds 2-4 OBSERVED (profiles/parity_r2.json .. parity_r4.json; no safety factor) - per neuron-step:
+#   RPN on N(0,1) pyramids  : 7 - 11 of 196 416 positions at T = 8 (bf16x3 / f32) = 1.7e-8 .. 2.7e-8, 2 - 5 of 87 984 (bdd), 18 mxfp6 (x2:
+#                             its digit planes round weights at 2^-29 of the block maximum); 55 at T = 16 = 6.8e-8: a later step carries
+#                             more accumulated rounding, hence the factor max(1, T / 8)                                  -> 3.5e-8
+#   RPN behind the backbone : 14 of 49 104 and 42 of 196 416 (firing rates are 3x those of N(0,1) inputs), pooled 1.1e-7 -> 1.1e-7
+#   detector                : 1 - 3 of 2000 RoIs on N(0,1) at T = 12, 7 mxfp6, 9 at T = 24 = 2e-8 .. 9e-8 (no growth with T seen)  -> 8e-8
+#   detector behind the backbone: 4 - 12 of 2000 RoIs since round 4, whose fc6 runs bin-major (k' = bin * C + c) on the structured-sparse
+#                             instruction - an order less like the oracle's k-ascending blocks (same-lease A/B: 7, 7 reference order / 9, 11
+#                             bin-major dense / 12, 12 bin-major sparse), 8 on average = 1.6e-7                           -> 2.0e-7
 # Every full-size test also ATTRIBUTES its flips (first_flip_margins): each first differing spike sits within TIE_MARGIN of the
 # threshold in the oracle's trace, so a regression that flips spikes away from ties fails whatever the count.
-FLIP_RATE = {"rpn_randn": 8e-8, "rpn_in_situ": 1.5e-7, "det": 2.5e-7, "det_in_situ": 5e-7}
+FLIP_RATE = {"rpn_randn": 3.5e-8, "rpn_in_situ": 1.1e-7, "det": 8e-8, "det_in_situ": 2.0e-7}
+FLIP_T_GROWTH = {"rpn_randn": True, "rpn_in_situ": True, "det": False, "det_in_situ": False}
 PRECISION_FACTOR = {"bf16x3": 1.0, "f32": 1.0, "f32_strict": 1.0, "mxfp6": 2.0}
-TIE_MARGIN = 5e-7            # observed: every first flip sits within 6e-8 of the threshold (profiles/parity_r3.json, parity_r4.json)
+TIE_MARGIN = 5e-7            # observed: every first flip sits within 7e-8 of the threshold (profiles/parity_r3.json, parity_r4.json)
+
+
+def flip_lambda(positions: int, channels: int, steps: int, kind: str = "rpn_in_situ", precision: str = "bf16x3") -> float:
+    """expected number of positions / RoIs that hold a hidden spike differing from the oracle's (see the table above)"""
+    growth = max(1.0, steps / 8.0) if FLIP_T_GROWTH[kind] else 1.0
+    return FLIP_RATE[kind] * PRECISION_FACTOR[precision] * channels * steps * positions * growth
 
 
 def flip_budget(positions: int, channels: int, steps: int, kind: str = "rpn_in_situ", precision: str = "bf16x3") -> float:
-    """how many positions / RoIs may hold a hidden spike that differs from the oracle's (see the table above)"""
-    return 2 + FLIP_RATE[kind] * PRECISION_FACTOR[precision] * channels * steps * positions
+    """how many positions / RoIs may hold a hidden spike that differs from the oracle's: expectation + 4 sigma (Poisson) + 2"""
+    lam = flip_lambda(positions, channels, steps, kind, precision)
+    return lam + 4.0 * lam ** 0.5 + 2.0
 
 
 def first_flip_margins(spk_got: np.ndarray, spk_exp: np.ndarray, vdec_exp: np.ndarray, theta: float = 0.1):
@@ -99,11 +109,11 @@ def assert_same_detections(got_boxes, got_scores, exp_boxes, exp_scores, got_lab
 
 
 def record_parity(test: str, **values):
-    """append observed off-tolerance counts to gpurun_out/parity_r4.jsonl (copied into profiles/parity_r4.json after a GPU
+    """append observed off-tolerance counts to gpurun_out/parity_r5.jsonl (copied into profiles/parity_r5.json after a GPU
     run): the flip budgets are tightened on this evidence"""
     import json
     import os
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_r4.jsonl")
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_r5.jsonl")
     try:
         os.makedirs(os.path.dirname(path), exist_ok=True)
         with open(path, "a") as f:

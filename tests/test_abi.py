@@ -11,8 +11,8 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _header_symbols():
-    txt = open(os.path.join(ROOT, "include", "snn_hip.h")).read()
+def _header_symbols(name="snn_hip.h"):
+    txt = open(os.path.join(ROOT, "include", name)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(snn_[a-z0-9_]+)\s*\(", txt)))
 
@@ -23,7 +23,10 @@ def test_library_exports_every_declared_symbol():
     names = _header_symbols()
     assert len(names) >= 25
     assert sorted(_lib.SYMBOLS) == names, (sorted(_lib.SYMBOLS), names)
-    for n in names:
+    assert not [n for n in names if n.startswith("snn_debug_")]        # test plumbing lives in its own header
+    dbg = _header_symbols("snn_hip_debug.h")
+    assert sorted(_lib.DEBUG_SYMBOLS) == dbg and all(n.startswith("snn_debug_") for n in dbg), (sorted(_lib.DEBUG_SYMBOLS), dbg)
+    for n in names + dbg:
         assert hasattr(lib, n)
     assert lib.snn_version() >= 1
 

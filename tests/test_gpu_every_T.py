@@ -3,32 +3,49 @@ The kernels group, window and tile the time steps (groups of 8 / 12 / 16 in the 
 structured-sparse launches for T = 5 .. 16, register-resident LIF beyond what a tile holds), so a defect can sit at ONE value of T:
 round 4 found the LI heads' matrix-core kernel wrong for T = 2, 10, 18, 26 at 256 channels - values no other test ran.  Here T runs
 2 .. 26 on small inputs with the channel counts that select the special paths (256: resident heads, split spike planes; 64 / 128:
-the general ones), default knobs, all three precisions."""
+the general ones), default knobs, all three precisions.
+
+Time budget (round 5, VERDICT r4 P-c): the default `-m gpu` run takes EVERY T = 2 .. 26 for one precision per head (bf16x3 at the channel
+counts that select the special paths) and a sample of T for the rest - the boundaries of every grouping: 2, 4 | 5 (sparse launches
+start), 8, 10, 12, 16 | 17 (straight-line LIF instances end), 18, 24, 26; `-m "gpu and sweep"` (or SNN_TEST_SWEEP=1) runs the
+exhaustive grid."""
 import pytest
 import torch
 
 from oracle import snn_oracle as OR
 from tests._util import flip_budget
+from tests.conftest import sweep_mode
 
 pytestmark = pytest.mark.gpu
 
+T_ALL = list(range(2, 27))
+T_SAMPLE = [2, 4, 5, 8, 10, 12, 16, 17, 18, 24, 26]
 
-@pytest.mark.parametrize("C,precision", [(256, "bf16x3"), (256, "f32"), (256, "mxfp6"), (64, "bf16x3"), (64, "f32"), (64, "f32_strict")])
-def test_rpn_head_every_T(gpu_device, C, precision):
+
+def _steps(request, every: bool):
+    return T_ALL if (every or sweep_mode(request.config)) else T_SAMPLE
+
+
+@pytest.mark.parametrize("C,precision,every", [(256, "bf16x3", True), (256, "f32", False), (256, "mxfp6", False), (64, "bf16x3", True), (64, "f32", False),
+                                               (64, "f32_strict", False)])
+def test_rpn_head_every_T(gpu_device, request, C, precision, every):
     import snn_automotive_object_detection_amd as S
+    from snn_automotive_object_detection_amd import _lib
     shapes = [(11, 14), (5, 6), (1, 2)]
     g = torch.Generator().manual_seed(C)
     feats = [torch.randn(2, C, h, w, generator=g) * 1.7 for h, w in shapes]
     fd = [f.to(gpu_device) for f in feats]
     pos = sum(2 * h * w for h, w in shapes)
     worst = {}
-    for T in range(2, 27):
+    for T in _steps(request, every):
         torch.manual_seed(100 + T)
         m = S.RPNHeadSNN(C, 3, T).to(gpu_device)
         m.precision = precision
         with torch.no_grad():
             m.shared_conv.weight.mul_(4.0)
         lg, bb = m(fd)
+        if precision == "bf16x3":                          # the plan the launcher reports is the launch that ran (structured-sparse: T = 5 .. 16, C % 64 == 0)
+            assert _lib.load().snn_debug_last_conv_path() == int(5 <= T <= 16)
         o_l, o_b = OR.rpn_head_forward(feats, m.shared_conv.weight.detach().cpu(), m.conv_cls.weight.detach().cpu(),
                                        m.conv_bbox.weight.detach().cpu(), T)
         bad = 0
@@ -40,22 +57,25 @@ def test_rpn_head_every_T(gpu_device, C, precision):
     assert sum(worst.values()) <= 6, worst          # (tie flips are rare at this size: ~0.01 expected per T)
 
 
-@pytest.mark.parametrize("C,Hd,K,precision", [(32, 128, 9, "bf16x3"), (32, 128, 9, "f32"), (64, 1024, 9, "bf16x3"), (64, 1024, 9, "f32"),
-                                              (8, 64, 5, "bf16x3"), (8, 64, 5, "f32"), (128, 256, 9, "mxfp6"), (32, 128, 9, "f32_strict")])
-def test_det_head_every_T(gpu_device, C, Hd, K, precision):
+@pytest.mark.parametrize("C,Hd,K,precision,every", [(32, 128, 9, "bf16x3", True), (32, 128, 9, "f32", False), (64, 1024, 9, "bf16x3", True), (64, 1024, 9, "f32", False),
+                                                    (8, 64, 5, "bf16x3", False), (8, 64, 5, "f32", False), (128, 256, 9, "mxfp6", False), (32, 128, 9, "f32_strict", False)])
+def test_det_head_every_T(gpu_device, request, C, Hd, K, precision, every):
     import snn_automotive_object_detection_amd as S
+    from snn_automotive_object_detection_amd import _lib
     R = 37
     g = torch.Generator().manual_seed(Hd)
     x = torch.randn(R, C, 7, 7, generator=g) * 2
     xd = x.to(gpu_device)
     worst = {}
-    for T in range(2, 27):
+    for T in _steps(request, every):
         torch.manual_seed(200 + T)
         d = S.FastRCNNPredictorSNNFull(C * 49, Hd, K, T).to(gpu_device)
         d.precision = precision
         with torch.no_grad():
             d.fc7.weight.mul_(3.0)
         c, b = d(xd)
+        if precision == "bf16x3":                          # fc6 on the structured-sparse launch: D / 32 even (C % 64 == 0), Hd % 64 == 0, T - 2 >= 4 planes (round 5: no upper T)
+            assert _lib.load().snn_debug_last_fc6_path() == int(C % 64 == 0 and Hd % 64 == 0 and T >= 6), T
         o_c, o_d = OR.det_head_forward(x, d.fc6.weight.detach().cpu(), d.fc7.weight.detach().cpu(), d.cls_score.weight.detach().cpu(),
                                        d.bbox_pred.weight.detach().cpu(), T)
         off = ((c.cpu() - o_c).abs().amax(1) > 1e-4) | ((b.cpu() - o_d).abs().amax(1) > 1e-4)
@@ -64,8 +84,8 @@ def test_det_head_every_T(gpu_device, C, Hd, K, precision):
     assert sum(worst.values()) <= 8, worst
 
 
-@pytest.mark.parametrize("C", [256, 64])
-def test_rpn_head_spike_rates_every_T(gpu_device, C):
+@pytest.mark.parametrize("C,every", [(256, True), (64, False)])
+def test_rpn_head_spike_rates_every_T(gpu_device, request, C, every):
     """spike-rate mode (rpn.py:172: counting launches, dense kernels, the LI membrane sums) at every T: logits / deltas within tolerance,
     the shared LIF's spike counts per (level, image) equal to the oracle's as integers, LI rates within tolerance"""
     import numpy as np
@@ -75,7 +95,7 @@ def test_rpn_head_spike_rates_every_T(gpu_device, C):
     feats = [torch.randn(2, C, h, w, generator=g) * 1.7 for h, w in shapes]
     fd = [f.to(gpu_device) for f in feats]
     flips = 0
-    for T in range(2, 27):
+    for T in _steps(request, every):
         torch.manual_seed(300 + T)
         m = S.RPNHeadSNN(C, 3, T)
         with torch.no_grad():
@@ -102,8 +122,8 @@ def test_rpn_head_spike_rates_every_T(gpu_device, C):
     assert flips <= 4
 
 
-@pytest.mark.parametrize("C,Hd,K", [(32, 128, 9), (64, 1024, 11)])
-def test_det_head_spike_rates_every_T(gpu_device, C, Hd, K):
+@pytest.mark.parametrize("C,Hd,K,every", [(32, 128, 9, False), (64, 1024, 11, True)])
+def test_det_head_spike_rates_every_T(gpu_device, request, C, Hd, K, every):
     """faster_rcnn.py:520-618 at every T: the rate list (four [R, 2] tensors) and lif6 / lif7 spike counts per RoI as integers"""
     import snn_automotive_object_detection_amd as S
     R = 29
@@ -111,7 +131,7 @@ def test_det_head_spike_rates_every_T(gpu_device, C, Hd, K):
     x = torch.randn(R, C, 7, 7, generator=g) * 2
     xd = x.to(gpu_device)
     differing = 0
-    for T in range(2, 27):
+    for T in _steps(request, every):
         torch.manual_seed(400 + T)
         d = S.FastRCNNPredictorSNNFull(C * 49, Hd, K, T)
         with torch.no_grad():
@@ -133,17 +153,17 @@ def test_det_head_spike_rates_every_T(gpu_device, C, Hd, K):
     assert differing <= 3
 
 
-@pytest.mark.parametrize("C,Hd", [(32, 128), (16, 64)])
-def test_fused_roialign_head_every_T(gpu_device, C, Hd):
+@pytest.mark.parametrize("C,Hd,every", [(32, 128, False), (64, 128, True), (16, 64, False)])
+def test_fused_roialign_head_every_T(gpu_device, request, C, Hd, every):
     """roi_heads.py:1217 + faster_rcnn.py:470-516 in one call (`forward_roialign`: RoIAlign fused with the encoder, then the head) against the
-    two-step path on pooled values of the stock-op restatement, at every T (C = 32: bin-major fc6 order + structured-sparse launch)"""
+    two-step path on pooled values of the stock-op restatement, at every T (C = 32: bin-major fc6 order; C = 64: + structured-sparse launch)"""
     import snn_automotive_object_detection_amd as S
     from tests.test_gpu_roialign import _setup
     pool, feats, boxes, shapes = _setup(gpu_device, R=60, C=C, seed=5)
     box_features = pool({k: v.cpu() for k, v in feats.items()}, [b.cpu() for b in boxes], shapes).to(gpu_device)
     flist, scales, rois, lvl = pool.assign(feats, boxes, shapes)
     total = 0
-    for T in range(2, 27):
+    for T in _steps(request, every):
         torch.manual_seed(500 + T)
         head = S.FastRCNNPredictorSNNFull(C * 49, Hd, 9, T).to(gpu_device)
         with torch.no_grad():

@@ -86,9 +86,10 @@ def test_det_head_hidden_widths(gpu_device, Hd):
     assert total <= 3
 
 
-@pytest.mark.parametrize("C", [1, 3, 8, 16, 32, 40, 64, 96, 128])
+@pytest.mark.parametrize("C", [1, 3, 8, 16, 32, 40, 64, 96, 128, 256, 352, 512])
 def test_det_head_channel_counts(gpu_device, C):
-    """D = 49 C: multiples of 32 channels take the bin-major fc6 order and the structured-sparse launch, the others the reference's order"""
+    """D = 49 C: multiples of 32 channels take the bin-major fc6 order (k_permute_planes in passes of 8 channel blocks: any channel count -
+    ADVICE r4: C >= 352 used to be refused) and, where D / 32 is even, the structured-sparse launch; the others the reference's order"""
     total = 0
     for Hd, K, T in [(128, 9, 12), (64, 3, 5)]:
         total += _det_case(gpu_device, 29, C, Hd, K, T, 3 * C + Hd)

@@ -4,7 +4,12 @@
    (the usual budget), on pyramids of several T and odd shapes;
  * nibbles with three and four spikes of one period (more than one instruction can take) go through the secondary compressed
    plane: inputs built to have them in a few places, and nearly everywhere, in a sparse plane still match the dense launch - and
-   repeat bit for bit."""
+   repeat bit for bit;
+ * (round 5) spike-rate mode really takes the structured-sparse COUNTING launches (rpn.py:126-200, faster_rcnn.py:520-618): the path
+   is asserted, the integer counts are the popcounts of the spike planes the same launch wrote, equal the all-dense launch's counts
+   wherever the two runs' planes agree, and the oracle's within the flip budget;
+ * (round 5) fc6 beyond 16 steps (T_det = 17 .. 26, config[4]'s 24) and in spike-rate mode (window T - 1) runs the sparse launch with the
+   general LIF epilogue."""
 import numpy as np
 import pytest
 import torch
@@ -183,3 +188,112 @@ def test_sparse_fc6_secondary_plane(gpu_device, monkeypatch, frac):
     off = ((a[0] - b[0]).abs().amax(1) > 1e-4) | ((a[1] - b[1]).abs().amax(1) > 1e-4)
     assert int(off.sum()) <= flip_budget(R, 2 * Hd, T, "det") and float((a[0] - b[0]).abs().max()) < 0.05
     assert float(a[0].abs().max()) > 0
+
+
+# ---- spike-rate mode on the sparse launches (VERDICT r4 P-a) ------------------------------------------------------------------
+def _popcount(t):
+    lut = torch.tensor([bin(i).count("1") for i in range(256)], dtype=torch.int64, device=t.device)
+    return lut[t.contiguous().view(torch.uint8).to(torch.int64)]
+
+
+def _rpn_hidden_planes(dev, T, Cw):
+    """the shared LIF's spike planes [T, P, Cw] the calling thread's last RPN head left in its workspace"""
+    import ctypes as Ct
+    from snn_automotive_object_detection_amd import _lib, ops
+    off3 = (Ct.c_uint64 * 3)()
+    _lib.load().snn_debug_last_rpn_planes(off3)
+    P = int(off3[2])
+    raw = ops._WS.get(dev, 1)[int(off3[0]): int(off3[0]) + T * P * Cw * 4].view(torch.int32)
+    planes = raw.view(T, Cw // 4, P, 4).permute(0, 2, 1, 3).reshape(T, P, Cw) if off3[1] else raw.view(T, P, Cw)
+    return planes.clone()
+
+
+@pytest.mark.parametrize("T", [8, 16])
+def test_spike_rate_mode_runs_the_sparse_counting_conv(gpu_device, monkeypatch, T):
+    from snn_automotive_object_detection_amd import _lib
+    C, shapes = 256, [(37, 53), (19, 27), (7, 9)]
+    m = _head(gpu_device, C, T, 40 + T)
+    g = torch.Generator().manual_seed(40 + T)
+    feats = [torch.randn(2, C, h, w, generator=g) * 1.7 for h, w in shapes]
+    gold = []
+    OR.rpn_head_forward(feats, m.shared_conv.weight.detach().cpu(), m.conv_cls.weight.detach().cpu(), m.conv_bbox.weight.detach().cpu(), T,
+                        spike_rates=True, counts_out=gold)
+    fd = [f.to(gpu_device) for f in feats]
+    m.spike_rates = True
+    runs = {}
+    for sparse in (True, False):
+        if not sparse:
+            monkeypatch.setenv("SNN_SPARSE", "0")
+        m(fd)
+        assert _lib.load().snn_debug_last_conv_path() == int(sparse)          # counting launches stay on the sparse kernel
+        runs[sparse] = (m.last_spike_counts.clone().cpu(), _rpn_hidden_planes(gpu_device, T, C // 32))
+    base, n_differ = 0, 0
+    for l, (h, w) in enumerate(shapes):
+        for n in range(2):
+            sl = slice(base + n * h * w, base + (n + 1) * h * w)
+            pops = {k: int(_popcount(runs[k][1][:, sl]).sum()) for k in runs}
+            for k in runs:                                                     # a launch's count IS the popcount of the planes it wrote
+                assert int(runs[k][0][l, n]) == pops[k], (k, l, n, int(runs[k][0][l, n]), pops[k])
+            differ = int((runs[True][1][:, sl] != runs[False][1][:, sl]).any(0).any(1).sum())      # positions whose trains differ (tie flips)
+            n_differ += differ
+            if differ == 0:
+                assert int(runs[True][0][l, n]) == int(runs[False][0][l, n])
+            assert abs(int(runs[True][0][l, n]) - int(gold[l][n])) <= 4 * flip_budget(h * w, C, T, "rpn_randn"), (l, n)
+        base += 2 * h * w
+    assert n_differ <= flip_budget(base, C, T, "rpn_randn"), n_differ
+    assert int(runs[True][0].sum()) > 0
+
+
+@pytest.mark.parametrize("T", [8, 12, 16, 24])
+def test_spike_rate_mode_runs_the_sparse_counting_fc6(gpu_device, monkeypatch, T):
+    import ctypes as Ct
+    from snn_automotive_object_detection_amd import _lib, ops
+    R, C, Hd, K = 333, 64, 256, 9
+    d = _det(gpu_device, C, Hd, K, T, 50 + T)
+    g = torch.Generator().manual_seed(50 + T)
+    x = torch.randn(R, C, 7, 7, generator=g) * 2
+    gold = []
+    OR.det_head_forward(x, d.fc6.weight.detach().cpu(), d.fc7.weight.detach().cpu(), d.cls_score.weight.detach().cpu(), d.bbox_pred.weight.detach().cpu(), T,
+                        spike_rates=True, counts_out=gold)
+    xd = x.to(gpu_device)
+    d.spike_rates = True
+    runs = {}
+    for sparse in (True, False):
+        if not sparse:
+            monkeypatch.setenv("SNN_SPARSE", "0")
+        d(xd)
+        assert _lib.load().snn_debug_last_fc6_path() == int(sparse)
+        off3 = (Ct.c_uint64 * 3)()
+        _lib.load().snn_debug_last_det_planes(off3)
+        assert off3[2] == 1                                                    # lif6's planes word-major [T][Hd / 32][R]
+        s6 = ops._WS.get(gpu_device, 1)[int(off3[0]): int(off3[0]) + T * (Hd // 32) * R * 4].view(torch.int32).view(T, Hd // 32, R).clone()
+        runs[sparse] = (d.last_spike_counts[0].clone(), d.last_spike_counts[1].clone(), s6)
+    for k in runs:                                                             # per-RoI count == popcount of the RoI's lif6 planes of the same launch
+        assert torch.equal(runs[k][0].to(torch.int64), _popcount(runs[k][2]).view(T, Hd // 32, R, 4).sum(dim=(0, 1, 3))), k
+    same = (runs[True][2] == runs[False][2]).all(0).all(0)                     # RoIs whose lif6 trains agree between the two launches
+    assert torch.equal(runs[True][0][same], runs[False][0][same])
+    assert int((~same).sum()) <= flip_budget(R, Hd, T, "det"), int((~same).sum())
+    off_gold = int((runs[True][0].cpu() != gold[0]).sum())
+    assert off_gold <= flip_budget(R, Hd, T, "det"), off_gold
+    assert int(runs[True][0].sum()) > 0
+
+
+@pytest.mark.parametrize("T", [17, 20, 24, 26])
+def test_sparse_fc6_beyond_16_steps(gpu_device, monkeypatch, T):
+    """T_det = 17 .. 26 (train.py:40-43 default 16, config[4] 24): 15 .. 24 period planes of 16 RoIs on the 4 x 2 wave grid, general LIF epilogue"""
+    R, C, Hd, K = 150, 64, 256, 9
+    d = _det(gpu_device, C, Hd, K, T, 60 + T)
+    g = torch.Generator().manual_seed(60 + T)
+    x = torch.randn(R, C, 7, 7, generator=g) * 2
+    a = _run_det(d, x.to(gpu_device), sparse=True)
+    o_c, o_d = OR.det_head_forward(x, d.fc6.weight.detach().cpu(), d.fc7.weight.detach().cpu(), d.cls_score.weight.detach().cpu(),
+                                   d.bbox_pred.weight.detach().cpu(), T)
+    off = ((a[0].cpu() - o_c).abs().amax(1) > 1e-4) | ((a[1].cpu() - o_d).abs().amax(1) > 1e-4)
+    assert int(off.sum()) <= flip_budget(R, 2 * Hd, T, "det"), int(off.sum())
+    assert float(a[0].abs().max()) > 0
+    again = _run_det(d, x.to(gpu_device), sparse=True)
+    assert torch.equal(a[0], again[0]) and torch.equal(a[1], again[1])
+    monkeypatch.setenv("SNN_SPARSE", "0")
+    b = _run_det(d, x.to(gpu_device), sparse=False)
+    off = ((a[0] - b[0]).abs().amax(1) > 1e-4) | ((a[1] - b[1]).abs().amax(1) > 1e-4)
+    assert int(off.sum()) <= flip_budget(R, 2 * Hd, T, "det") and float((a[0] - b[0]).abs().max()) < 0.05, int(off.sum())

@@ -205,7 +205,7 @@ def test_hip_gates_mirror_the_c_limits():
 def _copy_roundtrips(m):
     import io
     import pickle
-    out = [copy.deepcopy(m), pickle.loads(pickle.dumps(m))]
+    out = [copy.deepcopy(m)] + [pickle.loads(pickle.dumps(m, protocol=pr)) for pr in (0, 1, 2, pickle.HIGHEST_PROTOCOL)]     # (0 / 1 skip __setstate__ for a falsy state: ADVICE r4)
     buf = io.BytesIO()
     torch.save(m, buf)
     buf.seek(0)

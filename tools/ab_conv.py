@@ -40,7 +40,7 @@ while args:
             lib.snn_debug_reload_knobs()
         for k in env:
             os.environ.pop(k)
-        for n, (res, at) in _lib.SYMBOLS.items():
+        for n, (res, at) in (list(_lib.SYMBOLS.items()) + list(_lib.DEBUG_SYMBOLS.items())):
             if hasattr(lib, n):
                 getattr(lib, n).restype = res
                 getattr(lib, n).argtypes = at

@@ -39,8 +39,8 @@ Cw = CH // 32
 lv = (_lib.snn_rpn_level * len(feats))(*[_lib.snn_rpn_level(f.data_ptr(), f.shape[0], f.shape[2], f.shape[3], 0) for f in feats])
 ws_bytes = lib.snn_rpn_head_workspace_bytes(lv, len(feats), CH, A, T_RPN, head._params().precision)
 stamp_off = ws_bytes // 2 + T_RPN * P * Cw * 4                   # behind the spike planes (csrc/snn_bf16x3.h, SNN_EXP_CLOCK)
-tile = (C.c_int32 * 8)()
-assert lib.snn_debug_tile_shape(1, P, CH, T_RPN, 0, 0, tile) == 0
+tile = (C.c_int32 * 12)()
+assert lib.snn_debug_tile_shape(1, P, CH, CH, T_RPN, 0, 0, tile) == 0
 n_wg = int(tile[5])
 ws = ops._WS.get(dev, max(ws_bytes, stamp_off + n_wg * 16 + 4096) + (200 << 20))     # one workspace for everything below (grow-only)
 

@@ -17,7 +17,7 @@ os.environ["SNN_STAGE_PLANES"] = "wm"
 _lib.reload_knobs()
 lib = C.CDLL(sys.argv[1])
 lib.snn_debug_reload_knobs()
-for n, (res, at) in _lib.SYMBOLS.items():
+for n, (res, at) in (list(_lib.SYMBOLS.items()) + list(_lib.DEBUG_SYMBOLS.items())):
     if hasattr(lib, n):
         getattr(lib, n).restype = res
         getattr(lib, n).argtypes = at

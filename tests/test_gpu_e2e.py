@@ -19,7 +19,8 @@ def torch_nms_for_the_stock_comparators(monkeypatch):
     monkeypatch.setattr(box_ops, "HIP_NMS", False)
 
 
-@pytest.mark.parametrize("full,fused", [(False, False), (True, False), (False, True), (True, True)],
+# (default run: the small canvas on the two-call path and config[2] on the default fused path; the other two combinations are `sweep`)
+@pytest.mark.parametrize("full,fused", [(False, False), pytest.param(True, False, marks=pytest.mark.sweep), pytest.param(False, True, marks=pytest.mark.sweep), (True, True)],
                          ids=["canvas384x768", "config2_1024x2048", "canvas384x768_fused_roialign", "config2_1024x2048_fused_roialign"])
 def test_create_model_end_to_end_and_heads_in_situ(gpu_device, full, fused):
     """full=True is BASELINE.json config[2]: 2 x rand(3,1024,2048) through create_model at the reference's transform

@@ -1,7 +1,8 @@
 """Shape sweeps of both heads against the oracle (rpn.py:84-121, faster_rcnn.py:470-516) at default knobs: every channel count,
 anchor / class count, hidden width and row remainder selects tiles, wave grids, column blocks, resident / streamed / split head kernels
 and sparse / dense launches on the host side (csrc/snn_kernels.hip) - a defect can sit in one combination (cf. tests/test_gpu_every_T.py).
-Small inputs: the oracle takes well under a second per case."""
+Small inputs: the oracle takes well under a second per case.  The default `-m gpu` run takes the values on either side of every tile / block
+boundary; the values in between are marked `sweep` (`-m "gpu and sweep"`, tests/conftest.py)."""
 import pytest
 import torch
 
@@ -33,7 +34,7 @@ def _rpn_case(dev, C, A, T, shapes, N, seed, precision="bf16x3"):
     return bad
 
 
-@pytest.mark.parametrize("C", [3, 20, 32, 64, 96, 100, 128, 160, 192, 224, 256, 320, 384, 512])
+@pytest.mark.parametrize("C", [3, pytest.param(20, marks=pytest.mark.sweep), 32, 64, pytest.param(96, marks=pytest.mark.sweep), 100, pytest.param(128, marks=pytest.mark.sweep), pytest.param(160, marks=pytest.mark.sweep), 192, pytest.param(224, marks=pytest.mark.sweep), 256, 320, pytest.param(384, marks=pytest.mark.sweep), 512])
 def test_rpn_head_channel_counts(gpu_device, C):
     total = 0
     for T, A in [(8, 3), (6, 5), (12, 1)]:
@@ -41,7 +42,7 @@ def test_rpn_head_channel_counts(gpu_device, C):
     assert total <= 3
 
 
-@pytest.mark.parametrize("A", [1, 2, 3, 4, 5, 6, 9, 12, 13, 15, 16])
+@pytest.mark.parametrize("A", [1, pytest.param(2, marks=pytest.mark.sweep), 3, 4, pytest.param(5, marks=pytest.mark.sweep), pytest.param(6, marks=pytest.mark.sweep), 9, pytest.param(12, marks=pytest.mark.sweep), 13, pytest.param(15, marks=pytest.mark.sweep), 16])
 def test_rpn_head_anchor_counts(gpu_device, A):
     """5 A outputs per position: 16-column head tiles 1 .. 4, then a second launch for the columns beyond 64"""
     total = 0
@@ -78,7 +79,7 @@ def _det_case(dev, R, C, Hd, K, T, seed, precision="bf16x3"):
     return int(off.sum())
 
 
-@pytest.mark.parametrize("Hd", [8, 32, 40, 64, 96, 100, 128, 192, 256, 320, 512, 1024])
+@pytest.mark.parametrize("Hd", [8, pytest.param(32, marks=pytest.mark.sweep), 40, 64, pytest.param(96, marks=pytest.mark.sweep), 100, pytest.param(128, marks=pytest.mark.sweep), pytest.param(192, marks=pytest.mark.sweep), 256, pytest.param(320, marks=pytest.mark.sweep), pytest.param(512, marks=pytest.mark.sweep), 1024])
 def test_det_head_hidden_widths(gpu_device, Hd):
     total = 0
     for C, K, T in [(32, 9, 12), (8, 5, 8), (64, 2, 6)]:
@@ -86,7 +87,7 @@ def test_det_head_hidden_widths(gpu_device, Hd):
     assert total <= 3
 
 
-@pytest.mark.parametrize("C", [1, 3, 8, 16, 32, 40, 64, 96, 128, 256, 352, 512])
+@pytest.mark.parametrize("C", [1, pytest.param(3, marks=pytest.mark.sweep), 8, pytest.param(16, marks=pytest.mark.sweep), 32, 40, 64, pytest.param(96, marks=pytest.mark.sweep), 128, 256, 352, 512])
 def test_det_head_channel_counts(gpu_device, C):
     """D = 49 C: multiples of 32 channels take the bin-major fc6 order (k_permute_planes in passes of 8 channel blocks: any channel count -
     ADVICE r4: C >= 352 used to be refused) and, where D / 32 is even, the structured-sparse launch; the others the reference's order"""
@@ -96,7 +97,7 @@ def test_det_head_channel_counts(gpu_device, C):
     assert total <= 2
 
 
-@pytest.mark.parametrize("K", [2, 3, 4, 7, 9, 11, 13, 14, 16, 21, 24, 52, 91])
+@pytest.mark.parametrize("K", [2, pytest.param(3, marks=pytest.mark.sweep), pytest.param(4, marks=pytest.mark.sweep), pytest.param(7, marks=pytest.mark.sweep), 9, 11, 13, pytest.param(14, marks=pytest.mark.sweep), 16, pytest.param(21, marks=pytest.mark.sweep), 24, pytest.param(52, marks=pytest.mark.sweep), 91])
 def test_det_head_class_counts(gpu_device, K):
     """5 K outputs per RoI: head tiles of 16 columns 1 .. 4; beyond 64 outputs (K >= 13) one launch per block of 64 columns (the
     reference's configs: cityscapes 9, bdd 11, idd 16, pascal 24, coco 91)"""
@@ -106,7 +107,7 @@ def test_det_head_class_counts(gpu_device, K):
     assert total <= 2
 
 
-@pytest.mark.parametrize("R", [1, 2, 15, 16, 17, 31, 32, 33, 47, 48, 49, 63, 64, 65, 127, 129, 257])
+@pytest.mark.parametrize("R", [1, pytest.param(2, marks=pytest.mark.sweep), 15, 16, 17, pytest.param(31, marks=pytest.mark.sweep), pytest.param(32, marks=pytest.mark.sweep), 33, pytest.param(47, marks=pytest.mark.sweep), pytest.param(48, marks=pytest.mark.sweep), pytest.param(49, marks=pytest.mark.sweep), pytest.param(63, marks=pytest.mark.sweep), 64, 65, pytest.param(127, marks=pytest.mark.sweep), pytest.param(129, marks=pytest.mark.sweep), 257])
 def test_det_head_row_remainders(gpu_device, R):
     total = 0
     for C, Hd, T in [(32, 256, 12), (64, 128, 7)]:

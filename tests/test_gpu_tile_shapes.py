@@ -29,7 +29,7 @@ def _short_vs_full(monkeypatch, fn):
 
 
 @pytest.mark.parametrize("wn", ["1", "2"])
-@pytest.mark.parametrize("mt", ["4", "3", "2"])
+@pytest.mark.parametrize("mt", ["4", pytest.param("3", marks=pytest.mark.sweep), "2"])
 @pytest.mark.parametrize("R,Hd,K,T", [(300, 128, 9, 12), (2000, 160, 9, 12), (37, 96, 5, 8), (513, 256, 11, 16), (64, 64, 3, 5), (90, 64, 3, 24)])
 def test_det_head_short_waves(gpu_device, monkeypatch, wn, mt, R, Hd, K, T):
     import snn_automotive_object_detection_amd as S
@@ -53,7 +53,7 @@ def test_det_head_short_waves(gpu_device, monkeypatch, wn, mt, R, Hd, K, T):
 
 
 @pytest.mark.parametrize("wn", ["1", "2"])
-@pytest.mark.parametrize("mt", ["4", "3", "2"])
+@pytest.mark.parametrize("mt", ["4", pytest.param("3", marks=pytest.mark.sweep), "2"])
 @pytest.mark.parametrize("C,T,shapes", [(256, 8, [(2, 48, 96), (2, 24, 48), (2, 12, 24), (2, 6, 12), (2, 3, 6)]),
                                         (96, 12, [(1, 9, 14), (3, 5, 7), (1, 1, 1)]), (64, 4, [(2, 7, 33)]), (64, 24, [(1, 11, 13)])])
 def test_rpn_head_short_waves(gpu_device, monkeypatch, wn, mt, C, T, shapes):

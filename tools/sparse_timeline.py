@@ -1,6 +1,7 @@
-"""Per-work-group timeline of k_conv_lif_sparse (a -DSNN_EXP_TIMELINE build: bash tools/ab_build.sh TL:"-DSNN_EXP_TIMELINE", then on the
-GPU box SNN_HIP_LIB=tools/_ab/lib_TL.so python tools/sparse_timeline.py): s_memrealtime stamps at entry / K-loop start / K-loop end /
-end of the first epilogue pass / exit.  Run on the bench's own pyramid."""
+"""Per-work-group timeline of k_gemm_lif_sparse (a -DSNN_EXP_TIMELINE build: bash tools/ab_build.sh TL:"-DSNN_EXP_TIMELINE", then on the
+GPU box SNN_HIP_LIB=tools/_ab/lib_TL.so python tools/sparse_timeline.py [fc6]): s_memrealtime stamps at entry / K-loop start / K-loop end /
+end of the first epilogue pass / exit.  Run on the bench's own pyramid (default: the RPN conv) or RoI features (`fc6`: the detector's fc6,
+round 5 - VERDICT r4 item 3)."""
 import os
 import sys
 
@@ -18,6 +19,54 @@ model = S.create_model(wl["dataset"], wl["K"], True, True, 0, False, False, 8, 1
 leg = bench.Leg(wl, "bf16x3", dev, 1000, "backbone", model)
 del model
 lib = _lib.load()
+
+
+def report(raw, slots, what):
+    raw = raw[raw[:, 7] != 0]
+    t = raw[:, :5].double() / 100.0                              # us
+    t0 = float(t[:, 0].min())
+    print("%s: work-groups stamped: %d; launch span %.1f us" % (what, raw.shape[0], float(t[:, 4].max()) - t0))
+    print("mean us per work-group: before K loop %.2f | K loop %.2f | epilogue pass 0 %.2f | epilogue pass 1 %.2f | whole %.2f" % (
+        float((t[:, 1] - t[:, 0]).mean()), float((t[:, 2] - t[:, 1]).mean()), float((t[:, 3] - t[:, 2]).mean()), float((t[:, 4] - t[:, 3]).mean()),
+        float((t[:, 4] - t[:, 0]).mean())))
+    img = raw[:, 7].double() / 100.0
+    print("epilogue pass 0: accumulators -> tile image (two barriers) %.2f us | LIF recurrence + spike stores %.2f us" % (
+        float((img - t[:, 2]).mean()), float((t[:, 3] - img).mean())))
+    cu = (raw[:, 6] << 16) | (raw[:, 5] & 0x0000ff00) | ((raw[:, 5] >> 13) & 0x7)    # xcc | cu_id / sh / se bits
+    ids, counts = torch.unique(cu, return_counts=True)
+    print("distinct (XCC, CU) slots seen: %d; work-groups per slot: min %d max %d" % (ids.numel(), int(counts.min()), int(counts.max())))
+    busy = float((t[:, 4] - t[:, 0]).sum()) / slots
+    print("sum of work-group lifetimes / %d slots = %.1f us (= the span if every slot were always occupied)" % (slots, busy))
+    # start / end skew: how long does the launch run with fewer than all slots busy
+    starts, ends = t[:, 0] - t0, t[:, 4] - t0
+    print("work-group starts: first round (<= %d) all started by %.1f us; last start %.1f us; first exit %.1f us; last exit %.1f us" % (
+        slots, float(starts.sort().values[min(slots, starts.numel()) - 1]), float(starts.max()), float(ends.min()), float(ends.max())))
+    kl = (t[:, 2] - t[:, 1])
+    print("K loop per work-group: min %.2f  median %.2f  max %.2f us" % (float(kl.min()), float(kl.median()), float(kl.max())))
+    return t
+
+
+if len(sys.argv) > 1 and sys.argv[1] == "fc6":
+    T, R, D, HD = wl["T_det"], int(leg.rois.shape[0]), bench.C * 49, bench.HD
+    for _ in range(3):
+        leg.det_head(leg.rois)
+    torch.cuda.synchronize()
+    assert lib.snn_debug_last_fc6_path() == 1
+    import ctypes as Ct
+    o12 = (Ct.c_int32 * 12)()
+    assert lib.snn_debug_tile_shape(0, R, D, HD, T, 0, 6, o12) == 0 and o12[8] == 1
+    n_wg, steps = int(o12[5]), D // 64
+    al = lambda x: (x + 255) // 256 * 256
+    Dw = D // 32
+    o_cur = al(T * R * Dw * 4)                                   # det_ws_layout: the encoder planes, then the currents region = the sparse side buffers
+    side = al(max(T - 3, 1) * (Dw // 2) * 4 * R * 4) + al(R * 4) + 256
+    ws = ops._WS.get(dev, 1)
+    raw = ws[o_cur + side: o_cur + side + n_wg * 64].view(torch.int64).view(-1, 8).cpu()
+    t = report(raw, 512, "k_gemm_lif_sparse<false, %d> (fc6, T = %d: %d period planes, %d RoIs per tile, %d work-groups, %d K steps of 64)" % (
+        o12[7], T, o12[4], o12[3], n_wg, steps))
+    print("K loop: %.3f us per 64-k step (mean)" % (float((t[:, 2] - t[:, 1]).mean()) / steps))
+    sys.exit(0)
+
 T, C, A = wl["T_rpn"], bench.C, bench.A
 P = sum(f.shape[0] * f.shape[2] * f.shape[3] for f in leg.feats)
 lv = (_lib.snn_rpn_level * len(leg.feats))(*[_lib.snn_rpn_level(f.data_ptr(), f.shape[0], f.shape[2], f.shape[3], 0) for f in leg.feats])
@@ -34,18 +83,4 @@ for _ in range(5):
 torch.cuda.synchronize()
 assert lib.snn_debug_last_conv_path() == 1
 raw = ws[off: off + n_wg * 64].view(torch.int64).view(-1, 8).cpu()
-raw = raw[raw[:, 7] != 0]
-t = raw[:, :5].double() / 100.0                                  # us
-t0 = float(t[:, 0].min())
-print("work-groups stamped: %d; launch span %.1f us" % (raw.shape[0], float(t[:, 4].max()) - t0))
-print("mean us per work-group: before K loop %.2f | K loop %.2f | epilogue pass 0 %.2f | epilogue pass 1 %.2f | whole %.2f" % (
-    float((t[:, 1] - t[:, 0]).mean()), float((t[:, 2] - t[:, 1]).mean()), float((t[:, 3] - t[:, 2]).mean()), float((t[:, 4] - t[:, 3]).mean()),
-    float((t[:, 4] - t[:, 0]).mean())))
-img = raw[:, 7].double() / 100.0
-print("epilogue pass 0: accumulators -> tile image (two barriers) %.2f us | LIF recurrence + spike stores %.2f us" % (
-    float((img - t[:, 2]).mean()), float((t[:, 3] - img).mean())))
-cu = (raw[:, 6] << 16) | (raw[:, 5] & 0x0000ff00) | ((raw[:, 5] >> 13) & 0x7)        # xcc | cu_id / sh / se bits
-ids, counts = torch.unique(cu, return_counts=True)
-print("distinct (XCC, CU) slots seen: %d; work-groups per slot: min %d max %d" % (ids.numel(), int(counts.min()), int(counts.max())))
-busy = float((t[:, 4] - t[:, 0]).sum()) / 512.0
-print("sum of work-group lifetimes / 512 slots = %.1f us (= the span if every slot were always occupied)" % busy)
+report(raw, 512, "k_gemm_lif_sparse<true, 1> (RPN conv, T = %d)" % T)

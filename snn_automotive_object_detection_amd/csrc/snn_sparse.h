@@ -31,8 +31,11 @@ typedef __bf16 bfv16 __attribute__((ext_vector_type(16)));
 
 #define SP_MT 4                                     // M-tile slots per wave on the 8 x 1 wave grid (all waves span the 64 columns)
 #define SP_MT2 6                                    // ... per ROW-wave on the 4 x 2 grid (two waves of 32 columns share a row-wave's slots)
-#define SP_MTMAX 6
+#define SP_MT_BIG 12                                // ... per row-wave of the BIG shape (round 5): 4 x 2 grid, ONE work-group per CU with up to 256 registers per
+                                                    // lane and a 4-slot ring - 48 M-tiles per work-group, e.g. 64 RoIs x 10 planes (linear layers)
+#define SP_MTMAX 12
 #define SP_ROWS (8 * SP_MT * 16)                    // physical tile rows (512; 4 x 6 x 16 = 384 on the 4 x 2 grid)
+#define SP_ROWS_BIG (4 * SP_MT_BIG * 16)            // 768
 #define SP_A_ARR 4                                  // dword arrays per step: dense rows use two (the chunks' spike words), sparse rows all four:
                                                     // occupancy bytes of the four 16-k blocks, index halves 0-1, index halves 2-3 of the primary
                                                     // plane, occupancy bytes of the secondary plane (whose indices are the constant (2, 3))
@@ -40,6 +43,9 @@ typedef __bf16 bfv16 __attribute__((ext_vector_type(16)));
 #define SP_B_BYTES (2 * 3 * 64 * G3_ROWB)           // two chunks x three weight planes x 64 columns
 #define SP_SLOT (SP_A_BYTES + SP_B_BYTES)           // one 64-k step: 32 KB
 #define SP_LDS (G3_LUT_BYTES + 2 * SP_SLOT)         // 68 KB: two work-groups per CU
+#define SP_BIG_SLOTS 4                              // ring slots of the BIG shape: copies run three steps ahead of the matrix instructions
+#define SP_SLOT_BIG (SP_A_ARR * SP_ROWS_BIG * 4 + SP_B_BYTES)        // 36 KB
+#define SP_LDS_BIG (G3_LUT_BYTES + SP_BIG_SLOTS * SP_SLOT_BIG)       // 148 KB: one work-group per CU
 #define SP_PITCH 36                                 // epilogue tile image: 32 columns + 4 floats of padding per row
 
 struct SparseConvArgs {
@@ -275,7 +281,9 @@ __device__ __forceinline__ void sp_lif_general(const float* src, const int group
     }
 }
 
-// spike-rate mode of the sparse conv: spikes per (level, image) slot from the per-position counts; block = slot
+// spike-rate mode of the sparse conv: spikes per (level, image) slot from the per-position counts; block = (slot, chunk of the image's
+// positions), one integer atomic per block (round 5: one block per slot took 71 us for the 73 728 positions of a level-0 image)
+#define POSCNT_CHUNKS 32
 struct PosCountArgs { const uint32_t* cnt_pos; unsigned long long* cnt_img; int n_levels, max_n; ConvLevelDev lv[SNN_MAX_LEVELS]; };
 __global__ __launch_bounds__(256) void k_sum_pos_counts(const PosCountArgs a) {
     __shared__ unsigned long long part[4];
@@ -284,21 +292,35 @@ __global__ __launch_bounds__(256) void k_sum_pos_counts(const PosCountArgs a) {
     if (n < a.lv[l].N) {
         const int hw = a.lv[l].H * a.lv[l].W;
         const uint32_t* src = a.cnt_pos + a.lv[l].pos_base + (size_t)n * hw;
-        for (int i = threadIdx.x; i < hw; i += 256) sum += src[i];
+        for (int i = blockIdx.y * 256 + threadIdx.x; i < hw; i += 256 * POSCNT_CHUNKS) sum += src[i];
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sum;
     __syncthreads();
-    if (threadIdx.x == 0) a.cnt_img[blockIdx.x] += part[0] + part[1] + part[2] + part[3];
+    if (threadIdx.x == 0) {
+        const unsigned long long tot = part[0] + part[1] + part[2] + part[3];
+        if (tot) atomicAdd(a.cnt_img + blockIdx.x, tot);
+    }
 }
 
 // WN = waves along the 64 columns.  1: 8 row-waves x 4 slots, every wave reads the whole weight slot from LDS each step (192 KB per
 // work-group and step).  2: 4 row-waves x 6 slots, a wave covers 32 columns and reads half of the slot (96 KB): the shape for launches whose
 // matrix-pipe time per step is below what those LDS reads take - fc6, whose tiles hold 32 RoIs (tools: profiles/r4_sparse_timeline.txt).
-template <bool CONV, int WN>
-__global__ __launch_bounds__(512, 4) void k_gemm_lif_sparse(const SparseConvArgs args) {
-    constexpr int MTS = WN == 1 ? SP_MT : SP_MT2, NT = 4 / WN;      // slots per (row-)wave, 16-column N-tiles per wave
+// BIG (linear layers, WN = 2): the same loop on 12 M-tile slots per row-wave - each weight fragment read from LDS feeds twice the matrix
+// instructions, each work-group streams its 4.8-MB weight panel for twice the RoIs - with ONE work-group per CU (up to 256 registers per
+// lane).  What the second work-group of a CU gave the small shape (its waves fill the pipe while the first waits at its step barrier
+// for copies) comes from a 4-slot ring instead: copies are issued three steps ahead, and the wait before the step barrier leaves the two
+// youngest steps' copies in flight (s_waitcnt vmcnt counts in issue order; every wave issues the same SP_BIG_DMA copies per step).
+template <bool CONV, int WN, bool BIG = false>
+__global__ __launch_bounds__(512, BIG ? 2 : 4) void k_gemm_lif_sparse(const SparseConvArgs args) {
+    static_assert(!BIG || WN == 2, "the BIG shape runs the 4 x 2 wave grid");
+    constexpr int MTS = BIG ? SP_MT_BIG : WN == 1 ? SP_MT : SP_MT2, NT = 4 / WN;      // slots per (row-)wave, 16-column N-tiles per wave
+    constexpr int ROWS = BIG ? SP_ROWS_BIG : SP_ROWS;               // physical tile rows of a ring slot
+    constexpr int A_BYTES = SP_A_ARR * ROWS * 4, SLOT = A_BYTES + SP_B_BYTES;
+    constexpr int NSLOT = BIG ? SP_BIG_SLOTS : 2, DIST = NSLOT - 1; // ring slots; steps the copies run ahead
+    constexpr int NPASS = BIG ? 2 : 1;                              // A-staging passes of a wave (64 rows each) per step
+    constexpr int DMA_PER_STEP = SP_A_ARR * NPASS + 3;              // LDS-DMA instructions a wave issues per step (A arrays + three weight pieces)
 #ifdef SNN_EXP_TIMELINE     // diagnostic build: wall-clock stamps (s_memrealtime, 100 MHz) of the work-group's phases
     unsigned long long tl_entry = 0, tl_loop0 = 0, tl_loop1 = 0, tl_epi = 0, tl_img = 0;
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_entry) :: "memory");
@@ -332,15 +354,20 @@ __global__ __launch_bounds__(512, 4) void k_gemm_lif_sparse(const SparseConvArgs
     }
     const int nd_w = __builtin_amdgcn_readfirstlane((int)args.w_nd[wm]), ns_w = __builtin_amdgcn_readfirstlane((int)args.w_ns[wm]);
     // ---- A staging: lane L of the wave stages row L & 15 of one M-tile slot of its row-wave.  WN = 1: slot L >> 4 (64 rows per wave);
-    // WN = 2: the two column-waves of a row-wave take three slots each (lanes 0 .. 47)
-    const int xs = WN == 1 ? (lane >> 4) : min(3 * wn + (lane >> 4), MTS - 1);
-    const bool a_lane = WN == 1 || lane < 48;
-    const int xplane = args.mt_plane[wm][xs];
-    const bool xused = xplane >= 0, xdense = xused && xplane < args.nd;
-    uint32_t voff, inc;                                     // byte offset from args.enc of the lane's first dword; array j of the step is
+    // WN = 2: the two column-waves of a row-wave take three slots each (lanes 0 .. 47); BIG: six slots each, in two passes (64 + 32 lanes)
+    const void* a_base[SP_A_ARR];
+#pragma unroll
+    for (int j = 0; j < SP_A_ARR; ++j) a_base[j] = sgpr_ptr(reinterpret_cast<const char*>(args.enc) + (size_t)j * args.Pe * 4);
+    uint32_t voff[NPASS], inc[NPASS];                       // byte offset from args.enc of the lane's first dword; array j of the step is
                                                             // j word planes further (dense lanes use two, the rest lands in unused LDS)
-    uint32_t tap_fix, row_fix;
-    {
+    bool a_lane[NPASS];
+    uint32_t tap_fix[NPASS], row_fix[NPASS];
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+        const int xs = BIG ? min(6 * wn + 4 * ps + (lane >> 4), MTS - 1) : WN == 1 ? (lane >> 4) : min(3 * wn + (lane >> 4), MTS - 1);
+        a_lane[ps] = BIG ? (lane < (ps == 0 ? 64 : 32)) : (WN == 1 || lane < 48);
+        const int xplane = args.mt_plane[wm][xs];
+        const bool xused = xplane >= 0, xdense = xused && xplane < args.nd;
         const int lp = min(args.mt_j[wm][xs] * 16 + (lane & 15), pb - 1);
         const int p = min(m0 + (xused ? lp : 0), M - 1);
         uint32_t row0 = (uint32_t)p;                        // linear layer: the RoI
@@ -359,40 +386,42 @@ __global__ __launch_bounds__(512, 4) void k_gemm_lif_sparse(const SparseConvArgs
         const int Cw2 = args.Cw / 2;
         if (xdense || !xused) {
             const int t = xused ? xplane : 0;
-            voff = (uint32_t)(((size_t)t * args.Cw * Pe + row0) * 4);
-            inc = 2 * Pe * 4;
+            voff[ps] = (uint32_t)(((size_t)t * args.Cw * Pe + row0) * 4);
+            inc[ps] = 2 * Pe * 4;
         } else {
             const uint32_t delta = (uint32_t)((const char*)args.cmp - (const char*)args.enc);
-            voff = delta + (uint32_t)(((size_t)(xplane - args.nd) * Cw2 * SP_A_ARR * Pe + row0) * 4);
-            inc = SP_A_ARR * Pe * 4;
+            voff[ps] = delta + (uint32_t)(((size_t)(xplane - args.nd) * Cw2 * SP_A_ARR * Pe + row0) * 4);
+            inc[ps] = SP_A_ARR * Pe * 4;
         }
-        tap_fix = 4u - (uint32_t)Cw2 * inc;                 // next tap of the row: one position on, back to channel word 0
-        row_fix = (uint32_t)((W + 2 - 3) * 4);              // after the third tap of a row: one padded image row down
+        tap_fix[ps] = 4u - (uint32_t)Cw2 * inc[ps];         // next tap of the row: one position on, back to channel word 0
+        row_fix[ps] = (uint32_t)((W + 2 - 3) * 4);          // after the third tap of a row: one padded image row down
     }
-    const uint32_t a_dst = smem_base + G3_LUT_BYTES + (WN == 1 ? wave * 256 : (wm * MTS + 3 * wn) * 64);    // physical row (wm MTS + slot) 16 + r
-    const void* a_base[SP_A_ARR];
-#pragma unroll
-    for (int j = 0; j < SP_A_ARR; ++j) a_base[j] = sgpr_ptr(reinterpret_cast<const char*>(args.enc) + (size_t)j * args.Pe * 4);
+    // physical row (wm MTS + slot) 16 + r; a pass covers four slots
+    const uint32_t a_dst = smem_base + G3_LUT_BYTES + (BIG ? (wm * MTS + 6 * wn) * 64 : WN == 1 ? wave * 256 : (wm * MTS + 3 * wn) * 64);
     const int cw2_s = __builtin_amdgcn_readfirstlane(args.Cw / 2);
     int f_c = 0, f_tap = 0;
     auto stage_a = [&](const uint32_t slot_off) __attribute__((always_inline)) {
-        const uint32_t d = __builtin_amdgcn_readfirstlane(a_dst + slot_off);
-        if (a_lane) {
-            asm volatile("s_mov_b32 m0, %5\n\ts_nop 4\n\tglobal_load_lds_dword %0, %1\n\t"
-                         "s_add_u32 m0, m0, %6\n\ts_nop 0\n\tglobal_load_lds_dword %0, %2\n\t"
-                         "s_add_u32 m0, m0, %6\n\ts_nop 0\n\tglobal_load_lds_dword %0, %3\n\t"
-                         "s_add_u32 m0, m0, %6\n\ts_nop 0\n\tglobal_load_lds_dword %0, %4"
-                         :: "v"(voff), "s"(a_base[0]), "s"(a_base[1]), "s"(a_base[2]), "s"(a_base[3]), "s"(d), "s"((uint32_t)(SP_ROWS * 4))
-                         : "memory", "scc");
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const uint32_t d = __builtin_amdgcn_readfirstlane(a_dst + slot_off + ps * 256);
+            if (a_lane[ps]) {
+                asm volatile("s_mov_b32 m0, %5\n\ts_nop 4\n\tglobal_load_lds_dword %0, %1\n\t"
+                             "s_add_u32 m0, m0, %6\n\ts_nop 0\n\tglobal_load_lds_dword %0, %2\n\t"
+                             "s_add_u32 m0, m0, %6\n\ts_nop 0\n\tglobal_load_lds_dword %0, %3\n\t"
+                             "s_add_u32 m0, m0, %6\n\ts_nop 0\n\tglobal_load_lds_dword %0, %4"
+                             :: "v"(voff[ps]), "s"(a_base[0]), "s"(a_base[1]), "s"(a_base[2]), "s"(a_base[3]), "s"(d), "s"((uint32_t)(ROWS * 4))
+                             : "memory", "scc");
+            }
+            voff[ps] += inc[ps];
         }
-        voff += inc;
         if (!CONV) return;
         f_c = __builtin_amdgcn_readfirstlane(f_c + 1);
         if (f_c == cw2_s) {
             f_c = 0;
-            voff += tap_fix;
             f_tap = __builtin_amdgcn_readfirstlane(f_tap + 1);
-            if (f_tap == 3) { f_tap = 0; voff += row_fix; }
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps) voff[ps] += tap_fix[ps] + (f_tap == 3 ? row_fix[ps] : 0u);
+            if (f_tap == 3) f_tap = 0;
         }
     };
 
@@ -401,7 +430,7 @@ __global__ __launch_bounds__(512, 4) void k_gemm_lif_sparse(const SparseConvArgs
     const uint32_t b_off = (uint32_t)((nb * 64 + brow) * 64 + (((lane & 3) ^ G3_SWZ(brow)) << 4));
     const unsigned long long b_chunk = (unsigned long long)Np * 64, b_plane = args.plane_elems * 2;
     unsigned long long s_ptr = (unsigned long long)args.wpk;                  // chunk 2 * step, plane 0
-    const uint32_t b_dst = smem_base + G3_LUT_BYTES + SP_A_BYTES + (wave & 3) * 1024;
+    const uint32_t b_dst = smem_base + G3_LUT_BYTES + A_BYTES + (wave & 3) * 1024;
     auto stage_b = [&](const uint32_t slot_off) __attribute__((always_inline)) {
         const uint32_t d = __builtin_amdgcn_readfirstlane(b_dst + slot_off);
 #pragma unroll
@@ -414,7 +443,7 @@ __global__ __launch_bounds__(512, 4) void k_gemm_lif_sparse(const SparseConvArgs
     };
 
     const unsigned char* const a_rd = ring + (wm * MTS * 16 + lr) * 4;                      // + slot offset, M-tile slot * 64
-    const unsigned char* const b_rd = ring + SP_A_BYTES + (wn * NT * 16 + lr) * G3_ROWB + ((lg ^ G3_SWZ(lr)) << 4);
+    const unsigned char* const b_rd = ring + A_BYTES + (wn * NT * 16 + lr) * G3_ROWB + ((lg ^ G3_SWZ(lr)) << 4);
     f32x4 acc[MTS][NT];
 #pragma unroll
     for (int mt = 0; mt < MTS; ++mt)
@@ -422,8 +451,16 @@ __global__ __launch_bounds__(512, 4) void k_gemm_lif_sparse(const SparseConvArgs
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
     const int n_steps = Kc / 2;
-    stage_a(0); stage_b(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // vmcnt immediates of the ring: all but the `g` youngest steps' copies of this wave have landed
+    auto wait_groups = [&](const int g) __attribute__((always_inline)) {
+        if constexpr (DIST >= 3) { if (g >= 2) { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * DMA_PER_STEP) : "memory"); return; } }
+        if constexpr (DIST >= 2) { if (g == 1) { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DMA_PER_STEP) : "memory"); return; } }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+#pragma unroll
+    for (int s0 = 0; s0 < DIST; ++s0)
+        if (s0 < n_steps) { stage_a((uint32_t)(s0 * SLOT)); stage_b((uint32_t)(s0 * SLOT)); }
+    wait_groups(min(DIST, n_steps) - 1);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -431,11 +468,15 @@ __global__ __launch_bounds__(512, 4) void k_gemm_lif_sparse(const SparseConvArgs
 #ifdef SNN_EXP_TIMELINE
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_loop0) :: "memory");
 #endif
+#if defined(SNN_EXP_SP_NO_AREAD) || defined(SNN_EXP_SP_NO_BREAD)
+    const bfv8 exp_a = *reinterpret_cast<const bfv8*>(lut + ((lane * 5) & 255) * 16);
+    const bfv8 exp_b0 = *reinterpret_cast<const bfv8*>(b_rd), exp_b1 = *reinterpret_cast<const bfv8*>(b_rd + 3 * 64 * G3_ROWB);
+#endif
     auto step_loop = [&](auto nd_c, auto ns_c) __attribute__((always_inline)) {
         constexpr int ND = decltype(nd_c)::value, NS = decltype(ns_c)::value;
         for (int s = 0; s < n_steps; ++s) {
-            const uint32_t o_cur = (uint32_t)((s & 1) * SP_SLOT), o_nxt = (uint32_t)(((s + 1) & 1) * SP_SLOT);
-            if (s + 1 < n_steps) {
+            const uint32_t o_cur = (uint32_t)((s % NSLOT) * SLOT), o_nxt = (uint32_t)(((s + DIST) % NSLOT) * SLOT);
+            if (s + DIST < n_steps) {
 #ifndef SNN_EXP_SP_NO_A                             // (timing experiments: what do the copies cost - wrong results)
                 stage_a(o_nxt);
 #endif
@@ -446,12 +487,18 @@ __global__ __launch_bounds__(512, 4) void k_gemm_lif_sparse(const SparseConvArgs
             // A fragments of this step
             bfv8 ad[ND > 0 ? ND : 1][2], as[NS > 0 ? NS : 1];
             int ix[NS > 0 ? NS : 1];
-            unsigned long long sec = 0, sec2 = 0;
+            unsigned long long sec[3] = {0, 0, 0};                // bits 16 q .. 16 q + 15 of word b = sparse slot 4 b + q
+#ifdef SNN_EXP_SP_NO_AREAD                            // (timing experiment: no LDS reads on the A side - wrong results)
+#pragma unroll
+            for (int d = 0; d < ND; ++d) { ad[d][0] = exp_a; ad[d][1] = exp_a; }
+#pragma unroll
+            for (int q = 0; q < NS; ++q) { as[q] = exp_a; ix[q] = 0x4444; }
+#else
 #pragma unroll
             for (int d = 0; d < ND; ++d)
 #pragma unroll
                 for (int c2 = 0; c2 < 2; ++c2) {
-                    const uint32_t byte = *reinterpret_cast<const uint8_t*>(a_rd + o_cur + c2 * (SP_ROWS * 4) + d * 64 + lg);
+                    const uint32_t byte = *reinterpret_cast<const uint8_t*>(a_rd + o_cur + c2 * (ROWS * 4) + d * 64 + lg);
                     ad[d][c2] = *reinterpret_cast<const bfv8*>(lut + (byte << 4));
                 }
 #pragma unroll
@@ -459,28 +506,33 @@ __global__ __launch_bounds__(512, 4) void k_gemm_lif_sparse(const SparseConvArgs
                 const unsigned char* r = a_rd + o_cur + (ND + q) * 64;
                 const uint32_t occ = *reinterpret_cast<const uint8_t*>(r + lg);
                 as[q] = *reinterpret_cast<const bfv8*>(lut + (occ << 4));
-                ix[q] = (int)*reinterpret_cast<const uint16_t*>(r + (1 + (lg >> 1)) * (SP_ROWS * 4) + 2 * (lg & 1));
+                ix[q] = (int)*reinterpret_cast<const uint16_t*>(r + (1 + (lg >> 1)) * (ROWS * 4) + 2 * (lg & 1));
             }
             // which of the sparse M-tiles hold a third spike of a nibble in this step?  Lane L looks at the secondary occupancy dword of
-            // row L & 15 of sparse slot L >> 4 (6 slots on the 4 x 2 grid: a second look); bits 16 q .. 16 q + 15 of the ballot = slot q
-            if (NS > 0) {
-                const uint32_t o2 = *reinterpret_cast<const uint32_t*>(a_rd + o_cur + 3 * (SP_ROWS * 4) + (ND + lg) * 64);
-                sec = __ballot(o2 != 0u) & (NS >= 4 ? ~0ull : ((1ull << (16 * (NS & 3))) - 1ull));
-                if constexpr (NS > 4) {
-                    const uint32_t o3 = *reinterpret_cast<const uint32_t*>(a_rd + o_cur + 3 * (SP_ROWS * 4) + (ND + 4 + lg) * 64);
-                    sec2 = __ballot(o3 != 0u) & ((1ull << (16 * (NS - 4))) - 1ull);
-                }
+            // row L & 15 of sparse slot L >> 4 (more than four sparse slots: a second / third look)
+#pragma unroll
+            for (int b4 = 0; b4 < (NS + 3) / 4; ++b4) {
+                const uint32_t o2 = *reinterpret_cast<const uint32_t*>(a_rd + o_cur + 3 * (ROWS * 4) + min(ND + 4 * b4 + lg, MTS - 1) * 64);
+                sec[b4] = __ballot(o2 != 0u) & (NS - 4 * b4 >= 4 ? ~0ull : ((1ull << (16 * (NS - 4 * b4))) - 1ull));
             }
+#endif
+#ifdef SNN_EXP_SP_NO_BREAD                            // (timing experiment: the weight fragments stay what they were before the loop)
+            bfv8 b0 = exp_b0, b1 = exp_b1;
+#else
             bfv8 b0 = *reinterpret_cast<const bfv8*>(b_rd + o_cur + 2 * (64 * G3_ROWB));
             bfv8 b1 = *reinterpret_cast<const bfv8*>(b_rd + o_cur + 3 * 64 * G3_ROWB + 2 * (64 * G3_ROWB));
+#endif
 #pragma unroll
             for (int g = 0; g < 3 * NT; ++g) {              // group = (N-tile g / 3, plane 2 - g % 3): small terms first
                 bfv8 n0 = b0, n1 = b1;
+#ifndef SNN_EXP_SP_NO_BREAD
                 if (g + 1 < 3 * NT) {
                     const int gn = g + 1;
                     n0 = *reinterpret_cast<const bfv8*>(b_rd + o_cur + (2 - gn % 3) * (64 * G3_ROWB) + (gn / 3) * 16 * G3_ROWB);
                     n1 = *reinterpret_cast<const bfv8*>(b_rd + o_cur + 3 * 64 * G3_ROWB + (2 - gn % 3) * (64 * G3_ROWB) + (gn / 3) * 16 * G3_ROWB);
                 }
+#endif
+#ifndef SNN_EXP_SP_NO_MFMA                            // (timing experiment: everything but the matrix instructions)
 #pragma unroll
                 for (int d = 0; d < ND; ++d) {
                     acc[d][g / 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ad[d][0], b0, acc[d][g / 3], 0, 0, 0);
@@ -494,14 +546,21 @@ __global__ __launch_bounds__(512, 4) void k_gemm_lif_sparse(const SparseConvArgs
                     for (int q = 0; q < NS; ++q)
                         acc[ND + q][g / 3] = __builtin_amdgcn_smfmac_f32_16x16x64_bf16(as[q], bb, acc[ND + q][g / 3], ix[q], 0, 0);
                 }
+#else
+                asm volatile("" :: "v"(b0), "v"(b1));
+#pragma unroll
+                for (int d = 0; d < ND; ++d) asm volatile("" :: "v"(ad[d][0]), "v"(ad[d][1]));
+#pragma unroll
+                for (int q = 0; q < NS; ++q) asm volatile("" :: "v"(as[q]), "v"(ix[q]));
+#endif
                 b0 = n0; b1 = n1;
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (NS > 0 && (sec | sec2) != 0ull) {            // (rare) the secondary plane of the M-tiles that have one in this step
+            if (NS > 0 && (sec[0] | sec[1] | sec[2]) != 0ull) {   // (rare) the secondary plane of the M-tiles that have one in this step
 #pragma unroll
                 for (int q = 0; q < NS; ++q) {
-                    if ((((q < 4 ? sec : sec2) >> (16 * (q & 3))) & 0xffffull) == 0ull) continue;
-                    const unsigned char* r = a_rd + o_cur + (ND + q) * 64 + 3 * (SP_ROWS * 4);
+                    if (((sec[q >> 2] >> (16 * (q & 3))) & 0xffffull) == 0ull) continue;
+                    const unsigned char* r = a_rd + o_cur + (ND + q) * 64 + 3 * (ROWS * 4);
                     const uint32_t occ = *reinterpret_cast<const uint8_t*>(r + lg);
                     const bfv8 a2 = *reinterpret_cast<const bfv8*>(lut + (occ << 4));
                     const int i2 = 0xeeee;                   // every nibble: positions (2, 3)
@@ -517,16 +576,31 @@ __global__ __launch_bounds__(512, 4) void k_gemm_lif_sparse(const SparseConvArgs
                 }
             }
             asm volatile("" ::: "memory");
-            __builtin_amdgcn_s_waitcnt(0x0070);              // vmcnt(0) lgkmcnt(0): the next step's copies have landed
+            if constexpr (DIST == 1) {
+                __builtin_amdgcn_s_waitcnt(0x0070);          // vmcnt(0) lgkmcnt(0): the next step's copies have landed
+            } else {                                         // this wave's copies of step s + 1 have landed; those of the steps behind it stay in flight
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                wait_groups(min(DIST - 1, n_steps - s - 2));
+            }
+#ifndef SNN_EXP_SP_NO_BAR                             // (timing experiment: waves run ahead of each other's copies - wrong results)
             __builtin_amdgcn_s_barrier();
+#endif
             asm volatile("" ::: "memory");
         }
     };
+// (dense, sparse) M-tile counts of a row-wave the BIG shape has loop instances for (host: sparse_plan_wn checks against the same list)
+#define SP_BIG_INSTANCES {3, 8}, {3, 7}, {2, 8}, {2, 9}, {1, 10}, {1, 11}, {1, 9}
+#define SP_BIG_CASES SP_CASE(3, 8) SP_CASE(3, 7) SP_CASE(2, 8) SP_CASE(2, 9) SP_CASE(1, 10) SP_CASE(1, 11) SP_CASE(1, 9)
 #define SP_CASE(ND_, NS_) if (nd_w == ND_ && ns_w == NS_) step_loop(std::integral_constant<int, ND_>{}, std::integral_constant<int, NS_>{}); else
     if constexpr (WN == 1) {
         SP_CASE(1, 3) SP_CASE(1, 2) SP_CASE(2, 2) SP_CASE(0, 4) SP_CASE(0, 3) SP_CASE(1, 1) SP_CASE(2, 1) SP_CASE(0, 2) SP_CASE(0, 1)
         SP_CASE(2, 0) SP_CASE(1, 0)
         {   // a wave without M-tiles still stages and keeps the barriers
+            step_loop(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        }
+    } else if constexpr (BIG) {
+        SP_BIG_CASES
+        {
             step_loop(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
         }
     } else {

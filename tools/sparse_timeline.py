@@ -48,8 +48,7 @@ def report(raw, slots, what):
 
 if len(sys.argv) > 1 and sys.argv[1] == "fc6":
     T, R, D, HD = wl["T_det"], int(leg.rois.shape[0]), bench.C * 49, bench.HD
-    for _ in range(3):
-        leg.det_head(leg.rois)
+    leg.det_head(leg.rois)
     torch.cuda.synchronize()
     assert lib.snn_debug_last_fc6_path() == 1
     import ctypes as Ct
@@ -61,6 +60,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "fc6":
     o_cur = al(T * R * Dw * 4)                                   # det_ws_layout: the encoder planes, then the currents region = the sparse side buffers
     side = al(max(T - 3, 1) * (Dw // 2) * 4 * R * 4) + al(R * 4) + 256
     ws = ops._WS.get(dev, 1)
+    ws[o_cur + side: o_cur + side + n_wg * 64].zero_()           # (the allocator hands out used memory: stale bytes would read as stamps)
+    for _ in range(3):
+        leg.det_head(leg.rois)
+    torch.cuda.synchronize()
     raw = ws[o_cur + side: o_cur + side + n_wg * 64].view(torch.int64).view(-1, 8).cpu()
     t = report(raw, 512, "k_gemm_lif_sparse<false, %d> (fc6, T = %d: %d period planes, %d RoIs per tile, %d work-groups, %d K steps of 64)" % (
         o12[7], T, o12[4], o12[3], n_wg, steps))
@@ -78,6 +81,7 @@ off = ws_bytes                                                  # the stamps lan
 w_sh, w_hd = leg.rpn_head._packed_shared(), None
 leg.rpn_head(leg.feats)
 w_hd = leg.rpn_head._cache_heads.val
+ws[off: off + n_wg * 64].zero_()
 for _ in range(5):
     ops.rpn_head_forward(leg.feats, C, A, T, p, w_sh, w_hd, stage_mask=2)
 torch.cuda.synchronize()

@@ -482,8 +482,9 @@ def sweep_t_leg(leg, iters=8):
 
     def plan_of(o):                                   # the plan of the launch that runs (structured-sparse or the dense tile)
         if o[8]:
-            return {"kernel": "k_gemm_lif_sparse", "period_planes": {"dense": o[9], "sparse": o[10]}, "wave_grid": "%d x %d" % (8 // o[7], o[7]),
-                    "fill": round(o[11] / float((8 // o[7]) * o[0]), 4)}          # M-tile slots in use / slots of the wave grid
+            waves = 4 if o[1] else 8                                          # (o[1]: the FAT shape - four waves of up to 256 registers)
+            return {"kernel": "k_gemm_lif_sparse", "period_planes": {"dense": o[9], "sparse": o[10]}, "wave_grid": "%d x %d" % (waves // o[7], o[7]),
+                    "fill": round(o[11] / float((waves // o[7]) * o[0]), 4)}       # M-tile slots in use / slots of the wave grid
         return {"kernel": "k_gemm_bf16x3", "fill": round(o[3] * o[4] / o[2], 4)}
     try:
         for T in range(4, 13):

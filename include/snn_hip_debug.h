@@ -27,7 +27,7 @@ int snn_debug_encoder_thresholds(const snn_params* p, float* th32);
  *   spike_rates (conv = 0 only) non-zero: the head runs in spike-rate mode, whose fc6 window is one step longer (the rate counts
  *               lif6's spikes of every step, faster_rcnn.py:556)
  *   layer       (conv = 0 only) 6 or 7: fc6's or fc7's window of time steps (any other value reads as 6)
- * out[0..11] = {M-tile slots per (row-)wave, short row-waves, logical tile rows, positions or RoIs per tile, time steps whose currents
+ * out[0..11] = {M-tile slots per (row-)wave, short row-waves (dense tile) / 1 for the FAT shape of four waves (sparse plan), logical tile rows, positions or RoIs per tile, time steps whose currents
  * are formed (dead time steps removed), work-groups of the launch, column blocks, waves along N,
  * 1 if the structured-sparse launch runs (csrc/snn_sparse.h) / 0 for the dense k_gemm_bf16x3 tile, period planes on the dense
  * instruction, period planes on the structured-sparse instruction, M-tile slots in use per work-group (sparse plan; else 0)}.

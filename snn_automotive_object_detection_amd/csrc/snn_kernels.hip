@@ -133,7 +133,6 @@ __global__ void k_pack_heads(const float* __restrict__ wa, int NA, const float* 
 // Debug / A-B knobs.  They are read from the environment ONCE (first call into the library, thread-safe static
 // initialisation) and frozen: later setenv() calls change nothing, calls from several threads see one consistent set.
 // snn_debug_reload_knobs() re-reads them (the parity tests compare kernel variants in one process; not for concurrent use).
-#define SNN_SPARSE_BIG_DEFAULT 0
 struct Knobs {
     bool enc_generic;        // SNN_ENC_GENERIC=1     op-for-op encoder kernels even for zero rest / reset potentials
     bool enc_rows_ballot;    // SNN_ENC_ROWS=ballot   element-per-lane row encoder
@@ -161,8 +160,8 @@ struct Knobs {
                              //                       skips the steps whose currents cannot reach an output, lif_windows)
     bool sparse;             // SNN_SPARSE=0          RPN conv: every period plane on the dense matrix-core instruction (default: planes e_3.. on the
                              //                       structured-sparse one, snn_sparse.h)
-    int sparse_big;          // SNN_SPARSE_BIG=0..3   the BIG shape of k_gemm_lif_sparse (12 M-tile slots per row-wave, one work-group per CU, 4-slot ring): bit 0 =
-                             //                       linear layers (fc6), bit 1 = the RPN conv; default: see load_knobs
+    bool sparse_fat;         // SNN_SPARSE_FAT=0      linear layers (fc6) on the 8-wave shape of k_gemm_lif_sparse instead of the FAT one (four waves of up to 256
+                             //                       registers, twice the M-tile slots per wave: the default where its loop instances exist; bit-identical)
     int planes;              // SNN_PLANES=rm|wm      internal spike planes of the bf16x3 heads: all row-major [T][row][word] / all
                              //                       word-major [T][word][row] (1 / 2; 0 = default = word-major since round 3;
                              //                       bit-identical results either way, A/B + test switch)
@@ -183,8 +182,7 @@ static Knobs load_knobs() {
     e = getenv("SNN_LI_HEADS");
     k.li_heads = !e ? 0 : !strcmp(e, "valu") ? 1 : !strcmp(e, "mfma") ? 2 : !strcmp(e, "ksplit") ? 3 : 4;
     k.debug_occ = getenv("SNN_DEBUG_OCC") != nullptr;
-    e = getenv("SNN_SPARSE_BIG");
-    k.sparse_big = e ? atoi(e) : SNN_SPARSE_BIG_DEFAULT;
+    k.sparse_fat = !((e = getenv("SNN_SPARSE_FAT")) && e[0] == '0');
     e = getenv("SNN_PLANES");
     k.planes = !e ? 0 : !strcmp(e, "rm") ? 1 : !strcmp(e, "wm") ? 2 : 0;
     k.bf16x3_xcd = !((e = getenv("SNN_BF16X3_XCD")) && e[0] == '0');
@@ -898,15 +896,15 @@ static int count_spikes_per_image(const snn_rpn_level* lv, int n_levels, int Cw,
 
 static size_t sparse_side_bytes(long long P, long long Pe, int Kw, int T);
 // ---- structured-sparse conv (snn_sparse.h): tile geometry + wave assignment ----
-struct SparsePlan { int q, pb, nd, wn, big; signed char plane[8][SP_MTMAX]; unsigned char j[8][SP_MTMAX], w_nd[8], w_ns[8]; };
+struct SparsePlan { int q, pb, nd, wn, fat; signed char plane[8][SP_MTMAX]; unsigned char j[8][SP_MTMAX], w_nd[8], w_ns[8]; };
 // q = M-tiles (16 positions / RoIs each) per plane.  The conv has thousands of tiles and takes the largest one; a linear layer with a few
 // hundred work-groups takes the q with the fewest rounds of work-groups x work per tile (fc6 at 2000 RoIs, 10 planes: q = 3 is 672
 // work-groups = 1.31 rounds of the 512 slots, q = 2 is 1008 = 1.97 rounds of tiles two thirds the size: 687 -> ~520 us)
-static bool sparse_plan_wn(int Tc, int wn, int q, SparsePlan* sp, bool big = false) {
-    const int nd = 2, nwm = 8 / wn, mts = big ? SP_MT_BIG : wn == 1 ? SP_MT : SP_MT2;
-    if (q < 1 || Tc * q > nwm * mts || (big && wn != 2)) return false;
+static bool sparse_plan_wn(int Tc, int wn, int q, SparsePlan* sp, bool fat = false) {
+    const int nd = 2, nwm = (fat ? 4 : 8) / wn, mts = fat ? SP_MT2_FAT : wn == 1 ? SP_MT : SP_MT2;
+    if (q < 1 || Tc * q > nwm * mts || (fat && wn != 2)) return false;
     memset(sp, 0, sizeof(*sp));
-    sp->q = q; sp->pb = 16 * q; sp->nd = nd; sp->wn = wn; sp->big = big ? 1 : 0;
+    sp->q = q; sp->pb = 16 * q; sp->nd = nd; sp->wn = wn; sp->fat = fat ? 1 : 0;
     int used[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     double cost[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int w = 0; w < 8; ++w)
@@ -931,11 +929,11 @@ static bool sparse_plan_wn(int Tc, int wn, int q, SparsePlan* sp, bool big = fal
     // loop instances that exist (snn_sparse.h: SP_CASE)
     static const int inst1[][2] = {{1, 3}, {1, 2}, {2, 2}, {0, 4}, {0, 3}, {1, 1}, {2, 1}, {0, 2}, {0, 1}, {2, 0}, {1, 0}, {0, 0}, {0, 0}, {0, 0}};
     static const int inst2[][2] = {{1, 4}, {1, 5}, {2, 4}, {2, 3}, {1, 3}, {0, 6}, {0, 5}, {2, 2}, {0, 4}, {1, 2}, {0, 3}, {0, 0}, {0, 0}, {0, 0}};
-    static const int inst_big[][2] = {SP_BIG_INSTANCES, {0, 0}};
+    static const int inst_fat2[][2] = {SP_FAT2_INSTANCES, {0, 0}};
     for (int w = 0; w < nwm; ++w) {
         bool ok = false;
-        if (big) {
-            for (size_t i = 0; i < sizeof(inst_big) / sizeof(inst_big[0]); ++i) ok |= inst_big[i][0] == sp->w_nd[w] && inst_big[i][1] == sp->w_ns[w];
+        if (fat) {
+            for (size_t i = 0; i < sizeof(inst_fat2) / sizeof(inst_fat2[0]); ++i) ok |= inst_fat2[i][0] == sp->w_nd[w] && inst_fat2[i][1] == sp->w_ns[w];
         } else {
             for (int i = 0; i < 14; ++i) {
                 const int* c = wn == 1 ? inst1[i] : inst2[i];
@@ -954,11 +952,7 @@ static bool sparse_plan_wn(int Tc, int wn, int q, SparsePlan* sp, bool big = fal
 static bool sparse_plan(int Tc, SparsePlan* sp, long long units = 0, int n_blocks = 0) {
     if (Tc < 4 || Tc > 32) return false;
     const bool conv = !(units > 0 && n_blocks > 0);
-    // the BIG shape where it is switched on and has a plan (the largest tile whose row-waves have loop instances)
-    if (knobs().sparse_big & (conv ? 2 : 1)) {
-        for (int q = min(6, 48 / Tc); q >= 2; --q)
-            if (sparse_plan_wn(Tc, 2, q, sp, true)) return true;
-    }
+    const bool fat = !conv && knobs().sparse_fat;           // linear layers: the same tiles on four fat waves, where the plan's row-waves have loop instances
     if (conv) {
         int q = 32 / Tc;
         if (q > 8) q = 8;
@@ -978,6 +972,7 @@ static bool sparse_plan(int Tc, SparsePlan* sp, long long units = 0, int n_block
             const double cost = (double)((wgs + slots - 1) / slots) * (work + 2.0);
             if (!have || cost < best_cost * 0.97) { *sp = cand; best_cost = cost; have = true; }
         }
+    if (have && fat && sp->wn == 2 && sparse_plan_wn(Tc, 2, sp->q, &cand, true)) *sp = cand;
     return have;
 }
 
@@ -1004,8 +999,8 @@ static bool sparse_shape(bool conv, long long M, int Kw, int Kc, int Np, int T, 
         out->xcd_contig = cdiv(out->n_tiles, 8 / groups);
         out->grid = out->xcd_contig * out->xcd_cpx * 8;
     }
-    out->lds = max(sp.big ? (int)SP_LDS_BIG : (int)SP_LDS, Tc * sp.pb * SP_PITCH * 4);    // the ring, then the epilogue's tile image in the same bytes
-    if (out->lds > (sp.big ? 160 : 80) * 1024) return false;
+    out->lds = max((int)SP_LDS, Tc * sp.pb * SP_PITCH * 4);    // the ring, then the epilogue's tile image in the same bytes
+    if (out->lds > 80 * 1024) return false;
     out->epi_general = !(T >= 5 && T <= 16 && Tc == T - (conv ? 1 : 2));
     return true;
 }
@@ -1027,7 +1022,7 @@ static int gemm3_lif_sparse(const Gemm3Args& a, bool conv, void* side, size_t si
     const unsigned long long cmp_bytes = (unsigned long long)(a.Tc - sp.nd) * (Kw / 2) * SP_A_ARR * Pe * 4;
     // (the kernel addresses both the raw and the compressed planes by 32-bit offsets from the raw planes)
     if ((const char*)cmp < (const char*)a.A || (unsigned long long)((const char*)cmp - (const char*)a.A) + cmp_bytes > 0xffffffffULL) return 0;
-    const void* kern = sp.big ? (conv ? (const void*)k_gemm_lif_sparse<true, 2, true> : (const void*)k_gemm_lif_sparse<false, 2, true>)
+    const void* kern = sp.fat ? (const void*)k_gemm_lif_sparse<false, 2, true>
                               : conv ? (const void*)k_gemm_lif_sparse<true, 1> : sp.wn == 2 ? (const void*)k_gemm_lif_sparse<false, 2> : (const void*)k_gemm_lif_sparse<false, 1>;
     hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, sh.lds);
     if (e != hipSuccess) return fail(-3, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -1060,11 +1055,11 @@ static int gemm3_lif_sparse(const Gemm3Args& a, bool conv, void* side, size_t si
     sa.cnt_row = conv ? cnt_pos : a.cnt_row;
     if (knobs().debug_occ) {
         int v = 0;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, kern, 512, sh.lds);
-        fprintf(stderr, "k_gemm_lif_sparse<%d, %d, %d>: pb %d x Tc %d, q %d, lds %d B, %d work-groups per CU, grid %d\n", (int)conv, sp.wn, sp.big, sp.pb, a.Tc, sp.q, sh.lds, v, sh.grid);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, kern, sp.fat ? 256 : 512, sh.lds);
+        fprintf(stderr, "k_gemm_lif_sparse<%d, %d, %d>: pb %d x Tc %d, q %d, lds %d B, %d work-groups per CU, grid %d\n", (int)conv, sp.wn, sp.fat, sp.pb, a.Tc, sp.q, sh.lds, v, sh.grid);
     }
     void* kargs[] = {(void*)&sa};
-    e = hipLaunchKernel(kern, dim3(sh.grid), dim3(512), kargs, sh.lds, s);
+    e = hipLaunchKernel(kern, dim3(sh.grid), dim3(sp.fat ? 256 : 512), kargs, sh.lds, s);
     if (e != hipSuccess) return fail(-3, "k_gemm_lif_sparse launch failed: %s", hipGetErrorString(e));
     SNN_CHECK_LAUNCH("k_gemm_lif_sparse");
     if (cnt_pos) {
@@ -1093,8 +1088,8 @@ int snn_debug_tile_shape(int conv, long long units, int k_in, int n_cols, int nu
     if (knobs().periods && (conv || layer != 7) && sparse_shape(conv != 0, units, Kw, conv ? 9 * Kw : Kw, Np, num_steps, Tc, &sh)) {
         const SparsePlan& sp = sh.sp;
         int slots = 0;
-        for (int w = 0; w < 8 / sp.wn; ++w) slots += sp.w_nd[w] + sp.w_ns[w];
-        out[0] = sp.big ? SP_MT_BIG : sp.wn == 1 ? SP_MT : SP_MT2; out[1] = sp.big; out[2] = Tc * sp.pb; out[3] = sp.pb; out[4] = Tc; out[5] = sh.n_tiles * sh.n_blocks;
+        for (int w = 0; w < (sp.fat ? 4 : 8) / sp.wn; ++w) slots += sp.w_nd[w] + sp.w_ns[w];
+        out[0] = sp.fat ? SP_MT2_FAT : sp.wn == 1 ? SP_MT : SP_MT2; out[1] = sp.fat; out[2] = Tc * sp.pb; out[3] = sp.pb; out[4] = Tc; out[5] = sh.n_tiles * sh.n_blocks;
         out[6] = sh.n_blocks; out[7] = sp.wn; out[8] = 1; out[9] = sp.nd; out[10] = Tc - sp.nd; out[11] = slots;
         return 0;
     }

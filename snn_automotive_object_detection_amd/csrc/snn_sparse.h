@@ -31,11 +31,9 @@ typedef __bf16 bfv16 __attribute__((ext_vector_type(16)));
 
 #define SP_MT 4                                     // M-tile slots per wave on the 8 x 1 wave grid (all waves span the 64 columns)
 #define SP_MT2 6                                    // ... per ROW-wave on the 4 x 2 grid (two waves of 32 columns share a row-wave's slots)
-#define SP_MT_BIG 12                                // ... per row-wave of the BIG shape (round 5): 4 x 2 grid, ONE work-group per CU with up to 256 registers per
-                                                    // lane and a 4-slot ring - 48 M-tiles per work-group, e.g. 64 RoIs x 10 planes (linear layers)
+#define SP_MT2_FAT 12                               // ... per row-wave of the FAT shape (linear layers): 2 x 2 waves of up to 256 registers, 32 columns per wave
 #define SP_MTMAX 12
 #define SP_ROWS (8 * SP_MT * 16)                    // physical tile rows (512; 4 x 6 x 16 = 384 on the 4 x 2 grid)
-#define SP_ROWS_BIG (4 * SP_MT_BIG * 16)            // 768
 #define SP_A_ARR 4                                  // dword arrays per step: dense rows use two (the chunks' spike words), sparse rows all four:
                                                     // occupancy bytes of the four 16-k blocks, index halves 0-1, index halves 2-3 of the primary
                                                     // plane, occupancy bytes of the secondary plane (whose indices are the constant (2, 3))
@@ -43,9 +41,11 @@ typedef __bf16 bfv16 __attribute__((ext_vector_type(16)));
 #define SP_B_BYTES (2 * 3 * 64 * G3_ROWB)           // two chunks x three weight planes x 64 columns
 #define SP_SLOT (SP_A_BYTES + SP_B_BYTES)           // one 64-k step: 32 KB
 #define SP_LDS (G3_LUT_BYTES + 2 * SP_SLOT)         // 68 KB: two work-groups per CU
-#define SP_BIG_SLOTS 4                              // ring slots of the BIG shape: copies run three steps ahead of the matrix instructions
-#define SP_SLOT_BIG (SP_A_ARR * SP_ROWS_BIG * 4 + SP_B_BYTES)        // 36 KB
-#define SP_LDS_BIG (G3_LUT_BYTES + SP_BIG_SLOTS * SP_SLOT_BIG)       // 148 KB: one work-group per CU
+#ifdef SNN_EXP_SP_NO_BREAD                            // (timing experiment, see the K loop)
+#define SNN_EXP_BSEL(g) 0
+#else
+#define SNN_EXP_BSEL(g) (g)
+#endif
 #define SP_PITCH 36                                 // epilogue tile image: 32 columns + 4 floats of padding per row
 
 struct SparseConvArgs {
@@ -307,20 +307,29 @@ __global__ __launch_bounds__(256) void k_sum_pos_counts(const PosCountArgs a) {
 // WN = waves along the 64 columns.  1: 8 row-waves x 4 slots, every wave reads the whole weight slot from LDS each step (192 KB per
 // work-group and step).  2: 4 row-waves x 6 slots, a wave covers 32 columns and reads half of the slot (96 KB): the shape for launches whose
 // matrix-pipe time per step is below what those LDS reads take - fc6, whose tiles hold 32 RoIs (tools: profiles/r4_sparse_timeline.txt).
-// BIG (linear layers, WN = 2): the same loop on 12 M-tile slots per row-wave - each weight fragment read from LDS feeds twice the matrix
-// instructions, each work-group streams its 4.8-MB weight panel for twice the RoIs - with ONE work-group per CU (up to 256 registers per
-// lane).  What the second work-group of a CU gave the small shape (its waves fill the pipe while the first waits at its step barrier
-// for copies) comes from a 4-slot ring instead: copies are issued three steps ahead, and the wait before the step barrier leaves the two
-// youngest steps' copies in flight (s_waitcnt vmcnt counts in issue order; every wave issues the same SP_BIG_DMA copies per step).
-template <bool CONV, int WN, bool BIG = false>
-__global__ __launch_bounds__(512, BIG ? 2 : 4) void k_gemm_lif_sparse(const SparseConvArgs args) {
-    static_assert(!BIG || WN == 2, "the BIG shape runs the 4 x 2 wave grid");
-    constexpr int MTS = BIG ? SP_MT_BIG : WN == 1 ? SP_MT : SP_MT2, NT = 4 / WN;      // slots per (row-)wave, 16-column N-tiles per wave
-    constexpr int ROWS = BIG ? SP_ROWS_BIG : SP_ROWS;               // physical tile rows of a ring slot
+// FAT (linear layers, WN = 2; round 5): the same tile run by FOUR waves - 2 x 2, twelve M-tile slots per row-wave, 256 threads with up to
+// 256 registers per lane; still two work-groups per CU, i.e. two waves per SIMD from DIFFERENT work-groups.  Every weight fragment read
+// from LDS feeds twice the matrix instructions (the what-if builds price those reads at 9 % of the detector head and 14 % of the conv
+// launch, profiles/r5_sparse_whatif.txt), and the registers pay for a third weight-fragment buffer: fragments are requested two groups
+// ahead of their matrix instructions (one group ahead the shape LOSES 2 %).  Measured (profiles/r5_fat_wave_ab.txt, same lease): detector
+// head 0.780 -> 0.756 ms at T = 12.  For the conv (4 row-waves x 8 slots) the K loop gained 4.6 % and the LIF epilogue lost it again
+// (one wave per SIMD and work-group issues a vector instruction every four cycles, two interleave at two): 1.955 -> 1.940 ms at T = 8,
+// +2 % at T = 16 - not instantiated.  (The BIG shape tried first - 512 threads, 48 slots, ONE work-group per CU, 4-slot ring - was
+// bit-identical and 34 % / 6 % SLOWER on the conv / detector head, profiles/r5_big_tile_ab.txt: two lock-stepped waves of one work-group per
+// SIMD leave the pipe idle at every barrier.)
+template <bool CONV, int WN, bool FAT = false>
+__global__ __launch_bounds__(FAT ? 256 : 512, FAT ? 2 : 4) void k_gemm_lif_sparse(const SparseConvArgs args) {
+    static_assert(!FAT || (WN == 2 && !CONV), "the FAT shape is instantiated for linear layers (2 x 2 waves)");
+    constexpr int NWAVES = FAT ? 4 : 8;
+    constexpr int MTS = FAT ? SP_MT2_FAT : WN == 1 ? SP_MT : SP_MT2, NT = 4 / WN;      // slots per (row-)wave, 16-column N-tiles per wave
+    constexpr int ROWS = SP_ROWS;                                   // physical tile rows of a ring slot (row-waves x MTS x 16 <= 512 in every shape)
+    static_assert((NWAVES / WN) * MTS * 16 <= SP_ROWS, "ring slot rows");
     constexpr int A_BYTES = SP_A_ARR * ROWS * 4, SLOT = A_BYTES + SP_B_BYTES;
-    constexpr int NSLOT = BIG ? SP_BIG_SLOTS : 2, DIST = NSLOT - 1; // ring slots; steps the copies run ahead
-    constexpr int NPASS = BIG ? 2 : 1;                              // A-staging passes of a wave (64 rows each) per step
-    constexpr int DMA_PER_STEP = SP_A_ARR * NPASS + 3;              // LDS-DMA instructions a wave issues per step (A arrays + three weight pieces)
+    constexpr int NPASS = FAT ? 2 : 1;                              // A-staging passes of a wave (64 rows each) per step
+#ifndef SP_FAT_BDEPTH
+#define SP_FAT_BDEPTH 2
+#endif
+    constexpr int BDEPTH = FAT ? SP_FAT_BDEPTH : 1;                 // groups the weight-fragment reads run ahead of their matrix instructions
 #ifdef SNN_EXP_TIMELINE     // diagnostic build: wall-clock stamps (s_memrealtime, 100 MHz) of the work-group's phases
     unsigned long long tl_entry = 0, tl_loop0 = 0, tl_loop1 = 0, tl_epi = 0, tl_img = 0;
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_entry) :: "memory");
@@ -354,7 +363,8 @@ __global__ __launch_bounds__(512, BIG ? 2 : 4) void k_gemm_lif_sparse(const Spar
     }
     const int nd_w = __builtin_amdgcn_readfirstlane((int)args.w_nd[wm]), ns_w = __builtin_amdgcn_readfirstlane((int)args.w_ns[wm]);
     // ---- A staging: lane L of the wave stages row L & 15 of one M-tile slot of its row-wave.  WN = 1: slot L >> 4 (64 rows per wave);
-    // WN = 2: the two column-waves of a row-wave take three slots each (lanes 0 .. 47); BIG: six slots each, in two passes (64 + 32 lanes)
+    // WN = 2: the two column-waves of a row-wave take three slots each (lanes 0 .. 47).  FAT: two passes - WN = 1: the wave's eight slots
+    // (64 + 64 lanes); WN = 2: six slots per column-wave (64 + 32 lanes)
     const void* a_base[SP_A_ARR];
 #pragma unroll
     for (int j = 0; j < SP_A_ARR; ++j) a_base[j] = sgpr_ptr(reinterpret_cast<const char*>(args.enc) + (size_t)j * args.Pe * 4);
@@ -364,8 +374,8 @@ __global__ __launch_bounds__(512, BIG ? 2 : 4) void k_gemm_lif_sparse(const Spar
     uint32_t tap_fix[NPASS], row_fix[NPASS];
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
-        const int xs = BIG ? min(6 * wn + 4 * ps + (lane >> 4), MTS - 1) : WN == 1 ? (lane >> 4) : min(3 * wn + (lane >> 4), MTS - 1);
-        a_lane[ps] = BIG ? (lane < (ps == 0 ? 64 : 32)) : (WN == 1 || lane < 48);
+        const int xs = FAT ? (WN == 1 ? 4 * ps + (lane >> 4) : min(6 * wn + 4 * ps + (lane >> 4), MTS - 1)) : WN == 1 ? (lane >> 4) : min(3 * wn + (lane >> 4), MTS - 1);
+        a_lane[ps] = FAT ? (WN == 1 || lane < (ps == 0 ? 64 : 32)) : (WN == 1 || lane < 48);
         const int xplane = args.mt_plane[wm][xs];
         const bool xused = xplane >= 0, xdense = xused && xplane < args.nd;
         const int lp = min(args.mt_j[wm][xs] * 16 + (lane & 15), pb - 1);
@@ -397,7 +407,7 @@ __global__ __launch_bounds__(512, BIG ? 2 : 4) void k_gemm_lif_sparse(const Spar
         row_fix[ps] = (uint32_t)((W + 2 - 3) * 4);          // after the third tap of a row: one padded image row down
     }
     // physical row (wm MTS + slot) 16 + r; a pass covers four slots
-    const uint32_t a_dst = smem_base + G3_LUT_BYTES + (BIG ? (wm * MTS + 6 * wn) * 64 : WN == 1 ? wave * 256 : (wm * MTS + 3 * wn) * 64);
+    const uint32_t a_dst = smem_base + G3_LUT_BYTES + (FAT ? (wm * MTS + (WN == 1 ? 0 : 6 * wn)) * 64 : WN == 1 ? wave * 256 : (wm * MTS + 3 * wn) * 64);
     const int cw2_s = __builtin_amdgcn_readfirstlane(args.Cw / 2);
     int f_c = 0, f_tap = 0;
     auto stage_a = [&](const uint32_t slot_off) __attribute__((always_inline)) {
@@ -425,7 +435,7 @@ __global__ __launch_bounds__(512, BIG ? 2 : 4) void k_gemm_lif_sparse(const Spar
         }
     };
 
-    // ---- B staging: 24 pieces of 1 KB per step (2 chunks x 3 planes x 4 blocks of 16 columns); wave w copies pieces w, w + 8, w + 16
+    // ---- B staging: 24 pieces of 1 KB per step (2 chunks x 3 planes x 4 blocks of 16 columns); wave w copies pieces w, w + NWAVES, ..
     const int brow = (wave & 3) * 16 + (lane >> 2);
     const uint32_t b_off = (uint32_t)((nb * 64 + brow) * 64 + (((lane & 3) ^ G3_SWZ(brow)) << 4));
     const unsigned long long b_chunk = (unsigned long long)Np * 64, b_plane = args.plane_elems * 2;
@@ -434,8 +444,8 @@ __global__ __launch_bounds__(512, BIG ? 2 : 4) void k_gemm_lif_sparse(const Spar
     auto stage_b = [&](const uint32_t slot_off) __attribute__((always_inline)) {
         const uint32_t d = __builtin_amdgcn_readfirstlane(b_dst + slot_off);
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int piece = wave + 8 * i;                                    // wave-uniform
+        for (int i = 0; i < 24 / NWAVES; ++i) {
+            const int piece = wave + NWAVES * i;                               // wave-uniform; piece & 3 = wave & 3 = its block of 16 columns
             const int c2 = piece / 12, pl = (piece % 12) / 4;
             glds16(sgpr_ptr(reinterpret_cast<const void*>(s_ptr + c2 * b_chunk + pl * b_plane)), b_off, d + c2 * (3 * 64 * G3_ROWB) + pl * (64 * G3_ROWB));
         }
@@ -451,16 +461,8 @@ __global__ __launch_bounds__(512, BIG ? 2 : 4) void k_gemm_lif_sparse(const Spar
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
     const int n_steps = Kc / 2;
-    // vmcnt immediates of the ring: all but the `g` youngest steps' copies of this wave have landed
-    auto wait_groups = [&](const int g) __attribute__((always_inline)) {
-        if constexpr (DIST >= 3) { if (g >= 2) { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * DMA_PER_STEP) : "memory"); return; } }
-        if constexpr (DIST >= 2) { if (g == 1) { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DMA_PER_STEP) : "memory"); return; } }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    };
-#pragma unroll
-    for (int s0 = 0; s0 < DIST; ++s0)
-        if (s0 < n_steps) { stage_a((uint32_t)(s0 * SLOT)); stage_b((uint32_t)(s0 * SLOT)); }
-    wait_groups(min(DIST, n_steps) - 1);
+    stage_a(0); stage_b(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -475,8 +477,8 @@ __global__ __launch_bounds__(512, BIG ? 2 : 4) void k_gemm_lif_sparse(const Spar
     auto step_loop = [&](auto nd_c, auto ns_c) __attribute__((always_inline)) {
         constexpr int ND = decltype(nd_c)::value, NS = decltype(ns_c)::value;
         for (int s = 0; s < n_steps; ++s) {
-            const uint32_t o_cur = (uint32_t)((s % NSLOT) * SLOT), o_nxt = (uint32_t)(((s + DIST) % NSLOT) * SLOT);
-            if (s + DIST < n_steps) {
+            const uint32_t o_cur = (uint32_t)((s & 1) * SLOT), o_nxt = (uint32_t)(((s + 1) & 1) * SLOT);
+            if (s + 1 < n_steps) {
 #ifndef SNN_EXP_SP_NO_A                             // (timing experiments: what do the copies cost - wrong results)
                 stage_a(o_nxt);
 #endif
@@ -516,44 +518,47 @@ __global__ __launch_bounds__(512, BIG ? 2 : 4) void k_gemm_lif_sparse(const Spar
                 sec[b4] = __ballot(o2 != 0u) & (NS - 4 * b4 >= 4 ? ~0ull : ((1ull << (16 * (NS - 4 * b4))) - 1ull));
             }
 #endif
+            // weight fragments of group g = (N-tile g / 3, plane 2 - g % 3: small terms first): both 32-deep chunks of the step as ONE 16-element
+            // operand (the structured-sparse instruction's B; its halves are the dense instruction's B of chunk c, c + 1), double-buffered by
+            // the parity of g - the loads land in the halves of the buffer the next group reads, no register copies (round 5: the compiler
+            // rotated an 8-register pair per group with v_mov_b64)
+            bfv16 bbuf[BDEPTH + 1];
+            auto load_b = [&](bfv16& dst, const int gn) __attribute__((always_inline)) {
 #ifdef SNN_EXP_SP_NO_BREAD                            // (timing experiment: the weight fragments stay what they were before the loop)
-            bfv8 b0 = exp_b0, b1 = exp_b1;
+                const bfv8 lo = exp_b0, hi = exp_b1;
 #else
-            bfv8 b0 = *reinterpret_cast<const bfv8*>(b_rd + o_cur + 2 * (64 * G3_ROWB));
-            bfv8 b1 = *reinterpret_cast<const bfv8*>(b_rd + o_cur + 3 * 64 * G3_ROWB + 2 * (64 * G3_ROWB));
+                const bfv8 lo = *reinterpret_cast<const bfv8*>(b_rd + o_cur + (2 - gn % 3) * (64 * G3_ROWB) + (gn / 3) * 16 * G3_ROWB);
+                const bfv8 hi = *reinterpret_cast<const bfv8*>(b_rd + o_cur + 3 * 64 * G3_ROWB + (2 - gn % 3) * (64 * G3_ROWB) + (gn / 3) * 16 * G3_ROWB);
 #endif
+                dst = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+            };
 #pragma unroll
-            for (int g = 0; g < 3 * NT; ++g) {              // group = (N-tile g / 3, plane 2 - g % 3): small terms first
-                bfv8 n0 = b0, n1 = b1;
+            for (int g0 = 0; g0 < BDEPTH; ++g0) load_b(bbuf[g0], g0);
+#pragma unroll
+            for (int g = 0; g < 3 * NT; ++g) {
 #ifndef SNN_EXP_SP_NO_BREAD
-                if (g + 1 < 3 * NT) {
-                    const int gn = g + 1;
-                    n0 = *reinterpret_cast<const bfv8*>(b_rd + o_cur + (2 - gn % 3) * (64 * G3_ROWB) + (gn / 3) * 16 * G3_ROWB);
-                    n1 = *reinterpret_cast<const bfv8*>(b_rd + o_cur + 3 * 64 * G3_ROWB + (2 - gn % 3) * (64 * G3_ROWB) + (gn / 3) * 16 * G3_ROWB);
-                }
+                if (g + BDEPTH < 3 * NT) load_b(bbuf[(g + BDEPTH) % (BDEPTH + 1)], g + BDEPTH);
 #endif
+                const bfv16 bb = bbuf[SNN_EXP_BSEL(g) % (BDEPTH + 1)];
 #ifndef SNN_EXP_SP_NO_MFMA                            // (timing experiment: everything but the matrix instructions)
+                if (ND > 0) {
+                    const bfv8 b0 = __builtin_shufflevector(bb, bb, 0, 1, 2, 3, 4, 5, 6, 7), b1 = __builtin_shufflevector(bb, bb, 8, 9, 10, 11, 12, 13, 14, 15);
 #pragma unroll
-                for (int d = 0; d < ND; ++d) {
-                    acc[d][g / 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ad[d][0], b0, acc[d][g / 3], 0, 0, 0);
-                    acc[d][g / 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ad[d][1], b1, acc[d][g / 3], 0, 0, 0);
+                    for (int d = 0; d < ND; ++d) {
+                        acc[d][g / 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ad[d][0], b0, acc[d][g / 3], 0, 0, 0);
+                        acc[d][g / 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ad[d][1], b1, acc[d][g / 3], 0, 0, 0);
+                    }
                 }
-                if (NS > 0) {
-                    bfv16 bb;
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) { bb[i] = b0[i]; bb[8 + i] = b1[i]; }
-#pragma unroll
-                    for (int q = 0; q < NS; ++q)
-                        acc[ND + q][g / 3] = __builtin_amdgcn_smfmac_f32_16x16x64_bf16(as[q], bb, acc[ND + q][g / 3], ix[q], 0, 0);
-                }
+                for (int q = 0; q < NS; ++q)
+                    acc[ND + q][g / 3] = __builtin_amdgcn_smfmac_f32_16x16x64_bf16(as[q], bb, acc[ND + q][g / 3], ix[q], 0, 0);
 #else
-                asm volatile("" :: "v"(b0), "v"(b1));
+                asm volatile("" :: "v"(bb));
 #pragma unroll
                 for (int d = 0; d < ND; ++d) asm volatile("" :: "v"(ad[d][0]), "v"(ad[d][1]));
 #pragma unroll
                 for (int q = 0; q < NS; ++q) asm volatile("" :: "v"(as[q]), "v"(ix[q]));
 #endif
-                b0 = n0; b1 = n1;
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (NS > 0 && (sec[0] | sec[1] | sec[2]) != 0ull) {   // (rare) the secondary plane of the M-tiles that have one in this step
@@ -576,31 +581,24 @@ __global__ __launch_bounds__(512, BIG ? 2 : 4) void k_gemm_lif_sparse(const Spar
                 }
             }
             asm volatile("" ::: "memory");
-            if constexpr (DIST == 1) {
-                __builtin_amdgcn_s_waitcnt(0x0070);          // vmcnt(0) lgkmcnt(0): the next step's copies have landed
-            } else {                                         // this wave's copies of step s + 1 have landed; those of the steps behind it stay in flight
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                wait_groups(min(DIST - 1, n_steps - s - 2));
-            }
+            __builtin_amdgcn_s_waitcnt(0x0070);              // vmcnt(0) lgkmcnt(0): the next step's copies have landed
 #ifndef SNN_EXP_SP_NO_BAR                             // (timing experiment: waves run ahead of each other's copies - wrong results)
             __builtin_amdgcn_s_barrier();
 #endif
             asm volatile("" ::: "memory");
         }
     };
-// (dense, sparse) M-tile counts of a row-wave the BIG shape has loop instances for (host: sparse_plan_wn checks against the same list)
-#define SP_BIG_INSTANCES {3, 8}, {3, 7}, {2, 8}, {2, 9}, {1, 10}, {1, 11}, {1, 9}
-#define SP_BIG_CASES SP_CASE(3, 8) SP_CASE(3, 7) SP_CASE(2, 8) SP_CASE(2, 9) SP_CASE(1, 10) SP_CASE(1, 11) SP_CASE(1, 9)
+// (dense, sparse) M-tile counts of a row-wave the FAT shapes have loop instances for (host: sparse_plan_wn checks against the same lists)
+#define SP_FAT2_INSTANCES {2, 8}, {2, 7}, {2, 9}, {2, 10}, {2, 6}, {2, 5}, {2, 4}, {2, 3}, {2, 2}, {1, 10}, {1, 11}, {1, 9}, {1, 8}, {1, 7}, {1, 6}, {1, 5}
+#define SP_FAT2_CASES SP_CASE(2, 8) SP_CASE(2, 7) SP_CASE(2, 9) SP_CASE(2, 10) SP_CASE(2, 6) SP_CASE(2, 5) SP_CASE(2, 4) SP_CASE(2, 3) SP_CASE(2, 2) \
+                      SP_CASE(1, 10) SP_CASE(1, 11) SP_CASE(1, 9) SP_CASE(1, 8) SP_CASE(1, 7) SP_CASE(1, 6) SP_CASE(1, 5)
 #define SP_CASE(ND_, NS_) if (nd_w == ND_ && ns_w == NS_) step_loop(std::integral_constant<int, ND_>{}, std::integral_constant<int, NS_>{}); else
-    if constexpr (WN == 1) {
+    if constexpr (FAT) {
+        SP_FAT2_CASES { step_loop(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}); }
+    } else if constexpr (WN == 1) {
         SP_CASE(1, 3) SP_CASE(1, 2) SP_CASE(2, 2) SP_CASE(0, 4) SP_CASE(0, 3) SP_CASE(1, 1) SP_CASE(2, 1) SP_CASE(0, 2) SP_CASE(0, 1)
         SP_CASE(2, 0) SP_CASE(1, 0)
         {   // a wave without M-tiles still stages and keeps the barriers
-            step_loop(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
-        }
-    } else if constexpr (BIG) {
-        SP_BIG_CASES
-        {
             step_loop(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
         }
     } else {
@@ -648,17 +646,19 @@ __global__ __launch_bounds__(512, BIG ? 2 : 4) void k_gemm_lif_sparse(const Spar
 #endif
         const int word0 = (nb * 64 + h * 32) >> 5;
         const int par = lane >> 5, col = lane & 31;
-        // position pairs per wave and iteration (see sp_lif_fixed): two up to T = 10, one beyond (registers: T - 1 period sums per neuron)
+        // position pairs per wave and iteration (see sp_lif_fixed): two up to T = 10, one beyond (registers: T - 1 period sums per neuron);
+        // the FAT shape's waves have the registers for twice that - and half the waves to hide the recurrence's latencies with
+        constexpr int NP_SHORT = FAT ? 4 : 2, NP_LONG = FAT ? 2 : 1;
         auto lif_pass = [&](auto np_c, auto count_c) __attribute__((always_inline)) {
         constexpr int NP = decltype(np_c)::value;
         constexpr bool COUNT = decltype(count_c)::value;
-        for (int pp0 = wave; 2 * pp0 < pb; pp0 += 8 * NP) {
+        for (int pp0 = wave; 2 * pp0 < pb; pp0 += NWAVES * NP) {
             if (m0 + 2 * pp0 >= M) break;
             uint32_t my0[NP], my1[NP], cnt_lo[NP], cnt_hi[NP];
             const float* src[NP];
 #pragma unroll
             for (int u = 0; u < NP; ++u) {
-                const int pi = 2 * (pp0 + 8 * u) + par;
+                const int pi = 2 * (pp0 + NWAVES * u) + par;
                 const bool live = pi < pb && m0 + pi < M;
                 my0[u] = 0; my1[u] = 0; cnt_lo[u] = 0; cnt_hi[u] = 0;
                 src[u] = tile + (live ? pi : 2 * pp0) * SP_PITCH + col;    // (dead lanes / pairs recompute a live row: never stored)
@@ -666,17 +666,17 @@ __global__ __launch_bounds__(512, BIG ? 2 : 4) void k_gemm_lif_sparse(const Spar
 #define SP_T(n) case n: sp_lif_fixed<n, CONV ? 1 : 2, NP, COUNT>(src, group_stride, args.p, my0, my1, cnt_lo, cnt_hi); break;
             if (NP == 1 && !CONV && args.epi_general) {               // (block-uniform; linear layers only: the conv's launcher keeps to the fixed grid)
                 if constexpr (NP == 1 && !CONV) sp_lif_general<COUNT>(src[0], group_stride, args.p, T, Tc, args.div, lane, my0[0], my1[0], cnt_lo[0], cnt_hi[0]);
-            } else if constexpr (NP == 2) {
-                switch (T) { SP_T(5) SP_T(6) SP_T(7) SP_T(8) SP_T(9) SP_T(10) default: break; }
             } else if constexpr (COUNT) {
                 switch (T) { SP_T(5) SP_T(6) SP_T(7) SP_T(8) SP_T(9) SP_T(10) SP_T(11) SP_T(12) SP_T(13) SP_T(14) SP_T(15) SP_T(16) default: break; }
+            } else if constexpr (NP == NP_SHORT) {
+                switch (T) { SP_T(5) SP_T(6) SP_T(7) SP_T(8) SP_T(9) SP_T(10) default: break; }
             } else {
                 switch (T) { SP_T(11) SP_T(12) SP_T(13) SP_T(14) SP_T(15) SP_T(16) default: break; }
             }
 #undef SP_T
 #pragma unroll
             for (int u = 0; u < NP; ++u) {
-                const int pp = pp0 + 8 * u;
+                const int pp = pp0 + NWAVES * u;
                 if (2 * pp >= pb || m0 + 2 * pp >= M) continue;
                 const bool odd_ok = 2 * pp + 1 < pb && m0 + 2 * pp + 1 < M;
                 if (COUNT && lane == 0) {                                  // (dead odd rows recompute the even one: not counted)
@@ -701,11 +701,14 @@ __global__ __launch_bounds__(512, BIG ? 2 : 4) void k_gemm_lif_sparse(const Spar
             }
         }
         };
-        if (counting) {                                            // (one recurrence per lane: the counters take the registers of the second)
-            lif_pass(std::integral_constant<int, 1>{}, std::true_type{});
-        } else {
-            if (T <= 10 && !args.epi_general) lif_pass(std::integral_constant<int, 2>{}, std::false_type{});
+        if (args.epi_general) {                                    // (linear layers outside the straight-line grid: one run-time recurrence per lane)
+            if (counting) lif_pass(std::integral_constant<int, 1>{}, std::true_type{});
             else lif_pass(std::integral_constant<int, 1>{}, std::false_type{});
+        } else if (counting) {                                     // (the counters take the registers of one recurrence)
+            lif_pass(std::integral_constant<int, NP_LONG>{}, std::true_type{});
+        } else {
+            if (T <= 10) lif_pass(std::integral_constant<int, NP_SHORT>{}, std::false_type{});
+            else lif_pass(std::integral_constant<int, NP_LONG>{}, std::false_type{});
         }
 #ifdef SNN_EXP_TIMELINE
         if (h == 0) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_epi) :: "memory");

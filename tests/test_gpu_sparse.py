@@ -300,34 +300,21 @@ def test_sparse_fc6_beyond_16_steps(gpu_device, monkeypatch, T):
     assert int(off.sum()) <= flip_budget(R, 2 * Hd, T, "det") and float((a[0] - b[0]).abs().max()) < 0.5, int(off.sum())
 
 
-# ---- the BIG tile shape (12 M-tile slots per row-wave, one work-group per CU, 4-slot ring): the same sums in the same order -------------
-@pytest.mark.parametrize("T", [8, 16])
-def test_big_shape_conv_is_bit_identical(gpu_device, monkeypatch, T):
-    """every accumulator sees the same matrix instructions in the same order whatever the tile shape: outputs equal bit for bit"""
-    m = _head(gpu_device, 256, T, 70 + T)
-    g = torch.Generator().manual_seed(70 + T)
-    feats = [(torch.randn(2, 256, h, w, generator=g) * 1.7).to(gpu_device) for h, w in [(41, 67), (19, 27), (7, 9), (1, 3)]]
-    monkeypatch.setenv("SNN_SPARSE_BIG", "0")
-    a = _run(m, feats, sparse=True)
-    monkeypatch.setenv("SNN_SPARSE_BIG", "3")
-    for _ in range(3):
-        b = _run(m, feats, sparse=True)
-        assert all(torch.equal(x, y) for x, y in zip(a, b))
-    m.spike_rates = True                                       # counting launches on the BIG shape: the same integers
-    m(feats)
-    c_big = m.last_spike_counts.clone()
-    monkeypatch.setenv("SNN_SPARSE_BIG", "0")
-    m(feats)
-    assert torch.equal(c_big, m.last_spike_counts) and int(c_big.sum()) > 0
-
-
-@pytest.mark.parametrize("R,C,Hd,K,T", [(2000, 256, 1024, 9, 12), (333, 64, 256, 11, 24), (77, 64, 128, 5, 12), (1, 64, 128, 5, 24), (200, 128, 192, 3, 16)])
-def test_big_shape_fc6_is_bit_identical(gpu_device, monkeypatch, R, C, Hd, K, T):
+# ---- the FAT shape of linear layers (work-groups of four waves with twice the M-tile slots per wave; default): the same sums in the same
+# order as the 8-wave shape (SNN_SPARSE_FAT=0) - every accumulator sees the same matrix instructions in the same order -------------
+# (fat = 0: a plan whose row-waves have no FAT loop instance - four dense M-tiles per row-wave at T <= 8 - keeps the 8-wave shape)
+@pytest.mark.parametrize("R,C,Hd,K,T,fat", [(2000, 256, 1024, 9, 12, 1), (333, 64, 256, 11, 24, 1), (77, 64, 128, 5, 12, 1), (1, 64, 128, 5, 24, 1), (200, 128, 192, 3, 16, 1),
+                                            (90, 64, 128, 5, 7, 0), (2000, 256, 1024, 9, 8, 0), (500, 64, 256, 9, 19, 1), (2000, 256, 1024, 9, 14, 1)])
+def test_fat_shape_fc6_is_bit_identical(gpu_device, monkeypatch, R, C, Hd, K, T, fat):
     d = _det(gpu_device, C, Hd, K, T, R + T)
     x = torch.randn(R, C, 7, 7, device=gpu_device) * 2
-    monkeypatch.setenv("SNN_SPARSE_BIG", "0")
+    monkeypatch.setenv("SNN_SPARSE_FAT", "0")
     a = _run_det(d, x, sparse=True)
-    monkeypatch.setenv("SNN_SPARSE_BIG", "3")
+    monkeypatch.delenv("SNN_SPARSE_FAT")
+    import ctypes as Ct
+    from snn_automotive_object_detection_amd import _lib
+    o12 = (Ct.c_int32 * 12)()
+    assert _lib.load().snn_debug_tile_shape(0, R, C * 49, Hd, T, 0, 6, o12) == 0 and o12[8] == 1 and o12[1] == fat, list(o12)     # the FAT plan is the default
     for _ in range(3):
         b = _run_det(d, x, sparse=True)
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
@@ -335,6 +322,6 @@ def test_big_shape_fc6_is_bit_identical(gpu_device, monkeypatch, R, C, Hd, K, T)
     d.spike_rates = True
     d(x)
     c_big = [c.clone() for c in d.last_spike_counts]
-    monkeypatch.setenv("SNN_SPARSE_BIG", "0")
+    monkeypatch.setenv("SNN_SPARSE_FAT", "0")
     d(x)
     assert all(torch.equal(p, q) for p, q in zip(c_big, d.last_spike_counts))

@@ -626,18 +626,25 @@ def main():
     bd = leg.kernel_breakdown(iters)
     conv_fl, rpn_fl, det_fl = algorithmic_flops(wl)
     # HBM bytes per launch of the dominant kernel: NOT measured by this run (PMC counters need rocprofv3 around the process) but
-    # read from the committed PMC passes of the same launch (separate --pmc FETCH_SIZE / WRITE_SIZE runs, tools/prof_round.sh)
-    traffic = traffic_source = None
-    if args.workload == "cityscapes" and not args.t_rpn and not dead_steps_kept():
-        for name in ("r4_traffic.json", "r3_traffic.json"):
-            try:
-                with open(os.path.join(ROOT, "profiles", name)) as f:
-                    traffic = json.load(f)[args.precision]["hbm_bytes_per_launch"]
-                traffic_source = ("profiles/%s: 2 x FETCH_SIZE (gfx950 tallies 128-B requests at 64 B; calibrated for this access pattern, tools/fetch_calib.hip) "
-                                  "+ WRITE_SIZE, separate rocprofv3 --pmc passes of this launch, committed - NOT collected by this run" % name)
-                break
-            except Exception:
-                pass
+    # read from the committed PMC passes of the same launch (separate --pmc FETCH_SIZE / WRITE_SIZE runs, tools/prof_round.sh ->
+    # tools/make_traffic_json.py), per workload
+    def committed_traffic(workload):
+        if args.t_rpn or dead_steps_kept():
+            return None, None, {}
+        try:
+            with open(os.path.join(ROOT, "profiles", "r5_traffic.json")) as f:
+                e = json.load(f)[workload][args.precision]
+            c = e["conv"]
+            src = ("profiles/r5_traffic.json <- %s: 2 x FETCH_SIZE (gfx950 tallies 128-B requests at 64 B; calibrated for this access pattern, tools/fetch_calib.hip) "
+                   "+ WRITE_SIZE, separate rocprofv3 --pmc passes of this launch on this workload, committed - NOT collected by this run" % e["source"])
+            prof = {"profiled_launch_ms": round(c["avg_us"] / 1e3, 4), "profiled_hbm_gb_per_s": c.get("hbm_gb_per_s"), "profiled_hbm_frac_of_8tb_s": c.get("hbm_frac_of_8tb_s"),
+                    "profiled_mfma_busy": c.get("mfma_busy"), "profiled_clock_ghz": c.get("clock_ghz_profiled"), "traffic_over_operands": c.get("traffic_over_operands")}
+            if "fc6" in e:
+                prof["fc6"] = {k: e["fc6"].get(k) for k in ("kernel", "avg_us", "hbm_bytes_per_launch", "hbm_gb_per_s", "mfma_busy", "clock_ghz_profiled", "traffic_over_operands")}
+            return c["hbm_bytes_per_launch"], src, prof
+        except Exception:
+            return None, None, {}
+    traffic, traffic_source, traffic_prof = committed_traffic(args.workload)
 
     out = {
         "metric": "images/sec (T_rpn=%d,T_det=%d, %dx%d b=%d) spiking RPN+RoI heads forward" % (
@@ -655,7 +662,7 @@ def main():
                    "global_batch": wl["batch"] * world, "parallelism": "dp%d" % world,
                    "exchange": ("all-gather of per-image detections [100x6] (%s, %d ranks)" % (
                        "RCCL" if exchange["backend"] == "nccl" else exchange["backend"], exchange["ranks"])) if world > 1 else "none"},
-        "roofline": leg.roofline(bd["rpn_conv3x3_lif"], traffic, traffic_source),
+        "roofline": {**leg.roofline(bd["rpn_conv3x3_lif"], traffic, traffic_source), **traffic_prof},
         "breakdown_ms": {k: round(v, 3) for k, v in bd.items()},
         "heads_tflops": round((rpn_fl + det_fl) / ((bd["rpn_head"] + bd["det_head"]) * 1e-3) / 1e12, 2),
         "exchange": exchange,
@@ -716,10 +723,11 @@ def main():
             l2.step = l2.step_local                              # (no collective: the other ranks are not in this leg)
             dt2 = timed_steps(l2, args.steps, max(1, args.warmup), fence_local)
             bd2 = l2.kernel_breakdown(iters)
+            t2, t2_src, t2_prof = committed_traffic(name)
             return {"workload": "%s (T_rpn=%d, T_det=%d, b=%d, K=%d%s)" % (w2["name"], w2["T_rpn"], w2["T_det"], w2["batch"], w2["K"],
                                                                     ", spike-rate outputs on" if w2["spike_rates"] else ""),
                     "value": round(w2["batch"] * args.steps / dt2, 3), "unit": "images/s",
-                    "ms_per_step": round(dt2 / args.steps * 1e3, 4), "roofline": l2.roofline(bd2["rpn_conv3x3_lif"]),
+                    "ms_per_step": round(dt2 / args.steps * 1e3, 4), "roofline": {**l2.roofline(bd2["rpn_conv3x3_lif"], t2, t2_src), **t2_prof},
                     "breakdown_ms": {k: round(v, 3) for k, v in bd2.items()},
                     "kernels_over_step": round((bd2["rpn_head"] + bd2["det_head"]) / (dt2 / args.steps * 1e3), 4)}
         for name in ("bdd", "stress"):

@@ -164,3 +164,49 @@ __device__ __forceinline__ void expand_word(uint32_t w, float* dst) {
         *reinterpret_cast<f32x4*>(dst + 4 * j) = v;
     }
 }
+
+// ---- compressed period planes of the structured-sparse launches (snn_sparse.h; written by k_compress_planes and, for the RPN head, by the
+// encoder launch itself: snn_encode.h) ----
+#define SP_A_ARR 4                                  // dword arrays per step: dense rows use two (the chunks' spike words), sparse rows all four:
+                                                    // occupancy bytes of the four 16-k blocks, index halves 0-1, index halves 2-3 of the primary
+                                                    // plane, occupancy bytes of the secondary plane (whose indices are the constant (2, 3))
+// nibble -> (two occupancy bits, two 2-bit positions, leftover bits).  bits p0 < p1: slots (1, p0), (1, p1); one bit p < 3: (1, p), (0, 3);
+// p == 3: (0, 0), (1, 3); none: (0, 0), (0, 3): index 0 < index 1 always (tools/sparse_probe.hip A4 ran exactly this encoding).
+__host__ __device__ inline uint32_t sp_nibble_code(uint32_t x) {
+    int p0 = -1, p1 = -1;
+    uint32_t left = 0;
+    for (int b = 0; b < 4; ++b)
+        if (x & (1u << b)) {
+            if (p0 < 0) p0 = b;
+            else if (p1 < 0) p1 = b;
+            else left |= 1u << b;
+        }
+    uint32_t occ, i0, i1;
+    if (p1 >= 0) { occ = 3; i0 = p0; i1 = p1; }
+    else if (p0 >= 0 && p0 < 3) { occ = 1; i0 = p0; i1 = 3; }
+    else if (p0 == 3) { occ = 2; i0 = 0; i1 = 3; }
+    else { occ = 0; i0 = 0; i1 = 3; }
+    return occ | ((i0 | (i1 << 2)) << 2) | (left << 6);       // bits 1:0 occupancy, 5:2 indices, 9:6 leftover
+}
+
+// byte (two nibbles) -> bits 3:0 occupancy, 11:4 indices, 15:12 leftover bits 2 / 3 of the two nibbles: one table look-up per 8 k
+__host__ __device__ inline uint16_t sp_byte_code(uint32_t b) {
+    const uint32_t c0 = sp_nibble_code(b & 15u), c1 = sp_nibble_code((b >> 4) & 15u);
+    return (uint16_t)((c0 & 3u) | ((c1 & 3u) << 2) | (((c0 >> 2) & 15u) << 4) | (((c1 >> 2) & 15u) << 8) | (((c0 >> 8) & 3u) << 12) | (((c1 >> 8) & 3u) << 14));
+}
+// the four dwords of a (row, 64 k) step from its two spike words: primary occupancy (2 bits per nibble), index halves (4 bits per nibble)
+// of word 0 / word 1, secondary occupancy.  `code` = sp_byte_code of 0 .. 255 (in LDS)
+__device__ __forceinline__ void sp_compress_pair(const uint32_t wd0, const uint32_t wd1, const uint16_t* code, uint32_t (&out)[4]) {
+    const uint32_t wd[2] = {wd0, wd1};
+    uint32_t occ = 0, idx[2] = {0, 0}, occ2 = 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const uint32_t c = code[(wd[h] >> (8 * b)) & 255u];
+            occ |= (c & 15u) << (16 * h + 4 * b);
+            idx[h] |= ((c >> 4) & 255u) << (8 * b);
+            occ2 |= (c >> 12) << (16 * h + 4 * b);
+        }
+    out[0] = occ; out[1] = idx[0]; out[2] = idx[1]; out[3] = occ2;
+}

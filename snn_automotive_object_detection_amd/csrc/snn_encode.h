@@ -16,11 +16,17 @@
 // Wpad > 0: the planes carry a one-position zero halo around every image (row (n, y, x) -> (n*(H+2) + y+1)*(W+2) + x+1,
 // W = Wpad), written here as well (by the threads of the border positions).  The conv kernels of the bf16x3 and mxfp6 families
 // read their 3x3 taps from such planes without any border logic.
+// cmp != nullptr (round 5; word-major period planes of the bf16x3 RPN head whose conv runs the structured-sparse launch, csrc/snn_sparse.h): the
+// planes e_n, n > nd, leave COMPRESSED - the four dwords per (row, 64 k) k_compress_planes would make of them (primary occupancy, index
+// halves, secondary occupancy), computed from the block's words while they are in LDS - and their raw words are not written at all:
+// one launch and a 32-MB write + 32-MB read less per head (k_compress_planes stays for the stage-level entry points and the linear layers).
 template <int EM>
 __device__ __forceinline__ void encode_block(const float* __restrict__ feat, int C, int HW, int Cw, int T, const NeuronP& p,
                                              const EncTh& eth, uint32_t* __restrict__ planes, size_t plane_stride, int n, int bx, int by,
-                                             int Wpad = 0, size_t wm_rows = 0) {
+                                             int Wpad = 0, size_t wm_rows = 0, uint32_t* __restrict__ cmp = nullptr, int nd = 0) {
     constexpr bool ZR = EM != ENC_GENERIC;
+    __shared__ uint16_t nib_code[256];
+    if (cmp) nib_code[threadIdx.x] = sp_byte_code(threadIdx.x);          // (256 threads; the block's barrier below comes before the first use)
     // dynamic: ENC_LDS_BYTES(T) - sized by the launch's T, not by SNN_MAX_STEPS (40 KB, four blocks per CU: the loads of 16 waves did not
     // cover the HBM latency; T = 8: 9 KB)
     extern __shared__ uint32_t wbuf[];                                     // [t][position][4 words + 1 pad]
@@ -63,7 +69,23 @@ __device__ __forceinline__ void encode_block(const float* __restrict__ feat, int
             row = ((size_t)n * (H + 2) + y + 1) * (Wpad + 2) + x + 1;
         }
         uint32_t* out = wm_rows ? planes + (size_t)scg * wm_rows + row : planes + row * Cw + scg;
-        for (int t = 0; t < T; ++t) out[(size_t)t * plane_stride] = wbuf[(t * ENC_PB + sp) * (ENC_WB + 1) + sw];
+        const int t_raw = cmp ? min(T, nd) : T;                // (compressed planes: no raw words)
+        for (int t = 0; t < t_raw; ++t) out[(size_t)t * plane_stride] = wbuf[(t * ENC_PB + sp) * (ENC_WB + 1) + sw];
+        // compressed planes: the two threads of a word pair (sw = 2 pair + par) take alternate planes; array j of (plane ts, pair w2) starts
+        // at cmp + ((ts Cw / 2 + w2) 4 + j) wm_rows (k_compress_planes' layout)
+        const int w2 = scg >> 1, par = sw & 1;
+        uint32_t* cout = cmp ? cmp + (size_t)w2 * SP_A_ARR * wm_rows + row : nullptr;
+        const size_t cmp_plane = (size_t)(Cw / 2) * SP_A_ARR * wm_rows;
+        if (cmp && 2 * w2 + 1 < Cw) {
+            for (int t = nd + par; t < T; t += 2) {
+                const uint32_t* wp = wbuf + (t * ENC_PB + sp) * (ENC_WB + 1) + (sw & ~1);
+                uint32_t c4[4];
+                sp_compress_pair(wp[0], wp[1], nib_code, c4);
+                uint32_t* o = cout + (size_t)(t - nd) * cmp_plane;
+#pragma unroll
+                for (int j = 0; j < SP_A_ARR; ++j) o[(size_t)j * wm_rows] = c4[j];
+            }
+        }
         if (Wpad) {
             // the zero halo, written by the threads that own the image's border positions (round 4: a separate k_zero_halo launch
             // did this before - 5-6 us of a 1.1-ms head at T_rpn = 4): a border position zeroes the padded rows / columns next to it,
@@ -72,7 +94,13 @@ __device__ __forceinline__ void encode_block(const float* __restrict__ feat, int
             const size_t rs = wm_rows ? 1 : (size_t)Cw;
             auto zero = [&](const long long dr) __attribute__((always_inline)) {
                 uint32_t* z = out + dr * (long long)rs;
-                for (int t = 0; t < T; ++t) z[(size_t)t * plane_stride] = 0u;
+                for (int t = 0; t < t_raw; ++t) z[(size_t)t * plane_stride] = 0u;
+                if (cmp && 2 * w2 + 1 < Cw) {                  // (an empty word pair compresses to occupancy 0 and the index pattern (0, 3) per nibble)
+                    for (int t = nd + par; t < T; t += 2) {
+                        uint32_t* o = cout + dr + (size_t)(t - nd) * cmp_plane;
+                        o[0] = 0u; o[wm_rows] = 0xCCCCCCCCu; o[2 * wm_rows] = 0xCCCCCCCCu; o[3 * wm_rows] = 0u;
+                    }
+                }
             };
             const bool top = y == 0, bot = y == H - 1, lef = x == 0, rig = x == Wpad - 1;
             if (top) zero(-W2);
@@ -105,12 +133,13 @@ struct EncLevels {
 };
 template <int EM>
 __global__ __launch_bounds__(256) void k_encode_levels(const EncLevels lv, int C, int Cw, int T, NeuronP p, const EncTh eth,
-                                                       uint32_t* __restrict__ planes, size_t plane_stride, size_t wm_rows) {
+                                                       uint32_t* __restrict__ planes, size_t plane_stride, size_t wm_rows,
+                                                       uint32_t* __restrict__ cmp, int nd) {
     int l = 0;
     while (l + 1 < lv.n_levels && (int)blockIdx.x >= lv.blk_base[l + 1]) ++l;
     const int local = blockIdx.x - lv.blk_base[l];
     encode_block<EM>(lv.feat[l], C, lv.HW[l], Cw, T, p, eth, planes + (size_t)lv.pos_base[l] * (wm_rows ? 1 : Cw), plane_stride,
-                     local / lv.bpi[l], local % lv.bpi[l], blockIdx.y, lv.Wpad[l], wm_rows);
+                     local / lv.bpi[l], local % lv.bpi[l], blockIdx.y, lv.Wpad[l], wm_rows, cmp ? cmp + lv.pos_base[l] : nullptr, nd);
 }
 
 // K1b: encoder on row-major x[R][D] -> bit-planes [T][R][Dw]; a wave covers 64 consecutive reduction indices per
@@ -245,6 +274,86 @@ __global__ __launch_bounds__(256) void k_encode_rows_wm(const float* __restrict_
             for (int b = 31; b >= 0; --b) enc_step_word<ZR>(xv[b], v[b], p, word);          // bit 31 first
         }
         dst[(size_t)t * plane_stride] = word;
+    }
+}
+
+// K1d (round 5): the detector's encoder for the structured-sparse fc6 in ONE launch - period planes by thresholds, written straight in
+// fc6's reduction order k' = bin * C + channel (what k_permute_planes made of the reference-order planes) and, for the planes e_3 ..,
+// COMPRESSED (what k_compress_planes made of those): three launches and two HBM round trips of the planes become one.
+// x [R][C * S] fp32 in the reference's flatten order k = c * S + bin (faster_rcnn.py:473).  Block = ENCP_RB RoIs x 64 channels (two channel
+// blocks cb = 2 cp, 2 cp + 1: a compressed step is a pair of words (bin, cb), (bin, cb + 1)).  Encode: a wave takes (RoI, channel block)
+// tasks, lane = bin (S of 64 lanes), the lane's 32 channels are 32 loads at stride S floats - every load instruction reads one S-float run of
+// the RoI's row - and the T words go to LDS [t][cb][RoI][bin] (odd pitch S: conflict-free both ways).  Store: thread = (RoI, item): the dense planes' words as they are, a sparse
+// plane's pair through sp_compress_pair - runs of ENCP_RB consecutive RoIs of one word plane / array.
+#define ENCP_LDS_WORDS 19200                        // planes per pass through LDS: 19200 / (2 S RB) - 12 at RB = 16, 24 at RB = 8 (75 KB); longer windows take more passes
+template <int S, int RB>
+__global__ __launch_bounds__(256) void k_encode_rows_perm(const float* __restrict__ x, int R, int C, int T, int nd, const EncTh eth,
+                                                          uint32_t* __restrict__ planes, uint32_t* __restrict__ cmp) {
+    static_assert(S <= 64, "one lane per bin");
+    extern __shared__ uint32_t pw[];                          // [min(T, TMAX)][2][RB][S]
+    constexpr int TMAX = ENCP_LDS_WORDS / (2 * S * RB);
+    __shared__ uint16_t code[256];
+    code[threadIdx.x] = sp_byte_code(threadIdx.x);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r0 = blockIdx.x * RB, cp = blockIdx.y, cbn = C / 32, D = C * S, Dw = D / 32;
+    const size_t plane_words = (size_t)Dw * R, cmp_plane = (size_t)(Dw / 2) * SP_A_ARR * R;
+    for (int t0 = 0; t0 < T; t0 += TMAX) {
+        const int tn = min(TMAX, T - t0);
+        if (t0) __syncthreads();
+        // ---- encode: tasks (RoI, cb) over the waves; the next task's 32 loads are in flight while this one's words are formed
+        auto load_task = [&](float (&xv)[32], const int task) __attribute__((always_inline)) {
+            const int row = r0 + (task >> 1), cb = task & 1;
+            const float* src = x + (size_t)min(row, R - 1) * D + (size_t)((2 * cp + cb) * 32) * S + min(lane, S - 1);
+#pragma unroll
+            for (int j = 0; j < 32; ++j) xv[j] = src[j * S];
+        };
+        auto encode_task = [&](const float (&xv)[32], const int task) __attribute__((always_inline)) {
+            const int rl = task >> 1, cb = task & 1;
+            if (lane < S) {
+                uint32_t prev = 0;
+                for (int t = 0; t < t0 + tn; ++t) {          // (cumulative words from step 0: a later pass re-derives what it needs)
+                    uint32_t word = 0;
+                    const float th = eth.th[t];
+#pragma unroll
+                    for (int j = 31; j >= 0; --j) enc_quant_word(xv[j], th, word);
+                    const uint32_t cum = word;
+                    word = cum & ~prev;
+                    prev = cum;
+                    if (t >= t0) pw[(((t - t0) * 2 + cb) * RB + rl) * S + lane] = word;
+                }
+            }
+        };
+        float xa[32], xb[32];
+        load_task(xa, wave);
+#pragma unroll 1
+        for (int task = wave; task < 2 * RB; task += 8) {     // (2 RB / 4 tasks per wave: even)
+            load_task(xb, task + 4);
+            encode_task(xa, task);
+            if (task + 8 < 2 * RB) load_task(xa, task + 8);
+            encode_task(xb, task + 4);
+        }
+        __syncthreads();
+        // ---- store: thread = (RoI tid % RB, item tid / RB)
+        const int rl = tid & (RB - 1), row = r0 + rl;                    // (RB = 8 or 16)
+        if (row < R) {
+            for (int t = t0; t < t0 + tn; ++t) {
+                const uint32_t* pt = pw + (size_t)(t - t0) * 2 * S * RB;
+                if (t < nd || !cmp) {                         // raw words (bin, cb) -> word plane bin * cbn + 2 cp + cb
+                    for (int it = tid / RB; it < 2 * S; it += 256 / RB) {
+                        const int cb = it / S, bin = it % S;
+                        planes[(size_t)t * plane_words + (size_t)(bin * cbn + 2 * cp + cb) * R + row] = pt[(cb * RB + rl) * S + bin];
+                    }
+                } else {                                      // compressed step (bin, cp): pair index (bin * cbn + 2 cp) / 2
+                    for (int bin = tid / RB; bin < S; bin += 256 / RB) {
+                        uint32_t c4[4];
+                        sp_compress_pair(pt[rl * S + bin], pt[(RB + rl) * S + bin], code, c4);
+                        uint32_t* o = cmp + (size_t)(t - nd) * cmp_plane + (size_t)(bin * (cbn / 2) + cp) * SP_A_ARR * R + row;
+#pragma unroll
+                        for (int j = 0; j < SP_A_ARR; ++j) o[(size_t)j * R] = c4[j];
+                    }
+                }
+            }
+        }
     }
 }
 

@@ -160,6 +160,8 @@ struct Knobs {
                              //                       skips the steps whose currents cannot reach an output, lif_windows)
     bool sparse;             // SNN_SPARSE=0          RPN conv: every period plane on the dense matrix-core instruction (default: planes e_3.. on the
                              //                       structured-sparse one, snn_sparse.h)
+    int encp_rb;             // SNN_ENCP_RB=8|16      RoIs per block of k_encode_rows_perm (A/B; default: 16 where the window fits one pass through LDS)
+    bool enc_fold;           // SNN_ENC_FOLD=0        RPN head: k_compress_planes as its own launch again instead of inside the encoder launch (bit-identical planes)
     bool sparse_fat;         // SNN_SPARSE_FAT=0      linear layers (fc6) on the 8-wave shape of k_gemm_lif_sparse instead of the FAT one (four waves of up to 256
                              //                       registers, twice the M-tile slots per wave: the default where its loop instances exist; bit-identical)
     int planes;              // SNN_PLANES=rm|wm      internal spike planes of the bf16x3 heads: all row-major [T][row][word] / all
@@ -183,6 +185,8 @@ static Knobs load_knobs() {
     k.li_heads = !e ? 0 : !strcmp(e, "valu") ? 1 : !strcmp(e, "mfma") ? 2 : !strcmp(e, "ksplit") ? 3 : 4;
     k.debug_occ = getenv("SNN_DEBUG_OCC") != nullptr;
     k.sparse_fat = !((e = getenv("SNN_SPARSE_FAT")) && e[0] == '0');
+    k.enc_fold = !((e = getenv("SNN_ENC_FOLD")) && e[0] == '0');
+    k.encp_rb = (e = getenv("SNN_ENCP_RB")) ? atoi(e) : 0;
     e = getenv("SNN_PLANES");
     k.planes = !e ? 0 : !strcmp(e, "rm") ? 1 : !strcmp(e, "wm") ? 2 : 0;
     k.bf16x3_xcd = !((e = getenv("SNN_BF16X3_XCD")) && e[0] == '0');
@@ -1009,7 +1013,10 @@ static bool sparse_shape(bool conv, long long M, int Kw, int Kc, int Np, int T, 
 // convolution; !conv: a linear layer on word-major period planes - the detector's fc6).  `side` = sparse_side_bytes() of scratch.
 // Returns 1 if the launches were enqueued (the layer is done), 0 if this configuration takes the dense launch, negative on error.
 // (Every eligibility check comes before the first launch: a configuration that ends on the dense kernel enqueues nothing here.)
-static int gemm3_lif_sparse(const Gemm3Args& a, bool conv, void* side, size_t side_bytes, hipStream_t s) {
+// mode: SPARSE_RUN = compress + launch; SPARSE_QUERY = would it run? (nothing is enqueued); SPARSE_RUN_COMPRESSED = the caller's encoder has
+// already written the compressed planes into `side` (RPN head: encode_block, snn_encode.h)
+enum { SPARSE_RUN = 0, SPARSE_QUERY = 1, SPARSE_RUN_COMPRESSED = 2 };
+static int gemm3_lif_sparse(const Gemm3Args& a, bool conv, void* side, size_t side_bytes, hipStream_t s, int mode = SPARSE_RUN) {
     SparseShape sh;
     const int Kw = conv ? a.Cw : a.Kc;                        // plane words per row
     if (!side || !a.wm || !a.periods || a.t0 != 0 || a.p.v_leak != 0.0f || (float)(a.p.v_leak - a.p.v_th) > 0.0f || (!conv && !a.out_wm) ||
@@ -1022,15 +1029,18 @@ static int gemm3_lif_sparse(const Gemm3Args& a, bool conv, void* side, size_t si
     const unsigned long long cmp_bytes = (unsigned long long)(a.Tc - sp.nd) * (Kw / 2) * SP_A_ARR * Pe * 4;
     // (the kernel addresses both the raw and the compressed planes by 32-bit offsets from the raw planes)
     if ((const char*)cmp < (const char*)a.A || (unsigned long long)((const char*)cmp - (const char*)a.A) + cmp_bytes > 0xffffffffULL) return 0;
+    if (mode == SPARSE_QUERY) return 1;
     const void* kern = sp.fat ? (const void*)k_gemm_lif_sparse<false, 2, true>
                               : conv ? (const void*)k_gemm_lif_sparse<true, 1> : sp.wn == 2 ? (const void*)k_gemm_lif_sparse<false, 2> : (const void*)k_gemm_lif_sparse<false, 1>;
     hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, sh.lds);
     if (e != hipSuccess) return fail(-3, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-    CompressArgs ca;
-    memset(&ca, 0, sizeof(ca));
-    ca.enc = a.A; ca.cmp = cmp; ca.Pe = (unsigned)Pe; ca.Cw = Kw; ca.nd = sp.nd;
-    hipLaunchKernelGGL(k_compress_planes, dim3(cdiv(Pe, 256), Kw / 2, a.Tc - sp.nd), dim3(256), 0, s, ca);
-    SNN_CHECK_LAUNCH("k_compress_planes");
+    if (mode != SPARSE_RUN_COMPRESSED) {
+        CompressArgs ca;
+        memset(&ca, 0, sizeof(ca));
+        ca.enc = a.A; ca.cmp = cmp; ca.Pe = (unsigned)Pe; ca.Cw = Kw; ca.nd = sp.nd;
+        hipLaunchKernelGGL(k_compress_planes, dim3(cdiv(Pe, 256), Kw / 2, a.Tc - sp.nd), dim3(256), 0, s, ca);
+        SNN_CHECK_LAUNCH("k_compress_planes");
+    }
     SparseConvArgs sa;
     memset(&sa, 0, sizeof(sa));
     sa.enc = a.A; sa.cmp = cmp; sa.wpk = a.wpk; sa.spk = a.spk;
@@ -1105,7 +1115,10 @@ int snn_debug_tile_shape(int conv, long long units, int k_in, int n_cols, int nu
 static int conv3x3_lif_bf16x3_impl(const uint32_t* enc, size_t enc_stride, const snn_rpn_level* lv, int n_levels, int C_in,
                                    int C_out, int T, const snn_params* p, const uint16_t* w_packed, uint32_t* spk,
                                    size_t spk_stride, unsigned long long* counts, int max_n, snn_stream_t s, bool wm = false,
-                                   bool* out_split = nullptr, bool periods = false, void* sparse_side = nullptr, size_t sparse_bytes = 0) {
+                                   bool* out_split = nullptr, bool periods = false, void* sparse_side = nullptr, size_t sparse_bytes = 0,
+                                   int sparse_mode = SPARSE_RUN) {
+    // sparse_mode SPARSE_QUERY: returns 1 if this call would enqueue the structured-sparse launch pair, 0 if not - and enqueues nothing;
+    // SPARSE_RUN_COMPRESSED: the encoder wrote the planes e_3 .. compressed (and not raw): anything but the sparse launch is an error
     // out_split (in: wanted, out: done): spike planes in blocks of four words (Gemm3Args.out_split; T-in-tile kernels only)
     const bool want_split = out_split && *out_split;
     if (out_split) *out_split = false;
@@ -1131,6 +1144,7 @@ static int conv3x3_lif_bf16x3_impl(const uint32_t* enc, size_t enc_stride, const
         tl = g3_pick_tile(wn, [&](int rows) { return g3_tile_ok(Tc, rows) ? (long long)cdiv(P, rows / Tc) * a.n_blocks : 0ll; });
     }
     if (!tl.mt) {                                     // register-fused fallback: counts from the planes afterwards
+        if (sparse_mode == SPARSE_QUERY) return 0;
         if (periods) return fail(-4, "snn_conv3x3_lif_bf16x3: period planes need the T-in-tile kernel (T=%d does not fit a row tile)", T);
         a.n_blocks = cdiv(a.Np, G3_BN(2));
         rc = launch_gemm3(G3_CONV_LIF_REG, 4, 2, a, (hipStream_t)s);
@@ -1142,10 +1156,12 @@ static int conv3x3_lif_bf16x3_impl(const uint32_t* enc, size_t enc_stride, const
     if (want_split && a.Np % 128 == 0) { a.out_split = 1; *out_split = true; }
     if (periods && set_periods(a, "snn_conv3x3_lif_bf16x3")) return -1;
     // round 4: the sparse period planes on the structured-sparse matrix-core instruction (snn_sparse.h) where the configuration allows
-    rc = gemm3_lif_sparse(a, true, sparse_side, sparse_bytes, (hipStream_t)s);
+    rc = gemm3_lif_sparse(a, true, sparse_side, sparse_bytes, (hipStream_t)s, sparse_mode);
+    if (sparse_mode == SPARSE_QUERY) return rc > 0 ? 1 : 0;
     if (rc < 0) return rc;
     g_last_conv_sparse = rc;
     if (rc == 1) return 0;
+    if (sparse_mode == SPARSE_RUN_COMPRESSED) return fail(-3, "snn_conv3x3_lif_bf16x3: the encoder wrote compressed planes but the conv takes the dense launch (internal)");
     return launch_gemm3(G3_CONV_LIF_TILE, tl.mt, wn, a, (hipStream_t)s);
 }
 
@@ -1622,6 +1638,21 @@ int snn_rpn_head_forward_stages(const snn_rpn_level* lv, int n_levels, int C, in
     uint32_t* enc = (uint32_t*)ws;
     uint32_t* spk = (uint32_t*)((char*)ws + o_spk);
     hipStream_t s = (hipStream_t)stream;
+    // round 5: where the conv will run the structured-sparse launch, the encoder launch writes the planes e_3 .. compressed itself (no
+    // k_compress_planes launch, no raw words of those planes).  Asked of the conv's own launcher (nothing is enqueued by the query), so that
+    // the two stages cannot disagree - also for a stage-by-stage caller
+    bool fold = false;
+    {
+        NeuronP npq = make_p(p, p->v_th_enc);
+        if (per) npq.v_fire = ENC_FIRED;
+        const EncTh* ethq;
+        if (knobs().enc_fold && prec_family(p) == SNN_PRECISION_BF16X3 && per && wm_rows && enc_mode(npq, &ethq) == ENC_QUANT) {
+            bool split_q = split;
+            fold = conv3x3_lif_bf16x3_impl(enc, enc_stride, lv, n_levels, C, C, T, p, (const uint16_t*)w_shared_packed, spk, stride, spike_counts, max_n,
+                                           stream, true, &split_q, per, (char*)ws + o_cur, o_cnt - o_cur, SPARSE_QUERY) == 1;
+        }
+    }
+    uint32_t* enc_cmp = fold ? (uint32_t*)((char*)ws + o_cur) : nullptr;
     if (stage_mask & SNN_STAGE_ENCODE) {                        // rpn.py:101, all levels in one launch
         EncLevels el;
         memset(&el, 0, sizeof(el));
@@ -1641,9 +1672,9 @@ int snn_rpn_head_forward_stages(const snn_rpn_level* lv, int n_levels, int C, in
         const EncTh* eth;
         const int em = enc_mode(np, &eth);
         const dim3 ge(blocks, cdiv(Cw, ENC_WB));
-        if (em == ENC_QUANT) hipLaunchKernelGGL(k_encode_levels<ENC_QUANT>, ge, dim3(256), ENC_LDS_BYTES(Tc), s, el, C, Cw, Tc, np, *eth, enc, enc_stride, wm_rows);
-        else if (em == ENC_ZR) hipLaunchKernelGGL(k_encode_levels<ENC_ZR>, ge, dim3(256), ENC_LDS_BYTES(Tc), s, el, C, Cw, Tc, np, *eth, enc, enc_stride, wm_rows);
-        else hipLaunchKernelGGL(k_encode_levels<ENC_GENERIC>, ge, dim3(256), ENC_LDS_BYTES(Tc), s, el, C, Cw, Tc, np, *eth, enc, enc_stride, wm_rows);
+        if (em == ENC_QUANT) hipLaunchKernelGGL(k_encode_levels<ENC_QUANT>, ge, dim3(256), ENC_LDS_BYTES(Tc), s, el, C, Cw, Tc, np, *eth, enc, enc_stride, wm_rows, enc_cmp, 2);
+        else if (em == ENC_ZR) hipLaunchKernelGGL(k_encode_levels<ENC_ZR>, ge, dim3(256), ENC_LDS_BYTES(Tc), s, el, C, Cw, Tc, np, *eth, enc, enc_stride, wm_rows, (uint32_t*)nullptr, 0);
+        else hipLaunchKernelGGL(k_encode_levels<ENC_GENERIC>, ge, dim3(256), ENC_LDS_BYTES(Tc), s, el, C, Cw, Tc, np, *eth, enc, enc_stride, wm_rows, (uint32_t*)nullptr, 0);
         SNN_CHECK_LAUNCH("k_encode_levels");
     }
     if (stage_mask & SNN_STAGE_CONV_LIF) {
@@ -1667,7 +1698,7 @@ int snn_rpn_head_forward_stages(const snn_rpn_level* lv, int n_levels, int C, in
                                                spike_counts, max_n, stream)
                          : conv3x3_lif_bf16x3_impl(enc, enc_stride, lv, n_levels, C, C, T, p, (const uint16_t*)w_shared_packed,
                                                    spk, stride, spike_counts, max_n, stream, wm_rows != 0, &split, per,
-                                                   (char*)ws + o_cur, o_cnt - o_cur);
+                                                   (char*)ws + o_cur, o_cnt - o_cur, fold ? SPARSE_RUN_COMPRESSED : SPARSE_RUN);
             if (rc) return rc;
         }
     }
@@ -1962,7 +1993,9 @@ static bool det_planes_wm(const snn_params* p, const DetWindows& w) { return det
 static int det_head_from_planes(int R, int D, int Hd, int K, int K4, int T, const snn_params* p, const void* w6_packed,
                                 const void* w7_packed, const float* w_heads_packed, float* out_cls, float* out_bbox,
                                 uint32_t* spk6_count, uint32_t* spk7_count, float* sum_cls, float* sum_bbox, void* ws,
-                                bool enc_wm, const DetWindows& win, bool enc_periods, snn_stream_t stream, int k_inner = 0) {
+                                bool enc_wm, const DetWindows& win, bool enc_periods, snn_stream_t stream, int k_inner = 0, bool folded = false) {
+    // folded (round 5): the encoder launch already wrote the planes in fc6's permuted order, e_3 .. compressed (k_encode_rows_perm): no
+    // k_permute_planes, no k_compress_planes - fc6 must then run the structured-sparse launch (it was asked beforehand)
     size_t o_enc, o_cur, o_s6, o_s7, need;
     det_ws_layout(R, D, Hd, T, &o_enc, &o_cur, &o_s6, &o_s7, &need);
     hipStream_t s = (hipStream_t)stream;
@@ -1973,7 +2006,7 @@ static int det_head_from_planes(int R, int D, int Hd, int K, int K4, int T, cons
     const int Hw = cdiv(Hd, 32), Hp = Hw * 32;
     g_last_det_planes[0] = o_s6; g_last_det_planes[1] = o_s7; g_last_det_planes[2] = enc_wm ? 1 : 0;
     int rc;
-    if (k_inner > 1) {
+    if (k_inner > 1 && !folded) {
         // fc6's weights were packed in the permuted reduction order k' = s * C + c (snn_pack_linear_weight_bf16x3_perm): bring the
         // encoder's planes into the same order (snn_sparse.h: k_permute_planes).  Word-major planes of the fused bf16x3 layers only.
         const int C = D / k_inner;
@@ -2015,8 +2048,9 @@ static int det_head_from_planes(int R, int D, int Hd, int K, int K4, int T, cons
         const int wn = g3_wn();
         // round 4: fc6's sparse period planes e_3 .. on the structured-sparse matrix-core instruction (snn_sparse.h); its side buffers
         // live in the currents region of the workspace, which the fused layers never write
-        rc = gemm3_lif_sparse(a6, false, (char*)ws + o_cur, o_s6 - o_cur, s);
+        rc = gemm3_lif_sparse(a6, false, (char*)ws + o_cur, o_s6 - o_cur, s, folded ? SPARSE_RUN_COMPRESSED : SPARSE_RUN);
         if (rc < 0) return rc;
+        if (folded && rc != 1) return fail(-3, "snn_det_head_forward: the encoder wrote compressed planes but fc6 takes the dense launch (internal)");
         g_last_fc_sparse = rc;
         if (rc == 0 && (rc = launch_gemm3(G3_FC_LIF_TILE, t6.mt, wn, a6, s))) return rc;
         if ((rc = launch_gemm3(G3_FC_LIF_TILE, t7.mt, wn, a7, s))) return rc;
@@ -2061,11 +2095,43 @@ int snn_det_head_forward_k(const float* x, int R, int D, int Hd, int K, int K4, 
     const bool wm = det_planes_wm(p, win) && encode_rows_wm_ok(x, D);
     const bool per = knobs().periods && periods_possible(p) && det_b3_tiles(p, win);      // fc6 on the encoder's period planes (snn_common.h)
     if (w6_inner > 1 && !wm) return fail(-4, "snn_det_head_forward: permuted fc6 weights need the word-major fused bf16x3 path (D %% 32 == 0, x 16-byte aligned)");
-    uint32_t* enc_dst = (uint32_t*)((char*)ws + (w6_inner > 1 ? det_ws_perm_offset(R, D, Hd, T) : o_enc));
-    int rc = encode_rows_impl(x, R, D, win.enc_steps, p, enc_dst, (size_t)R * cdiv(D, 32), wm, stream, per);
-    if (rc) return rc;
+    // round 5: where fc6 will run the structured-sparse launch on bin-major planes, ONE encoder launch writes them - permuted, e_3 .. compressed
+    // (k_encode_rows_perm) - instead of encoder + k_permute_planes + k_compress_planes.  fc6's own launcher is asked (nothing is enqueued).
+    bool fold = false;
+    const EncTh* eth_f = nullptr;
+    if (knobs().enc_fold && w6_inner == 49 && wm && per && D % (49 * 64) == 0) {
+        NeuronP npq = make_p(p, p->v_th_enc);
+        npq.v_fire = ENC_FIRED;
+        if (enc_zero_rest(npq) && enc_mode(npq, &eth_f) == ENC_QUANT) {
+            Gemm3Args a6;
+            G3Tile t6;
+            const int Hw = cdiv(Hd, 32);
+            if (spike_gemm_lif_bf16x3_args((const uint32_t*)((char*)ws + o_enc), T, R, D, Hd, p, (const uint16_t*)w6_packed, (uint32_t*)((char*)ws + o_s6), (size_t)R * Hw,
+                                           spk6_count, true, true, &win.fc6, true, &a6, &t6) == 0)
+                fold = gemm3_lif_sparse(a6, false, (char*)ws + o_cur, o_s6 - o_cur, (hipStream_t)stream, SPARSE_QUERY) == 1;
+        }
+    }
+    int rc;
+    if (fold) {
+        const int Te = win.enc_steps, C = D / 49;
+        const int rb = knobs().encp_rb ? (knobs().encp_rb == 16 ? 16 : 8) : (Te <= ENCP_LDS_WORDS / (2 * 49 * 16) ? 16 : 8);     // (one pass through LDS where 16 RoIs per block allow it)
+        const size_t lds = (size_t)min(Te, ENCP_LDS_WORDS / (2 * 49 * rb)) * 2 * 49 * rb * 4;
+        const void* kern = rb == 16 ? (const void*)k_encode_rows_perm<49, 16> : (const void*)k_encode_rows_perm<49, 8>;
+        hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail(-3, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+        uint32_t* planes_f = (uint32_t*)((char*)ws + o_enc);
+        uint32_t* cmp_f = (uint32_t*)((char*)ws + o_cur);
+        const int nd_f = 2;
+        void* kargs[] = {(void*)&x, (void*)&R, (void*)&C, (void*)&Te, (void*)&nd_f, (void*)eth_f, (void*)&planes_f, (void*)&cmp_f};
+        e = hipLaunchKernel(kern, dim3(cdiv(R, rb), C / 64), dim3(256), kargs, lds, (hipStream_t)stream);
+        if (e != hipSuccess) return fail(-3, "k_encode_rows_perm launch failed: %s", hipGetErrorString(e));
+        SNN_CHECK_LAUNCH("k_encode_rows_perm");
+    } else {
+        uint32_t* enc_dst = (uint32_t*)((char*)ws + (w6_inner > 1 ? det_ws_perm_offset(R, D, Hd, T) : o_enc));
+        if ((rc = encode_rows_impl(x, R, D, win.enc_steps, p, enc_dst, (size_t)R * cdiv(D, 32), wm, stream, per))) return rc;
+    }
     return det_head_from_planes(R, D, Hd, K, K4, T, p, w6_packed, w7_packed, w_heads_packed, out_cls, out_bbox,
-                                spk6_count, spk7_count, sum_cls, sum_bbox, ws, wm, win, per, stream, w6_inner);
+                                spk6_count, spk7_count, sum_cls, sum_bbox, ws, wm, win, per, stream, w6_inner, fold);
 }
 
 int snn_det_head_forward_roialign(const snn_roi_level* levels_host, int n_levels, int C, const float* rois,

@@ -34,9 +34,7 @@ typedef __bf16 bfv16 __attribute__((ext_vector_type(16)));
 #define SP_MT2_FAT 12                               // ... per row-wave of the FAT shape (linear layers): 2 x 2 waves of up to 256 registers, 32 columns per wave
 #define SP_MTMAX 12
 #define SP_ROWS (8 * SP_MT * 16)                    // physical tile rows (512; 4 x 6 x 16 = 384 on the 4 x 2 grid)
-#define SP_A_ARR 4                                  // dword arrays per step: dense rows use two (the chunks' spike words), sparse rows all four:
-                                                    // occupancy bytes of the four 16-k blocks, index halves 0-1, index halves 2-3 of the primary
-                                                    // plane, occupancy bytes of the secondary plane (whose indices are the constant (2, 3))
+// (SP_A_ARR and sp_nibble_code live in snn_common.h: the RPN encoder writes the same compressed layout)
 #define SP_A_BYTES (SP_A_ARR * SP_ROWS * 4)
 #define SP_B_BYTES (2 * 3 * 64 * G3_ROWB)           // two chunks x three weight planes x 64 columns
 #define SP_SLOT (SP_A_BYTES + SP_B_BYTES)           // one 64-k step: 32 KB
@@ -72,25 +70,6 @@ struct SparseConvArgs {
     NeuronP p;
     ConvLevelDev lv[SNN_MAX_LEVELS];
 };
-
-// nibble -> (two occupancy bits, two 2-bit positions, leftover bits).  bits p0 < p1: slots (1, p0), (1, p1); one bit p < 3: (1, p), (0, 3);
-// p == 3: (0, 0), (1, 3); none: (0, 0), (0, 3): index 0 < index 1 always (tools/sparse_probe.hip A4 ran exactly this encoding).
-__host__ __device__ inline uint32_t sp_nibble_code(uint32_t x) {
-    int p0 = -1, p1 = -1;
-    uint32_t left = 0;
-    for (int b = 0; b < 4; ++b)
-        if (x & (1u << b)) {
-            if (p0 < 0) p0 = b;
-            else if (p1 < 0) p1 = b;
-            else left |= 1u << b;
-        }
-    uint32_t occ, i0, i1;
-    if (p1 >= 0) { occ = 3; i0 = p0; i1 = p1; }
-    else if (p0 >= 0 && p0 < 3) { occ = 1; i0 = p0; i1 = 3; }
-    else if (p0 == 3) { occ = 2; i0 = 0; i1 = 3; }
-    else { occ = 0; i0 = 0; i1 = 3; }
-    return occ | ((i0 | (i1 << 2)) << 2) | (left << 6);       // bits 1:0 occupancy, 5:2 indices, 9:6 leftover
-}
 
 // Reduction-index permutation of a linear layer's period planes (the detector's fc6).  The flattened RoI features run (channel, bin):
 // k = c * S + s, so four consecutive k are four neighbouring BINS of one channel - strongly correlated values, hence often the same
@@ -179,27 +158,18 @@ struct CompressArgs {
 // fourth spike of a nibble: zero almost everywhere).  A third spike can only sit at bit 2 or 3 of its nibble and a fourth at bit 3, so
 // the secondary slots are (value = leftover bit 2, position 2), (value = leftover bit 3, position 3): constant indices, nothing stored.
 __global__ __launch_bounds__(256) void k_compress_planes(const CompressArgs a) {
-    __shared__ uint16_t code[16];
-    if (threadIdx.x < 16) code[threadIdx.x] = (uint16_t)sp_nibble_code(threadIdx.x);
+    __shared__ uint16_t code[256];
+    code[threadIdx.x] = sp_byte_code(threadIdx.x);
     __syncthreads();
     const unsigned int row = blockIdx.x * 256 + threadIdx.x;
     if (row >= a.Pe) return;
     const int w2 = blockIdx.y, ts = blockIdx.z, t = a.nd + ts;
-    const uint32_t wd[2] = {a.enc[((size_t)t * a.Cw + 2 * w2) * a.Pe + row], a.enc[((size_t)t * a.Cw + 2 * w2 + 1) * a.Pe + row]};
-    uint32_t occ = 0, idx[2] = {0, 0}, occ2 = 0;
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int nb = 0; nb < 8; ++nb) {
-            const uint32_t c = code[(wd[h] >> (4 * nb)) & 15u];
-            occ |= (c & 3u) << (16 * h + 2 * nb);
-            idx[h] |= ((c >> 2) & 15u) << (4 * nb);
-            occ2 |= ((c >> 8) & 3u) << (16 * h + 2 * nb);           // leftover bits 2 and 3 of the nibble
-        }
+    uint32_t c4[4];
+    sp_compress_pair(a.enc[((size_t)t * a.Cw + 2 * w2) * a.Pe + row], a.enc[((size_t)t * a.Cw + 2 * w2 + 1) * a.Pe + row], code, c4);
     uint32_t* out = a.cmp + ((size_t)ts * (a.Cw / 2) + w2) * SP_A_ARR * a.Pe + row;
     const size_t Pe = a.Pe;
-    out[0] = occ; out[Pe] = idx[0]; out[2 * Pe] = idx[1];
-    out[3 * Pe] = occ2;
+    out[0] = c4[0]; out[Pe] = c4[1]; out[2 * Pe] = c4[2];
+    out[3 * Pe] = c4[3];
 }
 
 // LIF over T steps of NP independent neurons per lane from the period sums in the LDS tile image: the straight-line form of

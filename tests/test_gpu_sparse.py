@@ -325,3 +325,73 @@ def test_fat_shape_fc6_is_bit_identical(gpu_device, monkeypatch, R, C, Hd, K, T,
     monkeypatch.setenv("SNN_SPARSE_FAT", "0")
     d(x)
     assert all(torch.equal(p, q) for p, q in zip(c_big, d.last_spike_counts))
+
+
+# ---- plane compression inside the RPN encoder launch (round 5): the same compressed planes as the separate k_compress_planes pass ----------
+@pytest.mark.parametrize("C,T,shapes", [(256, 8, [(37, 53), (19, 27), (7, 9), (1, 3)]), (64, 5, [(23, 31), (6, 5)]), (128, 16, [(20, 30), (5, 7), (1, 1)]),
+                                        (256, 12, [(64, 64)]), (512, 8, [(9, 11), (3, 5)])])
+def test_encoder_fold_writes_the_same_compressed_planes(gpu_device, monkeypatch, C, T, shapes):
+    from snn_automotive_object_detection_amd import _lib, ops
+    m = _head(gpu_device, C, T, 80 + T)
+    g = torch.Generator().manual_seed(80 + T)
+    feats = [(torch.randn(2, C, h, w, generator=g) * 1.7).to(gpu_device) for h, w in shapes]
+    al = lambda x: (x + 255) // 256 * 256
+    Cw, Pe = C // 32, sum(2 * (h + 2) * (w + 2) for h, w in shapes)
+    o_cur = 2 * al(T * Pe * Cw * 4)                             # rpn_ws_layout: encoder planes, spike planes, then the sparse conv's side buffers
+    cmp_bytes = (T - 1 - 2) * (Cw // 2) * 4 * Pe * 4
+
+    def run():
+        ops._WS.get(gpu_device, 1)[o_cur: o_cur + cmp_bytes].fill_(0x5a) if ops._WS.get(gpu_device, 1).numel() >= o_cur + cmp_bytes else None
+        out = _run(m, feats, sparse=True)
+        return out, ops._WS.get(gpu_device, 1)[o_cur: o_cur + cmp_bytes].clone()
+    run()                                                       # (sizes the workspace)
+    monkeypatch.setenv("SNN_ENC_FOLD", "0")
+    a, cmp_a = run()
+    monkeypatch.delenv("SNN_ENC_FOLD")
+    for _ in range(2):
+        b, cmp_b = run()
+        assert torch.equal(cmp_a, cmp_b), int((cmp_a != cmp_b).sum())
+        assert all(torch.equal(x, y) for x, y in zip(a, b))
+    assert int((cmp_a.view(torch.int32)[: (Cw // 2) * 4 * Pe].view(-1, Pe)[0] != 0).sum()) > 0      # occupancy words of plane e_3: something fired
+    m.spike_rates = True                                        # the counting launches read the same planes
+    m(feats)
+    c_fold = m.last_spike_counts.clone()
+    monkeypatch.setenv("SNN_ENC_FOLD", "0")
+    m(feats)
+    assert torch.equal(c_fold, m.last_spike_counts)
+
+
+@pytest.mark.parametrize("R,C,Hd,K,T", [(2000, 256, 1024, 9, 12), (333, 64, 256, 11, 24), (77, 64, 128, 5, 12), (1, 64, 128, 5, 8), (50, 128, 192, 3, 16), (19, 192, 64, 3, 26)])
+def test_detector_encoder_fold_writes_the_same_planes(gpu_device, monkeypatch, R, C, Hd, K, T):
+    """k_encode_rows_perm (encoder + fc6's reduction order + compression in one launch) against k_encode_rows_wm -> k_permute_planes ->
+    k_compress_planes (SNN_ENC_FOLD=0): the dense planes e_1, e_2 and the compressed planes e_3 .. in the workspace bit for bit, and the
+    head's outputs and spike counts with them"""
+    from snn_automotive_object_detection_amd import ops
+    d = _det(gpu_device, C, Hd, K, T, R + 3 * T)
+    x = torch.randn(R, C, 7, 7, device=gpu_device) * 2
+    al = lambda v: (v + 255) // 256 * 256
+    Dw, Tc = C * 49 // 32, T - 2
+    o_cur = al(T * R * Dw * 4)                                  # det_ws_layout: the encoder planes (fc6 reads them at the front), then the side buffers
+    dense_bytes, cmp_bytes = 2 * Dw * R * 4, (Tc - 2) * (Dw // 2) * 4 * R * 4
+
+    def run():
+        out = _run_det(d, x, sparse=True)
+        ws = ops._WS.get(gpu_device, 1)
+        return out, ws[:dense_bytes].clone(), ws[o_cur: o_cur + cmp_bytes].clone()
+    run()
+    monkeypatch.setenv("SNN_ENC_FOLD", "0")
+    a, dense_a, cmp_a = run()
+    monkeypatch.delenv("SNN_ENC_FOLD")
+    ops._WS.get(gpu_device, 1)[: o_cur + cmp_bytes].fill_(0x5a)
+    for _ in range(2):
+        b, dense_b, cmp_b = run()
+        assert torch.equal(dense_a, dense_b), int((dense_a != dense_b).sum())
+        assert torch.equal(cmp_a, cmp_b), int((cmp_a != cmp_b).sum())
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert int((dense_a != 0).sum()) > 0
+    d.spike_rates = True                                        # (window T - 1: one more compressed plane)
+    d(x)
+    c_fold = [c.clone() for c in d.last_spike_counts]
+    monkeypatch.setenv("SNN_ENC_FOLD", "0")
+    d(x)
+    assert all(torch.equal(p, q) for p, q in zip(c_fold, d.last_spike_counts))

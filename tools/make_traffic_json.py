@@ -13,7 +13,7 @@ WORKLOADS = {  # shapes of bench.py's workloads: positions of the pyramid (batch
     "bdd": dict(levels=[(192, 344), (96, 172), (48, 86), (24, 43), (12, 22)], batch=4, T_rpn=8, R=4000, T_det=12, rates=False),
     "stress": dict(levels=[(192, 384), (96, 192), (48, 96), (24, 48), (12, 24)], batch=2, T_rpn=16, R=2000, T_det=24, rates=True),
 }
-KERNELS = {"conv": "k_gemm_lif_sparse<true, 1>", "fc6": "k_gemm_lif_sparse<false,", "fc7": "k_gemm_bf16x3<4,"}
+KERNELS = {"conv": "k_gemm_lif_sparse<true, 1", "fc6": "k_gemm_lif_sparse<false,", "fc7": "k_gemm_bf16x3<4,"}
 
 
 def parse(path):

@@ -146,5 +146,7 @@ def test_build_is_warning_free_and_the_big_kernels_keep_their_registers(tmp_path
         if (re.match(r"_Z13k_gemm_bf16x3ILi[34]ELi[34]ELi[234]E", name) or re.match(r"_Z9k_gemm_mxILi[34]ELi4E", name)
                 or name.startswith("_Z17k_gemm_lif_sparse")):                   # (+ the structured-sparse conv / fc6, csrc/snn_sparse.h)
             seen += 1
-            assert sc == 0 and vg <= 128, (name, vg, sc)
+            # two work-groups per CU: 128 registers per lane for the 512-thread shapes, 256 for the FAT shape's 256-thread work-groups (template flag b1)
+            fat = name.startswith("_Z17k_gemm_lif_sparse") and "ELb1EEv" in name
+            assert sc == 0 and vg <= (256 if fat else 128), (name, vg, sc)
     assert seen >= 16, seen

@@ -262,7 +262,7 @@ class Leg:
         exec_factor = per_step * (1.0 if (dead_steps_kept() or T < 2) else (T - 1) / T)
         achieved = conv_fl / (conv_ms * 1e-3) / 1e12
         if self.precision == "bf16x3" and getattr(self, "conv_sparse", False):
-            # Round 4: the stage is two launches - k_compress_planes and k_gemm_lif_sparse<true> (the work).  Of the T - 1 period planes two run on the dense instruction (peak 2.5 PF)
+            # The stage is k_gemm_lif_sparse<true> (round 4 also timed k_compress_planes here; since round 5 the encoder launch compresses).  Of the T - 1 period planes two run on the dense instruction (peak 2.5 PF)
             # and T - 3 on the structured-sparse one (v_smfmac_f32_16x16x64_bf16: 64 k per instruction, peak 5 PF dense-equivalent);
             # frac = (time the executed work takes at those peaks) / (measured time of the whole stage).
             Tc = T - 1
@@ -272,7 +272,8 @@ class Leg:
             return {"bound": "mfma", "kernel": "k_gemm_lif_sparse<true>", "achieved": round(achieved, 2),
                     "peak": round(conv_fl / t_peak / 1e12, 1), "unit": "TFLOP/s", "frac": round(t_peak / (conv_ms * 1e-3), 4),
                     "traffic": traffic, "traffic_source": traffic_source, "launch_ms": round(conv_ms, 4),
-                    "launches_timed": ["k_compress_planes", "k_gemm_lif_sparse<true>"],
+                    # (round 5: the encoder launch writes the planes e_3 .. compressed itself - k_compress_planes runs only under SNN_ENC_FOLD=0)
+                    "launches_timed": (["k_compress_planes"] if os.environ.get("SNN_ENC_FOLD") == "0" else []) + ["k_gemm_lif_sparse<true>"],
                     "algorithmic_gflop_per_launch": round(conv_fl / 1e9, 1),
                     "executed_dense_tflops": round(ex_dense / (conv_ms * 1e-3) / 1e12, 2), "executed_sparse_tflops": round(ex_sparse / (conv_ms * 1e-3) / 1e12, 2),
                     "mfma_peak_tflops": PEAK_BF16_MFMA_TFLOPS, "smfmac_peak_tflops": PEAK_BF16_SMFMAC_TFLOPS,

@@ -300,9 +300,12 @@ __global__ __launch_bounds__(FAT ? 256 : 512, FAT ? 2 : 4) void k_gemm_lif_spars
 #define SP_FAT_BDEPTH 2
 #endif
     constexpr int BDEPTH = FAT ? SP_FAT_BDEPTH : 1;                 // groups the weight-fragment reads run ahead of their matrix instructions
-#ifdef SNN_EXP_TIMELINE     // diagnostic build: wall-clock stamps (s_memrealtime, 100 MHz) of the work-group's phases
-    unsigned long long tl_entry = 0, tl_loop0 = 0, tl_loop1 = 0, tl_epi = 0, tl_img = 0;
-    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_entry) :: "memory");
+#ifdef SNN_EXP_TIMELINE     // diagnostic build: wall-clock stamps (s_memrealtime, 100 MHz) of the work-group's phases.  Each stamp is stored at once (thread 0): the
+    // 512-thread shapes sit at their 128-register limit, and stamps kept in registers until the end made the round-5 builds spill (304 bytes per lane: a
+    // K loop 35 % slower than the product's)
+#define SP_TL_STAMP(i) do { if (threadIdx.x == 0) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+                                                   args.tl[(size_t)blockIdx.x * 8 + (i)] = t_; } } while (0)
+    SP_TL_STAMP(0);
 #endif
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
@@ -438,7 +441,7 @@ __global__ __launch_bounds__(FAT ? 256 : 512, FAT ? 2 : 4) void k_gemm_lif_spars
     asm volatile("" ::: "memory");
 
 #ifdef SNN_EXP_TIMELINE
-    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_loop0) :: "memory");
+    SP_TL_STAMP(1);
 #endif
 #if defined(SNN_EXP_SP_NO_AREAD) || defined(SNN_EXP_SP_NO_BREAD)
     const bfv8 exp_a = *reinterpret_cast<const bfv8*>(lut + ((lane * 5) & 255) * 16);
@@ -581,7 +584,7 @@ __global__ __launch_bounds__(FAT ? 256 : 512, FAT ? 2 : 4) void k_gemm_lif_spars
 #undef SP_CASE
 
 #ifdef SNN_EXP_TIMELINE
-    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_loop1) :: "memory");
+    SP_TL_STAMP(2);
 #endif
     // ---- epilogue: currents -> LDS tile image (two passes of 32 columns), LIF over the T steps, spike words out
     const int T = args.T, Tc = args.Tc;
@@ -612,7 +615,7 @@ __global__ __launch_bounds__(FAT ? 256 : 512, FAT ? 2 : 4) void k_gemm_lif_spars
         }
         __syncthreads();
 #ifdef SNN_EXP_TIMELINE
-        if (h == 0) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_img) :: "memory");
+        if (h == 0) SP_TL_STAMP(7);
 #endif
         const int word0 = (nb * 64 + h * 32) >> 5;
         const int par = lane >> 5, col = lane & 31;
@@ -681,7 +684,7 @@ __global__ __launch_bounds__(FAT ? 256 : 512, FAT ? 2 : 4) void k_gemm_lif_spars
             else lif_pass(std::integral_constant<int, NP_LONG>{}, std::false_type{});
         }
 #ifdef SNN_EXP_TIMELINE
-        if (h == 0) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_epi) :: "memory");
+        if (h == 0) SP_TL_STAMP(3);
 #endif
     }
 #ifdef SNN_EXP_TIMELINE
@@ -691,7 +694,7 @@ __global__ __launch_bounds__(FAT ? 256 : 512, FAT ? 2 : 4) void k_gemm_lif_spars
         asm volatile("s_memrealtime %0\n\ts_getreg_b32 %1, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %2, hwreg(HW_REG_XCC_ID)\n\ts_waitcnt lgkmcnt(0)"
                      : "=s"(tl_exit), "=s"(hw), "=s"(xcc) :: "memory");
         unsigned long long* o = args.tl + (size_t)blockIdx.x * 8;       // (behind the compressed planes: tools/sparse_timeline.py allocates more)
-        o[0] = tl_entry; o[1] = tl_loop0; o[2] = tl_loop1; o[3] = tl_epi; o[4] = tl_exit; o[5] = hw; o[6] = xcc; o[7] = tl_img;       // (o[7] != 0 marks the record)
+        o[4] = tl_exit; o[5] = hw; o[6] = xcc;                          // (o[7] != 0 marks the record)
     }
 #endif
 }

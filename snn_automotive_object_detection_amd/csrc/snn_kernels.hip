@@ -133,6 +133,7 @@ __global__ void k_pack_heads(const float* __restrict__ wa, int NA, const float* 
 // Debug / A-B knobs.  They are read from the environment ONCE (first call into the library, thread-safe static
 // initialisation) and frozen: later setenv() calls change nothing, calls from several threads see one consistent set.
 // snn_debug_reload_knobs() re-reads them (the parity tests compare kernel variants in one process; not for concurrent use).
+#define SNN_SPARSE_FAT_CONV_DEFAULT true
 struct Knobs {
     bool enc_generic;        // SNN_ENC_GENERIC=1     op-for-op encoder kernels even for zero rest / reset potentials
     bool enc_rows_ballot;    // SNN_ENC_ROWS=ballot   element-per-lane row encoder
@@ -161,6 +162,8 @@ struct Knobs {
     bool sparse;             // SNN_SPARSE=0          RPN conv: every period plane on the dense matrix-core instruction (default: planes e_3.. on the
                              //                       structured-sparse one, snn_sparse.h)
     int encp_rb;             // SNN_ENCP_RB=8|16      RoIs per block of k_encode_rows_perm (A/B; default: 16 where the window fits one pass through LDS)
+    bool sparse_fat_conv;    // SNN_SPARSE_FAT_CONV=0 the RPN conv on the 8-wave shape where the FAT conv (four waves, LIF in registers) is the default: T = 7 .. 9 without
+                             //                       spike counting (bit-identical)
     bool enc_fold;           // SNN_ENC_FOLD=0        RPN head: k_compress_planes as its own launch again instead of inside the encoder launch (bit-identical planes)
     bool sparse_fat;         // SNN_SPARSE_FAT=0      linear layers (fc6) on the 8-wave shape of k_gemm_lif_sparse instead of the FAT one (four waves of up to 256
                              //                       registers, twice the M-tile slots per wave: the default where its loop instances exist; bit-identical)
@@ -186,6 +189,7 @@ static Knobs load_knobs() {
     k.debug_occ = getenv("SNN_DEBUG_OCC") != nullptr;
     k.sparse_fat = !((e = getenv("SNN_SPARSE_FAT")) && e[0] == '0');
     k.enc_fold = !((e = getenv("SNN_ENC_FOLD")) && e[0] == '0');
+    k.sparse_fat_conv = (e = getenv("SNN_SPARSE_FAT_CONV")) ? e[0] == '1' : SNN_SPARSE_FAT_CONV_DEFAULT;
     k.encp_rb = (e = getenv("SNN_ENCP_RB")) ? atoi(e) : 0;
     e = getenv("SNN_PLANES");
     k.planes = !e ? 0 : !strcmp(e, "rm") ? 1 : !strcmp(e, "wm") ? 2 : 0;
@@ -904,6 +908,20 @@ struct SparsePlan { int q, pb, nd, wn, fat; signed char plane[8][SP_MTMAX]; unsi
 // q = M-tiles (16 positions / RoIs each) per plane.  The conv has thousands of tiles and takes the largest one; a linear layer with a few
 // hundred work-groups takes the q with the fewest rounds of work-groups x work per tile (fc6 at 2000 RoIs, 10 planes: q = 3 is 672
 // work-groups = 1.31 rounds of the 512 slots, q = 2 is 1008 = 1.97 rounds of tiles two thirds the size: 687 -> ~520 us)
+// FAT conv (round 5): four waves, wave w holds ALL planes of position block w (slot s = plane s) - what its register LIF needs
+static bool sparse_plan_fat_conv(int Tc, SparsePlan* sp) {
+    static const int inst[][2] = {SP_FAT1_INSTANCES};
+    bool ok = false;
+    for (size_t i = 0; i < sizeof(inst) / sizeof(inst[0]); ++i) ok |= inst[i][0] == 2 && inst[i][1] == Tc - 2;
+    if (!ok || Tc > SP_MT_FAT) return false;
+    memset(sp, 0, sizeof(*sp));
+    sp->q = 4; sp->pb = 64; sp->nd = 2; sp->wn = 1; sp->fat = 1;
+    for (int w = 0; w < 8; ++w)
+        for (int m = 0; m < SP_MTMAX; ++m) { sp->plane[w][m] = (w < 4 && m < Tc) ? (signed char)m : (signed char)-1; sp->j[w][m] = (unsigned char)(w & 3); }
+    for (int w = 0; w < 4; ++w) { sp->w_nd[w] = 2; sp->w_ns[w] = (unsigned char)(Tc - 2); }
+    return true;
+}
+
 static bool sparse_plan_wn(int Tc, int wn, int q, SparsePlan* sp, bool fat = false) {
     const int nd = 2, nwm = (fat ? 4 : 8) / wn, mts = fat ? SP_MT2_FAT : wn == 1 ? SP_MT : SP_MT2;
     if (q < 1 || Tc * q > nwm * mts || (fat && wn != 2)) return false;
@@ -953,11 +971,12 @@ static bool sparse_plan_wn(int Tc, int wn, int q, SparsePlan* sp, bool fat = fal
 // (its K loop is matrix-pipe-bound there).  A linear layer with a few hundred work-groups takes the (wave grid, q) with the fewest
 // rounds of work-groups x work per tile; on the 8 x 1 grid small tiles are LDS-bound (every wave reads the whole weight slot), so the
 // 4 x 2 grid is preferred where its plan exists (fc6 at 2000 RoIs, 10 planes: q = 2 on 4 x 2 = 1008 work-groups = 1.97 rounds).
-static bool sparse_plan(int Tc, SparsePlan* sp, long long units = 0, int n_blocks = 0) {
+static bool sparse_plan(int Tc, SparsePlan* sp, long long units = 0, int n_blocks = 0, bool counting = false) {
     if (Tc < 4 || Tc > 32) return false;
     const bool conv = !(units > 0 && n_blocks > 0);
     const bool fat = !conv && knobs().sparse_fat;           // linear layers: the same tiles on four fat waves, where the plan's row-waves have loop instances
     if (conv) {
+        if (knobs().sparse_fat_conv && !counting && sparse_plan_fat_conv(Tc, sp)) return true;      // (its register LIF does not count spikes)
         int q = 32 / Tc;
         if (q > 8) q = 8;
         return sparse_plan_wn(Tc, 1, q, sp);
@@ -987,10 +1006,10 @@ static bool sparse_plan(int Tc, SparsePlan* sp, long long units = 0, int n_block
 // linear: any T whose window (T - 2, or T - 1 in spike-rate mode) fits the slot grid - 4 .. 24 planes on the 4 x 2 wave grid - with the
 // general LIF epilogue outside the straight-line grid (round 5: T_det = 17 .. 26 and spike-rate mode used to take the all-dense launch).
 struct SparseShape { SparsePlan sp; int n_tiles, n_blocks, grid, lds, xcd_cpx, xcd_contig, epi_general; };
-static bool sparse_shape(bool conv, long long M, int Kw, int Kc, int Np, int T, int Tc, SparseShape* out) {
+static bool sparse_shape(bool conv, long long M, int Kw, int Kc, int Np, int T, int Tc, SparseShape* out, bool counting = false) {
     if (!knobs().sparse || Kw % 2 || Np % 64 || Kc * 32 > 65536 || M <= 0) return false;
     if (conv ? (T < 5 || T > 16 || Tc != T - 1) : (T < 5 || T > SNN_MAX_STEPS || (Tc != T - 2 && Tc != T - 1))) return false;
-    if (!sparse_plan(Tc, &out->sp, conv ? 0 : M, Np / 64)) return false;
+    if (!sparse_plan(Tc, &out->sp, conv ? 0 : M, Np / 64, counting)) return false;
     const SparsePlan& sp = out->sp;
     out->n_tiles = cdiv(M, sp.pb);
     out->n_blocks = Np / 64;
@@ -1020,7 +1039,7 @@ static int gemm3_lif_sparse(const Gemm3Args& a, bool conv, void* side, size_t si
     SparseShape sh;
     const int Kw = conv ? a.Cw : a.Kc;                        // plane words per row
     if (!side || !a.wm || !a.periods || a.t0 != 0 || a.p.v_leak != 0.0f || (float)(a.p.v_leak - a.p.v_th) > 0.0f || (!conv && !a.out_wm) ||
-        !sparse_shape(conv, a.M, Kw, a.Kc, a.Np, a.T, a.Tc, &sh))
+        !sparse_shape(conv, a.M, Kw, a.Kc, a.Np, a.T, a.Tc, &sh, conv ? a.cnt_img != nullptr : a.cnt_row != nullptr))
         return 0;
     const SparsePlan& sp = sh.sp;
     const long long P = a.M, Pe = (long long)a.a_step;
@@ -1030,7 +1049,7 @@ static int gemm3_lif_sparse(const Gemm3Args& a, bool conv, void* side, size_t si
     // (the kernel addresses both the raw and the compressed planes by 32-bit offsets from the raw planes)
     if ((const char*)cmp < (const char*)a.A || (unsigned long long)((const char*)cmp - (const char*)a.A) + cmp_bytes > 0xffffffffULL) return 0;
     if (mode == SPARSE_QUERY) return 1;
-    const void* kern = sp.fat ? (const void*)k_gemm_lif_sparse<false, 2, true>
+    const void* kern = sp.fat ? (conv ? (const void*)k_gemm_lif_sparse<true, 1, true> : (const void*)k_gemm_lif_sparse<false, 2, true>)
                               : conv ? (const void*)k_gemm_lif_sparse<true, 1> : sp.wn == 2 ? (const void*)k_gemm_lif_sparse<false, 2> : (const void*)k_gemm_lif_sparse<false, 1>;
     hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, sh.lds);
     if (e != hipSuccess) return fail(-3, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -1095,11 +1114,11 @@ int snn_debug_tile_shape(int conv, long long units, int k_in, int n_cols, int nu
     // the structured-sparse plan, where the launchers take it (period planes of the default parameters: conv, fc6)
     SparseShape sh;
     const int Kw = cdiv(k_in, 32), Np = cdiv(n_cols, 32) * 32;
-    if (knobs().periods && (conv || layer != 7) && sparse_shape(conv != 0, units, Kw, conv ? 9 * Kw : Kw, Np, num_steps, Tc, &sh)) {
+    if (knobs().periods && (conv || layer != 7) && sparse_shape(conv != 0, units, Kw, conv ? 9 * Kw : Kw, Np, num_steps, Tc, &sh, spike_rates != 0)) {
         const SparsePlan& sp = sh.sp;
         int slots = 0;
         for (int w = 0; w < (sp.fat ? 4 : 8) / sp.wn; ++w) slots += sp.w_nd[w] + sp.w_ns[w];
-        out[0] = sp.fat ? SP_MT2_FAT : sp.wn == 1 ? SP_MT : SP_MT2; out[1] = sp.fat; out[2] = Tc * sp.pb; out[3] = sp.pb; out[4] = Tc; out[5] = sh.n_tiles * sh.n_blocks;
+        out[0] = sp.fat ? (sp.wn == 1 ? SP_MT_FAT : SP_MT2_FAT) : sp.wn == 1 ? SP_MT : SP_MT2; out[1] = sp.fat; out[2] = Tc * sp.pb; out[3] = sp.pb; out[4] = Tc; out[5] = sh.n_tiles * sh.n_blocks;
         out[6] = sh.n_blocks; out[7] = sp.wn; out[8] = 1; out[9] = sp.nd; out[10] = Tc - sp.nd; out[11] = slots;
         return 0;
     }

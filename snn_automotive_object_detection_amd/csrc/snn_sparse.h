@@ -32,6 +32,7 @@ typedef __bf16 bfv16 __attribute__((ext_vector_type(16)));
 #define SP_MT 4                                     // M-tile slots per wave on the 8 x 1 wave grid (all waves span the 64 columns)
 #define SP_MT2 6                                    // ... per ROW-wave on the 4 x 2 grid (two waves of 32 columns share a row-wave's slots)
 #define SP_MT2_FAT 12                               // ... per row-wave of the FAT shape (linear layers): 2 x 2 waves of up to 256 registers, 32 columns per wave
+#define SP_MT_FAT 8                                 // ... per wave of the FAT conv: 4 waves x all 64 columns, every wave ALL planes of its own 16 positions (register LIF)
 #define SP_MTMAX 12
 #define SP_ROWS (8 * SP_MT * 16)                    // physical tile rows (512; 4 x 6 x 16 = 384 on the 4 x 2 grid)
 // (SP_A_ARR and sp_nibble_code live in snn_common.h: the RPN encoder writes the same compressed layout)
@@ -274,6 +275,50 @@ __global__ __launch_bounds__(256) void k_sum_pos_counts(const PosCountArgs a) {
     }
 }
 
+// LIF of the FAT conv in REGISTERS (round 5).  The wave's accumulators hold all TS - 1 period sums of its own 16 positions x 64 columns
+// (slot s = plane s): lane (lg, lr) has, for r < 4 and nt < 4, the neuron (position 4 lg + r, column 16 nt + lr).  No tile image in LDS,
+// no work-group barrier: the recurrence of sp_lif_fixed (same operations, same order of the divisor sums) runs on the four N-tiles of a
+// row r at once (four independent chains), the ballot of N-tile nt holds in bits 16 lg .. 16 lg + 15 the half-word (columns 16 nt ..) of
+// position 4 lg + r, and lane lr of group lg keeps the word (step 1 + (lr >> 1), columns 32 (lr & 1) ..) of its position - 16 (step, word)
+// combinations per position for TS <= 9; step 0 never spikes (its plane is written as zeros).
+template <int TS, int MTS_>
+__device__ __forceinline__ void sp_lif_regs(const f32x4 (&acc)[MTS_][4], const NeuronP& p, const int lane, uint32_t (&mine)[4]) {
+    constexpr int TCS = TS - 1;
+    static_assert(TCS <= MTS_ && TS <= 9, "all planes of a position block in one wave; 16 (step, word) lanes per position");
+    const int sh = 16 * (lane >> 4), lr = lane & 15;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float vv[4] = {0.0f, 0.0f, 0.0f, 0.0f}, ii[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        uint32_t keep = 0;
+#pragma unroll
+        for (int t = 0; t < TS; ++t) {
+            unsigned long long b[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                float c = 0.0f;
+                if (t < TCS) {
+                    c = acc[0][nt][r];
+#pragma unroll
+                    for (int n = 2; n <= t + 1; ++n)
+                        if ((t + 1) % n == 0) c = __fadd_rn(c, acc[n - 1][nt][r]);
+                }
+                if (t == 0) { ii[nt] = __fadd_rn(0.0f, c); continue; }
+                const float v_dec = __fadd_rn(vv[nt], __fmul_rn(p.ca, __fsub_rn(ii[nt], vv[nt])));
+                const float i_dec = __fadd_rn(ii[nt], __fmul_rn(p.cb, ii[nt]));
+                const bool z = v_dec > p.v_th;
+                vv[nt] = z ? p.v_reset : v_dec;
+                ii[nt] = __fadd_rn(i_dec, c);
+                b[nt] = __ballot(z);
+            }
+            if (t == 0) continue;
+            const uint32_t w0 = ((uint32_t)(b[0] >> sh) & 0xffffu) | ((uint32_t)(b[1] >> sh) << 16);
+            const uint32_t w1 = ((uint32_t)(b[2] >> sh) & 0xffffu) | ((uint32_t)(b[3] >> sh) << 16);
+            keep = (lr >> 1) == t - 1 ? ((lr & 1) ? w1 : w0) : keep;
+        }
+        mine[r] = keep;
+    }
+}
+
 // WN = waves along the 64 columns.  1: 8 row-waves x 4 slots, every wave reads the whole weight slot from LDS each step (192 KB per
 // work-group and step).  2: 4 row-waves x 6 slots, a wave covers 32 columns and reads half of the slot (96 KB): the shape for launches whose
 // matrix-pipe time per step is below what those LDS reads take - fc6, whose tiles hold 32 RoIs (tools: profiles/r4_sparse_timeline.txt).
@@ -289,9 +334,9 @@ __global__ __launch_bounds__(256) void k_sum_pos_counts(const PosCountArgs a) {
 // SIMD leave the pipe idle at every barrier.)
 template <bool CONV, int WN, bool FAT = false>
 __global__ __launch_bounds__(FAT ? 256 : 512, FAT ? 2 : 4) void k_gemm_lif_sparse(const SparseConvArgs args) {
-    static_assert(!FAT || (WN == 2 && !CONV), "the FAT shape is instantiated for linear layers (2 x 2 waves)");
+    static_assert(!FAT || (WN == 2 && !CONV) || (WN == 1 && CONV), "the FAT shape: linear layers on 2 x 2 waves, the conv on 4 x 1");
     constexpr int NWAVES = FAT ? 4 : 8;
-    constexpr int MTS = FAT ? SP_MT2_FAT : WN == 1 ? SP_MT : SP_MT2, NT = 4 / WN;      // slots per (row-)wave, 16-column N-tiles per wave
+    constexpr int MTS = FAT ? (WN == 1 ? SP_MT_FAT : SP_MT2_FAT) : WN == 1 ? SP_MT : SP_MT2, NT = 4 / WN;      // slots per (row-)wave, 16-column N-tiles per wave
     constexpr int ROWS = SP_ROWS;                                   // physical tile rows of a ring slot (row-waves x MTS x 16 <= 512 in every shape)
     static_assert((NWAVES / WN) * MTS * 16 <= SP_ROWS, "ring slot rows");
     constexpr int A_BYTES = SP_A_ARR * ROWS * 4, SLOT = A_BYTES + SP_B_BYTES;
@@ -562,11 +607,17 @@ __global__ __launch_bounds__(FAT ? 256 : 512, FAT ? 2 : 4) void k_gemm_lif_spars
         }
     };
 // (dense, sparse) M-tile counts of a row-wave the FAT shapes have loop instances for (host: sparse_plan_wn checks against the same lists)
+// FAT conv: every wave (2 dense, Tc - 2 sparse), T = 7 .. 9 (T = 5 / 6 measured 9.5 % / 1.3 % SLOWER than the 8-wave shape, whose tiles
+// hold 128 / 80 positions there against the FAT conv's 64: profiles/r5_fat_conv_ab.txt)
+#define SP_FAT1_INSTANCES {2, 5}, {2, 4}, {2, 6}
+#define SP_FAT1_CASES SP_CASE(2, 5) SP_CASE(2, 4) SP_CASE(2, 6)
 #define SP_FAT2_INSTANCES {2, 8}, {2, 7}, {2, 9}, {2, 10}, {2, 6}, {2, 5}, {2, 4}, {2, 3}, {2, 2}, {1, 10}, {1, 11}, {1, 9}, {1, 8}, {1, 7}, {1, 6}, {1, 5}
 #define SP_FAT2_CASES SP_CASE(2, 8) SP_CASE(2, 7) SP_CASE(2, 9) SP_CASE(2, 10) SP_CASE(2, 6) SP_CASE(2, 5) SP_CASE(2, 4) SP_CASE(2, 3) SP_CASE(2, 2) \
                       SP_CASE(1, 10) SP_CASE(1, 11) SP_CASE(1, 9) SP_CASE(1, 8) SP_CASE(1, 7) SP_CASE(1, 6) SP_CASE(1, 5)
 #define SP_CASE(ND_, NS_) if (nd_w == ND_ && ns_w == NS_) step_loop(std::integral_constant<int, ND_>{}, std::integral_constant<int, NS_>{}); else
-    if constexpr (FAT) {
+    if constexpr (FAT && CONV) {
+        SP_FAT1_CASES { step_loop(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}); }
+    } else if constexpr (FAT) {
         SP_FAT2_CASES { step_loop(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}); }
     } else if constexpr (WN == 1) {
         SP_CASE(1, 3) SP_CASE(1, 2) SP_CASE(2, 2) SP_CASE(0, 4) SP_CASE(0, 3) SP_CASE(1, 1) SP_CASE(2, 1) SP_CASE(0, 2) SP_CASE(0, 1)
@@ -586,6 +637,40 @@ __global__ __launch_bounds__(FAT ? 256 : 512, FAT ? 2 : 4) void k_gemm_lif_spars
 #ifdef SNN_EXP_TIMELINE
     SP_TL_STAMP(2);
 #endif
+    if constexpr (FAT && CONV) {
+        // ---- epilogue of the FAT conv: the LIF in registers (sp_lif_regs), each wave for its own 16 positions; no LDS, no barrier
+        const int T = args.T;
+        uint32_t mine[4] = {0, 0, 0, 0};
+        switch (T) {
+        case 7: sp_lif_regs<7, MTS>(acc, args.p, lane, mine); break;
+        case 8: sp_lif_regs<8, MTS>(acc, args.p, lane, mine); break;
+        case 9: sp_lif_regs<9, MTS>(acc, args.p, lane, mine); break;
+        default: break;
+        }
+        const int t_mine = 1 + ((lane & 15) >> 1), h = lane & 1, word = nb * 2 + h;     // this lane's (step, word of the 64 columns)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int pos = m0 + 16 * wave + 4 * lg + r;
+            if (pos >= M || 16 * wave + 4 * lg + r >= pb) continue;
+            uint32_t* dst;
+            if (args.out_split) dst = args.spk + ((size_t)(word >> 2) * M + pos) * 4 + (word & 3);
+            else dst = args.spk + (size_t)pos * (Np >> 5) + word;
+            if (t_mine < T) dst[(size_t)t_mine * args.spk_stride] = mine[r];
+            if ((lane & 15) < 2) dst[0] = 0u;                                          // step 0: no spike
+        }
+#ifdef SNN_EXP_TIMELINE
+        SP_TL_STAMP(7); SP_TL_STAMP(3);
+        if (tid == 0) {
+            unsigned long long tl_exit;
+            uint32_t hw, xcc;
+            asm volatile("s_memrealtime %0\n\ts_getreg_b32 %1, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %2, hwreg(HW_REG_XCC_ID)\n\ts_waitcnt lgkmcnt(0)"
+                         : "=s"(tl_exit), "=s"(hw), "=s"(xcc) :: "memory");
+            unsigned long long* o = args.tl + (size_t)blockIdx.x * 8;
+            o[4] = tl_exit; o[5] = hw; o[6] = xcc;
+        }
+#endif
+        return;
+    }
     // ---- epilogue: currents -> LDS tile image (two passes of 32 columns), LIF over the T steps, spike words out
     const int T = args.T, Tc = args.Tc;
     float* const tile = reinterpret_cast<float*>(smem);

@@ -395,3 +395,36 @@ def test_detector_encoder_fold_writes_the_same_planes(gpu_device, monkeypatch, R
     monkeypatch.setenv("SNN_ENC_FOLD", "0")
     d(x)
     assert all(torch.equal(p, q) for p, q in zip(c_fold, d.last_spike_counts))
+
+
+# ---- the FAT conv (four waves, each ALL planes of its own 16 positions, the LIF in registers - no tile image) ---------------------------
+@pytest.mark.parametrize("T", [7, 8, 9])
+@pytest.mark.parametrize("C", [256, 64, 128])
+def test_fat_conv_register_lif_is_bit_identical(gpu_device, monkeypatch, T, C):
+    """same matrix instructions per accumulator, same LIF operations in the same order: the spike planes - and so the outputs - equal the
+    8-wave shape's bit for bit (pyramid with partial tiles and tiles that straddle levels)"""
+    m = _head(gpu_device, C, T, 90 + T)
+    g = torch.Generator().manual_seed(90 + T + C)
+    feats = [(torch.randn(2, C, h, w, generator=g) * 1.7).to(gpu_device) for h, w in [(41, 67), (19, 27), (7, 9), (1, 3)]]
+    monkeypatch.setenv("SNN_SPARSE_FAT_CONV", "0")
+    a = _run(m, feats, sparse=True)
+    planes_a = _rpn_hidden_planes(gpu_device, T, C // 32)
+    monkeypatch.setenv("SNN_SPARSE_FAT_CONV", "1")
+    for _ in range(3):
+        b = _run(m, feats, sparse=True)
+        planes_b = _rpn_hidden_planes(gpu_device, T, C // 32)
+        assert torch.equal(planes_a, planes_b), int((planes_a != planes_b).sum())
+        assert all(torch.equal(x, y) for x, y in zip(a, b))
+    assert int((planes_a != 0).sum()) > 0
+    import ctypes as Ct
+    from snn_automotive_object_detection_amd import _lib
+    o12 = (Ct.c_int32 * 12)()
+    pos = sum(2 * f.shape[2] * f.shape[3] for f in feats)
+    assert _lib.load().snn_debug_tile_shape(1, pos, C, C, T, 0, 0, o12) == 0 and o12[8] == 1 and o12[1] == 1 and o12[3] == 64, list(o12)
+    assert _lib.load().snn_debug_tile_shape(1, pos, C, C, T, 1, 0, o12) == 0 and o12[8] == 1 and o12[1] == 0, list(o12)      # counting launches: the 8-wave shape
+    m.spike_rates = True
+    m(feats)
+    c1 = m.last_spike_counts.clone()
+    monkeypatch.setenv("SNN_SPARSE_FAT_CONV", "0")
+    m(feats)
+    assert torch.equal(c1, m.last_spike_counts)

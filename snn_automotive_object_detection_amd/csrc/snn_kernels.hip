@@ -164,6 +164,7 @@ struct Knobs {
     int encp_rb;             // SNN_ENCP_RB=8|16      RoIs per block of k_encode_rows_perm (A/B; default: 16 where the window fits one pass through LDS)
     bool sparse_fat_conv;    // SNN_SPARSE_FAT_CONV=0 the RPN conv on the 8-wave shape where the FAT conv (four waves, LIF in registers) is the default: T = 7 .. 9 without
                              //                       spike counting (bit-identical)
+    bool lif_regs;           // SNN_LIF_REGS=0        FAT shapes: the LIF through the LDS tile image instead of in registers (linear layers; the FAT conv has no other form)
     bool enc_fold;           // SNN_ENC_FOLD=0        RPN head: k_compress_planes as its own launch again instead of inside the encoder launch (bit-identical planes)
     bool sparse_fat;         // SNN_SPARSE_FAT=0      linear layers (fc6) on the 8-wave shape of k_gemm_lif_sparse instead of the FAT one (four waves of up to 256
                              //                       registers, twice the M-tile slots per wave: the default where its loop instances exist; bit-identical)
@@ -189,6 +190,7 @@ static Knobs load_knobs() {
     k.debug_occ = getenv("SNN_DEBUG_OCC") != nullptr;
     k.sparse_fat = !((e = getenv("SNN_SPARSE_FAT")) && e[0] == '0');
     k.enc_fold = !((e = getenv("SNN_ENC_FOLD")) && e[0] == '0');
+    k.lif_regs = !((e = getenv("SNN_LIF_REGS")) && e[0] == '0');
     k.sparse_fat_conv = (e = getenv("SNN_SPARSE_FAT_CONV")) ? e[0] == '1' : SNN_SPARSE_FAT_CONV_DEFAULT;
     k.encp_rb = (e = getenv("SNN_ENCP_RB")) ? atoi(e) : 0;
     e = getenv("SNN_PLANES");
@@ -922,6 +924,19 @@ static bool sparse_plan_fat_conv(int Tc, SparsePlan* sp) {
     return true;
 }
 
+// may the LIF of this FAT plan run in registers (snn_sparse.h: sp_lif_regs)?  Every (row-)wave must hold ALL planes of its own block
+// (slot s = plane s, block = the row-wave), the (T, window) must have an instance, and the launch must not count spikes.
+static bool sparse_plan_lif_regs(const SparsePlan& sp, bool conv, int T, int Tc, bool counting, int epi_general) {
+    if (!sp.fat || counting || epi_general || !knobs().lif_regs) return false;
+    if (conv ? (T < 7 || T > 9) : (T < 6 || T > 14)) return false;
+    const int nwm = 4 / sp.wn;
+    if (sp.q != nwm) return false;
+    for (int w = 0; w < nwm; ++w)
+        for (int m = 0; m < Tc; ++m)
+            if (sp.plane[w][m] != m || sp.j[w][m] != w) return false;
+    return true;
+}
+
 static bool sparse_plan_wn(int Tc, int wn, int q, SparsePlan* sp, bool fat = false) {
     const int nd = 2, nwm = (fat ? 4 : 8) / wn, mts = fat ? SP_MT2_FAT : wn == 1 ? SP_MT : SP_MT2;
     if (q < 1 || Tc * q > nwm * mts || (fat && wn != 2)) return false;
@@ -1071,6 +1086,7 @@ static int gemm3_lif_sparse(const Gemm3Args& a, bool conv, void* side, size_t si
     memcpy(sa.w_nd, sp.w_nd, 8); memcpy(sa.w_ns, sp.w_ns, 8);
     sa.p = a.p;
     sa.epi_general = sh.epi_general;
+    sa.lif_regs = sparse_plan_lif_regs(sp, conv, a.T, a.Tc, conv ? a.cnt_img != nullptr : a.cnt_row != nullptr, sh.epi_general) ? 1 : 0;
     memcpy(sa.div, a.div, sizeof(sa.div));
     memcpy(sa.lv, a.lv, sizeof(sa.lv));
     sa.xcd_cpx = sh.xcd_cpx; sa.xcd_contig = sh.xcd_contig;

@@ -66,6 +66,8 @@ struct SparseConvArgs {
     int xcd_contig, xcd_cpx;             // block order, as Gemm3Args
     // epi_general != 0: the LIF epilogue's general form (run-time T and window: the current of step t < Tc is the sum of the row groups in
     // div[t], ascending) - every (T, window) without a straight-line instance: linear layers at T > 16 and in spike-rate mode (window T - 1)
+    int lif_regs;                // FAT shapes: every (row-)wave holds ALL planes of its own block of 16 positions / RoIs (slot s = plane s) and this
+                                 // (T, window) has a register-LIF instance: the LIF runs in registers (sp_lif_regs), no tile image (host: sparse_plan_lif_regs)
     int epi_general;
     uint32_t div[SNN_MAX_STEPS];
     NeuronP p;
@@ -281,20 +283,24 @@ __global__ __launch_bounds__(256) void k_sum_pos_counts(const PosCountArgs a) {
 // row r at once (four independent chains), the ballot of N-tile nt holds in bits 16 lg .. 16 lg + 15 the half-word (columns 16 nt ..) of
 // position 4 lg + r, and lane lr of group lg keeps the word (step 1 + (lr >> 1), columns 32 (lr & 1) ..) of its position - 16 (step, word)
 // combinations per position for TS <= 9; step 0 never spikes (its plane is written as zeros).
-template <int TS, int MTS_>
-__device__ __forceinline__ void sp_lif_regs(const f32x4 (&acc)[MTS_][4], const NeuronP& p, const int lane, uint32_t (&mine)[4]) {
-    constexpr int TCS = TS - 1;
-    static_assert(TCS <= MTS_ && TS <= 9, "all planes of a position block in one wave; 16 (step, word) lanes per position");
+template <int TS, int D, int NTL, int MTS_>
+__device__ __forceinline__ void sp_lif_regs(const f32x4 (&acc)[MTS_][NTL], const NeuronP& p, const int lane, uint32_t (&mine)[4]) {
+    constexpr int TCS = TS - D;                          // conv: D = 1; fc6: D = 2 (dead time steps)
+    static_assert(NTL == 4 || NTL == 2, "64 columns (two words per position) or 32 (one)");
+    static_assert(TCS <= MTS_ && TS - 1 <= (NTL == 4 ? 8 : 16), "all planes of a block in one wave; 16 (step, word) lanes per position");
     const int sh = 16 * (lane >> 4), lr = lane & 15;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        float vv[4] = {0.0f, 0.0f, 0.0f, 0.0f}, ii[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        float vv[NTL], ii[NTL];
+#pragma unroll
+        for (int nt = 0; nt < NTL; ++nt) { vv[nt] = 0.0f; ii[nt] = 0.0f; }
         uint32_t keep = 0;
 #pragma unroll
         for (int t = 0; t < TS; ++t) {
-            unsigned long long b[4] = {0, 0, 0, 0};
+            unsigned long long b[NTL];
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
+            for (int nt = 0; nt < NTL; ++nt) {
+                b[nt] = 0;
                 float c = 0.0f;
                 if (t < TCS) {
                     c = acc[0][nt][r];
@@ -312,8 +318,12 @@ __device__ __forceinline__ void sp_lif_regs(const f32x4 (&acc)[MTS_][4], const N
             }
             if (t == 0) continue;
             const uint32_t w0 = ((uint32_t)(b[0] >> sh) & 0xffffu) | ((uint32_t)(b[1] >> sh) << 16);
-            const uint32_t w1 = ((uint32_t)(b[2] >> sh) & 0xffffu) | ((uint32_t)(b[3] >> sh) << 16);
-            keep = (lr >> 1) == t - 1 ? ((lr & 1) ? w1 : w0) : keep;
+            if constexpr (NTL == 4) {                    // lane lr <-> (step 1 + (lr >> 1), word lr & 1)
+                const uint32_t w1 = ((uint32_t)(b[2] >> sh) & 0xffffu) | ((uint32_t)(b[3] >> sh) << 16);
+                keep = (lr >> 1) == t - 1 ? ((lr & 1) ? w1 : w0) : keep;
+            } else {                                     // lane lr <-> step 1 + lr
+                keep = lr == t - 1 ? w0 : keep;
+            }
         }
         mine[r] = keep;
     }
@@ -637,38 +647,40 @@ __global__ __launch_bounds__(FAT ? 256 : 512, FAT ? 2 : 4) void k_gemm_lif_spars
 #ifdef SNN_EXP_TIMELINE
     SP_TL_STAMP(2);
 #endif
-    if constexpr (FAT && CONV) {
-        // ---- epilogue of the FAT conv: the LIF in registers (sp_lif_regs), each wave for its own 16 positions; no LDS, no barrier
-        const int T = args.T;
-        uint32_t mine[4] = {0, 0, 0, 0};
-        switch (T) {
-        case 7: sp_lif_regs<7, MTS>(acc, args.p, lane, mine); break;
-        case 8: sp_lif_regs<8, MTS>(acc, args.p, lane, mine); break;
-        case 9: sp_lif_regs<9, MTS>(acc, args.p, lane, mine); break;
-        default: break;
-        }
-        const int t_mine = 1 + ((lane & 15) >> 1), h = lane & 1, word = nb * 2 + h;     // this lane's (step, word of the 64 columns)
+    if (FAT && args.lif_regs) {                                    // (block-uniform)
+        // ---- epilogue of the FAT shapes: the LIF in registers (sp_lif_regs), each (row-)wave for its own 16 positions / RoIs; no LDS, no barrier
+        if constexpr (FAT) {
+            const int T = args.T;
+            uint32_t mine[4] = {0, 0, 0, 0};
+#define SP_R(n) case n: sp_lif_regs<n, CONV ? 1 : 2, NT, MTS>(acc, args.p, lane, mine); break;
+            if constexpr (CONV) { switch (T) { SP_R(7) SP_R(8) SP_R(9) default: break; } }
+            else { switch (T) { SP_R(6) SP_R(7) SP_R(8) SP_R(9) SP_R(10) SP_R(11) SP_R(12) SP_R(13) SP_R(14) default: break; } }
+#undef SP_R
+            // this lane's (step, word): 64 columns = two words per position (conv), 32 columns per column-wave = one (linear)
+            const int t_mine = 1 + (CONV ? ((lane & 15) >> 1) : (lane & 15)), word = CONV ? nb * 2 + (lane & 1) : nb * 2 + wn;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int pos = m0 + 16 * wave + 4 * lg + r;
-            if (pos >= M || 16 * wave + 4 * lg + r >= pb) continue;
-            uint32_t* dst;
-            if (args.out_split) dst = args.spk + ((size_t)(word >> 2) * M + pos) * 4 + (word & 3);
-            else dst = args.spk + (size_t)pos * (Np >> 5) + word;
-            if (t_mine < T) dst[(size_t)t_mine * args.spk_stride] = mine[r];
-            if ((lane & 15) < 2) dst[0] = 0u;                                          // step 0: no spike
-        }
+            for (int r = 0; r < 4; ++r) {
+                const int lp = 16 * wm + 4 * lg + r, pos = m0 + lp;
+                if (pos >= M || lp >= pb) continue;
+                uint32_t* dst;
+                if (!CONV) dst = args.spk + (size_t)word * M + pos;                     // word-major spike planes [T][word][RoI] (fc6 -> fc7)
+                else if (args.out_split) dst = args.spk + ((size_t)(word >> 2) * M + pos) * 4 + (word & 3);
+                else dst = args.spk + (size_t)pos * (Np >> 5) + word;
+                if (t_mine < T) dst[(size_t)t_mine * args.spk_stride] = mine[r];
+                if ((lane & 15) < (CONV ? 2 : 1)) dst[0] = 0u;                         // step 0: no spike
+            }
 #ifdef SNN_EXP_TIMELINE
-        SP_TL_STAMP(7); SP_TL_STAMP(3);
-        if (tid == 0) {
-            unsigned long long tl_exit;
-            uint32_t hw, xcc;
-            asm volatile("s_memrealtime %0\n\ts_getreg_b32 %1, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %2, hwreg(HW_REG_XCC_ID)\n\ts_waitcnt lgkmcnt(0)"
-                         : "=s"(tl_exit), "=s"(hw), "=s"(xcc) :: "memory");
-            unsigned long long* o = args.tl + (size_t)blockIdx.x * 8;
-            o[4] = tl_exit; o[5] = hw; o[6] = xcc;
-        }
+            SP_TL_STAMP(7); SP_TL_STAMP(3);
+            if (tid == 0) {
+                unsigned long long tl_exit;
+                uint32_t hw, xcc;
+                asm volatile("s_memrealtime %0\n\ts_getreg_b32 %1, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %2, hwreg(HW_REG_XCC_ID)\n\ts_waitcnt lgkmcnt(0)"
+                             : "=s"(tl_exit), "=s"(hw), "=s"(xcc) :: "memory");
+                unsigned long long* o = args.tl + (size_t)blockIdx.x * 8;
+                o[4] = tl_exit; o[5] = hw; o[6] = xcc;
+            }
 #endif
+        }
         return;
     }
     // ---- epilogue: currents -> LDS tile image (two passes of 32 columns), LIF over the T steps, spike words out

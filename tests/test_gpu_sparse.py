@@ -428,3 +428,28 @@ def test_fat_conv_register_lif_is_bit_identical(gpu_device, monkeypatch, T, C):
     monkeypatch.setenv("SNN_SPARSE_FAT_CONV", "0")
     m(feats)
     assert torch.equal(c1, m.last_spike_counts)
+
+
+@pytest.mark.parametrize("R,C,Hd,K,T", [(2000, 256, 1024, 9, 12), (2000, 256, 1024, 9, 14), (333, 64, 256, 11, 11), (77, 64, 128, 5, 12), (31, 64, 128, 5, 9), (1, 64, 128, 5, 13)])
+def test_fat_fc6_register_lif_is_bit_identical(gpu_device, monkeypatch, R, C, Hd, K, T):
+    """fc6 on the FAT shape with the LIF in registers (each row-wave all planes of its own 16 RoIs) against the same shape through the LDS
+    tile image (SNN_LIF_REGS=0): lif6's spike planes in the workspace and the head's outputs bit for bit"""
+    import ctypes as Ct
+    from snn_automotive_object_detection_amd import _lib, ops
+    d = _det(gpu_device, C, Hd, K, T, R + 7 * T)
+    x = torch.randn(R, C, 7, 7, device=gpu_device) * 2
+
+    def run():
+        out = _run_det(d, x, sparse=True)
+        off3 = (Ct.c_uint64 * 3)()
+        _lib.load().snn_debug_last_det_planes(off3)
+        s6 = ops._WS.get(gpu_device, 1)[int(off3[0]): int(off3[0]) + T * (Hd // 32) * R * 4].clone()
+        return out, s6
+    monkeypatch.setenv("SNN_LIF_REGS", "0")
+    a, s6_a = run()
+    monkeypatch.delenv("SNN_LIF_REGS")
+    for _ in range(3):
+        b, s6_b = run()
+        assert torch.equal(s6_a, s6_b), int((s6_a != s6_b).sum())
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert int((s6_a != 0).sum()) > 0

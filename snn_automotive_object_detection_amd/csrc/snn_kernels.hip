@@ -133,7 +133,7 @@ __global__ void k_pack_heads(const float* __restrict__ wa, int NA, const float* 
 // Debug / A-B knobs.  They are read from the environment ONCE (first call into the library, thread-safe static
 // initialisation) and frozen: later setenv() calls change nothing, calls from several threads see one consistent set.
 // snn_debug_reload_knobs() re-reads them (the parity tests compare kernel variants in one process; not for concurrent use).
-#define SNN_SPARSE_FAT_CONV_DEFAULT true
+#define SNN_SPARSE_FAT_CONV_DEFAULT 3
 struct Knobs {
     bool enc_generic;        // SNN_ENC_GENERIC=1     op-for-op encoder kernels even for zero rest / reset potentials
     bool enc_rows_ballot;    // SNN_ENC_ROWS=ballot   element-per-lane row encoder
@@ -162,8 +162,8 @@ struct Knobs {
     bool sparse;             // SNN_SPARSE=0          RPN conv: every period plane on the dense matrix-core instruction (default: planes e_3.. on the
                              //                       structured-sparse one, snn_sparse.h)
     int encp_rb;             // SNN_ENCP_RB=8|16      RoIs per block of k_encode_rows_perm (A/B; default: 16 where the window fits one pass through LDS)
-    bool sparse_fat_conv;    // SNN_SPARSE_FAT_CONV=0 the RPN conv on the 8-wave shape where the FAT conv (four waves, LIF in registers) is the default: T = 7 .. 9 without
-                             //                       spike counting (bit-identical)
+    int sparse_fat_conv;     // SNN_SPARSE_FAT_CONV=0..3 the FAT conv (four waves, LIF in registers; bit-identical to the 8-wave shape): bit 0 = T = 7 .. 9 (4 x 1 waves, tiles of
+                             //                       64 positions), bit 1 = T = 12 .. 16 (2 x 2 waves, tiles of 32); default: both
     bool lif_regs;           // SNN_LIF_REGS=0        FAT shapes: the LIF through the LDS tile image instead of in registers (linear layers; the FAT conv has no other form)
     bool enc_fold;           // SNN_ENC_FOLD=0        RPN head: k_compress_planes as its own launch again instead of inside the encoder launch (bit-identical planes)
     bool sparse_fat;         // SNN_SPARSE_FAT=0      linear layers (fc6) on the 8-wave shape of k_gemm_lif_sparse instead of the FAT one (four waves of up to 256
@@ -191,7 +191,7 @@ static Knobs load_knobs() {
     k.sparse_fat = !((e = getenv("SNN_SPARSE_FAT")) && e[0] == '0');
     k.enc_fold = !((e = getenv("SNN_ENC_FOLD")) && e[0] == '0');
     k.lif_regs = !((e = getenv("SNN_LIF_REGS")) && e[0] == '0');
-    k.sparse_fat_conv = (e = getenv("SNN_SPARSE_FAT_CONV")) ? e[0] == '1' : SNN_SPARSE_FAT_CONV_DEFAULT;
+    k.sparse_fat_conv = (e = getenv("SNN_SPARSE_FAT_CONV")) ? atoi(e) : SNN_SPARSE_FAT_CONV_DEFAULT;
     k.encp_rb = (e = getenv("SNN_ENCP_RB")) ? atoi(e) : 0;
     e = getenv("SNN_PLANES");
     k.planes = !e ? 0 : !strcmp(e, "rm") ? 1 : !strcmp(e, "wm") ? 2 : 0;
@@ -910,25 +910,32 @@ struct SparsePlan { int q, pb, nd, wn, fat; signed char plane[8][SP_MTMAX]; unsi
 // q = M-tiles (16 positions / RoIs each) per plane.  The conv has thousands of tiles and takes the largest one; a linear layer with a few
 // hundred work-groups takes the q with the fewest rounds of work-groups x work per tile (fc6 at 2000 RoIs, 10 planes: q = 3 is 672
 // work-groups = 1.31 rounds of the 512 slots, q = 2 is 1008 = 1.97 rounds of tiles two thirds the size: 687 -> ~520 us)
-// FAT conv (round 5): four waves, wave w holds ALL planes of position block w (slot s = plane s) - what its register LIF needs
+// FAT conv (round 5): four waves; T <= 9: 4 x 1, wave w holds ALL planes of position block w (slot s = plane s, tiles of 64 positions); T = 10 .. 17:
+// 2 x 2, row-wave wm holds all planes of block wm for its column-wave's 32 columns (tiles of 32 positions) - what the register LIF needs
 static bool sparse_plan_fat_conv(int Tc, SparsePlan* sp) {
-    static const int inst[][2] = {SP_FAT1_INSTANCES};
-    bool ok = false;
-    for (size_t i = 0; i < sizeof(inst) / sizeof(inst[0]); ++i) ok |= inst[i][0] == 2 && inst[i][1] == Tc - 2;
-    if (!ok || Tc > SP_MT_FAT) return false;
+    static const int inst_a[][2] = {SP_FAT1_INSTANCES}, inst_b[][2] = {SP_FAT1B_INSTANCES};
+    bool ok_a = false, ok_b = false;
+    for (size_t i = 0; i < sizeof(inst_a) / sizeof(inst_a[0]); ++i) ok_a |= inst_a[i][0] == 2 && inst_a[i][1] == Tc - 2;
+    for (size_t i = 0; i < sizeof(inst_b) / sizeof(inst_b[0]); ++i) ok_b |= inst_b[i][0] == 2 && inst_b[i][1] == Tc - 2;
+    // (T = 10 / 11 stay on the 8-wave shape, whose tiles hold 48 positions there: the 2 x 2 shape measured +2 % / +4 %; -5.6 % / -7.3 % / -1.1 % at T = 12 / 14 / 16)
+    ok_a &= Tc <= SP_MT_FAT; ok_b &= Tc >= 11 && Tc <= SP_MT2_FAT_CONV && !ok_a;
+    if (!ok_a && !ok_b) return false;
+    if (ok_b && !(knobs().sparse_fat_conv & 2)) return false;
+    if (ok_a && !(knobs().sparse_fat_conv & 1)) return false;
+    const int nwm = ok_a ? 4 : 2;
     memset(sp, 0, sizeof(*sp));
-    sp->q = 4; sp->pb = 64; sp->nd = 2; sp->wn = 1; sp->fat = 1;
+    sp->q = nwm; sp->pb = 16 * nwm; sp->nd = 2; sp->wn = ok_a ? 1 : 2; sp->fat = 1;
     for (int w = 0; w < 8; ++w)
-        for (int m = 0; m < SP_MTMAX; ++m) { sp->plane[w][m] = (w < 4 && m < Tc) ? (signed char)m : (signed char)-1; sp->j[w][m] = (unsigned char)(w & 3); }
-    for (int w = 0; w < 4; ++w) { sp->w_nd[w] = 2; sp->w_ns[w] = (unsigned char)(Tc - 2); }
+        for (int m = 0; m < SP_MTMAX; ++m) { sp->plane[w][m] = (w < nwm && m < Tc) ? (signed char)m : (signed char)-1; sp->j[w][m] = (unsigned char)(w % nwm); }
+    for (int w = 0; w < nwm; ++w) { sp->w_nd[w] = 2; sp->w_ns[w] = (unsigned char)(Tc - 2); }
     return true;
 }
 
 // may the LIF of this FAT plan run in registers (snn_sparse.h: sp_lif_regs)?  Every (row-)wave must hold ALL planes of its own block
 // (slot s = plane s, block = the row-wave), the (T, window) must have an instance, and the launch must not count spikes.
 static bool sparse_plan_lif_regs(const SparsePlan& sp, bool conv, int T, int Tc, bool counting, int epi_general) {
-    if (!sp.fat || counting || epi_general || !knobs().lif_regs) return false;
-    if (conv ? (T < 7 || T > 9) : (T < 6 || T > 14)) return false;
+    if (!sp.fat || (counting && !conv) || epi_general || !knobs().lif_regs) return false;
+    if (conv ? (sp.wn == 1 ? (T < 7 || T > 9) : (T < 10 || T > 16)) : (T < 6 || T > 14)) return false;
     const int nwm = 4 / sp.wn;
     if (sp.q != nwm) return false;
     for (int w = 0; w < nwm; ++w)
@@ -991,7 +998,7 @@ static bool sparse_plan(int Tc, SparsePlan* sp, long long units = 0, int n_block
     const bool conv = !(units > 0 && n_blocks > 0);
     const bool fat = !conv && knobs().sparse_fat;           // linear layers: the same tiles on four fat waves, where the plan's row-waves have loop instances
     if (conv) {
-        if (knobs().sparse_fat_conv && !counting && sparse_plan_fat_conv(Tc, sp)) return true;      // (its register LIF does not count spikes)
+        if (knobs().sparse_fat_conv && knobs().lif_regs && sparse_plan_fat_conv(Tc, sp)) return true;      // (register LIF only: T = Tc + 1 = 7 .. 16)
         int q = 32 / Tc;
         if (q > 8) q = 8;
         return sparse_plan_wn(Tc, 1, q, sp);
@@ -1064,7 +1071,7 @@ static int gemm3_lif_sparse(const Gemm3Args& a, bool conv, void* side, size_t si
     // (the kernel addresses both the raw and the compressed planes by 32-bit offsets from the raw planes)
     if ((const char*)cmp < (const char*)a.A || (unsigned long long)((const char*)cmp - (const char*)a.A) + cmp_bytes > 0xffffffffULL) return 0;
     if (mode == SPARSE_QUERY) return 1;
-    const void* kern = sp.fat ? (conv ? (const void*)k_gemm_lif_sparse<true, 1, true> : (const void*)k_gemm_lif_sparse<false, 2, true>)
+    const void* kern = sp.fat ? (conv ? (sp.wn == 1 ? (const void*)k_gemm_lif_sparse<true, 1, true> : (const void*)k_gemm_lif_sparse<true, 2, true>) : (const void*)k_gemm_lif_sparse<false, 2, true>)
                               : conv ? (const void*)k_gemm_lif_sparse<true, 1> : sp.wn == 2 ? (const void*)k_gemm_lif_sparse<false, 2> : (const void*)k_gemm_lif_sparse<false, 1>;
     hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, sh.lds);
     if (e != hipSuccess) return fail(-3, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -1134,7 +1141,7 @@ int snn_debug_tile_shape(int conv, long long units, int k_in, int n_cols, int nu
         const SparsePlan& sp = sh.sp;
         int slots = 0;
         for (int w = 0; w < (sp.fat ? 4 : 8) / sp.wn; ++w) slots += sp.w_nd[w] + sp.w_ns[w];
-        out[0] = sp.fat ? (sp.wn == 1 ? SP_MT_FAT : SP_MT2_FAT) : sp.wn == 1 ? SP_MT : SP_MT2; out[1] = sp.fat; out[2] = Tc * sp.pb; out[3] = sp.pb; out[4] = Tc; out[5] = sh.n_tiles * sh.n_blocks;
+        out[0] = sp.fat ? (sp.wn == 1 ? SP_MT_FAT : conv ? SP_MT2_FAT_CONV : SP_MT2_FAT) : sp.wn == 1 ? SP_MT : SP_MT2; out[1] = sp.fat; out[2] = Tc * sp.pb; out[3] = sp.pb; out[4] = Tc; out[5] = sh.n_tiles * sh.n_blocks;
         out[6] = sh.n_blocks; out[7] = sp.wn; out[8] = 1; out[9] = sp.nd; out[10] = Tc - sp.nd; out[11] = slots;
         return 0;
     }

@@ -32,8 +32,9 @@ typedef __bf16 bfv16 __attribute__((ext_vector_type(16)));
 #define SP_MT 4                                     // M-tile slots per wave on the 8 x 1 wave grid (all waves span the 64 columns)
 #define SP_MT2 6                                    // ... per ROW-wave on the 4 x 2 grid (two waves of 32 columns share a row-wave's slots)
 #define SP_MT2_FAT 12                               // ... per row-wave of the FAT shape (linear layers): 2 x 2 waves of up to 256 registers, 32 columns per wave
-#define SP_MT_FAT 8                                 // ... per wave of the FAT conv: 4 waves x all 64 columns, every wave ALL planes of its own 16 positions (register LIF)
-#define SP_MTMAX 12
+#define SP_MT_FAT 8                                 // ... per wave of the FAT conv, T <= 9: 4 waves x all 64 columns, every wave ALL planes of its own 16 positions (register LIF)
+#define SP_MT2_FAT_CONV 16                          // ... per row-wave of the FAT conv, T = 12 .. 16: 2 x 2 waves, a row-wave = all planes of its 16 positions, 32 columns per wave
+#define SP_MTMAX 16
 #define SP_ROWS (8 * SP_MT * 16)                    // physical tile rows (512; 4 x 6 x 16 = 384 on the 4 x 2 grid)
 // (SP_A_ARR and sp_nibble_code live in snn_common.h: the RPN encoder writes the same compressed layout)
 #define SP_A_BYTES (SP_A_ARR * SP_ROWS * 4)
@@ -283,8 +284,8 @@ __global__ __launch_bounds__(256) void k_sum_pos_counts(const PosCountArgs a) {
 // row r at once (four independent chains), the ballot of N-tile nt holds in bits 16 lg .. 16 lg + 15 the half-word (columns 16 nt ..) of
 // position 4 lg + r, and lane lr of group lg keeps the word (step 1 + (lr >> 1), columns 32 (lr & 1) ..) of its position - 16 (step, word)
 // combinations per position for TS <= 9; step 0 never spikes (its plane is written as zeros).
-template <int TS, int D, int NTL, int MTS_>
-__device__ __forceinline__ void sp_lif_regs(const f32x4 (&acc)[MTS_][NTL], const NeuronP& p, const int lane, uint32_t (&mine)[4]) {
+template <int TS, int D, int NTL, int MTS_, bool COUNT>
+__device__ __forceinline__ void sp_lif_regs(const f32x4 (&acc)[MTS_][NTL], const NeuronP& p, const int lane, uint32_t (&mine)[4], uint32_t (&cnt)[4]) {
     constexpr int TCS = TS - D;                          // conv: D = 1; fc6: D = 2 (dead time steps)
     static_assert(NTL == 4 || NTL == 2, "64 columns (two words per position) or 32 (one)");
     static_assert(TCS <= MTS_ && TS - 1 <= (NTL == 4 ? 8 : 16), "all planes of a block in one wave; 16 (step, word) lanes per position");
@@ -294,7 +295,7 @@ __device__ __forceinline__ void sp_lif_regs(const f32x4 (&acc)[MTS_][NTL], const
         float vv[NTL], ii[NTL];
 #pragma unroll
         for (int nt = 0; nt < NTL; ++nt) { vv[nt] = 0.0f; ii[nt] = 0.0f; }
-        uint32_t keep = 0;
+        uint32_t keep = 0, count = 0;
 #pragma unroll
         for (int t = 0; t < TS; ++t) {
             unsigned long long b[NTL];
@@ -318,14 +319,17 @@ __device__ __forceinline__ void sp_lif_regs(const f32x4 (&acc)[MTS_][NTL], const
             }
             if (t == 0) continue;
             const uint32_t w0 = ((uint32_t)(b[0] >> sh) & 0xffffu) | ((uint32_t)(b[1] >> sh) << 16);
+            uint32_t w1 = 0;
             if constexpr (NTL == 4) {                    // lane lr <-> (step 1 + (lr >> 1), word lr & 1)
-                const uint32_t w1 = ((uint32_t)(b[2] >> sh) & 0xffffu) | ((uint32_t)(b[3] >> sh) << 16);
+                w1 = ((uint32_t)(b[2] >> sh) & 0xffffu) | ((uint32_t)(b[3] >> sh) << 16);
                 keep = (lr >> 1) == t - 1 ? ((lr & 1) ? w1 : w0) : keep;
             } else {                                     // lane lr <-> step 1 + lr
                 keep = lr == t - 1 ? w0 : keep;
             }
+            if (COUNT) count += (uint32_t)__builtin_popcount(w0) + (uint32_t)__builtin_popcount(w1);     // (spike-rate mode: this position's spikes of the step)
         }
         mine[r] = keep;
+        cnt[r] = count;
     }
 }
 
@@ -344,9 +348,9 @@ __device__ __forceinline__ void sp_lif_regs(const f32x4 (&acc)[MTS_][NTL], const
 // SIMD leave the pipe idle at every barrier.)
 template <bool CONV, int WN, bool FAT = false>
 __global__ __launch_bounds__(FAT ? 256 : 512, FAT ? 2 : 4) void k_gemm_lif_sparse(const SparseConvArgs args) {
-    static_assert(!FAT || (WN == 2 && !CONV) || (WN == 1 && CONV), "the FAT shape: linear layers on 2 x 2 waves, the conv on 4 x 1");
+    // (FAT: linear layers on 2 x 2 waves; the conv on 4 x 1 for T <= 9, on 2 x 2 beyond)
     constexpr int NWAVES = FAT ? 4 : 8;
-    constexpr int MTS = FAT ? (WN == 1 ? SP_MT_FAT : SP_MT2_FAT) : WN == 1 ? SP_MT : SP_MT2, NT = 4 / WN;      // slots per (row-)wave, 16-column N-tiles per wave
+    constexpr int MTS = FAT ? (WN == 1 ? SP_MT_FAT : CONV ? SP_MT2_FAT_CONV : SP_MT2_FAT) : WN == 1 ? SP_MT : SP_MT2, NT = 4 / WN;      // slots per (row-)wave, 16-column N-tiles per wave
     constexpr int ROWS = SP_ROWS;                                   // physical tile rows of a ring slot (row-waves x MTS x 16 <= 512 in every shape)
     static_assert((NWAVES / WN) * MTS * 16 <= SP_ROWS, "ring slot rows");
     constexpr int A_BYTES = SP_A_ARR * ROWS * 4, SLOT = A_BYTES + SP_B_BYTES;
@@ -392,7 +396,7 @@ __global__ __launch_bounds__(FAT ? 256 : 512, FAT ? 2 : 4) void k_gemm_lif_spars
     const int nd_w = __builtin_amdgcn_readfirstlane((int)args.w_nd[wm]), ns_w = __builtin_amdgcn_readfirstlane((int)args.w_ns[wm]);
     // ---- A staging: lane L of the wave stages row L & 15 of one M-tile slot of its row-wave.  WN = 1: slot L >> 4 (64 rows per wave);
     // WN = 2: the two column-waves of a row-wave take three slots each (lanes 0 .. 47).  FAT: two passes - WN = 1: the wave's eight slots
-    // (64 + 64 lanes); WN = 2: six slots per column-wave (64 + 32 lanes)
+    // (64 + 64 lanes); WN = 2: half the row-wave's slots per column-wave (six: 64 + 32 lanes; eight - the conv: 64 + 64)
     const void* a_base[SP_A_ARR];
 #pragma unroll
     for (int j = 0; j < SP_A_ARR; ++j) a_base[j] = sgpr_ptr(reinterpret_cast<const char*>(args.enc) + (size_t)j * args.Pe * 4);
@@ -402,8 +406,8 @@ __global__ __launch_bounds__(FAT ? 256 : 512, FAT ? 2 : 4) void k_gemm_lif_spars
     uint32_t tap_fix[NPASS], row_fix[NPASS];
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
-        const int xs = FAT ? (WN == 1 ? 4 * ps + (lane >> 4) : min(6 * wn + 4 * ps + (lane >> 4), MTS - 1)) : WN == 1 ? (lane >> 4) : min(3 * wn + (lane >> 4), MTS - 1);
-        a_lane[ps] = FAT ? (WN == 1 || lane < (ps == 0 ? 64 : 32)) : (WN == 1 || lane < 48);
+        const int xs = FAT ? (WN == 1 ? 4 * ps + (lane >> 4) : min((MTS / 2) * wn + 4 * ps + (lane >> 4), MTS - 1)) : WN == 1 ? (lane >> 4) : min(3 * wn + (lane >> 4), MTS - 1);
+        a_lane[ps] = FAT ? (WN == 1 || lane < (ps == 0 ? 64 : (MTS / 2 - 4) * 16)) : (WN == 1 || lane < 48);
         const int xplane = args.mt_plane[wm][xs];
         const bool xused = xplane >= 0, xdense = xused && xplane < args.nd;
         const int lp = min(args.mt_j[wm][xs] * 16 + (lane & 15), pb - 1);
@@ -435,7 +439,7 @@ __global__ __launch_bounds__(FAT ? 256 : 512, FAT ? 2 : 4) void k_gemm_lif_spars
         row_fix[ps] = (uint32_t)((W + 2 - 3) * 4);          // after the third tap of a row: one padded image row down
     }
     // physical row (wm MTS + slot) 16 + r; a pass covers four slots
-    const uint32_t a_dst = smem_base + G3_LUT_BYTES + (FAT ? (wm * MTS + (WN == 1 ? 0 : 6 * wn)) * 64 : WN == 1 ? wave * 256 : (wm * MTS + 3 * wn) * 64);
+    const uint32_t a_dst = smem_base + G3_LUT_BYTES + (FAT ? (wm * MTS + (WN == 1 ? 0 : (MTS / 2) * wn)) * 64 : WN == 1 ? wave * 256 : (wm * MTS + 3 * wn) * 64);
     const int cw2_s = __builtin_amdgcn_readfirstlane(args.Cw / 2);
     int f_c = 0, f_tap = 0;
     auto stage_a = [&](const uint32_t slot_off) __attribute__((always_inline)) {
@@ -514,82 +518,102 @@ __global__ __launch_bounds__(FAT ? 256 : 512, FAT ? 2 : 4) void k_gemm_lif_spars
                 stage_b(o_nxt);
 #endif
             }
-            // A fragments of this step
-            bfv8 ad[ND > 0 ? ND : 1][2], as[NS > 0 ? NS : 1];
-            int ix[NS > 0 ? NS : 1];
-            unsigned long long sec[3] = {0, 0, 0};                // bits 16 q .. 16 q + 15 of word b = sparse slot 4 b + q
-#ifdef SNN_EXP_SP_NO_AREAD                            // (timing experiment: no LDS reads on the A side - wrong results)
-#pragma unroll
-            for (int d = 0; d < ND; ++d) { ad[d][0] = exp_a; ad[d][1] = exp_a; }
-#pragma unroll
-            for (int q = 0; q < NS; ++q) { as[q] = exp_a; ix[q] = 0x4444; }
-#else
-#pragma unroll
-            for (int d = 0; d < ND; ++d)
-#pragma unroll
-                for (int c2 = 0; c2 < 2; ++c2) {
-                    const uint32_t byte = *reinterpret_cast<const uint8_t*>(a_rd + o_cur + c2 * (ROWS * 4) + d * 64 + lg);
-                    ad[d][c2] = *reinterpret_cast<const bfv8*>(lut + (byte << 4));
-                }
-#pragma unroll
-            for (int q = 0; q < NS; ++q) {
-                const unsigned char* r = a_rd + o_cur + (ND + q) * 64;
-                const uint32_t occ = *reinterpret_cast<const uint8_t*>(r + lg);
-                as[q] = *reinterpret_cast<const bfv8*>(lut + (occ << 4));
-                ix[q] = (int)*reinterpret_cast<const uint16_t*>(r + (1 + (lg >> 1)) * (ROWS * 4) + 2 * (lg & 1));
-            }
             // which of the sparse M-tiles hold a third spike of a nibble in this step?  Lane L looks at the secondary occupancy dword of
-            // row L & 15 of sparse slot L >> 4 (more than four sparse slots: a second / third look)
+            // row L & 15 of sparse slot L >> 4 (more than four sparse slots: a second / third / fourth look)
+            unsigned long long sec[4] = {0, 0, 0, 0};             // bits 16 q .. 16 q + 15 of word b = sparse slot 4 b + q
+#ifndef SNN_EXP_SP_NO_AREAD
 #pragma unroll
             for (int b4 = 0; b4 < (NS + 3) / 4; ++b4) {
                 const uint32_t o2 = *reinterpret_cast<const uint32_t*>(a_rd + o_cur + 3 * (ROWS * 4) + min(ND + 4 * b4 + lg, MTS - 1) * 64);
                 sec[b4] = __ballot(o2 != 0u) & (NS - 4 * b4 >= 4 ? ~0ull : ((1ull << (16 * (NS - 4 * b4))) - 1ull));
             }
 #endif
-            // weight fragments of group g = (N-tile g / 3, plane 2 - g % 3: small terms first): both 32-deep chunks of the step as ONE 16-element
-            // operand (the structured-sparse instruction's B; its halves are the dense instruction's B of chunk c, c + 1), double-buffered by
-            // the parity of g - the loads land in the halves of the buffer the next group reads, no register copies (round 5: the compiler
-            // rotated an 8-register pair per group with v_mov_b64)
-            bfv16 bbuf[BDEPTH + 1];
-            auto load_b = [&](bfv16& dst, const int gn) __attribute__((always_inline)) {
-#ifdef SNN_EXP_SP_NO_BREAD                            // (timing experiment: the weight fragments stay what they were before the loop)
-                const bfv8 lo = exp_b0, hi = exp_b1;
+            // The step's products, in one part or - the largest row-wave, 15 M-tiles: no registers for all A fragments at once - in two (each
+            // reads the weight fragments; every accumulator still sees its instructions in the same order).  part = the dense M-tiles (if
+            // DENSE) and the sparse slots Q0 .. Q1 - 1
+            auto do_part = [&](auto q0_c, auto q1_c, auto dense_c) __attribute__((always_inline)) {
+                constexpr int Q0 = decltype(q0_c)::value, Q1 = decltype(q1_c)::value, NQ = Q1 - Q0;
+                constexpr bool DENSE = decltype(dense_c)::value && ND > 0;
+                // A fragments of this part
+                bfv8 ad[ND > 0 ? ND : 1][2], as[NQ > 0 ? NQ : 1];
+                int ix[NQ > 0 ? NQ : 1];
+#ifdef SNN_EXP_SP_NO_AREAD                            // (timing experiment: no LDS reads on the A side - wrong results)
+#pragma unroll
+                for (int d = 0; d < ND; ++d) { ad[d][0] = exp_a; ad[d][1] = exp_a; }
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) { as[q] = exp_a; ix[q] = 0x4444; }
 #else
-                const bfv8 lo = *reinterpret_cast<const bfv8*>(b_rd + o_cur + (2 - gn % 3) * (64 * G3_ROWB) + (gn / 3) * 16 * G3_ROWB);
-                const bfv8 hi = *reinterpret_cast<const bfv8*>(b_rd + o_cur + 3 * 64 * G3_ROWB + (2 - gn % 3) * (64 * G3_ROWB) + (gn / 3) * 16 * G3_ROWB);
-#endif
-                dst = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
-            };
+                if (DENSE) {
 #pragma unroll
-            for (int g0 = 0; g0 < BDEPTH; ++g0) load_b(bbuf[g0], g0);
+                    for (int d = 0; d < ND; ++d)
 #pragma unroll
-            for (int g = 0; g < 3 * NT; ++g) {
-#ifndef SNN_EXP_SP_NO_BREAD
-                if (g + BDEPTH < 3 * NT) load_b(bbuf[(g + BDEPTH) % (BDEPTH + 1)], g + BDEPTH);
-#endif
-                const bfv16 bb = bbuf[SNN_EXP_BSEL(g) % (BDEPTH + 1)];
-#ifndef SNN_EXP_SP_NO_MFMA                            // (timing experiment: everything but the matrix instructions)
-                if (ND > 0) {
-                    const bfv8 b0 = __builtin_shufflevector(bb, bb, 0, 1, 2, 3, 4, 5, 6, 7), b1 = __builtin_shufflevector(bb, bb, 8, 9, 10, 11, 12, 13, 14, 15);
-#pragma unroll
-                    for (int d = 0; d < ND; ++d) {
-                        acc[d][g / 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ad[d][0], b0, acc[d][g / 3], 0, 0, 0);
-                        acc[d][g / 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ad[d][1], b1, acc[d][g / 3], 0, 0, 0);
-                    }
+                        for (int c2 = 0; c2 < 2; ++c2) {
+                            const uint32_t byte = *reinterpret_cast<const uint8_t*>(a_rd + o_cur + c2 * (ROWS * 4) + d * 64 + lg);
+                            ad[d][c2] = *reinterpret_cast<const bfv8*>(lut + (byte << 4));
+                        }
                 }
 #pragma unroll
-                for (int q = 0; q < NS; ++q)
-                    acc[ND + q][g / 3] = __builtin_amdgcn_smfmac_f32_16x16x64_bf16(as[q], bb, acc[ND + q][g / 3], ix[q], 0, 0);
-#else
-                asm volatile("" :: "v"(bb));
-#pragma unroll
-                for (int d = 0; d < ND; ++d) asm volatile("" :: "v"(ad[d][0]), "v"(ad[d][1]));
-#pragma unroll
-                for (int q = 0; q < NS; ++q) asm volatile("" :: "v"(as[q]), "v"(ix[q]));
+                for (int q = 0; q < NQ; ++q) {
+                    const unsigned char* r = a_rd + o_cur + (ND + Q0 + q) * 64;
+                    const uint32_t occ = *reinterpret_cast<const uint8_t*>(r + lg);
+                    as[q] = *reinterpret_cast<const bfv8*>(lut + (occ << 4));
+                    ix[q] = (int)*reinterpret_cast<const uint16_t*>(r + (1 + (lg >> 1)) * (ROWS * 4) + 2 * (lg & 1));
+                }
 #endif
-                __builtin_amdgcn_sched_barrier(0);
+                // weight fragments of group g = (N-tile g / 3, plane 2 - g % 3: small terms first): both 32-deep chunks of the step as ONE
+                // 16-element operand (the structured-sparse instruction's B; its halves are the dense instruction's B of chunk c, c + 1),
+                // buffered by g modulo the depth - the loads land in the halves of the buffer a later group reads, no register copies
+                constexpr int BD = (FAT && ND + NS > 12) ? 1 : BDEPTH;   // (the largest row-waves have no registers for a third buffer)
+                bfv16 bbuf[BD + 1];
+                auto load_b = [&](bfv16& dst, const int gn) __attribute__((always_inline)) {
+#ifdef SNN_EXP_SP_NO_BREAD                            // (timing experiment: the weight fragments stay what they were before the loop)
+                    const bfv8 lo = exp_b0, hi = exp_b1;
+#else
+                    const bfv8 lo = *reinterpret_cast<const bfv8*>(b_rd + o_cur + (2 - gn % 3) * (64 * G3_ROWB) + (gn / 3) * 16 * G3_ROWB);
+                    const bfv8 hi = *reinterpret_cast<const bfv8*>(b_rd + o_cur + 3 * 64 * G3_ROWB + (2 - gn % 3) * (64 * G3_ROWB) + (gn / 3) * 16 * G3_ROWB);
+#endif
+                    dst = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+                };
+#pragma unroll
+                for (int g0 = 0; g0 < BD; ++g0) load_b(bbuf[g0], g0);
+#pragma unroll
+                for (int g = 0; g < 3 * NT; ++g) {
+#ifndef SNN_EXP_SP_NO_BREAD
+                    if (g + BD < 3 * NT) load_b(bbuf[(g + BD) % (BD + 1)], g + BD);
+#endif
+                    const bfv16 bb = bbuf[SNN_EXP_BSEL(g) % (BD + 1)];
+#ifndef SNN_EXP_SP_NO_MFMA                            // (timing experiment: everything but the matrix instructions)
+                    if (DENSE) {
+                        const bfv8 b0 = __builtin_shufflevector(bb, bb, 0, 1, 2, 3, 4, 5, 6, 7), b1 = __builtin_shufflevector(bb, bb, 8, 9, 10, 11, 12, 13, 14, 15);
+#pragma unroll
+                        for (int d = 0; d < ND; ++d) {
+                            acc[d][g / 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ad[d][0], b0, acc[d][g / 3], 0, 0, 0);
+                            acc[d][g / 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ad[d][1], b1, acc[d][g / 3], 0, 0, 0);
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q)
+                        acc[ND + Q0 + q][g / 3] = __builtin_amdgcn_smfmac_f32_16x16x64_bf16(as[q], bb, acc[ND + Q0 + q][g / 3], ix[q], 0, 0);
+#else
+                    asm volatile("" :: "v"(bb));
+                    if (DENSE) {
+#pragma unroll
+                        for (int d = 0; d < ND; ++d) asm volatile("" :: "v"(ad[d][0]), "v"(ad[d][1]));
+                    }
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) asm volatile("" :: "v"(as[q]), "v"(ix[q]));
+#endif
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            if constexpr (FAT && ND + NS > 14) {
+                constexpr int QS = (NS - 2 * ND + 1) / 2;          // (two parts of about equal matrix work: a dense M-tile counts twice)
+                do_part(std::integral_constant<int, 0>{}, std::integral_constant<int, QS>{}, std::true_type{});
+                do_part(std::integral_constant<int, QS>{}, std::integral_constant<int, NS>{}, std::false_type{});
+            } else {
+                do_part(std::integral_constant<int, 0>{}, std::integral_constant<int, NS>{}, std::true_type{});
             }
-            if (NS > 0 && (sec[0] | sec[1] | sec[2]) != 0ull) {   // (rare) the secondary plane of the M-tiles that have one in this step
+            if (NS > 0 && (sec[0] | sec[1] | sec[2] | sec[3]) != 0ull) {   // (rare) the secondary plane of the M-tiles that have one in this step
 #pragma unroll
                 for (int q = 0; q < NS; ++q) {
                     if (((sec[q >> 2] >> (16 * (q & 3))) & 0xffffull) == 0ull) continue;
@@ -621,12 +645,17 @@ __global__ __launch_bounds__(FAT ? 256 : 512, FAT ? 2 : 4) void k_gemm_lif_spars
 // hold 128 / 80 positions there against the FAT conv's 64: profiles/r5_fat_conv_ab.txt)
 #define SP_FAT1_INSTANCES {2, 5}, {2, 4}, {2, 6}
 #define SP_FAT1_CASES SP_CASE(2, 5) SP_CASE(2, 4) SP_CASE(2, 6)
+// FAT conv on 2 x 2 waves, T = 12 .. 16 (instances from T = 10: 10 / 11 measured slower than the 8-wave shape): every row-wave (2 dense, Tc - 2 sparse)
+#define SP_FAT1B_INSTANCES {2, 7}, {2, 8}, {2, 9}, {2, 10}, {2, 11}, {2, 12}, {2, 13}
+#define SP_FAT1B_CASES SP_CASE(2, 7) SP_CASE(2, 8) SP_CASE(2, 9) SP_CASE(2, 10) SP_CASE(2, 11) SP_CASE(2, 12) SP_CASE(2, 13)
 #define SP_FAT2_INSTANCES {2, 8}, {2, 7}, {2, 9}, {2, 10}, {2, 6}, {2, 5}, {2, 4}, {2, 3}, {2, 2}, {1, 10}, {1, 11}, {1, 9}, {1, 8}, {1, 7}, {1, 6}, {1, 5}
 #define SP_FAT2_CASES SP_CASE(2, 8) SP_CASE(2, 7) SP_CASE(2, 9) SP_CASE(2, 10) SP_CASE(2, 6) SP_CASE(2, 5) SP_CASE(2, 4) SP_CASE(2, 3) SP_CASE(2, 2) \
                       SP_CASE(1, 10) SP_CASE(1, 11) SP_CASE(1, 9) SP_CASE(1, 8) SP_CASE(1, 7) SP_CASE(1, 6) SP_CASE(1, 5)
 #define SP_CASE(ND_, NS_) if (nd_w == ND_ && ns_w == NS_) step_loop(std::integral_constant<int, ND_>{}, std::integral_constant<int, NS_>{}); else
-    if constexpr (FAT && CONV) {
+    if constexpr (FAT && CONV && WN == 1) {
         SP_FAT1_CASES { step_loop(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}); }
+    } else if constexpr (FAT && CONV) {
+        SP_FAT1B_CASES { step_loop(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}); }
     } else if constexpr (FAT) {
         SP_FAT2_CASES { step_loop(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}); }
     } else if constexpr (WN == 1) {
@@ -647,17 +676,21 @@ __global__ __launch_bounds__(FAT ? 256 : 512, FAT ? 2 : 4) void k_gemm_lif_spars
 #ifdef SNN_EXP_TIMELINE
     SP_TL_STAMP(2);
 #endif
-    if (FAT && args.lif_regs) {                                    // (block-uniform)
+    if (FAT && (CONV || args.lif_regs)) {                          // (block-uniform; the FAT conv has no other epilogue: its launcher plans it only where an instance exists)
         // ---- epilogue of the FAT shapes: the LIF in registers (sp_lif_regs), each (row-)wave for its own 16 positions / RoIs; no LDS, no barrier
         if constexpr (FAT) {
             const int T = args.T;
-            uint32_t mine[4] = {0, 0, 0, 0};
-#define SP_R(n) case n: sp_lif_regs<n, CONV ? 1 : 2, NT, MTS>(acc, args.p, lane, mine); break;
-            if constexpr (CONV) { switch (T) { SP_R(7) SP_R(8) SP_R(9) default: break; } }
+            uint32_t mine[4] = {0, 0, 0, 0}, cnt[4] = {0, 0, 0, 0};
+            const bool counting = args.cnt_row != nullptr;
+#define SP_R(n) case n: if (counting) sp_lif_regs<n, CONV ? 1 : 2, NT, MTS, true>(acc, args.p, lane, mine, cnt); \
+                        else sp_lif_regs<n, CONV ? 1 : 2, NT, MTS, false>(acc, args.p, lane, mine, cnt); break;
+            if constexpr (CONV && WN == 1) { switch (T) { SP_R(7) SP_R(8) SP_R(9) default: break; } }
+            else if constexpr (CONV) { switch (T) { SP_R(10) SP_R(11) SP_R(12) SP_R(13) SP_R(14) SP_R(15) SP_R(16) default: break; } }
             else { switch (T) { SP_R(6) SP_R(7) SP_R(8) SP_R(9) SP_R(10) SP_R(11) SP_R(12) SP_R(13) SP_R(14) default: break; } }
 #undef SP_R
-            // this lane's (step, word): 64 columns = two words per position (conv), 32 columns per column-wave = one (linear)
-            const int t_mine = 1 + (CONV ? ((lane & 15) >> 1) : (lane & 15)), word = CONV ? nb * 2 + (lane & 1) : nb * 2 + wn;
+            // this lane's (step, word): 64 columns per wave = two words per position (lane lr <-> step 1 + (lr >> 1), word lr & 1), 32 columns per
+            // column-wave = one (lane lr <-> step 1 + lr)
+            const int t_mine = 1 + (NT == 4 ? ((lane & 15) >> 1) : (lane & 15)), word = NT == 4 ? nb * 2 + (lane & 1) : nb * 2 + wn;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int lp = 16 * wm + 4 * lg + r, pos = m0 + lp;
@@ -667,7 +700,8 @@ __global__ __launch_bounds__(FAT ? 256 : 512, FAT ? 2 : 4) void k_gemm_lif_spars
                 else if (args.out_split) dst = args.spk + ((size_t)(word >> 2) * M + pos) * 4 + (word & 3);
                 else dst = args.spk + (size_t)pos * (Np >> 5) + word;
                 if (t_mine < T) dst[(size_t)t_mine * args.spk_stride] = mine[r];
-                if ((lane & 15) < (CONV ? 2 : 1)) dst[0] = 0u;                         // step 0: no spike
+                if ((lane & 15) < (NT == 4 ? 2 : 1)) dst[0] = 0u;                      // step 0: no spike
+                if (counting && (lane & 15) == 0 && cnt[r]) atomicAdd(args.cnt_row + pos, cnt[r]);      // (this wave's 32 / 64 columns of the position / RoI)
             }
 #ifdef SNN_EXP_TIMELINE
             SP_TL_STAMP(7); SP_TL_STAMP(3);

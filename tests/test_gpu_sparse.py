@@ -398,36 +398,39 @@ def test_detector_encoder_fold_writes_the_same_planes(gpu_device, monkeypatch, R
 
 
 # ---- the FAT conv (four waves, each ALL planes of its own 16 positions, the LIF in registers - no tile image) ---------------------------
-@pytest.mark.parametrize("T", [7, 8, 9])
+@pytest.mark.parametrize("T", [7, 8, 9, 10, 12, 13, 16])
 @pytest.mark.parametrize("C", [256, 64, 128])
 def test_fat_conv_register_lif_is_bit_identical(gpu_device, monkeypatch, T, C):
-    """same matrix instructions per accumulator, same LIF operations in the same order: the spike planes - and so the outputs - equal the
-    8-wave shape's bit for bit (pyramid with partial tiles and tiles that straddle levels)"""
+    """same matrix instructions per accumulator, same LIF operations in the same order: the spike planes - and so the outputs and the
+    integer spike counts of spike-rate mode - equal the 8-wave shape's bit for bit (pyramid with partial tiles and tiles that straddle
+    levels).  T <= 9: 4 x 1 waves, tiles of 64 positions; T = 12 .. 16: 2 x 2 waves, tiles of 32"""
+    import ctypes as Ct
+    from snn_automotive_object_detection_amd import _lib
     m = _head(gpu_device, C, T, 90 + T)
     g = torch.Generator().manual_seed(90 + T + C)
     feats = [(torch.randn(2, C, h, w, generator=g) * 1.7).to(gpu_device) for h, w in [(41, 67), (19, 27), (7, 9), (1, 3)]]
     monkeypatch.setenv("SNN_SPARSE_FAT_CONV", "0")
     a = _run(m, feats, sparse=True)
     planes_a = _rpn_hidden_planes(gpu_device, T, C // 32)
-    monkeypatch.setenv("SNN_SPARSE_FAT_CONV", "1")
+    monkeypatch.setenv("SNN_SPARSE_FAT_CONV", "3")
+    o12 = (Ct.c_int32 * 12)()
+    pos = sum(2 * f.shape[2] * f.shape[3] for f in feats)
+    fat = T <= 9 or T >= 12                                     # (T = 10, 11: the 8-wave shape's tiles of 48 positions are faster)
+    for rates in (0, 1):
+        assert _lib.load().snn_debug_tile_shape(1, pos, C, C, T, rates, 0, o12) == 0 and o12[8] == 1 and o12[1] == int(fat), list(o12)
+        assert o12[3] == (64 if T <= 9 else 32 if fat else 48), list(o12)
     for _ in range(3):
         b = _run(m, feats, sparse=True)
         planes_b = _rpn_hidden_planes(gpu_device, T, C // 32)
         assert torch.equal(planes_a, planes_b), int((planes_a != planes_b).sum())
         assert all(torch.equal(x, y) for x, y in zip(a, b))
     assert int((planes_a != 0).sum()) > 0
-    import ctypes as Ct
-    from snn_automotive_object_detection_amd import _lib
-    o12 = (Ct.c_int32 * 12)()
-    pos = sum(2 * f.shape[2] * f.shape[3] for f in feats)
-    assert _lib.load().snn_debug_tile_shape(1, pos, C, C, T, 0, 0, o12) == 0 and o12[8] == 1 and o12[1] == 1 and o12[3] == 64, list(o12)
-    assert _lib.load().snn_debug_tile_shape(1, pos, C, C, T, 1, 0, o12) == 0 and o12[8] == 1 and o12[1] == 0, list(o12)      # counting launches: the 8-wave shape
-    m.spike_rates = True
+    m.spike_rates = True                                        # the register LIF counts spikes too (per-position atomics, then k_sum_pos_counts)
     m(feats)
     c1 = m.last_spike_counts.clone()
     monkeypatch.setenv("SNN_SPARSE_FAT_CONV", "0")
     m(feats)
-    assert torch.equal(c1, m.last_spike_counts)
+    assert torch.equal(c1, m.last_spike_counts) and int(c1.sum()) > 0
 
 
 @pytest.mark.parametrize("R,C,Hd,K,T", [(2000, 256, 1024, 9, 12), (2000, 256, 1024, 9, 14), (333, 64, 256, 11, 11), (77, 64, 128, 5, 12), (31, 64, 128, 5, 9), (1, 64, 128, 5, 13)])

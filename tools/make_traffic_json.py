@@ -1,6 +1,6 @@
 """Build profiles/r5_traffic.json from the summaries of tools/prof_round.sh (kernel stats + the five separate PMC passes), one per bench
 workload:   python tools/make_traffic_json.py profiles/r5_traffic.json cityscapes=profiles/r5_default_summary.txt stress=... bdd=...
-Per workload and big launch (conv = k_gemm_lif_sparse<true, 1>, fc6 = k_gemm_lif_sparse<false, ...>, fc7 = k_gemm_bf16x3<4, ...>): HBM bytes per launch
+Per workload and big launch (conv = k_gemm_lif_sparse<true, ...>, fc6 = k_gemm_lif_sparse<false, ...>, fc7 = k_gemm_bf16x3<4, ...>): HBM bytes per launch
 (2 x FETCH_SIZE + WRITE_SIZE, counter unit 1 KiB: MI355X_MICROARCH.md, HBM section; calibrated for this family's LDS-DMA gathers by
 tools/fetch_calib.hip), matrix-pipe busy fraction, clock, matrix instructions, L2 hits / misses - what bench.py quotes as `roofline.traffic`
 of each leg and what a reader needs to recompute every leg's `frac`."""
@@ -13,7 +13,7 @@ WORKLOADS = {  # shapes of bench.py's workloads: positions of the pyramid (batch
     "bdd": dict(levels=[(192, 344), (96, 172), (48, 86), (24, 43), (12, 22)], batch=4, T_rpn=8, R=4000, T_det=12, rates=False),
     "stress": dict(levels=[(192, 384), (96, 192), (48, 96), (24, 48), (12, 24)], batch=2, T_rpn=16, R=2000, T_det=24, rates=True),
 }
-KERNELS = {"conv": "k_gemm_lif_sparse<true, 1", "fc6": "k_gemm_lif_sparse<false,", "fc7": "k_gemm_bf16x3<4,"}
+KERNELS = {"conv": "k_gemm_lif_sparse<true,", "fc6": "k_gemm_lif_sparse<false,", "fc7": "k_gemm_bf16x3<4,"}
 
 
 def parse(path):

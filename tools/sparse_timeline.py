@@ -30,8 +30,11 @@ def report(raw, slots, what):
         float((t[:, 1] - t[:, 0]).mean()), float((t[:, 2] - t[:, 1]).mean()), float((t[:, 3] - t[:, 2]).mean()), float((t[:, 4] - t[:, 3]).mean()),
         float((t[:, 4] - t[:, 0]).mean())))
     img = raw[:, 7].double() / 100.0
-    print("epilogue pass 0: accumulators -> tile image (two barriers) %.2f us | LIF recurrence + spike stores %.2f us" % (
-        float((img - t[:, 2]).mean()), float((t[:, 3] - img).mean())))
+    if float((t[:, 4] - t[:, 3]).mean()) < 0.2:                  # FAT shapes with the LIF in registers: one phase (stamps 7 and 3 sit at its end)
+        print("epilogue = LIF in registers + spike stores (no tile image, no barrier): %.2f us" % float((t[:, 3] - t[:, 2]).mean()))
+    else:
+        print("epilogue pass 0: accumulators -> tile image (two barriers) %.2f us | LIF recurrence + spike stores %.2f us" % (
+            float((img - t[:, 2]).mean()), float((t[:, 3] - img).mean())))
     cu = (raw[:, 6] << 16) | (raw[:, 5] & 0x0000ff00) | ((raw[:, 5] >> 13) & 0x7)    # xcc | cu_id / sh / se bits
     ids, counts = torch.unique(cu, return_counts=True)
     print("distinct (XCC, CU) slots seen: %d; work-groups per slot: min %d max %d" % (ids.numel(), int(counts.min()), int(counts.max())))

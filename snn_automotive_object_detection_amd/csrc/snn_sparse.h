@@ -46,6 +46,9 @@ typedef __bf16 bfv16 __attribute__((ext_vector_type(16)));
 #else
 #define SNN_EXP_BSEL(g) (g)
 #endif
+#ifndef SP_PRE_A
+#define SP_PRE_A 1
+#endif
 #define SP_PITCH 36                                 // epilogue tile image: 32 columns + 4 floats of padding per row
 
 struct SparseConvArgs {
@@ -508,6 +511,36 @@ __global__ __launch_bounds__(FAT ? 256 : 512, FAT ? 2 : 4) void k_gemm_lif_spars
 #endif
     auto step_loop = [&](auto nd_c, auto ns_c) __attribute__((always_inline)) {
         constexpr int ND = decltype(nd_c)::value, NS = decltype(ns_c)::value;
+        // A AHEAD (FAT conv on 4 x 1 waves: a wave reads only the rows it staged itself): the next step's A fragments - occupancy bytes, table
+        // fragments, indices, secondary ballots - are requested at the END of a step, once this wave's copies have landed and BEFORE the step
+        // barrier, into the registers the step's own fragments have just left: the byte -> table-fragment chain runs while the wave would wait
+        // at the barrier anyway, and the first matrix instruction behind it finds its operand
+        constexpr bool PRE_A = SP_PRE_A && WN == 1 && FAT;     // (the 512-thread shapes have no register to spare: the 8 x 1 conv spills with it)
+        bfv8 p_ad[ND > 0 ? ND : 1][2], p_as[NS > 0 ? NS : 1];
+        int p_ix[NS > 0 ? NS : 1];
+        unsigned long long p_sec[4] = {0, 0, 0, 0};
+        auto load_a_all = [&](const uint32_t off) __attribute__((always_inline)) {
+#pragma unroll
+            for (int d = 0; d < ND; ++d)
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2) {
+                    const uint32_t byte = *reinterpret_cast<const uint8_t*>(a_rd + off + c2 * (ROWS * 4) + d * 64 + lg);
+                    p_ad[d][c2] = *reinterpret_cast<const bfv8*>(lut + (byte << 4));
+                }
+#pragma unroll
+            for (int q = 0; q < NS; ++q) {
+                const unsigned char* r = a_rd + off + (ND + q) * 64;
+                const uint32_t occ = *reinterpret_cast<const uint8_t*>(r + lg);
+                p_as[q] = *reinterpret_cast<const bfv8*>(lut + (occ << 4));
+                p_ix[q] = (int)*reinterpret_cast<const uint16_t*>(r + (1 + (lg >> 1)) * (ROWS * 4) + 2 * (lg & 1));
+            }
+#pragma unroll
+            for (int b4 = 0; b4 < (NS + 3) / 4; ++b4) {
+                const uint32_t o2 = *reinterpret_cast<const uint32_t*>(a_rd + off + 3 * (ROWS * 4) + min(ND + 4 * b4 + lg, MTS - 1) * 64);
+                p_sec[b4] = __ballot(o2 != 0u) & (NS - 4 * b4 >= 4 ? ~0ull : ((1ull << (16 * (NS - 4 * b4))) - 1ull));
+            }
+        };
+        if constexpr (PRE_A) load_a_all(0);
         for (int s = 0; s < n_steps; ++s) {
             const uint32_t o_cur = (uint32_t)((s & 1) * SLOT), o_nxt = (uint32_t)(((s + 1) & 1) * SLOT);
             if (s + 1 < n_steps) {
@@ -522,10 +555,15 @@ __global__ __launch_bounds__(FAT ? 256 : 512, FAT ? 2 : 4) void k_gemm_lif_spars
             // row L & 15 of sparse slot L >> 4 (more than four sparse slots: a second / third / fourth look)
             unsigned long long sec[4] = {0, 0, 0, 0};             // bits 16 q .. 16 q + 15 of word b = sparse slot 4 b + q
 #ifndef SNN_EXP_SP_NO_AREAD
+            if constexpr (PRE_A) {
 #pragma unroll
-            for (int b4 = 0; b4 < (NS + 3) / 4; ++b4) {
-                const uint32_t o2 = *reinterpret_cast<const uint32_t*>(a_rd + o_cur + 3 * (ROWS * 4) + min(ND + 4 * b4 + lg, MTS - 1) * 64);
-                sec[b4] = __ballot(o2 != 0u) & (NS - 4 * b4 >= 4 ? ~0ull : ((1ull << (16 * (NS - 4 * b4))) - 1ull));
+                for (int b4 = 0; b4 < 4; ++b4) sec[b4] = p_sec[b4];
+            } else {
+#pragma unroll
+                for (int b4 = 0; b4 < (NS + 3) / 4; ++b4) {
+                    const uint32_t o2 = *reinterpret_cast<const uint32_t*>(a_rd + o_cur + 3 * (ROWS * 4) + min(ND + 4 * b4 + lg, MTS - 1) * 64);
+                    sec[b4] = __ballot(o2 != 0u) & (NS - 4 * b4 >= 4 ? ~0ull : ((1ull << (16 * (NS - 4 * b4))) - 1ull));
+                }
             }
 #endif
             // The step's products, in one part or - the largest row-wave, 15 M-tiles: no registers for all A fragments at once - in two (each
@@ -543,21 +581,28 @@ __global__ __launch_bounds__(FAT ? 256 : 512, FAT ? 2 : 4) void k_gemm_lif_spars
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) { as[q] = exp_a; ix[q] = 0x4444; }
 #else
-                if (DENSE) {
+                if constexpr (PRE_A) {                          // (requested at the end of the previous step)
 #pragma unroll
-                    for (int d = 0; d < ND; ++d)
+                    for (int d = 0; d < ND; ++d) { ad[d][0] = p_ad[d][0]; ad[d][1] = p_ad[d][1]; }
 #pragma unroll
-                        for (int c2 = 0; c2 < 2; ++c2) {
-                            const uint32_t byte = *reinterpret_cast<const uint8_t*>(a_rd + o_cur + c2 * (ROWS * 4) + d * 64 + lg);
-                            ad[d][c2] = *reinterpret_cast<const bfv8*>(lut + (byte << 4));
-                        }
-                }
+                    for (int q = 0; q < NQ; ++q) { as[q] = p_as[Q0 + q]; ix[q] = p_ix[Q0 + q]; }
+                } else {
+                    if (DENSE) {
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) {
-                    const unsigned char* r = a_rd + o_cur + (ND + Q0 + q) * 64;
-                    const uint32_t occ = *reinterpret_cast<const uint8_t*>(r + lg);
-                    as[q] = *reinterpret_cast<const bfv8*>(lut + (occ << 4));
-                    ix[q] = (int)*reinterpret_cast<const uint16_t*>(r + (1 + (lg >> 1)) * (ROWS * 4) + 2 * (lg & 1));
+                        for (int d = 0; d < ND; ++d)
+#pragma unroll
+                            for (int c2 = 0; c2 < 2; ++c2) {
+                                const uint32_t byte = *reinterpret_cast<const uint8_t*>(a_rd + o_cur + c2 * (ROWS * 4) + d * 64 + lg);
+                                ad[d][c2] = *reinterpret_cast<const bfv8*>(lut + (byte << 4));
+                            }
+                    }
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        const unsigned char* r = a_rd + o_cur + (ND + Q0 + q) * 64;
+                        const uint32_t occ = *reinterpret_cast<const uint8_t*>(r + lg);
+                        as[q] = *reinterpret_cast<const bfv8*>(lut + (occ << 4));
+                        ix[q] = (int)*reinterpret_cast<const uint16_t*>(r + (1 + (lg >> 1)) * (ROWS * 4) + 2 * (lg & 1));
+                    }
                 }
 #endif
                 // weight fragments of group g = (N-tile g / 3, plane 2 - g % 3: small terms first): both 32-deep chunks of the step as ONE
@@ -634,6 +679,11 @@ __global__ __launch_bounds__(FAT ? 256 : 512, FAT ? 2 : 4) void k_gemm_lif_spars
             }
             asm volatile("" ::: "memory");
             __builtin_amdgcn_s_waitcnt(0x0070);              // vmcnt(0) lgkmcnt(0): the next step's copies have landed
+#ifndef SNN_EXP_SP_NO_AREAD
+            if constexpr (PRE_A) {
+                if (s + 1 < n_steps) load_a_all(o_nxt);       // (this wave's own rows; the table-fragment reads stay in flight across the barrier)
+            }
+#endif
 #ifndef SNN_EXP_SP_NO_BAR                             // (timing experiment: waves run ahead of each other's copies - wrong results)
             __builtin_amdgcn_s_barrier();
 #endif

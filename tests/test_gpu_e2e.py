@@ -106,7 +106,7 @@ def test_create_model_end_to_end_and_heads_in_situ(gpu_device, full, fused):
         det_in = cap["det_in"]
     o_c, o_d = OR.det_head_forward(det_in, dh.fc6.weight.cpu(), dh.fc7.weight.cpu(), dh.cls_score.weight.cpu(),
                                    dh.bbox_pred.weight.cpu(), 12)
-    dd = torch.maximum((cap["det_out"][0] - o_c).abs().amax(1), (cap["det_out"][1] - o_d).abs().amax(1))
+    dd = torch.maximum((cap["det_out"][0] - o_c).abs().amax(1), (cap["det_out"][1] - o_d).abs().amax(1)).detach()     # (the oracle ran on weights that require grad)
     record_parity("e2e_det_head_in_situ", full=full, fused_roialign=fused, rois_off_tolerance=int((dd > 1e-4).sum()), rois=dd.numel(),
                   budget=flip_budget(dd.numel(), 2 * 1024, 12, "det_in_situ"))
     assert int((dd > 1e-4).sum()) <= flip_budget(dd.numel(), 2 * 1024, 12, "det_in_situ")

@@ -1,4 +1,4 @@
-// Structured-sparse matrix cores for the SPARSE period planes of the RPN's shared 3x3 convolution (round 4).  Included by snn_kernels.hip
+// Structured-sparse matrix cores for the SPARSE period planes of the RPN's shared 3x3 convolution and the detector's fc6 (rounds 4-5).  Included by snn_kernels.hip
 // after snn_bf16x3.h (Gemm3-style staging helpers, f2bf / bf2f, G3_SWZ).
 //
 // With period planes (snn_common.h) a conv row tile holds Tc row groups u_n = W e_n, and for n >= 3 the planes are nearly empty
@@ -6,7 +6,7 @@
 // v_smfmac_f32_16x16x64_bf16 multiplies an A operand with at most TWO non-zeros per four consecutive k at 64 k per instruction:
 // 1.82 x the dense rate sustained in this kernel's LDS-fed shape (tools/sparse_probe.hip, profiles/r4_sparse_probe.txt).  So:
 //   * planes e_1, e_2 (densities 0.25 / 0.12: nibbles with three spikes are common) stay on the dense v_mfma_f32_16x16x32_bf16;
-//   * planes e_n, n >= 3, are COMPRESSED (k_compress_planes): per 16 k of a row 8 value slots (occupied or not: the value is 1.0) +
+//   * planes e_n, n >= 3, are COMPRESSED (by the encoder launches themselves since round 5 - snn_encode.h -, else by k_compress_planes): per 16 k of a row 8 value slots (occupied or not: the value is 1.0) +
 //     8 two-bit positions.  The A fragment of a lane is table[occupancy byte] - the dense kernels' byte -> 8 bf16 table - plus 16 index
 //     bits; operand layout and encoding were established on the hardware (sparse_probe A1 / A4);
 //   * a nibble with three or four spikes of ONE period (rare: ~0.16 per position over the five sparse planes) keeps its first two in
@@ -19,11 +19,19 @@
 //     dense fallback launch for inputs that overflowed them: 3.7 % of the conv launch, and a slow path for adversarial inputs.  The
 //     secondary plane needs neither lists nor fallback, and reads its entries through the same 3x3 tap walk as everything else.)
 //
-// Row tile = pb positions x Tc planes as M-tiles of 16 rows (plane t, positions 16 j .. 16 j + 15); each of the 8 waves owns up to
-// four M-tiles, dense ones first (table in SparseConvArgs); a wave's loop is instantiated for its (dense, sparse) counts.  The SIMDs
-// see balanced work (waves w and w + 4 share one), which is what matters: a wave waiting at the step barrier leaves its issue slots
-// to the other waves of its SIMD.  K runs in steps of 64 (two 32-deep chunks of the packed weights, whose LDS image is the dense
-// kernels'); ring = two step slots, one barrier per step.
+// Row tile = pb positions x Tc planes as M-tiles of 16 rows (plane t, positions 16 j .. 16 j + 15), assigned to M-tile SLOTS of the
+// waves (table in SparseConvArgs, dense ones first); a wave's K loop is instantiated for its (dense, sparse) counts.  K runs in steps
+// of 64 (two 32-deep chunks of the packed weights, whose LDS image is the dense kernels'); ring = two step slots, one barrier per step,
+// two work-groups per CU in every shape.  Shapes (k_gemm_lif_sparse<CONV, WN, FAT>; the launcher's planner picks, snn_kernels.hip):
+//   8-wave (512 threads, 128 registers)    8 x 1 waves x 4 slots (conv) or 4 x 2 x 6 (linear layers); LIF through a tile image in LDS,
+//                                          straight-line instances T = 5 .. 16, general (run-time) form for the linear layers beyond
+//   FAT (round 5; 256 threads, <= 256 regs) four waves with twice the slots: half (conv 2 x 2: a quarter) of the weight-fragment reads per
+//                                          matrix instruction, fragments requested two groups ahead.  Linear layers: 2 x 2 x 12.  Conv:
+//                                          4 x 1 x 8 for T = 7 .. 9 (tiles of 64 positions), 2 x 2 x 16 for T = 12 .. 16 (tiles of 32) - every
+//                                          (row-)wave holds ALL planes of its own 16 positions, so the LIF runs in REGISTERS (sp_lif_regs):
+//                                          no tile image, no epilogue barrier; also for fc6 where a row-wave holds all planes of its RoIs
+// All shapes give the same bits: every accumulator sees the same matrix instructions in the same order, and the LIF forms are the same
+// operations in the same order (tests/test_gpu_sparse.py compares the spike planes in the workspace).
 #pragma once
 
 typedef __bf16 bfv8 __attribute__((ext_vector_type(8)));

@@ -57,6 +57,10 @@ typedef __bf16 bfv16 __attribute__((ext_vector_type(16)));
 #ifndef SP_PRE_A
 #define SP_PRE_A 1
 #endif
+#ifndef SP_PRE_B
+#define SP_PRE_B 0                                  // (1: FAT shapes request a step's first weight fragments right behind the previous step's barrier -
+                                                    // measured 0.9 % / 1.2 % SLOWER on the conv / fc6, profiles/r5_preb_ab.txt: off)
+#endif
 #define SP_PITCH 36                                 // epilogue tile image: 32 columns + 4 floats of padding per row
 
 struct SparseConvArgs {
@@ -548,7 +552,31 @@ __global__ __launch_bounds__(FAT ? 256 : 512, FAT ? 2 : 4) void k_gemm_lif_spars
                 p_sec[b4] = __ballot(o2 != 0u) & (NS - 4 * b4 >= 4 ? ~0ull : ((1ull << (16 * (NS - 4 * b4))) - 1ull));
             }
         };
+        // weight fragments of group g = (N-tile g / 3, plane 2 - g % 3: small terms first): both 32-deep chunks of the step as ONE
+        // 16-element operand (the structured-sparse instruction's B; its halves are the dense instruction's B of chunk c, c + 1),
+        // buffered by g modulo the depth - the loads land in the halves of the buffer a later group reads, no register copies
+        constexpr int BD = (FAT && ND + NS > 12) ? 1 : BDEPTH;   // (the largest row-waves have no registers for a third buffer)
+        constexpr bool TWO_PART = FAT && ND + NS > 14;
+        // B HEAD START (-DSP_PRE_B=1, off: measured slower; FAT shapes whose step is one part): the first BD groups' fragments of step s + 1
+        // requested right behind the barrier of step s - ahead of the copies' issue and the secondary-plane ballots of the step's top
+        // (3 NT is a multiple of BD + 1: the ring carries over from step to step)
+        constexpr bool PRE_B = SP_PRE_B && FAT && !TWO_PART;
+        static_assert((3 * NT) % (BD + 1) == 0, "fragment ring carries over");
+        bfv16 bbuf[BD + 1];
+        auto load_b = [&](bfv16& dst, const uint32_t off, const int gn) __attribute__((always_inline)) {
+#ifdef SNN_EXP_SP_NO_BREAD                            // (timing experiment: the weight fragments stay what they were before the loop)
+            const bfv8 lo = exp_b0, hi = exp_b1;
+#else
+            const bfv8 lo = *reinterpret_cast<const bfv8*>(b_rd + off + (2 - gn % 3) * (64 * G3_ROWB) + (gn / 3) * 16 * G3_ROWB);
+            const bfv8 hi = *reinterpret_cast<const bfv8*>(b_rd + off + 3 * 64 * G3_ROWB + (2 - gn % 3) * (64 * G3_ROWB) + (gn / 3) * 16 * G3_ROWB);
+#endif
+            dst = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+        };
         if constexpr (PRE_A) load_a_all(0);
+        if constexpr (PRE_B) {
+#pragma unroll
+            for (int g0 = 0; g0 < BD; ++g0) load_b(bbuf[g0], 0u, g0);
+        }
         for (int s = 0; s < n_steps; ++s) {
             const uint32_t o_cur = (uint32_t)((s & 1) * SLOT), o_nxt = (uint32_t)(((s + 1) & 1) * SLOT);
             if (s + 1 < n_steps) {
@@ -613,26 +641,15 @@ __global__ __launch_bounds__(FAT ? 256 : 512, FAT ? 2 : 4) void k_gemm_lif_spars
                     }
                 }
 #endif
-                // weight fragments of group g = (N-tile g / 3, plane 2 - g % 3: small terms first): both 32-deep chunks of the step as ONE
-                // 16-element operand (the structured-sparse instruction's B; its halves are the dense instruction's B of chunk c, c + 1),
-                // buffered by g modulo the depth - the loads land in the halves of the buffer a later group reads, no register copies
-                constexpr int BD = (FAT && ND + NS > 12) ? 1 : BDEPTH;   // (the largest row-waves have no registers for a third buffer)
-                bfv16 bbuf[BD + 1];
-                auto load_b = [&](bfv16& dst, const int gn) __attribute__((always_inline)) {
-#ifdef SNN_EXP_SP_NO_BREAD                            // (timing experiment: the weight fragments stay what they were before the loop)
-                    const bfv8 lo = exp_b0, hi = exp_b1;
-#else
-                    const bfv8 lo = *reinterpret_cast<const bfv8*>(b_rd + o_cur + (2 - gn % 3) * (64 * G3_ROWB) + (gn / 3) * 16 * G3_ROWB);
-                    const bfv8 hi = *reinterpret_cast<const bfv8*>(b_rd + o_cur + 3 * 64 * G3_ROWB + (2 - gn % 3) * (64 * G3_ROWB) + (gn / 3) * 16 * G3_ROWB);
-#endif
-                    dst = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
-                };
+                // weight fragments: the ring of the step loop (BD groups ahead of their matrix instructions)
+                if constexpr (!PRE_B) {
 #pragma unroll
-                for (int g0 = 0; g0 < BD; ++g0) load_b(bbuf[g0], g0);
+                    for (int g0 = 0; g0 < BD; ++g0) load_b(bbuf[g0], o_cur, g0);
+                }
 #pragma unroll
                 for (int g = 0; g < 3 * NT; ++g) {
 #ifndef SNN_EXP_SP_NO_BREAD
-                    if (g + BD < 3 * NT) load_b(bbuf[(g + BD) % (BD + 1)], g + BD);
+                    if (g + BD < 3 * NT) load_b(bbuf[(g + BD) % (BD + 1)], o_cur, g + BD);
 #endif
                     const bfv16 bb = bbuf[SNN_EXP_BSEL(g) % (BD + 1)];
 #ifndef SNN_EXP_SP_NO_MFMA                            // (timing experiment: everything but the matrix instructions)
@@ -659,7 +676,7 @@ __global__ __launch_bounds__(FAT ? 256 : 512, FAT ? 2 : 4) void k_gemm_lif_spars
                     __builtin_amdgcn_sched_barrier(0);
                 }
             };
-            if constexpr (FAT && ND + NS > 14) {
+            if constexpr (TWO_PART) {
                 constexpr int QS = (NS - 2 * ND + 1) / 2;          // (two parts of about equal matrix work: a dense M-tile counts twice)
                 do_part(std::integral_constant<int, 0>{}, std::integral_constant<int, QS>{}, std::true_type{});
                 do_part(std::integral_constant<int, QS>{}, std::integral_constant<int, NS>{}, std::false_type{});
@@ -696,6 +713,12 @@ __global__ __launch_bounds__(FAT ? 256 : 512, FAT ? 2 : 4) void k_gemm_lif_spars
             __builtin_amdgcn_s_barrier();
 #endif
             asm volatile("" ::: "memory");
+            if constexpr (PRE_B) {
+                if (s + 1 < n_steps) {
+#pragma unroll
+                    for (int g0 = 0; g0 < BD; ++g0) load_b(bbuf[g0], o_nxt, g0);
+                }
+            }
         }
     };
 // (dense, sparse) M-tile counts of a row-wave the FAT shapes have loop instances for (host: sparse_plan_wn checks against the same lists)

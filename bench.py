@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the spiking-heads hot path on MI355X.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python bench.py [--gpus N] [--steps K] [--warmup W]          (defaults: 1, 100, 10)
 
 N > 1 works both ways: under torchrun (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py
 --gpus N ...`: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment, /root/reference/utils.py:268-312's
@@ -530,8 +530,8 @@ def sweep_t_leg(leg, iters=8):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)      # (0.27 s of timed work: the fence around a 20-step window was 1.5 % of it, profiles/r5_warmup_steps.txt)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the legs outside the headline timing (sustained / e2e / bdd / stress / alt precision)")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra timing leg with the other precision")

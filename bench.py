@@ -642,6 +642,12 @@ def main():
                     "profiled_mfma_busy": c.get("mfma_busy"), "profiled_clock_ghz": c.get("clock_ghz_profiled"), "traffic_over_operands": c.get("traffic_over_operands")}
             if "fc6" in e:
                 prof["fc6"] = {k: e["fc6"].get(k) for k in ("kernel", "avg_us", "hbm_bytes_per_launch", "hbm_gb_per_s", "mfma_busy", "clock_ghz_profiled", "traffic_over_operands")}
+            # the two encoders are the path's HBM-bound streaming launches ("report GB/s for them separately"): algorithmic bytes
+            # (fp32 features in, period planes out) / the profiled launch; their measured traffic is 1.00-1.06 x those bytes
+            enc = {k[4:]: {q: e[k].get(q) for q in ("kernel", "avg_us", "algorithmic_hbm_bytes", "hbm_bytes_per_launch", "hbm_gb_per_s", "hbm_frac_of_8tb_s", "hbm_frac_of_6p3tb_s_copy_rate", "traffic_over_operands")}
+                   for k in ("enc_rpn", "enc_det") if k in e}
+            if enc:
+                prof["encoders"] = enc
             return c["hbm_bytes_per_launch"], src, prof
         except Exception:
             return None, None, {}
@@ -668,6 +674,10 @@ def main():
         "heads_tflops": round((rpn_fl + det_fl) / ((bd["rpn_head"] + bd["det_head"]) * 1e-3) / 1e12, 2),
         "exchange": exchange,
     }
+    enc_rpn = out["roofline"].get("encoders", {}).get("rpn")
+    if enc_rpn and enc_rpn.get("algorithmic_hbm_bytes") and bd["rpn_encode"] > 0:      # (the RPN encoder is also timed live: stage 1 of the head by itself)
+        enc_rpn["live_ms"] = round(bd["rpn_encode"], 4)
+        enc_rpn["live_gb_per_s"] = round(enc_rpn["algorithmic_hbm_bytes"] / (bd["rpn_encode"] * 1e-3) / 1e9, 1)
     if "SNN_DP_DEVICE" in os.environ and world > 1:
         out["config"]["oversubscribed"] = "%d ranks on device %s (test of the N-rank path, not a scaling measurement)" % (world, os.environ["SNN_DP_DEVICE"])
 

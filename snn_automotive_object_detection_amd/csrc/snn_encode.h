@@ -34,11 +34,23 @@ __device__ __forceinline__ void encode_block(const float* __restrict__ feat, int
     const int pos = bx * ENC_PB + pl;
     const int cg = by * ENC_WB + cgl;
     float x[32], v[32];
+    if (cg * 32 + 32 <= C) {
+        // all 32 channels of the word exist (wave-uniform: a wave is one channel word): 32 plain loads off ONE address - the per-channel
+        // predicate cost 14 instructions per load, as many as the encoder steps themselves (round 5: the launch was VALU-bound at 62 % of
+        // the HBM rate).  Lanes past the level's last position read its last position; their words are never stored
+        const float* src = feat + ((size_t)n * C + cg * 32) * HW + min(pos, HW - 1);
 #pragma unroll
-    for (int j = 0; j < 32; ++j) {
-        const int c = cg * 32 + j;
-        x[j] = (pos < HW && c < C) ? feat[((size_t)n * C + c) * HW + pos] : 0.0f;
-        v[j] = 0.0f;                              // rpn.py:93  v = zeros
+        for (int j = 0; j < 32; ++j) {
+            x[j] = src[(size_t)j * HW];
+            v[j] = 0.0f;                          // rpn.py:93  v = zeros
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const int c = cg * 32 + j;
+            x[j] = (pos < HW && c < C) ? feat[((size_t)n * C + c) * HW + pos] : 0.0f;
+            v[j] = 0.0f;
+        }
     }
     uint32_t prev = 0;
     for (int t = 0; t < T; ++t) {
@@ -286,14 +298,15 @@ __global__ __launch_bounds__(256) void k_encode_rows_wm(const float* __restrict_
 // the RoI's row - and the T words go to LDS [t][cb][RoI][bin] (odd pitch S: conflict-free both ways).  Store: thread = (RoI, item): the dense planes' words as they are, a sparse
 // plane's pair through sp_compress_pair - runs of ENCP_RB consecutive RoIs of one word plane / array.
 #define ENCP_LDS_WORDS 19200                        // planes per pass through LDS: 19200 / (2 S RB) - 12 at RB = 16, 24 at RB = 8 (75 KB); longer windows take more passes
-template <int S, int RB>
-__global__ __launch_bounds__(256) void k_encode_rows_perm(const float* __restrict__ x, int R, int C, int T, int nd, const EncTh eth,
+template <int S, int RB, int NW>                    // NW waves per block (4 or 8: 2 RB tasks over NW waves, two at a time)
+__global__ __launch_bounds__(64 * NW) void k_encode_rows_perm(const float* __restrict__ x, int R, int C, int T, int nd, const EncTh eth,
                                                           uint32_t* __restrict__ planes, uint32_t* __restrict__ cmp) {
     static_assert(S <= 64, "one lane per bin");
     extern __shared__ uint32_t pw[];                          // [min(T, TMAX)][2][RB][S]
     constexpr int TMAX = ENCP_LDS_WORDS / (2 * S * RB);
+    static_assert((2 * RB) % (2 * NW) == 0, "tasks two at a time per wave");
     __shared__ uint16_t code[256];
-    code[threadIdx.x] = sp_byte_code(threadIdx.x);
+    if (threadIdx.x < 256) code[threadIdx.x] = sp_byte_code(threadIdx.x);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r0 = blockIdx.x * RB, cp = blockIdx.y, cbn = C / 32, D = C * S, Dw = D / 32;
     const size_t plane_words = (size_t)Dw * R, cmp_plane = (size_t)(Dw / 2) * SP_A_ARR * R;
@@ -326,11 +339,11 @@ __global__ __launch_bounds__(256) void k_encode_rows_perm(const float* __restric
         float xa[32], xb[32];
         load_task(xa, wave);
 #pragma unroll 1
-        for (int task = wave; task < 2 * RB; task += 8) {     // (2 RB / 4 tasks per wave: even)
-            load_task(xb, task + 4);
+        for (int task = wave; task < 2 * RB; task += 2 * NW) {     // (2 RB / NW tasks per wave: even)
+            load_task(xb, task + NW);
             encode_task(xa, task);
-            if (task + 8 < 2 * RB) load_task(xa, task + 8);
-            encode_task(xb, task + 4);
+            if (task + 2 * NW < 2 * RB) load_task(xa, task + 2 * NW);
+            encode_task(xb, task + NW);
         }
         __syncthreads();
         // ---- store: thread = (RoI tid % RB, item tid / RB)
@@ -339,12 +352,12 @@ __global__ __launch_bounds__(256) void k_encode_rows_perm(const float* __restric
             for (int t = t0; t < t0 + tn; ++t) {
                 const uint32_t* pt = pw + (size_t)(t - t0) * 2 * S * RB;
                 if (t < nd || !cmp) {                         // raw words (bin, cb) -> word plane bin * cbn + 2 cp + cb
-                    for (int it = tid / RB; it < 2 * S; it += 256 / RB) {
+                    for (int it = tid / RB; it < 2 * S; it += 64 * NW / RB) {
                         const int cb = it / S, bin = it % S;
                         planes[(size_t)t * plane_words + (size_t)(bin * cbn + 2 * cp + cb) * R + row] = pt[(cb * RB + rl) * S + bin];
                     }
                 } else {                                      // compressed step (bin, cp): pair index (bin * cbn + 2 cp) / 2
-                    for (int bin = tid / RB; bin < S; bin += 256 / RB) {
+                    for (int bin = tid / RB; bin < S; bin += 64 * NW / RB) {
                         uint32_t c4[4];
                         sp_compress_pair(pt[rl * S + bin], pt[(RB + rl) * S + bin], code, c4);
                         uint32_t* o = cmp + (size_t)(t - nd) * cmp_plane + (size_t)(bin * (cbn / 2) + cp) * SP_A_ARR * R + row;

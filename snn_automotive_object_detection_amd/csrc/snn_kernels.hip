@@ -161,6 +161,7 @@ struct Knobs {
                              //                       skips the steps whose currents cannot reach an output, lif_windows)
     bool sparse;             // SNN_SPARSE=0          RPN conv: every period plane on the dense matrix-core instruction (default: planes e_3.. on the
                              //                       structured-sparse one, snn_sparse.h)
+    int encp_nw;             // SNN_ENCP_NW=4|8       waves per block of k_encode_rows_perm (A/B; default: 8 where two blocks fit a CU, else 4)
     int encp_rb;             // SNN_ENCP_RB=8|16      RoIs per block of k_encode_rows_perm (A/B; default: 16 where the window fits one pass through LDS)
     int sparse_fat_conv;     // SNN_SPARSE_FAT_CONV=0..3 the FAT conv (four waves, LIF in registers; bit-identical to the 8-wave shape): bit 0 = T = 7 .. 9 (4 x 1 waves, tiles of
                              //                       64 positions), bit 1 = T = 12 .. 16 (2 x 2 waves, tiles of 32); default: both
@@ -193,6 +194,7 @@ static Knobs load_knobs() {
     k.lif_regs = !((e = getenv("SNN_LIF_REGS")) && e[0] == '0');
     k.sparse_fat_conv = (e = getenv("SNN_SPARSE_FAT_CONV")) ? atoi(e) : SNN_SPARSE_FAT_CONV_DEFAULT;
     k.encp_rb = (e = getenv("SNN_ENCP_RB")) ? atoi(e) : 0;
+    k.encp_nw = (e = getenv("SNN_ENCP_NW")) ? atoi(e) : 0;
     e = getenv("SNN_PLANES");
     k.planes = !e ? 0 : !strcmp(e, "rm") ? 1 : !strcmp(e, "wm") ? 2 : 0;
     k.bf16x3_xcd = !((e = getenv("SNN_BF16X3_XCD")) && e[0] == '0');
@@ -2158,14 +2160,18 @@ int snn_det_head_forward_k(const float* x, int R, int D, int Hd, int K, int K4, 
         const int Te = win.enc_steps, C = D / 49;
         const int rb = knobs().encp_rb ? (knobs().encp_rb == 16 ? 16 : 8) : (Te <= ENCP_LDS_WORDS / (2 * 49 * 16) ? 16 : 8);     // (one pass through LDS where 16 RoIs per block allow it)
         const size_t lds = (size_t)min(Te, ENCP_LDS_WORDS / (2 * 49 * rb)) * 2 * 49 * rb * 4;
-        const void* kern = rb == 16 ? (const void*)k_encode_rows_perm<49, 16> : (const void*)k_encode_rows_perm<49, 8>;
+        // eight waves per block where only two blocks fit a CU's LDS (T_det = 12: -2 us, T_det = 24: -10 us), four where three fit (T_det = 16: eight
+        // were 9 us slower) - profiles/r5_encoder_nw_ab.txt
+        const int nw = knobs().encp_nw ? (knobs().encp_nw == 4 ? 4 : 8) : (lds > 53 * 1024 ? 8 : 4);
+        const void* kern = rb == 16 ? (nw == 8 ? (const void*)k_encode_rows_perm<49, 16, 8> : (const void*)k_encode_rows_perm<49, 16, 4>)
+                                    : (nw == 8 ? (const void*)k_encode_rows_perm<49, 8, 8> : (const void*)k_encode_rows_perm<49, 8, 4>);
         hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fail(-3, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
         uint32_t* planes_f = (uint32_t*)((char*)ws + o_enc);
         uint32_t* cmp_f = (uint32_t*)((char*)ws + o_cur);
         const int nd_f = 2;
         void* kargs[] = {(void*)&x, (void*)&R, (void*)&C, (void*)&Te, (void*)&nd_f, (void*)eth_f, (void*)&planes_f, (void*)&cmp_f};
-        e = hipLaunchKernel(kern, dim3(cdiv(R, rb), C / 64), dim3(256), kargs, lds, (hipStream_t)stream);
+        e = hipLaunchKernel(kern, dim3(cdiv(R, rb), C / 64), dim3(64 * nw), kargs, lds, (hipStream_t)stream);
         if (e != hipSuccess) return fail(-3, "k_encode_rows_perm launch failed: %s", hipGetErrorString(e));
         SNN_CHECK_LAUNCH("k_encode_rows_perm");
     } else {

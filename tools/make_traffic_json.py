@@ -4,7 +4,9 @@ Per workload and big launch (conv = k_gemm_lif_sparse<true, ...>, fc6 = k_gemm_l
 (2 x FETCH_SIZE + WRITE_SIZE, counter unit 1 KiB: MI355X_MICROARCH.md, HBM section; calibrated for this family's LDS-DMA gathers by
 tools/fetch_calib.hip), matrix-pipe busy fraction, clock, matrix instructions, L2 hits / misses - what bench.py quotes as `roofline.traffic`
 of each leg and what a reader needs to recompute every leg's `frac`."""
+import csv
 import json
+import os
 import re
 import sys
 
@@ -13,7 +15,8 @@ WORKLOADS = {  # shapes of bench.py's workloads: positions of the pyramid (batch
     "bdd": dict(levels=[(192, 344), (96, 172), (48, 86), (24, 43), (12, 22)], batch=4, T_rpn=8, R=4000, T_det=12, rates=False),
     "stress": dict(levels=[(192, 384), (96, 192), (48, 96), (24, 48), (12, 24)], batch=2, T_rpn=16, R=2000, T_det=24, rates=True),
 }
-KERNELS = {"conv": "k_gemm_lif_sparse<true,", "fc6": "k_gemm_lif_sparse<false,", "fc7": "k_gemm_bf16x3<4,"}
+KERNELS = {"conv": "k_gemm_lif_sparse<true,", "fc6": "k_gemm_lif_sparse<false,", "fc7": "k_gemm_bf16x3<4,",
+           "enc_rpn": "k_encode_levels<", "enc_det": "k_encode_rows_perm<"}          # (the two encoders: HBM-bound streaming launches)
 
 
 def parse(path):
@@ -27,6 +30,13 @@ def parse(path):
         if cs:
             name = line[2:62].strip()
             pmc.setdefault(name, {}).update({c: (float(v), int(n)) for c, v, n in cs})
+    # the summary lists the 14 longest kernels only (under the profiler MIOpen's trial kernels of the input-making backbone can crowd the small
+    # launches out): the full kernel-stats table next to it fills in the rest
+    for sib in (path.replace("_summary.txt", "_kernel_stats.csv"), os.path.join(os.path.dirname(path), "kernel_stats.csv")):
+        if sib != path and os.path.exists(sib):
+            for r in csv.DictReader(open(sib)):
+                stats.setdefault(r["Name"][:70], (int(r["Calls"]), round(float(r["AverageNs"]) / 1e3, 1)))
+            break
     return stats, pmc
 
 
@@ -49,6 +59,13 @@ def operands(wl, which):
         Tc = w["T_det"] - (1 if w["rates"] else 2)
         R = w["R"]
         return 2 * R * 392 * 4 + (Tc - 2) * 196 * 16 * R + 77.1e6 + w["T_det"] * R * 128, "2 raw + %d compressed planes of %d RoIs in, 77 MB weight planes, lif6's planes out" % (Tc - 2, R)
+    if which == "enc_rpn":                                     # features in (fp32), 2 raw + Tc - 2 compressed period planes out
+        Tc = w["T_rpn"] - 1
+        return P * 256 * 4 + 2 * Pe * 32 + (Tc - 2) * 4 * 16 * Pe, "fp32 features of %d positions x 256 channels in, 2 raw + %d compressed period planes out" % (P, Tc - 2)
+    if which == "enc_det":                                     # RoI features in (fp32), planes out in fc6's order
+        Tc = w["T_det"] - (1 if w["rates"] else 2)
+        R = w["R"]
+        return R * 12544 * 4 + 2 * R * 392 * 4 + (Tc - 2) * 196 * 16 * R, "fp32 RoI features [%d, 12544] in, 2 raw + %d compressed period planes out" % (R, Tc - 2)
     return None, ""
 
 
@@ -73,6 +90,7 @@ def main():
                 e["hbm_bytes_per_launch"] = int(g("FETCH_SIZE") * 1024 * 2 + g("WRITE_SIZE") * 1024)
                 e["hbm_gb_per_s"] = round(e["hbm_bytes_per_launch"] / (st[1] * 1e-6) / 1e9, 1)
                 e["hbm_frac_of_8tb_s"] = round(e["hbm_gb_per_s"] / 8000.0, 4)
+                e["hbm_frac_of_6p3tb_s_copy_rate"] = round(e["hbm_gb_per_s"] / 6300.0, 4)      # (what a float4 copy reaches: MI355X_MICROARCH.md)
             ob, onote = operands(wl, key)
             if ob:
                 e["algorithmic_hbm_bytes"], e["algorithmic_note"] = int(ob), onote

@@ -397,6 +397,33 @@ def test_detector_encoder_fold_writes_the_same_planes(gpu_device, monkeypatch, R
     assert all(torch.equal(p, q) for p, q in zip(c_fold, d.last_spike_counts))
 
 
+@pytest.mark.parametrize("R,C,T", [(333, 64, 12), (77, 128, 16), (40, 64, 26), (2000, 256, 12)])
+def test_detector_encoder_block_shapes_write_the_same_planes(gpu_device, monkeypatch, R, C, T):
+    """k_encode_rows_perm on 8 / 16 RoIs x 4 / 8 waves per block (SNN_ENCP_RB, SNN_ENCP_NW; 16 RoIs with more than 12 planes: two passes
+    through LDS, the second re-deriving its cumulative words): the dense and the compressed planes in the workspace bit for bit"""
+    from snn_automotive_object_detection_amd import ops
+    d = _det(gpu_device, C, 128, 5, T, R + T)
+    x = torch.randn(R, C, 7, 7, device=gpu_device) * 2
+    al = lambda v: (v + 255) // 256 * 256
+    Dw, Tc = C * 49 // 32, T - 2
+    o_cur = al(T * R * Dw * 4)
+    dense_bytes, cmp_bytes = 2 * Dw * R * 4, (Tc - 2) * (Dw // 2) * 4 * R * 4
+
+    def run():
+        out = _run_det(d, x, sparse=True)
+        ws = ops._WS.get(gpu_device, 1)
+        return out, ws[:dense_bytes].clone(), ws[o_cur: o_cur + cmp_bytes].clone()
+    ref = run()
+    for rb in (8, 16):
+        for nw in (4, 8):
+            monkeypatch.setenv("SNN_ENCP_RB", str(rb))
+            monkeypatch.setenv("SNN_ENCP_NW", str(nw))
+            ops._WS.get(gpu_device, 1)[: o_cur + cmp_bytes].fill_(0x5a)
+            got = run()
+            assert torch.equal(ref[1], got[1]) and torch.equal(ref[2], got[2]), (rb, nw)
+            assert torch.equal(ref[0][0], got[0][0]) and torch.equal(ref[0][1], got[0][1]), (rb, nw)
+
+
 # ---- the FAT conv (four waves, each ALL planes of its own 16 positions, the LIF in registers - no tile image) ---------------------------
 @pytest.mark.parametrize("T", [7, 8, 9, 10, 12, 13, 16])
 @pytest.mark.parametrize("C", [256, 64, 128])

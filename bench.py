@@ -229,6 +229,7 @@ class Leg:
     def time_ms(fn, iters):
         import torch
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+        fn()                                                 # (untimed: a call's first-use costs - allocator growth behind a long side leg - are not its launch time)
         for a, b in ev:
             a.record(); fn(); b.record()
         torch.cuda.synchronize()

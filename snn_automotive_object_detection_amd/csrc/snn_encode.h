@@ -317,8 +317,13 @@ __global__ __launch_bounds__(64 * NW) void k_encode_rows_perm(const float* __res
         auto load_task = [&](float (&xv)[32], const int task) __attribute__((always_inline)) {
             const int row = r0 + (task >> 1), cb = task & 1;
             const float* src = x + (size_t)min(row, R - 1) * D + (size_t)((2 * cp + cb) * 32) * S + min(lane, S - 1);
+#ifdef SNN_EXP_ENCP_NOLOAD                             // (timing experiments - wrong results: which phase bounds the launch?)
+#pragma unroll
+            for (int j = 0; j < 32; ++j) xv[j] = (float)(j + lane) * 0.01f + (float)((size_t)src & 4);
+#else
 #pragma unroll
             for (int j = 0; j < 32; ++j) xv[j] = src[j * S];
+#endif
         };
         auto encode_task = [&](const float (&xv)[32], const int task) __attribute__((always_inline)) {
             const int rl = task >> 1, cb = task & 1;
@@ -327,8 +332,12 @@ __global__ __launch_bounds__(64 * NW) void k_encode_rows_perm(const float* __res
                 for (int t = 0; t < t0 + tn; ++t) {          // (cumulative words from step 0: a later pass re-derives what it needs)
                     uint32_t word = 0;
                     const float th = eth.th[t];
+#ifdef SNN_EXP_ENCP_NOENC
+                    word = __float_as_uint(xv[t & 31] + xv[(t + 7) & 31]) & (th > 0.0f ? 0x11111111u : 0u);
+#else
 #pragma unroll
                     for (int j = 31; j >= 0; --j) enc_quant_word(xv[j], th, word);
+#endif
                     const uint32_t cum = word;
                     word = cum & ~prev;
                     prev = cum;
@@ -348,7 +357,11 @@ __global__ __launch_bounds__(64 * NW) void k_encode_rows_perm(const float* __res
         __syncthreads();
         // ---- store: thread = (RoI tid % RB, item tid / RB)
         const int rl = tid & (RB - 1), row = r0 + rl;                    // (RB = 8 or 16)
+#ifdef SNN_EXP_ENCP_NOSTORE
+        if (row < R && pw[tid] == 0x12345678u) {
+#else
         if (row < R) {
+#endif
             for (int t = t0; t < t0 + tn; ++t) {
                 const uint32_t* pt = pw + (size_t)(t - t0) * 2 * S * RB;
                 if (t < nd || !cmp) {                         // raw words (bin, cb) -> word plane bin * cbn + 2 cp + cb

@@ -15,7 +15,7 @@
 // (snn_automotive_object_detection_amd/build.py) never does, and tests/test_code_object.py checks that this guard fires.
 #if !defined(SNN_EXPERIMENTS) && (defined(SNN_EXP_NO_FETCH) || defined(SNN_EXP_NO_GLDS) || defined(SNN_EXP_NO_BARRIER) || \
     defined(SNN_EXP_CLOCK) || defined(SNN_EXP_TIMELINE) || defined(SNN_EXP_SP_NO_A) || defined(SNN_EXP_SP_NO_B) || defined(SNN_EXP_SP_NO_AREAD) || defined(SNN_EXP_SP_NO_BREAD) || defined(SNN_EXP_SP_NO_MFMA) || defined(SNN_EXP_SP_NO_BAR) || defined(SNN_EXP_ONE_WG_PER_CU) || defined(SNN_EXP_MX_NOSTAGE) || defined(SNN_EXP_MX_NOREADB) || defined(SNN_EXP_MX_NOBAR) || \
-    defined(SNN_EXP_MX_NOA) || defined(SNN_EXP_MX_BAR2) || defined(SNN_EXP_MX_RDW_G))
+    defined(SNN_EXP_MX_NOA) || defined(SNN_EXP_MX_BAR2) || defined(SNN_EXP_MX_RDW_G) || defined(SNN_EXP_ENCP_NOLOAD) || defined(SNN_EXP_ENCP_NOENC) || defined(SNN_EXP_ENCP_NOSTORE))
 #error "SNN_EXP_* switches are timing experiments with wrong results: add -DSNN_EXPERIMENTS (never in a product build)"
 #endif
 

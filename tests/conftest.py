@@ -38,6 +38,24 @@ def gpu_device():
 
 
 @pytest.fixture(autouse=True)
+def _seed_per_test(request):
+    """every test starts from a generator state of its own (a hash of its node id), on the host and - where there is one - on the device: what a
+    test draws without seeding (module weights mostly) must not depend on which tests ran before it.  Round 5 found the full-size RPN
+    parity test passing in the suite's order and failing in a subset's, on another draw of the weights"""
+    import zlib
+
+    import torch
+    seed = zlib.crc32((request.node.nodeid + os.environ.get("SNN_TEST_SEED_SALT", "")).encode()) & 0x7fffffff     # (SNN_TEST_SEED_SALT=<anything>: another draw of everything)
+    torch.manual_seed(seed)
+    try:
+        import numpy as np
+        np.random.seed(seed)
+    except Exception:
+        pass
+    yield
+
+
+@pytest.fixture(autouse=True)
 def _snn_knobs(monkeypatch):
     """libsnnhip reads its SNN_* debug knobs once and freezes them: make monkeypatch.setenv / delenv of such a variable take
     effect immediately, and restore the frozen set when the test's environment changes are undone"""

@@ -71,6 +71,35 @@ def det_inputs(spec):
     return x, w6, w7, w_cls, w_bbox
 
 
+# ---------------------------------------------------------------------------------------------
+# energy report: tests/golden/energy_*.npz hold what the reference's own block train.py:472-515 computes
+# from these rate lists (oracle/make_golden.py execs it); the lists have the layout the spike-rate forwards return (rpn.py:177-200:
+# 3 entries per level, [N, 2] = (rate, FLOPs); faster_rcnn.py:594-618: 4 entries [R, 2])
+# ---------------------------------------------------------------------------------------------
+ENERGY_SPECS = {
+    "energy_city_T8_T12":  dict(seed=501, images=6, rois=2000, levels=[(192, 384), (96, 192), (48, 96), (24, 48), (12, 24)], C=256, A=3, K=9, T_rpn=8, T_det=12),
+    "energy_bdd_T16_T24":  dict(seed=502, images=4, rois=1500, levels=[(192, 344), (96, 172), (48, 86), (24, 43), (12, 22)], C=256, A=3, K=11, T_rpn=16, T_det=24),
+    "energy_small_T4_T6":  dict(seed=503, images=1, rois=7, levels=[(8, 16), (4, 8)], C=16, A=3, K=5, T_rpn=4, T_det=6),
+}
+
+
+def energy_rates(spec):
+    """{list position: [*, 2] float32 (rate, FLOPs)} with the FLOP constants of rpn.py:177-188 / faster_rcnn.py:594-603 (labels swapped
+    for obj / bbox, as the reference has them) and seeded rates in (0, 0.3)"""
+    s, n, C, A, K = spec["seed"], spec["images"], spec["C"], spec["A"], spec["K"]
+    rates = {}
+    for l, (h, w) in enumerate(spec["levels"]):
+        for j, fl in enumerate((9 * h * w * C * C, h * w * C * A * 4, h * w * C * A)):
+            r = PR.uniform((n,), s * 100 + 3 * l + j, 0.0, 0.3)
+            rates[3 * l + j] = _t(np.stack([r, np.full((n,), float(fl), dtype=np.float32)], 1).astype(np.float32))
+    base = 3 * len(spec["levels"])
+    D, Hd = C * 49, 1024
+    for j, fl in enumerate((D * Hd, Hd * Hd, Hd * K, Hd * K * 4)):
+        r = PR.uniform((spec["rois"],), s * 100 + 50 + j, 0.0, 0.3)
+        rates[base + j] = _t(np.stack([r, np.full((spec["rois"],), float(fl), dtype=np.float32)], 1).astype(np.float32))
+    return rates
+
+
 def load_expected(name):
     with np.load(os.path.join(GOLDEN_DIR, name + ".npz")) as z:
         return {k: z[k] for k in z.files}

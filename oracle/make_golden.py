@@ -277,6 +277,26 @@ def gen_roi(name, spec, out):
     print("wrote %-20s pooled %s |mean| %.3f" % (name, tuple(pooled.shape), float(pooled.abs().mean())))
 
 
+def gen_energy(name, spec, out):
+    """execs the reference's own energy block (train.py:472-515: text read from /root/reference at run time, never stored) on the
+    fixture's rate lists; stores per layer (mean spikes over T, FLOPs) and the two totals"""
+    import types as _types
+    rates = FX.energy_rates(spec)
+    with open(os.path.join(REF, "train.py")) as f:
+        src = textwrap.dedent("".join(f.readlines()[471:515]))
+    model = _types.SimpleNamespace(rpn=_types.SimpleNamespace(head=_types.SimpleNamespace(num_steps=spec["T_rpn"])),
+                                   roi_heads=_types.SimpleNamespace(box_head_and_predictor=_types.SimpleNamespace(num_steps=spec["T_det"])))
+    ns = {"torch": torch, "model": model, "all_images_per_layer_dict": dict(rates)}
+    with contextlib.redirect_stdout(io.StringIO()):
+        exec(src, ns)
+    per_layer = np.array([[float(a), float(b)] for a, b in ns["flops_per_layer"]], dtype=np.float64)
+    d = {"per_layer": per_layer, "ann_total": np.array(float(ns["ann_total_energy_consumption"])),
+         "snn_total": np.array(float(ns["snn_total_energy_consumption"])),
+         "layer_names": np.array(ns["all_layers_names"][:len(per_layer)])}
+    np.savez_compressed(os.path.join(out, name + ".npz"), **d)
+    print("wrote %-20s layers %d  SNN / ANN energy %.4f" % (name, len(per_layer), float(d["snn_total"]) / float(d["ann_total"])))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=FX.GOLDEN_DIR)
@@ -295,6 +315,8 @@ def main():
         gen_det_post(ref_roi, name, spec, args.out)
     for name, spec in FX.ROI_SPECS.items():
         gen_roi(name, spec, args.out)
+    for name, spec in FX.ENERGY_SPECS.items():
+        gen_energy(name, spec, args.out)
 
 
 if __name__ == "__main__":

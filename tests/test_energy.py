@@ -29,6 +29,24 @@ def test_energy_report_arithmetic():
     assert rep["ann_energy_j"] == pytest.approx(sum(l["ann_energy_j"] for l in rep["layers"]))
 
 
+@pytest.mark.parametrize("name", ["energy_city_T8_T12", "energy_bdd_T16_T24", "energy_small_T4_T6"])
+def test_energy_report_equals_the_references_own_block(name):
+    """tests/golden/energy_*.npz = what train.py:472-515 itself computes (exec-ed by oracle/make_golden.py) from the fixture's rate
+    lists; the reference works in fp32 tensors, energy_report in Python floats: 1e-6 relative"""
+    from oracle import fixtures as FX
+    spec = FX.ENERGY_SPECS[name]
+    exp = FX.load_expected(name)
+    rep = energy.energy_report(FX.energy_rates(spec), spec["T_rpn"], spec["T_det"])
+    assert [l["layer"] for l in rep["layers"]] == [str(x) for x in exp["layer_names"]]
+    got = [[l["mean_spikes"], l["flops"]] for l in rep["layers"]]
+    assert len(got) == len(exp["per_layer"])
+    for g, e in zip(got, exp["per_layer"]):
+        assert g[0] == pytest.approx(e[0], rel=1e-6) and g[1] == pytest.approx(e[1], rel=1e-6)
+    assert rep["ann_energy_j"] == pytest.approx(float(exp["ann_total"]), rel=1e-6)
+    assert rep["snn_energy_j"] == pytest.approx(float(exp["snn_total"]), rel=1e-6)
+    assert rep["snn_over_ann"] == pytest.approx(float(exp["snn_total"]) / float(exp["ann_total"]), rel=1e-6)
+
+
 @pytest.mark.gpu
 def test_extract_spike_rates_on_the_detector(gpu_device):
     import snn_automotive_object_detection_amd as S

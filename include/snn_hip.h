@@ -122,7 +122,13 @@ int snn_rpn_head_forward(const snn_rpn_level* levels_host, int n_levels, int C, 
                          void* workspace, size_t workspace_bytes, snn_stream_t stream);
 
 /* Same call restricted to a subset of its three stages (they communicate through the workspace);
- * lets a profiler bracket the dominant kernel exactly as the full call launches it. */
+ * lets a profiler bracket the dominant kernel exactly as the full call launches it.
+ * CONTRACT: the workspace contents between stages are OPAQUE (which planes exist raw, which only compressed, and where, depends on
+ * T, the precision and the library's knobs: since round 5 the encoder stage writes the period planes e_3 .. compressed only).  A
+ * stage-by-stage caller must run the stages in order on the SAME workspace with IDENTICAL arguments (levels, C, A, T, params,
+ * weights, spike_counts null or not) and an unchanged environment; a later stage after anything else has used the workspace, or
+ * with other arguments, computes on stale bytes (no error is raised: the library cannot tell).  Inspect hidden spike planes through
+ * snn_debug_last_rpn_planes (snn_hip_debug.h), not by reading the workspace. */
 #define SNN_STAGE_ENCODE 1
 #define SNN_STAGE_CONV_LIF 2
 #define SNN_STAGE_LI_HEADS 4

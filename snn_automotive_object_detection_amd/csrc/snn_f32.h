@@ -203,15 +203,18 @@ __global__ __launch_bounds__(512) void k_conv3x3_lif(const ConvArgs args) {
             }
           }
             if (DBG) {                         // test-hook instantiation: dump the step's input currents
-                float* d = args.dbg_cur + (size_t)t * (args.spk_stride * 32);
+                // (one base pointer per lane and 32-bit element offsets formed per store from two values the compiler may not hoist out of the time
+                // loop: 32 loop-invariant 64-bit addresses kept live made this instance spill 4 registers - 20 bytes of scratch per lane - at its
+                // 256-register limit; tests/test_code_object.py wants no scratch anywhere in the library)
+                float* const d = args.dbg_cur + (size_t)t * (args.spk_stride * 32) + (img_base + (size_t)y0 * W + x0) * (size_t)(Nw * 32) + ntg * 32 + li;
+                uint32_t row_pitch = (uint32_t)W * (uint32_t)(Nw * 32), col_pitch = (uint32_t)(Nw * 32);
+                asm volatile("" : "+v"(row_pitch), "+v"(col_pitch));
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = acc_row(r, lh);
-                        const int yy = y0 + mt * 4 + (row >> 3), xx = x0 + (row & 7);
-                        if (yy < H && xx < W)
-                            d[(img_base + (size_t)yy * W + xx) * (Nw * 32) + ntg * 32 + li] = acc[mt][r];
+                        if ((valid_bits >> (mt * 16 + r)) & 1u) d[(uint32_t)(mt * 4 + (row >> 3)) * row_pitch + (uint32_t)(row & 7) * col_pitch] = acc[mt][r];
                     }
             }
             // ---- LIF epilogue in registers; spikes leave as ballots ----

@@ -912,8 +912,9 @@ struct SparsePlan { int q, pb, nd, wn, fat; signed char plane[8][SP_MTMAX]; unsi
 // q = M-tiles (16 positions / RoIs each) per plane.  The conv has thousands of tiles and takes the largest one; a linear layer with a few
 // hundred work-groups takes the q with the fewest rounds of work-groups x work per tile (fc6 at 2000 RoIs, 10 planes: q = 3 is 672
 // work-groups = 1.31 rounds of the 512 slots, q = 2 is 1008 = 1.97 rounds of tiles two thirds the size: 687 -> ~520 us)
-// FAT conv (round 5): four waves; T <= 9: 4 x 1, wave w holds ALL planes of position block w (slot s = plane s, tiles of 64 positions); T = 10 .. 17:
-// 2 x 2, row-wave wm holds all planes of block wm for its column-wave's 32 columns (tiles of 32 positions) - what the register LIF needs
+// FAT conv (round 5): four waves; T = 7 .. 9: 4 x 1, wave w holds ALL planes of position block w (slot s = plane s, tiles of 64 positions); T = 12 .. 16
+// (loop instances exist from T = 10; 10 / 11 are not planned, see below): 2 x 2, row-wave wm holds all planes of block wm for its column-wave's 32
+// columns (tiles of 32 positions) - what the register LIF needs
 static bool sparse_plan_fat_conv(int Tc, SparsePlan* sp) {
     static const int inst_a[][2] = {SP_FAT1_INSTANCES}, inst_b[][2] = {SP_FAT1B_INSTANCES};
     bool ok_a = false, ok_b = false;
@@ -995,7 +996,7 @@ static bool sparse_plan_wn(int Tc, int wn, int q, SparsePlan* sp, bool fat = fal
 // (its K loop is matrix-pipe-bound there).  A linear layer with a few hundred work-groups takes the (wave grid, q) with the fewest
 // rounds of work-groups x work per tile; on the 8 x 1 grid small tiles are LDS-bound (every wave reads the whole weight slot), so the
 // 4 x 2 grid is preferred where its plan exists (fc6 at 2000 RoIs, 10 planes: q = 2 on 4 x 2 = 1008 work-groups = 1.97 rounds).
-static bool sparse_plan(int Tc, SparsePlan* sp, long long units = 0, int n_blocks = 0, bool counting = false) {
+static bool sparse_plan(int Tc, SparsePlan* sp, long long units = 0, int n_blocks = 0) {
     if (Tc < 4 || Tc > 32) return false;
     const bool conv = !(units > 0 && n_blocks > 0);
     const bool fat = !conv && knobs().sparse_fat;           // linear layers: the same tiles on four fat waves, where the plan's row-waves have loop instances
@@ -1030,10 +1031,10 @@ static bool sparse_plan(int Tc, SparsePlan* sp, long long units = 0, int n_block
 // linear: any T whose window (T - 2, or T - 1 in spike-rate mode) fits the slot grid - 4 .. 24 planes on the 4 x 2 wave grid - with the
 // general LIF epilogue outside the straight-line grid (round 5: T_det = 17 .. 26 and spike-rate mode used to take the all-dense launch).
 struct SparseShape { SparsePlan sp; int n_tiles, n_blocks, grid, lds, xcd_cpx, xcd_contig, epi_general; };
-static bool sparse_shape(bool conv, long long M, int Kw, int Kc, int Np, int T, int Tc, SparseShape* out, bool counting = false) {
+static bool sparse_shape(bool conv, long long M, int Kw, int Kc, int Np, int T, int Tc, SparseShape* out) {
     if (!knobs().sparse || Kw % 2 || Np % 64 || Kc * 32 > 65536 || M <= 0) return false;
     if (conv ? (T < 5 || T > 16 || Tc != T - 1) : (T < 5 || T > SNN_MAX_STEPS || (Tc != T - 2 && Tc != T - 1))) return false;
-    if (!sparse_plan(Tc, &out->sp, conv ? 0 : M, Np / 64, counting)) return false;
+    if (!sparse_plan(Tc, &out->sp, conv ? 0 : M, Np / 64)) return false;
     const SparsePlan& sp = out->sp;
     out->n_tiles = cdiv(M, sp.pb);
     out->n_blocks = Np / 64;
@@ -1063,7 +1064,7 @@ static int gemm3_lif_sparse(const Gemm3Args& a, bool conv, void* side, size_t si
     SparseShape sh;
     const int Kw = conv ? a.Cw : a.Kc;                        // plane words per row
     if (!side || !a.wm || !a.periods || a.t0 != 0 || a.p.v_leak != 0.0f || (float)(a.p.v_leak - a.p.v_th) > 0.0f || (!conv && !a.out_wm) ||
-        !sparse_shape(conv, a.M, Kw, a.Kc, a.Np, a.T, a.Tc, &sh, conv ? a.cnt_img != nullptr : a.cnt_row != nullptr))
+        !sparse_shape(conv, a.M, Kw, a.Kc, a.Np, a.T, a.Tc, &sh))      // (the plan does not depend on spike counting; whether the LIF runs in registers does: sparse_plan_lif_regs below)
         return 0;
     const SparsePlan& sp = sh.sp;
     const long long P = a.M, Pe = (long long)a.a_step;
@@ -1139,7 +1140,7 @@ int snn_debug_tile_shape(int conv, long long units, int k_in, int n_cols, int nu
     // the structured-sparse plan, where the launchers take it (period planes of the default parameters: conv, fc6)
     SparseShape sh;
     const int Kw = cdiv(k_in, 32), Np = cdiv(n_cols, 32) * 32;
-    if (knobs().periods && (conv || layer != 7) && sparse_shape(conv != 0, units, Kw, conv ? 9 * Kw : Kw, Np, num_steps, Tc, &sh, spike_rates != 0)) {
+    if (knobs().periods && (conv || layer != 7) && sparse_shape(conv != 0, units, Kw, conv ? 9 * Kw : Kw, Np, num_steps, Tc, &sh)) {      // (spike_rates only moves a linear layer's window: Tc above)
         const SparsePlan& sp = sh.sp;
         int slots = 0;
         for (int w = 0; w < (sp.fat ? 4 : 8) / sp.wn; ++w) slots += sp.w_nd[w] + sp.w_ns[w];

@@ -15,7 +15,12 @@ def pytest_configure(config):
 
 
 def sweep_mode(config) -> bool:
-    return "sweep" in (config.getoption("-m") or "") or os.environ.get("SNN_TEST_SWEEP") == "1"
+    """the exhaustive grids run when the marker expression names `sweep` UN-NEGATED (`-m "gpu and sweep"`) or under SNN_TEST_SWEEP=1;
+    `-m "gpu and not sweep"` is the sampled run (a substring test used to read it as sweep mode)"""
+    import re
+    expr = config.getoption("-m") or ""
+    positive = re.sub(r"\bnot\s+\(?\s*sweep\b", " ", expr)
+    return bool(re.search(r"\bsweep\b", positive)) or os.environ.get("SNN_TEST_SWEEP") == "1"
 
 
 def pytest_collection_modifyitems(config, items):

@@ -108,11 +108,12 @@ def cpu_model_name():
     return platform.processor() or "unknown"
 
 
-def cpu_baseline(leg, repeats=3):
+def cpu_baseline(leg, repeats=3, warm=True):
     """the oracle (CPU restatement of the reference loops, un-fused torch ops) on the SAME tensors as the GPU leg - the leg's
-    backbone-fed pyramid and RoI features and the modules' own weights, copied to the host once: both images (b=2 pyramid, T_rpn)
-    + the detector head on their 2000 RoIs (T_det); 1 warm-up (levels 1..4 + 256 RoIs: pages the thread pool and allocator in
-    without doubling the cost) + `repeats` timed passes, median reported"""
+    backbone-fed pyramid and RoI features and the modules' own weights, copied to the host once: all images of the batch (pyramid, T_rpn)
+    + the detector head on their RoIs (T_det); 1 warm-up (levels 1..4 + 256 RoIs: pages the thread pool and allocator in
+    without doubling the cost) + `repeats` timed passes, median reported (side legs: one pass).
+    Spike-rate workloads (config[4]) run the oracle's spike-rate variants (rpn.py:126-200, faster_rcnn.py:520-618)."""
     import torch
     from oracle import snn_oracle as OR
     wl = leg.wl
@@ -123,22 +124,25 @@ def cpu_baseline(leg, repeats=3):
     w6, w7 = d.fc6.weight.detach().cpu(), d.fc7.weight.detach().cpu()
     wc, wb = d.cls_score.weight.detach().cpu(), d.bbox_pred.weight.detach().cpu()
     threads = torch.get_num_threads()
+    rates = bool(wl["spike_rates"])
     times = []
     with torch.no_grad():
-        OR.rpn_head_forward(feats[1:], w_s, w_c, w_b, wl["T_rpn"])          # warm-up
-        OR.det_head_forward(rois[:256], w6, w7, wc, wb, wl["T_det"])
+        if warm:
+            OR.rpn_head_forward(feats[1:], w_s, w_c, w_b, wl["T_rpn"])          # warm-up
+            OR.det_head_forward(rois[:256], w6, w7, wc, wb, wl["T_det"])
         for _ in range(repeats):
             t0 = time.perf_counter()
-            OR.rpn_head_forward(feats, w_s, w_c, w_b, wl["T_rpn"])
-            OR.det_head_forward(rois, w6, w7, wc, wb, wl["T_det"])
+            OR.rpn_head_forward(feats, w_s, w_c, w_b, wl["T_rpn"], spike_rates=rates)
+            OR.det_head_forward(rois, w6, w7, wc, wb, wl["T_det"], spike_rates=rates)
             times.append(time.perf_counter() - t0)
     med = statistics.median(times)
     return {"value": round(wl["batch"] / med, 4), "unit": "images/s", "cores": threads, "kind": "port",
             "cpu": cpu_model_name(), "repeats": repeats, "seconds": [round(t, 2) for t in times],
             "inputs": "identical to the GPU leg (copied to the host)",
-            "sample": "b=%d: oracle RPN head (5-level pyramid, T=%d) + detector head (%d RoIs, T=%d) on the GPU leg's own inputs and "
-                      "weights; 1 warm-up + %d repeats, median %.1f s per batch" % (
-                          wl["batch"], wl["T_rpn"], rois.shape[0], wl["T_det"], repeats, med)}
+            "sample": "b=%d: oracle RPN head (5-level pyramid, T=%d) + detector head (%d RoIs, T=%d)%s on the GPU leg's own inputs and "
+                      "weights; %s%d repeat%s, median %.1f s per batch" % (
+                          wl["batch"], wl["T_rpn"], rois.shape[0], wl["T_det"], ", spike-rate variants" if rates else "",
+                          "1 warm-up + " if warm else "", repeats, "" if repeats == 1 else "s", med)}
 
 
 # ---------------------------------------------------------------------------------------------
@@ -159,6 +163,11 @@ class Leg:
         self.input_note = None
         if inputs == "backbone":
             self.feats, self.rois, self.input_note = self._backbone_inputs(seed, backbone_model)
+        elif inputs == "worst_case":
+            g = torch.Generator(device="cpu").manual_seed(seed)
+            self.feats = [worst_case_tensor((wl["batch"], C, h, w), g, wl["T_rpn"]).to(dev) for h, w in wl["levels"]]
+            self.rois = worst_case_tensor((wl["batch"] * ROIS_PER_IMG, C, 7, 7), g, wl["T_det"] - 1).to(dev)
+            self.input_note = "synthetic worst case: every four consecutive channels on one encoder period >= 3 (full nibbles in the structured-sparse planes)"
         else:
             g = torch.Generator(device="cpu").manual_seed(seed)
             self.feats = [torch.randn((wl["batch"], C, h, w), generator=g).to(dev) for h, w in wl["levels"]]
@@ -253,6 +262,23 @@ class Leg:
         det_ms = self.time_ms(lambda: self.det_head(self.rois), iters)
         return {"rpn_head": rpn_ms, "rpn_encode": enc_ms, "rpn_conv3x3_lif": conv_ms, "det_head": det_ms}
 
+    def conv_only_fn(self):
+        """the conv + LIF launch alone, on the planes a full head call left in the workspace (as kernel_breakdown times it)"""
+        from snn_automotive_object_detection_amd import ops
+        p, w_sh, w_hd, T = self.rpn_head._params(), self.rpn_head._packed_shared(), self.rpn_head._cache_heads.val, self.wl["T_rpn"]
+        ops.rpn_head_forward(self.feats, C, A, T, p, w_sh, w_hd, stage_mask=7)
+        return lambda: ops.rpn_head_forward(self.feats, C, A, T, p, w_sh, w_hd, stage_mask=2)
+
+    def held_clocks(self, step_ms, conv_ms):
+        """{step, conv_lif} clocks in GHz held while the whole step / the conv + LIF launch run back to back (None where the probe is unavailable)"""
+        try:
+            step = held_clock_ghz(self.step_local, step_ms, self.dev)
+            conv = held_clock_ghz(self.conv_only_fn(), conv_ms, self.dev)
+        except Exception as e:                                    # (an older libsnnhip.so behind SNN_HIP_LIB)
+            return {"step_ghz": None, "conv_lif_ghz": None, "error": repr(e)[:200]}
+        return {"step_ghz": round(step, 4) if step else None, "conv_lif_ghz": round(conv, 4) if conv else None, "nominal_ghz": NOMINAL_CLOCK_GHZ,
+                "method": "one-wave probe on a side stream beside >= 30 ms of back-to-back launches: 0.1 GHz x d(s_memtime) / d(s_memrealtime)"}
+
     def roofline(self, conv_ms, traffic=None, traffic_source=None):
         conv_fl, _, _ = algorithmic_flops(self.wl)
         kernel, peak, per_step = kernel_of(self.precision)
@@ -320,6 +346,29 @@ def timed_steps(leg, steps, warmup, fence):
         leg.step()
     fence()
     return time.perf_counter() - t0
+
+
+NOMINAL_CLOCK_GHZ = 2.4                                          # MI355X_MICROARCH.md chip table: the clock the 2.5 PF / 5 PF peaks are quoted at
+
+
+def held_clock_ghz(fn, est_ms, dev, window_ms=30.0):
+    """the shader clock the chip HOLDS while `fn` runs back to back: a one-wave probe (snn_debug_clock_probe: d s_memtime / d s_memrealtime x 100 MHz,
+    MI355X_MICROARCH.md 'DVFS give-back' item 6) on a side stream, started once the device is busy with `fn` and ended while it still is"""
+    import torch
+    from snn_automotive_object_detection_amd import _lib
+    lib = _lib.load()
+    out = torch.zeros(2, dtype=torch.int64, device=dev)
+    side = torch.cuda.Stream(device=dev)
+    n = max(6, int(window_ms / max(est_ms, 1e-3)))
+    torch.cuda.synchronize()
+    for _ in range(n // 2 + 1):
+        fn()
+    _lib.check(lib.snn_debug_clock_probe(out.data_ptr(), int(0.5 * n * est_ms * 1e-3 * 1e8) + 1, side.cuda_stream), "snn_debug_clock_probe")
+    for _ in range(n + n // 2 + 2):
+        fn()
+    torch.cuda.synchronize()
+    cyc, ticks = (int(v) for v in out.tolist())
+    return 0.1 * cyc / ticks if ticks > 0 else None
 
 
 def e2e_leg(model, dev, iters=5):
@@ -469,6 +518,78 @@ def dp_e2e_leg(model, dev, rank, world, fence, iters=3):
             "full_payload_bytes_per_image": (1101 * 6 + spec.width) * 4}
 
 
+def worst_case_tensor(shape, gen, T):
+    """feature values that put FOUR consecutive channels (a nibble of a plane word) on the SAME period n >= 3, the period cycling over the nibbles
+    3, 4, ..: every nibble of the structured-sparse planes e_3 .. that holds a spike holds four, so every (M-tile, 64-k step) of those planes takes
+    the secondary instruction (csrc/snn_sparse.h) - the slowest input the sparse launches can see.  Constant-current encoder (v += 0.1 (x - v), spike
+    at v > 0.25): period n <=> 0.25 / (1 - 0.9^n) < x <= 0.25 / (1 - 0.9^(n-1)); the value is the middle of that interval (+- 2 % jitter)."""
+    import torch
+    n_max = max(3, min(T - 1, 7))
+    periods = list(range(3, n_max + 1))
+    mid = [0.5 * (0.25 / (1 - 0.9 ** n) + 0.25 / (1 - 0.9 ** (n - 1))) for n in periods]
+    Cc = shape[1]
+    per_ch = torch.tensor([mid[(c // 4) % len(periods)] for c in range(Cc)], dtype=torch.float32)
+    x = per_ch.view(1, Cc, *([1] * (len(shape) - 2))).expand(*shape).clone()
+    return x * (1.0 + 0.02 * (torch.rand(shape, generator=gen) - 0.5))
+
+
+def planes_hit_stats(z):
+    """z: int64 [T, P, Cw] time-step spike planes (bit b of word w = channel 32 w + b) -> (blocks with a >= 3-spike nibble, blocks, ones, bits) over
+    the period planes e_3 .. e_(T-1); block = 16 consecutive positions x one 64-k step (word pair)"""
+    import torch
+    M1 = 0x11111111
+    T = z.shape[0]
+    hit = blocks = ones = bits = 0
+    before = torch.zeros_like(z[0])
+    for n in range(1, T):                                                        # period plane e_n = first spike at step n - 1
+        e = z[n - 1] & ~before
+        before = before | z[n - 1]
+        if n < 3:
+            continue
+        c = (e & M1) + ((e >> 1) & M1) + ((e >> 2) & M1) + ((e >> 3) & M1)       # spikes per nibble (0 .. 4), one nibble-sized counter each
+        ge3 = ((c & (c >> 1)) | (c >> 2)) & M1
+        P, Cw = e.shape
+        pair = (ge3 != 0).view(P, Cw // 2, 2).any(dim=2)                         # (position, 64-k step)
+        blk = pair[:(P // 16) * 16].view(P // 16, 16, Cw // 2).any(dim=1)
+        hit += int(blk.sum()); blocks += blk.numel()
+        ones += int(sum(((c >> (4 * i)) & 0xf).sum() for i in range(8)))
+        bits += e.numel() * 32
+    return hit, blocks, ones, bits
+
+
+def secondary_hit_rate(feats, T, p):
+    """fraction of (16 consecutive positions, 64-k step) blocks of the structured-sparse planes e_3 .. e_(T-1) in which some nibble holds >= 3 spikes -
+    the blocks whose M-tile issues the structured-sparse instruction a second time (estimated on the centre tap: the conv's other eight taps see the same
+    planes shifted by a position), and the mean density of those planes"""
+    import torch
+    from snn_automotive_object_detection_amd import ops
+    tot = [0, 0, 0, 0]
+    for f in feats:
+        z = ops.encode_nchw(f, T, p).to(torch.int64) & 0xffffffff              # [T, P, Cw] time-step planes
+        tot = [a + b for a, b in zip(tot, planes_hit_stats(z))]
+    return {"secondary_hit_rate_centre_tap": round(tot[0] / max(tot[1], 1), 4), "sparse_plane_density": round(tot[2] / max(tot[3], 1), 5)}
+
+
+def density_sweep_leg(leg, make_leg_with, steps, fence):
+    """the throughput is data-dependent (how 2:4-compressible the period planes e_3 .. are), so the same heads-only step on three
+    input distributions, outside the headline timing: the headline's backbone-fed tensors, N(0,1) tensors, and the synthetic WORST case (worst_case_tensor)"""
+    rows = {}
+    p = leg.rpn_head._params()
+    for name in ("backbone", "randn", "worst_case"):
+        l2 = leg if name == "backbone" else make_leg_with(name)
+        l2.step = l2.step_local
+        dt = timed_steps(l2, steps, 5, fence)
+        bd = l2.kernel_breakdown(5)
+        rows[name] = {"value": round(l2.wl["batch"] * steps / dt, 2), "unit": "images/s", "ms_per_step": round(dt / steps * 1e3, 4),
+                      "conv_lif_launch_ms": round(bd["rpn_conv3x3_lif"], 4), "rpn_head_ms": round(bd["rpn_head"], 4), "det_head_ms": round(bd["det_head"], 4),
+                      "conv_path_sparse": bool(getattr(l2, "conv_sparse", False)), **secondary_hit_rate(l2.feats, l2.wl["T_rpn"], p), "inputs": l2.input_note}
+        if l2 is not leg:
+            del l2
+    rows["note"] = ("same weights, same step, %d-step windows; secondary_hit_rate = share of (16 positions x 64 k) blocks of the planes e_3 .. whose M-tile issues a second "
+                    "structured-sparse instruction (centre-tap estimate); worst_case = every occupied nibble of those planes full" % steps)
+    return rows
+
+
 def sweep_t_leg(leg, iters=8):
     """throughput vs T over the paper's grid (metrics_for_different_timesteps.py:30-33,360-361: T_rpn 4..12, T_det 8..16): the two
     heads are independent, so 9 + 9 timings.  `steps` = time steps whose contractions are executed (dead ones removed),
@@ -537,7 +658,7 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the legs outside the headline timing (sustained / e2e / bdd / stress / alt precision)")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra timing leg with the other precision")
     ap.add_argument("--precision", choices=PRECISIONS, default="bf16x3")
-    ap.add_argument("--inputs", choices=["backbone", "randn"], default="backbone")
+    ap.add_argument("--inputs", choices=["backbone", "randn", "worst_case"], default="backbone")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cityscapes",
                     help="cityscapes = BASELINE.json's headline configuration (default); bdd = config[3] per-rank share "
                          "(720x1280, 4 images per GPU, K=11); stress = config[4] (T=16/24, spike-rate outputs on)")
@@ -630,14 +751,22 @@ def main():
     # HBM bytes per launch of the dominant kernel: NOT measured by this run (PMC counters need rocprofv3 around the process) but
     # read from the committed PMC passes of the same launch (separate --pmc FETCH_SIZE / WRITE_SIZE runs, tools/prof_round.sh ->
     # tools/make_traffic_json.py), per workload
+    from snn_automotive_object_detection_amd import build as _build
+    source_digest = _build.source_digest()                       # content hash of everything libsnnhip.so is built from
+    TRAFFIC_JSON = "r6_traffic.json"
+
     def committed_traffic(workload):
         if args.t_rpn or dead_steps_kept():
             return None, None, {}
         try:
-            with open(os.path.join(ROOT, "profiles", "r5_traffic.json")) as f:
-                e = json.load(f)[workload][args.precision]
+            with open(os.path.join(ROOT, "profiles", TRAFFIC_JSON)) as f:
+                doc = json.load(f)
+            if doc.get("source_digest") != source_digest:         # PMC passes of ANOTHER source tree say nothing about this build's launches
+                return None, ("profiles/%s was collected on source digest %s, this build is %s: traffic not quoted" % (
+                    TRAFFIC_JSON, str(doc.get("source_digest"))[:12], source_digest[:12])), {}
+            e = doc[workload][args.precision]
             c = e["conv"]
-            src = ("profiles/r5_traffic.json <- %s: 2 x FETCH_SIZE (gfx950 tallies 128-B requests at 64 B; calibrated for this access pattern, tools/fetch_calib.hip) "
+            src = ("profiles/" + TRAFFIC_JSON + " (same source digest as this build) <- %s: 2 x FETCH_SIZE (gfx950 tallies 128-B requests at 64 B; calibrated for this access pattern, tools/fetch_calib.hip) "
                    "+ WRITE_SIZE, separate rocprofv3 --pmc passes of this launch on this workload, committed - NOT collected by this run" % e["source"])
             prof = {"profiled_launch_ms": round(c["avg_us"] / 1e3, 4), "profiled_hbm_gb_per_s": c.get("hbm_gb_per_s"), "profiled_hbm_frac_of_8tb_s": c.get("hbm_frac_of_8tb_s"),
                     "profiled_mfma_busy": c.get("mfma_busy"), "profiled_clock_ghz": c.get("clock_ghz_profiled"), "traffic_over_operands": c.get("traffic_over_operands")}
@@ -653,6 +782,19 @@ def main():
         except Exception:
             return None, None, {}
     traffic, traffic_source, traffic_prof = committed_traffic(args.workload)
+
+    def roofline_of(l, bd_, step_ms, t_, t_src, t_prof):
+        """roofline of a leg + the clock the chip held under it: `frac` prices the launch against the peaks at the NOMINAL 2.4 GHz; boxes of this
+        pool hold different clocks under the same matrix-core load (MI355X_MICROARCH.md 'DVFS give-back' item 5), so `frac_at_held_clock` =
+        frac x 2.4 / held clock is the part of the fraction that is the kernel's and not the box's"""
+        rf = {**l.roofline(bd_["rpn_conv3x3_lif"], t_, t_src), **t_prof}
+        clk = l.held_clocks(step_ms, bd_["rpn_conv3x3_lif"])
+        if clk.get("conv_lif_ghz"):
+            rf["held_clock_ghz"] = clk["conv_lif_ghz"]
+            rf["frac_at_held_clock"] = round(rf["frac"] * NOMINAL_CLOCK_GHZ / clk["conv_lif_ghz"], 4)
+            rf["launch_cycles_at_held_clock"] = round(bd_["rpn_conv3x3_lif"] * 1e-3 * clk["conv_lif_ghz"] * 1e9)
+        return rf, clk
+    roofline, held = roofline_of(leg, bd, ms, traffic, traffic_source, traffic_prof)
 
     out = {
         "metric": "images/sec (T_rpn=%d,T_det=%d, %dx%d b=%d) spiking RPN+RoI heads forward" % (
@@ -670,7 +812,9 @@ def main():
                    "global_batch": wl["batch"] * world, "parallelism": "dp%d" % world,
                    "exchange": ("all-gather of per-image detections [100x6] (%s, %d ranks)" % (
                        "RCCL" if exchange["backend"] == "nccl" else exchange["backend"], exchange["ranks"])) if world > 1 else "none"},
-        "roofline": {**leg.roofline(bd["rpn_conv3x3_lif"], traffic, traffic_source), **traffic_prof},
+        "roofline": roofline,
+        "held_clock": held,
+        "build": {"source_digest": source_digest, "lib": os.path.relpath(_build.LIB_PATH, ROOT) if not os.environ.get("SNN_HIP_LIB") else os.environ["SNN_HIP_LIB"]},
         "breakdown_ms": {k: round(v, 3) for k, v in bd.items()},
         "heads_tflops": round((rpn_fl + det_fl) / ((bd["rpn_head"] + bd["det_head"]) * 1e-3) / 1e12, 2),
         "exchange": exchange,
@@ -713,6 +857,8 @@ def main():
                                   "seconds": round(t_acc, 3), "ms_per_step": round(t_acc / n * 1e3, 4)}
             if not wl["spike_rates"]:
                 side_leg("t_sweep", lambda: sweep_t_leg(leg))
+            if not wl["spike_rates"] and args.inputs == "backbone" and args.precision == "bf16x3":
+                side_leg("density_sweep", lambda: density_sweep_leg(leg, lambda kind: Leg(wl, args.precision, dev, 1000 + rank, kind, None), min(args.steps, 30), fence_local))
         if world == 1 and not args.no_alt:
             # the same K steps with the other matrix path of the two big contractions: "mxfp6" = fp4 x fp6 block-scaled MFMA
             # on 6 digit planes per weight (passes the same parity tests; weights are rounded at 2^-28 of their block maximum,
@@ -736,12 +882,18 @@ def main():
             dt2 = timed_steps(l2, args.steps, max(1, args.warmup), fence_local)
             bd2 = l2.kernel_breakdown(iters)
             t2, t2_src, t2_prof = committed_traffic(name)
-            return {"workload": "%s (T_rpn=%d, T_det=%d, b=%d, K=%d%s)" % (w2["name"], w2["T_rpn"], w2["T_det"], w2["batch"], w2["K"],
-                                                                    ", spike-rate outputs on" if w2["spike_rates"] else ""),
-                    "value": round(w2["batch"] * args.steps / dt2, 3), "unit": "images/s",
-                    "ms_per_step": round(dt2 / args.steps * 1e3, 4), "roofline": {**l2.roofline(bd2["rpn_conv3x3_lif"], t2, t2_src), **t2_prof},
-                    "breakdown_ms": {k: round(v, 3) for k, v in bd2.items()},
-                    "kernels_over_step": round((bd2["rpn_head"] + bd2["det_head"]) / (dt2 / args.steps * 1e3), 4)}
+            rf2, clk2 = roofline_of(l2, bd2, dt2 / args.steps * 1e3, t2, t2_src, t2_prof)
+            res = {"workload": "%s (T_rpn=%d, T_det=%d, b=%d, K=%d%s)" % (w2["name"], w2["T_rpn"], w2["T_det"], w2["batch"], w2["K"],
+                                                                   ", spike-rate outputs on" if w2["spike_rates"] else ""),
+                   "value": round(w2["batch"] * args.steps / dt2, 3), "unit": "images/s",
+                   "ms_per_step": round(dt2 / args.steps * 1e3, 4), "roofline": rf2, "held_clock": clk2,
+                   "breakdown_ms": {k: round(v, 3) for k, v in bd2.items()},
+                   "kernels_over_step": round((bd2["rpn_head"] + bd2["det_head"]) / (dt2 / args.steps * 1e3), 4)}
+            if not args.no_cpu_baseline:
+                # "report, per config ...": the oracle on THIS leg's tensors too (1 warm-up on the small levels + ONE timed pass:
+                # a pass is 25-50 s of host time)
+                res["cpu_baseline"] = cpu_baseline(l2, repeats=1)
+            return res
         for name in ("bdd", "stress"):
             if name != args.workload:
                 side_leg(name, lambda: workload_leg(name))
@@ -772,6 +924,10 @@ def main():
         other["dp_e2e_exchange_ms"] = extra["dp_e2e"]["exchange_ms"]
         other["dp_e2e_ranks"] = extra["dp_e2e"]["rccl_ranks"]
         other["dp_e2e_backend"] = extra["dp_e2e"]["backend"]
+    ds = extra.get("density_sweep", {})
+    if isinstance(ds, dict) and "worst_case" in ds:
+        other["worst_case_inputs_img_s"] = out["worst_case_inputs_img_s"] = ds["worst_case"]["value"]
+        other["randn_inputs_img_s"] = out["randn_inputs_img_s"] = ds["randn"]["value"]
     if "t_sweep" in extra and "worst_ms_per_step_rel" in extra["t_sweep"]:
         other["t_sweep_worst_ms_per_step_rel"] = extra["t_sweep"]["worst_ms_per_step_rel"]
     if other:

@@ -45,6 +45,11 @@ void snn_debug_last_det_planes(unsigned long long* out3);
  * four words [T][C/128][P][4] if out3[1] == 1), out3[2] = P. */
 void snn_debug_last_rpn_planes(unsigned long long* out3);
 
+/* Measurement (bench.py `held_clock`): enqueue a ONE-wave probe on `stream` that sleeps / polls the constant 100-MHz counter for
+ * `ticks_100mhz` ticks (<= 1 s) and then writes {shader-clock cycles elapsed, ticks elapsed} to out2_dev[0..1] (device memory, caller-owned):
+ * clock held over that window = 0.1 GHz x cycles / ticks.  Run it on a side stream BESIDE the launches whose clock is asked for. */
+int snn_debug_clock_probe(unsigned long long* out2_dev, unsigned int ticks_100mhz, snn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

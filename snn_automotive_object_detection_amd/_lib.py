@@ -45,6 +45,7 @@ DEBUG_SYMBOLS = {
     "snn_debug_last_det_planes": (None, [C.POINTER(C.c_uint64)]),
     "snn_debug_last_rpn_planes": (None, [C.POINTER(C.c_uint64)]),
     "snn_debug_tile_shape": (C.c_int, [C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32)]),
+    "snn_debug_clock_probe": (C.c_int, [C.c_void_p, C.c_uint, c_stream]),
 }
 
 # every symbol include/snn_hip.h declares: name -> (restype, argtypes)

@@ -403,6 +403,8 @@ struct RoiArgs {
     int R, C, T, Dw;
     int quant;                // period planes by thresholds (eth valid): snn_common.h
     int E, n_rg, RW;          // k_roi_align_encode_tab: groups of 64 elements per work-group, RoI groups, RoIs per wave (4 waves)
+    uint32_t* cmp;            // k_roi_align_encode_perm: compressed planes e_(nd+1) .. (csrc/snn_sparse.h), [T - nd][Dw / 2][4][R]
+    int nd;                   // ... the first nd planes leave raw (fc6's dense planes)
     NeuronP p;
     EncTh eth;
 };
@@ -641,5 +643,146 @@ __global__ __launch_bounds__(256) void k_roi_align_encode_tab(const RoiArgs a) {
         const int rl = idx % RG, wd = (idx / RG) % (2 * E), t = idx / (2 * E * RG);
         if (r0 + rl < a.R && w0 + wd < a.Dw)
             a.planes[(size_t)t * a.plane_stride + (size_t)(w0 + wd) * a.R + r0 + rl] = wbuf_dyn[(t * 2 * E + wd) * RG + rl];
+    }
+}
+
+
+// K1e (round 6): K1c'' writing what the structured-sparse fc6 reads - period planes in fc6's reduction order k' = bin * C + channel, the planes
+// e_3 .. COMPRESSED - so that the default product path (RoIHeadsSNN.fuse_roi_align) needs neither k_permute_planes nor k_compress_planes nor
+// their two 31-MB plane copies (row f1's fold was only on the stand-alone head; roi_heads.py:1217 -> faster_rcnn.py:494).
+// A word of a permuted plane = 32 CHANNELS at one bin, so the lanes of a wave are (bin column pw = lane >> 3 < 7, channel lane & 7) of ONE row of
+// bins ph: the ballot of a step holds, in byte pw, the eight channels of an octet at bin (ph, pw), and four octets make the word.  Work-group =
+// (4 RW RoIs, 64 channels = one compressed step per bin, one row of seven bins): wave w takes RW RoIs, for each of the 8 octets one task per RoI
+// (octet-major: the work-groups of an XCD sweep the channels in step, as in K1c''); the bytes meet in LDS as [t][pw][RoI][octet], i.e. the word
+// pair of (t, bin, RoI) is 8 consecutive bytes; store = thread per (t, pw, RoI): the dense planes' two words as they are, a sparse plane's
+// pair through sp_compress_pair - runs of 4 RW consecutive RoIs, exactly what k_encode_rows_perm writes.  The sample geometry comes from the
+// same per-RoI table (built with the operations of roi_bilinear, op for op), the eight tap pairs of an element from the same offsets: pooled
+// values and planes are bit-identical to K1c'' + k_permute_planes + k_compress_planes (tests/test_gpu_roialign.py compares the workspace bytes).
+// A load instruction touches 8 channel planes x one or two lines of ONE feature row (K1c'': ~28 lines - 7 bin rows of 1.3 channels).
+// Threshold form of the encoder only (a.quant: the launcher falls back to the three launches otherwise); C % 64 == 0.
+template <int RW>
+__global__ __launch_bounds__(256) void k_roi_align_encode_perm(const RoiArgs a) {
+    constexpr int RG = 4 * RW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char pbuf[];          // [t][7][RG][8] bytes
+    __shared__ RoiTabEntry tab[4][RW][16];                                        // per wave and RoI: 0, 1 = the two sample rows of ph; 2 .. 15 = sample columns
+    __shared__ uint16_t code[256];
+    code[threadIdx.x] = sp_byte_code(threadIdx.x);
+    const int T = a.T;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // work-group -> (channel pair-block cp, RoI group, bin row): XCD b % 8 keeps to ONE cp where the cp count divides 8, and takes the seven bin rows of
+    // a RoI group one after the other (neighbouring bin rows read neighbouring feature rows of the same windows)
+    const int n_cp = a.C / 64, n_items = a.n_rg * 7;
+    int cp, item;
+    if (8 % n_cp == 0) {
+        const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3, per = 8 / n_cp;
+        cp = xcd % n_cp;
+        item = jj * per + xcd / n_cp;
+    } else { cp = blockIdx.x % n_cp; item = blockIdx.x / n_cp; }
+    if (item >= n_items) return;
+    const int rgrp = item / 7, ph = item - 7 * rgrp;
+    const int r0 = rgrp * RG;
+    const int ch_l = lane & 7, pw = min(lane >> 3, 6);
+    const bool act = lane < 56;
+    // ---- sample tables of this wave's RoIs (K1c'': same operations, same order)
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+        const int r = r0 + wave * RW + i;                        // wave-uniform
+        if (r >= a.R) break;
+        const RoiLevel L = a.lv[a.roi_level[r]];
+        const float* roi = a.rois + (size_t)r * 4;
+        if (lane < 16) {
+            // lane 0, 1: sample row s = 2 ph + lane;  lane 2 .. 15: sample column s = lane - 2 = 2 pw + ix
+            const bool is_x = lane >= 2;
+            const int sidx = is_x ? lane - 2 : 2 * ph + lane, pb = sidx >> 1, ii = sidx & 1;
+            const float lo = __fmul_rn(is_x ? roi[0] : roi[1], L.scale);
+            const float ext = fmaxf(__fsub_rn(__fmul_rn(is_x ? roi[2] : roi[3], L.scale), lo), 1.0f);
+            const float bin = __fdiv_rn(ext, 7.0f);
+            const float b0 = __fadd_rn(lo, __fmul_rn((float)pb, bin));
+            float y = __fadd_rn(b0, __fdiv_rn(__fmul_rn((float)ii + 0.5f, bin), 2.0f));
+            const int n = is_x ? L.W : L.H;
+            RoiTabEntry e;
+            if (y < -1.0f || y > (float)n) { e.a = 0; e.b = 0; e.l = -1.0f; e.h = 0.0f; }     // outside the map: l < 0, offsets stay valid
+            else {
+                y = fmaxf(y, 0.0f);
+                int y_low = (int)y, y_high;
+                if (y_low >= n - 1) { y_high = y_low = n - 1; y = (float)y_low; } else y_high = y_low + 1;
+                e.l = __fsub_rn(y, (float)y_low);
+                e.h = __fsub_rn(1.0f, e.l);
+                if (is_x) { e.b = y_high == y_low; e.a = e.b ? y_low - 1 : y_low; }      // pair base, clamped
+                else { e.a = y_low * L.W; e.b = y_high * L.W; }
+            }
+            tab[wave][i][lane] = e;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
+#pragma unroll 1
+    for (int o = 0; o < 8; ++o) {
+        const int c = cp * 64 + o * 8 + ch_l;
+#pragma unroll
+        for (int i = 0; i < RW; ++i) {
+            const int rl = wave * RW + i, r = r0 + rl;           // wave-uniform
+            if (r >= a.R) break;
+            const RoiLevel L = a.lv[a.roi_level[r]];
+            const int HW = L.H * L.W;
+            const float* const f = L.feat + (size_t)a.roi_batch[r] * a.C * (size_t)HW + (unsigned)(c * HW);
+            const RoiTabEntry* const tb = tab[wave][i];
+            RoiTabEntry ye[2], xe[2];
+            ye[0] = tb[0]; ye[1] = tb[1]; xe[0] = tb[2 + 2 * pw]; xe[1] = tb[3 + 2 * pw];
+            // all eight tap pairs are requested before any is used (samples outside the map read row / column 0 and are dropped)
+            f32x2u pt[2][2], qt[2][2];
+#pragma unroll
+            for (int iy = 0; iy < 2; ++iy)
+#pragma unroll
+                for (int ix = 0; ix < 2; ++ix) {
+                    pt[iy][ix] = *reinterpret_cast<const f32x2u*>(f + (ye[iy].a + xe[ix].a));
+                    qt[iy][ix] = *reinterpret_cast<const f32x2u*>(f + (ye[iy].b + xe[ix].a));
+                }
+            float sm[2][2];
+#pragma unroll
+            for (int iy = 0; iy < 2; ++iy)
+#pragma unroll
+                for (int ix = 0; ix < 2; ++ix) {
+                    const bool ok = ye[iy].l >= 0.0f && xe[ix].l >= 0.0f;
+                    const f32x2u p2 = pt[iy][ix], q2 = qt[iy][ix];
+                    const float v1 = xe[ix].b ? p2.y : p2.x, v2 = p2.y, v3 = xe[ix].b ? q2.y : q2.x, v4 = q2.y;
+                    float acc = __fmul_rn(__fmul_rn(ye[iy].h, xe[ix].h), v1);
+                    acc = __fadd_rn(acc, __fmul_rn(__fmul_rn(ye[iy].h, xe[ix].l), v2));
+                    acc = __fadd_rn(acc, __fmul_rn(__fmul_rn(ye[iy].l, xe[ix].h), v3));
+                    acc = __fadd_rn(acc, __fmul_rn(__fmul_rn(ye[iy].l, xe[ix].l), v4));
+                    sm[iy][ix] = ok ? acc : 0.0f;
+                }
+            const float val = __fdiv_rn(__fadd_rn(__fadd_rn(__fadd_rn(sm[0][0], sm[0][1]), sm[1][0]), sm[1][1]), 4.0f);
+            unsigned long long prev = 0ull;
+            unsigned char* const dst = pbuf + ((size_t)pw * RG + rl) * 8 + o;
+            for (int t = 0; t < T; ++t) {
+                const unsigned long long cum = __ballot(act && val >= a.eth.th[t]);           // first spike at or before t
+                const unsigned long long m = cum & ~prev;
+                prev = cum;
+                if (ch_l == 0 && act) dst[(size_t)t * (7 * RG * 8)] = (unsigned char)(m >> (8 * pw));
+            }
+        }
+    }
+    __syncthreads();
+    // ---- store: item = (t, pw, RoI): the word pair (channel blocks 2 cp, 2 cp + 1) of bin ph * 7 + pw
+    const int cbn = a.C / 32;
+    const size_t R = (size_t)a.R, cmp_plane = (size_t)(a.Dw / 2) * SP_A_ARR * R;
+    for (int idx = threadIdx.x; idx < T * 7 * RG; idx += 256) {
+        const int rl = idx % RG, pwi = (idx / RG) % 7, t = idx / (7 * RG);
+        const size_t row = (size_t)(r0 + rl);
+        if (row >= R) continue;
+        const uint2 w2 = *reinterpret_cast<const uint2*>(pbuf + (size_t)idx * 8);
+        const int bin = ph * 7 + pwi;
+        if (t < a.nd || !a.cmp) {
+            uint32_t* o = a.planes + (size_t)t * a.plane_stride + (size_t)(bin * cbn + 2 * cp) * R + row;
+            o[0] = w2.x; o[R] = w2.y;
+        } else {
+            uint32_t c4[4];
+            sp_compress_pair(w2.x, w2.y, code, c4);
+            uint32_t* o = a.cmp + (size_t)(t - a.nd) * cmp_plane + (size_t)(bin * (cbn / 2) + cp) * SP_A_ARR * R + row;
+#pragma unroll
+            for (int j = 0; j < SP_A_ARR; ++j) o[(size_t)j * R] = c4[j];
+        }
     }
 }

@@ -120,6 +120,7 @@ __global__ void k_pack_heads(const float* __restrict__ wa, int NA, const float* 
 #include "snn_f32.h"
 #include "snn_bf16x3.h"
 #include "snn_sparse.h"
+#include "snn_sparse_pp.h"
 #include "snn_heads.h"
 #include "snn_post.h"
 
@@ -134,6 +135,9 @@ __global__ void k_pack_heads(const float* __restrict__ wa, int NA, const float* 
 // initialisation) and frozen: later setenv() calls change nothing, calls from several threads see one consistent set.
 // snn_debug_reload_knobs() re-reads them (the parity tests compare kernel variants in one process; not for concurrent use).
 #define SNN_SPARSE_FAT_CONV_DEFAULT 3
+#ifndef SNN_CONV_PP_DEFAULT
+#define SNN_CONV_PP_DEFAULT 0
+#endif
 struct Knobs {
     bool enc_generic;        // SNN_ENC_GENERIC=1     op-for-op encoder kernels even for zero rest / reset potentials
     bool enc_rows_ballot;    // SNN_ENC_ROWS=ballot   element-per-lane row encoder
@@ -166,6 +170,8 @@ struct Knobs {
     int sparse_fat_conv;     // SNN_SPARSE_FAT_CONV=0..3 the FAT conv (four waves, LIF in registers; bit-identical to the 8-wave shape): bit 0 = T = 7 .. 9 (4 x 1 waves, tiles of
                              //                       64 positions), bit 1 = T = 12 .. 16 (2 x 2 waves, tiles of 32); default: both
     bool lif_regs;           // SNN_LIF_REGS=0        FAT shapes: the LIF through the LDS tile image instead of in registers (linear layers; the FAT conv has no other form)
+    bool conv_pp;            // SNN_CONV_PP=0|1       RPN conv at T = 7 .. 9: the ping-pong form of the FAT conv (snn_sparse_pp.h: one persistent work-group of 8 waves per
+                             //                       CU, the two waves of a SIMD alternate matrix / memory phases; bit-identical spike planes)
     bool enc_fold;           // SNN_ENC_FOLD=0        RPN head: k_compress_planes as its own launch again instead of inside the encoder launch (bit-identical planes)
     bool sparse_fat;         // SNN_SPARSE_FAT=0      linear layers (fc6) on the 8-wave shape of k_gemm_lif_sparse instead of the FAT one (four waves of up to 256
                              //                       registers, twice the M-tile slots per wave: the default where its loop instances exist; bit-identical)
@@ -191,6 +197,7 @@ static Knobs load_knobs() {
     k.debug_occ = getenv("SNN_DEBUG_OCC") != nullptr;
     k.sparse_fat = !((e = getenv("SNN_SPARSE_FAT")) && e[0] == '0');
     k.enc_fold = !((e = getenv("SNN_ENC_FOLD")) && e[0] == '0');
+    k.conv_pp = (e = getenv("SNN_CONV_PP")) ? e[0] == '1' : SNN_CONV_PP_DEFAULT != 0;
     k.lif_regs = !((e = getenv("SNN_LIF_REGS")) && e[0] == '0');
     k.sparse_fat_conv = (e = getenv("SNN_SPARSE_FAT_CONV")) ? atoi(e) : SNN_SPARSE_FAT_CONV_DEFAULT;
     k.encp_rb = (e = getenv("SNN_ENCP_RB")) ? atoi(e) : 0;
@@ -670,6 +677,26 @@ int snn_debug_encoder_thresholds(const snn_params* p, float* th32) {
     return (t.ok && p->v_leak == 0.0f && p->v_reset == 0.0f) ? 1 : 0;
 }
 
+// The shader clock the chip HOLDS while other work runs (bench.py: `held_clock`): ONE wave that sleeps and polls the constant 100-MHz counter
+// (s_memrealtime) until `ticks` of it have passed, then reports how many shader-clock cycles (s_memtime) went by.  Launched on a side stream beside
+// the step it costs one wave slot of one CU and a few scalar instructions per microsecond.  out2[0] = cycles, out2[1] = ticks: GHz = 0.1 * cycles / ticks.
+__global__ __launch_bounds__(64) void k_clock_probe(unsigned long long* out2, const unsigned int ticks) {
+    unsigned long long t0, c0, t1, c1;
+    asm volatile("s_memrealtime %0\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0), "=s"(c0) :: "memory");
+    do {
+        __builtin_amdgcn_s_sleep(32);
+        asm volatile("s_memrealtime %0\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(c1) :: "memory");
+    } while (t1 - t0 < (unsigned long long)ticks);
+    if (threadIdx.x == 0) { out2[0] = c1 - c0; out2[1] = t1 - t0; }
+}
+
+int snn_debug_clock_probe(unsigned long long* out2_dev, unsigned int ticks_100mhz, snn_stream_t stream) {
+    if (!out2_dev || ticks_100mhz == 0 || ticks_100mhz > 100u * 1000u * 1000u) return fail(-1, "snn_debug_clock_probe: bad argument (at most one second)");
+    hipLaunchKernelGGL(k_clock_probe, dim3(1), dim3(64), 0, (hipStream_t)stream, out2_dev, ticks_100mhz);
+    SNN_CHECK_LAUNCH("k_clock_probe");
+    return 0;
+}
+
 int snn_debug_last_conv_path(void) { return g_last_conv_sparse; }
 int snn_debug_last_fc6_path(void) { return g_last_fc_sparse; }
 void snn_debug_last_rpn_planes(unsigned long long* out3) { if (out3) for (int i = 0; i < 3; ++i) out3[i] = g_last_rpn_planes[i]; }
@@ -1114,9 +1141,25 @@ static int gemm3_lif_sparse(const Gemm3Args& a, bool conv, void* side, size_t si
         fprintf(stderr, "k_gemm_lif_sparse<%d, %d, %d>: pb %d x Tc %d, q %d, lds %d B, %d work-groups per CU, grid %d\n", (int)conv, sp.wn, sp.fat, sp.pb, a.Tc, sp.q, sh.lds, v, sh.grid);
     }
     void* kargs[] = {(void*)&sa};
+    // round 6: the FAT conv on 4 x 1 waves (T = 7 .. 9, LIF in registers) in its ping-pong form - one persistent work-group of 8 waves per CU
+    // (snn_sparse_pp.h); same plan, same arguments, bit-identical planes
+    const int pp_ns = a.Tc - sp.nd;
+    if (conv && sp.fat && sp.wn == 1 && sa.lif_regs && knobs().conv_pp && sp.nd == 2 && pp_ns >= 4 && pp_ns <= 5 && sa.Kc >= 4) {      // (T = 7, 8; at T = 9 the 8-wave work-group has no register left: 68 bytes of scratch)
+        const void* kpp = pp_ns == 4 ? (const void*)k_conv_lif_pp<4> : (const void*)k_conv_lif_pp<5>;
+        e = hipFuncSetAttribute(kpp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PP_LDS);
+        if (e != hipSuccess) return fail(-3, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
+        const int pairs = (sh.xcd_contig * sh.xcd_cpx + 1) / 2;
+        const int grid = 8 * max(1, min(cus / 8, pairs));       // one work-group per CU (148 KB of LDS), a multiple of the 8 XCDs
+        e = hipLaunchKernel(kpp, dim3(grid), dim3(512), kargs, PP_LDS, s);
+        if (e != hipSuccess) return fail(-3, "k_conv_lif_pp launch failed: %s", hipGetErrorString(e));
+        SNN_CHECK_LAUNCH("k_conv_lif_pp");
+    } else {
     e = hipLaunchKernel(kern, dim3(sh.grid), dim3(sp.fat ? 256 : 512), kargs, sh.lds, s);
     if (e != hipSuccess) return fail(-3, "k_gemm_lif_sparse launch failed: %s", hipGetErrorString(e));
     SNN_CHECK_LAUNCH("k_gemm_lif_sparse");
+    }
     if (cnt_pos) {
         PosCountArgs pa;
         memset(&pa, 0, sizeof(pa));
@@ -2211,12 +2254,48 @@ int snn_det_head_forward_roialign_k(const snn_roi_level* levels_host, int n_leve
     const bool wm = det_planes_wm(p, win);
     const bool per = knobs().periods && periods_possible(p) && det_b3_tiles(p, win);
     if (w6_inner > 1 && (!wm || w6_inner != 49)) return fail(-4, "snn_det_head_forward_roialign: permuted fc6 weights need inner = 49 and the word-major fused bf16x3 path");
-    uint32_t* enc_dst = (uint32_t*)((char*)ws + (w6_inner > 1 ? det_ws_perm_offset(R, D, Hd, T) : o_enc));
-    int rc = roi_align_encode_impl(levels_host, n_levels, C, rois, roi_batch, roi_level, R, win.enc_steps, p,
-                                   enc_dst, (size_t)R * cdiv(D, 32), nullptr, wm, stream, per);
-    if (rc) return rc;
+    // round 6: where fc6 will run the structured-sparse launch on bin-major planes, the RoIAlign encoder writes them itself - permuted, e_3 .. compressed
+    // (k_roi_align_encode_perm) - as the row encoder does since round 5 (snn_det_head_forward_k).  fc6's own launcher is asked (nothing is enqueued).
+    bool fold = false;
+    RoiArgs fa;
+    if (knobs().enc_fold && knobs().roi_tab && w6_inner == 49 && wm && per && C % 64 == 0 && levels_host && rois && roi_batch && roi_level && n_levels > 0 && n_levels <= 4) {
+        memset(&fa, 0, sizeof(fa));
+        bool ok = true;
+        for (int l = 0; l < n_levels && ok; ++l) {
+            ok = levels_host[l].feat && levels_host[l].H > 0 && levels_host[l].W >= 2 && (long long)C * levels_host[l].H * levels_host[l].W < (1ll << 29);
+            fa.lv[l].feat = levels_host[l].feat; fa.lv[l].H = levels_host[l].H; fa.lv[l].W = levels_host[l].W; fa.lv[l].scale = levels_host[l].spatial_scale;
+        }
+        fa.p = make_p(p, p->v_th_enc);
+        fa.p.v_fire = ENC_FIRED;
+        const EncTh* eth_f = nullptr;
+        if (ok && enc_zero_rest(fa.p) && enc_mode(fa.p, &eth_f) == ENC_QUANT) {
+            fa.quant = 1; fa.eth = *eth_f;
+            Gemm3Args a6;
+            G3Tile t6;
+            const int Hw = cdiv(Hd, 32);
+            if (spike_gemm_lif_bf16x3_args((const uint32_t*)((char*)ws + o_enc), T, R, D, Hd, p, (const uint16_t*)w6_packed, (uint32_t*)((char*)ws + o_s6), (size_t)R * Hw,
+                                           spk6_count, true, true, &win.fc6, true, &a6, &t6) == 0)
+                fold = gemm3_lif_sparse(a6, false, (char*)ws + o_cur, o_s6 - o_cur, (hipStream_t)stream, SPARSE_QUERY) == 1;
+        }
+    }
+    if (fold) {
+        constexpr int RW = 4;
+        fa.rois = rois; fa.roi_batch = roi_batch; fa.roi_level = roi_level;
+        fa.planes = (uint32_t*)((char*)ws + o_enc); fa.cmp = (uint32_t*)((char*)ws + o_cur); fa.nd = 2;
+        fa.plane_stride = (unsigned long long)R * cdiv(D, 32); fa.R = R; fa.C = C; fa.T = win.enc_steps; fa.Dw = cdiv(D, 32);
+        fa.RW = RW; fa.n_rg = cdiv(R, 4 * RW);
+        const int n_cp = C / 64, n_items = fa.n_rg * 7;
+        const int grid = (8 % n_cp == 0) ? 8 * cdiv(n_items, 8 / n_cp) : n_cp * n_items;
+        hipLaunchKernelGGL(k_roi_align_encode_perm<RW>, dim3(grid), dim3(256), (size_t)fa.T * 7 * 4 * RW * 8, (hipStream_t)stream, fa);
+        SNN_CHECK_LAUNCH("k_roi_align_encode_perm");
+    } else {
+        uint32_t* enc_dst = (uint32_t*)((char*)ws + (w6_inner > 1 ? det_ws_perm_offset(R, D, Hd, T) : o_enc));
+        int rc = roi_align_encode_impl(levels_host, n_levels, C, rois, roi_batch, roi_level, R, win.enc_steps, p,
+                                       enc_dst, (size_t)R * cdiv(D, 32), nullptr, wm, stream, per);
+        if (rc) return rc;
+    }
     return det_head_from_planes(R, D, Hd, K, K4, T, p, w6_packed, w7_packed, w_heads_packed, out_cls, out_bbox,
-                                spk6_count, spk7_count, sum_cls, sum_bbox, ws, wm, win, per, stream, w6_inner);
+                                spk6_count, spk7_count, sum_cls, sum_bbox, ws, wm, win, per, stream, w6_inner, fold);
 }
 
 int snn_det_exchange_payload(const float* class_logits, const float* box_regression, int N, int rois_per_image, int K,

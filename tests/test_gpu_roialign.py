@@ -167,3 +167,46 @@ def test_roi_heads_uses_fusion_and_matches_unfused_on_identical_pooled_values(gp
     assert a[0]["all_scores"].shape == b[0]["all_scores"].shape
     assert torch.equal(a[0]["all_scores"], b[0]["all_scores"]) and torch.equal(a[0]["all_boxes"], b[0]["all_boxes"])
     assert torch.equal(a[0]["boxes"], b[0]["boxes"])
+
+
+@pytest.mark.parametrize("R,C,Hd,K,T", [(300, 64, 128, 5, 12), (1000, 256, 256, 9, 12), (130, 128, 64, 3, 24), (38, 64, 64, 3, 6), (2, 64, 64, 3, 8)])
+def test_roialign_encoder_fold_writes_the_same_planes(gpu_device, monkeypatch, R, C, Hd, K, T):
+    """round 6 (row f1 on the DEFAULT product path): k_roi_align_encode_perm - RoIAlign + encoder + fc6's reduction order + compression in ONE
+    launch - against k_roi_align_encode_tab -> k_permute_planes -> k_compress_planes (SNN_ENC_FOLD=0): the dense planes e_1, e_2 and the
+    compressed planes e_3 .. in the workspace bit for bit, the head's outputs and spike counts with them"""
+    import snn_automotive_object_detection_amd as S
+    from snn_automotive_object_detection_amd import _lib, ops
+    pool, feats, boxes, shapes = _setup(gpu_device, R=R, C=C, seed=R)
+    torch.manual_seed(R + T)
+    head = S.FastRCNNPredictorSNNFull(C * 49, Hd, K, T).to(gpu_device)
+    flist, scales, rois, lvl = pool.assign(feats, boxes, shapes)
+    Rn = int(rois.shape[0])
+    al = lambda v: (v + 255) // 256 * 256
+    Dw, Tc = C * 49 // 32, T - 2
+    o_cur = al(T * Rn * Dw * 4)                                 # det_ws_layout: the encoder planes (fc6 reads them at the front), then the side buffers
+    dense_bytes, cmp_bytes = 2 * Dw * Rn * 4, (Tc - 2) * (Dw // 2) * 4 * Rn * 4
+
+    def run():
+        ws = ops._WS.get(gpu_device, 1)
+        if ws.numel() >= o_cur + cmp_bytes:
+            ws[: o_cur + cmp_bytes].fill_(0x5a)
+        c, b = head.forward_roialign(flist, scales, rois, lvl)
+        assert _lib.load().snn_debug_last_fc6_path() == 1
+        ws = ops._WS.get(gpu_device, 1)
+        return (c.clone(), b.clone()), ws[:dense_bytes].clone(), ws[o_cur: o_cur + cmp_bytes].clone()
+    run()                                                       # (sizes the workspace)
+    monkeypatch.setenv("SNN_ENC_FOLD", "0")
+    a, dense_a, cmp_a = run()
+    monkeypatch.delenv("SNN_ENC_FOLD")
+    for _ in range(2):
+        b, dense_b, cmp_b = run()
+        assert torch.equal(dense_a, dense_b), int((dense_a != dense_b).sum())
+        assert torch.equal(cmp_a, cmp_b), int((cmp_a != cmp_b).sum())
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert int((dense_a != 0).sum()) > 0
+    head.spike_rates = True                                     # (window T - 1: one more compressed plane)
+    r_fold = head.forward_roialign(flist, scales, rois, lvl)
+    c_fold = [c.clone() for c in head.last_spike_counts]
+    monkeypatch.setenv("SNN_ENC_FOLD", "0")
+    head.forward_roialign(flist, scales, rois, lvl)
+    assert all(torch.equal(p, q) for p, q in zip(c_fold, head.last_spike_counts))

@@ -460,6 +460,35 @@ def test_fat_conv_register_lif_is_bit_identical(gpu_device, monkeypatch, T, C):
     assert torch.equal(c1, m.last_spike_counts) and int(c1.sum()) > 0
 
 
+# ---- the ping-pong form of the FAT conv (round 6: one persistent work-group of 8 waves per CU, the two waves of a SIMD alternate) ----------
+@pytest.mark.parametrize("T", [7, 8])
+@pytest.mark.parametrize("C,shapes", [(256, [(41, 67), (19, 27), (7, 9), (1, 3)]), (64, [(41, 67), (19, 27), (7, 9), (1, 3)]), (128, [(5, 7)]),
+                                      (256, [(192, 384), (96, 192), (48, 96), (24, 48), (12, 24)])])
+def test_ping_pong_conv_is_bit_identical(gpu_device, monkeypatch, T, C, shapes):
+    """k_conv_lif_pp (csrc/snn_sparse_pp.h) against k_gemm_lif_sparse<true, 1, FAT>: same matrix instructions per accumulator, same register LIF -
+    the hidden spike planes, the outputs and the integer spike counts of spike-rate mode bit for bit; pyramids with partial tiles, tiles that
+    straddle levels, fewer tile pairs than work-groups, an odd number of tiles per XCD, and the full Cityscapes pyramid"""
+    m = _head(gpu_device, C, T, 190 + T)
+    g = torch.Generator().manual_seed(190 + T + C)
+    feats = [(torch.randn(2, C, h, w, generator=g) * 1.7).to(gpu_device) for h, w in shapes]
+    monkeypatch.setenv("SNN_CONV_PP", "0")
+    a = _run(m, feats, sparse=True)
+    planes_a = _rpn_hidden_planes(gpu_device, T, C // 32)
+    monkeypatch.setenv("SNN_CONV_PP", "1")
+    for _ in range(3):
+        b = _run(m, feats, sparse=True)
+        planes_b = _rpn_hidden_planes(gpu_device, T, C // 32)
+        assert torch.equal(planes_a, planes_b), int((planes_a != planes_b).sum())
+        assert all(torch.equal(x, y) for x, y in zip(a, b))
+    assert int((planes_a != 0).sum()) > 0
+    m.spike_rates = True
+    m(feats)
+    c1 = m.last_spike_counts.clone()
+    monkeypatch.setenv("SNN_CONV_PP", "0")
+    m(feats)
+    assert torch.equal(c1, m.last_spike_counts) and int(c1.sum()) > 0
+
+
 @pytest.mark.parametrize("R,C,Hd,K,T", [(2000, 256, 1024, 9, 12), (2000, 256, 1024, 9, 14), (333, 64, 256, 11, 11), (77, 64, 128, 5, 12), (31, 64, 128, 5, 9), (1, 64, 128, 5, 13)])
 def test_fat_fc6_register_lif_is_bit_identical(gpu_device, monkeypatch, R, C, Hd, K, T):
     """fc6 on the FAT shape with the LIF in registers (each row-wave all planes of its own 16 RoIs) against the same shape through the LDS

@@ -1,4 +1,4 @@
-"""Build profiles/r5_traffic.json from the summaries of tools/prof_round.sh (kernel stats + the five separate PMC passes), one per bench
+"""Build profiles/r6_traffic.json (round 5: r5_traffic.json) from the summaries of tools/prof_round.sh (kernel stats + the five separate PMC passes), one per bench
 workload:   python tools/make_traffic_json.py profiles/r5_traffic.json cityscapes=profiles/r5_default_summary.txt stress=... bdd=...
 Per workload and big launch (conv = k_gemm_lif_sparse<true, ...>, fc6 = k_gemm_lif_sparse<false, ...>, fc7 = k_gemm_bf16x3<4, ...>): HBM bytes per launch
 (2 x FETCH_SIZE + WRITE_SIZE, counter unit 1 KiB: MI355X_MICROARCH.md, HBM section; calibrated for this family's LDS-DMA gathers by
@@ -106,6 +106,10 @@ def main():
                 e["l2_hits"], e["l2_misses"] = g("TCC_HIT_sum"), g("TCC_MISS_sum")
             entry[key] = e
         res[wl] = {"bf16x3": entry}
+    # the source tree the PMC passes were taken on: bench.py quotes `roofline.traffic` from this file only for a build of the SAME digest
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from snn_automotive_object_detection_amd import build as _build
+    res["source_digest"] = _build.source_digest()
     with open(out_path, "w") as f:
         json.dump(res, f, indent=1)
     print(json.dumps(res, indent=1)[:3000])

@@ -651,7 +651,7 @@ __global__ __launch_bounds__(256) void k_roi_align_encode_tab(const RoiArgs a) {
 // e_3 .. COMPRESSED - so that the default product path (RoIHeadsSNN.fuse_roi_align) needs neither k_permute_planes nor k_compress_planes nor
 // their two 31-MB plane copies (row f1's fold was only on the stand-alone head; roi_heads.py:1217 -> faster_rcnn.py:494).
 // A word of a permuted plane = 32 CHANNELS at one bin, so the lanes of a wave are (bin column pw = lane >> 3 < 7, channel lane & 7) of ONE row of
-// bins ph: the ballot of a step holds, in byte pw, the eight channels of an octet at bin (ph, pw), and four octets make the word.  Work-group =
+// bins ph: the (8 x 8 transposed) ballot of a step holds, in byte pw, the eight channels of an octet at bin (ph, pw), and four octets make the word.  Work-group =
 // (4 RW RoIs, 64 channels = one compressed step per bin, one row of seven bins): wave w takes RW RoIs, for each of the 8 octets one task per RoI
 // (octet-major: the work-groups of an XCD sweep the channels in step, as in K1c''); the bytes meet in LDS as [t][pw][RoI][octet], i.e. the word
 // pair of (t, bin, RoI) is 8 consecutive bytes; store = thread per (t, pw, RoI): the dense planes' two words as they are, a sparse plane's
@@ -663,7 +663,8 @@ __global__ __launch_bounds__(256) void k_roi_align_encode_tab(const RoiArgs a) {
 template <int RW>
 __global__ __launch_bounds__(256) void k_roi_align_encode_perm(const RoiArgs a) {
     constexpr int RG = 4 * RW;
-    extern __shared__ __attribute__((aligned(16))) unsigned char pbuf[];          // [t][7][RG][8] bytes
+    extern __shared__ __attribute__((aligned(16))) unsigned char pbuf[];          // word pairs [t][7][RG] (8 bytes each), then the raw ballots [t][RG][8 octets]
+    unsigned long long* const mbuf = reinterpret_cast<unsigned long long*>(pbuf + (size_t)a.T * 7 * RG * 8);
     __shared__ RoiTabEntry tab[4][RW][16];                                        // per wave and RoI: 0, 1 = the two sample rows of ph; 2 .. 15 = sample columns
     __shared__ uint16_t code[256];
     code[threadIdx.x] = sp_byte_code(threadIdx.x);
@@ -681,8 +682,10 @@ __global__ __launch_bounds__(256) void k_roi_align_encode_perm(const RoiArgs a) 
     if (item >= n_items) return;
     const int rgrp = item / 7, ph = item - 7 * rgrp;
     const int r0 = rgrp * RG;
-    const int ch_l = lane & 7, pw = min(lane >> 3, 6);
-    const bool act = lane < 56;
+    // lane = channel-of-the-octet * 8 + bin column (7 of 8 used): CONSECUTIVE lanes read neighbouring bins of one channel plane - the first form, with the
+    // channel fastest, put every lane of a quad on another channel plane and cost 0.42 ms against 0.25 for the table kernel (profiles/r6_roi_fold_ab.txt)
+    const int pw = min(lane & 7, 6), ch_l = lane >> 3;
+    const bool act = (lane & 7) < 7;
     // ---- sample tables of this wave's RoIs (K1c'': same operations, same order)
 #pragma unroll
     for (int i = 0; i < RW; ++i) {
@@ -755,14 +758,29 @@ __global__ __launch_bounds__(256) void k_roi_align_encode_perm(const RoiArgs a) 
                 }
             const float val = __fdiv_rn(__fadd_rn(__fadd_rn(__fadd_rn(sm[0][0], sm[0][1]), sm[1][0]), sm[1][1]), 4.0f);
             unsigned long long prev = 0ull;
-            unsigned char* const dst = pbuf + ((size_t)pw * RG + rl) * 8 + o;
+            unsigned long long* const dst = mbuf + (size_t)rl * 8 + o;
             for (int t = 0; t < T; ++t) {
                 const unsigned long long cum = __ballot(act && val >= a.eth.th[t]);           // first spike at or before t
-                const unsigned long long m = cum & ~prev;
+                const unsigned long long m = cum & ~prev;                                      // bit (channel * 8 + bin column): byte c = the bins of channel c
                 prev = cum;
-                if (ch_l == 0 && act) dst[(size_t)t * (7 * RG * 8)] = (unsigned char)(m >> (8 * pw));
+                if (lane == 0) dst[(size_t)t * (RG * 8)] = m;
             }
         }
+    }
+    __syncthreads();
+    // ---- bit transposition by ballot: for a (t, RoI) the 64 bytes of mbuf are the 64 channels' bin bits (byte = octet * 8 + channel of the octet); lane = channel
+    // reads its byte, and the ballot of bit pw over the lanes IS the word pair (channel blocks 2 cp, 2 cp + 1) of bin column pw.  (The first form
+    // transposed every 8 x 8 ballot on the scalar unit inside the task loop - 18 scalar instructions per step and task: 0.34 ms for the launch.)
+    for (int it = wave; it < T * RG; it += 4) {
+        const unsigned int byte = reinterpret_cast<const unsigned char*>(mbuf)[(size_t)it * 64 + lane];
+        const int t = it / RG, rl = it - t * RG;
+        unsigned long long wp = 0ull;
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
+            const unsigned long long b = __ballot((byte >> q) & 1u);
+            wp = lane == q ? b : wp;
+        }
+        if (lane < 7) *reinterpret_cast<unsigned long long*>(pbuf + ((size_t)(t * 7 + lane) * RG + rl) * 8) = wp;
     }
     __syncthreads();
     // ---- store: item = (t, pw, RoI): the word pair (channel blocks 2 cp, 2 cp + 1) of bin ph * 7 + pw

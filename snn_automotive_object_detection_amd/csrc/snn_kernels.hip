@@ -15,7 +15,8 @@
 // (snn_automotive_object_detection_amd/build.py) never does, and tests/test_code_object.py checks that this guard fires.
 #if !defined(SNN_EXPERIMENTS) && (defined(SNN_EXP_NO_FETCH) || defined(SNN_EXP_NO_GLDS) || defined(SNN_EXP_NO_BARRIER) || \
     defined(SNN_EXP_CLOCK) || defined(SNN_EXP_TIMELINE) || defined(SNN_EXP_SP_NO_A) || defined(SNN_EXP_SP_NO_B) || defined(SNN_EXP_SP_NO_AREAD) || defined(SNN_EXP_SP_NO_BREAD) || defined(SNN_EXP_SP_NO_MFMA) || defined(SNN_EXP_SP_NO_BAR) || defined(SNN_EXP_ONE_WG_PER_CU) || defined(SNN_EXP_MX_NOSTAGE) || defined(SNN_EXP_MX_NOREADB) || defined(SNN_EXP_MX_NOBAR) || \
-    defined(SNN_EXP_MX_NOA) || defined(SNN_EXP_MX_BAR2) || defined(SNN_EXP_MX_RDW_G) || defined(SNN_EXP_ENCP_NOLOAD) || defined(SNN_EXP_ENCP_NOENC) || defined(SNN_EXP_ENCP_NOSTORE))
+    defined(SNN_EXP_MX_NOA) || defined(SNN_EXP_MX_BAR2) || defined(SNN_EXP_MX_RDW_G) || defined(SNN_EXP_ENCP_NOLOAD) || defined(SNN_EXP_ENCP_NOENC) || defined(SNN_EXP_ENCP_NOSTORE) || \
+    defined(SNN_EXP_PP_NOWAIT) || defined(SNN_EXP_PP_NOCOPY) || defined(SNN_EXP_PP_NOBAR) || defined(SNN_EXP_PP_NOMFMA) || defined(SNN_EXP_PP_NOEPI) || defined(SNN_EXP_PP_NOY) || defined(SNN_EXP_PP_ALLDENSE) || defined(SNN_EXP_PP_ALLSPARSE) || defined(SNN_EXP_PP_NOBREAD))
 #error "SNN_EXP_* switches are timing experiments with wrong results: add -DSNN_EXPERIMENTS (never in a product build)"
 #endif
 
@@ -120,7 +121,9 @@ __global__ void k_pack_heads(const float* __restrict__ wa, int NA, const float* 
 #include "snn_f32.h"
 #include "snn_bf16x3.h"
 #include "snn_sparse.h"
+#ifdef SNN_PINGPONG                                 // (round 6: measured 14 % SLOWER than the FAT conv - profiles/r6_pingpong.txt; A/B builds only, tools/ab_build.sh)
 #include "snn_sparse_pp.h"
+#endif
 #include "snn_heads.h"
 #include "snn_post.h"
 
@@ -170,8 +173,9 @@ struct Knobs {
     int sparse_fat_conv;     // SNN_SPARSE_FAT_CONV=0..3 the FAT conv (four waves, LIF in registers; bit-identical to the 8-wave shape): bit 0 = T = 7 .. 9 (4 x 1 waves, tiles of
                              //                       64 positions), bit 1 = T = 12 .. 16 (2 x 2 waves, tiles of 32); default: both
     bool lif_regs;           // SNN_LIF_REGS=0        FAT shapes: the LIF through the LDS tile image instead of in registers (linear layers; the FAT conv has no other form)
-    bool conv_pp;            // SNN_CONV_PP=0|1       RPN conv at T = 7 .. 9: the ping-pong form of the FAT conv (snn_sparse_pp.h: one persistent work-group of 8 waves per
-                             //                       CU, the two waves of a SIMD alternate matrix / memory phases; bit-identical spike planes)
+    bool conv_pp;            // SNN_CONV_PP=0|1       -DSNN_PINGPONG builds only (tools/ab_build.sh): RPN conv at T = 7, 8 in the ping-pong form of the FAT conv (snn_sparse_pp.h:
+                             //                       one persistent work-group of 8 waves per CU, the two waves of a SIMD alternate matrix / memory phases; bit-identical spike
+                             //                       planes, measured 14 % slower: profiles/r6_pingpong.txt)
     bool enc_fold;           // SNN_ENC_FOLD=0        RPN head: k_compress_planes as its own launch again instead of inside the encoder launch (bit-identical planes)
     bool sparse_fat;         // SNN_SPARSE_FAT=0      linear layers (fc6) on the 8-wave shape of k_gemm_lif_sparse instead of the FAT one (four waves of up to 256
                              //                       registers, twice the M-tile slots per wave: the default where its loop instances exist; bit-identical)
@@ -1141,6 +1145,7 @@ static int gemm3_lif_sparse(const Gemm3Args& a, bool conv, void* side, size_t si
         fprintf(stderr, "k_gemm_lif_sparse<%d, %d, %d>: pb %d x Tc %d, q %d, lds %d B, %d work-groups per CU, grid %d\n", (int)conv, sp.wn, sp.fat, sp.pb, a.Tc, sp.q, sh.lds, v, sh.grid);
     }
     void* kargs[] = {(void*)&sa};
+#ifdef SNN_PINGPONG
     // round 6: the FAT conv on 4 x 1 waves (T = 7 .. 9, LIF in registers) in its ping-pong form - one persistent work-group of 8 waves per CU
     // (snn_sparse_pp.h); same plan, same arguments, bit-identical planes
     const int pp_ns = a.Tc - sp.nd;
@@ -1155,7 +1160,9 @@ static int gemm3_lif_sparse(const Gemm3Args& a, bool conv, void* side, size_t si
         e = hipLaunchKernel(kpp, dim3(grid), dim3(512), kargs, PP_LDS, s);
         if (e != hipSuccess) return fail(-3, "k_conv_lif_pp launch failed: %s", hipGetErrorString(e));
         SNN_CHECK_LAUNCH("k_conv_lif_pp");
-    } else {
+    } else
+#endif
+    {
     e = hipLaunchKernel(kern, dim3(sh.grid), dim3(sp.fat ? 256 : 512), kargs, sh.lds, s);
     if (e != hipSuccess) return fail(-3, "k_gemm_lif_sparse launch failed: %s", hipGetErrorString(e));
     SNN_CHECK_LAUNCH("k_gemm_lif_sparse");
@@ -2258,7 +2265,11 @@ int snn_det_head_forward_roialign_k(const snn_roi_level* levels_host, int n_leve
     // (k_roi_align_encode_perm) - as the row encoder does since round 5 (snn_det_head_forward_k).  fc6's own launcher is asked (nothing is enqueued).
     bool fold = false;
     RoiArgs fa;
-    if (knobs().enc_fold && knobs().roi_tab && w6_inner == 49 && wm && per && C % 64 == 0 && levels_host && rois && roi_batch && roi_level && n_levels > 0 && n_levels <= 4) {
+    // Planned for windows of up to 12 planes (T_det <= 14): measured on the bench's pyramid, 2000 RoIs (profiles/r6_roi_fold_ab.txt, same lease) the fused
+    // head takes 0.943 against 0.948 ms at T_det = 12 - the launch itself is 30 us slower than the table kernel (7 of 8 lanes per bin row, a second
+    // pass that transposes the ballots) and saves k_permute_planes + k_compress_planes (38 us) and their two 31-MB plane copies - but 2.04 against
+    // 1.88 ms at T_det = 24, where its 44 KB of LDS leave three work-groups per CU to a launch that lives on loads in flight.
+    if (knobs().enc_fold && knobs().roi_tab && win.enc_steps <= 12 && w6_inner == 49 && wm && per && C % 64 == 0 && levels_host && rois && roi_batch && roi_level && n_levels > 0 && n_levels <= 4) {
         memset(&fa, 0, sizeof(fa));
         bool ok = true;
         for (int l = 0; l < n_levels && ok; ++l) {
@@ -2286,7 +2297,7 @@ int snn_det_head_forward_roialign_k(const snn_roi_level* levels_host, int n_leve
         fa.RW = RW; fa.n_rg = cdiv(R, 4 * RW);
         const int n_cp = C / 64, n_items = fa.n_rg * 7;
         const int grid = (8 % n_cp == 0) ? 8 * cdiv(n_items, 8 / n_cp) : n_cp * n_items;
-        hipLaunchKernelGGL(k_roi_align_encode_perm<RW>, dim3(grid), dim3(256), (size_t)fa.T * 7 * 4 * RW * 8, (hipStream_t)stream, fa);
+        hipLaunchKernelGGL(k_roi_align_encode_perm<RW>, dim3(grid), dim3(256), (size_t)fa.T * (7 + 8) * 4 * RW * 8, (hipStream_t)stream, fa);     // word pairs + raw ballots
         SNN_CHECK_LAUNCH("k_roi_align_encode_perm");
     } else {
         uint32_t* enc_dst = (uint32_t*)((char*)ws + (w6_inner > 1 ? det_ws_perm_offset(R, D, Hd, T) : o_enc));

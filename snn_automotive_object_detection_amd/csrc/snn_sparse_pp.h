@@ -184,9 +184,32 @@ __global__ __launch_bounds__(512, 2) void k_conv_lif_pp(const SparseConvArgs arg
         auto x_phase = [&](const uint32_t oa, const uint32_t ob) __attribute__((always_inline)) {
 #pragma unroll
             for (int g = 0; g < 3 * NT; ++g) {
+#ifndef SNN_EXP_PP_NOBREAD                               // (timing experiment: the weight fragments stay what the Y phase loaded)
                 if (g + BD < 3 * NT) load_b(bbuf[(g + BD) % (BD + 1)], ob, g + BD);
+#endif
                 const bfv16 bb = bbuf[g % (BD + 1)];
                 const bfv8 b0 = __builtin_shufflevector(bb, bb, 0, 1, 2, 3, 4, 5, 6, 7), b1 = __builtin_shufflevector(bb, bb, 8, 9, 10, 11, 12, 13, 14, 15);
+#ifdef SNN_EXP_PP_NOMFMA
+                asm volatile("" :: "v"(bb));
+#elif defined(SNN_EXP_PP_ALLDENSE)                       // (timing experiment: the same number of matrix instructions, all of the dense type)
+#pragma unroll
+                for (int d = 0; d < ND; ++d) {
+                    acc[d][g / 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(p_ad[d][0], b0, acc[d][g / 3], 0, 0, 0);
+                    acc[d][g / 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(p_ad[d][1], b1, acc[d][g / 3], 0, 0, 0);
+                }
+#pragma unroll
+                for (int q = 0; q < NS; ++q)
+                    acc[ND + q][g / 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(p_as[q], (q & 1) ? b1 : b0, acc[ND + q][g / 3], 0, 0, 0);
+#elif defined(SNN_EXP_PP_ALLSPARSE)                      // (timing experiment: ... all of the structured-sparse type)
+#pragma unroll
+                for (int d = 0; d < ND; ++d) {
+                    acc[d][g / 3] = __builtin_amdgcn_smfmac_f32_16x16x64_bf16(p_ad[d][0], bb, acc[d][g / 3], p_ix[0], 0, 0);
+                    acc[d][g / 3] = __builtin_amdgcn_smfmac_f32_16x16x64_bf16(p_ad[d][1], bb, acc[d][g / 3], p_ix[1], 0, 0);
+                }
+#pragma unroll
+                for (int q = 0; q < NS; ++q)
+                    acc[ND + q][g / 3] = __builtin_amdgcn_smfmac_f32_16x16x64_bf16(p_as[q], bb, acc[ND + q][g / 3], p_ix[q], 0, 0);
+#else
 #pragma unroll
                 for (int d = 0; d < ND; ++d) {
                     acc[d][g / 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(p_ad[d][0], b0, acc[d][g / 3], 0, 0, 0);
@@ -195,6 +218,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_lif_pp(const SparseConvArgs arg
 #pragma unroll
                 for (int q = 0; q < NS; ++q)
                     acc[ND + q][g / 3] = __builtin_amdgcn_smfmac_f32_16x16x64_bf16(p_as[q], bb, acc[ND + q][g / 3], p_ix[q], 0, 0);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
             }
             if ((p_sec[0] | p_sec[1]) != 0ull) {               // (rare) the secondary plane of the M-tiles that have one in this step
@@ -217,7 +241,17 @@ __global__ __launch_bounds__(512, 2) void k_conv_lif_pp(const SparseConvArgs arg
                 }
             }
         };
+#ifdef SNN_EXP_PP_NOBAR                                  // (timing experiments - wrong results: what does each ingredient of an interval cost?)
+#define PP_BARRIER() do { asm volatile("" ::: "memory"); } while (0)
+#else
 #define PP_BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+#endif
+#ifdef SNN_EXP_TIMELINE                                  // diagnostic build: shader-clock stamps (s_memtime) of work-group 0's first tile pair, five per step and half
+#define PP_STAMP(i) do { if (blockIdx.x == 0 && pr == wslot && (tid & 255) == 0 && s < 64) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+                                                   args.tl[((size_t)h * 64 + s) * 8 + (i)] = t_; } } while (0)
+#else
+#define PP_STAMP(i) do { } while (0)
+#endif
 
         if (h == 1) PP_BARRIER();                               // half 1 runs one interval behind half 0
         // ---- P: the first copies of the tile (A(0), B(0), A(1)); A(0) and B(0) must have landed before Y_0
@@ -233,20 +267,31 @@ __global__ __launch_bounds__(512, 2) void k_conv_lif_pp(const SparseConvArgs arg
         for (int s = 0; s < n_steps; ++s) {
             const uint32_t ob = (uint32_t)((s & 1) * SP_B_BYTES), ob_n = (uint32_t)(((s + 1) & 1) * SP_B_BYTES);
             // ---- Y_s: this step's fragments into registers, then the copies of the steps ahead (B(s + 1) first: the wait behind X_s leaves A(s + 2) in flight)
+            PP_STAMP(0);
             if (live) {
+#ifndef SNN_EXP_PP_NOY
                 load_a_all(sa);
 #pragma unroll
                 for (int g0 = 0; g0 < BD; ++g0) load_b(bbuf[g0], ob, g0);
+#endif
+#ifndef SNN_EXP_PP_NOCOPY
                 if (s + 1 < n_steps) stage_b(ob_n);
                 if (s + 2 < n_steps) stage_a(sa2);
+#endif
             }
+            PP_STAMP(1);
             PP_BARRIER();
+            PP_STAMP(2);
             // ---- X_s
             if (live) {
                 x_phase(sa, ob);
                 asm volatile("" ::: "memory");
+                PP_STAMP(3);
+#ifndef SNN_EXP_PP_NOWAIT
                 if (s + 2 < n_steps) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
             }
+            PP_STAMP(4);
             PP_BARRIER();
             sa = sa + PP_A_BYTES == PP_A_SLOTS * PP_A_BYTES ? 0u : sa + PP_A_BYTES;
             sa2 = sa2 + PP_A_BYTES == PP_A_SLOTS * PP_A_BYTES ? 0u : sa2 + PP_A_BYTES;
@@ -256,8 +301,12 @@ __global__ __launch_bounds__(512, 2) void k_conv_lif_pp(const SparseConvArgs arg
             const int T = args.T;
             uint32_t mine[4] = {0, 0, 0, 0}, cnt[4] = {0, 0, 0, 0};
             const bool counting = args.cnt_row != nullptr;
+#ifdef SNN_EXP_PP_NOEPI
+            for (int r = 0; r < 4; ++r) mine[r] = __float_as_uint(acc[r][0][0] + acc[r + 1][1][1]);
+#else
             if (counting) sp_lif_regs<NS + 3, 1, NT, MTS, true>(acc, args.p, lane, mine, cnt);
             else sp_lif_regs<NS + 3, 1, NT, MTS, false>(acc, args.p, lane, mine, cnt);
+#endif
             const int t_mine = 1 + ((lane & 15) >> 1), word = nb * 2 + (lane & 1);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -273,5 +322,6 @@ __global__ __launch_bounds__(512, 2) void k_conv_lif_pp(const SparseConvArgs arg
         }
         if (h == 0) PP_BARRIER();                               // (pairs with half 1's barrier behind its last X)
 #undef PP_BARRIER
+#undef PP_STAMP
     }
 }

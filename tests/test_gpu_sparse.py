@@ -11,6 +11,8 @@
  * (round 5) fc6 beyond 16 steps (T_det = 17 .. 26, config[4]'s 24) and in spike-rate mode (window T - 1) runs the sparse launch with the
    general LIF epilogue."""
 import numpy as np
+import os
+
 import pytest
 import torch
 
@@ -461,6 +463,8 @@ def test_fat_conv_register_lif_is_bit_identical(gpu_device, monkeypatch, T, C):
 
 
 # ---- the ping-pong form of the FAT conv (round 6: one persistent work-group of 8 waves per CU, the two waves of a SIMD alternate) ----------
+@pytest.mark.skipif("PP" not in os.path.basename(os.environ.get("SNN_HIP_LIB", "")), reason="needs a -DSNN_PINGPONG build (bash tools/ab_build.sh PP:\"-DSNN_PINGPONG\"; "
+                    "SNN_HIP_LIB=tools/_ab/lib_PP.so): the ping-pong conv measured slower than the FAT conv and is not in the product library")
 @pytest.mark.parametrize("T", [7, 8])
 @pytest.mark.parametrize("C,shapes", [(256, [(41, 67), (19, 27), (7, 9), (1, 3)]), (64, [(41, 67), (19, 27), (7, 9), (1, 3)]), (128, [(5, 7)]),
                                       (256, [(192, 384), (96, 192), (48, 96), (24, 48), (12, 24)])])

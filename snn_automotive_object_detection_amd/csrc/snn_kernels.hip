@@ -16,7 +16,7 @@
 #if !defined(SNN_EXPERIMENTS) && (defined(SNN_EXP_NO_FETCH) || defined(SNN_EXP_NO_GLDS) || defined(SNN_EXP_NO_BARRIER) || \
     defined(SNN_EXP_CLOCK) || defined(SNN_EXP_TIMELINE) || defined(SNN_EXP_SP_NO_A) || defined(SNN_EXP_SP_NO_B) || defined(SNN_EXP_SP_NO_AREAD) || defined(SNN_EXP_SP_NO_BREAD) || defined(SNN_EXP_SP_NO_MFMA) || defined(SNN_EXP_SP_NO_BAR) || defined(SNN_EXP_ONE_WG_PER_CU) || defined(SNN_EXP_MX_NOSTAGE) || defined(SNN_EXP_MX_NOREADB) || defined(SNN_EXP_MX_NOBAR) || \
     defined(SNN_EXP_MX_NOA) || defined(SNN_EXP_MX_BAR2) || defined(SNN_EXP_MX_RDW_G) || defined(SNN_EXP_ENCP_NOLOAD) || defined(SNN_EXP_ENCP_NOENC) || defined(SNN_EXP_ENCP_NOSTORE) || \
-    defined(SNN_EXP_PP_NOWAIT) || defined(SNN_EXP_PP_NOCOPY) || defined(SNN_EXP_PP_NOBAR) || defined(SNN_EXP_PP_NOMFMA) || defined(SNN_EXP_PP_NOEPI) || defined(SNN_EXP_PP_NOY) || defined(SNN_EXP_PP_ALLDENSE) || defined(SNN_EXP_PP_ALLSPARSE) || defined(SNN_EXP_PP_NOBREAD))
+    defined(SNN_EXP_PP_NOWAIT) || defined(SNN_EXP_PP_NOCOPY) || defined(SNN_EXP_PP_NOBAR) || defined(SNN_EXP_PP_NOMFMA) || defined(SNN_EXP_PP_NOEPI) || defined(SNN_EXP_PP_NOY) || defined(SNN_EXP_PP_ALLDENSE) || defined(SNN_EXP_PP_ALLSPARSE) || defined(SNN_EXP_PP_NOBREAD) || defined(SNN_EXP_SP_NO_SEC))
 #error "SNN_EXP_* switches are timing experiments with wrong results: add -DSNN_EXPERIMENTS (never in a product build)"
 #endif
 

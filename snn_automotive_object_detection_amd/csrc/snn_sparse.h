@@ -683,7 +683,11 @@ __global__ __launch_bounds__(FAT ? 256 : 512, FAT ? 2 : 4) void k_gemm_lif_spars
             } else {
                 do_part(std::integral_constant<int, 0>{}, std::integral_constant<int, NS>{}, std::true_type{});
             }
+#ifdef SNN_EXP_SP_NO_SEC                              // (timing experiment - wrong results: what does the secondary plane's second pass cost?)
+            if (false) {
+#else
             if (NS > 0 && (sec[0] | sec[1] | sec[2] | sec[3]) != 0ull) {   // (rare) the secondary plane of the M-tiles that have one in this step
+#endif
 #pragma unroll
                 for (int q = 0; q < NS; ++q) {
                     if (((sec[q >> 2] >> (16 * (q & 3))) & 0xffffull) == 0ull) continue;

@@ -142,7 +142,7 @@ def cpu_baseline(leg, repeats=3, warm=True):
             "sample": "b=%d: oracle RPN head (5-level pyramid, T=%d) + detector head (%d RoIs, T=%d)%s on the GPU leg's own inputs and "
                       "weights; %s%d repeat%s, median %.1f s per batch" % (
                           wl["batch"], wl["T_rpn"], rois.shape[0], wl["T_det"], ", spike-rate variants" if rates else "",
-                          "1 warm-up + " if warm else "", repeats, "" if repeats == 1 else "s", med)}
+                          "1 warm-up + " if warm else "behind the headline's warm-up: ", repeats, "" if repeats == 1 else "s", med)}
 
 
 # ---------------------------------------------------------------------------------------------
@@ -670,6 +670,7 @@ def main():
     ap.add_argument("--sustain-s", type=float, default=2.0)
     ap.add_argument("--sweep-t", action="store_true", help="only the throughput-vs-T grid (T_rpn 4..12, T_det 8..16) besides the headline")
     ap.add_argument("--no-dp-e2e", action="store_true", help="skip the whole-model data-parallel leg (config[3])")
+    ap.add_argument("--no-clock-probe", action="store_true", help="skip the held-clock probe (runs under rocprofv3 --pmc, where kernels are serialised and the probe says nothing)")
     args = ap.parse_args()
 
     # ---- stand-alone multi-rank launch: start the ranks BEFORE anything initialises the GPU in this process ----
@@ -788,7 +789,7 @@ def main():
         pool hold different clocks under the same matrix-core load (MI355X_MICROARCH.md 'DVFS give-back' item 5), so `frac_at_held_clock` =
         frac x 2.4 / held clock is the part of the fraction that is the kernel's and not the box's"""
         rf = {**l.roofline(bd_["rpn_conv3x3_lif"], t_, t_src), **t_prof}
-        clk = l.held_clocks(step_ms, bd_["rpn_conv3x3_lif"])
+        clk = l.held_clocks(step_ms, bd_["rpn_conv3x3_lif"]) if not args.no_clock_probe else {"step_ghz": None, "conv_lif_ghz": None, "note": "--no-clock-probe"}
         if clk.get("conv_lif_ghz"):
             rf["held_clock_ghz"] = clk["conv_lif_ghz"]
             rf["frac_at_held_clock"] = round(rf["frac"] * NOMINAL_CLOCK_GHZ / clk["conv_lif_ghz"], 4)
@@ -825,6 +826,13 @@ def main():
         enc_rpn["live_gb_per_s"] = round(enc_rpn["algorithmic_hbm_bytes"] / (bd["rpn_encode"] * 1e-3) / 1e9, 1)
     if "SNN_DP_DEVICE" in os.environ and world > 1:
         out["config"]["oversubscribed"] = "%d ranks on device %s (test of the N-rank path, not a scaling measurement)" % (world, os.environ["SNN_DP_DEVICE"])
+
+    # ---- the CPU baseline of the headline (the oracle on the host cores, same tensors): before the side legs, whose own single passes then find the
+    # thread pool and the allocator warm
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(leg, args.cpu_repeats)
+    elif rank == 0:
+        out["cpu_baseline"] = None
 
     extra = {}
 
@@ -890,9 +898,9 @@ def main():
                    "breakdown_ms": {k: round(v, 3) for k, v in bd2.items()},
                    "kernels_over_step": round((bd2["rpn_head"] + bd2["det_head"]) / (dt2 / args.steps * 1e3), 4)}
             if not args.no_cpu_baseline:
-                # "report, per config ...": the oracle on THIS leg's tensors too (1 warm-up on the small levels + ONE timed pass:
-                # a pass is 25-50 s of host time)
-                res["cpu_baseline"] = cpu_baseline(l2, repeats=1)
+                # "report, per config ...": the oracle on THIS leg's tensors too - ONE timed pass (25-50 s of host time) behind the
+                # headline's warm-up and repeats
+                res["cpu_baseline"] = cpu_baseline(l2, repeats=1, warm=False)
             return res
         for name in ("bdd", "stress"):
             if name != args.workload:
@@ -901,10 +909,6 @@ def main():
             side_leg("e2e", lambda: e2e_leg(model_for("cityscapes", 9), dev))
     if extra:
         out["extra"] = extra
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(leg, args.cpu_repeats)
-    elif rank == 0:
-        out["cpu_baseline"] = None
     # ---- the side legs' headline numbers once more at the top level and (compact) inside `config`, which the driver keeps
     other = {}
     for name, key in (("sustained", "sustained_img_s"), ("bdd", "bdd_heads_img_s"), ("stress", "stress_heads_img_s"),

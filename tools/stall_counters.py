@@ -56,7 +56,7 @@ def main():
             continue
         d = os.path.join(outdir, "pass%d" % i)
         cmd = ["rocprofv3", "--kernel-trace", "--pmc"] + have + ["--output-format", "csv", "-d", d, "--",
-               "python3", "bench.py", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extra"] + bench_args
+               "python3", "bench.py", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extra", "--no-clock-probe"] + bench_args
         try:                                                     # (a pass of TCP counters once sat for 25 minutes: every pass has its own limit)
             r = subprocess.run(["timeout", "-k", "10", "240"] + cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         except Exception as e:

@@ -1,5 +1,5 @@
 """Interval timeline of the ping-pong conv (k_conv_lif_pp, csrc/snn_sparse_pp.h) from a -DSNN_EXP_TIMELINE build:
-  bash tools/ab_build.sh TLPP:"-DSNN_EXP_TIMELINE -DSNN_CONV_PP_DEFAULT=1"   then on the GPU box   SNN_HIP_LIB=tools/_ab/lib_TLPP.so python tools/pp_timeline.py
+  bash tools/ab_build.sh TLPP:"-DSNN_PINGPONG -DSNN_EXP_TIMELINE -DSNN_CONV_PP_DEFAULT=1"   then on the GPU box   SNN_HIP_LIB=tools/_ab/lib_TLPP.so python tools/pp_timeline.py
 Work-group 0 stamps s_memtime (shader-clock cycles) five times per step and half on its first tile pair: Y start | Y end | barrier passed (X start) |
 matrix instructions issued | copies of the next step landed (then the barrier behind X).  Printed per half: mean cycles of each segment."""
 import os

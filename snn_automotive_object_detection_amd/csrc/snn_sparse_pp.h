@@ -1,4 +1,7 @@
 // Ping-pong form of the FAT conv + LIF (round 6; VERDICT r5 item 1b: "an explicit two-phase ping-pong of the two co-resident waves per SIMD").
+// MEASURED NEGATIVE: bit-identical to the FAT conv and 14 % SLOWER (profiles/r6_pingpong.txt, with the interval timeline this file's SNN_EXP_TIMELINE stamps
+// produce).  Compiled only into -DSNN_PINGPONG builds (tools/ab_build.sh); the product library does not contain it.  What the design assumed and what the
+// hardware did is in the last paragraph.
 // Included by snn_kernels.hip behind snn_sparse.h (its staging layout, loop body and register LIF are reused verbatim).
 //
 // What round 5 measured on k_gemm_lif_sparse<true, 1, FAT> (profiles/r5_sparse_whatif_final.txt, r5_fat_timelines.txt, r6_conv_stalls.txt): the
@@ -20,6 +23,12 @@
 // column blocks) at a time - with one work-group per CU a relaunch per tile would leave the pipe idle through every prologue.  The LIF runs in
 // registers (sp_lif_regs) at the end of a tile; both halves' epilogues fall together (one interval apart), the only stretch without matrix work.
 // Same instructions in the same order per accumulator as the FAT shape: bit-identical spike planes (tests/test_gpu_sparse.py).
+//
+// What happened (profiles/r6_pingpong.txt): an interval takes ~2930 cycles against the 1728 of its 108 matrix instructions.  X alone is 2230-2480 cycles - ONE wave issues
+// this stream at 20.7-23 cycles per matrix instruction (18.8 without any fragment read in X; the instruction type does not matter), because an in-order wave stalls at every
+// s_waitcnt on a fragment and 11 % of its steps carry the secondary plane's pass (+ ~1080 cycles) - and the barrier behind X adds ~510 cycles of skew: 8 waves in lock
+// step wait for the slowest.  Y (1460-1530 cycles: 14 LDS-DMA instructions at ~100 cycles of issue each) hides as designed.  Two INDEPENDENT waves per SIMD (the FAT conv)
+// reach 20.6 cycles per instruction per SIMD by filling each other's stalls by chance; a pipe fed by one wave at a time cannot.
 #pragma once
 
 #define PP_A_SLOTS 3

@@ -10,6 +10,9 @@ grep -E "passed|failed|FAILED|Error" gpurun_out/${TAG}_tests.log | tail -5
 # the exhaustive grids too, once per round on the final tree (VERDICT r5 P-3 / ADVICE r5: a claim about them needs a kept log): profiles/r6_sweep_pytest.txt
 timeout 2400 python -m pytest tests -q -m "gpu and sweep" --durations=10 > gpurun_out/${TAG}_sweep_tests.log 2>&1; echo "gpu sweep tests rc=$?"
 grep -E "passed|failed|FAILED|Error" gpurun_out/${TAG}_sweep_tests.log | tail -5
+# ... and EVERYTHING with its full grid (the unmarked tests' sampled loops at every T / shape too): profiles/r6_exhaustive_pytest.txt
+SNN_TEST_SWEEP=1 timeout 2700 python -m pytest tests -q -m gpu --durations=15 > gpurun_out/${TAG}_exhaustive_tests.log 2>&1; echo "gpu exhaustive tests rc=$?"
+grep -E "passed|failed|FAILED|Error" gpurun_out/${TAG}_exhaustive_tests.log | tail -5
 python tools/parity_watch.py > gpurun_out/${TAG}_parity_watch.txt 2>&1; tail -3 gpurun_out/${TAG}_parity_watch.txt
 bash tools/prof_round.sh ${TAG}_default > gpurun_out/prof_${TAG}_default.log 2>&1; grep -E "k_gemm_lif_sparse|k_gemm_bf16x3" gpurun_out/prof_${TAG}_default/summary.txt | head -8
 BENCH_ARGS="--workload stress" bash tools/prof_round.sh ${TAG}_stress > gpurun_out/prof_${TAG}_stress.log 2>&1; head -6 gpurun_out/prof_${TAG}_stress/summary.txt

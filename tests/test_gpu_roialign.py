@@ -169,7 +169,7 @@ def test_roi_heads_uses_fusion_and_matches_unfused_on_identical_pooled_values(gp
     assert torch.equal(a[0]["boxes"], b[0]["boxes"])
 
 
-@pytest.mark.parametrize("R,C,Hd,K,T", [(300, 64, 128, 5, 12), (1000, 256, 256, 9, 12), (130, 128, 64, 3, 14), (38, 64, 64, 3, 6), (6, 64, 64, 3, 8)])
+@pytest.mark.parametrize("R,C,Hd,K,T", [(300, 64, 128, 5, 12), (1000, 256, 256, 9, 12), (130, 128, 64, 3, 14), (38, 64, 64, 3, 6), (6, 64, 64, 3, 8), (60, 192, 64, 3, 8)])
 def test_roialign_encoder_fold_writes_the_same_planes(gpu_device, monkeypatch, R, C, Hd, K, T):
     """round 6 (row f1 on the DEFAULT product path): k_roi_align_encode_perm - RoIAlign + encoder + fc6's reduction order + compression in ONE
     launch - against k_roi_align_encode_tab -> k_permute_planes -> k_compress_planes (SNN_ENC_FOLD=0): the dense planes e_1, e_2 and the

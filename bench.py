@@ -897,9 +897,9 @@ def main():
                    "ms_per_step": round(dt2 / args.steps * 1e3, 4), "roofline": rf2, "held_clock": clk2,
                    "breakdown_ms": {k: round(v, 3) for k, v in bd2.items()},
                    "kernels_over_step": round((bd2["rpn_head"] + bd2["det_head"]) / (dt2 / args.steps * 1e3), 4)}
-            if not args.no_cpu_baseline:
+            if not args.no_cpu_baseline and world == 1:
                 # "report, per config ...": the oracle on THIS leg's tensors too - ONE timed pass (25-50 s of host time) behind the
-                # headline's warm-up and repeats
+                # headline's warm-up and repeats; at N = 1 only, like the headline's (at N > 1 the other ranks wait at the final barrier meanwhile)
                 res["cpu_baseline"] = cpu_baseline(l2, repeats=1, warm=False)
             return res
         for name in ("bdd", "stress"):

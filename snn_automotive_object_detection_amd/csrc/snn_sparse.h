@@ -555,7 +555,15 @@ __global__ __launch_bounds__(FAT ? 256 : 512, FAT ? 2 : 4) void k_gemm_lif_spars
         // weight fragments of group g = (N-tile g / 3, plane 2 - g % 3: small terms first): both 32-deep chunks of the step as ONE
         // 16-element operand (the structured-sparse instruction's B; its halves are the dense instruction's B of chunk c, c + 1),
         // buffered by g modulo the depth - the loads land in the halves of the buffer a later group reads, no register copies
-        constexpr int BD = (FAT && ND + NS > 12) ? 1 : BDEPTH;   // (the largest row-waves have no registers for a third buffer)
+#ifndef SP_FAT_BDEPTH_LIN
+#define SP_FAT_BDEPTH_LIN 5
+#endif
+#ifndef SP_FAT_BDEPTH_C41
+#define SP_FAT_BDEPTH_C41 BDEPTH
+#endif
+        // (round 6) the FAT linear layers (2 x 2 waves, six groups per step, 211 registers at two ahead) have the registers to request ALL of a step's weight fragments at its
+        // top - five groups ahead, six buffers: detector head 0.700 -> 0.685 ms at T_det = 12, 1.533 -> 1.519 at 24 (profiles/r6_fc6_bdepth_ab.txt), same bits
+        constexpr int BD = (FAT && ND + NS > 12) ? 1 : (FAT && !CONV) ? SP_FAT_BDEPTH_LIN : (FAT && CONV && WN == 1) ? SP_FAT_BDEPTH_C41 : BDEPTH;   // (the largest row-waves have no registers for a third buffer)
         constexpr bool TWO_PART = FAT && ND + NS > 14;
         // B HEAD START (-DSP_PRE_B=1, off: measured slower; FAT shapes whose step is one part): the first BD groups' fragments of step s + 1
         // requested right behind the barrier of step s - ahead of the copies' issue and the secondary-plane ballots of the step's top

@@ -61,6 +61,9 @@ typedef __bf16 bfv16 __attribute__((ext_vector_type(16)));
 #define SP_PRE_B 0                                  // (1: FAT shapes request a step's first weight fragments right behind the previous step's barrier -
                                                     // measured 0.9 % / 1.2 % SLOWER on the conv / fc6, profiles/r5_preb_ab.txt: off)
 #endif
+#ifndef SP_SEC_LATE
+#define SP_SEC_LATE 1
+#endif
 #define SP_PITCH 36                                 // epilogue tile image: 32 columns + 4 floats of padding per row
 
 struct SparseConvArgs {
@@ -602,7 +605,17 @@ __global__ __launch_bounds__(FAT ? 256 : 512, FAT ? 2 : 4) void k_gemm_lif_spars
             if constexpr (PRE_A) {
 #pragma unroll
                 for (int b4 = 0; b4 < 4; ++b4) sec[b4] = p_sec[b4];
-            } else {
+            }
+            // (round 6, FAT conv on 2 x 2 waves: the secondary occupancy words are REQUESTED here and looked at behind the step's products, where the answer is
+            // first needed - the ballot right behind the read made every step open with a full LDS round trip: conv + LIF 3.789 -> 3.753 ms at T = 16; the
+            // linear layers measured 0.4 % slower with it and keep the early look, profiles/r6_sec_late_ab.txt)
+            constexpr bool SEC_LATE = SP_SEC_LATE && FAT && CONV && WN == 2;
+            uint32_t o2_late[(NS + 3) / 4 > 0 ? (NS + 3) / 4 : 1];
+            if constexpr (!PRE_A && SEC_LATE) {
+#pragma unroll
+                for (int b4 = 0; b4 < (NS + 3) / 4; ++b4)
+                    o2_late[b4] = *reinterpret_cast<const uint32_t*>(a_rd + o_cur + 3 * (ROWS * 4) + min(ND + 4 * b4 + lg, MTS - 1) * 64);
+            } else if constexpr (!PRE_A) {
 #pragma unroll
                 for (int b4 = 0; b4 < (NS + 3) / 4; ++b4) {
                     const uint32_t o2 = *reinterpret_cast<const uint32_t*>(a_rd + o_cur + 3 * (ROWS * 4) + min(ND + 4 * b4 + lg, MTS - 1) * 64);
@@ -691,6 +704,13 @@ __global__ __launch_bounds__(FAT ? 256 : 512, FAT ? 2 : 4) void k_gemm_lif_spars
             } else {
                 do_part(std::integral_constant<int, 0>{}, std::integral_constant<int, NS>{}, std::true_type{});
             }
+#if !defined(SNN_EXP_SP_NO_AREAD)
+            if constexpr (!PRE_A && SEC_LATE) {
+#pragma unroll
+                for (int b4 = 0; b4 < (NS + 3) / 4; ++b4)
+                    sec[b4] = __ballot(o2_late[b4] != 0u) & (NS - 4 * b4 >= 4 ? ~0ull : ((1ull << (16 * (NS - 4 * b4))) - 1ull));
+            }
+#endif
 #ifdef SNN_EXP_SP_NO_SEC                              // (timing experiment - wrong results: what does the secondary plane's second pass cost?)
             if (false) {
 #else

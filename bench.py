@@ -649,6 +649,36 @@ def sweep_t_leg(leg, iters=8):
     return res
 
 
+def load_committed_traffic(path, source_digest, workload, precision):
+    """(HBM bytes per launch of the dominant kernel, where the figure comes from, the profiled side figures) from the committed PMC summary `path`
+    (tools/make_traffic_json.py) - ONLY if that file was collected on the source tree this build comes from: the file carries the `source_digest`
+    of its tree and a mismatch gives (None, the two digests, {}) - PMC passes of another tree say nothing about this build's launches"""
+    name = os.path.basename(path)
+    try:
+        with open(path) as f:
+            doc = json.load(f)
+        if doc.get("source_digest") != source_digest:
+            return None, ("profiles/%s was collected on source digest %s, this build is %s: traffic not quoted" % (
+                name, str(doc.get("source_digest"))[:12], str(source_digest)[:12])), {}
+        e = doc[workload][precision]
+        c = e["conv"]
+        src = ("profiles/" + name + " (same source digest as this build) <- %s: 2 x FETCH_SIZE (gfx950 tallies 128-B requests at 64 B; calibrated for this access pattern, tools/fetch_calib.hip) "
+               "+ WRITE_SIZE, separate rocprofv3 --pmc passes of this launch on this workload, committed - NOT collected by this run" % e["source"])
+        prof = {"profiled_launch_ms": round(c["avg_us"] / 1e3, 4), "profiled_hbm_gb_per_s": c.get("hbm_gb_per_s"), "profiled_hbm_frac_of_8tb_s": c.get("hbm_frac_of_8tb_s"),
+                "profiled_mfma_busy": c.get("mfma_busy"), "profiled_clock_ghz": c.get("clock_ghz_profiled"), "traffic_over_operands": c.get("traffic_over_operands")}
+        if "fc6" in e:
+            prof["fc6"] = {k: e["fc6"].get(k) for k in ("kernel", "avg_us", "hbm_bytes_per_launch", "hbm_gb_per_s", "mfma_busy", "clock_ghz_profiled", "traffic_over_operands")}
+        # the two encoders are the path's HBM-bound streaming launches (SURVEY 8(d): "report GB/s for them separately"): algorithmic bytes
+        # (fp32 features in, period planes out) / the profiled launch; their measured traffic is 1.00-1.06 x those bytes
+        enc = {k[4:]: {q: e[k].get(q) for q in ("kernel", "avg_us", "algorithmic_hbm_bytes", "hbm_bytes_per_launch", "hbm_gb_per_s", "hbm_frac_of_8tb_s", "hbm_frac_of_6p3tb_s_copy_rate", "traffic_over_operands")}
+               for k in ("enc_rpn", "enc_det") if k in e}
+        if enc:
+            prof["encoders"] = enc
+        return c["hbm_bytes_per_launch"], src, prof
+    except Exception:
+        return None, None, {}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -759,29 +789,7 @@ def main():
     def committed_traffic(workload):
         if args.t_rpn or dead_steps_kept():
             return None, None, {}
-        try:
-            with open(os.path.join(ROOT, "profiles", TRAFFIC_JSON)) as f:
-                doc = json.load(f)
-            if doc.get("source_digest") != source_digest:         # PMC passes of ANOTHER source tree say nothing about this build's launches
-                return None, ("profiles/%s was collected on source digest %s, this build is %s: traffic not quoted" % (
-                    TRAFFIC_JSON, str(doc.get("source_digest"))[:12], source_digest[:12])), {}
-            e = doc[workload][args.precision]
-            c = e["conv"]
-            src = ("profiles/" + TRAFFIC_JSON + " (same source digest as this build) <- %s: 2 x FETCH_SIZE (gfx950 tallies 128-B requests at 64 B; calibrated for this access pattern, tools/fetch_calib.hip) "
-                   "+ WRITE_SIZE, separate rocprofv3 --pmc passes of this launch on this workload, committed - NOT collected by this run" % e["source"])
-            prof = {"profiled_launch_ms": round(c["avg_us"] / 1e3, 4), "profiled_hbm_gb_per_s": c.get("hbm_gb_per_s"), "profiled_hbm_frac_of_8tb_s": c.get("hbm_frac_of_8tb_s"),
-                    "profiled_mfma_busy": c.get("mfma_busy"), "profiled_clock_ghz": c.get("clock_ghz_profiled"), "traffic_over_operands": c.get("traffic_over_operands")}
-            if "fc6" in e:
-                prof["fc6"] = {k: e["fc6"].get(k) for k in ("kernel", "avg_us", "hbm_bytes_per_launch", "hbm_gb_per_s", "mfma_busy", "clock_ghz_profiled", "traffic_over_operands")}
-            # the two encoders are the path's HBM-bound streaming launches ("report GB/s for them separately"): algorithmic bytes
-            # (fp32 features in, period planes out) / the profiled launch; their measured traffic is 1.00-1.06 x those bytes
-            enc = {k[4:]: {q: e[k].get(q) for q in ("kernel", "avg_us", "algorithmic_hbm_bytes", "hbm_bytes_per_launch", "hbm_gb_per_s", "hbm_frac_of_8tb_s", "hbm_frac_of_6p3tb_s_copy_rate", "traffic_over_operands")}
-                   for k in ("enc_rpn", "enc_det") if k in e}
-            if enc:
-                prof["encoders"] = enc
-            return c["hbm_bytes_per_launch"], src, prof
-        except Exception:
-            return None, None, {}
+        return load_committed_traffic(os.path.join(ROOT, "profiles", TRAFFIC_JSON), source_digest, workload, args.precision)
     traffic, traffic_source, traffic_prof = committed_traffic(args.workload)
 
     def roofline_of(l, bd_, step_ms, t_, t_src, t_prof):

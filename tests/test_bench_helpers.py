@@ -53,3 +53,20 @@ def test_randn_has_some_but_not_all_blocks_hit():
     planes, _ = _planes(torch.randn((1, 256, 16, 32), generator=torch.Generator().manual_seed(1)), 8)
     hit, blocks, ones, bits = bench.planes_hit_stats(planes)
     assert 0.02 < hit / blocks < 0.4 and 0.02 < ones / bits < 0.08
+
+
+def test_committed_traffic_is_quoted_only_for_the_tree_it_was_collected_on(tmp_path):
+    """profiles/r6_traffic.json carries the source digest of its tree; bench.py's roofline.traffic is null (with the two digests as the reason) for any other build"""
+    import json
+    import os
+    from snn_automotive_object_detection_amd import build
+    path = os.path.join(bench.ROOT, "profiles", "r6_traffic.json")
+    doc = json.load(open(path))
+    assert len(doc["source_digest"]) == 64 and {"cityscapes", "stress", "bdd"} <= set(doc)
+    t, src, prof = bench.load_committed_traffic(path, doc["source_digest"], "cityscapes", "bf16x3")
+    assert t == doc["cityscapes"]["bf16x3"]["conv"]["hbm_bytes_per_launch"] and "same source digest" in src and "fc6" in prof and "encoders" in prof
+    t, src, prof = bench.load_committed_traffic(path, "0" * 64, "cityscapes", "bf16x3")
+    assert t is None and prof == {} and "traffic not quoted" in src and doc["source_digest"][:12] in src
+    assert bench.load_committed_traffic(str(tmp_path / "missing.json"), doc["source_digest"], "cityscapes", "bf16x3") == (None, None, {})
+    # the committed file belongs to the committed tree (fails when a kernel source changes without a new evidence run: re-run tools/r6_final.sh + r6_collect.sh)
+    assert doc["source_digest"] == build.source_digest(), "profiles/r6_traffic.json is stale against csrc/ + include/"

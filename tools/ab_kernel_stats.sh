@@ -9,7 +9,13 @@ for round in 1 2 3; do
     d=$OUT/${n}_$round
     timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extra --no-clock-probe ${BENCH_ARGS:-} > $d.log 2>&1
     f=$(find $d -name "*kernel_stats.csv" | head -1)
-    [ -n "$f" ] && grep -E "$PAT" $f | awk -F, -v n=$n -v r=$round '{gsub(/"/,""); printf "%-8s round %s  %-60s calls %s  avg %.1f us\n", n, r, substr($1,1,60), $2, $4/1000}'
+    [ -n "$f" ] && python3 - "$f" "$PAT" $n $round <<'PY'
+import csv, re, sys
+f, pat, n, r = sys.argv[1:5]
+for row in csv.DictReader(open(f)):                      # (kernel names hold commas: a real CSV reader)
+    if re.search(pat, row["Name"]):
+        print("%-8s round %s  %-60s calls %3s  avg %8.1f us" % (n, r, row["Name"][:60], row["Calls"], float(row["AverageNs"]) / 1000))
+PY
     grep -o '"value": [0-9.]*' $d.log | head -1 | sed "s/^/$n round $round  bench /"
     find $d -name "*.csv" -size +1M -delete
   done
